@@ -1,0 +1,275 @@
+/*
+ * rovat.h — C ABI of librovat_hip.so, the MI355X-native batched rigid-body
+ * backend behind RoboVat's `env.step()` hot path.
+ *
+ * This header is the drop-in boundary.  Each entry point
+ * replaces the reference-side interface cited next to it (file:line relative
+ * to the StanfordVL/robovat tree).  Everything is `extern "C"`, plain pointers
+ * and sizes; no torch / HIP types appear in the signatures (a HIP stream is
+ * passed as `void*`).  Bulk buffers named `d_*` are DEVICE pointers, buffers
+ * named `h_*` are HOST pointers.  The caller owns every buffer it passes in;
+ * the library never frees caller memory.
+ *
+ * Conventions (must match robovat/math, third_party/transformations.py:1034-1359):
+ *   quaternions are xyzw, Euler angles are static-xyz ("sxyz"), poses are
+ *   world-frame, SI units, float32 everywhere on the device.
+ *
+ * Error convention (reference: Python exceptions, bullet_physics.py:162,184,
+ * 779,1286): every call returns an int status, 0 = RV_OK; rv_last_error()
+ * returns a thread-local message.  The Python shim maps codes to the same
+ * exception types the reference raises.
+ */
+#ifndef ROVAT_H_
+#define ROVAT_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- compile-time capacities (one env = one wave64; state lives in LDS) ---- */
+#define RV_MAXB        4   /* max movable bodies per env (MAX_MOVABLE_BODIES)      */
+#define RV_MAXH        4   /* convex hulls per shape (V-HACD parts)                */
+#define RV_MAXV       16   /* vertices per convex hull                             */
+#define RV_MAX_SHAPES 16   /* shape templates per scene                            */
+#define RV_NJ          9   /* arm joints: 7 limb (right_j0..j6) + 2 finger         */
+#define RV_NLIMB       7
+#define RV_NFRAME     10   /* link frames: 7 limb links, hand, l_finger, r_finger  */
+#define RV_NCOL       10   /* arm collider boxes                                   */
+#define RV_MAXTILES   24   /* tiles per list of a push layout (layouts.py:25-245)  */
+#define RV_MAXG        4   /* NUM_GOAL_STEPS upper bound (push_env.py:72)          */
+#define RV_MAXQ        8   /* link-target pose queue (controllable_body.py:133)    */
+#define RV_NBB   (RV_MAXB * (RV_MAXB - 1) / 2)
+#define RV_NMAN  (2 * RV_MAXB + RV_NBB) /* manifolds: body-table, body-body, arm-body */
+#define RV_BODY_STRIDE 13  /* pos3, quat4(xyzw), lin3, ang3                        */
+
+/* status codes -> Python exceptions in robovat_amd/lib.py */
+#define RV_OK            0
+#define RV_ERR_VALUE     1   /* ValueError   */
+#define RV_ERR_STATE     2   /* RuntimeError */
+#define RV_ERR_HIP       3   /* RuntimeError (HIP runtime failure) */
+#define RV_ERR_NOTIMPL   4   /* NotImplementedError */
+
+/* task ids (push_reward.py:282-299) */
+#define RV_TASK_NONE      0
+#define RV_TASK_CLEARING  1
+#define RV_TASK_INSERTION 2
+#define RV_TASK_CROSSING  3
+
+/* phases of PushEnv._execute_action (push_env.py:121-127) */
+#define RV_PHASE_INITIAL  0
+#define RV_PHASE_PRE      1
+#define RV_PHASE_START    2
+#define RV_PHASE_MOTION   3
+#define RV_PHASE_POST     4
+#define RV_PHASE_OFFSTAGE 5
+#define RV_PHASE_DONE     6
+
+/* One convex-decomposed shape template, expressed in its centre-of-mass /
+ * principal-axes frame at unit scale (replaces URDF+OBJ ingest,
+ * bullet_physics.py:143-186; hull format of tools/convert_obj_to_urdf.py). */
+typedef struct rv_shape {
+  int32_t n_hulls;
+  int32_t n_verts[RV_MAXH];
+  float   verts[RV_MAXH][RV_MAXV][3];
+  float   inertia_k[3]; /* principal inertia per unit mass at unit scale        */
+  float   radius;       /* bounding radius about the COM at unit scale          */
+} rv_shape;
+
+/* Kinematic description of the Sawyer-like arm (replaces the URDF tree that
+ * sawyer_sim.py:86-171 loads; numbers are BUILD-CHOSEN). */
+typedef struct rv_arm {
+  float base_pos[3];
+  float base_quat[4];
+  float jpos[RV_NLIMB + 1][3];   /* parent->child origin; entry 7 = fixed hand frame */
+  float jquat[RV_NLIMB + 1][4];
+  float q_lo[RV_NJ], q_hi[RV_NJ];
+  float v_max[RV_NJ];            /* URDF velocity limits (joint.py:57)          */
+  float a_max[RV_NJ];            /* effort-equivalent acceleration limits       */
+  float finger_y0[2];            /* finger frame y offset in the hand frame     */
+  int32_t col_frame[RV_NCOL];    /* which link frame each collider box rides on */
+  float col_center[RV_NCOL][3];
+  float col_half[RV_NCOL][3];
+} rv_arm;
+
+typedef struct rv_scene {
+  int32_t  n_shapes;
+  rv_shape shapes[RV_MAX_SHAPES];
+  rv_arm   arm;
+} rv_scene;
+
+/* Every config key the hot path reads, flattened.
+ * Values are BUILD-CHOSEN defaults in robovat_amd/configs.py because the
+ * reference's YAML files are not distributed with its source. */
+typedef struct rv_config {
+  /* world */
+  int32_t  n_envs;
+  int32_t  env_id_offset;        /* global id of env 0 on this rank            */
+  uint32_t seed_lo, seed_hi;
+  float    dt;                   /* simulator.py:26                            */
+  float    gravity_z;            /* simulator.py:27                            */
+  /* contact solver */
+  int32_t  solver_iters;
+  float    erp, slop, margin, breaking, warmstart, max_pushout;
+  float    lin_damp, ang_damp;   /* per-substep velocity multipliers           */
+  float    contact_query_dist;   /* check_contact threshold (simulator.py:246) */
+  /* table (arm_env.py:78-99; layouts.py:30) */
+  float    table_center[2];
+  float    table_half[2];
+  float    table_thickness;
+  float    table_z;
+  float    table_height_range[2];
+  float    table_friction;
+  float    arm_friction;
+  float    fall_depth;           /* bodies this far below the table are frozen */
+  /* movable bodies (push_env.py:399-597) */
+  int32_t  n_bodies_min, n_bodies_max;
+  float    scale_range[2], mass_range[2], friction_range[2];
+  float    margin_xy;
+  float    pose_lo[6], pose_hi[6];
+  float    drop_mass, drop_friction;
+  float    safe_drop_height;
+  int32_t  n_movable_shapes;
+  int32_t  movable_shapes[RV_MAX_SHAPES];
+  int32_t  n_target_shapes;
+  int32_t  target_shapes[RV_MAX_SHAPES];
+  /* layout (layouts.py:14-24) */
+  int32_t  task;
+  int32_t  layout_id;
+  int32_t  use_tiles;
+  float    tile_size;
+  float    tile_offset[2];
+  int32_t  n_region, n_goal, n_target, n_obstacle;
+  float    region[RV_MAXTILES][2];
+  float    goal[RV_MAXTILES][2];
+  float    target[RV_MAXTILES][2];
+  float    obstacle[RV_MAXTILES][2];
+  /* arm control (controllable_body.py:14-25; sawyer_sim.py:186-308) */
+  float    kp, kd;
+  float    velocity_threshold;
+  float    limb_max_velocity_ratio;
+  float    limb_timeout;
+  float    limb_position_threshold;
+  int32_t  ik_iters;
+  float    ik_damping, ik_residual, ik_max_step;
+  float    neutral_positions[RV_NLIMB];
+  float    offstage_positions[RV_NLIMB];
+  int32_t  open_gripper_when_reset;
+  /* push env (push_env.py:58-94, 631-937) */
+  float    cspace_low[3], cspace_high[3];
+  float    translation_x, translation_y;
+  float    finger_tip_offset;
+  float    gripper_safe_height;
+  float    min_delta_position, min_delta_angle;
+  float    workspace_x_range, workspace_y_range;
+  int32_t  steps_check, max_phase_steps, max_motion_steps, max_offstage_steps;
+  int32_t  num_goal_steps;       /* 0 = None                                   */
+  int32_t  max_steps;            /* 0 = None (robot_env.py:214)                */
+  float    success_thresh;
+  /* observation (camera_obs.py:127-238) */
+  int32_t  num_points;
+  float    camera_pos[3];
+} rv_config;
+
+/* Per-launch statistics of rv_step_macro / rv_reset (device-side reductions of
+ * the counters push_env.py:136-141,729-733 keeps). */
+typedef struct rv_macro_stats {
+  int64_t substeps;      /* sum over envs of Simulator.step() calls           */
+  int64_t env_steps;     /* envs that completed an env.step()                 */
+  int64_t unsafe, ineffective, useful, successes, episodes_done;
+  int64_t max_substeps;  /* slowest env of the launch                         */
+} rv_macro_stats;
+
+typedef struct rv_world rv_world;
+
+/* ---- lifecycle: Simulator.__init__/reset/start (simulator.py:23-92),
+ *      BulletPhysics.__init__/reset/start (bullet_physics.py:31-104) ---- */
+int  rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world** out);
+int  rv_destroy(rv_world* w);
+const char* rv_last_error(void);
+int  rv_set_stream(rv_world* w, void* hip_stream);
+int  rv_synchronize(rv_world* w);
+int  rv_num_envs(const rv_world* w);
+
+/* ---- RobotEnv.reset (robot_env.py:204-237) = PushEnv._reset_scene +
+ *      _load_movable_bodies + _sample_body_poses(_on_tiles) (push_env.py:331-597)
+ *      + ArmEnv._reset_robot (arm_env.py:101-107).  d_env_mask: uint8[N], NULL = all. */
+int  rv_reset(rv_world* w, const uint8_t* d_env_mask);
+
+/* ---- RobotEnv.step (robot_env.py:239-275) = PushEnv._execute_action
+ *      (push_env.py:631-733) + get_observation + get_reward, for all envs whose
+ *      episode is not done.  d_actions: float[N][G][4] in [-1,1]. ---- */
+int  rv_set_actions(rv_world* w, const float* d_actions);
+int  rv_step_macro(rv_world* w);
+
+/* ---- RandomPolicy._action (random_policy.py:14-23): U(-1,1)^(G*4) from
+ *      Philox keyed by (seed, global env id, macro_index). ---- */
+int  rv_policy_random(rv_world* w, int32_t macro_index, float* d_actions);
+/* ---- HeuristicPushPolicy._action / HeuristicPushSampler._sample
+ *      (push_policy.py:33-52, heuristic_push_sampler.py:66-123). ---- */
+int  rv_policy_heuristic(rv_world* w, int32_t max_attempts, float* d_actions);
+
+/* ---- Simulator.step x n (simulator.py:94-103): ControllableBody.update +
+ *      BulletPhysics.step (bullet_physics.py:106-109), no phase machine. ---- */
+int  rv_step_sub(rv_world* w, int32_t n_substeps);
+/* ---- Simulator.wait_until_stable (simulator.py:325-376) over all movables. */
+int  rv_wait_until_stable(rv_world* w, float lin_thresh, float ang_thresh,
+                          int32_t check_after, int32_t min_stable, int32_t max_steps);
+
+/* ---- state getters: Body.pose/linear_velocity/angular_velocity
+ *      (body.py:72-125, bullet_physics.py:197-249); Joint.position/velocity
+ *      (bullet_physics.py:635-663); Link.pose (bullet_physics.py:460-473). ---- */
+int  rv_get_body_state(rv_world* w, float* d_out /* [N][RV_MAXB][13] */);
+int  rv_set_body_state(rv_world* w, const float* d_in /* [N][RV_MAXB][13] */);
+int  rv_get_body_params(rv_world* w, float* d_out /* [N][RV_MAXB][8]: active,shape,scale,mass,friction,frozen,0,0 */);
+int  rv_set_body_params(rv_world* w, const float* d_in);
+int  rv_get_joint_state(rv_world* w, float* d_out /* [N][RV_NJ][2] */);
+int  rv_set_joint_state(rv_world* w, const float* d_in /* [N][RV_NJ][2] */);
+int  rv_get_link_poses(rv_world* w, float* d_out /* [N][RV_NFRAME][7] */);
+int  rv_get_env_counters(rv_world* w, int32_t* d_out /* [N][8]: sim_steps, num_steps, num_episodes, phase, done, is_safe, is_effective, substeps_last */);
+
+/* ---- ControllableBody.set_target_joint_positions / set_target_link_pose
+ *      (controllable_body.py:263-345) via RobotCommand (simulator.py:226-244). */
+int  rv_set_joint_targets(rv_world* w, const float* d_q /* [N][RV_NLIMB] */);
+int  rv_set_link_target(rv_world* w, const float* d_pose /* [N][7] pos+xyzw */);
+/* ---- BulletPhysics.compute_inverse_kinematics (bullet_physics.py:1203-1262). */
+int  rv_compute_ik(rv_world* w, const float* d_pose /* [N][7] */, float* d_q /* [N][RV_NLIMB] */);
+
+/* ---- Simulator.check_contact / BulletPhysics.get_contact_points
+ *      (simulator.py:246-287, bullet_physics.py:1268-1304).
+ *      d_out: uint8[N][2+RV_MAXB]: arm-table, arm-any-movable, arm-movable[b]. */
+int  rv_query_contacts(rv_world* w, uint8_t* d_out);
+/* Number of manifold points per manifold slot, for parity tests. */
+int  rv_get_manifold_counts(rv_world* w, int32_t* d_out /* [N][RV_NMAN] */);
+
+/* ---- observations (push_env.py:169-236): PoseObs('position') pose_obs.py:53-73,
+ *      attribute obs attribute_obs.py:16-115, SegmentedPointCloudObs
+ *      camera_obs.py:182-238 (analytic surface sampling).  NULL pointers are skipped. */
+typedef struct rv_obs_buffers {
+  float*   d_position;     /* [N][RV_MAXB][3]                                   */
+  float*   d_body_mask;    /* [N][RV_MAXB]                                      */
+  int64_t* d_num_episodes; /* [N]                                               */
+  int64_t* d_num_steps;    /* [N]                                               */
+  int64_t* d_layout_id;    /* [N]                                               */
+  int64_t* d_is_safe;      /* [N]                                               */
+  int64_t* d_is_effective; /* [N]                                               */
+  float*   d_point_cloud;  /* [N][RV_MAXB][num_points][3]                       */
+} rv_obs_buffers;
+int  rv_observe(rv_world* w, const rv_obs_buffers* obs);
+
+/* ---- PushReward.get_reward (push_reward.py:377-405, 272-374) of the last
+ *      macro step, and RobotEnv done flag (robot_env.py:257-259). ---- */
+int  rv_reward(rv_world* w, float* d_reward /* [N] */, uint8_t* d_done /* [N] */);
+int  rv_get_episode_returns(rv_world* w, float* d_returns /* [N] */);
+
+/* ---- stats of the last rv_step_macro / rv_reset launch (host struct). ---- */
+int  rv_get_stats(rv_world* w, rv_macro_stats* h_stats);
+/* HIP-event duration of the last rv_step_macro / rv_step_sub / rv_reset kernel
+ * on the world's stream, in milliseconds (used by bench.py's roofline). */
+int  rv_last_kernel_ms(rv_world* w, float* h_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROVAT_H_ */

@@ -1,0 +1,201 @@
+"""ctypes front-end of the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module; the product package
+``robovat_amd`` never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from robovat_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+def build(force=False):
+    """Compile liborc_f32.so / liborc_f64.so with the Makefile next to this file."""
+    targets = [os.path.join(_HERE, n) for n in ('liborc_f32.so', 'liborc_f64.so')]
+    srcs = [os.path.join(_HERE, n) for n in ('rv_oracle.c', 'orc_math.h', 'orc_collide.h')]
+    srcs.append(os.path.join(_HERE, '..', 'include', 'rovat.h'))
+    stale = force or any(
+        (not os.path.exists(t)) or any(os.path.getmtime(s) > os.path.getmtime(t) for s in srcs)
+        for t in targets)
+    if stale:
+        subprocess.run(['make', '-C', _HERE, '-s', '-B'], check=True)
+    return targets
+
+
+def _lib(double):
+    key = bool(double)
+    if key not in _LIBS:
+        build()
+        lib = C.CDLL(os.path.join(_HERE, 'liborc_f64.so' if double else 'liborc_f32.so'))
+        lib.orc_create.restype = C.c_void_p
+        lib.orc_create.argtypes = [C.POINTER(abi.rv_config), C.POINTER(abi.rv_scene)]
+        for name in ('orc_destroy', 'orc_reset', 'orc_set_actions', 'orc_step_macro', 'orc_step_sub',
+                     'orc_wait_until_stable', 'orc_policy_random', 'orc_policy_heuristic',
+                     'orc_get_body_state', 'orc_set_body_state', 'orc_get_body_params',
+                     'orc_set_body_params', 'orc_get_joint_state', 'orc_set_joint_state',
+                     'orc_get_link_poses', 'orc_get_env_counters', 'orc_set_joint_targets',
+                     'orc_set_link_target', 'orc_compute_ik', 'orc_query_contacts',
+                     'orc_get_manifold_counts', 'orc_observe', 'orc_reward',
+                     'orc_get_episode_returns', 'orc_get_stats', 'orc_eval_reward',
+                     'orc_eval_waypoints'):
+            getattr(lib, name).restype = None
+        lib.orc_eval_gjk.restype = C.c_int
+        _LIBS[key] = lib
+    return _LIBS[key]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleWorld(object):
+    """N independent envs stepped on the CPU (OpenMP over envs)."""
+
+    def __init__(self, cfg, scene, double=False):
+        self.lib = _lib(double)
+        self.double = double
+        self.cfg = cfg
+        self.scene = scene
+        self.n = cfg.n_envs
+        self.G = cfg.num_goal_steps if cfg.num_goal_steps > 0 else 1
+        self.h = C.c_void_p(self.lib.orc_create(C.byref(cfg), C.byref(scene)))
+
+    def __del__(self):
+        if getattr(self, 'h', None):
+            self.lib.orc_destroy(self.h)
+            self.h = None
+
+    def reset(self, mask=None):
+        if mask is None:
+            self.lib.orc_reset(self.h, None)
+        else:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            self.lib.orc_reset(self.h, _p(m))
+
+    def set_actions(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, self.G, 4)
+        self.lib.orc_set_actions(self.h, _p(a))
+
+    def step_macro(self):
+        self.lib.orc_step_macro(self.h)
+
+    def step_sub(self, n):
+        self.lib.orc_step_sub(self.h, C.c_int(n))
+
+    def wait_until_stable(self, lin=0.005, ang=0.005, check_after=100, min_stable=100, max_steps=2000):
+        self.lib.orc_wait_until_stable(self.h, C.c_float(lin), C.c_float(ang), C.c_int(check_after),
+                                       C.c_int(min_stable), C.c_int(max_steps))
+
+    def policy_random(self, macro_index):
+        a = np.zeros((self.n, self.G, 4), dtype=np.float32)
+        self.lib.orc_policy_random(self.h, C.c_int(macro_index), _p(a))
+        return a
+
+    def policy_heuristic(self, max_attempts=20000):
+        a = np.zeros((self.n, self.G, 4), dtype=np.float32)
+        self.lib.orc_policy_heuristic(self.h, C.c_int(max_attempts), _p(a))
+        return a
+
+    def _get(self, fn, shape, dtype=np.float64):
+        a = np.zeros(shape, dtype=dtype)
+        getattr(self.lib, fn)(self.h, _p(a))
+        return a
+
+    def body_state(self):
+        return self._get('orc_get_body_state', (self.n, abi.RV_MAXB, 13))
+
+    def set_body_state(self, s):
+        a = np.ascontiguousarray(s, dtype=np.float64).reshape(self.n, abi.RV_MAXB, 13)
+        self.lib.orc_set_body_state(self.h, _p(a))
+
+    def body_params(self):
+        return self._get('orc_get_body_params', (self.n, abi.RV_MAXB, 8))
+
+    def set_body_params(self, p):
+        a = np.ascontiguousarray(p, dtype=np.float64).reshape(self.n, abi.RV_MAXB, 8)
+        self.lib.orc_set_body_params(self.h, _p(a))
+
+    def joint_state(self):
+        return self._get('orc_get_joint_state', (self.n, abi.RV_NJ, 2))
+
+    def set_joint_state(self, s):
+        a = np.ascontiguousarray(s, dtype=np.float64).reshape(self.n, abi.RV_NJ, 2)
+        self.lib.orc_set_joint_state(self.h, _p(a))
+
+    def link_poses(self):
+        return self._get('orc_get_link_poses', (self.n, abi.RV_NFRAME, 7))
+
+    def env_counters(self):
+        return self._get('orc_get_env_counters', (self.n, 8), np.int32)
+
+    def set_joint_targets(self, q):
+        a = np.ascontiguousarray(q, dtype=np.float32).reshape(self.n, abi.RV_NLIMB)
+        self.lib.orc_set_joint_targets(self.h, _p(a))
+
+    def set_link_target(self, pose):
+        a = np.ascontiguousarray(pose, dtype=np.float32).reshape(self.n, 7)
+        self.lib.orc_set_link_target(self.h, _p(a))
+
+    def compute_ik(self, pose):
+        a = np.ascontiguousarray(pose, dtype=np.float32).reshape(self.n, 7)
+        q = np.zeros((self.n, abi.RV_NLIMB), dtype=np.float64)
+        self.lib.orc_compute_ik(self.h, _p(a), _p(q))
+        return q
+
+    def query_contacts(self):
+        return self._get('orc_query_contacts', (self.n, 2 + abi.RV_MAXB), np.uint8)
+
+    def manifold_counts(self):
+        return self._get('orc_get_manifold_counts', (self.n, abi.RV_NMAN), np.int32)
+
+    def observe(self):
+        pos = np.zeros((self.n, abi.RV_MAXB, 3)); mask = np.zeros((self.n, abi.RV_MAXB))
+        self.lib.orc_observe(self.h, _p(pos), _p(mask))
+        return pos, mask
+
+    def reward(self):
+        r = np.zeros(self.n); d = np.zeros(self.n, dtype=np.uint8)
+        self.lib.orc_reward(self.h, _p(r), _p(d))
+        return r, d
+
+    def episode_returns(self):
+        return self._get('orc_get_episode_returns', (self.n,))
+
+    def stats(self):
+        s = abi.rv_macro_stats()
+        self.lib.orc_get_stats(self.h, C.byref(s))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+
+def eval_reward(cfg, state, next_state, double=False):
+    lib = _lib(double)
+    s = np.ascontiguousarray(state, dtype=np.float64).reshape(abi.RV_MAXB, 2)
+    n = np.ascontiguousarray(next_state, dtype=np.float64).reshape(abi.RV_MAXB, 2)
+    r = C.c_double(); t = C.c_int32()
+    lib.orc_eval_reward(C.byref(cfg), _p(s), _p(n), C.byref(r), C.byref(t))
+    return r.value, bool(t.value)
+
+
+def eval_waypoints(cfg, action, double=False):
+    lib = _lib(double)
+    a = np.ascontiguousarray(action, dtype=np.float32).reshape(4)
+    s = np.zeros(7); e = np.zeros(7)
+    lib.orc_eval_waypoints(C.byref(cfg), _p(a), _p(s), _p(e))
+    return s, e
+
+
+def eval_gjk(A, B, max_dist=1e9, double=False):
+    lib = _lib(double)
+    A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64)
+    out = np.zeros(10)
+    hit = lib.orc_eval_gjk(_p(A), C.c_int(len(A)), _p(B), C.c_int(len(B)), C.c_double(max_dist), _p(out))
+    if not hit:
+        return None
+    return dict(n=out[0:3].copy(), dist=out[3], pa=out[4:7].copy(), pb=out[7:10].copy())

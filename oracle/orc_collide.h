@@ -1,0 +1,348 @@
+/*
+ * orc_collide.h — GJK / EPA narrow phase and persistent 4-point manifolds of
+ * the CPU oracle (TEST INFRASTRUCTURE ONLY; see orc_math.h).
+ *
+ * What it restates: the arithmetic behind `pybullet.stepSimulation`
+ * (robovat/simulation/physics/bullet_physics.py:106-109) for convex-hull
+ * pairs.  PyBullet 2.6.5 itself is a third-party wheel that is not vendored
+ * in the reference tree (requirements.txt:9) — PARITY UNPINNED for this part:
+ * the algorithm below is the published GJK (Gilbert-Johnson-Keerthi 1988,
+ * Ericson "Real-Time Collision Detection" §5.1/§9.5 closest-point
+ * sub-algorithms), EPA (van den Bergen 2001) and Bullet-style persistent
+ * contact manifolds (contact cache keyed on local points, area-maximising
+ * 4-point reduction), as DESIGN.md §3 specifies them.
+ */
+#ifndef ORC_COLLIDE_H_
+#define ORC_COLLIDE_H_
+
+#include "orc_math.h"
+
+#define GJK_MAX_ITERS 32
+#define GJK_REL_TOL R(1e-4)
+#define EPA_MAX_VERTS 24
+#define EPA_MAX_FACES 48
+#define EPA_MAX_EDGES 32
+#define EPA_MAX_ITERS 32
+#define EPA_TOL R(1e-6)
+
+typedef struct {
+  real w[4][3], a[4][3], b[4][3];
+  real lam[4];
+  int n;
+} orc_simplex;
+
+static inline int orc_support(const real (*verts)[3], int n, const real* d) {
+  int best = 0;
+  real bd = v3dot(verts[0], d);
+  for (int i = 1; i < n; ++i) {
+    real x = v3dot(verts[i], d);
+    if (x > bd) { bd = x; best = i; }
+  }
+  return best;
+}
+
+/* closest point to the origin on segment (p0,p1): barycentrics l0,l1 */
+static inline void orc_closest_segment(const real* p0, const real* p1, real* l) {
+  real d[3]; v3sub(d, p1, p0);
+  real dd = v3dot(d, d);
+  if (!(dd > R(0.0))) { l[0] = R(0.0); l[1] = R(1.0); return; }
+  real t = -v3dot(p0, d) / dd;
+  if (t <= R(0.0)) { l[0] = R(1.0); l[1] = R(0.0); }
+  else if (t >= R(1.0)) { l[0] = R(0.0); l[1] = R(1.0); }
+  else { l[0] = R(1.0) - t; l[1] = t; }
+}
+
+/* closest point to the origin on triangle (a,b,c) — Ericson §5.1.5 with p = 0 */
+static inline void orc_closest_triangle(const real* a, const real* b, const real* c, real* l) {
+  real ab[3], ac[3];
+  v3sub(ab, b, a); v3sub(ac, c, a);
+  real d1 = -v3dot(ab, a), d2 = -v3dot(ac, a);
+  if (d1 <= R(0.0) && d2 <= R(0.0)) { l[0] = R(1.0); l[1] = R(0.0); l[2] = R(0.0); return; }
+  real d3 = -v3dot(ab, b), d4 = -v3dot(ac, b);
+  if (d3 >= R(0.0) && d4 <= d3) { l[0] = R(0.0); l[1] = R(1.0); l[2] = R(0.0); return; }
+  real vc = d1 * d4 - d3 * d2;
+  if (vc <= R(0.0) && d1 >= R(0.0) && d3 <= R(0.0)) {
+    real v = d1 / (d1 - d3);
+    l[0] = R(1.0) - v; l[1] = v; l[2] = R(0.0); return;
+  }
+  real d5 = -v3dot(ab, c), d6 = -v3dot(ac, c);
+  if (d6 >= R(0.0) && d5 <= d6) { l[0] = R(0.0); l[1] = R(0.0); l[2] = R(1.0); return; }
+  real vb = d5 * d2 - d1 * d6;
+  if (vb <= R(0.0) && d2 >= R(0.0) && d6 <= R(0.0)) {
+    real w = d2 / (d2 - d6);
+    l[0] = R(1.0) - w; l[1] = R(0.0); l[2] = w; return;
+  }
+  real va = d3 * d6 - d5 * d4;
+  if (va <= R(0.0) && (d4 - d3) >= R(0.0) && (d5 - d6) >= R(0.0)) {
+    real w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    l[0] = R(0.0); l[1] = R(1.0) - w; l[2] = w; return;
+  }
+  real s = va + vb + vc;
+  if (!(s > R(0.0))) {
+    /* degenerate (collinear) triangle: best of the three edges */
+    real le[2], p[3], best = R(-1.0);
+    const real* vs[3] = {a, b, c};
+    l[0] = R(0.0); l[1] = R(0.0); l[2] = R(1.0);
+    for (int e = 0; e < 3; ++e) {
+      int i = e, j = (e + 1) % 3;
+      orc_closest_segment(vs[i], vs[j], le);
+      p[0] = vs[i][0] * le[0] + vs[j][0] * le[1];
+      p[1] = vs[i][1] * le[0] + vs[j][1] * le[1];
+      p[2] = vs[i][2] * le[0] + vs[j][2] * le[1];
+      real dd = v3dot(p, p);
+      if (best < R(0.0) || dd < best) {
+        best = dd; l[0] = l[1] = l[2] = R(0.0); l[i] = le[0]; l[j] = le[1];
+      }
+    }
+    return;
+  }
+  real denom = R(1.0) / s;
+  real v = vb * denom, w = vc * denom;
+  l[0] = R(1.0) - v - w; l[1] = v; l[2] = w;
+}
+
+/* Reduce the simplex to the feature closest to the origin; writes v (closest
+ * point) and lam.  Returns 1 when the origin is enclosed by a tetrahedron. */
+static inline int orc_simplex_solve(orc_simplex* s, real* v) {
+  real l[4] = {R(0.0), R(0.0), R(0.0), R(0.0)};
+  if (s->n == 1) {
+    l[0] = R(1.0);
+  } else if (s->n == 2) {
+    orc_closest_segment(s->w[0], s->w[1], l);
+  } else if (s->n == 3) {
+    orc_closest_triangle(s->w[0], s->w[1], s->w[2], l);
+  } else {
+    static const int F[4][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 3, 1}, {1, 2, 3, 0}};
+    int any_outside = 0;
+    real best = R(-1.0);
+    for (int f = 0; f < 4; ++f) {
+      const real* p = s->w[F[f][0]]; const real* q = s->w[F[f][1]];
+      const real* r = s->w[F[f][2]]; const real* o = s->w[F[f][3]];
+      real pq[3], pr[3], nrm[3], po[3];
+      v3sub(pq, q, p); v3sub(pr, r, p); v3cross(nrm, pq, pr); v3sub(po, o, p);
+      real sp = v3dot(nrm, po);
+      real so = -v3dot(nrm, p);
+      if (sp * so > R(0.0)) continue; /* origin strictly on the inner side */
+      any_outside = 1;
+      real lf[3], c[3];
+      orc_closest_triangle(p, q, r, lf);
+      for (int k = 0; k < 3; ++k) c[k] = p[k] * lf[0] + q[k] * lf[1] + r[k] * lf[2];
+      real dd = v3dot(c, c);
+      if (best < R(0.0) || dd < best) {
+        best = dd;
+        l[0] = l[1] = l[2] = l[3] = R(0.0);
+        l[F[f][0]] = lf[0]; l[F[f][1]] = lf[1]; l[F[f][2]] = lf[2];
+      }
+    }
+    if (!any_outside) return 1;
+  }
+  /* compact: keep vertices with positive weight, preserve order */
+  int m = 0;
+  for (int i = 0; i < s->n; ++i) {
+    if (l[i] > R(0.0)) {
+      if (m != i) { v3cpy(s->w[m], s->w[i]); v3cpy(s->a[m], s->a[i]); v3cpy(s->b[m], s->b[i]); }
+      s->lam[m] = l[i];
+      ++m;
+    }
+  }
+  s->n = m;
+  v[0] = v[1] = v[2] = R(0.0);
+  for (int i = 0; i < m; ++i) v3madd(v, v, s->w[i], s->lam[i]);
+  return 0;
+}
+
+/* EPA on a tetrahedron that encloses the origin.  Outputs the penetration
+ * depth (>= 0), the face normal nf (pointing away from the origin) and the
+ * witness points on A and B. */
+static inline void orc_epa(const real (*A)[3], int nA, const real (*B)[3], int nB,
+                           const orc_simplex* s, real* out_nf, real* out_depth, real* pa, real* pb) {
+  real W[EPA_MAX_VERTS][3], VA[EPA_MAX_VERTS][3], VB[EPA_MAX_VERTS][3];
+  int fi[EPA_MAX_FACES][3]; real fn[EPA_MAX_FACES][3]; real fd[EPA_MAX_FACES]; int alive[EPA_MAX_FACES];
+  int nv = 4, nf = 0;
+  for (int i = 0; i < 4; ++i) { v3cpy(W[i], s->w[i]); v3cpy(VA[i], s->a[i]); v3cpy(VB[i], s->b[i]); }
+  static const int F[4][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 3, 1}, {1, 2, 3, 0}};
+  for (int f = 0; f < 4; ++f) {
+    int i = F[f][0], j = F[f][1], k = F[f][2], o = F[f][3];
+    real e1[3], e2[3], n[3], eo[3];
+    v3sub(e1, W[j], W[i]); v3sub(e2, W[k], W[i]); v3cross(n, e1, e2); v3sub(eo, W[o], W[i]);
+    if (v3dot(n, eo) > R(0.0)) { int t = j; j = k; k = t; v3scale(n, n, R(-1.0)); }
+    real len = v3len(n);
+    if (!(len > R(0.0))) { len = R(1.0); }
+    v3scale(n, n, R(1.0) / len);
+    fi[nf][0] = i; fi[nf][1] = j; fi[nf][2] = k; v3cpy(fn[nf], n); fd[nf] = v3dot(n, W[i]); alive[nf] = 1; ++nf;
+  }
+  int bestf = 0;
+  for (int it = 0; it < EPA_MAX_ITERS; ++it) {
+    bestf = -1;
+    for (int f = 0; f < nf; ++f) if (alive[f] && (bestf < 0 || fd[f] < fd[bestf])) bestf = f;
+    real nd[3]; v3scale(nd, fn[bestf], R(-1.0));
+    int ia = orc_support(A, nA, fn[bestf]);
+    int ib = orc_support(B, nB, nd);
+    real w[3]; v3sub(w, A[ia], B[ib]);
+    if (v3dot(fn[bestf], w) - fd[bestf] < EPA_TOL || nv >= EPA_MAX_VERTS) break;
+    /* expand */
+    int en = 0; int ea[EPA_MAX_EDGES], eb[EPA_MAX_EDGES];
+    for (int f = 0; f < nf; ++f) {
+      if (!alive[f]) continue;
+      real d[3]; v3sub(d, w, W[fi[f][0]]);
+      if (v3dot(fn[f], d) > R(0.0)) {
+        alive[f] = 0;
+        for (int e = 0; e < 3; ++e) {
+          int p = fi[f][e], q = fi[f][(e + 1) % 3];
+          int found = -1;
+          for (int x = 0; x < en; ++x) if (ea[x] == q && eb[x] == p) { found = x; break; }
+          if (found >= 0) { ea[found] = ea[en - 1]; eb[found] = eb[en - 1]; --en; }
+          else if (en < EPA_MAX_EDGES) { ea[en] = p; eb[en] = q; ++en; }
+        }
+      }
+    }
+    if (en == 0) break;
+    v3cpy(W[nv], w); v3cpy(VA[nv], A[ia]); v3cpy(VB[nv], B[ib]);
+    int overflow = 0;
+    for (int x = 0; x < en; ++x) {
+      int slot = -1;
+      for (int f = 0; f < nf; ++f) if (!alive[f]) { slot = f; break; }
+      if (slot < 0) { if (nf < EPA_MAX_FACES) slot = nf++; else { overflow = 1; break; } }
+      int i = ea[x], j = eb[x], k = nv;
+      real e1[3], e2[3], n[3];
+      v3sub(e1, W[j], W[i]); v3sub(e2, W[k], W[i]); v3cross(n, e1, e2);
+      real len = v3len(n);
+      if (!(len > R(0.0))) { len = R(1.0); }
+      v3scale(n, n, R(1.0) / len);
+      real d = v3dot(n, W[i]);
+      if (d < R(0.0)) { int t = i; i = j; j = t; v3scale(n, n, R(-1.0)); d = -d; }
+      fi[slot][0] = i; fi[slot][1] = j; fi[slot][2] = k; v3cpy(fn[slot], n); fd[slot] = d; alive[slot] = 1;
+    }
+    ++nv;
+    if (overflow) break;
+  }
+  bestf = -1;
+  for (int f = 0; f < nf; ++f) if (alive[f] && (bestf < 0 || fd[f] < fd[bestf])) bestf = f;
+  /* project the origin on the best face */
+  real c[3], p0[3], p1[3], p2[3], l[3];
+  v3scale(c, fn[bestf], fd[bestf]);
+  v3sub(p0, W[fi[bestf][0]], c); v3sub(p1, W[fi[bestf][1]], c); v3sub(p2, W[fi[bestf][2]], c);
+  orc_closest_triangle(p0, p1, p2, l);
+  for (int k = 0; k < 3; ++k) {
+    pa[k] = VA[fi[bestf][0]][k] * l[0] + VA[fi[bestf][1]][k] * l[1] + VA[fi[bestf][2]][k] * l[2];
+    pb[k] = VB[fi[bestf][0]][k] * l[0] + VB[fi[bestf][1]][k] * l[1] + VB[fi[bestf][2]][k] * l[2];
+  }
+  v3cpy(out_nf, fn[bestf]);
+  *out_depth = fd[bestf];
+}
+
+/* GJK distance between convex vertex sets A and B (world frame), with EPA on
+ * overlap.  Returns 0 if the sets are farther apart than max_dist, else 1 and
+ * n (unit, from B towards A), signed core distance (negative = overlap) and
+ * witness points on the two cores.  guess = initial search direction. */
+static inline int orc_gjk_epa(const real (*A)[3], int nA, const real (*B)[3], int nB,
+                              const real* guess, real max_dist,
+                              real* n, real* dist, real* pa, real* pb) {
+  orc_simplex s; s.n = 0;
+  real v[3]; v3cpy(v, guess);
+  if (!(v3dot(v, v) > R(1e-12))) v3set(v, R(1.0), R(0.0), R(0.0));
+  int have_v = 0, penetrating = 0;
+  for (int it = 0; it < GJK_MAX_ITERS; ++it) {
+    real nv[3]; v3scale(nv, v, R(-1.0));
+    int ia = orc_support(A, nA, nv);
+    int ib = orc_support(B, nB, v);
+    real w[3]; v3sub(w, A[ia], B[ib]);
+    real vv = v3dot(v, v), vw = v3dot(v, w);
+    if (vw > R(0.0) && vw * vw > max_dist * max_dist * vv) return 0;
+    int dup = 0;
+    for (int k = 0; k < s.n; ++k)
+      if (s.w[k][0] == w[0] && s.w[k][1] == w[1] && s.w[k][2] == w[2]) dup = 1;
+    if (dup) break;
+    if (have_v && vv - vw <= GJK_REL_TOL * vv) break;
+    v3cpy(s.w[s.n], w); v3cpy(s.a[s.n], A[ia]); v3cpy(s.b[s.n], B[ib]); s.n++;
+    if (orc_simplex_solve(&s, v)) { penetrating = 1; break; }
+    have_v = 1;
+    if (!(v3dot(v, v) > R(1e-14))) { penetrating = 2; break; }
+  }
+  if (penetrating == 1) {
+    real nf[3], depth;
+    orc_epa(A, nA, B, nB, &s, nf, &depth, pa, pb);
+    v3scale(n, nf, R(-1.0));
+    *dist = -depth;
+    return 1;
+  }
+  pa[0] = pa[1] = pa[2] = R(0.0); pb[0] = pb[1] = pb[2] = R(0.0);
+  for (int i = 0; i < s.n; ++i) { v3madd(pa, pa, s.a[i], s.lam[i]); v3madd(pb, pb, s.b[i], s.lam[i]); }
+  if (penetrating == 2) {
+    /* cores touch on a lower-dimensional simplex: zero depth along the guess */
+    real g[3]; v3cpy(g, guess);
+    real gl = v3len(g);
+    if (!(gl > R(1e-6))) { v3set(g, R(0.0), R(0.0), R(1.0)); gl = R(1.0); }
+    v3scale(n, g, R(1.0) / gl);
+    *dist = R(0.0);
+    return 1;
+  }
+  real d = v3len(v);
+  if (d > max_dist) return 0;
+  v3scale(n, v, R(1.0) / d);
+  *dist = d;
+  return 1;
+}
+
+/* ---------------- persistent manifold ---------------- */
+typedef struct {
+  int n;
+  real la[4][3];   /* contact point on A, in A's body frame            */
+  real lb[4][3];   /* contact point on B, in B's frame (world if static) */
+  real nrm[4][3];  /* world normal, from B towards A                    */
+  real dist[4];
+  real ln[4], lt1[4], lt2[4]; /* accumulated impulses (warm start)      */
+  int  col[4];     /* arm collider id for arm-body manifolds, else -1   */
+} orc_manifold;
+
+static inline void orc_man_remove(orc_manifold* m, int i) {
+  int last = m->n - 1;
+  if (i != last) {
+    v3cpy(m->la[i], m->la[last]); v3cpy(m->lb[i], m->lb[last]); v3cpy(m->nrm[i], m->nrm[last]);
+    m->dist[i] = m->dist[last]; m->ln[i] = m->ln[last]; m->lt1[i] = m->lt1[last]; m->lt2[i] = m->lt2[last];
+    m->col[i] = m->col[last];
+  }
+  m->n = last;
+}
+
+static inline real orc_area4(const real* p0, const real* p1, const real* p2, const real* p3) {
+  real a0[3], b0[3], c0[3], c1[3], c2[3];
+  v3sub(a0, p0, p1); v3sub(b0, p2, p3); v3cross(c0, a0, b0);
+  v3sub(a0, p0, p2); v3sub(b0, p1, p3); v3cross(c1, a0, b0);
+  v3sub(a0, p0, p3); v3sub(b0, p1, p2); v3cross(c2, a0, b0);
+  return rmax(rmax(v3dot(c0, c0), v3dot(c1, c1)), v3dot(c2, c2));
+}
+
+/* add (or merge) a contact; la/lb local points, nrm world normal */
+static inline void orc_man_add(orc_manifold* m, const real* la, const real* lb, const real* nrm,
+                               real dist, int col, real breaking) {
+  int slot = -1;
+  real best = breaking * breaking;
+  for (int i = 0; i < m->n; ++i) {
+    real d[3]; v3sub(d, m->la[i], la);
+    real dd = v3dot(d, d);
+    if (dd < best && m->col[i] == col) { best = dd; slot = i; }
+  }
+  int keep_impulse = 0;
+  if (slot >= 0) {
+    keep_impulse = 1;
+  } else if (m->n < 4) {
+    slot = m->n++;
+  } else {
+    /* keep the deepest point, maximise the contact area (Bullet-style) */
+    int deepest = -1; real dmin = dist;
+    for (int i = 0; i < 4; ++i) if (m->dist[i] < dmin) { dmin = m->dist[i]; deepest = i; }
+    real r[4];
+    r[0] = (deepest == 0) ? R(-1.0) : orc_area4(la, m->la[1], m->la[2], m->la[3]);
+    r[1] = (deepest == 1) ? R(-1.0) : orc_area4(la, m->la[0], m->la[2], m->la[3]);
+    r[2] = (deepest == 2) ? R(-1.0) : orc_area4(la, m->la[0], m->la[1], m->la[3]);
+    r[3] = (deepest == 3) ? R(-1.0) : orc_area4(la, m->la[0], m->la[1], m->la[2]);
+    slot = 0;
+    for (int i = 1; i < 4; ++i) if (r[i] > r[slot]) slot = i;
+  }
+  v3cpy(m->la[slot], la); v3cpy(m->lb[slot], lb); v3cpy(m->nrm[slot], nrm);
+  m->dist[slot] = dist; m->col[slot] = col;
+  if (!keep_impulse) { m->ln[slot] = R(0.0); m->lt1[slot] = R(0.0); m->lt2[slot] = R(0.0); }
+}
+
+#endif /* ORC_COLLIDE_H_ */

@@ -1,0 +1,1475 @@
+/*
+ * rv_oracle.c — CPU restatement of RoboVat's `env.step()` hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's `cpu_baseline` leg may build, load or call this file.  The
+ * product (librovat_hip.so) never links it and fails loudly without a GPU.
+ *
+ * PARITY STATUS
+ *   - control / task logic (ControllableBody, SawyerSim, PushEnv phase machine,
+ *     wait_until_stable, rewards): restated from the reference Python, pinned
+ *     by golden vectors generated from the reference itself
+ *     (tests/golden/gen_golden.py).
+ *   - physics arithmetic (`pybullet.stepSimulation`, IK): PARITY UNPINNED.
+ *     It lives in the third-party wheel pybullet==2.6.5 (requirements.txt:9),
+ *     which is neither vendored under the reference tree nor installed here.
+ *     The restated algorithm (GJK/EPA + persistent manifolds + PGS sequential
+ *     impulses + kinematic articulated pusher + DLS IK) is specified in
+ *     DESIGN.md §3 and anchored on the reference's call sites only.
+ *
+ * Build: see oracle/Makefile (float build = bit-for-bit target of the HIP
+ * kernels; -DORC_DOUBLE build = pose-error oracle of record).
+ */
+#include <stdlib.h>
+#include <stdio.h>
+#include "../include/rovat.h"
+#include "orc_math.h"
+#include "orc_collide.h"
+
+#define STREAM_RESET  1u
+#define STREAM_RANDOM 2u
+#define STREAM_HEUR   3u
+
+/* controllable_body.py:14-25 */
+#define STEPS_TO_CHECK_DONE 100
+#define STEPS_TO_UPDATE_IK  10
+
+typedef struct { real p[3], q[4], v[3], w[3]; } orc_body;
+typedef struct {
+  int active, frozen, shape;
+  real scale, mass, inv_mass, inv_inertia[3], friction, radius;
+} orc_bparam;
+
+/* JointTarget (controllable_body.py:28-129) */
+typedef struct {
+  int active, n_idx, idx[RV_NJ], has_vel, has_stop;
+  real pos[RV_NJ];
+  real start_t, stop_t, pos_thr, vel_thr;
+} orc_jtarget;
+/* LinkTarget (controllable_body.py:132-233) */
+typedef struct {
+  int active, has_pose, nq, has_stop;
+  real pose[7];
+  real queue[RV_MAXQ][7];
+  real start_t, stop_t, pos_thr, vel_thr;
+} orc_ltarget;
+
+typedef struct {
+  /* rigid bodies */
+  orc_body body[RV_MAXB];
+  orc_bparam bp[RV_MAXB];
+  real table_z;
+  int n_bodies;
+  /* arm */
+  int arm_enabled;
+  real q[RV_NJ], qd[RV_NJ];
+  int motor_on[RV_NJ];
+  real motor_q[RV_NJ], motor_kp[RV_NJ], motor_kd[RV_NJ];
+  real vmax_cmd[RV_NJ];          /* ControllableBody._max_joint_velocities */
+  orc_jtarget jt; orc_ltarget lt;
+  real gripper_ready_time;
+  real fpos[RV_NFRAME][3], fquat[RV_NFRAME][4], frot[RV_NFRAME][9];
+  real fv[RV_NFRAME][3], fw[RV_NFRAME][3];
+  real axis[RV_NLIMB][3];
+  real colv[RV_NCOL][8][3], colc[RV_NCOL][3], colr[RV_NCOL];
+  /* per-substep caches */
+  real rot[RV_MAXB][9], iinv[RV_MAXB][9];
+  real wv[RV_MAXB][RV_MAXH][RV_MAXV][3];
+  real tablev[8][3];
+  /* contacts */
+  orc_manifold man[RV_NMAN];
+  int flag_arm_table, flag_arm_body[RV_MAXB];
+  /* counters */
+  int sim_steps;                 /* Simulator.num_steps            */
+  int num_steps, num_episodes;   /* RobotEnv counters              */
+  int done, phase, is_safe, is_effective;
+  int reset_count;
+  int substeps_last;
+  real episode_reward, last_reward;
+  real action[RV_MAXG][4];
+  real obs_pos[RV_MAXB][3], prev_obs_pos[RV_MAXB][3];
+  int has_prev;
+  /* stats */
+  long num_total_steps, num_unsafe, num_ineffective, num_useful, num_successes;
+} orc_env;
+
+typedef struct orc_world {
+  rv_config cfg;
+  rv_scene scene;
+  int n;
+  orc_env* env;
+  rv_macro_stats stats;
+} orc_world;
+
+#define TIDX(b) (b)
+#define BBIDX(k) (RV_MAXB + (k))
+#define AIDX(b) (RV_MAXB + RV_NBB + (b))
+
+static const int BB_A[RV_NBB] = {0, 0, 0, 1, 1, 2};
+static const int BB_B[RV_NBB] = {1, 2, 3, 2, 3, 3};
+/* round-robin colouring: pairs of one round touch disjoint bodies */
+static const int BB_ROUND[3][2] = {{0, 5}, {1, 4}, {2, 3}};
+
+static real sim_time(const orc_world* w, const orc_env* e) { return (real)w->cfg.dt * (real)e->sim_steps; }
+
+/* ------------------------------------------------------------------ arm -- */
+static void frame_compose(real* po, real* qo, const real* pp, const real* pq, const real* prot,
+                          const real* lp, const real* lq) {
+  real t[3]; m3mulv(t, prot, lp); v3add(po, pp, t);
+  qmul(qo, pq, lq);
+}
+
+/* forward kinematics of the limb for joint vector q; fills frames 0..7 */
+static void arm_fk_limb(const rv_arm* a, const real* q, real fpos[][3], real fquat[][4], real frot[][9], real axis[][3]) {
+  real pp[3] = {(real)a->base_pos[0], (real)a->base_pos[1], (real)a->base_pos[2]};
+  real pq[4] = {(real)a->base_quat[0], (real)a->base_quat[1], (real)a->base_quat[2], (real)a->base_quat[3]};
+  real prot[9]; qmat(prot, pq);
+  for (int i = 0; i < RV_NLIMB; ++i) {
+    real lp[3] = {(real)a->jpos[i][0], (real)a->jpos[i][1], (real)a->jpos[i][2]};
+    real lq[4] = {(real)a->jquat[i][0], (real)a->jquat[i][1], (real)a->jquat[i][2], (real)a->jquat[i][3]};
+    real po[3], qo[4];
+    frame_compose(po, qo, pp, pq, prot, lp, lq);
+    real s, c; rsincos(q[i] * R(0.5), &s, &c);
+    real qz[4] = {R(0.0), R(0.0), s, c};
+    real qf[4]; qmul(qf, qo, qz);
+    v3cpy(fpos[i], po); fquat[i][0] = qf[0]; fquat[i][1] = qf[1]; fquat[i][2] = qf[2]; fquat[i][3] = qf[3];
+    qmat(frot[i], qf);
+    axis[i][0] = frot[i][2]; axis[i][1] = frot[i][5]; axis[i][2] = frot[i][8];
+    v3cpy(pp, po); pq[0] = qf[0]; pq[1] = qf[1]; pq[2] = qf[2]; pq[3] = qf[3];
+    memcpy(prot, frot[i], sizeof(prot));
+  }
+  real lp[3] = {(real)a->jpos[7][0], (real)a->jpos[7][1], (real)a->jpos[7][2]};
+  real lq[4] = {(real)a->jquat[7][0], (real)a->jquat[7][1], (real)a->jquat[7][2], (real)a->jquat[7][3]};
+  frame_compose(fpos[7], fquat[7], pp, pq, prot, lp, lq);
+  qmat(frot[7], fquat[7]);
+}
+
+/* full kinematic update: frames, twists, collider vertices */
+static void arm_update_kinematics(const orc_world* w, orc_env* e) {
+  const rv_arm* a = &w->scene.arm;
+  arm_fk_limb(a, e->q, e->fpos, e->fquat, e->frot, e->axis);
+  /* twists (base is static) */
+  real wprev[3] = {R(0.0), R(0.0), R(0.0)}, vprev[3] = {R(0.0), R(0.0), R(0.0)};
+  real pprev[3] = {(real)a->base_pos[0], (real)a->base_pos[1], (real)a->base_pos[2]};
+  for (int i = 0; i < RV_NLIMB; ++i) {
+    real d[3], c[3];
+    v3sub(d, e->fpos[i], pprev); v3cross(c, wprev, d);
+    v3add(e->fv[i], vprev, c);
+    v3madd(e->fw[i], wprev, e->axis[i], e->qd[i]);
+    v3cpy(wprev, e->fw[i]); v3cpy(vprev, e->fv[i]); v3cpy(pprev, e->fpos[i]);
+  }
+  {
+    real d[3], c[3];
+    v3sub(d, e->fpos[7], pprev); v3cross(c, wprev, d);
+    v3add(e->fv[7], vprev, c); v3cpy(e->fw[7], wprev);
+  }
+  real yax[3] = {e->frot[7][1], e->frot[7][4], e->frot[7][7]};
+  for (int k = 0; k < 2; ++k) {
+    int f = 8 + k;
+    real off = (real)a->finger_y0[k] + e->q[7 + k];
+    v3madd(e->fpos[f], e->fpos[7], yax, off);
+    memcpy(e->fquat[f], e->fquat[7], sizeof(real) * 4);
+    memcpy(e->frot[f], e->frot[7], sizeof(real) * 9);
+    real d[3], c[3];
+    v3sub(d, e->fpos[f], e->fpos[7]); v3cross(c, e->fw[7], d);
+    v3add(e->fv[f], e->fv[7], c);
+    v3madd(e->fv[f], e->fv[f], yax, e->qd[7 + k]);
+    v3cpy(e->fw[f], e->fw[7]);
+  }
+  for (int c = 0; c < RV_NCOL; ++c) {
+    int f = a->col_frame[c];
+    real cc[3] = {(real)a->col_center[c][0], (real)a->col_center[c][1], (real)a->col_center[c][2]};
+    real hh[3] = {(real)a->col_half[c][0], (real)a->col_half[c][1], (real)a->col_half[c][2]};
+    real t[3]; m3mulv(t, e->frot[f], cc); v3add(e->colc[c], e->fpos[f], t);
+    e->colr[c] = rsqrt_(hh[0] * hh[0] + hh[1] * hh[1] + hh[2] * hh[2]) + (real)w->cfg.margin;
+    for (int k = 0; k < 8; ++k) {
+      real l[3] = {cc[0] + ((k & 1) ? hh[0] : -hh[0]), cc[1] + ((k & 2) ? hh[1] : -hh[1]), cc[2] + ((k & 4) ? hh[2] : -hh[2])};
+      m3mulv(t, e->frot[f], l); v3add(e->colv[c][k], e->fpos[f], t);
+    }
+  }
+}
+
+/* Damped-least-squares IK from the current joint state; restates the call
+ * bullet_physics.py:1203-1262 makes (target pose of the end-effector link,
+ * restPoses only => no null-space term).  out: 7 limb joint positions. */
+static void arm_ik(const orc_world* w, const orc_env* e, const real* pose, real* out) {
+  const rv_arm* a = &w->scene.arm;
+  const rv_config* c = &w->cfg;
+  real q[RV_NLIMB];
+  for (int i = 0; i < RV_NLIMB; ++i) q[i] = e->q[i];
+  real fpos[RV_NFRAME][3], fquat[RV_NFRAME][4], frot[RV_NFRAME][9], axis[RV_NLIMB][3];
+  for (int it = 0; it < c->ik_iters; ++it) {
+    arm_fk_limb(a, q, fpos, fquat, frot, axis);
+    real err[6];
+    v3sub(err, pose, fpos[7]);
+    real qc[4] = {-fquat[7][0], -fquat[7][1], -fquat[7][2], fquat[7][3]};
+    real qe[4]; qmul(qe, pose + 3, qc);
+    real sg = qe[3] < R(0.0) ? R(-2.0) : R(2.0);
+    err[3] = qe[0] * sg; err[4] = qe[1] * sg; err[5] = qe[2] * sg;
+    real e2 = R(0.0);
+    for (int k = 0; k < 6; ++k) e2 += err[k] * err[k];
+    if (e2 < (real)c->ik_residual * (real)c->ik_residual) break;
+    real J[6][RV_NLIMB];
+    for (int j = 0; j < RV_NLIMB; ++j) {
+      real d[3], cr[3];
+      v3sub(d, fpos[7], fpos[j]); v3cross(cr, axis[j], d);
+      J[0][j] = cr[0]; J[1][j] = cr[1]; J[2][j] = cr[2];
+      J[3][j] = axis[j][0]; J[4][j] = axis[j][1]; J[5][j] = axis[j][2];
+    }
+    real A[6][6];
+    real lam2 = (real)c->ik_damping * (real)c->ik_damping;
+    for (int r = 0; r < 6; ++r)
+      for (int s = 0; s < 6; ++s) {
+        real acc = R(0.0);
+        for (int j = 0; j < RV_NLIMB; ++j) acc += J[r][j] * J[s][j];
+        A[r][s] = acc + (r == s ? lam2 : R(0.0));
+      }
+    /* Cholesky A = L L^T, solve A y = err */
+    real L[6][6];
+    for (int r = 0; r < 6; ++r)
+      for (int s = 0; s <= r; ++s) {
+        real acc = A[r][s];
+        for (int k = 0; k < s; ++k) acc -= L[r][k] * L[s][k];
+        if (r == s) L[r][r] = rsqrt_(rmax(acc, R(1e-12)));
+        else L[r][s] = acc / L[s][s];
+      }
+    real y[6];
+    for (int r = 0; r < 6; ++r) {
+      real acc = err[r];
+      for (int k = 0; k < r; ++k) acc -= L[r][k] * y[k];
+      y[r] = acc / L[r][r];
+    }
+    for (int r = 5; r >= 0; --r) {
+      real acc = y[r];
+      for (int k = r + 1; k < 6; ++k) acc -= L[k][r] * y[k];
+      y[r] = acc / L[r][r];
+    }
+    real dq[RV_NLIMB], mx = R(0.0);
+    for (int j = 0; j < RV_NLIMB; ++j) {
+      real acc = R(0.0);
+      for (int r = 0; r < 6; ++r) acc += J[r][j] * y[r];
+      dq[j] = acc;
+      mx = rmax(mx, rabs(acc));
+    }
+    real sc = mx > (real)c->ik_max_step ? (real)c->ik_max_step / mx : R(1.0);
+    for (int j = 0; j < RV_NLIMB; ++j) q[j] = rclamp(q[j] + dq[j] * sc, (real)a->q_lo[j], (real)a->q_hi[j]);
+  }
+  for (int i = 0; i < RV_NLIMB; ++i) out[i] = q[i];
+}
+
+/* ------------------------------------------- ControllableBody restated -- */
+static void jt_reset(orc_jtarget* t) { t->active = 0; t->n_idx = 0; t->has_stop = 0; }
+static void lt_reset(orc_ltarget* t) { t->active = 0; t->has_pose = 0; t->nq = 0; t->has_stop = 0; }
+
+/* JointTarget.set (controllable_body.py:91-129) */
+static void jt_set(const orc_world* w, orc_env* e, int n, const int* idx, const real* pos, int has_vel,
+                   int use_times, real start_t, real stop_t, real pos_thr, real vel_thr, real timeout) {
+  orc_jtarget* t = &e->jt;
+  t->active = 1; t->n_idx = n; t->has_vel = has_vel;
+  for (int i = 0; i < n; ++i) { t->idx[i] = idx[i]; t->pos[i] = pos[i]; }
+  if (use_times) { t->start_t = start_t; t->stop_t = stop_t; }
+  else { t->start_t = sim_time(w, e); t->stop_t = t->start_t + timeout; }
+  t->has_stop = 1;
+  t->pos_thr = pos_thr; t->vel_thr = vel_thr;
+}
+
+/* ControllableBody.check_joints_reached (controllable_body.py:501-537) */
+static int check_joints_reached(const orc_env* e) {
+  const orc_jtarget* t = &e->jt;
+  if (!t->active) return 1;
+  for (int i = 0; i < t->n_idx; ++i) {
+    int j = t->idx[i];
+    real dp = t->pos[i] - e->q[j];
+    int pr = rabs(dp) < t->pos_thr;
+    int vr = 1;
+    if (t->has_vel) { real dv = R(0.0) - e->qd[j]; vr = rabs(dv) < t->vel_thr; }
+    if (!(pr && vr)) return 0;
+  }
+  return 1;
+}
+/* _check_link_target_done (controllable_body.py:415-432) */
+static int check_link_target_done(const orc_world* w, const orc_env* e) {
+  const orc_ltarget* t = &e->lt;
+  if (!t->has_stop) return 1;
+  if (sim_time(w, e) >= t->stop_t) return 1;
+  if (!t->has_pose && t->nq == 0) return 1;
+  return 0;
+}
+/* _check_joint_target_done (controllable_body.py:434-456) */
+static int check_joint_target_done(const orc_world* w, const orc_env* e) {
+  const orc_jtarget* t = &e->jt;
+  if (!t->has_stop) return 1;
+  if (sim_time(w, e) >= t->stop_t) return 1;
+  if (check_joints_reached(e)) return 1;
+  return 0;
+}
+/* LinkTarget.pop (controllable_body.py:226-233) */
+static void lt_pop(orc_ltarget* t) {
+  if (t->nq == 0) { lt_reset(t); return; }
+  memcpy(t->pose, t->queue[0], sizeof(real) * 7);
+  for (int i = 1; i < t->nq; ++i) memcpy(t->queue[i - 1], t->queue[i], sizeof(real) * 7);
+  t->nq--; t->has_pose = 1;
+}
+/* _update_ik (controllable_body.py:468-499) */
+static void update_ik(const orc_world* w, orc_env* e) {
+  real qik[RV_NLIMB];
+  arm_ik(w, e, e->lt.pose, qik);
+  int idx[RV_NLIMB];
+  for (int i = 0; i < RV_NLIMB; ++i) idx[i] = i;
+  jt_set(w, e, RV_NLIMB, idx, qik, e->lt.nq == 0, 1, e->lt.start_t, e->lt.stop_t, e->lt.pos_thr, e->lt.vel_thr, R(0.0));
+}
+/* _update_position_control (controllable_body.py:458-466) ->
+ * setJointMotorControlArray(POSITION_CONTROL) (bullet_physics.py:1061-1104) */
+static void update_position_control(const orc_world* w, orc_env* e) {
+  for (int i = 0; i < e->jt.n_idx; ++i) {
+    int j = e->jt.idx[i];
+    e->motor_on[j] = 1; e->motor_q[j] = e->jt.pos[i];
+    e->motor_kp[j] = (real)w->cfg.kp; e->motor_kd[j] = (real)w->cfg.kd;
+  }
+}
+/* ControllableBody.update (controllable_body.py:387-413) */
+static void control_update(const orc_world* w, orc_env* e) {
+  int ik_updated = 0;
+  if (e->lt.active) {
+    if (e->sim_steps % STEPS_TO_CHECK_DONE == 0)
+      if (check_link_target_done(w, e)) lt_reset(&e->lt);
+  }
+  if (e->lt.active) {
+    if (e->sim_steps % STEPS_TO_UPDATE_IK == 0 || !e->jt.active) {
+      update_ik(w, e);
+      ik_updated = 1;
+      if (check_joints_reached(e)) lt_pop(&e->lt);
+    }
+  }
+  if (e->jt.active) {
+    if (e->sim_steps % STEPS_TO_CHECK_DONE == 0 || ik_updated)
+      if (check_joint_target_done(w, e)) jt_reset(&e->jt);
+  }
+  if (e->jt.active) update_position_control(w, e);
+}
+/* ControllableBody.is_ready(joint_inds=limb) (controllable_body.py:565-595) */
+static int arm_is_ready_limb(const orc_world* w, orc_env* e) {
+  if (check_link_target_done(w, e)) lt_reset(&e->lt);
+  if (check_joint_target_done(w, e)) jt_reset(&e->jt);
+  if (e->lt.active) return 0; /* every limb joint index < end-effector link index */
+  if (e->jt.active) {
+    for (int i = 0; i < e->jt.n_idx; ++i) if (e->jt.idx[i] < RV_NLIMB) return 0;
+  }
+  return 1;
+}
+static void arm_reset_targets(orc_env* e) { lt_reset(&e->lt); jt_reset(&e->jt); }
+
+/* SawyerSim.move_to_joint_positions (sawyer_sim.py:186-234) */
+static void robot_move_to_joint_positions(const orc_world* w, orc_env* e, const real* pos) {
+  const rv_config* c = &w->cfg;
+  arm_reset_targets(e);
+  for (int j = 0; j < RV_NLIMB; ++j) e->vmax_cmd[j] = (real)c->limb_max_velocity_ratio * (real)w->scene.arm.v_max[j];
+  int idx[RV_NLIMB];
+  for (int i = 0; i < RV_NLIMB; ++i) idx[i] = i;
+  jt_set(w, e, RV_NLIMB, idx, pos, 1, 0, R(0.0), R(0.0), (real)c->limb_position_threshold, (real)c->velocity_threshold, (real)c->limb_timeout);
+}
+/* SawyerSim.move_to_gripper_pose, straight_line=False (sawyer_sim.py:236-308) */
+static void robot_move_to_gripper_pose(const orc_world* w, orc_env* e, const real* pose) {
+  const rv_config* c = &w->cfg;
+  arm_reset_targets(e);
+  for (int j = 0; j < RV_NLIMB; ++j) e->vmax_cmd[j] = (real)c->limb_max_velocity_ratio * (real)w->scene.arm.v_max[j];
+  orc_ltarget* t = &e->lt;
+  t->active = 1; t->has_pose = 1; t->nq = 0;
+  memcpy(t->pose, pose, sizeof(real) * 7);
+  t->start_t = sim_time(w, e); t->stop_t = t->start_t + (real)c->limb_timeout; t->has_stop = 1;
+  t->pos_thr = (real)c->limb_position_threshold; t->vel_thr = (real)c->velocity_threshold;
+}
+/* SawyerSim.grip (sawyer_sim.py:362-392) */
+static void robot_grip(const orc_world* w, orc_env* e, real value) {
+  const rv_arm* a = &w->scene.arm;
+  value = rclamp(value, R(0.01), R(0.99));
+  real lpos = (real)a->q_hi[7] - value * ((real)a->q_hi[7] - (real)a->q_lo[7]);
+  real rpos = (real)a->q_lo[8] + value * ((real)a->q_hi[8] - (real)a->q_lo[8]);
+  int idx[2] = {7, 8}; real pos[2] = {lpos, rpos};
+  jt_set(w, e, 2, idx, pos, 1, 0, R(0.0), R(0.0), R(0.008726640), (real)w->cfg.velocity_threshold, R(10000.0));
+  e->gripper_ready_time = sim_time(w, e) + R(0.5);
+}
+static int robot_is_gripper_ready(const orc_world* w, const orc_env* e) { return sim_time(w, e) >= e->gripper_ready_time; }
+
+/* joint motors of the kinematic arm: velocity-level position
+ * motor, command-velocity and acceleration limited, joint limits clamped */
+static void arm_motor_step(const orc_world* w, orc_env* e) {
+  const rv_arm* a = &w->scene.arm;
+  real dt = (real)w->cfg.dt;
+  for (int j = 0; j < RV_NJ; ++j) {
+    real vd = R(0.0);
+    if (e->motor_on[j]) {
+      vd = e->motor_kp[j] * (e->motor_q[j] - e->q[j]) / dt;
+      vd = rclamp(vd, -e->vmax_cmd[j], e->vmax_cmd[j]);
+    }
+    real dv = rclamp(vd - e->qd[j], -(real)a->a_max[j] * dt, (real)a->a_max[j] * dt);
+    real qd = e->qd[j] + dv;
+    real qn = e->q[j] + qd * dt;
+    if (qn < (real)a->q_lo[j]) { qn = (real)a->q_lo[j]; qd = R(0.0); }
+    if (qn > (real)a->q_hi[j]) { qn = (real)a->q_hi[j]; qd = R(0.0); }
+    e->q[j] = qn; e->qd[j] = qd;
+  }
+}
+
+/* --------------------------------------------------------- rigid bodies -- */
+static void body_set_mass(const orc_world* w, orc_env* e, int b, real mass) {
+  const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
+  orc_bparam* p = &e->bp[b];
+  p->mass = mass; p->inv_mass = R(1.0) / mass;
+  real s2 = p->scale * p->scale;
+  for (int k = 0; k < 3; ++k) p->inv_inertia[k] = R(1.0) / (mass * s2 * (real)s->inertia_k[k]);
+  p->radius = (real)s->radius * p->scale + (real)w->cfg.margin;
+}
+
+static void bodies_prepare(const orc_world* w, orc_env* e) {
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (!e->bp[b].active || e->bp[b].frozen) continue;
+    const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
+    real* m = e->rot[b];
+    qmat(m, e->body[b].q);
+    const real* ii = e->bp[b].inv_inertia;
+    /* I^-1 world = R diag(ii) R^T */
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        e->iinv[b][r * 3 + c] = m[r * 3 + 0] * ii[0] * m[c * 3 + 0] + m[r * 3 + 1] * ii[1] * m[c * 3 + 1] + m[r * 3 + 2] * ii[2] * m[c * 3 + 2];
+    for (int h = 0; h < s->n_hulls; ++h)
+      for (int i = 0; i < s->n_verts[h]; ++i) {
+        real l[3] = {(real)s->verts[h][i][0] * e->bp[b].scale, (real)s->verts[h][i][1] * e->bp[b].scale, (real)s->verts[h][i][2] * e->bp[b].scale};
+        real t[3]; m3mulv(t, m, l); v3add(e->wv[b][h][i], e->body[b].p, t);
+      }
+  }
+}
+
+static void table_prepare(const orc_world* w, orc_env* e) {
+  const rv_config* c = &w->cfg;
+  real mg = (real)c->margin;
+  real hx = (real)c->table_half[0] - mg, hy = (real)c->table_half[1] - mg;
+  real ztop = e->table_z - mg, zbot = e->table_z - (real)c->table_thickness + mg;
+  for (int k = 0; k < 8; ++k) {
+    e->tablev[k][0] = (real)c->table_center[0] + ((k & 1) ? hx : -hx);
+    e->tablev[k][1] = (real)c->table_center[1] + ((k & 2) ? hy : -hy);
+    e->tablev[k][2] = (k & 4) ? ztop : zbot;
+  }
+}
+
+static void plane_space(const real* n, real* t1, real* t2) {
+  if (rabs(n[2]) > R(0.7071067811865476)) {
+    real a = n[1] * n[1] + n[2] * n[2];
+    real k = R(1.0) / rsqrt_(a);
+    t1[0] = R(0.0); t1[1] = -n[2] * k; t1[2] = n[1] * k;
+    t2[0] = a * k; t2[1] = -n[0] * t1[2]; t2[2] = n[0] * t1[1];
+  } else {
+    real a = n[0] * n[0] + n[1] * n[1];
+    real k = R(1.0) / rsqrt_(a);
+    t1[0] = -n[1] * k; t1[1] = n[0] * k; t1[2] = R(0.0);
+    t2[0] = -n[2] * t1[1]; t2[1] = n[2] * t1[0]; t2[2] = a * k;
+  }
+}
+
+/* world -> local helpers for manifold points */
+static void to_local_body(const orc_env* e, int b, const real* wp, real* lp) {
+  real d[3]; v3sub(d, wp, e->body[b].p); m3tmulv(lp, e->rot[b], d);
+}
+static void to_world_body(const orc_env* e, int b, const real* lp, real* wp) {
+  real t[3]; m3mulv(t, e->rot[b], lp); v3add(wp, e->body[b].p, t);
+}
+static void to_local_frame(const orc_env* e, int f, const real* wp, real* lp) {
+  real d[3]; v3sub(d, wp, e->fpos[f]); m3tmulv(lp, e->frot[f], d);
+}
+static void to_world_frame(const orc_env* e, int f, const real* lp, real* wp) {
+  real t[3]; m3mulv(t, e->frot[f], lp); v3add(wp, e->fpos[f], t);
+}
+
+/* kind: 0 = body-table, 1 = body-body, 2 = arm-body */
+static void manifold_world_points(const orc_world* w, const orc_env* e, int kind, int a, int b, const orc_manifold* m, int i, real* wa, real* wb) {
+  to_world_body(e, a, m->la[i], wa);
+  if (kind == 0) v3cpy(wb, m->lb[i]);
+  else if (kind == 1) to_world_body(e, b, m->lb[i], wb);
+  else to_world_frame(e, w->scene.arm.col_frame[m->col[i]], m->lb[i], wb);
+}
+
+static void manifold_refresh(const orc_world* w, orc_env* e, int kind, int a, int b, orc_manifold* m) {
+  real brk = (real)w->cfg.breaking;
+  for (int i = m->n - 1; i >= 0; --i) {
+    real wa[3], wb[3], d[3];
+    manifold_world_points(w, e, kind, a, b, m, i, wa, wb);
+    v3sub(d, wa, wb);
+    real dist = v3dot(d, m->nrm[i]);
+    m->dist[i] = dist;
+    if (dist > brk) { orc_man_remove(m, i); continue; }
+    real proj[3], dr[3];
+    v3madd(proj, wa, m->nrm[i], -dist);
+    v3sub(dr, wb, proj);
+    if (v3dot(dr, dr) > brk * brk) orc_man_remove(m, i);
+  }
+}
+
+/* tangent-plane direction set used for one-shot manifold generation: the
+ * frame (t1,t2) rotated by 0.37 rad so box edges rarely tie */
+#define MAN_C R(0.932327)
+#define MAN_S R(0.361615)
+#define MAN_TAU R(0.1)
+
+static void manifold_add_world(const orc_world* w, orc_env* e, int kind, int a, int b, int col, orc_manifold* m,
+                               const real* wa, const real* wb, const real* n, real d) {
+  real la[3], lb[3];
+  to_local_body(e, a, wa, la);
+  if (kind == 0) v3cpy(lb, wb);
+  else if (kind == 1) to_local_body(e, b, wb, lb);
+  else to_local_frame(e, w->scene.arm.col_frame[col], wb, lb);
+  orc_man_add(m, la, lb, n, d, col, (real)w->cfg.breaking);
+}
+
+/* narrow phase of one convex pair: GJK/EPA witness point plus the feature
+ * vertices of either hull that lie within the contact-breaking distance of
+ * the other hull's support plane. */
+static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, int col,
+                        const real (*A)[3], int nA, const real (*B)[3], int nB,
+                        const real* guess, orc_manifold* m, real* out_dist) {
+  real mg = (real)w->cfg.margin, brk = (real)w->cfg.breaking;
+  real n[3], dist, pa[3], pb[3];
+  if (!orc_gjk_epa(A, nA, B, nB, guess, brk + R(2.0) * mg, n, &dist, pa, pb)) return 0;
+  real d = dist - R(2.0) * mg;
+  if (d > brk) return 0;
+  *out_dist = d;
+  if (!m) return 1;
+  real wa[3], wb[3];
+  v3madd(wa, pa, n, -mg); v3madd(wb, pb, n, mg);
+  manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, d);
+  real t1[3], t2[3], dir[4][3], extA[4], extB[4];
+  plane_space(n, t1, t2);
+  for (int k = 0; k < 3; ++k) {
+    dir[0][k] = MAN_C * t1[k] + MAN_S * t2[k];
+    dir[1][k] = MAN_C * t2[k] - MAN_S * t1[k];
+    dir[2][k] = -dir[0][k];
+    dir[3][k] = -dir[1][k];
+  }
+  for (int j = 0; j < 4; ++j) {
+    extA[j] = v3dot(A[orc_support(A, nA, dir[j])], dir[j]) + mg;
+    extB[j] = v3dot(B[orc_support(B, nB, dir[j])], dir[j]) + mg;
+  }
+  for (int k = 0; k < 4; ++k) {
+    real sd[3];
+    /* vertex of A's contact feature, projected on B's support plane */
+    v3madd(sd, dir[k], n, R(-1.0) / MAN_TAU);
+    const real* va = A[orc_support(A, nA, sd)];
+    real dv[3]; v3sub(dv, va, pb);
+    real sep = v3dot(dv, n);
+    real gap = sep - R(2.0) * mg;
+    if (gap <= brk) {
+      real pt[3]; v3madd(pt, va, n, -sep);
+      int ok = 1;
+      for (int j = 0; j < 4; ++j) if (v3dot(pt, dir[j]) > extB[j]) ok = 0;
+      if (ok) {
+        v3madd(wa, va, n, -mg); v3madd(wb, pt, n, mg);
+        manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, gap);
+      }
+    }
+    /* vertex of B's contact feature, projected on A's support plane */
+    v3madd(sd, dir[k], n, R(1.0) / MAN_TAU);
+    const real* vb = B[orc_support(B, nB, sd)];
+    v3sub(dv, pa, vb);
+    sep = v3dot(dv, n);
+    gap = sep - R(2.0) * mg;
+    if (gap <= brk) {
+      real pt[3]; v3madd(pt, vb, n, sep);
+      int ok = 1;
+      for (int j = 0; j < 4; ++j) if (v3dot(pt, dir[j]) > extA[j]) ok = 0;
+      if (ok) {
+        v3madd(wa, pt, n, -mg); v3madd(wb, vb, n, mg);
+        manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, gap);
+      }
+    }
+  }
+  return 1;
+}
+
+static real sphere_box_dist2(const real* p, const real* c, const real* h) {
+  real d2 = R(0.0);
+  for (int k = 0; k < 3; ++k) {
+    real d = rabs(p[k] - c[k]) - h[k];
+    if (d > R(0.0)) d2 += d * d;
+  }
+  return d2;
+}
+
+static void collide_all(const orc_world* w, orc_env* e) {
+  const rv_config* c = &w->cfg;
+  real brk = (real)c->breaking, qd = (real)c->contact_query_dist;
+  real tc[3] = {(real)c->table_center[0], (real)c->table_center[1], e->table_z - R(0.5) * (real)c->table_thickness};
+  real th[3] = {(real)c->table_half[0], (real)c->table_half[1], R(0.5) * (real)c->table_thickness};
+  /* refresh */
+  for (int b = 0; b < RV_MAXB; ++b) {
+    int on = e->bp[b].active && !e->bp[b].frozen;
+    if (!on) { e->man[TIDX(b)].n = 0; e->man[AIDX(b)].n = 0; continue; }
+    manifold_refresh(w, e, 0, b, -1, &e->man[TIDX(b)]);
+    if (e->arm_enabled) manifold_refresh(w, e, 2, b, -1, &e->man[AIDX(b)]); else e->man[AIDX(b)].n = 0;
+  }
+  for (int k = 0; k < RV_NBB; ++k) {
+    int a = BB_A[k], b = BB_B[k];
+    int on = e->bp[a].active && !e->bp[a].frozen && e->bp[b].active && !e->bp[b].frozen;
+    if (!on) { e->man[BBIDX(k)].n = 0; continue; }
+    manifold_refresh(w, e, 1, a, b, &e->man[BBIDX(k)]);
+  }
+  /* body - table */
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (!e->bp[b].active || e->bp[b].frozen) continue;
+    real r = e->bp[b].radius + brk;
+    if (sphere_box_dist2(e->body[b].p, tc, th) >= r * r) continue;
+    const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
+    real guess[3]; v3sub(guess, e->body[b].p, tc);
+    guess[0] = R(0.0); guess[1] = R(0.0);
+    for (int h = 0; h < s->n_hulls; ++h) {
+      real d;
+      collide_pair(w, e, 0, b, -1, -1, (const real(*)[3])e->wv[b][h], s->n_verts[h], (const real(*)[3])e->tablev, 8, guess, &e->man[TIDX(b)], &d);
+    }
+  }
+  /* body - body */
+  for (int k = 0; k < RV_NBB; ++k) {
+    int a = BB_A[k], b = BB_B[k];
+    if (!(e->bp[a].active && !e->bp[a].frozen && e->bp[b].active && !e->bp[b].frozen)) continue;
+    real d[3]; v3sub(d, e->body[a].p, e->body[b].p);
+    real r = e->bp[a].radius + e->bp[b].radius + brk;
+    if (v3dot(d, d) >= r * r) continue;
+    const rv_shape* sa = &w->scene.shapes[e->bp[a].shape];
+    const rv_shape* sb = &w->scene.shapes[e->bp[b].shape];
+    for (int ha = 0; ha < sa->n_hulls; ++ha)
+      for (int hb = 0; hb < sb->n_hulls; ++hb) {
+        real dd;
+        collide_pair(w, e, 1, a, b, -1, (const real(*)[3])e->wv[a][ha], sa->n_verts[ha], (const real(*)[3])e->wv[b][hb], sb->n_verts[hb], d, &e->man[BBIDX(k)], &dd);
+      }
+  }
+  /* arm */
+  e->flag_arm_table = 0;
+  for (int b = 0; b < RV_MAXB; ++b) e->flag_arm_body[b] = 0;
+  if (e->arm_enabled) {
+    for (int col = 0; col < RV_NCOL; ++col) {
+      for (int b = 0; b < RV_MAXB; ++b) {
+        if (!e->bp[b].active || e->bp[b].frozen) continue;
+        real d[3]; v3sub(d, e->body[b].p, e->colc[col]);
+        real r = e->bp[b].radius + e->colr[col] + brk;
+        if (v3dot(d, d) >= r * r) continue;
+        const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
+        for (int h = 0; h < s->n_hulls; ++h) {
+          real dd;
+          collide_pair(w, e, 2, b, -1, col, (const real(*)[3])e->wv[b][h], s->n_verts[h], (const real(*)[3])e->colv[col], 8, d, &e->man[AIDX(b)], &dd);
+        }
+      }
+      /* arm - table: detection only (push_env.py:839-855) */
+      real r = e->colr[col] + brk;
+      if (sphere_box_dist2(e->colc[col], tc, th) < r * r) {
+        real guess[3] = {R(0.0), R(0.0), R(1.0)}, dd;
+        if (collide_pair(w, e, 0, 0, -1, col, (const real(*)[3])e->colv[col], 8, (const real(*)[3])e->tablev, 8, guess, NULL, &dd))
+          if (dd < qd) e->flag_arm_table = 1;
+      }
+    }
+    for (int b = 0; b < RV_MAXB; ++b) {
+      const orc_manifold* m = &e->man[AIDX(b)];
+      for (int i = 0; i < m->n; ++i) if (m->dist[i] < qd) e->flag_arm_body[b] = 1;
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- PGS ---- */
+typedef struct {
+  real dir[3][3];     /* n, t1, t2 */
+  real rxa[3][3], rxb[3][3];
+  real aa[3][3], ab[3][3];
+  real invk[3];
+  real vbc[3];        /* dir . (kinematic surface velocity) */
+  real target, mu;
+} orc_row;
+
+static void row_setup(const orc_world* w, orc_env* e, int kind, int a, int b, const orc_manifold* m, int i, orc_row* r) {
+  const rv_config* c = &w->cfg;
+  real dt = (real)c->dt;
+  real wa[3], wb[3], ra[3], rb[3];
+  manifold_world_points(w, e, kind, a, b, m, i, wa, wb);
+  v3sub(ra, wa, e->body[a].p);
+  v3cpy(r->dir[0], m->nrm[i]);
+  plane_space(r->dir[0], r->dir[1], r->dir[2]);
+  real vb_pt[3] = {R(0.0), R(0.0), R(0.0)};
+  real imb = R(0.0);
+  if (kind == 1) { v3sub(rb, wb, e->body[b].p); imb = e->bp[b].inv_mass; }
+  else { rb[0] = rb[1] = rb[2] = R(0.0); }
+  if (kind == 2) {
+    int f = w->scene.arm.col_frame[m->col[i]];
+    real d[3], cr[3];
+    v3sub(d, wb, e->fpos[f]); v3cross(cr, e->fw[f], d); v3add(vb_pt, e->fv[f], cr);
+  }
+  for (int k = 0; k < 3; ++k) {
+    v3cross(r->rxa[k], ra, r->dir[k]);
+    m3mulv(r->aa[k], e->iinv[a], r->rxa[k]);
+    real kk = e->bp[a].inv_mass + v3dot(r->rxa[k], r->aa[k]);
+    if (kind == 1) {
+      v3cross(r->rxb[k], rb, r->dir[k]);
+      m3mulv(r->ab[k], e->iinv[b], r->rxb[k]);
+      kk += imb + v3dot(r->rxb[k], r->ab[k]);
+    } else {
+      r->rxb[k][0] = r->rxb[k][1] = r->rxb[k][2] = R(0.0);
+      r->ab[k][0] = r->ab[k][1] = r->ab[k][2] = R(0.0);
+    }
+    r->invk[k] = R(1.0) / kk;
+    r->vbc[k] = v3dot(r->dir[k], vb_pt);
+  }
+  real dist = m->dist[i];
+  if (dist > R(0.0)) r->target = -dist / dt;
+  else r->target = rmin((real)c->erp * rmax(-dist - (real)c->slop, R(0.0)) / dt, (real)c->max_pushout);
+  real mub = (kind == 0) ? (real)c->table_friction : (kind == 1 ? e->bp[b].friction : (real)c->arm_friction);
+  r->mu = e->bp[a].friction * mub;
+}
+
+static void row_apply(orc_env* e, int kind, int a, int b, const orc_row* r, int k, real dl) {
+  v3madd(e->body[a].v, e->body[a].v, r->dir[k], dl * e->bp[a].inv_mass);
+  v3madd(e->body[a].w, e->body[a].w, r->aa[k], dl);
+  if (kind == 1) {
+    v3madd(e->body[b].v, e->body[b].v, r->dir[k], -dl * e->bp[b].inv_mass);
+    v3madd(e->body[b].w, e->body[b].w, r->ab[k], -dl);
+  }
+}
+static real row_jv(const orc_env* e, int kind, int a, int b, const orc_row* r, int k) {
+  real jv = v3dot(r->dir[k], e->body[a].v) + v3dot(r->rxa[k], e->body[a].w);
+  if (kind == 1) jv -= v3dot(r->dir[k], e->body[b].v) + v3dot(r->rxb[k], e->body[b].w);
+  else jv -= r->vbc[k];
+  return jv;
+}
+static void point_solve(orc_env* e, int kind, int a, int b, orc_manifold* m, int i, const orc_row* r) {
+  /* normal */
+  real jv = row_jv(e, kind, a, b, r, 0);
+  real dl = (r->target - jv) * r->invk[0];
+  real ln = rmax(m->ln[i] + dl, R(0.0));
+  dl = ln - m->ln[i]; m->ln[i] = ln;
+  row_apply(e, kind, a, b, r, 0, dl);
+  /* friction pyramid */
+  real lim = r->mu * m->ln[i];
+  jv = row_jv(e, kind, a, b, r, 1);
+  dl = -jv * r->invk[1];
+  real l1 = rclamp(m->lt1[i] + dl, -lim, lim);
+  dl = l1 - m->lt1[i]; m->lt1[i] = l1;
+  row_apply(e, kind, a, b, r, 1, dl);
+  jv = row_jv(e, kind, a, b, r, 2);
+  dl = -jv * r->invk[2];
+  real l2 = rclamp(m->lt2[i] + dl, -lim, lim);
+  dl = l2 - m->lt2[i]; m->lt2[i] = l2;
+  row_apply(e, kind, a, b, r, 2, dl);
+}
+
+static void solve_contacts(const orc_world* w, orc_env* e) {
+  const rv_config* c = &w->cfg;
+  orc_row rows[RV_NMAN][4];
+  /* setup + warm start, in the order the iterations visit the points */
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int b = 0; b < RV_MAXB; ++b) {
+      for (int kind = 0; kind <= 2; kind += 2) {
+        int mi = kind == 0 ? TIDX(b) : AIDX(b);
+        orc_manifold* m = &e->man[mi];
+        for (int i = 0; i < m->n; ++i) {
+          if (pass == 0) {
+            row_setup(w, e, kind, b, -1, m, i, &rows[mi][i]);
+            m->ln[i] *= (real)c->warmstart; m->lt1[i] *= (real)c->warmstart; m->lt2[i] *= (real)c->warmstart;
+          } else {
+            row_apply(e, kind, b, -1, &rows[mi][i], 0, m->ln[i]);
+            row_apply(e, kind, b, -1, &rows[mi][i], 1, m->lt1[i]);
+            row_apply(e, kind, b, -1, &rows[mi][i], 2, m->lt2[i]);
+          }
+        }
+      }
+    }
+    for (int rd = 0; rd < 3; ++rd)
+      for (int x = 0; x < 2; ++x) {
+        int k = BB_ROUND[rd][x]; int mi = BBIDX(k);
+        orc_manifold* m = &e->man[mi];
+        for (int i = 0; i < m->n; ++i) {
+          if (pass == 0) {
+            row_setup(w, e, 1, BB_A[k], BB_B[k], m, i, &rows[mi][i]);
+            m->ln[i] *= (real)c->warmstart; m->lt1[i] *= (real)c->warmstart; m->lt2[i] *= (real)c->warmstart;
+          } else {
+            row_apply(e, 1, BB_A[k], BB_B[k], &rows[mi][i], 0, m->ln[i]);
+            row_apply(e, 1, BB_A[k], BB_B[k], &rows[mi][i], 1, m->lt1[i]);
+            row_apply(e, 1, BB_A[k], BB_B[k], &rows[mi][i], 2, m->lt2[i]);
+          }
+        }
+      }
+  }
+  for (int it = 0; it < c->solver_iters; ++it) {
+    for (int b = 0; b < RV_MAXB; ++b) {
+      orc_manifold* m = &e->man[TIDX(b)];
+      for (int i = 0; i < m->n; ++i) point_solve(e, 0, b, -1, m, i, &rows[TIDX(b)][i]);
+      m = &e->man[AIDX(b)];
+      for (int i = 0; i < m->n; ++i) point_solve(e, 2, b, -1, m, i, &rows[AIDX(b)][i]);
+    }
+    for (int rd = 0; rd < 3; ++rd)
+      for (int x = 0; x < 2; ++x) {
+        int k = BB_ROUND[rd][x];
+        orc_manifold* m = &e->man[BBIDX(k)];
+        for (int i = 0; i < m->n; ++i) point_solve(e, 1, BB_A[k], BB_B[k], m, i, &rows[BBIDX(k)][i]);
+      }
+  }
+}
+
+/* ------------------------------------------------- Simulator.step ------- */
+/* Simulator.step (simulator.py:94-103): body.update() for the arm, then
+ * physics.step() (bullet_physics.py:106-109), then num_steps += 1. */
+static void sim_substep(const orc_world* w, orc_env* e) {
+  const rv_config* c = &w->cfg;
+  real dt = (real)c->dt;
+  if (e->arm_enabled) {
+    control_update(w, e);
+    arm_motor_step(w, e);
+    arm_update_kinematics(w, e);
+  }
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (!e->bp[b].active || e->bp[b].frozen) continue;
+    orc_body* B = &e->body[b];
+    B->v[2] += (real)c->gravity_z * dt;
+    v3scale(B->v, B->v, (real)c->lin_damp);
+    v3scale(B->w, B->w, (real)c->ang_damp);
+  }
+  bodies_prepare(w, e);
+  collide_all(w, e);
+  solve_contacts(w, e);
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (!e->bp[b].active || e->bp[b].frozen) continue;
+    orc_body* B = &e->body[b];
+    v3madd(B->p, B->p, B->v, dt);
+    real wq[4] = {B->w[0], B->w[1], B->w[2], R(0.0)}, dq[4];
+    qmul(dq, wq, B->q);
+    for (int k = 0; k < 4; ++k) B->q[k] += R(0.5) * dt * dq[k];
+    qnormalize(B->q);
+    if (B->p[2] < e->table_z - (real)c->fall_depth) {
+      e->bp[b].frozen = 1;
+      v3set(B->v, R(0.0), R(0.0), R(0.0)); v3set(B->w, R(0.0), R(0.0), R(0.0));
+    }
+  }
+  e->sim_steps++;
+  e->substeps_last++;
+}
+
+/* Simulator.check_stable over a body mask (simulator.py:289-323) */
+static int bodies_stable(const orc_env* e, unsigned mask, real lin_thr, real ang_thr) {
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (!((mask >> b) & 1u) || !e->bp[b].active) continue;
+    real lv = v3len(e->body[b].v), av = v3len(e->body[b].w);
+    if (lv >= lin_thr || av >= ang_thr) return 0;
+  }
+  return 1;
+}
+/* Simulator.wait_until_stable (simulator.py:325-376) */
+static int wait_until_stable(const orc_world* w, orc_env* e, unsigned mask, real lin_thr, real ang_thr,
+                             int check_after, int min_stable, int max_steps) {
+  int num_steps = 0, num_stable = 0;
+  for (;;) {
+    sim_substep(w, e);
+    num_steps++;
+    if (num_steps < check_after) continue;
+    if (bodies_stable(e, mask, lin_thr, ang_thr)) num_stable++;
+    if (num_stable >= min_stable || num_steps >= max_steps) break;
+  }
+  return num_steps;
+}
+
+/* --------------------------------------------------- observation/reward -- */
+static void compute_obs(orc_env* e) {
+  memcpy(e->prev_obs_pos, e->obs_pos, sizeof(e->obs_pos));
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (e->bp[b].active) v3cpy(e->obs_pos[b], e->body[b].p);
+    else v3set(e->obs_pos[b], R(0.0), R(0.0), R(0.0));
+  }
+}
+
+/* check_on_tiles (push_reward.py:57-68): note the tile centres use `size` */
+static int on_tiles(const real* xy, const float (*tiles)[2], int n, real size, const float* offset, real max_dist) {
+  for (int i = 0; i < n; ++i) {
+    real tx = (real)offset[0] + (real)tiles[i][0] * size;
+    real ty = (real)offset[1] + (real)tiles[i][1] * size;
+    if (rabs(xy[0] - tx) <= R(0.5) * max_dist && rabs(xy[1] - ty) <= R(0.5) * max_dist) return 1;
+  }
+  return 0;
+}
+/* get_tile_dists (push_reward.py:71-76) */
+static real tile_dist(const real* xy, const float (*tiles)[2], int n, real size, const float* offset) {
+  real best = R(1e30);
+  for (int i = 0; i < n; ++i) {
+    real dx = xy[0] - ((real)offset[0] + (real)tiles[i][0] * size);
+    real dy = xy[1] - ((real)offset[1] + (real)tiles[i][1] * size);
+    real d = rsqrt_(dx * dx + dy * dy);
+    if (d < best) best = d;
+  }
+  return best;
+}
+static real task_score(const rv_config* c, real st[][3]) {
+  real size = (real)c->tile_size;
+  if (c->task == RV_TASK_CLEARING) {
+    /* clearing_score (push_reward.py:101-107), including the overwritten min */
+    real d1 = R(0.0), d3 = R(0.0);
+    for (int b = 0; b < RV_MAXB; ++b) { d1 += rabs(st[b][0] - R(0.7)); d3 += rabs(st[b][1] + R(0.9)); }
+    d1 /= (real)RV_MAXB; d3 /= (real)RV_MAXB;
+    return -rmin(d1, d3);
+  }
+  return -tile_dist(st[0], c->goal, c->n_goal, size, c->tile_offset);
+}
+/* get_reward_fn(...).reward_fn with is_planning=False (push_reward.py:302-372) */
+static void compute_reward(const orc_world* w, orc_env* e, real* reward, int* termination) {
+  const rv_config* c = &w->cfg;
+  if (c->task == RV_TASK_NONE) { *reward = R(1.0); *termination = 0; return; } /* dummy_reward_fn :34-47 */
+  real size = (real)c->tile_size;
+  int term = 0, goal = 0;
+  if (c->task == RV_TASK_CROSSING)
+    term = !on_tiles(e->obs_pos[0], c->region, c->n_region, size, c->tile_offset, size * R(1.5));
+  if (c->task == RV_TASK_CLEARING) {
+    goal = 1;
+    for (int b = 0; b < RV_MAXB; ++b)
+      if (on_tiles(e->obs_pos[b], c->region, c->n_region, size * R(1.25), c->tile_offset, size * R(1.25))) goal = 0;
+  } else {
+    goal = on_tiles(e->obs_pos[0], c->goal, c->n_goal, size, c->tile_offset, size);
+  }
+  goal = goal && !term;
+  real r = R(0.0);
+  r += R(100.0) * (real)goal;
+  int penalty = term && !goal;
+  r += R(-100.0) * (real)penalty;
+  r += rabs(task_score(c, e->obs_pos) - task_score(c, e->prev_obs_pos));
+  r += R(-1.0);
+  *reward = r; *termination = term || goal;
+}
+
+/* --------------------------------------------------------- PushEnv ------- */
+static void set_gripper_pose(real* pose, real x, real y, real z) {
+  /* euler [pi, 0, 0] (push_env.py:771,782) */
+  pose[0] = x; pose[1] = y; pose[2] = z;
+  euler_to_quat(pose + 3, ORC_PI, R(0.0), R(0.0));
+}
+/* PushEnv._compute_waypoints (push_env.py:752-786) */
+static void compute_waypoints(const rv_config* c, const real* action, real* start, real* end) {
+  real lo0 = (real)c->cspace_low[0], hi0 = (real)c->cspace_high[0];
+  real lo1 = (real)c->cspace_low[1], hi1 = (real)c->cspace_high[1];
+  real lo2 = (real)c->cspace_low[2], hi2 = (real)c->cspace_high[2];
+  real x = action[0] * (R(0.5) * (hi0 - lo0)) + R(0.5) * (hi0 + lo0);
+  real y = action[1] * (R(0.5) * (hi1 - lo1)) + R(0.5) * (hi1 + lo1);
+  real z = (real)c->finger_tip_offset + R(0.5) * (hi2 + lo2);
+  set_gripper_pose(start, x, y, z);
+  real ex = rclamp(x + action[2] * (real)c->translation_x, lo0, hi0);
+  real ey = rclamp(y + action[3] * (real)c->translation_y, lo1, hi1);
+  set_gripper_pose(end, ex, ey, z);
+}
+static int arm_touches_movables(const orc_env* e) {
+  for (int b = 0; b < RV_MAXB; ++b) if (e->bp[b].active && e->flag_arm_body[b]) return 1;
+  return 0;
+}
+/* PushEnv._check_safety (push_env.py:857-898) */
+static int check_safety(const orc_world* w, const orc_env* e, real start_z) {
+  const rv_config* c = &w->cfg;
+  if (e->phase == RV_PHASE_PRE) { if (arm_touches_movables(e)) return 0; }
+  if (e->phase == RV_PHASE_START) {
+    if (arm_touches_movables(e)) {
+      real dist = e->fpos[7][2] - start_z;
+      if (rabs(dist) <= R(0.01)) return 1;
+      return 0;
+    }
+  }
+  if (e->phase == RV_PHASE_DONE) {
+    if (arm_touches_movables(e)) return 0;
+    real lx = (real)c->table_center[0] - R(0.5) * (real)c->workspace_x_range, hx = (real)c->table_center[0] + R(0.5) * (real)c->workspace_x_range;
+    real ly = (real)c->table_center[1] - R(0.5) * (real)c->workspace_y_range, hy = (real)c->table_center[1] + R(0.5) * (real)c->workspace_y_range;
+    for (int b = 0; b < RV_MAXB; ++b) {
+      if (!e->bp[b].active) continue;
+      const real* p = e->body[b].p;
+      if (p[0] < lx || p[0] > hx || p[1] < ly || p[1] > hy) return 0;
+    }
+  }
+  return 1;
+}
+
+/* PushEnv._execute_action (push_env.py:631-733) */
+static void execute_action(const orc_world* w, orc_env* e) {
+  const rv_config* c = &w->cfg;
+  int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
+  real wp[RV_MAXG][2][7];
+  for (int g = 0; g < G; ++g) compute_waypoints(c, e->action[g], wp[g][0], wp[g][1]);
+  real start_z = (real)c->finger_tip_offset + R(0.5) * ((real)c->cspace_high[2] + (real)c->cspace_low[2]);
+  e->is_safe = 1; e->is_effective = 1;
+  e->phase = RV_PHASE_INITIAL;
+  int num_waypoints = 0, interrupt = 0, has_budget = 0, max_phase_steps = 0;
+  real start_pos[RV_MAXB][3], start_yaw[RV_MAXB];
+  for (int b = 0; b < RV_MAXB; ++b) { v3cpy(start_pos[b], e->body[b].p); start_yaw[b] = quat_yaw(e->body[b].q); }
+  while (e->phase != RV_PHASE_DONE) {
+    sim_substep(w, e);
+    if (e->sim_steps % c->steps_check != 0) continue;
+    /* _is_phase_ready (push_env.py:812-837) */
+    int ready = 0;
+    if (interrupt) ready = 1;
+    else if (arm_is_ready_limb(w, e) && robot_is_gripper_ready(w, e)) { arm_reset_targets(e); ready = 1; }
+    else if (!has_budget) ready = 1;
+    else if (e->sim_steps >= max_phase_steps) { arm_reset_targets(e); ready = 1; }
+    if (ready) {
+      /* _get_next_phase (push_env.py:788-810) */
+      int next;
+      if (interrupt && e->phase != RV_PHASE_POST && e->phase != RV_PHASE_OFFSTAGE) next = RV_PHASE_POST;
+      else if (c->num_goal_steps > 0 && e->phase == RV_PHASE_POST && num_waypoints < c->num_goal_steps) next = RV_PHASE_PRE;
+      else next = e->phase + 1;
+#ifdef ORC_TRACE
+      fprintf(stderr, "phase %d -> %d at sim_step %d (lt %d jt %d) ee=(%.3f %.3f %.3f) interrupt=%d\n", e->phase, next, e->sim_steps, e->lt.active, e->jt.active, (double)e->fpos[7][0], (double)e->fpos[7][1], (double)e->fpos[7][2], interrupt);
+#endif
+      e->phase = next;
+      has_budget = 1;
+      max_phase_steps = e->sim_steps;
+      if (next == RV_PHASE_MOTION) max_phase_steps += c->max_motion_steps;
+      else if (next == RV_PHASE_OFFSTAGE) max_phase_steps += c->max_offstage_steps;
+      else max_phase_steps += c->max_phase_steps;
+      if (next == RV_PHASE_PRE) {
+        real pose[7]; memcpy(pose, wp[num_waypoints][0], sizeof(pose));
+        pose[2] = (real)c->gripper_safe_height;
+        robot_move_to_gripper_pose(w, e, pose);
+      } else if (next == RV_PHASE_START) {
+        robot_move_to_gripper_pose(w, e, wp[num_waypoints][0]);
+      } else if (next == RV_PHASE_MOTION) {
+        robot_move_to_gripper_pose(w, e, wp[num_waypoints][1]);
+      } else if (next == RV_PHASE_POST) {
+        num_waypoints++;
+        real pose[7];
+        v3cpy(pose, e->fpos[7]); memcpy(pose + 3, e->fquat[7], sizeof(real) * 4);
+        pose[2] = (real)c->gripper_safe_height;
+        robot_move_to_gripper_pose(w, e, pose);
+      } else if (next == RV_PHASE_OFFSTAGE) {
+        real off[RV_NLIMB];
+        for (int j = 0; j < RV_NLIMB; ++j) off[j] = (real)c->offstage_positions[j];
+        robot_move_to_joint_positions(w, e, off);
+      }
+    }
+    interrupt = 0;
+    /* _check_singularity (push_env.py:839-855) */
+    if (e->phase == RV_PHASE_MOTION && e->flag_arm_table) interrupt = 1;
+    if (!check_safety(w, e, start_z)) { interrupt = 1; e->is_safe = 0; }
+    if (interrupt && e->phase == RV_PHASE_DONE) { e->done = 1; break; }
+  }
+  unsigned mask = 0;
+  for (int b = 0; b < RV_MAXB; ++b) if (e->bp[b].active) mask |= 1u << b;
+  wait_until_stable(w, e, mask, R(0.005), R(0.005), 100, 100, 2000);
+  /* _check_effectiveness (push_env.py:900-923) */
+  real dpos = R(0.0), dang = R(0.0);
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (!e->bp[b].active) continue;
+    real d[3]; v3sub(d, e->body[b].p, start_pos[b]);
+    dpos += v3len(d);
+    real da = quat_yaw(e->body[b].q) - start_yaw[b];
+    da = da + ORC_PI;
+    da = da - R(2.0) * ORC_PI * R(floor)(da / (R(2.0) * ORC_PI));
+    da = da - ORC_PI;
+    dang += rabs(da);
+  }
+  if (dpos <= (real)c->min_delta_position && dang <= (real)c->min_delta_angle) e->is_effective = 0;
+  e->num_total_steps++;
+  e->num_unsafe += !e->is_safe;
+  e->num_ineffective += !e->is_effective;
+  e->num_useful += (e->is_safe && e->is_effective);
+}
+
+/* RobotEnv.step (robot_env.py:239-275) + PushEnv.step (push_env.py:599-629) */
+static void env_step(const orc_world* w, orc_env* e) {
+  const rv_config* c = &w->cfg;
+  if (e->done) return;
+  e->substeps_last = 0;
+  execute_action(w, e);
+  e->num_steps++;
+  compute_obs(e);
+  real r; int term;
+  compute_reward(w, e, &r, &term);
+  e->last_reward = r;
+  e->episode_reward += r;
+  e->done = e->done || term;
+  if (c->max_steps > 0 && e->num_steps >= c->max_steps) e->done = 1;
+  if (e->done) {
+    e->num_episodes++;
+    if (r >= (real)c->success_thresh) e->num_successes++;
+  }
+}
+
+/* --------------------------------------------------------------- reset --- */
+/* PushEnv._sample_body_poses / _sample_body_poses_on_tiles, intent version
+ * (push_env.py:473-597; SURVEY.md Appendix B-7 documents why the reference's
+ * RNG stream is not replicated). */
+static void sample_poses(const orc_world* w, orc_env* e, orc_rng* g, int nb, real poses[][7]) {
+  const rv_config* c = &w->cfg;
+  for (;;) {
+    int ok = 1;
+    for (int i = 0; i < nb && ok; ++i) {
+      int placed = 0;
+      for (int att = 0; att <= 32 && !placed; ++att) {
+        real x, y, z, roll, pitch, yaw;
+        if (c->use_tiles) {
+          const float (*tiles)[2] = (i == 0 && c->n_target > 0) ? c->target : c->obstacle;
+          int nt = (i == 0 && c->n_target > 0) ? c->n_target : c->n_obstacle;
+          int tid = rng_randint(g, nt);
+          real cx = (real)c->tile_offset[0] + (real)tiles[tid][0] * (real)c->tile_size;
+          real cy = (real)c->tile_offset[1] + (real)tiles[tid][1] * (real)c->tile_size;
+          x = rng_uniform(g, cx - R(0.5) * (real)c->tile_size, cx + R(0.5) * (real)c->tile_size);
+          y = rng_uniform(g, cy - R(0.5) * (real)c->tile_size, cy + R(0.5) * (real)c->tile_size);
+          z = e->table_z + (real)c->safe_drop_height;
+          roll = rng_uniform(g, -ORC_PI, ORC_PI);
+          pitch = rng_uniform(g, R(-0.5) * ORC_PI, R(0.5) * ORC_PI);
+          yaw = rng_uniform(g, -ORC_PI, ORC_PI);
+        } else {
+          x = rng_uniform(g, (real)c->pose_lo[0], (real)c->pose_hi[0]);
+          y = rng_uniform(g, (real)c->pose_lo[1], (real)c->pose_hi[1]);
+          z = e->table_z + rng_uniform(g, (real)c->pose_lo[2], (real)c->pose_hi[2]);
+          roll = rng_uniform(g, (real)c->pose_lo[3], (real)c->pose_hi[3]);
+          pitch = rng_uniform(g, (real)c->pose_lo[4], (real)c->pose_hi[4]);
+          yaw = rng_uniform(g, (real)c->pose_lo[5], (real)c->pose_hi[5]);
+        }
+        int valid = 1;
+        for (int j = 0; j < i; ++j) {
+          real dx = x - poses[j][0], dy = y - poses[j][1];
+          if (rsqrt_(dx * dx + dy * dy) < (real)c->margin_xy) { valid = 0; break; }
+        }
+        if (valid) {
+          poses[i][0] = x; poses[i][1] = y; poses[i][2] = z;
+          euler_to_quat(poses[i] + 3, roll, pitch, yaw);
+          placed = 1;
+        }
+      }
+      if (!placed) ok = 0;
+    }
+    if (ok) return;
+  }
+}
+
+/* RobotEnv.reset (robot_env.py:204-237) for one env */
+static void env_reset(const orc_world* w, orc_env* e, int gid) {
+  const rv_config* c = &w->cfg;
+  orc_rng g; rng_init(&g, c->seed_lo, c->seed_hi, (uint32_t)gid, STREAM_RESET, (uint32_t)e->reset_count);
+  e->reset_count++;
+  e->substeps_last = 0;
+  e->sim_steps = 0; e->num_steps = 0; e->episode_reward = R(0.0); e->last_reward = R(0.0);
+  e->done = 0;
+  e->phase = RV_PHASE_INITIAL; e->is_safe = 1; e->is_effective = 1;
+  e->arm_enabled = 0;
+  for (int i = 0; i < RV_NMAN; ++i) e->man[i].n = 0;
+  e->flag_arm_table = 0;
+  for (int b = 0; b < RV_MAXB; ++b) e->flag_arm_body[b] = 0;
+  /* ArmEnv._reset_scene (arm_env.py:78-99) */
+  e->table_z = (real)c->table_z + rng_uniform(&g, (real)c->table_height_range[0], (real)c->table_height_range[1]);
+  table_prepare(w, e);
+  /* PushEnv._reset_scene / _load_movable_bodies (push_env.py:331-471) */
+  int nb = c->n_bodies_min + rng_randint(&g, c->n_bodies_max - c->n_bodies_min + 1);
+  e->n_bodies = nb;
+  for (;;) {
+    real poses[RV_MAXB][7];
+    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; }
+    for (int i = 0; i < RV_NMAN; ++i) e->man[i].n = 0;
+    sample_poses(w, e, &g, nb, poses);
+    for (int i = 0; i < nb; ++i) {
+      int use_target = (i == 0 && c->use_tiles && c->n_target > 0 && c->n_target_shapes > 0);
+      int shape = use_target ? c->target_shapes[rng_randint(&g, c->n_target_shapes)]
+                             : c->movable_shapes[rng_randint(&g, c->n_movable_shapes)];
+      real scale = rng_uniform(&g, (real)c->scale_range[0], (real)c->scale_range[1]);
+      orc_bparam* p = &e->bp[i];
+      p->active = 1; p->frozen = 0; p->shape = shape; p->scale = scale; p->friction = (real)c->drop_friction;
+      body_set_mass(w, e, i, (real)c->drop_mass);
+      v3cpy(e->body[i].p, poses[i]); memcpy(e->body[i].q, poses[i] + 3, sizeof(real) * 4);
+      v3set(e->body[i].v, R(0.0), R(0.0), R(0.0)); v3set(e->body[i].w, R(0.0), R(0.0), R(0.0));
+      wait_until_stable(w, e, 1u << i, R(0.1), R(0.1), 100, 100, 500);
+      real mass = rng_uniform(&g, (real)c->mass_range[0], (real)c->mass_range[1]);
+      real fr = rng_uniform(&g, (real)c->friction_range[0], (real)c->friction_range[1]);
+      body_set_mass(w, e, i, mass); p->friction = fr;
+    }
+    int valid = 1;
+    for (int i = 0; i < nb; ++i) if (e->body[i].p[2] < e->table_z) valid = 0;
+    if (valid) break;
+  }
+  unsigned mask = 0;
+  for (int b = 0; b < RV_MAXB; ++b) if (e->bp[b].active) mask |= 1u << b;
+  wait_until_stable(w, e, mask, R(0.005), R(0.005), 100, 100, 2000);
+  /* ArmEnv._reset_robot (arm_env.py:101-107) -> SawyerSim.reboot (sawyer_sim.py:86-171) */
+  const rv_arm* a = &w->scene.arm;
+  for (int j = 0; j < RV_NLIMB; ++j) { e->q[j] = (real)c->neutral_positions[j]; e->qd[j] = R(0.0); }
+  e->q[7] = (real)a->q_hi[7]; e->q[8] = (real)a->q_lo[8]; e->qd[7] = e->qd[8] = R(0.0);
+  for (int j = 0; j < RV_NJ; ++j) { e->motor_on[j] = 0; e->motor_q[j] = e->q[j]; e->motor_kp[j] = (real)c->kp; e->motor_kd[j] = (real)c->kd; e->vmax_cmd[j] = (real)a->v_max[j]; }
+  arm_reset_targets(e);
+  e->gripper_ready_time = R(0.0);
+  e->arm_enabled = 1;
+  arm_update_kinematics(w, e);
+  if (c->open_gripper_when_reset) robot_grip(w, e, R(0.0));
+  real off[RV_NLIMB];
+  for (int j = 0; j < RV_NLIMB; ++j) off[j] = (real)c->offstage_positions[j];
+  robot_move_to_joint_positions(w, e, off);
+  e->has_prev = 0;
+  compute_obs(e);
+  memcpy(e->prev_obs_pos, e->obs_pos, sizeof(e->obs_pos));
+}
+
+/* ------------------------------------------------------------ C API ------ */
+orc_world* orc_create(const rv_config* cfg, const rv_scene* scene) {
+  orc_world* w = (orc_world*)calloc(1, sizeof(orc_world));
+  w->cfg = *cfg; w->scene = *scene; w->n = cfg->n_envs;
+  w->env = (orc_env*)calloc((size_t)w->n, sizeof(orc_env));
+  return w;
+}
+void orc_destroy(orc_world* w) { if (w) { free(w->env); free(w); } }
+int orc_is_double(void) { return (int)(sizeof(real) == 8); }
+
+static void stats_begin(orc_world* w) { memset(&w->stats, 0, sizeof(w->stats)); }
+static void stats_env(orc_world* w, const orc_env* e) {
+  w->stats.substeps += e->substeps_last;
+  if (e->substeps_last > w->stats.max_substeps) w->stats.max_substeps = e->substeps_last;
+}
+
+void orc_reset(orc_world* w, const uint8_t* mask) {
+  stats_begin(w);
+#pragma omp parallel for schedule(dynamic)
+  for (int i = 0; i < w->n; ++i) {
+    if (mask && !mask[i]) { w->env[i].substeps_last = 0; continue; }
+    env_reset(w, &w->env[i], w->cfg.env_id_offset + i);
+  }
+  for (int i = 0; i < w->n; ++i) stats_env(w, &w->env[i]);
+}
+void orc_set_actions(orc_world* w, const float* actions) {
+  int G = w->cfg.num_goal_steps > 0 ? w->cfg.num_goal_steps : 1;
+  for (int i = 0; i < w->n; ++i)
+    for (int g = 0; g < G; ++g)
+      for (int k = 0; k < 4; ++k) w->env[i].action[g][k] = (real)actions[(i * G + g) * 4 + k];
+}
+void orc_step_macro(orc_world* w) {
+  stats_begin(w);
+#pragma omp parallel for schedule(dynamic)
+  for (int i = 0; i < w->n; ++i) {
+    orc_env* e = &w->env[i];
+    e->substeps_last = 0;
+    if (e->done) continue;
+    env_step(w, e);
+  }
+  for (int i = 0; i < w->n; ++i) {
+    const orc_env* e = &w->env[i];
+    stats_env(w, e);
+    if (e->substeps_last > 0) {
+      w->stats.env_steps++;
+      w->stats.unsafe += !e->is_safe; w->stats.ineffective += !e->is_effective;
+      w->stats.useful += (e->is_safe && e->is_effective);
+      if (e->done) { w->stats.episodes_done++; if (e->last_reward >= (real)w->cfg.success_thresh) w->stats.successes++; }
+    }
+  }
+}
+void orc_step_sub(orc_world* w, int n) {
+  stats_begin(w);
+#pragma omp parallel for schedule(dynamic)
+  for (int i = 0; i < w->n; ++i) {
+    w->env[i].substeps_last = 0;
+    for (int k = 0; k < n; ++k) sim_substep(w, &w->env[i]);
+  }
+  for (int i = 0; i < w->n; ++i) stats_env(w, &w->env[i]);
+}
+void orc_wait_until_stable(orc_world* w, float lin, float ang, int check_after, int min_stable, int max_steps) {
+  stats_begin(w);
+#pragma omp parallel for schedule(dynamic)
+  for (int i = 0; i < w->n; ++i) {
+    orc_env* e = &w->env[i];
+    e->substeps_last = 0;
+    unsigned mask = 0;
+    for (int b = 0; b < RV_MAXB; ++b) if (e->bp[b].active) mask |= 1u << b;
+    wait_until_stable(w, e, mask, (real)lin, (real)ang, check_after, min_stable, max_steps);
+  }
+  for (int i = 0; i < w->n; ++i) stats_env(w, &w->env[i]);
+}
+void orc_policy_random(orc_world* w, int macro_index, float* actions) {
+  int G = w->cfg.num_goal_steps > 0 ? w->cfg.num_goal_steps : 1;
+  for (int i = 0; i < w->n; ++i) {
+    orc_rng g; rng_init(&g, w->cfg.seed_lo, w->cfg.seed_hi, (uint32_t)(w->cfg.env_id_offset + i), STREAM_RANDOM, (uint32_t)macro_index);
+    for (int k = 0; k < G * 4; ++k) actions[i * G * 4 + k] = (float)rng_uniform(&g, R(-1.0), R(1.0));
+  }
+}
+
+/* HeuristicPushSampler._sample (heuristic_push_sampler.py:66-123): candidates
+ * are drawn from Philox keyed by (env, episode, step, attempt) so that the
+ * lowest successful attempt index wins regardless of evaluation order. */
+void orc_policy_heuristic(orc_world* w, int max_attempts, float* actions) {
+  const rv_config* c = &w->cfg;
+  int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
+  for (int i = 0; i < w->n; ++i) {
+    const orc_env* e = &w->env[i];
+    int nb = 0;
+    for (int b = 0; b < RV_MAXB; ++b) nb += e->bp[b].active;
+    if (nb == 0) nb = 1;
+    int body_id = e->num_episodes % nb;
+    real base = (real)e->num_episodes * R(42.0);
+    base = base - R(2.0) * ORC_PI * R(floor)(base / (R(2.0) * ORC_PI));
+    real lo0 = (real)c->cspace_low[0], hi0 = (real)c->cspace_high[0], lo1 = (real)c->cspace_low[1], hi1 = (real)c->cspace_high[1];
+    real start[2] = {0, 0}, motion[2] = {0, 0};
+    for (int att = 0; att < max_attempts; ++att) {
+      orc_rng g; rng_init(&g, c->seed_lo, c->seed_hi, (uint32_t)(c->env_id_offset + i), STREAM_HEUR,
+                          (uint32_t)(e->num_episodes * 64 + e->num_steps));
+      g.ctr[0] = (uint32_t)att * 2u;
+      start[0] = rng_uniform(&g, R(-1.0), R(1.0)); start[1] = rng_uniform(&g, R(-1.0), R(1.0));
+      real ang = base + rng_uniform(&g, R(-0.25) * ORC_PI, R(0.25) * ORC_PI);
+      real s, co; rsincos(ang, &s, &co);
+      motion[0] = rclamp(co + rng_uniform(&g, R(-0.3), R(0.3)), R(-1.0), R(1.0));
+      motion[1] = rclamp(s + rng_uniform(&g, R(-0.3), R(0.3)), R(-1.0), R(1.0));
+      real x = start[0] * (R(0.5) * (hi0 - lo0)) + R(0.5) * (hi0 + lo0);
+      real y = start[1] * (R(0.5) * (hi1 - lo1)) + R(0.5) * (hi1 + lo1);
+      real ex = rclamp(x + motion[0] * (real)c->translation_x, lo0, hi0);
+      real ey = rclamp(y + motion[1] * (real)c->translation_y, lo1, hi1);
+      int safe = 1;
+      for (int b = 0; b < nb; ++b) {
+        real dx = e->obs_pos[b][0] - x, dy = e->obs_pos[b][1] - y;
+        if (!(rsqrt_(dx * dx + dy * dy) > R(0.05))) safe = 0;
+      }
+      if (!safe) continue;
+      real dx1 = e->obs_pos[body_id][0] - x, dy1 = e->obs_pos[body_id][1] - y;
+      real dx2 = e->obs_pos[body_id][0] - ex, dy2 = e->obs_pos[body_id][1] - ey;
+      int clear = rsqrt_(dx1 * dx1 + dy1 * dy1) >= R(0.01) && rsqrt_(dx2 * dx2 + dy2 * dy2) >= R(0.01);
+      if (!clear) break; /* effective and safe */
+    }
+    for (int g2 = 0; g2 < G; ++g2) {
+      actions[(i * G + g2) * 4 + 0] = (float)start[0]; actions[(i * G + g2) * 4 + 1] = (float)start[1];
+      actions[(i * G + g2) * 4 + 2] = (float)motion[0]; actions[(i * G + g2) * 4 + 3] = (float)motion[1];
+    }
+  }
+}
+
+void orc_get_body_state(orc_world* w, double* out) {
+  for (int i = 0; i < w->n; ++i)
+    for (int b = 0; b < RV_MAXB; ++b) {
+      double* o = out + ((size_t)i * RV_MAXB + b) * 13;
+      const orc_body* B = &w->env[i].body[b];
+      for (int k = 0; k < 3; ++k) { o[k] = B->p[k]; o[7 + k] = B->v[k]; o[10 + k] = B->w[k]; }
+      for (int k = 0; k < 4; ++k) o[3 + k] = B->q[k];
+    }
+}
+void orc_set_body_state(orc_world* w, const double* in) {
+  for (int i = 0; i < w->n; ++i)
+    for (int b = 0; b < RV_MAXB; ++b) {
+      const double* o = in + ((size_t)i * RV_MAXB + b) * 13;
+      orc_body* B = &w->env[i].body[b];
+      for (int k = 0; k < 3; ++k) { B->p[k] = (real)o[k]; B->v[k] = (real)o[7 + k]; B->w[k] = (real)o[10 + k]; }
+      for (int k = 0; k < 4; ++k) B->q[k] = (real)o[3 + k];
+      w->env[i].man[TIDX(b)].n = 0; w->env[i].man[AIDX(b)].n = 0;
+    }
+  for (int i = 0; i < w->n; ++i) for (int k = 0; k < RV_NBB; ++k) w->env[i].man[BBIDX(k)].n = 0;
+}
+void orc_get_body_params(orc_world* w, double* out) {
+  for (int i = 0; i < w->n; ++i)
+    for (int b = 0; b < RV_MAXB; ++b) {
+      double* o = out + ((size_t)i * RV_MAXB + b) * 8;
+      const orc_bparam* p = &w->env[i].bp[b];
+      o[0] = p->active; o[1] = p->shape; o[2] = p->scale; o[3] = p->mass; o[4] = p->friction; o[5] = p->frozen; o[6] = w->env[i].table_z; o[7] = 0;
+    }
+}
+void orc_set_body_params(orc_world* w, const double* in) {
+  for (int i = 0; i < w->n; ++i) {
+    orc_env* e = &w->env[i];
+    for (int b = 0; b < RV_MAXB; ++b) {
+      const double* o = in + ((size_t)i * RV_MAXB + b) * 8;
+      orc_bparam* p = &e->bp[b];
+      p->active = (int)o[0]; p->shape = (int)o[1]; p->scale = (real)o[2]; p->friction = (real)o[4]; p->frozen = (int)o[5];
+      if (b == 0) { e->table_z = (real)o[6]; table_prepare(w, e); }
+      if (p->active) body_set_mass(w, e, b, (real)o[3]);
+    }
+    e->n_bodies = 0;
+    for (int b = 0; b < RV_MAXB; ++b) e->n_bodies += e->bp[b].active;
+  }
+}
+void orc_get_joint_state(orc_world* w, double* out) {
+  for (int i = 0; i < w->n; ++i)
+    for (int j = 0; j < RV_NJ; ++j) { out[((size_t)i * RV_NJ + j) * 2] = w->env[i].q[j]; out[((size_t)i * RV_NJ + j) * 2 + 1] = w->env[i].qd[j]; }
+}
+void orc_set_joint_state(orc_world* w, const double* in) {
+  for (int i = 0; i < w->n; ++i) {
+    orc_env* e = &w->env[i];
+    for (int j = 0; j < RV_NJ; ++j) { e->q[j] = (real)in[((size_t)i * RV_NJ + j) * 2]; e->qd[j] = (real)in[((size_t)i * RV_NJ + j) * 2 + 1]; e->motor_q[j] = e->q[j]; }
+    if (!e->arm_enabled) {
+      const rv_arm* a = &w->scene.arm;
+      for (int j = 0; j < RV_NJ; ++j) { e->motor_on[j] = 0; e->motor_kp[j] = (real)w->cfg.kp; e->motor_kd[j] = (real)w->cfg.kd; e->vmax_cmd[j] = (real)a->v_max[j]; }
+      arm_reset_targets(e); e->gripper_ready_time = R(0.0); e->arm_enabled = 1;
+    }
+    arm_update_kinematics(w, e);
+  }
+}
+void orc_get_link_poses(orc_world* w, double* out) {
+  for (int i = 0; i < w->n; ++i)
+    for (int f = 0; f < RV_NFRAME; ++f) {
+      double* o = out + ((size_t)i * RV_NFRAME + f) * 7;
+      for (int k = 0; k < 3; ++k) o[k] = w->env[i].fpos[f][k];
+      for (int k = 0; k < 4; ++k) o[3 + k] = w->env[i].fquat[f][k];
+    }
+}
+void orc_get_env_counters(orc_world* w, int32_t* out) {
+  for (int i = 0; i < w->n; ++i) {
+    const orc_env* e = &w->env[i]; int32_t* o = out + (size_t)i * 8;
+    o[0] = e->sim_steps; o[1] = e->num_steps; o[2] = e->num_episodes; o[3] = e->phase; o[4] = e->done; o[5] = e->is_safe; o[6] = e->is_effective; o[7] = e->substeps_last;
+  }
+}
+void orc_set_joint_targets(orc_world* w, const float* q) {
+  for (int i = 0; i < w->n; ++i) {
+    real pos[RV_NLIMB];
+    for (int j = 0; j < RV_NLIMB; ++j) pos[j] = (real)q[i * RV_NLIMB + j];
+    robot_move_to_joint_positions(w, &w->env[i], pos);
+  }
+}
+void orc_set_link_target(orc_world* w, const float* pose) {
+  for (int i = 0; i < w->n; ++i) {
+    real p[7];
+    for (int k = 0; k < 7; ++k) p[k] = (real)pose[i * 7 + k];
+    robot_move_to_gripper_pose(w, &w->env[i], p);
+  }
+}
+void orc_compute_ik(orc_world* w, const float* pose, double* q) {
+  for (int i = 0; i < w->n; ++i) {
+    real p[7], out[RV_NLIMB];
+    for (int k = 0; k < 7; ++k) p[k] = (real)pose[i * 7 + k];
+    arm_ik(w, &w->env[i], p, out);
+    for (int j = 0; j < RV_NLIMB; ++j) q[i * RV_NLIMB + j] = out[j];
+  }
+}
+void orc_query_contacts(orc_world* w, uint8_t* out) {
+  for (int i = 0; i < w->n; ++i) {
+    const orc_env* e = &w->env[i]; uint8_t* o = out + (size_t)i * (2 + RV_MAXB);
+    o[0] = (uint8_t)e->flag_arm_table; o[1] = (uint8_t)arm_touches_movables(e);
+    for (int b = 0; b < RV_MAXB; ++b) o[2 + b] = (uint8_t)(e->bp[b].active && e->flag_arm_body[b]);
+  }
+}
+void orc_get_manifold_counts(orc_world* w, int32_t* out) {
+  for (int i = 0; i < w->n; ++i) for (int m = 0; m < RV_NMAN; ++m) out[(size_t)i * RV_NMAN + m] = w->env[i].man[m].n;
+}
+void orc_observe(orc_world* w, double* position, double* body_mask) {
+  for (int i = 0; i < w->n; ++i)
+    for (int b = 0; b < RV_MAXB; ++b) {
+      for (int k = 0; k < 3; ++k) position[((size_t)i * RV_MAXB + b) * 3 + k] = w->env[i].obs_pos[b][k];
+      body_mask[(size_t)i * RV_MAXB + b] = w->env[i].bp[b].active;
+    }
+}
+void orc_reward(orc_world* w, double* reward, uint8_t* done) {
+  for (int i = 0; i < w->n; ++i) { reward[i] = w->env[i].last_reward; done[i] = (uint8_t)w->env[i].done; }
+}
+void orc_get_episode_returns(orc_world* w, double* r) { for (int i = 0; i < w->n; ++i) r[i] = w->env[i].episode_reward; }
+void orc_get_stats(orc_world* w, rv_macro_stats* s) { *s = w->stats; }
+
+/* stand-alone reward evaluation for golden-vector tests (push_reward.py:302-372) */
+void orc_eval_reward(const rv_config* cfg, const double* state, const double* next_state, double* reward, int32_t* term) {
+  orc_world w; memset(&w, 0, sizeof(w)); w.cfg = *cfg;
+  orc_env e; memset(&e, 0, sizeof(e));
+  for (int b = 0; b < RV_MAXB; ++b) {
+    e.prev_obs_pos[b][0] = (real)state[b * 2]; e.prev_obs_pos[b][1] = (real)state[b * 2 + 1];
+    e.obs_pos[b][0] = (real)next_state[b * 2]; e.obs_pos[b][1] = (real)next_state[b * 2 + 1];
+  }
+  real r; int t;
+  compute_reward(&w, &e, &r, &t);
+  *reward = r; *term = t;
+}
+/* stand-alone waypoint evaluation (push_env.py:752-786) */
+void orc_eval_waypoints(const rv_config* cfg, const float* action, double* start, double* end) {
+  real a[4] = {(real)action[0], (real)action[1], (real)action[2], (real)action[3]}, s[7], e[7];
+  compute_waypoints(cfg, a, s, e);
+  for (int k = 0; k < 7; ++k) { start[k] = s[k]; end[k] = e[k]; }
+}
+/* stand-alone GJK query for unit tests */
+int orc_eval_gjk(const double* A, int nA, const double* B, int nB, double max_dist, double* out /* n3, dist, pa3, pb3 */) {
+  real a[64][3], b[64][3];
+  for (int i = 0; i < nA; ++i) for (int k = 0; k < 3; ++k) a[i][k] = (real)A[i * 3 + k];
+  for (int i = 0; i < nB; ++i) for (int k = 0; k < 3; ++k) b[i][k] = (real)B[i * 3 + k];
+  real ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0}, g[3];
+  for (int i = 0; i < nA; ++i) v3madd(ca, ca, a[i], R(1.0) / (real)nA);
+  for (int i = 0; i < nB; ++i) v3madd(cb, cb, b[i], R(1.0) / (real)nB);
+  v3sub(g, ca, cb);
+  real n[3], dist, pa[3], pb[3];
+  int hit = orc_gjk_epa((const real(*)[3])a, nA, (const real(*)[3])b, nB, g, (real)max_dist, n, &dist, pa, pb);
+  if (hit) { for (int k = 0; k < 3; ++k) { out[k] = n[k]; out[4 + k] = pa[k]; out[7 + k] = pb[k]; } out[3] = dist; }
+  return hit;
+}

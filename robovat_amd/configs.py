@@ -1,0 +1,249 @@
+"""BUILD-CHOSEN configuration values for the push / arm environments.
+
+The reference reads these keys from ``configs/envs/push_env.yaml``,
+``configs/robots/sawyer_sim.yaml`` and ``configs/policies/*.yaml``, none of
+which is distributed with its source (README.md:48-59; key list in SURVEY.md
+Appendix A).  The key *names* below follow the reference; every *value* is this
+build's choice and is documented in DESIGN.md §6.  ``make_rv_config`` flattens
+the nested dictionary into the C ``rv_config`` struct of ``include/rovat.h``.
+"""
+import copy
+import math
+
+import numpy as np
+
+from robovat_amd import abi
+from robovat_amd.envs.push import push_layouts
+
+
+class AttrDict(dict):
+    """Minimal EasyDict stand-in (attribute access, recursive)."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        d = dict(d or {}, **kw)
+        for k, v in d.items():
+            self[k] = AttrDict(v) if isinstance(v, dict) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+PUSH_ENV_CONFIG = {
+    'TASK_NAME': None,              # None | 'clearing' | 'insertion' | 'crossing'
+    'LAYOUT_ID': 0,
+    'NUM_GOAL_STEPS': None,
+    'MAX_STEPS': None,
+    'SUCCESS_THRESH': 50.0,
+    'DEBUG': False,
+    'ACTION': {
+        'CSPACE': {'LOW': [0.35, -0.35, 0.02], 'HIGH': [0.85, 0.35, 0.02]},
+        'MOTION': {'TRANSLATION_X': 0.2, 'TRANSLATION_Y': 0.2},
+        'MIN_DELTA_POSITION': 0.01,
+        'MIN_DELTA_ANGLE': 0.05,
+    },
+    'ARM': {
+        'FINGER_TIP_OFFSET': 0.14,
+        'GRIPPER_SAFE_HEIGHT': 0.30,
+        'OFFSTAGE_POSITIONS': [-1.5, -1.26, 0.00, 1.98, 0.00, 0.85, 3.3161],
+    },
+    'TABLE': {'X_RANGE': 0.76, 'Y_RANGE': 1.22, 'HEIGHT_RANGE': [-0.005, 0.005]},
+    'SIM': {
+        'TABLE': {'POSE': [[0.6, 0.0, 0.0], [0, 0, 0]], 'HALF_EXTENTS': [0.38, 0.61],
+                  'THICKNESS': 0.05, 'FRICTION': 1.0},
+        'STEPS_CHECK': 10,
+        'MAX_PHASE_STEPS': 2000,
+        'MAX_MOTION_STEPS': 3000,
+        'MAX_OFFSTAGE_STEPS': 3000,
+        'FALL_DEPTH': 0.3,
+    },
+    'MIN_MOVABLE_BODIES': 4,
+    'MAX_MOVABLE_BODIES': 4,
+    'MOVABLE_NAME': 'CONVEX',
+    'MOVABLE': {
+        'CONVEX': {
+            'PATHS': ['box', 'cylinder16', 'hull_a', 'hull_b'],
+            'TARGET_PATHS': ['box'],
+            'SCALE': [0.8, 1.2], 'MASS': [0.1, 0.5], 'FRICTION': [0.3, 1.0],
+            'MARGIN': 0.12,
+            'POSE': {'X': [0.40, 0.80], 'Y': [-0.30, 0.30], 'Z': [0.08, 0.08],
+                     'ROLL': [0.0, 0.0], 'PITCH': [0.0, 0.0],
+                     'YAW': [-math.pi, math.pi]},
+        },
+        'CONCAVE': {
+            'PATHS': ['concave_L', 'concave_T', 'concave_U', 'concave_X'],
+            'TARGET_PATHS': ['concave_L', 'concave_T'],
+            'SCALE': [0.8, 1.0], 'MASS': [0.1, 0.5], 'FRICTION': [0.3, 1.0],
+            'MARGIN': 0.15,
+            'POSE': {'X': [0.40, 0.80], 'Y': [-0.30, 0.30], 'Z': [0.08, 0.08],
+                     'ROLL': [0.0, 0.0], 'PITCH': [0.0, 0.0],
+                     'YAW': [-math.pi, math.pi]},
+        },
+    },
+    'DROP': {'MASS': 0.1, 'FRICTION': 1.0, 'SAFE_HEIGHT': 0.2},
+    'OBS': {'NUM_POINTS': 256},
+    'USE_PRESTIGE_OBS': True,
+    'USE_VISUALIZATION_OBS': False,
+    'KINECT2': {'DEPTH': {'TRANSLATION': [0.6, 0.0, 1.2]}},
+    'PHYSICS': {
+        'TIME_STEP': 1e-3, 'GRAVITY_Z': -9.8,
+        'SOLVER_ITERS': 8, 'ERP': 0.2, 'SLOP': 0.0005, 'MARGIN': 0.001,
+        'BREAKING': 0.01, 'WARMSTART': 0.85, 'MAX_PUSHOUT': 0.5,
+        'LINEAR_DAMPING': 0.04, 'ANGULAR_DAMPING': 0.04,
+        'CONTACT_QUERY_DIST': 0.001, 'ARM_FRICTION': 0.8,
+    },
+}
+
+SAWYER_SIM_CONFIG = {
+    'LIMB_JOINT_NAMES': ['right_j%d' % i for i in range(7)],
+    'LIMB_NEUTRAL_POSITIONS': [0.0, -1.18, 0.0, 2.18, 0.0, 0.57, 3.3161],
+    'END_EFFCTOR_NAME': 'right_hand',
+    'L_FINGER_NAME': 'right_gripper_l_finger_joint',
+    'R_FINGER_NAME': 'right_gripper_r_finger_joint',
+    'L_FINGER_TIP_NAME': 'right_gripper_l_finger_tip',
+    'R_FINGER_TIP_NAME': 'right_gripper_r_finger_tip',
+    'OPEN_GRIPPER_WHEN_RESET': True,
+    'LIMB_MAX_VELOCITY_RATIO': 0.5,
+    'LIMB_TIMEOUT': 15.0,
+    'LIMB_POSITION_THRESHOLD': 0.008726640,
+    'END_EFFECTOR_STEP': 0.1,
+    'POSITION_GAIN': 0.05, 'VELOCITY_GAIN': 1.0, 'VELOCITY_THRESHOLD': 0.05,
+    'IK': {'ITERS': 8, 'DAMPING': 0.05, 'RESIDUAL': 1e-4, 'MAX_STEP': 0.2},
+}
+
+HEURISTIC_PUSH_POLICY_CONFIG = {
+    'ACTION': PUSH_ENV_CONFIG['ACTION'],
+    'HEURISTICS': {'MAX_ATTEMPS': 20000},
+}
+
+
+def push_env_config(**overrides):
+    cfg = AttrDict(copy.deepcopy(PUSH_ENV_CONFIG))
+    for k, v in overrides.items():
+        node = cfg
+        parts = k.split('.')
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = AttrDict(v) if isinstance(v, dict) else v
+    return cfg
+
+
+def sawyer_config(**overrides):
+    cfg = AttrDict(copy.deepcopy(SAWYER_SIM_CONFIG))
+    cfg.update(overrides)
+    return cfg
+
+
+def make_rv_config(env_cfg=None, robot_cfg=None, shape_names=None, n_envs=1,
+                   env_id_offset=0, seed=0):
+    """Flatten the nested configs into the C ``rv_config`` struct."""
+    env_cfg = env_cfg or push_env_config()
+    robot_cfg = robot_cfg or sawyer_config()
+    if shape_names is None:
+        from robovat_amd import scenes
+        shape_names = [n for n, _ in scenes.default_shape_hulls()]
+    c = abi.rv_config()
+    c.n_envs = int(n_envs)
+    c.env_id_offset = int(env_id_offset)
+    c.seed_lo = int(seed) & 0xFFFFFFFF
+    c.seed_hi = (int(seed) >> 32) & 0xFFFFFFFF
+    ph = env_cfg.PHYSICS
+    c.dt = ph.TIME_STEP
+    c.gravity_z = ph.GRAVITY_Z
+    c.solver_iters = ph.SOLVER_ITERS
+    c.erp, c.slop, c.margin = ph.ERP, ph.SLOP, ph.MARGIN
+    c.breaking, c.warmstart, c.max_pushout = ph.BREAKING, ph.WARMSTART, ph.MAX_PUSHOUT
+    c.lin_damp = float(np.float32((1.0 - ph.LINEAR_DAMPING) ** ph.TIME_STEP))
+    c.ang_damp = float(np.float32((1.0 - ph.ANGULAR_DAMPING) ** ph.TIME_STEP))
+    c.contact_query_dist = ph.CONTACT_QUERY_DIST
+    tb = env_cfg.SIM.TABLE
+    abi.assign(c.table_center, tb.POSE[0][:2])
+    abi.assign(c.table_half, tb.HALF_EXTENTS)
+    c.table_thickness = tb.THICKNESS
+    c.table_z = tb.POSE[0][2]
+    abi.assign(c.table_height_range, env_cfg.TABLE.HEIGHT_RANGE)
+    c.table_friction = tb.FRICTION
+    c.arm_friction = ph.ARM_FRICTION
+    c.fall_depth = env_cfg.SIM.FALL_DEPTH
+    c.n_bodies_min = env_cfg.MIN_MOVABLE_BODIES
+    c.n_bodies_max = env_cfg.MAX_MOVABLE_BODIES
+    assert 1 <= c.n_bodies_min <= c.n_bodies_max <= abi.RV_MAXB
+    mv = env_cfg.MOVABLE[env_cfg.MOVABLE_NAME.upper()]
+    abi.assign(c.scale_range, _rng(mv.SCALE))
+    abi.assign(c.mass_range, _rng(mv.MASS))
+    abi.assign(c.friction_range, _rng(mv.FRICTION))
+    c.margin_xy = mv.MARGIN
+    keys = ['X', 'Y', 'Z', 'ROLL', 'PITCH', 'YAW']
+    abi.assign(c.pose_lo, [_rng(mv.POSE[k])[0] for k in keys])
+    abi.assign(c.pose_hi, [_rng(mv.POSE[k])[1] for k in keys])
+    c.drop_mass = env_cfg.DROP.MASS
+    c.drop_friction = env_cfg.DROP.FRICTION
+    c.safe_drop_height = env_cfg.DROP.SAFE_HEIGHT
+    mov = [shape_names.index(p) for p in mv.PATHS]
+    tgt = [shape_names.index(p) for p in mv.TARGET_PATHS]
+    c.n_movable_shapes = len(mov)
+    abi.assign(c.movable_shapes, mov)
+    c.n_target_shapes = len(tgt)
+    abi.assign(c.target_shapes, tgt)
+    # layout
+    task = env_cfg.TASK_NAME
+    c.task = abi.TASK_IDS[task]
+    c.layout_id = int(env_cfg.LAYOUT_ID)
+    c.tile_size = push_layouts.SIZE
+    abi.assign(c.tile_offset, push_layouts.OFFSET)
+    if c.task != abi.RV_TASK_NONE:
+        layout = push_layouts.TASK_NAME_TO_LAYOUTS[task][c.layout_id]
+        c.use_tiles = 1
+        c.tile_size = layout.size
+        abi.assign(c.tile_offset, layout.offset)
+        for name in ('region', 'goal', 'target', 'obstacle'):
+            tiles = getattr(layout, name) or []
+            assert len(tiles) <= abi.RV_MAXTILES
+            setattr(c, 'n_' + name, len(tiles))
+            abi.assign(getattr(c, name), tiles)
+    # arm control
+    c.kp, c.kd = robot_cfg.POSITION_GAIN, robot_cfg.VELOCITY_GAIN
+    c.velocity_threshold = robot_cfg.VELOCITY_THRESHOLD
+    c.limb_max_velocity_ratio = robot_cfg.LIMB_MAX_VELOCITY_RATIO
+    c.limb_timeout = robot_cfg.LIMB_TIMEOUT
+    c.limb_position_threshold = robot_cfg.LIMB_POSITION_THRESHOLD
+    c.ik_iters = robot_cfg.IK.ITERS
+    c.ik_damping, c.ik_residual, c.ik_max_step = (
+        robot_cfg.IK.DAMPING, robot_cfg.IK.RESIDUAL, robot_cfg.IK.MAX_STEP)
+    abi.assign(c.neutral_positions, robot_cfg.LIMB_NEUTRAL_POSITIONS)
+    abi.assign(c.offstage_positions, env_cfg.ARM.OFFSTAGE_POSITIONS)
+    c.open_gripper_when_reset = int(bool(robot_cfg.OPEN_GRIPPER_WHEN_RESET))
+    # push env
+    abi.assign(c.cspace_low, env_cfg.ACTION.CSPACE.LOW)
+    abi.assign(c.cspace_high, env_cfg.ACTION.CSPACE.HIGH)
+    c.translation_x = env_cfg.ACTION.MOTION.TRANSLATION_X
+    c.translation_y = env_cfg.ACTION.MOTION.TRANSLATION_Y
+    c.finger_tip_offset = env_cfg.ARM.FINGER_TIP_OFFSET
+    c.gripper_safe_height = env_cfg.ARM.GRIPPER_SAFE_HEIGHT
+    c.min_delta_position = env_cfg.ACTION.MIN_DELTA_POSITION
+    c.min_delta_angle = env_cfg.ACTION.MIN_DELTA_ANGLE
+    c.workspace_x_range = env_cfg.TABLE.X_RANGE
+    c.workspace_y_range = env_cfg.TABLE.Y_RANGE
+    c.steps_check = env_cfg.SIM.STEPS_CHECK
+    c.max_phase_steps = env_cfg.SIM.MAX_PHASE_STEPS
+    c.max_motion_steps = env_cfg.SIM.MAX_MOTION_STEPS
+    c.max_offstage_steps = env_cfg.SIM.MAX_OFFSTAGE_STEPS
+    c.num_goal_steps = int(env_cfg.NUM_GOAL_STEPS or 0)
+    assert c.num_goal_steps <= abi.RV_MAXG
+    c.max_steps = int(env_cfg.MAX_STEPS or 0)
+    c.success_thresh = env_cfg.SUCCESS_THRESH
+    c.num_points = env_cfg.OBS.NUM_POINTS
+    abi.assign(c.camera_pos, env_cfg.KINECT2.DEPTH.TRANSLATION)
+    return c
+
+
+def _rng(v):
+    if isinstance(v, (int, float)):
+        return [float(v), float(v)]
+    return [float(v[0]), float(v[1])]

@@ -1,0 +1,388 @@
+// rv_dev_collide.h — GJK / EPA narrow phase and persistent 4-point contact
+// manifolds for the CDNA4 env kernel.
+//
+// One lane owns one manifold slot and runs the convex queries of its pair(s);
+// the simplex lives in registers (all array indices are compile-time after
+// unrolling), hull vertices are read from the env's LDS block, the rarely
+// needed EPA polytope lives in an LDS workspace guarded by a wave-level lock.
+#pragma once
+#include "rv_dev_math.h"
+
+namespace rv {
+
+#define RV_GJK_MAX_ITERS 32
+#define RV_GJK_REL_TOL 1e-4f
+#define RV_EPA_MAX_VERTS 24
+#define RV_EPA_MAX_FACES 48
+#define RV_EPA_MAX_EDGES 32
+#define RV_EPA_MAX_ITERS 32
+#define RV_EPA_TOL 1e-6f
+
+struct Simplex {
+  v3 w[4], a[4], b[4];
+  float lam[4];
+  int n;
+};
+
+// EPA polytope workspace (LDS; aliased with the solver rows)
+struct EpaWork {
+  float W[RV_EPA_MAX_VERTS][3], VA[RV_EPA_MAX_VERTS][3], VB[RV_EPA_MAX_VERTS][3];
+  int fi[RV_EPA_MAX_FACES][3];
+  float fn[RV_EPA_MAX_FACES][3];
+  float fd[RV_EPA_MAX_FACES];
+  int alive[RV_EPA_MAX_FACES];
+  int ea[RV_EPA_MAX_EDGES], eb[RV_EPA_MAX_EDGES];
+};
+
+// persistent manifold (one per pair slot), 61 words
+struct DevMan {
+  int n;
+  int col[4];
+  float la[4][3], lb[4][3], nrm[4][3];
+  float dist[4], ln[4], lt1[4], lt2[4];
+};
+
+RV_DEV int support(const float* verts, int n, v3 d) {
+  int best = 0;
+  float bd = dot(ld3(verts), d);
+  for (int i = 1; i < n; ++i) {
+    float x = dot(ld3(verts + 3 * i), d);
+    if (x > bd) { bd = x; best = i; }
+  }
+  return best;
+}
+
+RV_DEV void closest_segment(v3 p0, v3 p1, float* l0, float* l1) {
+  v3 d = sub(p1, p0);
+  float dd = dot(d, d);
+  if (!(dd > 0.0f)) { *l0 = 0.0f; *l1 = 1.0f; return; }
+  float t = -dot(p0, d) / dd;
+  if (t <= 0.0f) { *l0 = 1.0f; *l1 = 0.0f; }
+  else if (t >= 1.0f) { *l0 = 0.0f; *l1 = 1.0f; }
+  else { *l0 = 1.0f - t; *l1 = t; }
+}
+
+RV_DEV void closest_triangle(v3 a, v3 b, v3 c, float* l0, float* l1, float* l2) {
+  v3 ab = sub(b, a), ac = sub(c, a);
+  float d1 = -dot(ab, a), d2 = -dot(ac, a);
+  if (d1 <= 0.0f && d2 <= 0.0f) { *l0 = 1.0f; *l1 = 0.0f; *l2 = 0.0f; return; }
+  float d3 = -dot(ab, b), d4 = -dot(ac, b);
+  if (d3 >= 0.0f && d4 <= d3) { *l0 = 0.0f; *l1 = 1.0f; *l2 = 0.0f; return; }
+  float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+    float v = d1 / (d1 - d3);
+    *l0 = 1.0f - v; *l1 = v; *l2 = 0.0f; return;
+  }
+  float d5 = -dot(ab, c), d6 = -dot(ac, c);
+  if (d6 >= 0.0f && d5 <= d6) { *l0 = 0.0f; *l1 = 0.0f; *l2 = 1.0f; return; }
+  float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+    float w = d2 / (d2 - d6);
+    *l0 = 1.0f - w; *l1 = 0.0f; *l2 = w; return;
+  }
+  float va = d3 * d6 - d5 * d4;
+  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+    float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    *l0 = 0.0f; *l1 = 1.0f - w; *l2 = w; return;
+  }
+  float s = va + vb + vc;
+  if (!(s > 0.0f)) {
+    // degenerate (collinear) triangle: best of the three edges
+    float best = -1.0f;
+    float r0 = 0.0f, r1 = 0.0f, r2 = 1.0f;
+    {
+      float e0, e1; closest_segment(a, b, &e0, &e1);
+      v3 p = mk(a.x * e0 + b.x * e1, a.y * e0 + b.y * e1, a.z * e0 + b.z * e1);
+      float dd = dot(p, p);
+      if (best < 0.0f || dd < best) { best = dd; r0 = e0; r1 = e1; r2 = 0.0f; }
+    }
+    {
+      float e0, e1; closest_segment(b, c, &e0, &e1);
+      v3 p = mk(b.x * e0 + c.x * e1, b.y * e0 + c.y * e1, b.z * e0 + c.z * e1);
+      float dd = dot(p, p);
+      if (best < 0.0f || dd < best) { best = dd; r0 = 0.0f; r1 = e0; r2 = e1; }
+    }
+    {
+      float e0, e1; closest_segment(c, a, &e0, &e1);
+      v3 p = mk(c.x * e0 + a.x * e1, c.y * e0 + a.y * e1, c.z * e0 + a.z * e1);
+      float dd = dot(p, p);
+      if (best < 0.0f || dd < best) { best = dd; r0 = e1; r1 = 0.0f; r2 = e0; }
+    }
+    *l0 = r0; *l1 = r1; *l2 = r2;
+    return;
+  }
+  float denom = 1.0f / s;
+  float v = vb * denom, w = vc * denom;
+  *l0 = 1.0f - v - w; *l1 = v; *l2 = w;
+}
+
+// returns 1 when a tetrahedron encloses the origin
+RV_DEV int simplex_solve(Simplex& s, v3* vout) {
+  float l[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (s.n == 1) {
+    l[0] = 1.0f;
+  } else if (s.n == 2) {
+    closest_segment(s.w[0], s.w[1], &l[0], &l[1]);
+  } else if (s.n == 3) {
+    closest_triangle(s.w[0], s.w[1], s.w[2], &l[0], &l[1], &l[2]);
+  } else {
+    const int F[4][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 3, 1}, {1, 2, 3, 0}};
+    int any_outside = 0;
+    float best = -1.0f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      v3 p = s.w[F[f][0]], q = s.w[F[f][1]], r = s.w[F[f][2]], o = s.w[F[f][3]];
+      v3 nrm = cross(sub(q, p), sub(r, p));
+      float sp = dot(nrm, sub(o, p));
+      float so = -dot(nrm, p);
+      if (!(sp * so > 0.0f)) {
+        any_outside = 1;
+        float f0, f1, f2;
+        closest_triangle(p, q, r, &f0, &f1, &f2);
+        v3 c = mk(p.x * f0 + q.x * f1 + r.x * f2, p.y * f0 + q.y * f1 + r.y * f2, p.z * f0 + q.z * f1 + r.z * f2);
+        float dd = dot(c, c);
+        if (best < 0.0f || dd < best) {
+          best = dd;
+          l[0] = l[1] = l[2] = l[3] = 0.0f;
+          l[F[f][0]] = f0; l[F[f][1]] = f1; l[F[f][2]] = f2;
+        }
+      }
+    }
+    if (!any_outside) return 1;
+  }
+  int m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < s.n && l[i] > 0.0f) {
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        if (j == m) { s.w[j] = s.w[i]; s.a[j] = s.a[i]; s.b[j] = s.b[i]; s.lam[j] = l[i]; }
+      }
+      ++m;
+    }
+  }
+  s.n = m;
+  v3 v = mk(0.0f, 0.0f, 0.0f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (i < m) v = madd(v, s.w[i], s.lam[i]);
+  *vout = v;
+  return 0;
+}
+
+// EPA on an origin-enclosing tetrahedron; polytope in the LDS workspace E.
+RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const Simplex& s, EpaWork& E,
+                         v3* out_nf, float* out_depth, v3* pa, v3* pb) {
+  int nv = 4, nf = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { st3(E.W[i], s.w[i]); st3(E.VA[i], s.a[i]); st3(E.VB[i], s.b[i]); }
+  const int F[4][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 3, 1}, {1, 2, 3, 0}};
+  for (int f = 0; f < 4; ++f) {
+    int i = F[f][0], j = F[f][1], k = F[f][2], o = F[f][3];
+    v3 wi = ld3(E.W[i]);
+    v3 n = cross(sub(ld3(E.W[j]), wi), sub(ld3(E.W[k]), wi));
+    if (dot(n, sub(ld3(E.W[o]), wi)) > 0.0f) { int t = j; j = k; k = t; n = scale(n, -1.0f); }
+    float ln = len(n);
+    if (!(ln > 0.0f)) ln = 1.0f;
+    n = scale(n, 1.0f / ln);
+    E.fi[nf][0] = i; E.fi[nf][1] = j; E.fi[nf][2] = k; st3(E.fn[nf], n); E.fd[nf] = dot(n, wi); E.alive[nf] = 1; ++nf;
+  }
+  int bestf = 0;
+  for (int it = 0; it < RV_EPA_MAX_ITERS; ++it) {
+    bestf = -1;
+    for (int f = 0; f < nf; ++f) if (E.alive[f] && (bestf < 0 || E.fd[f] < E.fd[bestf])) bestf = f;
+    v3 fnb = ld3(E.fn[bestf]);
+    int ia = support(A, nA, fnb);
+    int ib = support(B, nB, scale(fnb, -1.0f));
+    v3 va = ld3(A + 3 * ia), vb = ld3(B + 3 * ib);
+    v3 w = sub(va, vb);
+    if (dot(fnb, w) - E.fd[bestf] < RV_EPA_TOL || nv >= RV_EPA_MAX_VERTS) break;
+    int en = 0;
+    for (int f = 0; f < nf; ++f) {
+      if (!E.alive[f]) continue;
+      v3 d = sub(w, ld3(E.W[E.fi[f][0]]));
+      if (dot(ld3(E.fn[f]), d) > 0.0f) {
+        E.alive[f] = 0;
+        for (int e = 0; e < 3; ++e) {
+          int p = E.fi[f][e], q = E.fi[f][(e + 1) % 3];
+          int found = -1;
+          for (int x = 0; x < en; ++x) if (E.ea[x] == q && E.eb[x] == p) { found = x; break; }
+          if (found >= 0) { E.ea[found] = E.ea[en - 1]; E.eb[found] = E.eb[en - 1]; --en; }
+          else if (en < RV_EPA_MAX_EDGES) { E.ea[en] = p; E.eb[en] = q; ++en; }
+        }
+      }
+    }
+    if (en == 0) break;
+    st3(E.W[nv], w); st3(E.VA[nv], va); st3(E.VB[nv], vb);
+    int overflow = 0;
+    for (int x = 0; x < en; ++x) {
+      int slot = -1;
+      for (int f = 0; f < nf; ++f) if (!E.alive[f]) { slot = f; break; }
+      if (slot < 0) { if (nf < RV_EPA_MAX_FACES) slot = nf++; else { overflow = 1; break; } }
+      int i = E.ea[x], j = E.eb[x], k = nv;
+      v3 wi = ld3(E.W[i]);
+      v3 n = cross(sub(ld3(E.W[j]), wi), sub(ld3(E.W[k]), wi));
+      float ln = len(n);
+      if (!(ln > 0.0f)) ln = 1.0f;
+      n = scale(n, 1.0f / ln);
+      float d = dot(n, wi);
+      if (d < 0.0f) { int t = i; i = j; j = t; n = scale(n, -1.0f); d = -d; }
+      E.fi[slot][0] = i; E.fi[slot][1] = j; E.fi[slot][2] = k; st3(E.fn[slot], n); E.fd[slot] = d; E.alive[slot] = 1;
+    }
+    ++nv;
+    if (overflow) break;
+  }
+  bestf = -1;
+  for (int f = 0; f < nf; ++f) if (E.alive[f] && (bestf < 0 || E.fd[f] < E.fd[bestf])) bestf = f;
+  v3 fnb = ld3(E.fn[bestf]);
+  v3 c = scale(fnb, E.fd[bestf]);
+  int i0 = E.fi[bestf][0], i1 = E.fi[bestf][1], i2 = E.fi[bestf][2];
+  float l0, l1, l2;
+  closest_triangle(sub(ld3(E.W[i0]), c), sub(ld3(E.W[i1]), c), sub(ld3(E.W[i2]), c), &l0, &l1, &l2);
+  *pa = mk(E.VA[i0][0] * l0 + E.VA[i1][0] * l1 + E.VA[i2][0] * l2,
+           E.VA[i0][1] * l0 + E.VA[i1][1] * l1 + E.VA[i2][1] * l2,
+           E.VA[i0][2] * l0 + E.VA[i1][2] * l1 + E.VA[i2][2] * l2);
+  *pb = mk(E.VB[i0][0] * l0 + E.VB[i1][0] * l1 + E.VB[i2][0] * l2,
+           E.VB[i0][1] * l0 + E.VB[i1][1] * l1 + E.VB[i2][1] * l2,
+           E.VB[i0][2] * l0 + E.VB[i1][2] * l1 + E.VB[i2][2] * l2);
+  *out_nf = fnb;
+  *out_depth = E.fd[bestf];
+}
+
+// wave-level lock around the shared EPA workspace
+RV_DEV void epa_locked(const float* A, int nA, const float* B, int nB, const Simplex& s, EpaWork& E, int* lock,
+                       v3* out_nf, float* out_depth, v3* pa, v3* pb) {
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+  bool done = false;
+  while (!done) {
+    if (atomicCAS(lock, 0, 1) == 0) {
+      epa(A, nA, B, nB, s, E, out_nf, out_depth, pa, pb);
+      __threadfence_block();
+      atomicExch(lock, 0);
+      done = true;
+    }
+  }
+#else
+  (void)lock;
+  epa(A, nA, B, nB, s, E, out_nf, out_depth, pa, pb);
+#endif
+}
+
+// GJK distance with EPA fallback.  Returns 0 when farther apart than max_dist.
+RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, float max_dist,
+                   EpaWork& E, int* lock, v3* n, float* dist, v3* pa, v3* pb) {
+  Simplex s; s.n = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s.w[i] = mk(0, 0, 0); s.a[i] = mk(0, 0, 0); s.b[i] = mk(0, 0, 0); s.lam[i] = 0.0f; }
+  v3 v = guess;
+  if (!(dot(v, v) > 1e-12f)) v = mk(1.0f, 0.0f, 0.0f);
+  int have_v = 0, penetrating = 0;
+  for (int it = 0; it < RV_GJK_MAX_ITERS; ++it) {
+    int ia = support(A, nA, scale(v, -1.0f));
+    int ib = support(B, nB, v);
+    v3 va = ld3(A + 3 * ia), vb = ld3(B + 3 * ib);
+    v3 w = sub(va, vb);
+    float vv = dot(v, v), vw = dot(v, w);
+    if (vw > 0.0f && vw * vw > max_dist * max_dist * vv) return 0;
+    int dup = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < s.n && s.w[k].x == w.x && s.w[k].y == w.y && s.w[k].z == w.z) dup = 1;
+    if (dup) break;
+    if (have_v && vv - vw <= RV_GJK_REL_TOL * vv) break;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k == s.n) { s.w[k] = w; s.a[k] = va; s.b[k] = vb; }
+    s.n++;
+    if (simplex_solve(s, &v)) { penetrating = 1; break; }
+    have_v = 1;
+    if (!(dot(v, v) > 1e-14f)) { penetrating = 2; break; }
+  }
+  if (penetrating == 1) {
+    v3 nf; float depth;
+    epa_locked(A, nA, B, nB, s, E, lock, &nf, &depth, pa, pb);
+    *n = scale(nf, -1.0f);
+    *dist = -depth;
+    return 1;
+  }
+  v3 qa = mk(0, 0, 0), qb = mk(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (i < s.n) { qa = madd(qa, s.a[i], s.lam[i]); qb = madd(qb, s.b[i], s.lam[i]); }
+  *pa = qa; *pb = qb;
+  if (penetrating == 2) {
+    v3 g = guess;
+    float gl = len(g);
+    if (!(gl > 1e-6f)) { g = mk(0.0f, 0.0f, 1.0f); gl = 1.0f; }
+    *n = scale(g, 1.0f / gl);
+    *dist = 0.0f;
+    return 1;
+  }
+  float d = len(v);
+  if (d > max_dist) return 0;
+  *n = scale(v, 1.0f / d);
+  *dist = d;
+  return 1;
+}
+
+// ---------------------------------------------------------------- manifold
+RV_DEV void man_remove(DevMan& m, int i) {
+  int last = m.n - 1;
+  if (i != last) {
+    for (int k = 0; k < 3; ++k) { m.la[i][k] = m.la[last][k]; m.lb[i][k] = m.lb[last][k]; m.nrm[i][k] = m.nrm[last][k]; }
+    m.dist[i] = m.dist[last]; m.ln[i] = m.ln[last]; m.lt1[i] = m.lt1[last]; m.lt2[i] = m.lt2[last];
+    m.col[i] = m.col[last];
+  }
+  m.n = last;
+}
+
+RV_DEV float area4(v3 p0, v3 p1, v3 p2, v3 p3) {
+  v3 c0 = cross(sub(p0, p1), sub(p2, p3));
+  v3 c1 = cross(sub(p0, p2), sub(p1, p3));
+  v3 c2 = cross(sub(p0, p3), sub(p1, p2));
+  return fmaxr(fmaxr(dot(c0, c0), dot(c1, c1)), dot(c2, c2));
+}
+
+RV_DEV void man_add(DevMan& m, v3 la, v3 lb, v3 nrm, float dist, int col, float breaking) {
+  int slot = -1;
+  float best = breaking * breaking;
+  for (int i = 0; i < m.n; ++i) {
+    v3 d = sub(ld3(m.la[i]), la);
+    float dd = dot(d, d);
+    if (dd < best && m.col[i] == col) { best = dd; slot = i; }
+  }
+  int keep_impulse = 0;
+  if (slot >= 0) {
+    keep_impulse = 1;
+  } else if (m.n < 4) {
+    slot = m.n; m.n = m.n + 1;
+  } else {
+    int deepest = -1; float dmin = dist;
+    for (int i = 0; i < 4; ++i) if (m.dist[i] < dmin) { dmin = m.dist[i]; deepest = i; }
+    v3 q0 = ld3(m.la[0]), q1 = ld3(m.la[1]), q2 = ld3(m.la[2]), q3 = ld3(m.la[3]);
+    float r0 = (deepest == 0) ? -1.0f : area4(la, q1, q2, q3);
+    float r1 = (deepest == 1) ? -1.0f : area4(la, q0, q2, q3);
+    float r2 = (deepest == 2) ? -1.0f : area4(la, q0, q1, q3);
+    float r3 = (deepest == 3) ? -1.0f : area4(la, q0, q1, q2);
+    slot = 0; float rb = r0;
+    if (r1 > rb) { rb = r1; slot = 1; }
+    if (r2 > rb) { rb = r2; slot = 2; }
+    if (r3 > rb) { rb = r3; slot = 3; }
+  }
+  st3(m.la[slot], la); st3(m.lb[slot], lb); st3(m.nrm[slot], nrm);
+  m.dist[slot] = dist; m.col[slot] = col;
+  if (!keep_impulse) { m.ln[slot] = 0.0f; m.lt1[slot] = 0.0f; m.lt2[slot] = 0.0f; }
+}
+
+RV_DEV void plane_space(v3 n, v3* t1, v3* t2) {
+  if (fabsr(n.z) > 0.7071067811865476f) {
+    float a = n.y * n.y + n.z * n.z;
+    float k = 1.0f / fsqrtr(a);
+    *t1 = mk(0.0f, -n.z * k, n.y * k);
+    *t2 = mk(a * k, -n.x * t1->z, n.x * t1->y);
+  } else {
+    float a = n.x * n.x + n.y * n.y;
+    float k = 1.0f / fsqrtr(a);
+    *t1 = mk(-n.y * k, n.x * k, 0.0f);
+    *t2 = mk(-n.z * t1->y, n.z * t1->x, a * k);
+  }
+}
+
+}  // namespace rv

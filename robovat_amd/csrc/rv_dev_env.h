@@ -1,0 +1,1271 @@
+// rv_dev_env.h — the per-env simulation program of the MI355X backend.
+//
+// Execution model: ONE wave64 owns ONE env for the whole
+// launch.  The env's persistent state (`DevEnv`, ~5 KB) is copied from its
+// contiguous HBM block into LDS once, every substep of the macro action runs
+// out of LDS / registers, and the block is written back once at the end.  The
+// program is written as a sequence of *lane phases*: inside a phase each of
+// the 64 lanes works on its own item (a body, a manifold, a contact point, a
+// hull vertex ...) and only reads data produced by earlier phases; phases are
+// separated by a workgroup barrier (a workgroup is exactly one wave, so the
+// barrier is an LDS wait).  With -DRV_EMULATE the same source compiles as
+// host C++ where a phase is a loop over 64 lanes (tests/emu, debugging aid).
+//
+// Reference behaviour restated here (file:line in StanfordVL/robovat):
+//   Simulator.step                      robovat/simulation/simulator.py:94-103
+//   Simulator.wait_until_stable         robovat/simulation/simulator.py:325-376
+//   ControllableBody.update & friends   robovat/simulation/controllable_body.py:387-595
+//   SawyerSim.move_to_* / grip          robovat/robots/sawyer/sawyer_sim.py:186-408
+//   PushEnv._execute_action & checks    robovat/envs/push/push_env.py:631-937
+//   PushEnv._load_movable_bodies        robovat/envs/push/push_env.py:399-597
+//   RobotEnv.reset / step               robovat/envs/robot_env.py:204-275
+//   push_reward.get_reward_fn           robovat/reward_fns/push_reward.py:272-374
+#pragma once
+#include "../../include/rovat.h"
+#include "rv_dev_collide.h"
+
+namespace rv {
+
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#define RV_LANES_BEGIN { const int lane = (int)threadIdx.x;
+#define RV_LANES_END } __syncthreads();
+#else
+#define RV_LANES_BEGIN for (int lane = 0; lane < 64; ++lane) {
+#define RV_LANES_END }
+#endif
+
+#define RV_STREAM_RESET  1u
+#define RV_STREAM_RANDOM 2u
+#define RV_STREAM_HEUR   3u
+#define RV_STEPS_TO_CHECK_DONE 100   // controllable_body.py:21
+#define RV_STEPS_TO_UPDATE_IK  10    // controllable_body.py:24
+
+#define RV_TIDX(b) (b)
+#define RV_BBIDX(k) (RV_MAXB + (k))
+#define RV_AIDX(b) (RV_MAXB + RV_NBB + (b))
+
+// JointTarget / LinkTarget (controllable_body.py:28-233)
+struct JTarget {
+  int active, n_idx, has_vel, has_stop;
+  int idx[RV_NJ];
+  float pos[RV_NJ];
+  float start_t, stop_t, pos_thr, vel_thr;
+};
+struct LTarget {
+  int active, has_pose, nq, has_stop;
+  float pose[7];
+  float queue[RV_MAXQ][7];
+  float start_t, stop_t, pos_thr, vel_thr;
+};
+
+// Persistent per-env state: one contiguous block in HBM, staged in LDS.
+struct DevEnv {
+  float body[RV_MAXB][RV_BODY_STRIDE];
+  int active[RV_MAXB], frozen[RV_MAXB], shape[RV_MAXB];
+  float scale[RV_MAXB], mass[RV_MAXB], inv_mass[RV_MAXB], inv_inertia[RV_MAXB][3], friction[RV_MAXB], radius[RV_MAXB];
+  float table_z;
+  int n_bodies;
+  int arm_enabled;
+  float q[RV_NJ], qd[RV_NJ];
+  int motor_on[RV_NJ];
+  float motor_q[RV_NJ], motor_kp[RV_NJ], motor_kd[RV_NJ], vmax_cmd[RV_NJ];
+  JTarget jt;
+  LTarget lt;
+  float gripper_ready_time;
+  float fpos[RV_NFRAME][3], fquat[RV_NFRAME][4];
+  DevMan man[RV_NMAN];
+  int flag_arm_table, flag_arm_body[RV_MAXB];
+  int sim_steps, num_steps, num_episodes, done, phase, is_safe, is_effective, reset_count, substeps_last;
+  int stepped;      // this env executed an env.step() in the last macro launch
+  float episode_reward, last_reward;
+  float action[RV_MAXG][4];
+  float obs_pos[RV_MAXB][3], prev_obs_pos[RV_MAXB][3];
+  int num_total_steps, num_unsafe, num_ineffective, num_useful, num_successes;
+  int pad_[3];
+};
+
+// one solver row set per contact point (normal + two friction directions)
+struct Row {
+  float dir[3][3], rxa[3][3], rxb[3][3], aa[3][3], ab[3][3];
+  float invk[3], vbc[3];
+  float target, mu;
+};
+
+struct Scratch {
+  float frot[RV_NFRAME][9], fv[RV_NFRAME][3], fw[RV_NFRAME][3], axis[RV_NLIMB][3];
+  float colv[RV_NCOL][8][3], colc[RV_NCOL][3], colr[RV_NCOL];
+  int colflag[RV_NCOL];
+  float rot[RV_MAXB][9], iinv[RV_MAXB][9];
+  float wv[RV_MAXB][RV_MAXH][RV_MAXV][3];
+  float tablev[8][3];
+  union {
+    Row rows[RV_NMAN][4];
+    EpaWork epa;
+  } u;
+  int epa_lock;
+  // macro-step locals that must survive across phases
+  float wp[RV_MAXG][2][7];
+  float start_pos[RV_MAXB][3], start_yaw[RV_MAXB];
+  float poses[RV_MAXB][7];
+  int num_waypoints, interrupt, has_budget, max_phase_steps;
+  int loop_break, wus_steps, wus_stable, valid;
+  Rng rng;
+};
+
+struct Shared {
+  DevEnv e;
+  Scratch s;
+};
+
+struct Consts {
+  const rv_config* cfg;
+  const rv_scene* scene;
+};
+
+RV_DEV int bb_a(int k) { return k < 3 ? 0 : (k < 5 ? 1 : 2); }
+RV_DEV int bb_b(int k) { return k == 0 ? 1 : (k == 1 ? 2 : (k == 2 ? 3 : (k == 3 ? 2 : 3))); }
+// round-robin colouring: round r solves pairs {r, 5-r}, which touch disjoint bodies
+RV_DEV int bb_round_pair(int r, int x) { return x == 0 ? r : 5 - r; }
+
+RV_DEV float sim_time(const Shared& S, const Consts& K) { return K.cfg->dt * (float)S.e.sim_steps; }
+RV_DEV int body_on(const DevEnv& e, int b) { return e.active[b] && !e.frozen[b]; }
+
+// ------------------------------------------------------------------- arm --
+// FK of the limb for joint vector q (registers / LDS), frames 0..7
+struct LimbFK {
+  v3 pos[RV_NLIMB + 1];
+  q4 quat[RV_NLIMB + 1];
+  v3 axis[RV_NLIMB];
+};
+RV_DEV void fk_limb(const rv_arm* a, const float* q, LimbFK& F, float* frot_out /* [8][9] or null */) {
+  v3 pp = ld3(a->base_pos);
+  q4 pq = ldq(a->base_quat);
+  m3 prot = qmat(pq);
+#pragma unroll
+  for (int i = 0; i < RV_NLIMB; ++i) {
+    v3 po = add(pp, mulv(prot, ld3(a->jpos[i])));
+    q4 qo = qmul(pq, ldq(a->jquat[i]));
+    float s, c; sincosr(q[i] * 0.5f, &s, &c);
+    q4 qz; qz.x = 0.0f; qz.y = 0.0f; qz.z = s; qz.w = c;
+    q4 qf = qmul(qo, qz);
+    m3 r = qmat(qf);
+    F.pos[i] = po; F.quat[i] = qf;
+    F.axis[i] = mk(r.m[2], r.m[5], r.m[8]);
+    if (frot_out) stm(frot_out + 9 * i, r);
+    pp = po; pq = qf; prot = r;
+  }
+  F.pos[7] = add(pp, mulv(prot, ld3(a->jpos[7])));
+  F.quat[7] = qmul(pq, ldq(a->jquat[7]));
+  if (frot_out) stm(frot_out + 9 * 7, qmat(F.quat[7]));
+}
+
+// damped-least-squares IK (bullet_physics.py:1203-1262 call site), lane-serial
+RV_DEV_NOINLINE void arm_ik(const Consts& K, const float* q0, const float* pose, float* out) {
+  const rv_arm* a = &K.scene->arm;
+  const rv_config* c = K.cfg;
+  float q[RV_NLIMB];
+#pragma unroll
+  for (int i = 0; i < RV_NLIMB; ++i) q[i] = q0[i];
+  v3 tp = ld3(pose);
+  q4 tq = ldq(pose + 3);
+  for (int it = 0; it < c->ik_iters; ++it) {
+    LimbFK F;
+    fk_limb(a, q, F, nullptr);
+    float err[6];
+    v3 ep = sub(tp, F.pos[7]);
+    err[0] = ep.x; err[1] = ep.y; err[2] = ep.z;
+    q4 qc; qc.x = -F.quat[7].x; qc.y = -F.quat[7].y; qc.z = -F.quat[7].z; qc.w = F.quat[7].w;
+    q4 qe = qmul(tq, qc);
+    float sg = qe.w < 0.0f ? -2.0f : 2.0f;
+    err[3] = qe.x * sg; err[4] = qe.y * sg; err[5] = qe.z * sg;
+    float e2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) e2 += err[k] * err[k];
+    if (e2 < c->ik_residual * c->ik_residual) break;
+    float J[6][RV_NLIMB];
+#pragma unroll
+    for (int j = 0; j < RV_NLIMB; ++j) {
+      v3 cr = cross(F.axis[j], sub(F.pos[7], F.pos[j]));
+      J[0][j] = cr.x; J[1][j] = cr.y; J[2][j] = cr.z;
+      J[3][j] = F.axis[j].x; J[4][j] = F.axis[j].y; J[5][j] = F.axis[j].z;
+    }
+    float A[6][6];
+    float lam2 = c->ik_damping * c->ik_damping;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < RV_NLIMB; ++j) acc += J[r][j] * J[s][j];
+        A[r][s] = acc + (r == s ? lam2 : 0.0f);
+      }
+    float L[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int s = 0; s <= r; ++s) {
+        float acc = A[r][s];
+#pragma unroll
+        for (int k = 0; k < s; ++k) acc -= L[r][k] * L[s][k];
+        if (r == s) L[r][r] = fsqrtr(fmaxr(acc, 1e-12f));
+        else L[r][s] = acc / L[s][s];
+      }
+    float y[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float acc = err[r];
+#pragma unroll
+      for (int k = 0; k < r; ++k) acc -= L[r][k] * y[k];
+      y[r] = acc / L[r][r];
+    }
+#pragma unroll
+    for (int r = 5; r >= 0; --r) {
+      float acc = y[r];
+#pragma unroll
+      for (int k = r + 1; k < 6; ++k) acc -= L[k][r] * y[k];
+      y[r] = acc / L[r][r];
+    }
+    float dq[RV_NLIMB], mx = 0.0f;
+#pragma unroll
+    for (int j = 0; j < RV_NLIMB; ++j) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc += J[r][j] * y[r];
+      dq[j] = acc;
+      mx = fmaxr(mx, fabsr(acc));
+    }
+    float sc = mx > c->ik_max_step ? c->ik_max_step / mx : 1.0f;
+#pragma unroll
+    for (int j = 0; j < RV_NLIMB; ++j) q[j] = fclampr(q[j] + dq[j] * sc, a->q_lo[j], a->q_hi[j]);
+  }
+#pragma unroll
+  for (int i = 0; i < RV_NLIMB; ++i) out[i] = q[i];
+}
+
+// --------------------------------------------- ControllableBody restated --
+RV_DEV void jt_reset(JTarget& t) { t.active = 0; t.n_idx = 0; t.has_stop = 0; }
+RV_DEV void lt_reset(LTarget& t) { t.active = 0; t.has_pose = 0; t.nq = 0; t.has_stop = 0; }
+
+RV_DEV int check_joints_reached(const DevEnv& e) {
+  const JTarget& t = e.jt;
+  if (!t.active) return 1;
+  for (int i = 0; i < t.n_idx; ++i) {
+    int j = t.idx[i];
+    float dp = t.pos[i] - e.q[j];
+    int pr = fabsr(dp) < t.pos_thr;
+    int vr = 1;
+    if (t.has_vel) { float dv = 0.0f - e.qd[j]; vr = fabsr(dv) < t.vel_thr; }
+    if (!(pr && vr)) return 0;
+  }
+  return 1;
+}
+RV_DEV int check_link_target_done(const Shared& S, const Consts& K) {
+  const LTarget& t = S.e.lt;
+  if (!t.has_stop) return 1;
+  if (sim_time(S, K) >= t.stop_t) return 1;
+  if (!t.has_pose && t.nq == 0) return 1;
+  return 0;
+}
+RV_DEV int check_joint_target_done(const Shared& S, const Consts& K) {
+  const JTarget& t = S.e.jt;
+  if (!t.has_stop) return 1;
+  if (sim_time(S, K) >= t.stop_t) return 1;
+  if (check_joints_reached(S.e)) return 1;
+  return 0;
+}
+RV_DEV void lt_pop(LTarget& t) {
+  if (t.nq == 0) { lt_reset(t); return; }
+  for (int k = 0; k < 7; ++k) t.pose[k] = t.queue[0][k];
+  for (int i = 1; i < t.nq; ++i) for (int k = 0; k < 7; ++k) t.queue[i - 1][k] = t.queue[i][k];
+  t.nq--; t.has_pose = 1;
+}
+RV_DEV void arm_reset_targets(DevEnv& e) { lt_reset(e.lt); jt_reset(e.jt); }
+
+// ControllableBody.update (controllable_body.py:387-413), one lane
+RV_DEV void control_update(Shared& S, const Consts& K) {
+  DevEnv& e = S.e;
+  int ik_updated = 0;
+  if (e.lt.active) {
+    if (e.sim_steps % RV_STEPS_TO_CHECK_DONE == 0)
+      if (check_link_target_done(S, K)) lt_reset(e.lt);
+  }
+  if (e.lt.active) {
+    if (e.sim_steps % RV_STEPS_TO_UPDATE_IK == 0 || !e.jt.active) {
+      // _update_ik (controllable_body.py:468-499)
+      float qik[RV_NLIMB];
+      arm_ik(K, e.q, e.lt.pose, qik);
+      JTarget& t = e.jt;
+      t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = (e.lt.nq == 0);
+      for (int i = 0; i < RV_NLIMB; ++i) { t.idx[i] = i; t.pos[i] = qik[i]; }
+      t.start_t = e.lt.start_t; t.stop_t = e.lt.stop_t; t.has_stop = 1;
+      t.pos_thr = e.lt.pos_thr; t.vel_thr = e.lt.vel_thr;
+      ik_updated = 1;
+      if (check_joints_reached(e)) lt_pop(e.lt);
+    }
+  }
+  if (e.jt.active) {
+    if (e.sim_steps % RV_STEPS_TO_CHECK_DONE == 0 || ik_updated)
+      if (check_joint_target_done(S, K)) jt_reset(e.jt);
+  }
+  if (e.jt.active) {
+    // _update_position_control (controllable_body.py:458-466)
+    for (int i = 0; i < e.jt.n_idx; ++i) {
+      int j = e.jt.idx[i];
+      e.motor_on[j] = 1; e.motor_q[j] = e.jt.pos[i];
+      e.motor_kp[j] = K.cfg->kp; e.motor_kd[j] = K.cfg->kd;
+    }
+  }
+}
+// ControllableBody.is_ready(limb joints) (controllable_body.py:565-595)
+RV_DEV int arm_is_ready_limb(Shared& S, const Consts& K) {
+  DevEnv& e = S.e;
+  if (check_link_target_done(S, K)) lt_reset(e.lt);
+  if (check_joint_target_done(S, K)) jt_reset(e.jt);
+  if (e.lt.active) return 0;
+  if (e.jt.active) {
+    for (int i = 0; i < e.jt.n_idx; ++i) if (e.jt.idx[i] < RV_NLIMB) return 0;
+  }
+  return 1;
+}
+// SawyerSim.move_to_joint_positions (sawyer_sim.py:186-234)
+RV_DEV void robot_move_to_joint_positions(Shared& S, const Consts& K, const float* pos) {
+  DevEnv& e = S.e; const rv_config* c = K.cfg;
+  arm_reset_targets(e);
+  for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = c->limb_max_velocity_ratio * K.scene->arm.v_max[j];
+  JTarget& t = e.jt;
+  t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = 1;
+  for (int i = 0; i < RV_NLIMB; ++i) { t.idx[i] = i; t.pos[i] = pos[i]; }
+  t.start_t = sim_time(S, K); t.stop_t = t.start_t + c->limb_timeout; t.has_stop = 1;
+  t.pos_thr = c->limb_position_threshold; t.vel_thr = c->velocity_threshold;
+}
+// SawyerSim.move_to_gripper_pose, straight_line=False (sawyer_sim.py:236-308)
+RV_DEV void robot_move_to_gripper_pose(Shared& S, const Consts& K, const float* pose) {
+  DevEnv& e = S.e; const rv_config* c = K.cfg;
+  arm_reset_targets(e);
+  for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = c->limb_max_velocity_ratio * K.scene->arm.v_max[j];
+  LTarget& t = e.lt;
+  t.active = 1; t.has_pose = 1; t.nq = 0;
+  for (int k = 0; k < 7; ++k) t.pose[k] = pose[k];
+  t.start_t = sim_time(S, K); t.stop_t = t.start_t + c->limb_timeout; t.has_stop = 1;
+  t.pos_thr = c->limb_position_threshold; t.vel_thr = c->velocity_threshold;
+}
+// SawyerSim.grip (sawyer_sim.py:362-392)
+RV_DEV void robot_grip(Shared& S, const Consts& K, float value) {
+  DevEnv& e = S.e; const rv_arm* a = &K.scene->arm;
+  value = fclampr(value, 0.01f, 0.99f);
+  float lpos = a->q_hi[7] - value * (a->q_hi[7] - a->q_lo[7]);
+  float rpos = a->q_lo[8] + value * (a->q_hi[8] - a->q_lo[8]);
+  JTarget& t = e.jt;
+  t.active = 1; t.n_idx = 2; t.has_vel = 1;
+  t.idx[0] = 7; t.idx[1] = 8; t.pos[0] = lpos; t.pos[1] = rpos;
+  t.start_t = sim_time(S, K); t.stop_t = t.start_t + 10000.0f; t.has_stop = 1;
+  t.pos_thr = 0.008726640f; t.vel_thr = K.cfg->velocity_threshold;
+  e.gripper_ready_time = sim_time(S, K) + 0.5f;
+}
+
+// ---------------------------------------------------------- rigid bodies --
+RV_DEV void body_set_mass(DevEnv& e, const Consts& K, int b, float mass) {
+  const rv_shape* s = &K.scene->shapes[e.shape[b]];
+  e.mass[b] = mass; e.inv_mass[b] = 1.0f / mass;
+  float s2 = e.scale[b] * e.scale[b];
+  for (int k = 0; k < 3; ++k) e.inv_inertia[b][k] = 1.0f / (mass * s2 * s->inertia_k[k]);
+  e.radius[b] = s->radius * e.scale[b] + K.cfg->margin;
+}
+RV_DEV void table_prepare(Shared& S, const Consts& K, int k) {
+  const rv_config* c = K.cfg;
+  float mg = c->margin;
+  float hx = c->table_half[0] - mg, hy = c->table_half[1] - mg;
+  float ztop = S.e.table_z - mg, zbot = S.e.table_z - c->table_thickness + mg;
+  S.s.tablev[k][0] = c->table_center[0] + ((k & 1) ? hx : -hx);
+  S.s.tablev[k][1] = c->table_center[1] + ((k & 2) ? hy : -hy);
+  S.s.tablev[k][2] = (k & 4) ? ztop : zbot;
+}
+
+RV_DEV v3 to_local_body(const Shared& S, int b, v3 wp) { return tmulv(S.s.rot[b], sub(wp, ld3(S.e.body[b]))); }
+RV_DEV v3 to_world_body(const Shared& S, int b, v3 lp) { return add(ld3(S.e.body[b]), mulv(S.s.rot[b], lp)); }
+RV_DEV v3 to_local_frame(const Shared& S, int f, v3 wp) { return tmulv(S.s.frot[f], sub(wp, ld3(S.e.fpos[f]))); }
+RV_DEV v3 to_world_frame(const Shared& S, int f, v3 lp) { return add(ld3(S.e.fpos[f]), mulv(S.s.frot[f], lp)); }
+
+// kind: 0 body-table, 1 body-body, 2 arm-body
+RV_DEV void manifold_world_points(const Shared& S, const Consts& K, int kind, int a, int b, const DevMan& m, int i, v3* wa, v3* wb) {
+  *wa = to_world_body(S, a, ld3(m.la[i]));
+  if (kind == 0) *wb = ld3(m.lb[i]);
+  else if (kind == 1) *wb = to_world_body(S, b, ld3(m.lb[i]));
+  else *wb = to_world_frame(S, K.scene->arm.col_frame[m.col[i]], ld3(m.lb[i]));
+}
+RV_DEV void manifold_refresh(Shared& S, const Consts& K, int kind, int a, int b, DevMan& m) {
+  float brk = K.cfg->breaking;
+  for (int i = m.n - 1; i >= 0; --i) {
+    v3 wa, wb;
+    manifold_world_points(S, K, kind, a, b, m, i, &wa, &wb);
+    v3 nrm = ld3(m.nrm[i]);
+    float dist = dot(sub(wa, wb), nrm);
+    m.dist[i] = dist;
+    if (dist > brk) { man_remove(m, i); continue; }
+    v3 proj = madd(wa, nrm, -dist);
+    v3 dr = sub(wb, proj);
+    if (dot(dr, dr) > brk * brk) man_remove(m, i);
+  }
+}
+RV_DEV void manifold_add_world(Shared& S, const Consts& K, int kind, int a, int b, int col, DevMan& m, v3 wa, v3 wb, v3 n, float d) {
+  v3 la = to_local_body(S, a, wa), lb;
+  if (kind == 0) lb = wb;
+  else if (kind == 1) lb = to_local_body(S, b, wb);
+  else lb = to_local_frame(S, K.scene->arm.col_frame[col], wb);
+  man_add(m, la, lb, n, d, col, K.cfg->breaking);
+}
+
+#define RV_MAN_C 0.932327f
+#define RV_MAN_S 0.361615f
+#define RV_MAN_TAU 0.1f
+
+// narrow phase of one convex pair; m == nullptr: distance only
+RV_DEV int collide_pair(Shared& S, const Consts& K, int kind, int a, int b, int col,
+                        const float* A, int nA, const float* B, int nB, v3 guess, DevMan* m, float* out_dist) {
+  float mg = K.cfg->margin, brk = K.cfg->breaking;
+  v3 n, pa, pb; float dist;
+  if (!gjk_epa(A, nA, B, nB, guess, brk + 2.0f * mg, S.s.u.epa, &S.s.epa_lock, &n, &dist, &pa, &pb)) return 0;
+  float d = dist - 2.0f * mg;
+  if (d > brk) return 0;
+  *out_dist = d;
+  if (!m) return 1;
+  manifold_add_world(S, K, kind, a, b, col, *m, madd(pa, n, -mg), madd(pb, n, mg), n, d);
+  v3 t1, t2, dir[4];
+  float extA[4], extB[4];
+  plane_space(n, &t1, &t2);
+  dir[0] = mk(RV_MAN_C * t1.x + RV_MAN_S * t2.x, RV_MAN_C * t1.y + RV_MAN_S * t2.y, RV_MAN_C * t1.z + RV_MAN_S * t2.z);
+  dir[1] = mk(RV_MAN_C * t2.x - RV_MAN_S * t1.x, RV_MAN_C * t2.y - RV_MAN_S * t1.y, RV_MAN_C * t2.z - RV_MAN_S * t1.z);
+  dir[2] = mk(-dir[0].x, -dir[0].y, -dir[0].z);
+  dir[3] = mk(-dir[1].x, -dir[1].y, -dir[1].z);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    extA[j] = dot(ld3(A + 3 * support(A, nA, dir[j])), dir[j]) + mg;
+    extB[j] = dot(ld3(B + 3 * support(B, nB, dir[j])), dir[j]) + mg;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v3 sd = madd(dir[k], n, -1.0f / RV_MAN_TAU);
+    v3 va = ld3(A + 3 * support(A, nA, sd));
+    float sep = dot(sub(va, pb), n);
+    float gap = sep - 2.0f * mg;
+    if (gap <= brk) {
+      v3 pt = madd(va, n, -sep);
+      int ok = 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (dot(pt, dir[j]) > extB[j]) ok = 0;
+      if (ok) manifold_add_world(S, K, kind, a, b, col, *m, madd(va, n, -mg), madd(pt, n, mg), n, gap);
+    }
+    sd = madd(dir[k], n, 1.0f / RV_MAN_TAU);
+    v3 vb = ld3(B + 3 * support(B, nB, sd));
+    sep = dot(sub(pa, vb), n);
+    gap = sep - 2.0f * mg;
+    if (gap <= brk) {
+      v3 pt = madd(vb, n, sep);
+      int ok = 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (dot(pt, dir[j]) > extA[j]) ok = 0;
+      if (ok) manifold_add_world(S, K, kind, a, b, col, *m, madd(pt, n, -mg), madd(vb, n, mg), n, gap);
+    }
+  }
+  return 1;
+}
+
+RV_DEV float sphere_box_dist2(v3 p, v3 c, v3 h) {
+  float d2 = 0.0f;
+  float dx = fabsr(p.x - c.x) - h.x; if (dx > 0.0f) d2 += dx * dx;
+  float dy = fabsr(p.y - c.y) - h.y; if (dy > 0.0f) d2 += dy * dy;
+  float dz = fabsr(p.z - c.z) - h.z; if (dz > 0.0f) d2 += dz * dz;
+  return d2;
+}
+
+// ------------------------------------------------------------------ PGS --
+RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, const DevMan& m, int i, Row& r) {
+  const rv_config* c = K.cfg; const DevEnv& e = S.e;
+  float dt = c->dt;
+  v3 wa, wb;
+  manifold_world_points(S, K, kind, a, b, m, i, &wa, &wb);
+  v3 ra = sub(wa, ld3(e.body[a]));
+  v3 d0 = ld3(m.nrm[i]), d1, d2;
+  plane_space(d0, &d1, &d2);
+  v3 vb_pt = mk(0.0f, 0.0f, 0.0f);
+  v3 rb = mk(0.0f, 0.0f, 0.0f);
+  float imb = 0.0f;
+  if (kind == 1) { rb = sub(wb, ld3(e.body[b])); imb = e.inv_mass[b]; }
+  if (kind == 2) {
+    int f = K.scene->arm.col_frame[m.col[i]];
+    vb_pt = add(ld3(S.s.fv[f]), cross(ld3(S.s.fw[f]), sub(wb, ld3(e.fpos[f]))));
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    v3 dk = k == 0 ? d0 : (k == 1 ? d1 : d2);
+    v3 rxa = cross(ra, dk);
+    v3 aa = mulv(S.s.iinv[a], rxa);
+    float kk = e.inv_mass[a] + dot(rxa, aa);
+    v3 rxb = mk(0.0f, 0.0f, 0.0f), ab = mk(0.0f, 0.0f, 0.0f);
+    if (kind == 1) {
+      rxb = cross(rb, dk);
+      ab = mulv(S.s.iinv[b], rxb);
+      kk += imb + dot(rxb, ab);
+    }
+    st3(r.dir[k], dk); st3(r.rxa[k], rxa); st3(r.aa[k], aa); st3(r.rxb[k], rxb); st3(r.ab[k], ab);
+    r.invk[k] = 1.0f / kk;
+    r.vbc[k] = dot(dk, vb_pt);
+  }
+  float dist = m.dist[i];
+  if (dist > 0.0f) r.target = -dist / dt;
+  else r.target = fminr(c->erp * fmaxr(-dist - c->slop, 0.0f) / dt, c->max_pushout);
+  float mub = (kind == 0) ? c->table_friction : (kind == 1 ? e.friction[b] : c->arm_friction);
+  r.mu = e.friction[a] * mub;
+}
+
+// body velocity pair held in registers by the solving lane
+struct BV { v3 v, w; };
+RV_DEV BV ld_bv(const DevEnv& e, int b) { BV x; x.v = ld3(e.body[b] + 7); x.w = ld3(e.body[b] + 10); return x; }
+RV_DEV void st_bv(DevEnv& e, int b, const BV& x) { st3(e.body[b] + 7, x.v); st3(e.body[b] + 10, x.w); }
+
+RV_DEV void row_apply(BV& A, BV* B, float ima, float imb, const Row& r, int k, float dl) {
+  A.v = madd(A.v, ld3(r.dir[k]), dl * ima);
+  A.w = madd(A.w, ld3(r.aa[k]), dl);
+  if (B) {
+    B->v = madd(B->v, ld3(r.dir[k]), -dl * imb);
+    B->w = madd(B->w, ld3(r.ab[k]), -dl);
+  }
+}
+RV_DEV float row_jv(const BV& A, const BV* B, const Row& r, int k) {
+  float jv = dot(ld3(r.dir[k]), A.v) + dot(ld3(r.rxa[k]), A.w);
+  if (B) jv -= dot(ld3(r.dir[k]), B->v) + dot(ld3(r.rxb[k]), B->w);
+  else jv -= r.vbc[k];
+  return jv;
+}
+RV_DEV void point_solve(BV& A, BV* B, float ima, float imb, DevMan& m, int i, const Row& r) {
+  float jv = row_jv(A, B, r, 0);
+  float dl = (r.target - jv) * r.invk[0];
+  float ln = fmaxr(m.ln[i] + dl, 0.0f);
+  dl = ln - m.ln[i]; m.ln[i] = ln;
+  row_apply(A, B, ima, imb, r, 0, dl);
+  float lim = r.mu * ln;
+  jv = row_jv(A, B, r, 1);
+  dl = -jv * r.invk[1];
+  float l1 = fclampr(m.lt1[i] + dl, -lim, lim);
+  dl = l1 - m.lt1[i]; m.lt1[i] = l1;
+  row_apply(A, B, ima, imb, r, 1, dl);
+  jv = row_jv(A, B, r, 2);
+  dl = -jv * r.invk[2];
+  float l2 = fclampr(m.lt2[i] + dl, -lim, lim);
+  dl = l2 - m.lt2[i]; m.lt2[i] = l2;
+  row_apply(A, B, ima, imb, r, 2, dl);
+}
+
+// ---------------------------------------------------- Simulator.step -----
+// One dt of Simulator.step (simulator.py:94-103): the arm's
+// ControllableBody.update, then the physics step, then num_steps += 1.
+RV_DEV void sim_substep(Shared& S, const Consts& K) {
+  const rv_config* c = K.cfg;
+  const rv_arm* arm = &K.scene->arm;
+  const int arm_on = S.e.arm_enabled;
+
+  if (arm_on) {
+    RV_LANES_BEGIN
+      if (lane == 0) control_update(S, K);
+    RV_LANES_END
+    // joint motors of the kinematic arm
+    RV_LANES_BEGIN
+      if (lane < RV_NJ) {
+        DevEnv& e = S.e; int j = lane; float dt = c->dt;
+        float vd = 0.0f;
+        if (e.motor_on[j]) {
+          vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) / dt;
+          vd = fclampr(vd, -e.vmax_cmd[j], e.vmax_cmd[j]);
+        }
+        float dv = fclampr(vd - e.qd[j], -arm->a_max[j] * dt, arm->a_max[j] * dt);
+        float qd = e.qd[j] + dv;
+        float qn = e.q[j] + qd * dt;
+        if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
+        if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
+        e.q[j] = qn; e.qd[j] = qd;
+      }
+    RV_LANES_END
+    // forward kinematics + link twists (serial chain)
+    RV_LANES_BEGIN
+      if (lane == 0) {
+        DevEnv& e = S.e;
+        LimbFK F;
+        fk_limb(arm, e.q, F, &S.s.frot[0][0]);
+        v3 wprev = mk(0, 0, 0), vprev = mk(0, 0, 0), pprev = ld3(arm->base_pos);
+#pragma unroll
+        for (int i = 0; i < RV_NLIMB; ++i) {
+          st3(e.fpos[i], F.pos[i]); stq(e.fquat[i], F.quat[i]); st3(S.s.axis[i], F.axis[i]);
+          v3 fv = add(vprev, cross(wprev, sub(F.pos[i], pprev)));
+          v3 fw = madd(wprev, F.axis[i], e.qd[i]);
+          st3(S.s.fv[i], fv); st3(S.s.fw[i], fw);
+          wprev = fw; vprev = fv; pprev = F.pos[i];
+        }
+        st3(e.fpos[7], F.pos[7]); stq(e.fquat[7], F.quat[7]);
+        v3 v7 = add(vprev, cross(wprev, sub(F.pos[7], pprev)));
+        st3(S.s.fv[7], v7); st3(S.s.fw[7], wprev);
+        v3 yax = mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          int f = 8 + k;
+          float off = arm->finger_y0[k] + e.q[7 + k];
+          v3 pf = madd(F.pos[7], yax, off);
+          st3(e.fpos[f], pf); stq(e.fquat[f], F.quat[7]);
+          for (int x = 0; x < 9; ++x) S.s.frot[f][x] = S.s.frot[7][x];
+          v3 vf = add(v7, cross(wprev, sub(pf, F.pos[7])));
+          vf = madd(vf, yax, e.qd[7 + k]);
+          st3(S.s.fv[f], vf); st3(S.s.fw[f], wprev);
+        }
+      }
+    RV_LANES_END
+  }
+
+  // collider geometry + body velocity update + rotations
+  RV_LANES_BEGIN
+    if (arm_on) {
+      for (int item = lane; item < RV_NCOL * 8; item += 64) {
+        int col = item >> 3, k = item & 7;
+        int f = arm->col_frame[col];
+        v3 cc = ld3(arm->col_center[col]), hh = ld3(arm->col_half[col]);
+        v3 l = mk(cc.x + ((k & 1) ? hh.x : -hh.x), cc.y + ((k & 2) ? hh.y : -hh.y), cc.z + ((k & 4) ? hh.z : -hh.z));
+        st3(S.s.colv[col][k], add(ld3(S.e.fpos[f]), mulv(S.s.frot[f], l)));
+      }
+      if (lane < RV_NCOL) {
+        int col = lane; int f = arm->col_frame[col];
+        v3 cc = ld3(arm->col_center[col]), hh = ld3(arm->col_half[col]);
+        st3(S.s.colc[col], add(ld3(S.e.fpos[f]), mulv(S.s.frot[f], cc)));
+        S.s.colr[col] = fsqrtr(hh.x * hh.x + hh.y * hh.y + hh.z * hh.z) + c->margin;
+        S.s.colflag[col] = 0;
+      }
+    }
+    if (lane >= 16 && lane < 16 + RV_MAXB) {
+      int b = lane - 16; DevEnv& e = S.e;
+      if (body_on(e, b)) {
+        float dt = c->dt;
+        e.body[b][9] += c->gravity_z * dt;
+        v3 v = scale(ld3(e.body[b] + 7), c->lin_damp);
+        v3 w = scale(ld3(e.body[b] + 10), c->ang_damp);
+        st3(e.body[b] + 7, v); st3(e.body[b] + 10, w);
+        m3 m = qmat(ldq(e.body[b] + 3));
+        stm(S.s.rot[b], m);
+        const float* ii = e.inv_inertia[b];
+        for (int r = 0; r < 3; ++r)
+          for (int cc2 = 0; cc2 < 3; ++cc2)
+            S.s.iinv[b][r * 3 + cc2] = m.m[r * 3 + 0] * ii[0] * m.m[cc2 * 3 + 0] + m.m[r * 3 + 1] * ii[1] * m.m[cc2 * 3 + 1] + m.m[r * 3 + 2] * ii[2] * m.m[cc2 * 3 + 2];
+      }
+    }
+  RV_LANES_END
+
+  // hull vertices to world frame
+  RV_LANES_BEGIN
+    for (int item = lane; item < RV_MAXB * RV_MAXH * RV_MAXV; item += 64) {
+      int b = item / (RV_MAXH * RV_MAXV), h = (item / RV_MAXV) % RV_MAXH, i = item % RV_MAXV;
+      if (!body_on(S.e, b)) continue;
+      const rv_shape* s = &K.scene->shapes[S.e.shape[b]];
+      if (h >= s->n_hulls || i >= s->n_verts[h]) continue;
+      float sc = S.e.scale[b];
+      v3 l = mk(s->verts[h][i][0] * sc, s->verts[h][i][1] * sc, s->verts[h][i][2] * sc);
+      st3(S.s.wv[b][h][i], add(ld3(S.e.body[b]), mulv(S.s.rot[b], l)));
+    }
+  RV_LANES_END
+
+  // manifold refresh: one lane per manifold slot
+  RV_LANES_BEGIN
+    if (lane < RV_NMAN) {
+      DevEnv& e = S.e;
+      if (lane < RV_MAXB) {
+        int b = lane;
+        if (!body_on(e, b)) e.man[RV_TIDX(b)].n = 0;
+        else manifold_refresh(S, K, 0, b, -1, e.man[RV_TIDX(b)]);
+      } else if (lane < RV_MAXB + RV_NBB) {
+        int k = lane - RV_MAXB; int a = bb_a(k), b = bb_b(k);
+        if (!(body_on(e, a) && body_on(e, b))) e.man[RV_BBIDX(k)].n = 0;
+        else manifold_refresh(S, K, 1, a, b, e.man[RV_BBIDX(k)]);
+      } else {
+        int b = lane - RV_MAXB - RV_NBB;
+        if (!body_on(e, b) || !arm_on) e.man[RV_AIDX(b)].n = 0;
+        else manifold_refresh(S, K, 2, b, -1, e.man[RV_AIDX(b)]);
+      }
+    }
+    if (lane == 63) S.s.epa_lock = 0;
+  RV_LANES_END
+
+  // narrow phase: one lane per manifold owner (+ arm-table detection lanes)
+  RV_LANES_BEGIN
+    DevEnv& e = S.e;
+    float brk = c->breaking;
+    v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
+    v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
+    if (lane < RV_MAXB) {
+      int b = lane;
+      if (body_on(e, b)) {
+        float r = e.radius[b] + brk;
+        if (!(sphere_box_dist2(ld3(e.body[b]), tc, th) >= r * r)) {
+          const rv_shape* s = &K.scene->shapes[e.shape[b]];
+          v3 guess = mk(0.0f, 0.0f, e.body[b][2] - tc.z);
+          for (int h = 0; h < s->n_hulls; ++h) {
+            float d;
+            collide_pair(S, K, 0, b, -1, -1, &S.s.wv[b][h][0][0], s->n_verts[h], &S.s.tablev[0][0], 8, guess, &e.man[RV_TIDX(b)], &d);
+          }
+        }
+      }
+    } else if (lane < RV_MAXB + RV_NBB) {
+      int k = lane - RV_MAXB; int a = bb_a(k), b = bb_b(k);
+      if (body_on(e, a) && body_on(e, b)) {
+        v3 d = sub(ld3(e.body[a]), ld3(e.body[b]));
+        float r = e.radius[a] + e.radius[b] + brk;
+        if (!(dot(d, d) >= r * r)) {
+          const rv_shape* sa = &K.scene->shapes[e.shape[a]];
+          const rv_shape* sb = &K.scene->shapes[e.shape[b]];
+          for (int ha = 0; ha < sa->n_hulls; ++ha)
+            for (int hb = 0; hb < sb->n_hulls; ++hb) {
+              float dd;
+              collide_pair(S, K, 1, a, b, -1, &S.s.wv[a][ha][0][0], sa->n_verts[ha], &S.s.wv[b][hb][0][0], sb->n_verts[hb], d, &e.man[RV_BBIDX(k)], &dd);
+            }
+        }
+      }
+    } else if (lane < RV_NMAN) {
+      int b = lane - RV_MAXB - RV_NBB;
+      if (arm_on && body_on(e, b)) {
+        const rv_shape* s = &K.scene->shapes[e.shape[b]];
+        for (int col = 0; col < RV_NCOL; ++col) {
+          v3 d = sub(ld3(e.body[b]), ld3(S.s.colc[col]));
+          float r = e.radius[b] + S.s.colr[col] + brk;
+          if (dot(d, d) >= r * r) continue;
+          for (int h = 0; h < s->n_hulls; ++h) {
+            float dd;
+            collide_pair(S, K, 2, b, -1, col, &S.s.wv[b][h][0][0], s->n_verts[h], &S.s.colv[col][0][0], 8, d, &e.man[RV_AIDX(b)], &dd);
+          }
+        }
+      }
+    } else if (lane < RV_NMAN + RV_NCOL) {
+      // arm - table: detection only (push_env.py:839-855)
+      int col = lane - RV_NMAN;
+      if (arm_on) {
+        float r = S.s.colr[col] + brk;
+        if (sphere_box_dist2(ld3(S.s.colc[col]), tc, th) < r * r) {
+          float dd;
+          if (collide_pair(S, K, 0, 0, -1, col, &S.s.colv[col][0][0], 8, &S.s.tablev[0][0], 8, mk(0.0f, 0.0f, 1.0f), nullptr, &dd))
+            if (dd < c->contact_query_dist) S.s.colflag[col] = 1;
+        }
+      }
+    }
+  RV_LANES_END
+
+  // solver row setup (one lane per contact point) + contact flags
+  RV_LANES_BEGIN
+    DevEnv& e = S.e;
+    if (lane < RV_NMAN * 4) {
+      int mi = lane >> 2, i = lane & 3;
+      DevMan& m = e.man[mi];
+      if (i < m.n) {
+        int kind, a, b = -1;
+        if (mi < RV_MAXB) { kind = 0; a = mi; }
+        else if (mi < RV_MAXB + RV_NBB) { kind = 1; a = bb_a(mi - RV_MAXB); b = bb_b(mi - RV_MAXB); }
+        else { kind = 2; a = mi - RV_MAXB - RV_NBB; }
+        row_setup(S, K, kind, a, b, m, i, S.s.u.rows[mi][i]);
+        m.ln[i] *= c->warmstart; m.lt1[i] *= c->warmstart; m.lt2[i] *= c->warmstart;
+      }
+    } else if (lane == 56) {
+      int f = 0;
+      if (arm_on) for (int col = 0; col < RV_NCOL; ++col) f |= S.s.colflag[col];
+      e.flag_arm_table = f;
+    } else if (lane >= 57 && lane < 57 + RV_MAXB) {
+      int b = lane - 57; int f = 0;
+      if (arm_on) {
+        const DevMan& m = e.man[RV_AIDX(b)];
+        for (int i = 0; i < m.n; ++i) if (m.dist[i] < c->contact_query_dist) f = 1;
+      }
+      e.flag_arm_body[b] = f;
+    }
+  RV_LANES_END
+
+  // warm start (pass 0) and PGS iterations: body-vs-static/kinematic contacts
+  // are solved one lane per body; body-body contacts by colour rounds.
+  for (int it = -1; it < c->solver_iters; ++it) {
+    RV_LANES_BEGIN
+      if (lane < RV_MAXB) {
+        int b = lane; DevEnv& e = S.e;
+        DevMan& mt = e.man[RV_TIDX(b)];
+        DevMan& ma = e.man[RV_AIDX(b)];
+        if (mt.n + ma.n > 0) {
+          BV A = ld_bv(e, b); float ima = e.inv_mass[b];
+          for (int i = 0; i < mt.n; ++i) {
+            const Row& r = S.s.u.rows[RV_TIDX(b)][i];
+            if (it < 0) { row_apply(A, nullptr, ima, 0.0f, r, 0, mt.ln[i]); row_apply(A, nullptr, ima, 0.0f, r, 1, mt.lt1[i]); row_apply(A, nullptr, ima, 0.0f, r, 2, mt.lt2[i]); }
+            else point_solve(A, nullptr, ima, 0.0f, mt, i, r);
+          }
+          for (int i = 0; i < ma.n; ++i) {
+            const Row& r = S.s.u.rows[RV_AIDX(b)][i];
+            if (it < 0) { row_apply(A, nullptr, ima, 0.0f, r, 0, ma.ln[i]); row_apply(A, nullptr, ima, 0.0f, r, 1, ma.lt1[i]); row_apply(A, nullptr, ima, 0.0f, r, 2, ma.lt2[i]); }
+            else point_solve(A, nullptr, ima, 0.0f, ma, i, r);
+          }
+          st_bv(e, b, A);
+        }
+      }
+    RV_LANES_END
+    const int any_bb = S.e.man[RV_BBIDX(0)].n | S.e.man[RV_BBIDX(1)].n | S.e.man[RV_BBIDX(2)].n |
+                       S.e.man[RV_BBIDX(3)].n | S.e.man[RV_BBIDX(4)].n | S.e.man[RV_BBIDX(5)].n;
+    if (any_bb) {
+      for (int rd = 0; rd < 3; ++rd) {
+        RV_LANES_BEGIN
+          if (lane < 2) {
+            int k = bb_round_pair(rd, lane); DevEnv& e = S.e;
+            DevMan& m = e.man[RV_BBIDX(k)];
+            if (m.n > 0) {
+              int a = bb_a(k), b = bb_b(k);
+              BV A = ld_bv(e, a), B = ld_bv(e, b);
+              float ima = e.inv_mass[a], imb = e.inv_mass[b];
+              for (int i = 0; i < m.n; ++i) {
+                const Row& r = S.s.u.rows[RV_BBIDX(k)][i];
+                if (it < 0) { row_apply(A, &B, ima, imb, r, 0, m.ln[i]); row_apply(A, &B, ima, imb, r, 1, m.lt1[i]); row_apply(A, &B, ima, imb, r, 2, m.lt2[i]); }
+                else point_solve(A, &B, ima, imb, m, i, r);
+              }
+              st_bv(e, a, A); st_bv(e, b, B);
+            }
+          }
+        RV_LANES_END
+      }
+    }
+  }
+
+  // integrate positions, freeze fallen bodies, counters
+  RV_LANES_BEGIN
+    DevEnv& e = S.e;
+    if (lane < RV_MAXB) {
+      int b = lane;
+      if (body_on(e, b)) {
+        float dt = c->dt;
+        v3 v = ld3(e.body[b] + 7), w = ld3(e.body[b] + 10);
+        v3 p = madd(ld3(e.body[b]), v, dt);
+        st3(e.body[b], p);
+        q4 q = ldq(e.body[b] + 3);
+        q4 wq; wq.x = w.x; wq.y = w.y; wq.z = w.z; wq.w = 0.0f;
+        q4 dq = qmul(wq, q);
+        q.x += 0.5f * dt * dq.x; q.y += 0.5f * dt * dq.y; q.z += 0.5f * dt * dq.z; q.w += 0.5f * dt * dq.w;
+        q = qnormalize(q);
+        stq(e.body[b] + 3, q);
+        if (p.z < e.table_z - c->fall_depth) {
+          e.frozen[b] = 1;
+          st3(e.body[b] + 7, mk(0, 0, 0)); st3(e.body[b] + 10, mk(0, 0, 0));
+        }
+      }
+    }
+    if (lane == 32) { e.sim_steps++; e.substeps_last++; }
+  RV_LANES_END
+}
+
+// Simulator.check_stable over a body mask (simulator.py:289-323)
+RV_DEV int bodies_stable(const DevEnv& e, unsigned mask, float lin_thr, float ang_thr) {
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (!((mask >> b) & 1u) || !e.active[b]) continue;
+    float lv = len(ld3(e.body[b] + 7)), av = len(ld3(e.body[b] + 10));
+    if (lv >= lin_thr || av >= ang_thr) return 0;
+  }
+  return 1;
+}
+RV_DEV unsigned active_mask(const DevEnv& e) {
+  unsigned m = 0;
+  for (int b = 0; b < RV_MAXB; ++b) if (e.active[b]) m |= 1u << b;
+  return m;
+}
+// Simulator.wait_until_stable (simulator.py:325-376); mask == 0 => all active
+RV_DEV void wait_until_stable(Shared& S, const Consts& K, unsigned mask, float lin_thr, float ang_thr,
+                              int check_after, int min_stable, int max_steps) {
+  RV_LANES_BEGIN
+    if (lane == 0) { S.s.wus_steps = 0; S.s.wus_stable = 0; S.s.loop_break = 0; }
+  RV_LANES_END
+  for (;;) {
+    sim_substep(S, K);
+    RV_LANES_BEGIN
+      if (lane == 0) {
+        S.s.wus_steps++;
+        if (S.s.wus_steps >= check_after) {
+          unsigned mk_ = mask ? mask : active_mask(S.e);
+          if (bodies_stable(S.e, mk_, lin_thr, ang_thr)) S.s.wus_stable++;
+          if (S.s.wus_stable >= min_stable || S.s.wus_steps >= max_steps) S.s.loop_break = 1;
+        }
+      }
+    RV_LANES_END
+    if (S.s.loop_break) break;
+  }
+}
+
+// ------------------------------------------------- observation / reward --
+RV_DEV void compute_obs(DevEnv& e) {
+  for (int b = 0; b < RV_MAXB; ++b)
+    for (int k = 0; k < 3; ++k) {
+      e.prev_obs_pos[b][k] = e.obs_pos[b][k];
+      e.obs_pos[b][k] = e.active[b] ? e.body[b][k] : 0.0f;
+    }
+}
+RV_DEV int on_tiles(const float* xy, const float (*tiles)[2], int n, float size, const float* offset, float max_dist) {
+  for (int i = 0; i < n; ++i) {
+    float tx = offset[0] + tiles[i][0] * size;
+    float ty = offset[1] + tiles[i][1] * size;
+    if (fabsr(xy[0] - tx) <= 0.5f * max_dist && fabsr(xy[1] - ty) <= 0.5f * max_dist) return 1;
+  }
+  return 0;
+}
+RV_DEV float tile_dist(const float* xy, const float (*tiles)[2], int n, float size, const float* offset) {
+  float best = 1e30f;
+  for (int i = 0; i < n; ++i) {
+    float dx = xy[0] - (offset[0] + tiles[i][0] * size);
+    float dy = xy[1] - (offset[1] + tiles[i][1] * size);
+    float d = fsqrtr(dx * dx + dy * dy);
+    if (d < best) best = d;
+  }
+  return best;
+}
+RV_DEV float task_score(const rv_config* c, const float (*st)[3]) {
+  float size = c->tile_size;
+  if (c->task == RV_TASK_CLEARING) {
+    float d1 = 0.0f, d3 = 0.0f;
+    for (int b = 0; b < RV_MAXB; ++b) { d1 += fabsr(st[b][0] - 0.7f); d3 += fabsr(st[b][1] + 0.9f); }
+    d1 /= (float)RV_MAXB; d3 /= (float)RV_MAXB;
+    return -fminr(d1, d3);
+  }
+  return -tile_dist(st[0], c->goal, c->n_goal, size, c->tile_offset);
+}
+// get_reward_fn(...).reward_fn, is_planning=False (push_reward.py:302-372)
+RV_DEV void compute_reward(const DevEnv& e, const rv_config* c, float* reward, int* termination) {
+  if (c->task == RV_TASK_NONE) { *reward = 1.0f; *termination = 0; return; }
+  float size = c->tile_size;
+  int term = 0, goal = 0;
+  if (c->task == RV_TASK_CROSSING)
+    term = !on_tiles(e.obs_pos[0], c->region, c->n_region, size, c->tile_offset, size * 1.5f);
+  if (c->task == RV_TASK_CLEARING) {
+    goal = 1;
+    for (int b = 0; b < RV_MAXB; ++b)
+      if (on_tiles(e.obs_pos[b], c->region, c->n_region, size * 1.25f, c->tile_offset, size * 1.25f)) goal = 0;
+  } else {
+    goal = on_tiles(e.obs_pos[0], c->goal, c->n_goal, size, c->tile_offset, size);
+  }
+  goal = goal && !term;
+  float r = 0.0f;
+  r += 100.0f * (float)goal;
+  int penalty = term && !goal;
+  r += -100.0f * (float)penalty;
+  r += fabsr(task_score(c, e.obs_pos) - task_score(c, e.prev_obs_pos));
+  r += -1.0f;
+  *reward = r; *termination = term || goal;
+}
+
+// ---------------------------------------------------------------- PushEnv --
+RV_DEV void set_gripper_pose(float* pose, float x, float y, float z) {
+  pose[0] = x; pose[1] = y; pose[2] = z;
+  stq(pose + 3, euler_to_quat(RV_PI, 0.0f, 0.0f));
+}
+// PushEnv._compute_waypoints (push_env.py:752-786)
+RV_DEV void compute_waypoints(const rv_config* c, const float* action, float* start, float* end) {
+  float lo0 = c->cspace_low[0], hi0 = c->cspace_high[0];
+  float lo1 = c->cspace_low[1], hi1 = c->cspace_high[1];
+  float lo2 = c->cspace_low[2], hi2 = c->cspace_high[2];
+  float x = action[0] * (0.5f * (hi0 - lo0)) + 0.5f * (hi0 + lo0);
+  float y = action[1] * (0.5f * (hi1 - lo1)) + 0.5f * (hi1 + lo1);
+  float z = c->finger_tip_offset + 0.5f * (hi2 + lo2);
+  set_gripper_pose(start, x, y, z);
+  float ex = fclampr(x + action[2] * c->translation_x, lo0, hi0);
+  float ey = fclampr(y + action[3] * c->translation_y, lo1, hi1);
+  set_gripper_pose(end, ex, ey, z);
+}
+RV_DEV int arm_touches_movables(const DevEnv& e) {
+  for (int b = 0; b < RV_MAXB; ++b) if (e.active[b] && e.flag_arm_body[b]) return 1;
+  return 0;
+}
+// PushEnv._check_safety (push_env.py:857-898)
+RV_DEV int check_safety(const DevEnv& e, const rv_config* c, float start_z) {
+  if (e.phase == RV_PHASE_PRE) { if (arm_touches_movables(e)) return 0; }
+  if (e.phase == RV_PHASE_START) {
+    if (arm_touches_movables(e)) {
+      float dist = e.fpos[7][2] - start_z;
+      if (fabsr(dist) <= 0.01f) return 1;
+      return 0;
+    }
+  }
+  if (e.phase == RV_PHASE_DONE) {
+    if (arm_touches_movables(e)) return 0;
+    float lx = c->table_center[0] - 0.5f * c->workspace_x_range, hx = c->table_center[0] + 0.5f * c->workspace_x_range;
+    float ly = c->table_center[1] - 0.5f * c->workspace_y_range, hy = c->table_center[1] + 0.5f * c->workspace_y_range;
+    for (int b = 0; b < RV_MAXB; ++b) {
+      if (!e.active[b]) continue;
+      const float* p = e.body[b];
+      if (p[0] < lx || p[0] > hx || p[1] < ly || p[1] > hy) return 0;
+    }
+  }
+  return 1;
+}
+
+// one phase-machine tick of PushEnv._execute_action (push_env.py:662-720), lane 0
+RV_DEV void phase_tick(Shared& S, const Consts& K) {
+  DevEnv& e = S.e; Scratch& s = S.s; const rv_config* c = K.cfg;
+  float start_z = c->finger_tip_offset + 0.5f * (c->cspace_high[2] + c->cspace_low[2]);
+  int ready = 0;
+  if (s.interrupt) ready = 1;
+  else if (arm_is_ready_limb(S, K) && (sim_time(S, K) >= e.gripper_ready_time)) { arm_reset_targets(e); ready = 1; }
+  else if (!s.has_budget) ready = 1;
+  else if (e.sim_steps >= s.max_phase_steps) { arm_reset_targets(e); ready = 1; }
+  if (ready) {
+    int next;
+    if (s.interrupt && e.phase != RV_PHASE_POST && e.phase != RV_PHASE_OFFSTAGE) next = RV_PHASE_POST;
+    else if (c->num_goal_steps > 0 && e.phase == RV_PHASE_POST && s.num_waypoints < c->num_goal_steps) next = RV_PHASE_PRE;
+    else next = e.phase + 1;
+    e.phase = next;
+    s.has_budget = 1;
+    s.max_phase_steps = e.sim_steps;
+    if (next == RV_PHASE_MOTION) s.max_phase_steps += c->max_motion_steps;
+    else if (next == RV_PHASE_OFFSTAGE) s.max_phase_steps += c->max_offstage_steps;
+    else s.max_phase_steps += c->max_phase_steps;
+    if (next == RV_PHASE_PRE) {
+      float pose[7];
+      for (int k = 0; k < 7; ++k) pose[k] = s.wp[s.num_waypoints][0][k];
+      pose[2] = c->gripper_safe_height;
+      robot_move_to_gripper_pose(S, K, pose);
+    } else if (next == RV_PHASE_START) {
+      robot_move_to_gripper_pose(S, K, s.wp[s.num_waypoints][0]);
+    } else if (next == RV_PHASE_MOTION) {
+      robot_move_to_gripper_pose(S, K, s.wp[s.num_waypoints][1]);
+    } else if (next == RV_PHASE_POST) {
+      s.num_waypoints++;
+      float pose[7];
+      for (int k = 0; k < 3; ++k) pose[k] = e.fpos[7][k];
+      for (int k = 0; k < 4; ++k) pose[3 + k] = e.fquat[7][k];
+      pose[2] = c->gripper_safe_height;
+      robot_move_to_gripper_pose(S, K, pose);
+    } else if (next == RV_PHASE_OFFSTAGE) {
+      float off[RV_NLIMB];
+      for (int j = 0; j < RV_NLIMB; ++j) off[j] = c->offstage_positions[j];
+      robot_move_to_joint_positions(S, K, off);
+    }
+  }
+  s.interrupt = 0;
+  if (e.phase == RV_PHASE_MOTION && e.flag_arm_table) s.interrupt = 1;
+  if (!check_safety(e, c, start_z)) { s.interrupt = 1; e.is_safe = 0; }
+  if (s.interrupt && e.phase == RV_PHASE_DONE) e.done = 1;
+}
+
+// RobotEnv.step (robot_env.py:239-275) + PushEnv._execute_action
+// (push_env.py:631-733) + PushEnv.step bookkeeping (push_env.py:599-629)
+RV_DEV void env_step(Shared& S, const Consts& K) {
+  const rv_config* c = K.cfg;
+  RV_LANES_BEGIN
+    if (lane == 0) {
+      DevEnv& e = S.e; Scratch& s = S.s;
+      e.substeps_last = 0; e.stepped = 1;
+      int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
+      for (int g = 0; g < G; ++g) compute_waypoints(c, e.action[g], s.wp[g][0], s.wp[g][1]);
+      e.is_safe = 1; e.is_effective = 1;
+      e.phase = RV_PHASE_INITIAL;
+      s.num_waypoints = 0; s.interrupt = 0; s.has_budget = 0; s.max_phase_steps = 0;
+      for (int b = 0; b < RV_MAXB; ++b) {
+        for (int k = 0; k < 3; ++k) s.start_pos[b][k] = e.body[b][k];
+        s.start_yaw[b] = quat_yaw(ldq(e.body[b] + 3));
+      }
+    }
+  RV_LANES_END
+  while (S.e.phase != RV_PHASE_DONE) {
+    sim_substep(S, K);
+    if (S.e.sim_steps % c->steps_check != 0) continue;
+    RV_LANES_BEGIN
+      if (lane == 0) phase_tick(S, K);
+    RV_LANES_END
+  }
+  wait_until_stable(S, K, 0u, 0.005f, 0.005f, 100, 100, 2000);
+  RV_LANES_BEGIN
+    if (lane == 0) {
+      DevEnv& e = S.e; Scratch& s = S.s;
+      // _check_effectiveness (push_env.py:900-923)
+      float dpos = 0.0f, dang = 0.0f;
+      for (int b = 0; b < RV_MAXB; ++b) {
+        if (!e.active[b]) continue;
+        dpos += len(sub(ld3(e.body[b]), ld3(s.start_pos[b])));
+        float da = quat_yaw(ldq(e.body[b] + 3)) - s.start_yaw[b];
+        da = da + RV_PI;
+        da = da - 2.0f * RV_PI * ffloorr(da / (2.0f * RV_PI));
+        da = da - RV_PI;
+        dang += fabsr(da);
+      }
+      if (dpos <= c->min_delta_position && dang <= c->min_delta_angle) e.is_effective = 0;
+      e.num_total_steps++;
+      e.num_unsafe += !e.is_safe;
+      e.num_ineffective += !e.is_effective;
+      e.num_useful += (e.is_safe && e.is_effective);
+      e.num_steps++;
+      compute_obs(e);
+      float r; int term;
+      compute_reward(e, c, &r, &term);
+      e.last_reward = r;
+      e.episode_reward += r;
+      e.done = e.done || term;
+      if (c->max_steps > 0 && e.num_steps >= c->max_steps) e.done = 1;
+      if (e.done) {
+        e.num_episodes++;
+        if (r >= c->success_thresh) e.num_successes++;
+      }
+    }
+  RV_LANES_END
+}
+
+// --------------------------------------------------------------- reset ---
+// rejection sampling of one layout (push_env.py:473-597, intent version), lane 0
+RV_DEV void sample_poses(Shared& S, const Consts& K, int nb) {
+  const rv_config* c = K.cfg; DevEnv& e = S.e; Rng& g = S.s.rng;
+  for (;;) {
+    int ok = 1;
+    for (int i = 0; i < nb && ok; ++i) {
+      int placed = 0;
+      for (int att = 0; att <= 32 && !placed; ++att) {
+        float x, y, z, roll, pitch, yaw;
+        if (c->use_tiles) {
+          int use_t = (i == 0 && c->n_target > 0);
+          const float (*tiles)[2] = use_t ? c->target : c->obstacle;
+          int nt = use_t ? c->n_target : c->n_obstacle;
+          int tid = rng_randint(g, nt);
+          float cx = c->tile_offset[0] + tiles[tid][0] * c->tile_size;
+          float cy = c->tile_offset[1] + tiles[tid][1] * c->tile_size;
+          x = rng_uniform(g, cx - 0.5f * c->tile_size, cx + 0.5f * c->tile_size);
+          y = rng_uniform(g, cy - 0.5f * c->tile_size, cy + 0.5f * c->tile_size);
+          z = e.table_z + c->safe_drop_height;
+          roll = rng_uniform(g, -RV_PI, RV_PI);
+          pitch = rng_uniform(g, -0.5f * RV_PI, 0.5f * RV_PI);
+          yaw = rng_uniform(g, -RV_PI, RV_PI);
+        } else {
+          x = rng_uniform(g, c->pose_lo[0], c->pose_hi[0]);
+          y = rng_uniform(g, c->pose_lo[1], c->pose_hi[1]);
+          z = e.table_z + rng_uniform(g, c->pose_lo[2], c->pose_hi[2]);
+          roll = rng_uniform(g, c->pose_lo[3], c->pose_hi[3]);
+          pitch = rng_uniform(g, c->pose_lo[4], c->pose_hi[4]);
+          yaw = rng_uniform(g, c->pose_lo[5], c->pose_hi[5]);
+        }
+        int valid = 1;
+        for (int j = 0; j < i; ++j) {
+          float dx = x - S.s.poses[j][0], dy = y - S.s.poses[j][1];
+          if (fsqrtr(dx * dx + dy * dy) < c->margin_xy) { valid = 0; break; }
+        }
+        if (valid) {
+          S.s.poses[i][0] = x; S.s.poses[i][1] = y; S.s.poses[i][2] = z;
+          stq(S.s.poses[i] + 3, euler_to_quat(roll, pitch, yaw));
+          placed = 1;
+        }
+      }
+      if (!placed) ok = 0;
+    }
+    if (ok) return;
+  }
+}
+
+// RobotEnv.reset for one env (robot_env.py:204-237)
+RV_DEV void env_reset(Shared& S, const Consts& K, int gid) {
+  const rv_config* c = K.cfg;
+  RV_LANES_BEGIN
+    DevEnv& e = S.e;
+    if (lane == 0) {
+      S.s.rng = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RESET, (uint32_t)e.reset_count);
+      e.reset_count++;
+      e.substeps_last = 0; e.stepped = 0;
+      e.sim_steps = 0; e.num_steps = 0; e.episode_reward = 0.0f; e.last_reward = 0.0f;
+      e.done = 0; e.phase = RV_PHASE_INITIAL; e.is_safe = 1; e.is_effective = 1;
+      e.arm_enabled = 0;
+      e.flag_arm_table = 0;
+      for (int b = 0; b < RV_MAXB; ++b) e.flag_arm_body[b] = 0;
+      // ArmEnv._reset_scene (arm_env.py:78-99)
+      e.table_z = c->table_z + rng_uniform(S.s.rng, c->table_height_range[0], c->table_height_range[1]);
+      e.n_bodies = c->n_bodies_min + rng_randint(S.s.rng, c->n_bodies_max - c->n_bodies_min + 1);
+      S.s.valid = 0;
+    }
+    if (lane < RV_NMAN) e.man[lane].n = 0;
+  RV_LANES_END
+  RV_LANES_BEGIN
+    if (lane < 8) table_prepare(S, K, lane);
+  RV_LANES_END
+  // PushEnv._load_movable_bodies (push_env.py:399-471)
+  while (!S.s.valid) {
+    RV_LANES_BEGIN
+      DevEnv& e = S.e;
+      if (lane == 0) {
+        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; }
+        sample_poses(S, K, e.n_bodies);
+      }
+      if (lane >= 1 && lane <= RV_NMAN) e.man[lane - 1].n = 0;
+    RV_LANES_END
+    const int nb = S.e.n_bodies;
+    for (int i = 0; i < nb; ++i) {
+      RV_LANES_BEGIN
+        if (lane == 0) {
+          DevEnv& e = S.e; Rng& g = S.s.rng;
+          int use_target = (i == 0 && c->use_tiles && c->n_target > 0 && c->n_target_shapes > 0);
+          int shape = use_target ? c->target_shapes[rng_randint(g, c->n_target_shapes)]
+                                 : c->movable_shapes[rng_randint(g, c->n_movable_shapes)];
+          float sc = rng_uniform(g, c->scale_range[0], c->scale_range[1]);
+          e.active[i] = 1; e.frozen[i] = 0; e.shape[i] = shape; e.scale[i] = sc; e.friction[i] = c->drop_friction;
+          body_set_mass(e, K, i, c->drop_mass);
+          for (int k = 0; k < 3; ++k) e.body[i][k] = S.s.poses[i][k];
+          for (int k = 0; k < 4; ++k) e.body[i][3 + k] = S.s.poses[i][3 + k];
+          for (int k = 7; k < 13; ++k) e.body[i][k] = 0.0f;
+        }
+      RV_LANES_END
+      wait_until_stable(S, K, 1u << i, 0.1f, 0.1f, 100, 100, 500);
+      RV_LANES_BEGIN
+        if (lane == 0) {
+          DevEnv& e = S.e; Rng& g = S.s.rng;
+          float mass = rng_uniform(g, c->mass_range[0], c->mass_range[1]);
+          float fr = rng_uniform(g, c->friction_range[0], c->friction_range[1]);
+          body_set_mass(e, K, i, mass); e.friction[i] = fr;
+        }
+      RV_LANES_END
+    }
+    RV_LANES_BEGIN
+      if (lane == 0) {
+        int valid = 1;
+        for (int i = 0; i < nb; ++i) if (S.e.body[i][2] < S.e.table_z) valid = 0;
+        S.s.valid = valid;
+      }
+    RV_LANES_END
+  }
+  wait_until_stable(S, K, 0u, 0.005f, 0.005f, 100, 100, 2000);
+  // ArmEnv._reset_robot (arm_env.py:101-107) -> SawyerSim.reboot (sawyer_sim.py:86-171)
+  RV_LANES_BEGIN
+    if (lane == 0) {
+      DevEnv& e = S.e; const rv_arm* a = &K.scene->arm;
+      for (int j = 0; j < RV_NLIMB; ++j) { e.q[j] = c->neutral_positions[j]; e.qd[j] = 0.0f; }
+      e.q[7] = a->q_hi[7]; e.q[8] = a->q_lo[8]; e.qd[7] = 0.0f; e.qd[8] = 0.0f;
+      for (int j = 0; j < RV_NJ; ++j) { e.motor_on[j] = 0; e.motor_q[j] = e.q[j]; e.motor_kp[j] = c->kp; e.motor_kd[j] = c->kd; e.vmax_cmd[j] = a->v_max[j]; }
+      arm_reset_targets(e);
+      e.gripper_ready_time = 0.0f;
+      e.arm_enabled = 1;
+      if (c->open_gripper_when_reset) robot_grip(S, K, 0.0f);
+      float off[RV_NLIMB];
+      for (int j = 0; j < RV_NLIMB; ++j) off[j] = c->offstage_positions[j];
+      robot_move_to_joint_positions(S, K, off);
+      compute_obs(e);
+      for (int b = 0; b < RV_MAXB; ++b) for (int k = 0; k < 3; ++k) e.prev_obs_pos[b][k] = e.obs_pos[b][k];
+      // link frames of the rebooted arm, for getters before the first substep
+      LimbFK F;
+      fk_limb(a, e.q, F, &S.s.frot[0][0]);
+      for (int i = 0; i <= RV_NLIMB; ++i) { st3(e.fpos[i], F.pos[i]); stq(e.fquat[i], F.quat[i]); }
+      v3 yax = mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]);
+      for (int k = 0; k < 2; ++k) {
+        st3(e.fpos[8 + k], madd(F.pos[7], yax, a->finger_y0[k] + e.q[7 + k]));
+        stq(e.fquat[8 + k], F.quat[7]);
+      }
+    }
+  RV_LANES_END
+}
+
+// rebuild the per-launch caches that are not part of the persistent block
+RV_DEV void env_enter(Shared& S, const Consts& K) {
+  RV_LANES_BEGIN
+    if (lane < 8) table_prepare(S, K, lane);
+    if (lane >= 8 && lane < 8 + RV_NFRAME) {
+      int f = lane - 8;
+      stm(S.s.frot[f], qmat(ldq(S.e.fquat[f])));
+    }
+    if (lane >= 32 && lane < 32 + RV_MAXB) {
+      int b = lane - 32;
+      stm(S.s.rot[b], qmat(ldq(S.e.body[b] + 3)));
+    }
+    if (lane == 63) S.s.epa_lock = 0;
+  RV_LANES_END
+}
+
+}  // namespace rv

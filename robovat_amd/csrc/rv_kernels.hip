@@ -1,0 +1,491 @@
+// rv_kernels.hip — __global__ kernels and the C ABI of librovat_hip.so
+// (include/rovat.h).  gfx950 only; built with hipcc --offload-arch=gfx950.
+//
+// Kernel inventory:
+//   k_env<MODE>     one wave64 per env, the whole reset / macro step / n
+//                   substeps / settle loop out of LDS (rv_dev_env.h)
+//   k_*             small one-thread-per-env accessors behind the getters,
+//                   setters, observation, reward and policy entry points
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <new>
+
+#include "../../include/rovat.h"
+#include "rv_dev_env.h"
+
+using namespace rv;
+
+// ------------------------------------------------------------------ kernels
+enum { MODE_RESET = 0, MODE_MACRO = 1, MODE_SUB = 2, MODE_WAIT = 3 };
+
+struct EnvKernelArgs {
+  const rv_config* cfg;
+  const rv_scene* scene;
+  DevEnv* envs;
+  const uint8_t* mask;
+  int n_envs;
+  int n_substeps;
+  float lin_thr, ang_thr;
+  int check_after, min_stable, max_steps;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
+  __shared__ Shared S;
+  const int env = (int)blockIdx.x;
+  if (env >= args.n_envs) return;
+  Consts K; K.cfg = args.cfg; K.scene = args.scene;
+  DevEnv* g = args.envs + env;
+  const int lane = (int)threadIdx.x;
+  constexpr int W = (int)(sizeof(DevEnv) / 4);
+  bool skip = false;
+  if (MODE == MODE_RESET) skip = (args.mask != nullptr) && (args.mask[env] == 0);
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&S.e);
+    for (int i = lane; i < W; i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  if (MODE == MODE_MACRO) skip = (S.e.done != 0);
+  if (skip) {
+    if (lane == 0) { g->substeps_last = 0; g->stepped = 0; }
+    return;
+  }
+  if (MODE != MODE_RESET) env_enter(S, K);
+  if (MODE == MODE_RESET) {
+    env_reset(S, K, K.cfg->env_id_offset + env);
+  } else if (MODE == MODE_MACRO) {
+    env_step(S, K);
+  } else if (MODE == MODE_SUB) {
+    if (lane == 0) { S.e.substeps_last = 0; S.e.stepped = 0; }
+    __syncthreads();
+    for (int k = 0; k < args.n_substeps; ++k) sim_substep(S, K);
+  } else {
+    if (lane == 0) { S.e.substeps_last = 0; S.e.stepped = 0; }
+    __syncthreads();
+    wait_until_stable(S, K, 0u, args.lin_thr, args.ang_thr, args.check_after, args.min_stable, args.max_steps);
+  }
+  __syncthreads();
+  {
+    uint32_t* dst = reinterpret_cast<uint32_t*>(g);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.e);
+    for (int i = lane; i < W; i += 64) dst[i] = src[i];
+  }
+}
+
+#define ENV_THREAD() const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return; DevEnv& e = envs[i];
+
+__global__ void k_init(DevEnv* envs, int n) {
+  ENV_THREAD();
+  uint32_t* p = reinterpret_cast<uint32_t*>(&e);
+  for (int k = 0; k < (int)(sizeof(DevEnv) / 4); ++k) p[k] = 0u;
+  for (int b = 0; b < RV_MAXB; ++b) e.body[b][6] = 1.0f;
+  for (int f = 0; f < RV_NFRAME; ++f) e.fquat[f][3] = 1.0f;
+  e.done = 1;  // RobotEnv.__init__: self._done = True (robot_env.py:66)
+}
+__global__ void k_get_body_state(const DevEnv* envs, int n, float* out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  for (int b = 0; b < RV_MAXB; ++b) for (int k = 0; k < 13; ++k) out[((size_t)i * RV_MAXB + b) * 13 + k] = envs[i].body[b][k];
+}
+__global__ void k_set_body_state(DevEnv* envs, int n, const float* in) {
+  ENV_THREAD();
+  for (int b = 0; b < RV_MAXB; ++b) for (int k = 0; k < 13; ++k) e.body[b][k] = in[((size_t)i * RV_MAXB + b) * 13 + k];
+  for (int m = 0; m < RV_NMAN; ++m) e.man[m].n = 0;
+}
+__global__ void k_get_body_params(const DevEnv* envs, int n, float* out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  const DevEnv& e = envs[i];
+  for (int b = 0; b < RV_MAXB; ++b) {
+    float* o = out + ((size_t)i * RV_MAXB + b) * 8;
+    o[0] = (float)e.active[b]; o[1] = (float)e.shape[b]; o[2] = e.scale[b]; o[3] = e.mass[b]; o[4] = e.friction[b];
+    o[5] = (float)e.frozen[b]; o[6] = e.table_z; o[7] = 0.0f;
+  }
+}
+__global__ void k_set_body_params(DevEnv* envs, int n, const float* in, const rv_config* cfg, const rv_scene* scene) {
+  ENV_THREAD();
+  Consts K; K.cfg = cfg; K.scene = scene;
+  int nb = 0;
+  for (int b = 0; b < RV_MAXB; ++b) {
+    const float* o = in + ((size_t)i * RV_MAXB + b) * 8;
+    e.active[b] = (int)o[0]; e.shape[b] = (int)o[1]; e.scale[b] = o[2]; e.friction[b] = o[4]; e.frozen[b] = (int)o[5];
+    if (b == 0) e.table_z = o[6];
+    if (e.active[b]) { body_set_mass(e, K, b, o[3]); nb++; }
+  }
+  e.n_bodies = nb;
+}
+__global__ void k_get_joint_state(const DevEnv* envs, int n, float* out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  for (int j = 0; j < RV_NJ; ++j) { out[((size_t)i * RV_NJ + j) * 2] = envs[i].q[j]; out[((size_t)i * RV_NJ + j) * 2 + 1] = envs[i].qd[j]; }
+}
+__device__ void update_link_frames(DevEnv& e, const rv_arm* a) {
+  LimbFK F;
+  fk_limb(a, e.q, F, nullptr);
+  for (int f = 0; f <= RV_NLIMB; ++f) { st3(e.fpos[f], F.pos[f]); stq(e.fquat[f], F.quat[f]); }
+  m3 r7 = qmat(F.quat[7]);
+  v3 yax = mk(r7.m[1], r7.m[4], r7.m[7]);
+  for (int k = 0; k < 2; ++k) {
+    st3(e.fpos[8 + k], madd(F.pos[7], yax, a->finger_y0[k] + e.q[7 + k]));
+    stq(e.fquat[8 + k], F.quat[7]);
+  }
+}
+__global__ void k_set_joint_state(DevEnv* envs, int n, const float* in, const rv_config* cfg, const rv_scene* scene) {
+  ENV_THREAD();
+  const rv_arm* a = &scene->arm;
+  for (int j = 0; j < RV_NJ; ++j) { e.q[j] = in[((size_t)i * RV_NJ + j) * 2]; e.qd[j] = in[((size_t)i * RV_NJ + j) * 2 + 1]; e.motor_q[j] = e.q[j]; }
+  if (!e.arm_enabled) {
+    for (int j = 0; j < RV_NJ; ++j) { e.motor_on[j] = 0; e.motor_kp[j] = cfg->kp; e.motor_kd[j] = cfg->kd; e.vmax_cmd[j] = a->v_max[j]; }
+    arm_reset_targets(e); e.gripper_ready_time = 0.0f; e.arm_enabled = 1;
+  }
+  update_link_frames(e, a);
+}
+__global__ void k_get_link_poses(const DevEnv* envs, int n, float* out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  for (int f = 0; f < RV_NFRAME; ++f) {
+    float* o = out + ((size_t)i * RV_NFRAME + f) * 7;
+    for (int k = 0; k < 3; ++k) o[k] = envs[i].fpos[f][k];
+    for (int k = 0; k < 4; ++k) o[3 + k] = envs[i].fquat[f][k];
+  }
+}
+__global__ void k_get_env_counters(const DevEnv* envs, int n, int32_t* out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  const DevEnv& e = envs[i]; int32_t* o = out + (size_t)i * 8;
+  o[0] = e.sim_steps; o[1] = e.num_steps; o[2] = e.num_episodes; o[3] = e.phase; o[4] = e.done; o[5] = e.is_safe; o[6] = e.is_effective; o[7] = e.substeps_last;
+}
+__global__ void k_set_actions(DevEnv* envs, int n, const float* a, int G) {
+  ENV_THREAD();
+  for (int g = 0; g < G; ++g) for (int k = 0; k < 4; ++k) e.action[g][k] = a[((size_t)i * G + g) * 4 + k];
+}
+__global__ void k_set_joint_targets(DevEnv* envs, int n, const float* q, const rv_config* cfg, const rv_scene* scene) {
+  ENV_THREAD();
+  // SawyerSim.move_to_joint_positions (sawyer_sim.py:186-234)
+  arm_reset_targets(e);
+  for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = cfg->limb_max_velocity_ratio * scene->arm.v_max[j];
+  JTarget& t = e.jt;
+  t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = 1;
+  for (int j = 0; j < RV_NLIMB; ++j) { t.idx[j] = j; t.pos[j] = q[(size_t)i * RV_NLIMB + j]; }
+  t.start_t = cfg->dt * (float)e.sim_steps; t.stop_t = t.start_t + cfg->limb_timeout; t.has_stop = 1;
+  t.pos_thr = cfg->limb_position_threshold; t.vel_thr = cfg->velocity_threshold;
+}
+__global__ void k_set_link_target(DevEnv* envs, int n, const float* pose, const rv_config* cfg, const rv_scene* scene) {
+  ENV_THREAD();
+  // SawyerSim.move_to_gripper_pose (sawyer_sim.py:236-308)
+  arm_reset_targets(e);
+  for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = cfg->limb_max_velocity_ratio * scene->arm.v_max[j];
+  LTarget& t = e.lt;
+  t.active = 1; t.has_pose = 1; t.nq = 0;
+  for (int k = 0; k < 7; ++k) t.pose[k] = pose[(size_t)i * 7 + k];
+  t.start_t = cfg->dt * (float)e.sim_steps; t.stop_t = t.start_t + cfg->limb_timeout; t.has_stop = 1;
+  t.pos_thr = cfg->limb_position_threshold; t.vel_thr = cfg->velocity_threshold;
+}
+__global__ void k_compute_ik(const DevEnv* envs, int n, const float* pose, float* q, const rv_config* cfg, const rv_scene* scene) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  Consts K; K.cfg = cfg; K.scene = scene;
+  float p[7], q0[RV_NLIMB], out[RV_NLIMB];
+  for (int k = 0; k < 7; ++k) p[k] = pose[(size_t)i * 7 + k];
+  for (int j = 0; j < RV_NLIMB; ++j) q0[j] = envs[i].q[j];
+  arm_ik(K, q0, p, out);
+  for (int j = 0; j < RV_NLIMB; ++j) q[(size_t)i * RV_NLIMB + j] = out[j];
+}
+__global__ void k_query_contacts(const DevEnv* envs, int n, uint8_t* out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  const DevEnv& e = envs[i]; uint8_t* o = out + (size_t)i * (2 + RV_MAXB);
+  o[0] = (uint8_t)e.flag_arm_table; o[1] = (uint8_t)arm_touches_movables(e);
+  for (int b = 0; b < RV_MAXB; ++b) o[2 + b] = (uint8_t)(e.active[b] && e.flag_arm_body[b]);
+}
+__global__ void k_manifold_counts(const DevEnv* envs, int n, int32_t* out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  for (int m = 0; m < RV_NMAN; ++m) out[(size_t)i * RV_NMAN + m] = envs[i].man[m].n;
+}
+__global__ void k_observe(const DevEnv* envs, int n, rv_obs_buffers o, const rv_config* cfg) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  const DevEnv& e = envs[i];
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (o.d_position) for (int k = 0; k < 3; ++k) o.d_position[((size_t)i * RV_MAXB + b) * 3 + k] = e.obs_pos[b][k];
+    if (o.d_body_mask) o.d_body_mask[(size_t)i * RV_MAXB + b] = (float)e.active[b];
+  }
+  if (o.d_num_episodes) o.d_num_episodes[i] = e.num_episodes;
+  if (o.d_num_steps) o.d_num_steps[i] = e.num_steps;
+  if (o.d_layout_id) o.d_layout_id[i] = cfg->layout_id;
+  if (o.d_is_safe) o.d_is_safe[i] = e.is_safe;
+  if (o.d_is_effective) o.d_is_effective[i] = e.is_effective;
+}
+// SegmentedPointCloudObs (camera_obs.py:182-238), analytic stand-in for the
+// render -> deproject -> group_by_labels chain: P points per body drawn inside
+// the body's hulls (convex combinations of hull vertices), zeros for absent
+// bodies (point_cloud_utils.py:134-157).  One thread per (env, body, point).
+__global__ void k_point_cloud(const DevEnv* envs, int n, float* out, const rv_config* cfg, const rv_scene* scene) {
+  const int P = cfg->num_points;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * RV_MAXB * P) return;
+  const int p = (int)(t % P); const int b = (int)((t / P) % RV_MAXB); const int i = (int)(t / ((size_t)P * RV_MAXB));
+  const DevEnv& e = envs[i];
+  float* o = out + t * 3;
+  if (!e.active[b]) { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; return; }
+  const rv_shape* s = &scene->shapes[e.shape[b]];
+  Rng g = rng_init(cfg->seed_lo, cfg->seed_hi, (uint32_t)(cfg->env_id_offset + i), 7u, (uint32_t)(b * 65536 + p));
+  int h = rng_randint(g, s->n_hulls);
+  int nv = s->n_verts[h];
+  int i0 = rng_randint(g, nv), i1 = rng_randint(g, nv), i2 = rng_randint(g, nv);
+  float u = rng_uniform01(g), v = rng_uniform01(g);
+  if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+  float w0 = 1.0f - u - v;
+  float sc = e.scale[b];
+  v3 l = mk((s->verts[h][i0][0] * w0 + s->verts[h][i1][0] * u + s->verts[h][i2][0] * v) * sc,
+            (s->verts[h][i0][1] * w0 + s->verts[h][i1][1] * u + s->verts[h][i2][1] * v) * sc,
+            (s->verts[h][i0][2] * w0 + s->verts[h][i1][2] * u + s->verts[h][i2][2] * v) * sc);
+  m3 r = qmat(ldq(e.body[b] + 3));
+  st3(o, add(ld3(e.body[b]), mulv(r, l)));
+}
+__global__ void k_reward(const DevEnv* envs, int n, float* reward, uint8_t* done) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  if (reward) reward[i] = envs[i].last_reward;
+  if (done) done[i] = (uint8_t)envs[i].done;
+}
+__global__ void k_returns(const DevEnv* envs, int n, float* r) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  r[i] = envs[i].episode_reward;
+}
+__global__ void k_policy_random(int n, const rv_config* cfg, int macro_index, float* actions) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  int G = cfg->num_goal_steps > 0 ? cfg->num_goal_steps : 1;
+  Rng g = rng_init(cfg->seed_lo, cfg->seed_hi, (uint32_t)(cfg->env_id_offset + i), RV_STREAM_RANDOM, (uint32_t)macro_index);
+  for (int k = 0; k < G * 4; ++k) actions[(size_t)i * G * 4 + k] = rng_uniform(g, -1.0f, 1.0f);
+}
+// HeuristicPushSampler._sample (heuristic_push_sampler.py:66-123): one wave
+// per env, 64 candidate pushes per round; the lowest successful attempt wins.
+__global__ __launch_bounds__(64) void k_policy_heuristic(const DevEnv* envs, int n, const rv_config* c, int max_attempts, float* actions) {
+  const int i = (int)blockIdx.x; if (i >= n) return;
+  const int lane = (int)threadIdx.x;
+  const DevEnv& e = envs[i];
+  int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
+  int nb = 0;
+  for (int b = 0; b < RV_MAXB; ++b) nb += e.active[b];
+  if (nb == 0) nb = 1;
+  int body_id = e.num_episodes % nb;
+  float base = (float)e.num_episodes * 42.0f;
+  base = base - 2.0f * RV_PI * ffloorr(base / (2.0f * RV_PI));
+  float lo0 = c->cspace_low[0], hi0 = c->cspace_high[0], lo1 = c->cspace_low[1], hi1 = c->cspace_high[1];
+  float s0 = 0.0f, s1 = 0.0f, m0 = 0.0f, m1 = 0.0f;
+  int found_att = -1;
+  for (int base_att = 0; base_att < max_attempts; base_att += 64) {
+    int att = base_att + lane;
+    bool good = false;
+    if (att < max_attempts) {
+      Rng g = rng_init(c->seed_lo, c->seed_hi, (uint32_t)(c->env_id_offset + i), RV_STREAM_HEUR, (uint32_t)(e.num_episodes * 64 + e.num_steps));
+      g.c0 = (uint32_t)att * 2u;
+      s0 = rng_uniform(g, -1.0f, 1.0f); s1 = rng_uniform(g, -1.0f, 1.0f);
+      float ang = base + rng_uniform(g, -0.25f * RV_PI, 0.25f * RV_PI);
+      float sn, co; sincosr(ang, &sn, &co);
+      m0 = fclampr(co + rng_uniform(g, -0.3f, 0.3f), -1.0f, 1.0f);
+      m1 = fclampr(sn + rng_uniform(g, -0.3f, 0.3f), -1.0f, 1.0f);
+      float x = s0 * (0.5f * (hi0 - lo0)) + 0.5f * (hi0 + lo0);
+      float y = s1 * (0.5f * (hi1 - lo1)) + 0.5f * (hi1 + lo1);
+      float ex = fclampr(x + m0 * c->translation_x, lo0, hi0);
+      float ey = fclampr(y + m1 * c->translation_y, lo1, hi1);
+      int safe = 1;
+      for (int b = 0; b < nb; ++b) {
+        float dx = e.obs_pos[b][0] - x, dy = e.obs_pos[b][1] - y;
+        if (!(fsqrtr(dx * dx + dy * dy) > 0.05f)) safe = 0;
+      }
+      float dx1 = e.obs_pos[body_id][0] - x, dy1 = e.obs_pos[body_id][1] - y;
+      float dx2 = e.obs_pos[body_id][0] - ex, dy2 = e.obs_pos[body_id][1] - ey;
+      int clear = fsqrtr(dx1 * dx1 + dy1 * dy1) >= 0.01f && fsqrtr(dx2 * dx2 + dy2 * dy2) >= 0.01f;
+      good = safe && !clear;
+    }
+    unsigned long long ballot = __ballot(good);
+    if (ballot) { found_att = base_att + (int)__ffsll((long long)ballot) - 1; break; }
+  }
+  // winner (or, like the reference, the last attempt drawn) writes the action
+  int writer = found_att >= 0 ? (found_att & 63) : ((max_attempts - 1) & 63);
+  if (lane == writer) {
+    for (int g2 = 0; g2 < G; ++g2) {
+      float* a = actions + ((size_t)i * G + g2) * 4;
+      a[0] = s0; a[1] = s1; a[2] = m0; a[3] = m1;
+    }
+  }
+}
+__global__ void k_stats(const DevEnv* envs, int n, rv_macro_stats* st, float success_thresh) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  const DevEnv& e = envs[i];
+  typedef unsigned long long u64;
+  if (e.substeps_last > 0) {
+    atomicAdd((u64*)&st->substeps, (u64)e.substeps_last);
+    atomicMax((u64*)&st->max_substeps, (u64)e.substeps_last);
+  }
+  if (e.stepped) {
+    atomicAdd((u64*)&st->env_steps, (u64)1);
+    if (!e.is_safe) atomicAdd((u64*)&st->unsafe, (u64)1);
+    if (!e.is_effective) atomicAdd((u64*)&st->ineffective, (u64)1);
+    if (e.is_safe && e.is_effective) atomicAdd((u64*)&st->useful, (u64)1);
+    if (e.done) {
+      atomicAdd((u64*)&st->episodes_done, (u64)1);
+      if (e.last_reward >= success_thresh) atomicAdd((u64*)&st->successes, (u64)1);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host ABI
+struct rv_world {
+  rv_config cfg;
+  int device;
+  int n;
+  hipStream_t stream;
+  rv_config* d_cfg;
+  rv_scene* d_scene;
+  DevEnv* d_envs;
+  rv_macro_stats* d_stats;
+  hipEvent_t ev0, ev1;
+  bool timed;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(RV_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define WCHK(w) do { if (!(w)) return fail(RV_ERR_VALUE, "null world"); HIPCHK(hipSetDevice((w)->device)); } while (0)
+
+static inline dim3 grid1(int n) { return dim3((unsigned)((n + 127) / 128)); }
+#define TPB 128
+
+template <int MODE>
+static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, float ang, int ca, int ms, int mx) {
+  EnvKernelArgs a;
+  a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.mask = mask; a.n_envs = w->n;
+  a.n_substeps = n_sub; a.lin_thr = lin; a.ang_thr = ang; a.check_after = ca; a.min_stable = ms; a.max_steps = mx;
+  HIPCHK(hipMemsetAsync(w->d_stats, 0, sizeof(rv_macro_stats), w->stream));
+  HIPCHK(hipEventRecord(w->ev0, w->stream));
+  hipLaunchKernelGGL(k_env<MODE>, dim3((unsigned)w->n), dim3(64), 0, w->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(w->ev1, w->stream));
+  w->timed = true;
+  hipLaunchKernelGGL(k_stats, grid1(w->n), dim3(TPB), 0, w->stream, w->d_envs, w->n, w->d_stats, w->cfg.success_thresh);
+  HIPCHK(hipGetLastError());
+  return RV_OK;
+}
+
+extern "C" {
+
+const char* rv_last_error(void) { return g_err.c_str(); }
+
+int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world** out) {
+  if (!cfg || !scene || !out) return fail(RV_ERR_VALUE, "rv_create: null argument");
+  if (cfg->n_envs <= 0) return fail(RV_ERR_VALUE, "rv_create: n_envs must be positive");
+  if (cfg->n_bodies_max > RV_MAXB || cfg->n_bodies_min < 1 || cfg->n_bodies_min > cfg->n_bodies_max)
+    return fail(RV_ERR_VALUE, "rv_create: body count outside [1, RV_MAXB]");
+  if (scene->n_shapes <= 0 || scene->n_shapes > RV_MAX_SHAPES) return fail(RV_ERR_VALUE, "rv_create: bad n_shapes");
+  int ndev = 0;
+  hipError_t e0 = hipGetDeviceCount(&ndev);
+  if (e0 != hipSuccess || ndev == 0)
+    return fail(RV_ERR_HIP, "rv_create: no HIP device available (librovat_hip has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(RV_ERR_VALUE, "rv_create: bad device index");
+  HIPCHK(hipSetDevice(device));
+  rv_world* w = new (std::nothrow) rv_world();
+  if (!w) return fail(RV_ERR_STATE, "rv_create: out of host memory");
+  w->cfg = *cfg; w->device = device; w->n = cfg->n_envs; w->stream = nullptr; w->timed = false;
+  HIPCHK(hipMalloc(&w->d_cfg, sizeof(rv_config)));
+  HIPCHK(hipMalloc(&w->d_scene, sizeof(rv_scene)));
+  HIPCHK(hipMalloc(&w->d_envs, sizeof(DevEnv) * (size_t)w->n));
+  HIPCHK(hipMalloc(&w->d_stats, sizeof(rv_macro_stats)));
+  HIPCHK(hipMemcpy(w->d_cfg, cfg, sizeof(rv_config), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(w->d_scene, scene, sizeof(rv_scene), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(w->d_stats, 0, sizeof(rv_macro_stats)));
+  HIPCHK(hipEventCreate(&w->ev0));
+  HIPCHK(hipEventCreate(&w->ev1));
+  hipLaunchKernelGGL(k_init, grid1(w->n), dim3(TPB), 0, w->stream, w->d_envs, w->n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(w->stream));
+  *out = w;
+  return RV_OK;
+}
+
+int rv_destroy(rv_world* w) {
+  if (!w) return RV_OK;
+  hipSetDevice(w->device);
+  hipStreamSynchronize(w->stream);
+  hipFree(w->d_cfg); hipFree(w->d_scene); hipFree(w->d_envs); hipFree(w->d_stats);
+  hipEventDestroy(w->ev0); hipEventDestroy(w->ev1);
+  delete w;
+  return RV_OK;
+}
+
+int rv_set_stream(rv_world* w, void* s) { WCHK(w); w->stream = (hipStream_t)s; return RV_OK; }
+int rv_synchronize(rv_world* w) { WCHK(w); HIPCHK(hipStreamSynchronize(w->stream)); return RV_OK; }
+int rv_num_envs(const rv_world* w) { return w ? w->n : 0; }
+
+int rv_reset(rv_world* w, const uint8_t* d_env_mask) { WCHK(w); return launch_env<MODE_RESET>(w, d_env_mask, 0, 0, 0, 0, 0, 0); }
+int rv_step_macro(rv_world* w) { WCHK(w); return launch_env<MODE_MACRO>(w, nullptr, 0, 0, 0, 0, 0, 0); }
+int rv_step_sub(rv_world* w, int32_t n) {
+  WCHK(w);
+  if (n < 0) return fail(RV_ERR_VALUE, "rv_step_sub: negative substep count");
+  return launch_env<MODE_SUB>(w, nullptr, n, 0, 0, 0, 0, 0);
+}
+int rv_wait_until_stable(rv_world* w, float lin, float ang, int32_t ca, int32_t ms, int32_t mx) {
+  WCHK(w);
+  if (mx <= 0) return fail(RV_ERR_VALUE, "rv_wait_until_stable: max_steps must be positive");
+  return launch_env<MODE_WAIT>(w, nullptr, 0, lin, ang, ca, ms, mx);
+}
+
+#define SIMPLE_LAUNCH(kern, ...) do { hipLaunchKernelGGL(kern, grid1(w->n), dim3(TPB), 0, w->stream, __VA_ARGS__); HIPCHK(hipGetLastError()); } while (0)
+#define NEED(p, name) do { if (!(p)) return fail(RV_ERR_VALUE, name ": null buffer"); } while (0)
+
+int rv_set_actions(rv_world* w, const float* d) {
+  WCHK(w); NEED(d, "rv_set_actions");
+  int G = w->cfg.num_goal_steps > 0 ? w->cfg.num_goal_steps : 1;
+  SIMPLE_LAUNCH(k_set_actions, w->d_envs, w->n, d, G); return RV_OK;
+}
+int rv_policy_random(rv_world* w, int32_t macro_index, float* d) {
+  WCHK(w); NEED(d, "rv_policy_random");
+  SIMPLE_LAUNCH(k_policy_random, w->n, w->d_cfg, macro_index, d); return RV_OK;
+}
+int rv_policy_heuristic(rv_world* w, int32_t max_attempts, float* d) {
+  WCHK(w); NEED(d, "rv_policy_heuristic");
+  if (max_attempts <= 0) return fail(RV_ERR_VALUE, "rv_policy_heuristic: max_attempts must be positive");
+  hipLaunchKernelGGL(k_policy_heuristic, dim3((unsigned)w->n), dim3(64), 0, w->stream, w->d_envs, w->n, w->d_cfg, max_attempts, d);
+  HIPCHK(hipGetLastError());
+  return RV_OK;
+}
+int rv_get_body_state(rv_world* w, float* d) { WCHK(w); NEED(d, "rv_get_body_state"); SIMPLE_LAUNCH(k_get_body_state, w->d_envs, w->n, d); return RV_OK; }
+int rv_set_body_state(rv_world* w, const float* d) { WCHK(w); NEED(d, "rv_set_body_state"); SIMPLE_LAUNCH(k_set_body_state, w->d_envs, w->n, d); return RV_OK; }
+int rv_get_body_params(rv_world* w, float* d) { WCHK(w); NEED(d, "rv_get_body_params"); SIMPLE_LAUNCH(k_get_body_params, w->d_envs, w->n, d); return RV_OK; }
+int rv_set_body_params(rv_world* w, const float* d) { WCHK(w); NEED(d, "rv_set_body_params"); SIMPLE_LAUNCH(k_set_body_params, w->d_envs, w->n, d, w->d_cfg, w->d_scene); return RV_OK; }
+int rv_get_joint_state(rv_world* w, float* d) { WCHK(w); NEED(d, "rv_get_joint_state"); SIMPLE_LAUNCH(k_get_joint_state, w->d_envs, w->n, d); return RV_OK; }
+int rv_set_joint_state(rv_world* w, const float* d) { WCHK(w); NEED(d, "rv_set_joint_state"); SIMPLE_LAUNCH(k_set_joint_state, w->d_envs, w->n, d, w->d_cfg, w->d_scene); return RV_OK; }
+int rv_get_link_poses(rv_world* w, float* d) { WCHK(w); NEED(d, "rv_get_link_poses"); SIMPLE_LAUNCH(k_get_link_poses, w->d_envs, w->n, d); return RV_OK; }
+int rv_get_env_counters(rv_world* w, int32_t* d) { WCHK(w); NEED(d, "rv_get_env_counters"); SIMPLE_LAUNCH(k_get_env_counters, w->d_envs, w->n, d); return RV_OK; }
+int rv_set_joint_targets(rv_world* w, const float* d) { WCHK(w); NEED(d, "rv_set_joint_targets"); SIMPLE_LAUNCH(k_set_joint_targets, w->d_envs, w->n, d, w->d_cfg, w->d_scene); return RV_OK; }
+int rv_set_link_target(rv_world* w, const float* d) { WCHK(w); NEED(d, "rv_set_link_target"); SIMPLE_LAUNCH(k_set_link_target, w->d_envs, w->n, d, w->d_cfg, w->d_scene); return RV_OK; }
+int rv_compute_ik(rv_world* w, const float* d_pose, float* d_q) {
+  WCHK(w); NEED(d_pose, "rv_compute_ik"); NEED(d_q, "rv_compute_ik");
+  SIMPLE_LAUNCH(k_compute_ik, w->d_envs, w->n, d_pose, d_q, w->d_cfg, w->d_scene); return RV_OK;
+}
+int rv_query_contacts(rv_world* w, uint8_t* d) { WCHK(w); NEED(d, "rv_query_contacts"); SIMPLE_LAUNCH(k_query_contacts, w->d_envs, w->n, d); return RV_OK; }
+int rv_get_manifold_counts(rv_world* w, int32_t* d) { WCHK(w); NEED(d, "rv_get_manifold_counts"); SIMPLE_LAUNCH(k_manifold_counts, w->d_envs, w->n, d); return RV_OK; }
+int rv_observe(rv_world* w, const rv_obs_buffers* obs) {
+  WCHK(w); NEED(obs, "rv_observe");
+  SIMPLE_LAUNCH(k_observe, w->d_envs, w->n, *obs, w->d_cfg);
+  if (obs->d_point_cloud) {
+    if (w->cfg.num_points <= 0) return fail(RV_ERR_VALUE, "rv_observe: num_points must be positive");
+    size_t total = (size_t)w->n * RV_MAXB * (size_t)w->cfg.num_points;
+    hipLaunchKernelGGL(k_point_cloud, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, w->stream, w->d_envs, w->n, obs->d_point_cloud, w->d_cfg, w->d_scene);
+    HIPCHK(hipGetLastError());
+  }
+  return RV_OK;
+}
+int rv_reward(rv_world* w, float* d_reward, uint8_t* d_done) { WCHK(w); SIMPLE_LAUNCH(k_reward, w->d_envs, w->n, d_reward, d_done); return RV_OK; }
+int rv_get_episode_returns(rv_world* w, float* d) { WCHK(w); NEED(d, "rv_get_episode_returns"); SIMPLE_LAUNCH(k_returns, w->d_envs, w->n, d); return RV_OK; }
+int rv_get_stats(rv_world* w, rv_macro_stats* h) {
+  WCHK(w); NEED(h, "rv_get_stats");
+  HIPCHK(hipMemcpyAsync(h, w->d_stats, sizeof(rv_macro_stats), hipMemcpyDeviceToHost, w->stream));
+  HIPCHK(hipStreamSynchronize(w->stream));
+  return RV_OK;
+}
+int rv_last_kernel_ms(rv_world* w, float* h_ms) {
+  WCHK(w); NEED(h_ms, "rv_last_kernel_ms");
+  if (!w->timed) return fail(RV_ERR_STATE, "rv_last_kernel_ms: no env kernel launched yet");
+  HIPCHK(hipEventSynchronize(w->ev1));
+  HIPCHK(hipEventElapsedTime(h_ms, w->ev0, w->ev1));
+  return RV_OK;
+}
+
+}  // extern "C"
