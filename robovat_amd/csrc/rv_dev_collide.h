@@ -24,7 +24,7 @@ struct Simplex {
   int n;
 };
 
-// EPA polytope workspace (LDS; aliased with the solver rows)
+// EPA polytope workspace (per-lane private memory)
 struct EpaWork {
   float W[RV_EPA_MAX_VERTS][3], VA[RV_EPA_MAX_VERTS][3], VB[RV_EPA_MAX_VERTS][3];
   int fi[RV_EPA_MAX_FACES][3];
@@ -170,8 +170,9 @@ RV_DEV int simplex_solve(Simplex& s, v3* vout) {
 }
 
 // EPA on an origin-enclosing tetrahedron; polytope in the LDS workspace E.
-RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const Simplex& s, EpaWork& E,
+RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const Simplex& s,
                          v3* out_nf, float* out_depth, v3* pa, v3* pb) {
+  EpaWork E;  // private (scratch) memory: deep penetration is rare, LDS is not spent on it
   int nv = 4, nf = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { st3(E.W[i], s.w[i]); st3(E.VA[i], s.a[i]); st3(E.VB[i], s.b[i]); }
@@ -248,28 +249,9 @@ RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const S
   *out_depth = E.fd[bestf];
 }
 
-// wave-level lock around the shared EPA workspace
-RV_DEV void epa_locked(const float* A, int nA, const float* B, int nB, const Simplex& s, EpaWork& E, int* lock,
-                       v3* out_nf, float* out_depth, v3* pa, v3* pb) {
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
-  bool done = false;
-  while (!done) {
-    if (atomicCAS(lock, 0, 1) == 0) {
-      epa(A, nA, B, nB, s, E, out_nf, out_depth, pa, pb);
-      __threadfence_block();
-      atomicExch(lock, 0);
-      done = true;
-    }
-  }
-#else
-  (void)lock;
-  epa(A, nA, B, nB, s, E, out_nf, out_depth, pa, pb);
-#endif
-}
-
 // GJK distance with EPA fallback.  Returns 0 when farther apart than max_dist.
 RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, float max_dist,
-                   EpaWork& E, int* lock, v3* n, float* dist, v3* pa, v3* pb) {
+                   v3* n, float* dist, v3* pa, v3* pb) {
   Simplex s; s.n = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { s.w[i] = mk(0, 0, 0); s.a[i] = mk(0, 0, 0); s.b[i] = mk(0, 0, 0); s.lam[i] = 0.0f; }
@@ -298,7 +280,7 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
   }
   if (penetrating == 1) {
     v3 nf; float depth;
-    epa_locked(A, nA, B, nB, s, E, lock, &nf, &depth, pa, pb);
+    epa(A, nA, B, nB, s, &nf, &depth, pa, pb);
     *n = scale(nf, -1.0f);
     *dist = -depth;
     return 1;

@@ -98,11 +98,9 @@ struct Scratch {
   float rot[RV_MAXB][9], iinv[RV_MAXB][9];
   float wv[RV_MAXB][RV_MAXH][RV_MAXV][3];
   float tablev[8][3];
-  union {
+  struct {
     Row rows[RV_NMAN][4];
-    EpaWork epa;
   } u;
-  int epa_lock;
   // macro-step locals that must survive across phases
   float wp[RV_MAXG][2][7];
   float start_pos[RV_MAXB][3], start_yaw[RV_MAXB];
@@ -425,7 +423,7 @@ RV_DEV int collide_pair(Shared& S, const Consts& K, int kind, int a, int b, int 
                         const float* A, int nA, const float* B, int nB, v3 guess, DevMan* m, float* out_dist) {
   float mg = K.cfg->margin, brk = K.cfg->breaking;
   v3 n, pa, pb; float dist;
-  if (!gjk_epa(A, nA, B, nB, guess, brk + 2.0f * mg, S.s.u.epa, &S.s.epa_lock, &n, &dist, &pa, &pb)) return 0;
+  if (!gjk_epa(A, nA, B, nB, guess, brk + 2.0f * mg, &n, &dist, &pa, &pb)) return 0;
   float d = dist - 2.0f * mg;
   if (d > brk) return 0;
   *out_dist = d;
@@ -687,7 +685,6 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
         else manifold_refresh(S, K, 2, b, -1, e.man[RV_AIDX(b)]);
       }
     }
-    if (lane == 63) S.s.epa_lock = 0;
   RV_LANES_END
 
   // narrow phase: one lane per manifold owner (+ arm-table detection lanes)
@@ -1264,7 +1261,6 @@ RV_DEV void env_enter(Shared& S, const Consts& K) {
       int b = lane - 32;
       stm(S.s.rot[b], qmat(ldq(S.e.body[b] + 3)));
     }
-    if (lane == 63) S.s.epa_lock = 0;
   RV_LANES_END
 }
 

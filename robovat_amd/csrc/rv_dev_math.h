@@ -26,13 +26,10 @@ RV_DEV float fminr(float a, float b) { return a < b ? a : b; }
 RV_DEV float fmaxr(float a, float b) { return a > b ? a : b; }
 RV_DEV float fclampr(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 RV_DEV float fabsr(float x) { return x < 0.0f ? -x : x; }
-RV_DEV float fsqrtr(float x) {
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
-  return __fsqrt_rn(x);
-#else
-  return sqrtf(x);
-#endif
-}
+// sqrtf() lowers to the correctly rounded v_sqrt_f32 + fma fix-up sequence on
+// gfx950 (ROCm 7.2); __fsqrt_rn() lowers to the bare ~1 ulp v_sqrt_f32 and
+// breaks bit-parity with the CPU oracle.
+RV_DEV float fsqrtr(float x) { return sqrtf(x); }
 RV_DEV float frintr(float x) { return rintf(x); }
 RV_DEV float ffloorr(float x) { return floorf(x); }
 

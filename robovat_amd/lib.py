@@ -1,0 +1,272 @@
+"""Loader and thin Python binding of ``librovat_hip.so`` (``include/rovat.h``).
+
+The library is the product: there is NO CPU fallback.  Importing this module
+is cheap; ``load()`` raises ``RuntimeError`` if the shared object has not been
+built (``python -c "import __graft_entry__ as g; g.build()"``) and
+``World(...)`` raises if no HIP device is present.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from robovat_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librovat_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+HIPCC_FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off',
+               '-fPIC', '-shared']
+
+# every symbol include/rovat.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    'rv_create', 'rv_destroy', 'rv_last_error', 'rv_set_stream', 'rv_synchronize',
+    'rv_num_envs', 'rv_reset', 'rv_set_actions', 'rv_step_macro', 'rv_policy_random',
+    'rv_policy_heuristic', 'rv_step_sub', 'rv_wait_until_stable', 'rv_get_body_state',
+    'rv_set_body_state', 'rv_get_body_params', 'rv_set_body_params',
+    'rv_get_joint_state', 'rv_set_joint_state', 'rv_get_link_poses',
+    'rv_get_env_counters', 'rv_set_joint_targets', 'rv_set_link_target',
+    'rv_compute_ik', 'rv_query_contacts', 'rv_get_manifold_counts', 'rv_observe',
+    'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
+]
+
+_EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
+        abi.RV_ERR_HIP: RuntimeError, abi.RV_ERR_NOTIMPL: NotImplementedError}
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/rv_kernels.hip for gfx950 into librovat_hip.so (in-tree)."""
+    src = os.path.join(CSRC, 'rv_kernels.hip')
+    deps = [src] + [os.path.join(CSRC, n) for n in
+                    ('rv_dev_env.h', 'rv_dev_collide.h', 'rv_dev_math.h')]
+    deps.append(os.path.join(_HERE, '..', 'include', 'rovat.h'))
+    if (not force and os.path.exists(LIB_PATH) and
+            all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps)):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc] + HIPCC_FLAGS + [src, '-o', LIB_PATH]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def load():
+    """dlopen librovat_hip.so; fails loudly when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'librovat_hip.so is not built (%s). Run __graft_entry__.build(); '
+            'there is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.rv_last_error.restype = C.c_char_p
+    lib.rv_create.argtypes = [C.POINTER(abi.rv_config), C.POINTER(abi.rv_scene),
+                              C.c_int, C.POINTER(C.c_void_p)]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name != 'rv_last_error':
+            fn.restype = C.c_int
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    lib.rv_destroy.argtypes = [vp]
+    lib.rv_set_stream.argtypes = [vp, vp]
+    lib.rv_synchronize.argtypes = [vp]
+    lib.rv_num_envs.argtypes = [vp]
+    lib.rv_reset.argtypes = [vp, vp]
+    lib.rv_step_macro.argtypes = [vp]
+    lib.rv_step_sub.argtypes = [vp, i32]
+    lib.rv_wait_until_stable.argtypes = [vp, f32, f32, i32, i32, i32]
+    lib.rv_policy_random.argtypes = [vp, i32, vp]
+    lib.rv_policy_heuristic.argtypes = [vp, i32, vp]
+    lib.rv_observe.argtypes = [vp, C.POINTER(abi.rv_obs_buffers)]
+    lib.rv_reward.argtypes = [vp, vp, vp]
+    lib.rv_compute_ik.argtypes = [vp, vp, vp]
+    lib.rv_get_stats.argtypes = [vp, C.POINTER(abi.rv_macro_stats)]
+    lib.rv_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    for name in ('rv_set_actions', 'rv_get_body_state', 'rv_set_body_state',
+                 'rv_get_body_params', 'rv_set_body_params', 'rv_get_joint_state',
+                 'rv_set_joint_state', 'rv_get_link_poses', 'rv_get_env_counters',
+                 'rv_set_joint_targets', 'rv_set_link_target', 'rv_query_contacts',
+                 'rv_get_manifold_counts', 'rv_get_episode_returns'):
+        getattr(lib, name).argtypes = [vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != abi.RV_OK:
+        msg = load().rv_last_error().decode('utf-8', 'replace')
+        raise _EXC.get(status, RuntimeError)(msg)
+
+
+class World(object):
+    """N batched envs on one GPU.  Buffers are torch tensors on that device;
+    the C ABI only ever sees their raw ``data_ptr()``."""
+
+    def __init__(self, cfg, scene, device=0):
+        import torch
+        self.torch = torch
+        self.lib = load()
+        self.cfg = cfg
+        self.scene = scene
+        self.n = int(cfg.n_envs)
+        self.G = cfg.num_goal_steps if cfg.num_goal_steps > 0 else 1
+        self.device_index = int(device)
+        self.device = torch.device('cuda', self.device_index)
+        self.h = C.c_void_p()
+        check(self.lib.rv_create(C.byref(cfg), C.byref(scene), self.device_index, C.byref(self.h)))
+        # run on torch's current stream so torch ops and kernels are ordered
+        self.use_current_stream()
+
+    def use_current_stream(self):
+        stream = self.torch.cuda.current_stream(self.device)
+        check(self.lib.rv_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
+
+    def close(self):
+        if getattr(self, 'h', None) and self.h:
+            self.lib.rv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers
+    def _new(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _in(self, x, shape, dtype):
+        t = self.torch.as_tensor(x, dtype=dtype, device=self.device).reshape(shape).contiguous()
+        return t
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr())
+
+    def synchronize(self):
+        check(self.lib.rv_synchronize(self.h))
+
+    # -- env stepping
+    def reset(self, mask=None):
+        if mask is None:
+            check(self.lib.rv_reset(self.h, None))
+        else:
+            m = self._in(mask, (self.n,), self.torch.uint8)
+            check(self.lib.rv_reset(self.h, self._ptr(m)))
+
+    def set_actions(self, actions):
+        a = self._in(actions, (self.n, self.G, 4), self.torch.float32)
+        check(self.lib.rv_set_actions(self.h, self._ptr(a)))
+
+    def step_macro(self):
+        check(self.lib.rv_step_macro(self.h))
+
+    def step_sub(self, n):
+        check(self.lib.rv_step_sub(self.h, int(n)))
+
+    def wait_until_stable(self, lin=0.005, ang=0.005, check_after=100, min_stable=100, max_steps=2000):
+        check(self.lib.rv_wait_until_stable(self.h, lin, ang, check_after, min_stable, max_steps))
+
+    def policy_random(self, macro_index):
+        a = self._new((self.n, self.G, 4), self.torch.float32)
+        check(self.lib.rv_policy_random(self.h, int(macro_index), self._ptr(a)))
+        return a
+
+    def policy_heuristic(self, max_attempts=20000):
+        a = self._new((self.n, self.G, 4), self.torch.float32)
+        check(self.lib.rv_policy_heuristic(self.h, int(max_attempts), self._ptr(a)))
+        return a
+
+    # -- state
+    def _get(self, fn, shape, dtype):
+        t = self._new(shape, dtype)
+        check(getattr(self.lib, fn)(self.h, self._ptr(t)))
+        return t
+
+    def body_state(self):
+        return self._get('rv_get_body_state', (self.n, abi.RV_MAXB, 13), self.torch.float32)
+
+    def set_body_state(self, s):
+        check(self.lib.rv_set_body_state(self.h, self._ptr(self._in(s, (self.n, abi.RV_MAXB, 13), self.torch.float32))))
+
+    def body_params(self):
+        return self._get('rv_get_body_params', (self.n, abi.RV_MAXB, 8), self.torch.float32)
+
+    def set_body_params(self, p):
+        check(self.lib.rv_set_body_params(self.h, self._ptr(self._in(p, (self.n, abi.RV_MAXB, 8), self.torch.float32))))
+
+    def joint_state(self):
+        return self._get('rv_get_joint_state', (self.n, abi.RV_NJ, 2), self.torch.float32)
+
+    def set_joint_state(self, s):
+        check(self.lib.rv_set_joint_state(self.h, self._ptr(self._in(s, (self.n, abi.RV_NJ, 2), self.torch.float32))))
+
+    def link_poses(self):
+        return self._get('rv_get_link_poses', (self.n, abi.RV_NFRAME, 7), self.torch.float32)
+
+    def env_counters(self):
+        return self._get('rv_get_env_counters', (self.n, 8), self.torch.int32)
+
+    def set_joint_targets(self, q):
+        check(self.lib.rv_set_joint_targets(self.h, self._ptr(self._in(q, (self.n, abi.RV_NLIMB), self.torch.float32))))
+
+    def set_link_target(self, pose):
+        check(self.lib.rv_set_link_target(self.h, self._ptr(self._in(pose, (self.n, 7), self.torch.float32))))
+
+    def compute_ik(self, pose):
+        p = self._in(pose, (self.n, 7), self.torch.float32)
+        q = self._new((self.n, abi.RV_NLIMB), self.torch.float32)
+        check(self.lib.rv_compute_ik(self.h, self._ptr(p), self._ptr(q)))
+        return q
+
+    def query_contacts(self):
+        return self._get('rv_query_contacts', (self.n, 2 + abi.RV_MAXB), self.torch.uint8)
+
+    def manifold_counts(self):
+        return self._get('rv_get_manifold_counts', (self.n, abi.RV_NMAN), self.torch.int32)
+
+    def observe(self, point_cloud=False):
+        t = self.torch
+        out = {
+            'position': self._new((self.n, abi.RV_MAXB, 3), t.float32),
+            'body_mask': self._new((self.n, abi.RV_MAXB), t.float32),
+            'num_episodes': self._new((self.n,), t.int64),
+            'num_steps': self._new((self.n,), t.int64),
+            'layout_id': self._new((self.n,), t.int64),
+            'is_safe': self._new((self.n,), t.int64),
+            'is_effective': self._new((self.n,), t.int64),
+        }
+        b = abi.rv_obs_buffers()
+        b.d_position = out['position'].data_ptr(); b.d_body_mask = out['body_mask'].data_ptr()
+        b.d_num_episodes = out['num_episodes'].data_ptr(); b.d_num_steps = out['num_steps'].data_ptr()
+        b.d_layout_id = out['layout_id'].data_ptr(); b.d_is_safe = out['is_safe'].data_ptr()
+        b.d_is_effective = out['is_effective'].data_ptr()
+        if point_cloud:
+            out['point_cloud'] = self._new((self.n, abi.RV_MAXB, int(self.cfg.num_points), 3), t.float32)
+            b.d_point_cloud = out['point_cloud'].data_ptr()
+        check(self.lib.rv_observe(self.h, C.byref(b)))
+        return out
+
+    def reward(self):
+        r = self._new((self.n,), self.torch.float32)
+        d = self._new((self.n,), self.torch.uint8)
+        check(self.lib.rv_reward(self.h, self._ptr(r), self._ptr(d)))
+        return r, d
+
+    def episode_returns(self):
+        return self._get('rv_get_episode_returns', (self.n,), self.torch.float32)
+
+    def stats(self):
+        s = abi.rv_macro_stats()
+        check(self.lib.rv_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        check(self.lib.rv_last_kernel_ms(self.h, C.byref(ms)))
+        return float(ms.value)

@@ -18,6 +18,7 @@ struct EmuWorld {
 static void run_env(EmuWorld* w, int i, int mode, int n_sub, float lin, float ang, int ca, int ms, int mx) {
   static thread_local Shared S;
   Consts K; K.cfg = &w->cfg; K.scene = &w->scene;
+  memset(&S.s, 0xFF, sizeof(S.s));  /* LDS is not zero-initialised on the GPU: poison it */
   memcpy(&S.e, &w->envs[i], sizeof(DevEnv));
   if (mode == 1 && S.e.done) { w->envs[i].substeps_last = 0; w->envs[i].stepped = 0; return; }
   if (mode != 0) env_enter(S, K);
