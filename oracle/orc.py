@@ -47,6 +47,7 @@ def _lib(double):
                      'orc_eval_waypoints'):
             getattr(lib, name).restype = None
         lib.orc_eval_gjk.restype = C.c_int
+        lib.orc_eval_wait_until_stable.restype = C.c_int
         _LIBS[key] = lib
     return _LIBS[key]
 
@@ -199,3 +200,10 @@ def eval_gjk(A, B, max_dist=1e9, double=False):
     if not hit:
         return None
     return dict(n=out[0:3].copy(), dist=out[3], pa=out[4:7].copy(), pb=out[7:10].copy())
+
+
+def eval_wait_until_stable(stable, check_after=100, min_stable=100, max_steps=2000):
+    lib = _lib(False)
+    a = np.ascontiguousarray(stable, dtype=np.uint8)
+    assert len(a) >= max_steps
+    return lib.orc_eval_wait_until_stable(_p(a), C.c_int(check_after), C.c_int(min_stable), C.c_int(max_steps))

@@ -1202,6 +1202,11 @@ orc_world* orc_create(const rv_config* cfg, const rv_scene* scene) {
   orc_world* w = (orc_world*)calloc(1, sizeof(orc_world));
   w->cfg = *cfg; w->scene = *scene; w->n = cfg->n_envs;
   w->env = (orc_env*)calloc((size_t)w->n, sizeof(orc_env));
+  for (int i = 0; i < w->n; ++i) {
+    for (int b = 0; b < RV_MAXB; ++b) w->env[i].body[b].q[3] = R(1.0);
+    for (int f = 0; f < RV_NFRAME; ++f) w->env[i].fquat[f][3] = R(1.0);
+    w->env[i].done = 1; /* RobotEnv.__init__: self._done = True (robot_env.py:66) */
+  }
   return w;
 }
 void orc_destroy(orc_world* w) { if (w) { free(w->env); free(w); } }
@@ -1458,6 +1463,19 @@ void orc_eval_waypoints(const rv_config* cfg, const float* action, double* start
   real a[4] = {(real)action[0], (real)action[1], (real)action[2], (real)action[3]}, s[7], e[7];
   compute_waypoints(cfg, a, s, e);
   for (int k = 0; k < 7; ++k) { start[k] = s[k]; end[k] = e[k]; }
+}
+/* Simulator.wait_until_stable counter logic (simulator.py:325-376) driven by a
+ * scripted per-step stability flag instead of physics; stable[k-1] is the
+ * check_stable() outcome after the k-th step. */
+int orc_eval_wait_until_stable(const uint8_t* stable, int check_after, int min_stable, int max_steps) {
+  int num_steps = 0, num_stable = 0;
+  for (;;) {
+    num_steps++;
+    if (num_steps < check_after) continue;
+    if (stable[num_steps - 1]) num_stable++;
+    if (num_stable >= min_stable || num_steps >= max_steps) break;
+  }
+  return num_steps;
 }
 /* stand-alone GJK query for unit tests */
 int orc_eval_gjk(const double* A, int nA, const double* B, int nB, double max_dist, double* out /* n3, dist, pa3, pb3 */) {

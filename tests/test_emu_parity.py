@@ -1,0 +1,86 @@
+"""The kernel program (robovat_amd/csrc/rv_dev_env.h) compiled for the host by
+the lane emulator (tests/emu) must match the float oracle bit for bit.  This
+is the CPU-side check of the kernel's lane/phase decomposition; the real HIP
+parity tests are tests/test_gpu_parity.py (-m gpu)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from robovat_amd import abi, configs, scenes
+
+EMU_DIR = os.path.join(os.path.dirname(__file__), 'emu')
+
+
+@pytest.fixture(scope='module')
+def emu():
+    so = os.path.join(EMU_DIR, 'librv_emu.so')
+    src = os.path.join(EMU_DIR, 'rv_emu.cpp')
+    csrc = os.path.join(EMU_DIR, '..', '..', 'robovat_amd', 'csrc')
+    deps = [src] + [os.path.join(csrc, n) for n in ('rv_dev_env.h', 'rv_dev_collide.h', 'rv_dev_math.h')]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fopenmp', '-shared', src, '-o', so], check=True)
+    lib = C.CDLL(so)
+    lib.emu_create.restype = C.c_void_p
+    lib.emu_create.argtypes = [C.POINTER(abi.rv_config), C.POINTER(abi.rv_scene)]
+    return lib
+
+
+class Emu(object):
+    def __init__(self, lib, cfg, scene):
+        self.lib, self.n = lib, cfg.n_envs
+        self.h = C.c_void_p(lib.emu_create(C.byref(cfg), C.byref(scene)))
+
+    def _get(self, fn, shape, dt):
+        a = np.zeros(shape, dt); getattr(self.lib, fn)(self.h, a.ctypes.data_as(C.c_void_p)); return a
+
+    def body_state(self): return self._get('emu_get_body_state', (self.n, abi.RV_MAXB, 13), np.float32)
+    def joint_state(self): return self._get('emu_get_joint_state', (self.n, abi.RV_NJ, 2), np.float32)
+    def counters(self): return self._get('emu_get_env_counters', (self.n, 8), np.int32)
+    def manifolds(self): return self._get('emu_get_manifold_counts', (self.n, abi.RV_NMAN), np.int32)
+    def link_poses(self): return self._get('emu_get_link_poses', (self.n, abi.RV_NFRAME, 7), np.float32)
+
+
+def _check(e, ref):
+    assert np.array_equal(e.body_state(), ref.body_state().astype(np.float32))
+    assert np.array_equal(e.joint_state(), ref.joint_state().astype(np.float32))
+    assert np.array_equal(e.counters(), ref.env_counters())
+    assert np.array_equal(e.manifolds(), ref.manifold_counts())
+    assert np.array_equal(e.link_poses(), ref.link_poses().astype(np.float32))
+
+
+@pytest.mark.parametrize('over', [{}, dict(TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=3),
+                                  dict(MIN_MOVABLE_BODIES=1, MAX_MOVABLE_BODIES=4, NUM_GOAL_STEPS=2)])
+def test_emulated_kernel_is_bit_exact_vs_float_oracle(emu, over):
+    from oracle import orc
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(env_cfg=configs.push_env_config(**over), n_envs=6, seed=17, shape_names=names)
+    ref = orc.OracleWorld(cfg, scene, double=False)
+    e = Emu(emu, cfg, scene)
+    ref.reset(); emu.emu_reset(e.h, None)
+    _check(e, ref)
+    for k in range(2):
+        a = ref.policy_random(k)
+        ref.set_actions(a); emu.emu_set_actions(e.h, a.ctypes.data_as(C.c_void_p))
+        ref.step_macro(); emu.emu_step_macro(e.h)
+        _check(e, ref)
+        r = np.zeros(6, np.float32); d = np.zeros(6, np.uint8)
+        emu.emu_reward(e.h, r.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p))
+        rr, rd = ref.reward()
+        assert np.array_equal(r, rr.astype(np.float32)) and np.array_equal(d, rd)
+
+
+def test_masked_reset_only_touches_masked_envs(emu):
+    from oracle import orc
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(n_envs=4, seed=2, shape_names=names)
+    ref = orc.OracleWorld(cfg, scene); e = Emu(emu, cfg, scene)
+    ref.reset(); emu.emu_reset(e.h, None)
+    before = e.body_state().copy()
+    mask = np.array([0, 1, 0, 1], np.uint8)
+    ref.reset(mask); emu.emu_reset(e.h, mask.ctypes.data_as(C.c_void_p))
+    after = e.body_state()
+    assert np.array_equal(after[[0, 2]], before[[0, 2]]) and not np.array_equal(after[[1, 3]], before[[1, 3]])
+    _check(e, ref)
