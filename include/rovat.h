@@ -114,6 +114,18 @@ typedef struct rv_config {
   float    erp, slop, margin, breaking, warmstart, max_pushout;
   float    lin_damp, ang_damp;   /* per-substep velocity multipliers           */
   float    contact_query_dist;   /* check_contact threshold (simulator.py:246) */
+  float    solver_tol;           /* PGS stops when max |d lambda| < tol (0 = run all iterations) */
+  /* body deactivation ("sleeping", Bullet default behaviour): a body whose
+   * speeds stay below the thresholds for sleep_steps substeps is put to
+   * sleep until something comes near it (0 steps = never sleep) */
+  float    sleep_lin, sleep_ang;
+  int32_t  sleep_steps;
+  /* narrow-phase gating: a pair's full GJK/feature pass is re-run only after
+   * its bodies moved np_gate metres (linear + angular*radius) since the last
+   * pass, when a cached point was lost, or every np_max_age-th substep; cached
+   * points are refreshed every substep (np_max_age = 0: every substep) */
+  float    np_gate;
+  int32_t  np_max_age;
   /* table (arm_env.py:78-99; layouts.py:30) */
   float    table_center[2];
   float    table_half[2];
@@ -179,6 +191,7 @@ typedef struct rv_macro_stats {
   int64_t env_steps;     /* envs that completed an env.step()                 */
   int64_t unsafe, ineffective, useful, successes, episodes_done;
   int64_t max_substeps;  /* slowest env of the launch                         */
+  int64_t awake_substeps;/* substeps in which at least one body was awake     */
 } rv_macro_stats;
 
 typedef struct rv_world rv_world;
@@ -227,7 +240,8 @@ int  rv_set_body_params(rv_world* w, const float* d_in);
 int  rv_get_joint_state(rv_world* w, float* d_out /* [N][RV_NJ][2] */);
 int  rv_set_joint_state(rv_world* w, const float* d_in /* [N][RV_NJ][2] */);
 int  rv_get_link_poses(rv_world* w, float* d_out /* [N][RV_NFRAME][7] */);
-int  rv_get_env_counters(rv_world* w, int32_t* d_out /* [N][8]: sim_steps, num_steps, num_episodes, phase, done, is_safe, is_effective, substeps_last */);
+#define RV_NCOUNTERS 10
+int  rv_get_env_counters(rv_world* w, int32_t* d_out /* [N][RV_NCOUNTERS]: sim_steps, num_steps, num_episodes, phase, done, is_safe, is_effective, substeps_last, awake_substeps_last, reset_count */);
 
 /* ---- ControllableBody.set_target_joint_positions / set_target_link_pose
  *      (controllable_body.py:263-345) via RobotCommand (simulator.py:226-244). */

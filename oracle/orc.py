@@ -134,7 +134,7 @@ class OracleWorld(object):
         return self._get('orc_get_link_poses', (self.n, abi.RV_NFRAME, 7))
 
     def env_counters(self):
-        return self._get('orc_get_env_counters', (self.n, 8), np.int32)
+        return self._get('orc_get_env_counters', (self.n, abi.RV_NCOUNTERS), np.int32)
 
     def set_joint_targets(self, q):
         a = np.ascontiguousarray(q, dtype=np.float32).reshape(self.n, abi.RV_NLIMB)

@@ -293,6 +293,8 @@ typedef struct {
   real dist[4];
   real ln[4], lt1[4], lt2[4]; /* accumulated impulses (warm start)      */
   int  col[4];     /* arm collider id for arm-body manifolds, else -1   */
+  real acc;        /* relative motion since the last full narrow phase  */
+  int  age;        /* substeps since the last full narrow phase         */
 } orc_manifold;
 
 static inline void orc_man_remove(orc_manifold* m, int i) {

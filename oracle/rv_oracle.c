@@ -37,6 +37,7 @@
 typedef struct { real p[3], q[4], v[3], w[3]; } orc_body;
 typedef struct {
   int active, frozen, shape;
+  int asleep, sleep_count;
   real scale, mass, inv_mass, inv_inertia[3], friction, radius;
 } orc_bparam;
 
@@ -74,6 +75,7 @@ typedef struct {
   real colv[RV_NCOL][8][3], colc[RV_NCOL][3], colr[RV_NCOL];
   /* per-substep caches */
   real rot[RV_MAXB][9], iinv[RV_MAXB][9];
+  real mot[RV_MAXB];
   real wv[RV_MAXB][RV_MAXH][RV_MAXV][3];
   real tablev[8][3];
   /* contacts */
@@ -84,7 +86,7 @@ typedef struct {
   int num_steps, num_episodes;   /* RobotEnv counters              */
   int done, phase, is_safe, is_effective;
   int reset_count;
-  int substeps_last;
+  int substeps_last, awake_last;
   real episode_reward, last_reward;
   real action[RV_MAXG][4];
   real obs_pos[RV_MAXB][3], prev_obs_pos[RV_MAXB][3];
@@ -110,6 +112,7 @@ static const int BB_B[RV_NBB] = {1, 2, 3, 2, 3, 3};
 /* round-robin colouring: pairs of one round touch disjoint bodies */
 static const int BB_ROUND[3][2] = {{0, 5}, {1, 4}, {2, 3}};
 
+static int body_on(const orc_env* e, int b) { return e->bp[b].active && !e->bp[b].frozen && !e->bp[b].asleep; }
 static real sim_time(const orc_world* w, const orc_env* e) { return (real)w->cfg.dt * (real)e->sim_steps; }
 
 /* ------------------------------------------------------------------ arm -- */
@@ -421,9 +424,12 @@ static void body_set_mass(const orc_world* w, orc_env* e, int b, real mass) {
   p->radius = (real)s->radius * p->scale + (real)w->cfg.margin;
 }
 
+static void body_prepare(const orc_world* w, orc_env* e, int b);
 static void bodies_prepare(const orc_world* w, orc_env* e) {
-  for (int b = 0; b < RV_MAXB; ++b) {
-    if (!e->bp[b].active || e->bp[b].frozen) continue;
+  for (int b = 0; b < RV_MAXB; ++b) if (body_on(e, b)) body_prepare(w, e, b);
+}
+static void body_prepare(const orc_world* w, orc_env* e, int b) {
+  {
     const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
     real* m = e->rot[b];
     qmat(m, e->body[b].q);
@@ -488,8 +494,9 @@ static void manifold_world_points(const orc_world* w, const orc_env* e, int kind
   else to_world_frame(e, w->scene.arm.col_frame[m->col[i]], m->lb[i], wb);
 }
 
-static void manifold_refresh(const orc_world* w, orc_env* e, int kind, int a, int b, orc_manifold* m) {
+static int manifold_refresh(const orc_world* w, orc_env* e, int kind, int a, int b, orc_manifold* m) {
   real brk = (real)w->cfg.breaking;
+  int n0 = m->n;
   for (int i = m->n - 1; i >= 0; --i) {
     real wa[3], wb[3], d[3];
     manifold_world_points(w, e, kind, a, b, m, i, wa, wb);
@@ -502,6 +509,7 @@ static void manifold_refresh(const orc_world* w, orc_env* e, int kind, int a, in
     v3sub(dr, wb, proj);
     if (v3dot(dr, dr) > brk * brk) orc_man_remove(m, i);
   }
+  return n0 - m->n;
 }
 
 /* tangent-plane direction set used for one-shot manifold generation: the
@@ -598,22 +606,36 @@ static void collide_all(const orc_world* w, orc_env* e) {
   real brk = (real)c->breaking, qd = (real)c->contact_query_dist;
   real tc[3] = {(real)c->table_center[0], (real)c->table_center[1], e->table_z - R(0.5) * (real)c->table_thickness};
   real th[3] = {(real)c->table_half[0], (real)c->table_half[1], R(0.5) * (real)c->table_thickness};
+  int run[RV_NMAN];
+  for (int i = 0; i < RV_NMAN; ++i) run[i] = 1;
   /* refresh */
   for (int b = 0; b < RV_MAXB; ++b) {
-    int on = e->bp[b].active && !e->bp[b].frozen;
-    if (!on) { e->man[TIDX(b)].n = 0; e->man[AIDX(b)].n = 0; continue; }
-    manifold_refresh(w, e, 0, b, -1, &e->man[TIDX(b)]);
+    if (!(e->bp[b].active && !e->bp[b].frozen)) { e->man[TIDX(b)].n = 0; e->man[AIDX(b)].n = 0; continue; }
+    if (e->bp[b].asleep) continue; /* manifolds of a sleeping body stay frozen */
+    {
+      orc_manifold* m = &e->man[TIDX(b)];
+      int lost = manifold_refresh(w, e, 0, b, -1, m);
+      m->acc += e->mot[b]; m->age += 1;
+      run[TIDX(b)] = (c->np_max_age <= 0) || m->n == 0 || lost > 0 || m->acc > (real)c->np_gate || (e->sim_steps % c->np_max_age) == 0;
+    }
     if (e->arm_enabled) manifold_refresh(w, e, 2, b, -1, &e->man[AIDX(b)]); else e->man[AIDX(b)].n = 0;
   }
   for (int k = 0; k < RV_NBB; ++k) {
     int a = BB_A[k], b = BB_B[k];
     int on = e->bp[a].active && !e->bp[a].frozen && e->bp[b].active && !e->bp[b].frozen;
     if (!on) { e->man[BBIDX(k)].n = 0; continue; }
-    manifold_refresh(w, e, 1, a, b, &e->man[BBIDX(k)]);
+    if (e->bp[a].asleep || e->bp[b].asleep) continue;
+    {
+      orc_manifold* m = &e->man[BBIDX(k)];
+      int lost = manifold_refresh(w, e, 1, a, b, m);
+      m->acc += e->mot[a] + e->mot[b]; m->age += 1;
+      run[BBIDX(k)] = (c->np_max_age <= 0) || m->n == 0 || lost > 0 || m->acc > (real)c->np_gate || (e->sim_steps % c->np_max_age) == 0;
+    }
   }
   /* body - table */
   for (int b = 0; b < RV_MAXB; ++b) {
-    if (!e->bp[b].active || e->bp[b].frozen) continue;
+    if (!body_on(e, b) || !run[TIDX(b)]) continue;
+    e->man[TIDX(b)].acc = R(0.0); e->man[TIDX(b)].age = 0;
     real r = e->bp[b].radius + brk;
     if (sphere_box_dist2(e->body[b].p, tc, th) >= r * r) continue;
     const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
@@ -627,7 +649,8 @@ static void collide_all(const orc_world* w, orc_env* e) {
   /* body - body */
   for (int k = 0; k < RV_NBB; ++k) {
     int a = BB_A[k], b = BB_B[k];
-    if (!(e->bp[a].active && !e->bp[a].frozen && e->bp[b].active && !e->bp[b].frozen)) continue;
+    if (!(body_on(e, a) && body_on(e, b)) || !run[BBIDX(k)]) continue;
+    e->man[BBIDX(k)].acc = R(0.0); e->man[BBIDX(k)].age = 0;
     real d[3]; v3sub(d, e->body[a].p, e->body[b].p);
     real r = e->bp[a].radius + e->bp[b].radius + brk;
     if (v3dot(d, d) >= r * r) continue;
@@ -645,7 +668,7 @@ static void collide_all(const orc_world* w, orc_env* e) {
   if (e->arm_enabled) {
     for (int col = 0; col < RV_NCOL; ++col) {
       for (int b = 0; b < RV_MAXB; ++b) {
-        if (!e->bp[b].active || e->bp[b].frozen) continue;
+        if (!body_on(e, b)) continue;
         real d[3]; v3sub(d, e->body[b].p, e->colc[col]);
         real r = e->bp[b].radius + e->colr[col] + brk;
         if (v3dot(d, d) >= r * r) continue;
@@ -657,6 +680,10 @@ static void collide_all(const orc_world* w, orc_env* e) {
       }
       /* arm - table: detection only (push_env.py:839-855) */
       real r = e->colr[col] + brk;
+      real minz = e->colv[col][0][2];
+      for (int k = 1; k < 8; ++k) minz = rmin(minz, e->colv[col][k][2]);
+      /* exact rejection: the flag needs dist < query_dist and dist >= minz - table_z - margin */
+      if (minz - e->table_z - (real)c->margin >= qd) continue;
       if (sphere_box_dist2(e->colc[col], tc, th) < r * r) {
         real guess[3] = {R(0.0), R(0.0), R(1.0)}, dd;
         if (collide_pair(w, e, 0, 0, -1, col, (const real(*)[3])e->colv[col], 8, (const real(*)[3])e->tablev, 8, guess, NULL, &dd))
@@ -733,12 +760,14 @@ static real row_jv(const orc_env* e, int kind, int a, int b, const orc_row* r, i
   else jv -= r->vbc[k];
   return jv;
 }
-static void point_solve(orc_env* e, int kind, int a, int b, orc_manifold* m, int i, const orc_row* r) {
+static real point_solve(orc_env* e, int kind, int a, int b, orc_manifold* m, int i, const orc_row* r) {
   /* normal */
+  real res;
   real jv = row_jv(e, kind, a, b, r, 0);
   real dl = (r->target - jv) * r->invk[0];
   real ln = rmax(m->ln[i] + dl, R(0.0));
   dl = ln - m->ln[i]; m->ln[i] = ln;
+  res = rabs(dl);
   row_apply(e, kind, a, b, r, 0, dl);
   /* friction pyramid */
   real lim = r->mu * m->ln[i];
@@ -746,23 +775,31 @@ static void point_solve(orc_env* e, int kind, int a, int b, orc_manifold* m, int
   dl = -jv * r->invk[1];
   real l1 = rclamp(m->lt1[i] + dl, -lim, lim);
   dl = l1 - m->lt1[i]; m->lt1[i] = l1;
+  res = rmax(res, rabs(dl));
   row_apply(e, kind, a, b, r, 1, dl);
   jv = row_jv(e, kind, a, b, r, 2);
   dl = -jv * r->invk[2];
   real l2 = rclamp(m->lt2[i] + dl, -lim, lim);
   dl = l2 - m->lt2[i]; m->lt2[i] = l2;
+  res = rmax(res, rabs(dl));
   row_apply(e, kind, a, b, r, 2, dl);
+  return res;
 }
 
 static void solve_contacts(const orc_world* w, orc_env* e) {
   const rv_config* c = &w->cfg;
   orc_row rows[RV_NMAN][4];
+  /* manifolds that take part: both bodies awake (a sleeping body has none) */
+  int use[RV_NMAN];
+  for (int b = 0; b < RV_MAXB; ++b) { use[TIDX(b)] = body_on(e, b); use[AIDX(b)] = body_on(e, b); }
+  for (int k = 0; k < RV_NBB; ++k) use[BBIDX(k)] = body_on(e, BB_A[k]) && body_on(e, BB_B[k]);
   /* setup + warm start, in the order the iterations visit the points */
   for (int pass = 0; pass < 2; ++pass) {
     for (int b = 0; b < RV_MAXB; ++b) {
       for (int kind = 0; kind <= 2; kind += 2) {
         int mi = kind == 0 ? TIDX(b) : AIDX(b);
         orc_manifold* m = &e->man[mi];
+        if (!use[mi]) continue;
         for (int i = 0; i < m->n; ++i) {
           if (pass == 0) {
             row_setup(w, e, kind, b, -1, m, i, &rows[mi][i]);
@@ -779,6 +816,7 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
       for (int x = 0; x < 2; ++x) {
         int k = BB_ROUND[rd][x]; int mi = BBIDX(k);
         orc_manifold* m = &e->man[mi];
+        if (!use[mi]) continue;
         for (int i = 0; i < m->n; ++i) {
           if (pass == 0) {
             row_setup(w, e, 1, BB_A[k], BB_B[k], m, i, &rows[mi][i]);
@@ -791,19 +829,40 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
         }
       }
   }
+  int any_bb = 0;
+  for (int k = 0; k < RV_NBB; ++k) if (use[BBIDX(k)]) any_bb += e->man[BBIDX(k)].n;
+  if (!any_bb) {
+    /* no body-body coupling: every body is an independent problem and stops
+     * on its own residual */
+    for (int b = 0; b < RV_MAXB; ++b) {
+      if (!use[TIDX(b)]) continue;
+      orc_manifold* mt = &e->man[TIDX(b)];
+      orc_manifold* ma = &e->man[AIDX(b)];
+      if (mt->n + ma->n == 0) continue;
+      for (int it = 0; it < c->solver_iters; ++it) {
+        real res = R(0.0);
+        for (int i = 0; i < mt->n; ++i) res = rmax(res, point_solve(e, 0, b, -1, mt, i, &rows[TIDX(b)][i]));
+        for (int i = 0; i < ma->n; ++i) res = rmax(res, point_solve(e, 2, b, -1, ma, i, &rows[AIDX(b)][i]));
+        if (res < (real)c->solver_tol) break;
+      }
+    }
+    return;
+  }
   for (int it = 0; it < c->solver_iters; ++it) {
+    real res = R(0.0);
     for (int b = 0; b < RV_MAXB; ++b) {
       orc_manifold* m = &e->man[TIDX(b)];
-      for (int i = 0; i < m->n; ++i) point_solve(e, 0, b, -1, m, i, &rows[TIDX(b)][i]);
+      if (use[TIDX(b)]) for (int i = 0; i < m->n; ++i) res = rmax(res, point_solve(e, 0, b, -1, m, i, &rows[TIDX(b)][i]));
       m = &e->man[AIDX(b)];
-      for (int i = 0; i < m->n; ++i) point_solve(e, 2, b, -1, m, i, &rows[AIDX(b)][i]);
+      if (use[AIDX(b)]) for (int i = 0; i < m->n; ++i) res = rmax(res, point_solve(e, 2, b, -1, m, i, &rows[AIDX(b)][i]));
     }
     for (int rd = 0; rd < 3; ++rd)
       for (int x = 0; x < 2; ++x) {
         int k = BB_ROUND[rd][x];
         orc_manifold* m = &e->man[BBIDX(k)];
-        for (int i = 0; i < m->n; ++i) point_solve(e, 1, BB_A[k], BB_B[k], m, i, &rows[BBIDX(k)][i]);
+        if (use[BBIDX(k)]) for (int i = 0; i < m->n; ++i) res = rmax(res, point_solve(e, 1, BB_A[k], BB_B[k], m, i, &rows[BBIDX(k)][i]));
       }
+    if (res < (real)c->solver_tol) break;   /* residual-based early exit */
   }
 }
 
@@ -818,19 +877,48 @@ static void sim_substep(const orc_world* w, orc_env* e) {
     arm_motor_step(w, e);
     arm_update_kinematics(w, e);
   }
+  /* wake sleeping bodies that an awake body or an arm collider comes near */
+  {
+    int wake[RV_MAXB];
+    for (int b = 0; b < RV_MAXB; ++b) {
+      wake[b] = 0;
+      if (!(e->bp[b].active && !e->bp[b].frozen && e->bp[b].asleep)) continue;
+      for (int a = 0; a < RV_MAXB; ++a) {
+        /* only a MOVING neighbour wakes a sleeper (resting neighbours would ping-pong) */
+        if (a == b || !body_on(e, a) || e->bp[a].sleep_count > 0) continue;
+        real d[3]; v3sub(d, e->body[a].p, e->body[b].p);
+        real r = e->bp[a].radius + e->bp[b].radius + (real)c->breaking;
+        if (v3dot(d, d) < r * r) wake[b] = 1;
+      }
+      if (e->arm_enabled)
+        for (int col = 0; col < RV_NCOL; ++col) {
+          real d[3]; v3sub(d, e->body[b].p, e->colc[col]);
+          real r = e->bp[b].radius + e->colr[col] + (real)c->breaking;
+          if (v3dot(d, d) < r * r) wake[b] = 1;
+        }
+    }
+    for (int b = 0; b < RV_MAXB; ++b) if (wake[b]) { e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; }
+  }
   for (int b = 0; b < RV_MAXB; ++b) {
-    if (!e->bp[b].active || e->bp[b].frozen) continue;
+    if (!body_on(e, b)) continue;
     orc_body* B = &e->body[b];
     B->v[2] += (real)c->gravity_z * dt;
     v3scale(B->v, B->v, (real)c->lin_damp);
     v3scale(B->w, B->w, (real)c->ang_damp);
+    e->mot[b] = (v3len(B->v) + v3len(B->w) * e->bp[b].radius) * dt;
+  }
+  {
+    int aw = 0;
+    for (int b = 0; b < RV_MAXB; ++b) aw |= body_on(e, b);
+    e->awake_last += aw;
   }
   bodies_prepare(w, e);
   collide_all(w, e);
   solve_contacts(w, e);
   for (int b = 0; b < RV_MAXB; ++b) {
-    if (!e->bp[b].active || e->bp[b].frozen) continue;
+    if (!body_on(e, b)) continue;
     orc_body* B = &e->body[b];
+    real vv = v3dot(B->v, B->v), ww = v3dot(B->w, B->w);
     v3madd(B->p, B->p, B->v, dt);
     real wq[4] = {B->w[0], B->w[1], B->w[2], R(0.0)}, dq[4];
     qmul(dq, wq, B->q);
@@ -839,6 +927,15 @@ static void sim_substep(const orc_world* w, orc_env* e) {
     if (B->p[2] < e->table_z - (real)c->fall_depth) {
       e->bp[b].frozen = 1;
       v3set(B->v, R(0.0), R(0.0), R(0.0)); v3set(B->w, R(0.0), R(0.0), R(0.0));
+    }
+    /* deactivation counter */
+    if (c->sleep_steps > 0) {
+      if (vv < (real)c->sleep_lin * (real)c->sleep_lin && ww < (real)c->sleep_ang * (real)c->sleep_ang) e->bp[b].sleep_count++;
+      else e->bp[b].sleep_count = 0;
+      if (e->bp[b].sleep_count >= c->sleep_steps) {
+        e->bp[b].asleep = 1;
+        v3set(B->v, R(0.0), R(0.0), R(0.0)); v3set(B->w, R(0.0), R(0.0), R(0.0));
+      }
     }
   }
   e->sim_steps++;
@@ -1068,7 +1165,7 @@ static void execute_action(const orc_world* w, orc_env* e) {
 static void env_step(const orc_world* w, orc_env* e) {
   const rv_config* c = &w->cfg;
   if (e->done) return;
-  e->substeps_last = 0;
+  e->substeps_last = 0; e->awake_last = 0;
   execute_action(w, e);
   e->num_steps++;
   compute_obs(e);
@@ -1138,7 +1235,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   const rv_config* c = &w->cfg;
   orc_rng g; rng_init(&g, c->seed_lo, c->seed_hi, (uint32_t)gid, STREAM_RESET, (uint32_t)e->reset_count);
   e->reset_count++;
-  e->substeps_last = 0;
+  e->substeps_last = 0; e->awake_last = 0;
   e->sim_steps = 0; e->num_steps = 0; e->episode_reward = R(0.0); e->last_reward = R(0.0);
   e->done = 0;
   e->phase = RV_PHASE_INITIAL; e->is_safe = 1; e->is_effective = 1;
@@ -1154,7 +1251,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   e->n_bodies = nb;
   for (;;) {
     real poses[RV_MAXB][7];
-    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; }
+    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; }
     for (int i = 0; i < RV_NMAN; ++i) e->man[i].n = 0;
     sample_poses(w, e, &g, nb, poses);
     for (int i = 0; i < nb; ++i) {
@@ -1163,7 +1260,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
                              : c->movable_shapes[rng_randint(&g, c->n_movable_shapes)];
       real scale = rng_uniform(&g, (real)c->scale_range[0], (real)c->scale_range[1]);
       orc_bparam* p = &e->bp[i];
-      p->active = 1; p->frozen = 0; p->shape = shape; p->scale = scale; p->friction = (real)c->drop_friction;
+      p->active = 1; p->frozen = 0; p->asleep = 0; p->sleep_count = 0; p->shape = shape; p->scale = scale; p->friction = (real)c->drop_friction;
       body_set_mass(w, e, i, (real)c->drop_mass);
       v3cpy(e->body[i].p, poses[i]); memcpy(e->body[i].q, poses[i] + 3, sizeof(real) * 4);
       v3set(e->body[i].v, R(0.0), R(0.0), R(0.0)); v3set(e->body[i].w, R(0.0), R(0.0), R(0.0));
@@ -1215,6 +1312,7 @@ int orc_is_double(void) { return (int)(sizeof(real) == 8); }
 static void stats_begin(orc_world* w) { memset(&w->stats, 0, sizeof(w->stats)); }
 static void stats_env(orc_world* w, const orc_env* e) {
   w->stats.substeps += e->substeps_last;
+  w->stats.awake_substeps += e->awake_last;
   if (e->substeps_last > w->stats.max_substeps) w->stats.max_substeps = e->substeps_last;
 }
 
@@ -1222,7 +1320,7 @@ void orc_reset(orc_world* w, const uint8_t* mask) {
   stats_begin(w);
 #pragma omp parallel for schedule(dynamic)
   for (int i = 0; i < w->n; ++i) {
-    if (mask && !mask[i]) { w->env[i].substeps_last = 0; continue; }
+    if (mask && !mask[i]) { w->env[i].substeps_last = 0; w->env[i].awake_last = 0; continue; }
     env_reset(w, &w->env[i], w->cfg.env_id_offset + i);
   }
   for (int i = 0; i < w->n; ++i) stats_env(w, &w->env[i]);
@@ -1238,7 +1336,7 @@ void orc_step_macro(orc_world* w) {
 #pragma omp parallel for schedule(dynamic)
   for (int i = 0; i < w->n; ++i) {
     orc_env* e = &w->env[i];
-    e->substeps_last = 0;
+    e->substeps_last = 0; e->awake_last = 0;
     if (e->done) continue;
     env_step(w, e);
   }
@@ -1257,7 +1355,7 @@ void orc_step_sub(orc_world* w, int n) {
   stats_begin(w);
 #pragma omp parallel for schedule(dynamic)
   for (int i = 0; i < w->n; ++i) {
-    w->env[i].substeps_last = 0;
+    w->env[i].substeps_last = 0; w->env[i].awake_last = 0;
     for (int k = 0; k < n; ++k) sim_substep(w, &w->env[i]);
   }
   for (int i = 0; i < w->n; ++i) stats_env(w, &w->env[i]);
@@ -1267,7 +1365,7 @@ void orc_wait_until_stable(orc_world* w, float lin, float ang, int check_after, 
 #pragma omp parallel for schedule(dynamic)
   for (int i = 0; i < w->n; ++i) {
     orc_env* e = &w->env[i];
-    e->substeps_last = 0;
+    e->substeps_last = 0; e->awake_last = 0;
     unsigned mask = 0;
     for (int b = 0; b < RV_MAXB; ++b) if (e->bp[b].active) mask |= 1u << b;
     wait_until_stable(w, e, mask, (real)lin, (real)ang, check_after, min_stable, max_steps);
@@ -1346,6 +1444,7 @@ void orc_set_body_state(orc_world* w, const double* in) {
       for (int k = 0; k < 3; ++k) { B->p[k] = (real)o[k]; B->v[k] = (real)o[7 + k]; B->w[k] = (real)o[10 + k]; }
       for (int k = 0; k < 4; ++k) B->q[k] = (real)o[3 + k];
       w->env[i].man[TIDX(b)].n = 0; w->env[i].man[AIDX(b)].n = 0;
+      w->env[i].bp[b].asleep = 0; w->env[i].bp[b].sleep_count = 0;
     }
   for (int i = 0; i < w->n; ++i) for (int k = 0; k < RV_NBB; ++k) w->env[i].man[BBIDX(k)].n = 0;
 }
@@ -1354,7 +1453,7 @@ void orc_get_body_params(orc_world* w, double* out) {
     for (int b = 0; b < RV_MAXB; ++b) {
       double* o = out + ((size_t)i * RV_MAXB + b) * 8;
       const orc_bparam* p = &w->env[i].bp[b];
-      o[0] = p->active; o[1] = p->shape; o[2] = p->scale; o[3] = p->mass; o[4] = p->friction; o[5] = p->frozen; o[6] = w->env[i].table_z; o[7] = 0;
+      o[0] = p->active; o[1] = p->shape; o[2] = p->scale; o[3] = p->mass; o[4] = p->friction; o[5] = p->frozen; o[6] = w->env[i].table_z; o[7] = p->asleep;
     }
 }
 void orc_set_body_params(orc_world* w, const double* in) {
@@ -1363,7 +1462,7 @@ void orc_set_body_params(orc_world* w, const double* in) {
     for (int b = 0; b < RV_MAXB; ++b) {
       const double* o = in + ((size_t)i * RV_MAXB + b) * 8;
       orc_bparam* p = &e->bp[b];
-      p->active = (int)o[0]; p->shape = (int)o[1]; p->scale = (real)o[2]; p->friction = (real)o[4]; p->frozen = (int)o[5];
+      p->active = (int)o[0]; p->shape = (int)o[1]; p->scale = (real)o[2]; p->friction = (real)o[4]; p->frozen = (int)o[5]; p->asleep = 0; p->sleep_count = 0;
       if (b == 0) { e->table_z = (real)o[6]; table_prepare(w, e); }
       if (p->active) body_set_mass(w, e, b, (real)o[3]);
     }
@@ -1397,7 +1496,8 @@ void orc_get_link_poses(orc_world* w, double* out) {
 }
 void orc_get_env_counters(orc_world* w, int32_t* out) {
   for (int i = 0; i < w->n; ++i) {
-    const orc_env* e = &w->env[i]; int32_t* o = out + (size_t)i * 8;
+    const orc_env* e = &w->env[i]; int32_t* o = out + (size_t)i * RV_NCOUNTERS;
+    o[8] = e->awake_last; o[9] = e->reset_count;
     o[0] = e->sim_steps; o[1] = e->num_steps; o[2] = e->num_episodes; o[3] = e->phase; o[4] = e->done; o[5] = e->is_safe; o[6] = e->is_effective; o[7] = e->substeps_last;
   }
 }

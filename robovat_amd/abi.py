@@ -19,6 +19,7 @@ RV_MAXQ = 8
 RV_NBB = RV_MAXB * (RV_MAXB - 1) // 2
 RV_NMAN = 2 * RV_MAXB + RV_NBB
 RV_BODY_STRIDE = 13
+RV_NCOUNTERS = 10
 
 RV_OK, RV_ERR_VALUE, RV_ERR_STATE, RV_ERR_HIP, RV_ERR_NOTIMPL = 0, 1, 2, 3, 4
 RV_TASK_NONE, RV_TASK_CLEARING, RV_TASK_INSERTION, RV_TASK_CROSSING = 0, 1, 2, 3
@@ -73,6 +74,8 @@ class rv_config(C.Structure):
         ('warmstart', f32), ('max_pushout', f32),
         ('lin_damp', f32), ('ang_damp', f32),
         ('contact_query_dist', f32),
+        ('solver_tol', f32), ('sleep_lin', f32), ('sleep_ang', f32), ('sleep_steps', i32),
+        ('np_gate', f32), ('np_max_age', i32),
         ('table_center', f32 * 2), ('table_half', f32 * 2),
         ('table_thickness', f32), ('table_z', f32),
         ('table_height_range', f32 * 2),
@@ -119,7 +122,7 @@ class rv_macro_stats(C.Structure):
     _fields_ = [
         ('substeps', i64), ('env_steps', i64), ('unsafe', i64),
         ('ineffective', i64), ('useful', i64), ('successes', i64),
-        ('episodes_done', i64), ('max_substeps', i64),
+        ('episodes_done', i64), ('max_substeps', i64), ('awake_substeps', i64),
     ]
 
 

@@ -97,6 +97,9 @@ PUSH_ENV_CONFIG = {
         'BREAKING': 0.01, 'WARMSTART': 0.85, 'MAX_PUSHOUT': 0.5,
         'LINEAR_DAMPING': 0.04, 'ANGULAR_DAMPING': 0.04,
         'CONTACT_QUERY_DIST': 0.001, 'ARM_FRICTION': 0.8,
+        'SOLVER_TOL': 1e-7,
+        'SLEEP_LINEAR': 0.01, 'SLEEP_ANGULAR': 0.05, 'SLEEP_STEPS': 200,
+        'NARROWPHASE_GATE': 5e-4, 'NARROWPHASE_MAX_AGE': 8,
     },
 }
 
@@ -162,6 +165,9 @@ def make_rv_config(env_cfg=None, robot_cfg=None, shape_names=None, n_envs=1,
     c.lin_damp = float(np.float32((1.0 - ph.LINEAR_DAMPING) ** ph.TIME_STEP))
     c.ang_damp = float(np.float32((1.0 - ph.ANGULAR_DAMPING) ** ph.TIME_STEP))
     c.contact_query_dist = ph.CONTACT_QUERY_DIST
+    c.solver_tol = ph.SOLVER_TOL
+    c.sleep_lin, c.sleep_ang, c.sleep_steps = ph.SLEEP_LINEAR, ph.SLEEP_ANGULAR, int(ph.SLEEP_STEPS)
+    c.np_gate, c.np_max_age = ph.NARROWPHASE_GATE, int(ph.NARROWPHASE_MAX_AGE)
     tb = env_cfg.SIM.TABLE
     abi.assign(c.table_center, tb.POSE[0][:2])
     abi.assign(c.table_half, tb.HALF_EXTENTS)

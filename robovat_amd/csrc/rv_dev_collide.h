@@ -17,6 +17,7 @@ namespace rv {
 #define RV_EPA_MAX_EDGES 32
 #define RV_EPA_MAX_ITERS 32
 #define RV_EPA_TOL 1e-6f
+#define RV_MAXV_REG 16
 
 struct Simplex {
   v3 w[4], a[4], b[4];
@@ -34,13 +35,40 @@ struct EpaWork {
   int ea[RV_EPA_MAX_EDGES], eb[RV_EPA_MAX_EDGES];
 };
 
-// persistent manifold (one per pair slot), 61 words
+// persistent manifold (one per pair slot), 63 words
 struct DevMan {
   int n;
   int col[4];
   float la[4][3], lb[4][3], nrm[4][3];
   float dist[4], ln[4], lt1[4], lt2[4];
+  float acc;   // relative motion since the last full narrow phase
+  int age;     // substeps since the last full narrow phase
 };
+
+// Support vertex (by value) of a hull stored as n <= RV_MAXV_REG packed xyz
+// triples: fully unrolled over RV_MAXV_REG slots with the index clamped to n-1
+// (a repeated vertex can never win the strict argmax, so the result equals the
+// plain loop over n vertices).  All loads are independent of the compare chain,
+// so the compiler issues them as one batch instead of one LDS round trip per
+// vertex.
+RV_DEV v3 support_v(const float* verts, int n, v3 d, float* proj) {
+  float px[RV_MAXV_REG], py[RV_MAXV_REG], pz[RV_MAXV_REG];
+#pragma unroll
+  for (int i = 0; i < RV_MAXV_REG; ++i) {
+    int j = i < n ? i : n - 1;
+    px[i] = verts[3 * j]; py[i] = verts[3 * j + 1]; pz[i] = verts[3 * j + 2];
+  }
+  v3 best = mk(px[0], py[0], pz[0]);
+  float bd = dot(best, d);
+#pragma unroll
+  for (int i = 1; i < RV_MAXV_REG; ++i) {
+    v3 p = mk(px[i], py[i], pz[i]);
+    float x = dot(p, d);
+    if (x > bd) { bd = x; best = p; }
+  }
+  *proj = bd;
+  return best;
+}
 
 RV_DEV int support(const float* verts, int n, v3 d) {
   int best = 0;
@@ -259,9 +287,8 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
   if (!(dot(v, v) > 1e-12f)) v = mk(1.0f, 0.0f, 0.0f);
   int have_v = 0, penetrating = 0;
   for (int it = 0; it < RV_GJK_MAX_ITERS; ++it) {
-    int ia = support(A, nA, scale(v, -1.0f));
-    int ib = support(B, nB, v);
-    v3 va = ld3(A + 3 * ia), vb = ld3(B + 3 * ib);
+    float pja, pjb;
+    v3 va = support_v(A, nA, scale(v, -1.0f), &pja), vb = support_v(B, nB, v, &pjb);
     v3 w = sub(va, vb);
     float vv = dot(v, v), vw = dot(v, w);
     if (vw > 0.0f && vw * vw > max_dist * max_dist * vv) return 0;
@@ -305,13 +332,23 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
 }
 
 // ---------------------------------------------------------------- manifold
+// The manifold stays in LDS; each operation first stages what it needs in
+// registers (independent loads -> one batch), decides, then writes back only
+// the slot it changes.
+struct ManPoint { v3 la, lb, nrm; float dist, ln, lt1, lt2; int col; };
+RV_DEV ManPoint man_get(const DevMan& m, int i) {
+  ManPoint p;
+  p.la = ld3(m.la[i]); p.lb = ld3(m.lb[i]); p.nrm = ld3(m.nrm[i]);
+  p.dist = m.dist[i]; p.ln = m.ln[i]; p.lt1 = m.lt1[i]; p.lt2 = m.lt2[i]; p.col = m.col[i];
+  return p;
+}
+RV_DEV void man_put(DevMan& m, int i, const ManPoint& p) {
+  st3(m.la[i], p.la); st3(m.lb[i], p.lb); st3(m.nrm[i], p.nrm);
+  m.dist[i] = p.dist; m.ln[i] = p.ln; m.lt1[i] = p.lt1; m.lt2[i] = p.lt2; m.col[i] = p.col;
+}
 RV_DEV void man_remove(DevMan& m, int i) {
   int last = m.n - 1;
-  if (i != last) {
-    for (int k = 0; k < 3; ++k) { m.la[i][k] = m.la[last][k]; m.lb[i][k] = m.lb[last][k]; m.nrm[i][k] = m.nrm[last][k]; }
-    m.dist[i] = m.dist[last]; m.ln[i] = m.ln[last]; m.lt1[i] = m.lt1[last]; m.lt2[i] = m.lt2[last];
-    m.col[i] = m.col[last];
-  }
+  if (i != last) { ManPoint p = man_get(m, last); man_put(m, i, p); }
   m.n = last;
 }
 
@@ -323,26 +360,33 @@ RV_DEV float area4(v3 p0, v3 p1, v3 p2, v3 p3) {
 }
 
 RV_DEV void man_add(DevMan& m, v3 la, v3 lb, v3 nrm, float dist, int col, float breaking) {
+  const int n = m.n;
+  v3 q[4]; float qd[4]; int qc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { q[i] = ld3(m.la[i]); qd[i] = m.dist[i]; qc[i] = m.col[i]; }
   int slot = -1;
   float best = breaking * breaking;
-  for (int i = 0; i < m.n; ++i) {
-    v3 d = sub(ld3(m.la[i]), la);
-    float dd = dot(d, d);
-    if (dd < best && m.col[i] == col) { best = dd; slot = i; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < n) {
+      v3 d = sub(q[i], la);
+      float dd = dot(d, d);
+      if (dd < best && qc[i] == col) { best = dd; slot = i; }
+    }
   }
   int keep_impulse = 0;
   if (slot >= 0) {
     keep_impulse = 1;
-  } else if (m.n < 4) {
-    slot = m.n; m.n = m.n + 1;
+  } else if (n < 4) {
+    slot = n; m.n = n + 1;
   } else {
     int deepest = -1; float dmin = dist;
-    for (int i = 0; i < 4; ++i) if (m.dist[i] < dmin) { dmin = m.dist[i]; deepest = i; }
-    v3 q0 = ld3(m.la[0]), q1 = ld3(m.la[1]), q2 = ld3(m.la[2]), q3 = ld3(m.la[3]);
-    float r0 = (deepest == 0) ? -1.0f : area4(la, q1, q2, q3);
-    float r1 = (deepest == 1) ? -1.0f : area4(la, q0, q2, q3);
-    float r2 = (deepest == 2) ? -1.0f : area4(la, q0, q1, q3);
-    float r3 = (deepest == 3) ? -1.0f : area4(la, q0, q1, q2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (qd[i] < dmin) { dmin = qd[i]; deepest = i; }
+    float r0 = (deepest == 0) ? -1.0f : area4(la, q[1], q[2], q[3]);
+    float r1 = (deepest == 1) ? -1.0f : area4(la, q[0], q[2], q[3]);
+    float r2 = (deepest == 2) ? -1.0f : area4(la, q[0], q[1], q[3]);
+    float r3 = (deepest == 3) ? -1.0f : area4(la, q[0], q[1], q[2]);
     slot = 0; float rb = r0;
     if (r1 > rb) { rb = r1; slot = 1; }
     if (r2 > rb) { rb = r2; slot = 2; }

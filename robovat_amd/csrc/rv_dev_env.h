@@ -62,6 +62,7 @@ struct LTarget {
 struct DevEnv {
   float body[RV_MAXB][RV_BODY_STRIDE];
   int active[RV_MAXB], frozen[RV_MAXB], shape[RV_MAXB];
+  int asleep[RV_MAXB], sleep_count[RV_MAXB];
   float scale[RV_MAXB], mass[RV_MAXB], inv_mass[RV_MAXB], inv_inertia[RV_MAXB][3], friction[RV_MAXB], radius[RV_MAXB];
   float table_z;
   int n_bodies;
@@ -75,7 +76,7 @@ struct DevEnv {
   float fpos[RV_NFRAME][3], fquat[RV_NFRAME][4];
   DevMan man[RV_NMAN];
   int flag_arm_table, flag_arm_body[RV_MAXB];
-  int sim_steps, num_steps, num_episodes, done, phase, is_safe, is_effective, reset_count, substeps_last;
+  int sim_steps, num_steps, num_episodes, done, phase, is_safe, is_effective, reset_count, substeps_last, awake_last;
   int stepped;      // this env executed an env.step() in the last macro launch
   float episode_reward, last_reward;
   float action[RV_MAXG][4];
@@ -83,6 +84,7 @@ struct DevEnv {
   int num_total_steps, num_unsafe, num_ineffective, num_useful, num_successes;
   int pad_[3];
 };
+static_assert(sizeof(DevEnv) % 4 == 0, "DevEnv is copied word-wise");
 
 // one solver row set per contact point (normal + two friction directions)
 struct Row {
@@ -107,6 +109,9 @@ struct Scratch {
   float poses[RV_MAXB][7];
   int num_waypoints, interrupt, has_budget, max_phase_steps;
   int loop_break, wus_steps, wus_stable, valid;
+  int wake[RV_MAXB];
+  float res[16];
+  float mot[RV_MAXB];
   Rng rng;
 };
 
@@ -118,6 +123,7 @@ struct Shared {
 struct Consts {
   const rv_config* cfg;
   const rv_scene* scene;
+  int stop_after;
 };
 
 RV_DEV int bb_a(int k) { return k < 3 ? 0 : (k < 5 ? 1 : 2); }
@@ -126,7 +132,8 @@ RV_DEV int bb_b(int k) { return k == 0 ? 1 : (k == 1 ? 2 : (k == 2 ? 3 : (k == 3
 RV_DEV int bb_round_pair(int r, int x) { return x == 0 ? r : 5 - r; }
 
 RV_DEV float sim_time(const Shared& S, const Consts& K) { return K.cfg->dt * (float)S.e.sim_steps; }
-RV_DEV int body_on(const DevEnv& e, int b) { return e.active[b] && !e.frozen[b]; }
+RV_DEV int body_present(const DevEnv& e, int b) { return e.active[b] && !e.frozen[b]; }
+RV_DEV int body_on(const DevEnv& e, int b) { return e.active[b] && !e.frozen[b] && !e.asleep[b]; }
 
 // ------------------------------------------------------------------- arm --
 // FK of the limb for joint vector q (registers / LDS), frames 0..7
@@ -386,27 +393,42 @@ RV_DEV v3 to_local_frame(const Shared& S, int f, v3 wp) { return tmulv(S.s.frot[
 RV_DEV v3 to_world_frame(const Shared& S, int f, v3 lp) { return add(ld3(S.e.fpos[f]), mulv(S.s.frot[f], lp)); }
 
 // kind: 0 body-table, 1 body-body, 2 arm-body
-RV_DEV void manifold_world_points(const Shared& S, const Consts& K, int kind, int a, int b, const DevMan& m, int i, v3* wa, v3* wb) {
-  *wa = to_world_body(S, a, ld3(m.la[i]));
-  if (kind == 0) *wb = ld3(m.lb[i]);
-  else if (kind == 1) *wb = to_world_body(S, b, ld3(m.lb[i]));
-  else *wb = to_world_frame(S, K.scene->arm.col_frame[m.col[i]], ld3(m.lb[i]));
+RV_DEV void point_world(const Shared& S, const Consts& K, int kind, int a, int b, const ManPoint& p, v3* wa, v3* wb) {
+  *wa = to_world_body(S, a, p.la);
+  if (kind == 0) *wb = p.lb;
+  else if (kind == 1) *wb = to_world_body(S, b, p.lb);
+  else *wb = to_world_frame(S, K.scene->arm.col_frame[p.col], p.lb);
 }
-RV_DEV void manifold_refresh(Shared& S, const Consts& K, int kind, int a, int b, DevMan& m) {
+RV_DEV int manifold_refresh(const Shared& S, const Consts& K, int kind, int a, int b, DevMan& m) {
   float brk = K.cfg->breaking;
-  for (int i = m.n - 1; i >= 0; --i) {
-    v3 wa, wb;
-    manifold_world_points(S, K, kind, a, b, m, i, &wa, &wb);
-    v3 nrm = ld3(m.nrm[i]);
-    float dist = dot(sub(wa, wb), nrm);
-    m.dist[i] = dist;
-    if (dist > brk) { man_remove(m, i); continue; }
-    v3 proj = madd(wa, nrm, -dist);
-    v3 dr = sub(wb, proj);
-    if (dot(dr, dr) > brk * brk) man_remove(m, i);
+  const int n0 = m.n;
+  // distances of all cached points first (independent work), removals after
+  float dist[4]; int rm[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dist[i] = 0.0f; rm[i] = 0;
+    if (i < n0) {
+      ManPoint p;
+      p.la = ld3(m.la[i]); p.lb = ld3(m.lb[i]); p.nrm = ld3(m.nrm[i]); p.col = m.col[i];
+      v3 wa, wb;
+      point_world(S, K, kind, a, b, p, &wa, &wb);
+      float d = dot(sub(wa, wb), p.nrm);
+      dist[i] = d;
+      if (d > brk) rm[i] = 1;
+      else {
+        v3 proj = madd(wa, p.nrm, -d);
+        v3 dr = sub(wb, proj);
+        if (dot(dr, dr) > brk * brk) rm[i] = 1;
+      }
+    }
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (i < n0) m.dist[i] = dist[i];
+#pragma unroll
+  for (int i = 3; i >= 0; --i) if (i < n0 && rm[i]) man_remove(m, i);
+  return n0 - m.n;
 }
-RV_DEV void manifold_add_world(Shared& S, const Consts& K, int kind, int a, int b, int col, DevMan& m, v3 wa, v3 wb, v3 n, float d) {
+RV_DEV void manifold_add_world(const Shared& S, const Consts& K, int kind, int a, int b, int col, DevMan& m, v3 wa, v3 wb, v3 n, float d) {
   v3 la = to_local_body(S, a, wa), lb;
   if (kind == 0) lb = wb;
   else if (kind == 1) lb = to_local_body(S, b, wb);
@@ -419,7 +441,7 @@ RV_DEV void manifold_add_world(Shared& S, const Consts& K, int kind, int a, int 
 #define RV_MAN_TAU 0.1f
 
 // narrow phase of one convex pair; m == nullptr: distance only
-RV_DEV int collide_pair(Shared& S, const Consts& K, int kind, int a, int b, int col,
+RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b, int col,
                         const float* A, int nA, const float* B, int nB, v3 guess, DevMan* m, float* out_dist) {
   float mg = K.cfg->margin, brk = K.cfg->breaking;
   v3 n, pa, pb; float dist;
@@ -438,13 +460,15 @@ RV_DEV int collide_pair(Shared& S, const Consts& K, int kind, int a, int b, int 
   dir[3] = mk(-dir[1].x, -dir[1].y, -dir[1].z);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    extA[j] = dot(ld3(A + 3 * support(A, nA, dir[j])), dir[j]) + mg;
-    extB[j] = dot(ld3(B + 3 * support(B, nB, dir[j])), dir[j]) + mg;
+    float pj;
+    support_v(A, nA, dir[j], &pj); extA[j] = pj + mg;
+    support_v(B, nB, dir[j], &pj); extB[j] = pj + mg;
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
+    float pj;
     v3 sd = madd(dir[k], n, -1.0f / RV_MAN_TAU);
-    v3 va = ld3(A + 3 * support(A, nA, sd));
+    v3 va = support_v(A, nA, sd, &pj);
     float sep = dot(sub(va, pb), n);
     float gap = sep - 2.0f * mg;
     if (gap <= brk) {
@@ -455,7 +479,7 @@ RV_DEV int collide_pair(Shared& S, const Consts& K, int kind, int a, int b, int 
       if (ok) manifold_add_world(S, K, kind, a, b, col, *m, madd(va, n, -mg), madd(pt, n, mg), n, gap);
     }
     sd = madd(dir[k], n, 1.0f / RV_MAN_TAU);
-    v3 vb = ld3(B + 3 * support(B, nB, sd));
+    v3 vb = support_v(B, nB, sd, &pj);
     sep = dot(sub(pa, vb), n);
     gap = sep - 2.0f * mg;
     if (gap <= brk) {
@@ -478,39 +502,42 @@ RV_DEV float sphere_box_dist2(v3 p, v3 c, v3 h) {
 }
 
 // ------------------------------------------------------------------ PGS --
-RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, const DevMan& m, int i, Row& r) {
+RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, const ManPoint& p, Row& r) {
   const rv_config* c = K.cfg; const DevEnv& e = S.e;
   float dt = c->dt;
   v3 wa, wb;
-  manifold_world_points(S, K, kind, a, b, m, i, &wa, &wb);
+  point_world(S, K, kind, a, b, p, &wa, &wb);
   v3 ra = sub(wa, ld3(e.body[a]));
-  v3 d0 = ld3(m.nrm[i]), d1, d2;
+  v3 d0 = p.nrm, d1, d2;
   plane_space(d0, &d1, &d2);
   v3 vb_pt = mk(0.0f, 0.0f, 0.0f);
   v3 rb = mk(0.0f, 0.0f, 0.0f);
   float imb = 0.0f;
-  if (kind == 1) { rb = sub(wb, ld3(e.body[b])); imb = e.inv_mass[b]; }
+  m3 iia = ldm(S.s.iinv[a]);
+  m3 iib = iia;
+  if (kind == 1) { rb = sub(wb, ld3(e.body[b])); imb = e.inv_mass[b]; iib = ldm(S.s.iinv[b]); }
   if (kind == 2) {
-    int f = K.scene->arm.col_frame[m.col[i]];
+    int f = K.scene->arm.col_frame[p.col];
     vb_pt = add(ld3(S.s.fv[f]), cross(ld3(S.s.fw[f]), sub(wb, ld3(e.fpos[f]))));
   }
+  float ima = e.inv_mass[a];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     v3 dk = k == 0 ? d0 : (k == 1 ? d1 : d2);
     v3 rxa = cross(ra, dk);
-    v3 aa = mulv(S.s.iinv[a], rxa);
-    float kk = e.inv_mass[a] + dot(rxa, aa);
+    v3 aa = mulv(iia, rxa);
+    float kk = ima + dot(rxa, aa);
     v3 rxb = mk(0.0f, 0.0f, 0.0f), ab = mk(0.0f, 0.0f, 0.0f);
     if (kind == 1) {
       rxb = cross(rb, dk);
-      ab = mulv(S.s.iinv[b], rxb);
+      ab = mulv(iib, rxb);
       kk += imb + dot(rxb, ab);
     }
     st3(r.dir[k], dk); st3(r.rxa[k], rxa); st3(r.aa[k], aa); st3(r.rxb[k], rxb); st3(r.ab[k], ab);
     r.invk[k] = 1.0f / kk;
     r.vbc[k] = dot(dk, vb_pt);
   }
-  float dist = m.dist[i];
+  float dist = p.dist;
   if (dist > 0.0f) r.target = -dist / dt;
   else r.target = fminr(c->erp * fmaxr(-dist - c->slop, 0.0f) / dt, c->max_pushout);
   float mub = (kind == 0) ? c->table_friction : (kind == 1 ? e.friction[b] : c->arm_friction);
@@ -536,28 +563,38 @@ RV_DEV float row_jv(const BV& A, const BV* B, const Row& r, int k) {
   else jv -= r.vbc[k];
   return jv;
 }
-RV_DEV void point_solve(BV& A, BV* B, float ima, float imb, DevMan& m, int i, const Row& r) {
+struct Lam { float n, t1, t2; };
+RV_DEV float point_solve(BV& A, BV* B, float ima, float imb, Lam& l, const Row& r) {
   float jv = row_jv(A, B, r, 0);
   float dl = (r.target - jv) * r.invk[0];
-  float ln = fmaxr(m.ln[i] + dl, 0.0f);
-  dl = ln - m.ln[i]; m.ln[i] = ln;
+  float ln = fmaxr(l.n + dl, 0.0f);
+  dl = ln - l.n; l.n = ln;
+  float res = fabsr(dl);
   row_apply(A, B, ima, imb, r, 0, dl);
   float lim = r.mu * ln;
   jv = row_jv(A, B, r, 1);
   dl = -jv * r.invk[1];
-  float l1 = fclampr(m.lt1[i] + dl, -lim, lim);
-  dl = l1 - m.lt1[i]; m.lt1[i] = l1;
+  float l1 = fclampr(l.t1 + dl, -lim, lim);
+  dl = l1 - l.t1; l.t1 = l1;
+  res = fmaxr(res, fabsr(dl));
   row_apply(A, B, ima, imb, r, 1, dl);
   jv = row_jv(A, B, r, 2);
   dl = -jv * r.invk[2];
-  float l2 = fclampr(m.lt2[i] + dl, -lim, lim);
-  dl = l2 - m.lt2[i]; m.lt2[i] = l2;
+  float l2 = fclampr(l.t2 + dl, -lim, lim);
+  dl = l2 - l.t2; l.t2 = l2;
+  res = fmaxr(res, fabsr(dl));
   row_apply(A, B, ima, imb, r, 2, dl);
+  return res;
+}
+RV_DEV void warm_apply(BV& A, BV* B, float ima, float imb, const Lam& l, const Row& r) {
+  row_apply(A, B, ima, imb, r, 0, l.n); row_apply(A, B, ima, imb, r, 1, l.t1); row_apply(A, B, ima, imb, r, 2, l.t2);
 }
 
 // ---------------------------------------------------- Simulator.step -----
 // One dt of Simulator.step (simulator.py:94-103): the arm's
 // ControllableBody.update, then the physics step, then num_steps += 1.
+// K.stop_after (profiling hook, 0 = off): return after a given phase group so that
+// per-phase costs can be read off as differences (tools/prof_phases.sh)
 RV_DEV void sim_substep(Shared& S, const Consts& K) {
   const rv_config* c = K.cfg;
   const rv_arm* arm = &K.scene->arm;
@@ -618,7 +655,8 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
     RV_LANES_END
   }
 
-  // collider geometry + body velocity update + rotations
+  if (K.stop_after == 1) return;
+  // collider geometry
   RV_LANES_BEGIN
     if (arm_on) {
       for (int item = lane; item < RV_NCOL * 8; item += 64) {
@@ -636,14 +674,45 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
         S.s.colflag[col] = 0;
       }
     }
-    if (lane >= 16 && lane < 16 + RV_MAXB) {
-      int b = lane - 16; DevEnv& e = S.e;
+  RV_LANES_END
+
+  // wake sleeping bodies that an awake body or an arm collider comes near
+  RV_LANES_BEGIN
+    if (lane < RV_MAXB) {
+      int b = lane; const DevEnv& e = S.e;
+      int wk = 0;
+      if (body_present(e, b) && e.asleep[b]) {
+        v3 pb = ld3(e.body[b]);
+        for (int a = 0; a < RV_MAXB; ++a) {
+          // only a MOVING neighbour wakes a sleeper (resting neighbours would ping-pong)
+          if (a == b || !body_on(e, a) || e.sleep_count[a] > 0) continue;
+          v3 d = sub(ld3(e.body[a]), pb);
+          float r = e.radius[a] + e.radius[b] + c->breaking;
+          if (dot(d, d) < r * r) wk = 1;
+        }
+        if (arm_on)
+          for (int col = 0; col < RV_NCOL; ++col) {
+            v3 d = sub(pb, ld3(S.s.colc[col]));
+            float r = e.radius[b] + S.s.colr[col] + c->breaking;
+            if (dot(d, d) < r * r) wk = 1;
+          }
+      }
+      S.s.wake[b] = wk;
+    }
+  RV_LANES_END
+
+  // body velocity update + rotations
+  RV_LANES_BEGIN
+    if (lane < RV_MAXB) {
+      int b = lane; DevEnv& e = S.e;
+      if (S.s.wake[b]) { e.asleep[b] = 0; e.sleep_count[b] = 0; }
       if (body_on(e, b)) {
         float dt = c->dt;
         e.body[b][9] += c->gravity_z * dt;
         v3 v = scale(ld3(e.body[b] + 7), c->lin_damp);
         v3 w = scale(ld3(e.body[b] + 10), c->ang_damp);
         st3(e.body[b] + 7, v); st3(e.body[b] + 10, w);
+        S.s.mot[b] = (len(v) + len(w) * e.radius[b]) * dt;
         m3 m = qmat(ldq(e.body[b] + 3));
         stm(S.s.rot[b], m);
         const float* ii = e.inv_inertia[b];
@@ -656,6 +725,11 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
 
   // hull vertices to world frame
   RV_LANES_BEGIN
+    if (lane == 63) {
+      int aw = 0;
+      for (int b = 0; b < RV_MAXB; ++b) aw |= body_on(S.e, b);
+      S.e.awake_last += aw;
+    }
     for (int item = lane; item < RV_MAXB * RV_MAXH * RV_MAXV; item += 64) {
       int b = item / (RV_MAXH * RV_MAXV), h = (item / RV_MAXV) % RV_MAXH, i = item % RV_MAXV;
       if (!body_on(S.e, b)) continue;
@@ -667,101 +741,117 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
     }
   RV_LANES_END
 
-  // manifold refresh: one lane per manifold slot
-  RV_LANES_BEGIN
-    if (lane < RV_NMAN) {
-      DevEnv& e = S.e;
-      if (lane < RV_MAXB) {
-        int b = lane;
-        if (!body_on(e, b)) e.man[RV_TIDX(b)].n = 0;
-        else manifold_refresh(S, K, 0, b, -1, e.man[RV_TIDX(b)]);
-      } else if (lane < RV_MAXB + RV_NBB) {
-        int k = lane - RV_MAXB; int a = bb_a(k), b = bb_b(k);
-        if (!(body_on(e, a) && body_on(e, b))) e.man[RV_BBIDX(k)].n = 0;
-        else manifold_refresh(S, K, 1, a, b, e.man[RV_BBIDX(k)]);
-      } else {
-        int b = lane - RV_MAXB - RV_NBB;
-        if (!body_on(e, b) || !arm_on) e.man[RV_AIDX(b)].n = 0;
-        else manifold_refresh(S, K, 2, b, -1, e.man[RV_AIDX(b)]);
-      }
-    }
-  RV_LANES_END
-
-  // narrow phase: one lane per manifold owner (+ arm-table detection lanes)
+  if (K.stop_after == 2) return;
+  // manifold refresh + narrow phase: one lane per manifold owner (+ arm-table
+  // detection lanes).  The lane's manifold lives in registers for the whole
+  // phase; every role walks its list of convex pairs through ONE collide_pair
+  // call site, so body-table, body-body, arm-body and arm-table queries of a
+  // substep run side by side in the wave.
   RV_LANES_BEGIN
     DevEnv& e = S.e;
     float brk = c->breaking;
     v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
     v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
+    int role = -1, a = 0, b = -1, mi = 0, n_outer = 0, n_inner = 0;
+    int clear = 0, live = 0;     // live: manifold is loaded, refreshed and stored
+    const rv_shape* sa = nullptr; const rv_shape* sb = nullptr;
+    v3 guess0 = mk(0.0f, 0.0f, 1.0f);
     if (lane < RV_MAXB) {
-      int b = lane;
-      if (body_on(e, b)) {
-        float r = e.radius[b] + brk;
-        if (!(sphere_box_dist2(ld3(e.body[b]), tc, th) >= r * r)) {
-          const rv_shape* s = &K.scene->shapes[e.shape[b]];
-          v3 guess = mk(0.0f, 0.0f, e.body[b][2] - tc.z);
-          for (int h = 0; h < s->n_hulls; ++h) {
-            float d;
-            collide_pair(S, K, 0, b, -1, -1, &S.s.wv[b][h][0][0], s->n_verts[h], &S.s.tablev[0][0], 8, guess, &e.man[RV_TIDX(b)], &d);
-          }
+      a = lane; mi = RV_TIDX(a);
+      if (!body_present(e, a)) clear = 1;
+      else if (!e.asleep[a]) {
+        live = 1;
+        float r = e.radius[a] + brk;
+        if (!(sphere_box_dist2(ld3(e.body[a]), tc, th) >= r * r)) {
+          role = 0; sa = &K.scene->shapes[e.shape[a]]; n_outer = 1; n_inner = sa->n_hulls;
+          guess0 = mk(0.0f, 0.0f, e.body[a][2] - tc.z);
         }
       }
     } else if (lane < RV_MAXB + RV_NBB) {
-      int k = lane - RV_MAXB; int a = bb_a(k), b = bb_b(k);
-      if (body_on(e, a) && body_on(e, b)) {
+      int k = lane - RV_MAXB; a = bb_a(k); b = bb_b(k); mi = RV_BBIDX(k);
+      if (!(body_present(e, a) && body_present(e, b))) clear = 1;
+      else if (!e.asleep[a] && !e.asleep[b]) {
+        live = 1;
         v3 d = sub(ld3(e.body[a]), ld3(e.body[b]));
         float r = e.radius[a] + e.radius[b] + brk;
         if (!(dot(d, d) >= r * r)) {
-          const rv_shape* sa = &K.scene->shapes[e.shape[a]];
-          const rv_shape* sb = &K.scene->shapes[e.shape[b]];
-          for (int ha = 0; ha < sa->n_hulls; ++ha)
-            for (int hb = 0; hb < sb->n_hulls; ++hb) {
-              float dd;
-              collide_pair(S, K, 1, a, b, -1, &S.s.wv[a][ha][0][0], sa->n_verts[ha], &S.s.wv[b][hb][0][0], sb->n_verts[hb], d, &e.man[RV_BBIDX(k)], &dd);
-            }
+          role = 1; sa = &K.scene->shapes[e.shape[a]]; sb = &K.scene->shapes[e.shape[b]];
+          n_outer = sa->n_hulls; n_inner = sb->n_hulls; guess0 = d;
         }
       }
     } else if (lane < RV_NMAN) {
-      int b = lane - RV_MAXB - RV_NBB;
-      if (arm_on && body_on(e, b)) {
-        const rv_shape* s = &K.scene->shapes[e.shape[b]];
-        for (int col = 0; col < RV_NCOL; ++col) {
-          v3 d = sub(ld3(e.body[b]), ld3(S.s.colc[col]));
-          float r = e.radius[b] + S.s.colr[col] + brk;
-          if (dot(d, d) >= r * r) continue;
-          for (int h = 0; h < s->n_hulls; ++h) {
-            float dd;
-            collide_pair(S, K, 2, b, -1, col, &S.s.wv[b][h][0][0], s->n_verts[h], &S.s.colv[col][0][0], 8, d, &e.man[RV_AIDX(b)], &dd);
-          }
-        }
+      a = lane - RV_MAXB - RV_NBB; mi = RV_AIDX(a);
+      if (!body_present(e, a)) clear = 1;
+      else if (!e.asleep[a]) {
+        if (!arm_on) clear = 1;
+        else { live = 1; role = 2; sa = &K.scene->shapes[e.shape[a]]; n_outer = RV_NCOL; n_inner = sa->n_hulls; }
       }
     } else if (lane < RV_NMAN + RV_NCOL) {
       // arm - table: detection only (push_env.py:839-855)
       int col = lane - RV_NMAN;
       if (arm_on) {
         float r = S.s.colr[col] + brk;
-        if (sphere_box_dist2(ld3(S.s.colc[col]), tc, th) < r * r) {
-          float dd;
-          if (collide_pair(S, K, 0, 0, -1, col, &S.s.colv[col][0][0], 8, &S.s.tablev[0][0], 8, mk(0.0f, 0.0f, 1.0f), nullptr, &dd))
-            if (dd < c->contact_query_dist) S.s.colflag[col] = 1;
-        }
+        float minz = S.s.colv[col][0][2];
+        for (int k = 1; k < 8; ++k) minz = fminr(minz, S.s.colv[col][k][2]);
+        // exact rejection: the flag needs dist < query_dist and dist >= minz - table_z - margin
+        if (!(minz - e.table_z - c->margin >= c->contact_query_dist) &&
+            sphere_box_dist2(ld3(S.s.colc[col]), tc, th) < r * r) { role = 3; a = col; n_outer = 1; n_inner = 1; }
       }
+    }
+    if (clear) e.man[mi].n = 0;
+    if (live) {
+      DevMan& m = e.man[mi];
+      int lost = manifold_refresh(S, K, lane < RV_MAXB ? 0 : (lane < RV_MAXB + RV_NBB ? 1 : 2), a, b, m);
+      if (lane < RV_MAXB + RV_NBB) {
+        // narrow-phase gating (body-table and body-body pairs)
+        float mo = S.s.mot[a];
+        if (b >= 0) mo = mo + S.s.mot[b];
+        float acc = m.acc + mo; int age = m.age + 1;
+        int run = (c->np_max_age <= 0) || m.n == 0 || lost > 0 || acc > c->np_gate || (e.sim_steps % c->np_max_age) == 0;
+        if (run) { acc = 0.0f; age = 0; } else { n_outer = 0; n_inner = 0; }
+        m.acc = acc; m.age = age;
+      }
+    }
+    const int n_pairs = n_outer * n_inner;
+    for (int t = 0; t < n_pairs; ++t) {
+      int io = t / n_inner, ii = t - io * n_inner;
+      const float* A; const float* B; int nA, nB, ckind, col = -1;
+      v3 guess = guess0;
+      if (role == 0) { A = &S.s.wv[a][ii][0][0]; nA = sa->n_verts[ii]; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
+      else if (role == 1) { A = &S.s.wv[a][io][0][0]; nA = sa->n_verts[io]; B = &S.s.wv[b][ii][0][0]; nB = sb->n_verts[ii]; ckind = 1; }
+      else if (role == 2) {
+        col = io;
+        v3 d = sub(ld3(e.body[a]), ld3(S.s.colc[col]));
+        float r = e.radius[a] + S.s.colr[col] + brk;
+        if (dot(d, d) >= r * r) continue;
+        A = &S.s.wv[a][ii][0][0]; nA = sa->n_verts[ii]; B = &S.s.colv[col][0][0]; nB = 8; ckind = 2; guess = d;
+      } else { col = a; A = &S.s.colv[col][0][0]; nA = 8; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
+      float dd;
+      int hit = collide_pair(S, K, ckind, role == 3 ? 0 : a, b, col, A, nA, B, nB, guess, role == 3 ? nullptr : &e.man[mi], &dd);
+      if (role == 3 && hit && dd < c->contact_query_dist) S.s.colflag[col] = 1;
     }
   RV_LANES_END
 
+  if (K.stop_after == 3) return;
   // solver row setup (one lane per contact point) + contact flags
   RV_LANES_BEGIN
     DevEnv& e = S.e;
     if (lane < RV_NMAN * 4) {
       int mi = lane >> 2, i = lane & 3;
       DevMan& m = e.man[mi];
-      if (i < m.n) {
-        int kind, a, b = -1;
-        if (mi < RV_MAXB) { kind = 0; a = mi; }
-        else if (mi < RV_MAXB + RV_NBB) { kind = 1; a = bb_a(mi - RV_MAXB); b = bb_b(mi - RV_MAXB); }
-        else { kind = 2; a = mi - RV_MAXB - RV_NBB; }
-        row_setup(S, K, kind, a, b, m, i, S.s.u.rows[mi][i]);
-        m.ln[i] *= c->warmstart; m.lt1[i] *= c->warmstart; m.lt2[i] *= c->warmstart;
+      int kind, a, b = -1;
+      if (mi < RV_MAXB) { kind = 0; a = mi; }
+      else if (mi < RV_MAXB + RV_NBB) { kind = 1; a = bb_a(mi - RV_MAXB); b = bb_b(mi - RV_MAXB); }
+      else { kind = 2; a = mi - RV_MAXB - RV_NBB; }
+      int use = body_on(e, a) && (kind != 1 || body_on(e, b));
+      if (use && i < m.n) {
+        ManPoint p;
+        p.la = ld3(m.la[i]); p.lb = ld3(m.lb[i]); p.nrm = ld3(m.nrm[i]); p.dist = m.dist[i]; p.col = m.col[i];
+        p.ln = m.ln[i]; p.lt1 = m.lt1[i]; p.lt2 = m.lt2[i];
+        Row r;
+        row_setup(S, K, kind, a, b, p, r);
+        S.s.u.rows[mi][i] = r;
+        m.ln[i] = p.ln * c->warmstart; m.lt1[i] = p.lt1 * c->warmstart; m.lt2[i] = p.lt2 * c->warmstart;
       }
     } else if (lane == 56) {
       int f = 0;
@@ -777,55 +867,115 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
     }
   RV_LANES_END
 
-  // warm start (pass 0) and PGS iterations: body-vs-static/kinematic contacts
-  // are solved one lane per body; body-body contacts by colour rounds.
-  for (int it = -1; it < c->solver_iters; ++it) {
+  if (K.stop_after == 4) return;
+  // PGS.  Bodies that are not coupled by a body-body contact are independent
+  // problems: each body lane runs warm start + all its iterations in ONE phase
+  // with rows and impulses in registers, stopping when ITS largest impulse
+  // change drops below solver_tol.  With body-body contacts the iterations are
+  // interleaved with colour rounds and the stop test uses the env-wide residual.
+  int n_rows = 0, any_bb = 0;
+  for (int b = 0; b < RV_MAXB; ++b)
+    if (body_on(S.e, b)) n_rows += S.e.man[RV_TIDX(b)].n + S.e.man[RV_AIDX(b)].n;
+  for (int k = 0; k < RV_NBB; ++k)
+    if (body_on(S.e, bb_a(k)) && body_on(S.e, bb_b(k))) any_bb += S.e.man[RV_BBIDX(k)].n;
+  n_rows += any_bb;
+  if (n_rows > 0 && !any_bb) {
     RV_LANES_BEGIN
       if (lane < RV_MAXB) {
         int b = lane; DevEnv& e = S.e;
         DevMan& mt = e.man[RV_TIDX(b)];
         DevMan& ma = e.man[RV_AIDX(b)];
-        if (mt.n + ma.n > 0) {
+        const int nt = mt.n, na = ma.n;
+        if (body_on(e, b) && nt + na > 0) {
           BV A = ld_bv(e, b); float ima = e.inv_mass[b];
-          for (int i = 0; i < mt.n; ++i) {
-            const Row& r = S.s.u.rows[RV_TIDX(b)][i];
-            if (it < 0) { row_apply(A, nullptr, ima, 0.0f, r, 0, mt.ln[i]); row_apply(A, nullptr, ima, 0.0f, r, 1, mt.lt1[i]); row_apply(A, nullptr, ima, 0.0f, r, 2, mt.lt2[i]); }
-            else point_solve(A, nullptr, ima, 0.0f, mt, i, r);
+          Lam lt[4], la[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            lt[i].n = mt.ln[i]; lt[i].t1 = mt.lt1[i]; lt[i].t2 = mt.lt2[i];
+            la[i].n = ma.ln[i]; la[i].t1 = ma.lt1[i]; la[i].t2 = ma.lt2[i];
           }
-          for (int i = 0; i < ma.n; ++i) {
-            const Row& r = S.s.u.rows[RV_AIDX(b)][i];
-            if (it < 0) { row_apply(A, nullptr, ima, 0.0f, r, 0, ma.ln[i]); row_apply(A, nullptr, ima, 0.0f, r, 1, ma.lt1[i]); row_apply(A, nullptr, ima, 0.0f, r, 2, ma.lt2[i]); }
-            else point_solve(A, nullptr, ima, 0.0f, ma, i, r);
+          // rows are re-read from LDS by value (one batched load per point);
+          // only the impulses and the body velocity stay in registers
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (i < nt) { Row r = S.s.u.rows[RV_TIDX(b)][i]; warm_apply(A, nullptr, ima, 0.0f, lt[i], r); }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (i < na) { Row r = S.s.u.rows[RV_AIDX(b)][i]; warm_apply(A, nullptr, ima, 0.0f, la[i], r); }
+          for (int it = 0; it < c->solver_iters; ++it) {
+            float res = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nt) { Row r = S.s.u.rows[RV_TIDX(b)][i]; res = fmaxr(res, point_solve(A, nullptr, ima, 0.0f, lt[i], r)); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < na) { Row r = S.s.u.rows[RV_AIDX(b)][i]; res = fmaxr(res, point_solve(A, nullptr, ima, 0.0f, la[i], r)); }
+            if (res < c->solver_tol) break;
           }
           st_bv(e, b, A);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i < nt) { mt.ln[i] = lt[i].n; mt.lt1[i] = lt[i].t1; mt.lt2[i] = lt[i].t2; }
+            if (i < na) { ma.ln[i] = la[i].n; ma.lt1[i] = la[i].t1; ma.lt2[i] = la[i].t2; }
+          }
         }
       }
     RV_LANES_END
-    const int any_bb = S.e.man[RV_BBIDX(0)].n | S.e.man[RV_BBIDX(1)].n | S.e.man[RV_BBIDX(2)].n |
-                       S.e.man[RV_BBIDX(3)].n | S.e.man[RV_BBIDX(4)].n | S.e.man[RV_BBIDX(5)].n;
-    if (any_bb) {
+  } else if (n_rows > 0) {
+    for (int it = -1; it < c->solver_iters; ++it) {
+      RV_LANES_BEGIN
+        if (lane < 16) S.s.res[lane] = 0.0f;
+        if (lane < RV_MAXB) {
+          int b = lane; DevEnv& e = S.e;
+          DevMan& mt = e.man[RV_TIDX(b)];
+          DevMan& ma = e.man[RV_AIDX(b)];
+          if (body_on(e, b) && mt.n + ma.n > 0) {
+            BV A = ld_bv(e, b); float ima = e.inv_mass[b];
+            float res = 0.0f;
+            for (int i = 0; i < mt.n; ++i) {
+              Row r = S.s.u.rows[RV_TIDX(b)][i];
+              Lam l; l.n = mt.ln[i]; l.t1 = mt.lt1[i]; l.t2 = mt.lt2[i];
+              if (it < 0) warm_apply(A, nullptr, ima, 0.0f, l, r);
+              else { res = fmaxr(res, point_solve(A, nullptr, ima, 0.0f, l, r)); mt.ln[i] = l.n; mt.lt1[i] = l.t1; mt.lt2[i] = l.t2; }
+            }
+            for (int i = 0; i < ma.n; ++i) {
+              Row r = S.s.u.rows[RV_AIDX(b)][i];
+              Lam l; l.n = ma.ln[i]; l.t1 = ma.lt1[i]; l.t2 = ma.lt2[i];
+              if (it < 0) warm_apply(A, nullptr, ima, 0.0f, l, r);
+              else { res = fmaxr(res, point_solve(A, nullptr, ima, 0.0f, l, r)); ma.ln[i] = l.n; ma.lt1[i] = l.t1; ma.lt2[i] = l.t2; }
+            }
+            st_bv(e, b, A);
+            S.s.res[b] = res;
+          }
+        }
+      RV_LANES_END
       for (int rd = 0; rd < 3; ++rd) {
         RV_LANES_BEGIN
           if (lane < 2) {
             int k = bb_round_pair(rd, lane); DevEnv& e = S.e;
             DevMan& m = e.man[RV_BBIDX(k)];
-            if (m.n > 0) {
-              int a = bb_a(k), b = bb_b(k);
+            int a = bb_a(k), b = bb_b(k);
+            if (m.n > 0 && body_on(e, a) && body_on(e, b)) {
               BV A = ld_bv(e, a), B = ld_bv(e, b);
               float ima = e.inv_mass[a], imb = e.inv_mass[b];
+              float res = 0.0f;
               for (int i = 0; i < m.n; ++i) {
-                const Row& r = S.s.u.rows[RV_BBIDX(k)][i];
-                if (it < 0) { row_apply(A, &B, ima, imb, r, 0, m.ln[i]); row_apply(A, &B, ima, imb, r, 1, m.lt1[i]); row_apply(A, &B, ima, imb, r, 2, m.lt2[i]); }
-                else point_solve(A, &B, ima, imb, m, i, r);
+                Row r = S.s.u.rows[RV_BBIDX(k)][i];
+                Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
+                if (it < 0) warm_apply(A, &B, ima, imb, l, r);
+                else { res = fmaxr(res, point_solve(A, &B, ima, imb, l, r)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
               }
               st_bv(e, a, A); st_bv(e, b, B);
+              S.s.res[4 + rd * 2 + lane] = res;
             }
           }
         RV_LANES_END
       }
+      if (it >= 0) {
+        float res = 0.0f;
+        for (int k = 0; k < 10; ++k) res = fmaxr(res, S.s.res[k]);
+        if (res < c->solver_tol) break;
+      }
     }
   }
 
+  if (K.stop_after == 5) return;
   // integrate positions, freeze fallen bodies, counters
   RV_LANES_BEGIN
     DevEnv& e = S.e;
@@ -846,11 +996,29 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
           e.frozen[b] = 1;
           st3(e.body[b] + 7, mk(0, 0, 0)); st3(e.body[b] + 10, mk(0, 0, 0));
         }
+        if (c->sleep_steps > 0) {   // deactivation counter
+          if (dot(v, v) < c->sleep_lin * c->sleep_lin && dot(w, w) < c->sleep_ang * c->sleep_ang) e.sleep_count[b]++;
+          else e.sleep_count[b] = 0;
+          if (e.sleep_count[b] >= c->sleep_steps) {
+            e.asleep[b] = 1;
+            st3(e.body[b] + 7, mk(0, 0, 0)); st3(e.body[b] + 10, mk(0, 0, 0));
+          }
+        }
       }
     }
     if (lane == 32) { e.sim_steps++; e.substeps_last++; }
   RV_LANES_END
 }
+
+// The env block lives in ONE statically addressed LDS object so that the
+// (large) substep body can be a real function with a single copy in the
+// instruction stream instead of being inlined at every call site.
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+__shared__ Shared g_shared;
+#else
+static thread_local Shared g_shared;
+#endif
+RV_DEV_NOINLINE void sim_substep_call(Consts K) { sim_substep(g_shared, K); }
 
 // Simulator.check_stable over a body mask (simulator.py:289-323)
 RV_DEV int bodies_stable(const DevEnv& e, unsigned mask, float lin_thr, float ang_thr) {
@@ -873,7 +1041,7 @@ RV_DEV void wait_until_stable(Shared& S, const Consts& K, unsigned mask, float l
     if (lane == 0) { S.s.wus_steps = 0; S.s.wus_stable = 0; S.s.loop_break = 0; }
   RV_LANES_END
   for (;;) {
-    sim_substep(S, K);
+    sim_substep_call(K);
     RV_LANES_BEGIN
       if (lane == 0) {
         S.s.wus_steps++;
@@ -1048,7 +1216,7 @@ RV_DEV void env_step(Shared& S, const Consts& K) {
   RV_LANES_BEGIN
     if (lane == 0) {
       DevEnv& e = S.e; Scratch& s = S.s;
-      e.substeps_last = 0; e.stepped = 1;
+      e.substeps_last = 0; e.awake_last = 0; e.stepped = 1;
       int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
       for (int g = 0; g < G; ++g) compute_waypoints(c, e.action[g], s.wp[g][0], s.wp[g][1]);
       e.is_safe = 1; e.is_effective = 1;
@@ -1061,7 +1229,7 @@ RV_DEV void env_step(Shared& S, const Consts& K) {
     }
   RV_LANES_END
   while (S.e.phase != RV_PHASE_DONE) {
-    sim_substep(S, K);
+    sim_substep_call(K);
     if (S.e.sim_steps % c->steps_check != 0) continue;
     RV_LANES_BEGIN
       if (lane == 0) phase_tick(S, K);
@@ -1159,7 +1327,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid) {
     if (lane == 0) {
       S.s.rng = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RESET, (uint32_t)e.reset_count);
       e.reset_count++;
-      e.substeps_last = 0; e.stepped = 0;
+      e.substeps_last = 0; e.awake_last = 0; e.stepped = 0;
       e.sim_steps = 0; e.num_steps = 0; e.episode_reward = 0.0f; e.last_reward = 0.0f;
       e.done = 0; e.phase = RV_PHASE_INITIAL; e.is_safe = 1; e.is_effective = 1;
       e.arm_enabled = 0;
@@ -1180,7 +1348,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid) {
     RV_LANES_BEGIN
       DevEnv& e = S.e;
       if (lane == 0) {
-        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; }
+        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; }
         sample_poses(S, K, e.n_bodies);
       }
       if (lane >= 1 && lane <= RV_NMAN) e.man[lane - 1].n = 0;
@@ -1194,7 +1362,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid) {
           int shape = use_target ? c->target_shapes[rng_randint(g, c->n_target_shapes)]
                                  : c->movable_shapes[rng_randint(g, c->n_movable_shapes)];
           float sc = rng_uniform(g, c->scale_range[0], c->scale_range[1]);
-          e.active[i] = 1; e.frozen[i] = 0; e.shape[i] = shape; e.scale[i] = sc; e.friction[i] = c->drop_friction;
+          e.active[i] = 1; e.frozen[i] = 0; e.asleep[i] = 0; e.sleep_count[i] = 0; e.shape[i] = shape; e.scale[i] = sc; e.friction[i] = c->drop_friction;
           body_set_mass(e, K, i, c->drop_mass);
           for (int k = 0; k < 3; ++k) e.body[i][k] = S.s.poses[i][k];
           for (int k = 0; k < 4; ++k) e.body[i][3 + k] = S.s.poses[i][3 + k];

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include <string>
 #include <new>
 
@@ -29,14 +30,15 @@ struct EnvKernelArgs {
   int n_substeps;
   float lin_thr, ang_thr;
   int check_after, min_stable, max_steps;
+  int stop_after;   // profiling hook (env RV_DEBUG_STOP, MODE_SUB only)
 };
 
 template <int MODE>
 __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
-  __shared__ Shared S;
+  Shared& S = g_shared;
   const int env = (int)blockIdx.x;
   if (env >= args.n_envs) return;
-  Consts K; K.cfg = args.cfg; K.scene = args.scene;
+  Consts K; K.cfg = args.cfg; K.scene = args.scene; K.stop_after = (MODE == MODE_SUB) ? args.stop_after : 0;
   DevEnv* g = args.envs + env;
   const int lane = (int)threadIdx.x;
   constexpr int W = (int)(sizeof(DevEnv) / 4);
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   __syncthreads();
   if (MODE == MODE_MACRO) skip = (S.e.done != 0);
   if (skip) {
-    if (lane == 0) { g->substeps_last = 0; g->stepped = 0; }
+    if (lane == 0) { g->substeps_last = 0; g->awake_last = 0; g->stepped = 0; }
     return;
   }
   if (MODE != MODE_RESET) env_enter(S, K);
@@ -59,11 +61,11 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   } else if (MODE == MODE_MACRO) {
     env_step(S, K);
   } else if (MODE == MODE_SUB) {
-    if (lane == 0) { S.e.substeps_last = 0; S.e.stepped = 0; }
+    if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.stepped = 0; }
     __syncthreads();
-    for (int k = 0; k < args.n_substeps; ++k) sim_substep(S, K);
+    for (int k = 0; k < args.n_substeps; ++k) sim_substep_call(K);
   } else {
-    if (lane == 0) { S.e.substeps_last = 0; S.e.stepped = 0; }
+    if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.stepped = 0; }
     __syncthreads();
     wait_until_stable(S, K, 0u, args.lin_thr, args.ang_thr, args.check_after, args.min_stable, args.max_steps);
   }
@@ -93,6 +95,7 @@ __global__ void k_set_body_state(DevEnv* envs, int n, const float* in) {
   ENV_THREAD();
   for (int b = 0; b < RV_MAXB; ++b) for (int k = 0; k < 13; ++k) e.body[b][k] = in[((size_t)i * RV_MAXB + b) * 13 + k];
   for (int m = 0; m < RV_NMAN; ++m) e.man[m].n = 0;
+  for (int b = 0; b < RV_MAXB; ++b) { e.asleep[b] = 0; e.sleep_count[b] = 0; }
 }
 __global__ void k_get_body_params(const DevEnv* envs, int n, float* out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
@@ -100,16 +103,16 @@ __global__ void k_get_body_params(const DevEnv* envs, int n, float* out) {
   for (int b = 0; b < RV_MAXB; ++b) {
     float* o = out + ((size_t)i * RV_MAXB + b) * 8;
     o[0] = (float)e.active[b]; o[1] = (float)e.shape[b]; o[2] = e.scale[b]; o[3] = e.mass[b]; o[4] = e.friction[b];
-    o[5] = (float)e.frozen[b]; o[6] = e.table_z; o[7] = 0.0f;
+    o[5] = (float)e.frozen[b]; o[6] = e.table_z; o[7] = (float)e.asleep[b];
   }
 }
 __global__ void k_set_body_params(DevEnv* envs, int n, const float* in, const rv_config* cfg, const rv_scene* scene) {
   ENV_THREAD();
-  Consts K; K.cfg = cfg; K.scene = scene;
+  Consts K; K.cfg = cfg; K.scene = scene; K.stop_after = 0;
   int nb = 0;
   for (int b = 0; b < RV_MAXB; ++b) {
     const float* o = in + ((size_t)i * RV_MAXB + b) * 8;
-    e.active[b] = (int)o[0]; e.shape[b] = (int)o[1]; e.scale[b] = o[2]; e.friction[b] = o[4]; e.frozen[b] = (int)o[5];
+    e.active[b] = (int)o[0]; e.shape[b] = (int)o[1]; e.scale[b] = o[2]; e.friction[b] = o[4]; e.frozen[b] = (int)o[5]; e.asleep[b] = 0; e.sleep_count[b] = 0;
     if (b == 0) e.table_z = o[6];
     if (e.active[b]) { body_set_mass(e, K, b, o[3]); nb++; }
   }
@@ -150,7 +153,8 @@ __global__ void k_get_link_poses(const DevEnv* envs, int n, float* out) {
 }
 __global__ void k_get_env_counters(const DevEnv* envs, int n, int32_t* out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
-  const DevEnv& e = envs[i]; int32_t* o = out + (size_t)i * 8;
+  const DevEnv& e = envs[i]; int32_t* o = out + (size_t)i * RV_NCOUNTERS;
+  o[8] = e.awake_last; o[9] = e.reset_count;
   o[0] = e.sim_steps; o[1] = e.num_steps; o[2] = e.num_episodes; o[3] = e.phase; o[4] = e.done; o[5] = e.is_safe; o[6] = e.is_effective; o[7] = e.substeps_last;
 }
 __global__ void k_set_actions(DevEnv* envs, int n, const float* a, int G) {
@@ -181,7 +185,7 @@ __global__ void k_set_link_target(DevEnv* envs, int n, const float* pose, const 
 }
 __global__ void k_compute_ik(const DevEnv* envs, int n, const float* pose, float* q, const rv_config* cfg, const rv_scene* scene) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
-  Consts K; K.cfg = cfg; K.scene = scene;
+  Consts K; K.cfg = cfg; K.scene = scene; K.stop_after = 0;
   float p[7], q0[RV_NLIMB], out[RV_NLIMB];
   for (int k = 0; k < 7; ++k) p[k] = pose[(size_t)i * 7 + k];
   for (int j = 0; j < RV_NLIMB; ++j) q0[j] = envs[i].q[j];
@@ -313,6 +317,7 @@ __global__ void k_stats(const DevEnv* envs, int n, rv_macro_stats* st, float suc
   if (e.substeps_last > 0) {
     atomicAdd((u64*)&st->substeps, (u64)e.substeps_last);
     atomicMax((u64*)&st->max_substeps, (u64)e.substeps_last);
+    atomicAdd((u64*)&st->awake_substeps, (u64)e.awake_last);
   }
   if (e.stepped) {
     atomicAdd((u64*)&st->env_steps, (u64)1);
@@ -352,6 +357,7 @@ template <int MODE>
 static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, float ang, int ca, int ms, int mx) {
   EnvKernelArgs a;
   a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.mask = mask; a.n_envs = w->n;
+  { const char* ds = getenv("RV_DEBUG_STOP"); a.stop_after = ds ? atoi(ds) : 0; }
   a.n_substeps = n_sub; a.lin_thr = lin; a.ang_thr = ang; a.check_after = ca; a.min_stable = ms; a.max_steps = mx;
   HIPCHK(hipMemsetAsync(w->d_stats, 0, sizeof(rv_macro_stats), w->stream));
   HIPCHK(hipEventRecord(w->ev0, w->stream));

@@ -14,7 +14,7 @@ import numpy as np
 from robovat_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librovat_hip.so')
+LIB_PATH = os.environ.get('RV_LIB', os.path.join(_HERE, 'librovat_hip.so'))
 CSRC = os.path.join(_HERE, 'csrc')
 HIPCC_FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off',
                '-fPIC', '-shared']
@@ -210,7 +210,7 @@ class World(object):
         return self._get('rv_get_link_poses', (self.n, abi.RV_NFRAME, 7), self.torch.float32)
 
     def env_counters(self):
-        return self._get('rv_get_env_counters', (self.n, 8), self.torch.int32)
+        return self._get('rv_get_env_counters', (self.n, abi.RV_NCOUNTERS), self.torch.int32)
 
     def set_joint_targets(self, q):
         check(self.lib.rv_set_joint_targets(self.h, self._ptr(self._in(q, (self.n, abi.RV_NLIMB), self.torch.float32))))

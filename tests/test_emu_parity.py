@@ -38,7 +38,7 @@ class Emu(object):
 
     def body_state(self): return self._get('emu_get_body_state', (self.n, abi.RV_MAXB, 13), np.float32)
     def joint_state(self): return self._get('emu_get_joint_state', (self.n, abi.RV_NJ, 2), np.float32)
-    def counters(self): return self._get('emu_get_env_counters', (self.n, 8), np.int32)
+    def counters(self): return self._get('emu_get_env_counters', (self.n, abi.RV_NCOUNTERS), np.int32)
     def manifolds(self): return self._get('emu_get_manifold_counts', (self.n, abi.RV_NMAN), np.int32)
     def link_poses(self): return self._get('emu_get_link_poses', (self.n, abi.RV_NFRAME, 7), np.float32)
 
