@@ -241,7 +241,7 @@ int  rv_get_joint_state(rv_world* w, float* d_out /* [N][RV_NJ][2] */);
 int  rv_set_joint_state(rv_world* w, const float* d_in /* [N][RV_NJ][2] */);
 int  rv_get_link_poses(rv_world* w, float* d_out /* [N][RV_NFRAME][7] */);
 #define RV_NCOUNTERS 10
-int  rv_get_env_counters(rv_world* w, int32_t* d_out /* [N][RV_NCOUNTERS]: sim_steps, num_steps, num_episodes, phase, done, is_safe, is_effective, substeps_last, awake_substeps_last, reset_count */);
+int  rv_get_env_counters(rv_world* w, int32_t* d_out /* [N][RV_NCOUNTERS]: sim_steps, num_steps, num_episodes, phase, done, is_safe, is_effective, substeps_last, awake_substeps_last, narrowphase_pairs_last */);
 
 /* ---- ControllableBody.set_target_joint_positions / set_target_link_pose
  *      (controllable_body.py:263-345) via RobotCommand (simulator.py:226-244). */

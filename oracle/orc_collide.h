@@ -19,6 +19,7 @@
 
 #define GJK_MAX_ITERS 32
 #define GJK_REL_TOL R(1e-4)
+#define GJK_PROGRESS_TOL R(1e-6)
 #define EPA_MAX_VERTS 24
 #define EPA_MAX_FACES 48
 #define EPA_MAX_EDGES 32
@@ -167,9 +168,11 @@ static inline void orc_epa(const real (*A)[3], int nA, const real (*B)[3], int n
     v3sub(e1, W[j], W[i]); v3sub(e2, W[k], W[i]); v3cross(n, e1, e2); v3sub(eo, W[o], W[i]);
     if (v3dot(n, eo) > R(0.0)) { int t = j; j = k; k = t; v3scale(n, n, R(-1.0)); }
     real len = v3len(n);
-    if (!(len > R(0.0))) { len = R(1.0); }
+    int degen = !(len > R(1e-12));
+    if (degen) { len = R(1.0); }
     v3scale(n, n, R(1.0) / len);
-    fi[nf][0] = i; fi[nf][1] = j; fi[nf][2] = k; v3cpy(fn[nf], n); fd[nf] = v3dot(n, W[i]); alive[nf] = 1; ++nf;
+    /* a zero-area face has no normal: give it infinite distance so it is never selected */
+    fi[nf][0] = i; fi[nf][1] = j; fi[nf][2] = k; v3cpy(fn[nf], n); fd[nf] = degen ? R(1e30) : v3dot(n, W[i]); alive[nf] = 1; ++nf;
   }
   int bestf = 0;
   for (int it = 0; it < EPA_MAX_ITERS; ++it) {
@@ -207,10 +210,12 @@ static inline void orc_epa(const real (*A)[3], int nA, const real (*B)[3], int n
       real e1[3], e2[3], n[3];
       v3sub(e1, W[j], W[i]); v3sub(e2, W[k], W[i]); v3cross(n, e1, e2);
       real len = v3len(n);
-      if (!(len > R(0.0))) { len = R(1.0); }
+      int degen = !(len > R(1e-12));
+      if (degen) { len = R(1.0); }
       v3scale(n, n, R(1.0) / len);
       real d = v3dot(n, W[i]);
       if (d < R(0.0)) { int t = i; i = j; j = t; v3scale(n, n, R(-1.0)); d = -d; }
+      if (degen) d = R(1e30);
       fi[slot][0] = i; fi[slot][1] = j; fi[slot][2] = k; v3cpy(fn[slot], n); fd[slot] = d; alive[slot] = 1;
     }
     ++nv;
@@ -256,18 +261,28 @@ static inline int orc_gjk_epa(const real (*A)[3], int nA, const real (*B)[3], in
     if (have_v && vv - vw <= GJK_REL_TOL * vv) break;
     v3cpy(s.w[s.n], w); v3cpy(s.a[s.n], A[ia]); v3cpy(s.b[s.n], B[ib]); s.n++;
     if (orc_simplex_solve(&s, v)) { penetrating = 1; break; }
+    real vn = v3dot(v, v);
+    if (!(vn > R(1e-14))) { penetrating = 2; break; }
+    /* no progress: the closest point stopped getting closer (face-face contacts
+     * would otherwise cycle through the vertices of the touching faces) */
+    if (have_v && vv - vn <= GJK_PROGRESS_TOL * vv) break;
     have_v = 1;
-    if (!(v3dot(v, v) > R(1e-14))) { penetrating = 2; break; }
   }
   if (penetrating == 1) {
     real nf[3], depth;
     orc_epa(A, nA, B, nB, &s, nf, &depth, pa, pb);
-    v3scale(n, nf, R(-1.0));
-    *dist = -depth;
-    return 1;
+    if (depth < R(1e29)) {
+      v3scale(n, nf, R(-1.0));
+      *dist = -depth;
+      return 1;
+    }
+    /* fully degenerate polytope: treat as touching along the guess */
+    penetrating = 2;
+    goto touching;
   }
   pa[0] = pa[1] = pa[2] = R(0.0); pb[0] = pb[1] = pb[2] = R(0.0);
   for (int i = 0; i < s.n; ++i) { v3madd(pa, pa, s.a[i], s.lam[i]); v3madd(pb, pb, s.b[i], s.lam[i]); }
+touching:
   if (penetrating == 2) {
     /* cores touch on a lower-dimensional simplex: zero depth along the guess */
     real g[3]; v3cpy(g, guess);
@@ -294,7 +309,7 @@ typedef struct {
   real ln[4], lt1[4], lt2[4]; /* accumulated impulses (warm start)      */
   int  col[4];     /* arm collider id for arm-body manifolds, else -1   */
   real acc;        /* relative motion since the last full narrow phase  */
-  int  age;        /* substeps since the last full narrow phase         */
+  int  age;        /* full passes since the last feature stage          */
 } orc_manifold;
 
 static inline void orc_man_remove(orc_manifold* m, int i) {

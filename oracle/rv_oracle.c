@@ -86,7 +86,7 @@ typedef struct {
   int num_steps, num_episodes;   /* RobotEnv counters              */
   int done, phase, is_safe, is_effective;
   int reset_count;
-  int substeps_last, awake_last;
+  int substeps_last, awake_last, pairs_last;
   real episode_reward, last_reward;
   real action[RV_MAXG][4];
   real obs_pos[RV_MAXB][3], prev_obs_pos[RV_MAXB][3];
@@ -517,6 +517,7 @@ static int manifold_refresh(const orc_world* w, orc_env* e, int kind, int a, int
 #define MAN_C R(0.932327)
 #define MAN_S R(0.361615)
 #define MAN_TAU R(0.1)
+#define FEATURE_PERIOD 4
 
 static void manifold_add_world(const orc_world* w, orc_env* e, int kind, int a, int b, int col, orc_manifold* m,
                                const real* wa, const real* wb, const real* n, real d) {
@@ -536,14 +537,20 @@ static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, 
                         const real* guess, orc_manifold* m, real* out_dist) {
   real mg = (real)w->cfg.margin, brk = (real)w->cfg.breaking;
   real n[3], dist, pa[3], pb[3];
+  e->pairs_last++;
   if (!orc_gjk_epa(A, nA, B, nB, guess, brk + R(2.0) * mg, n, &dist, pa, pb)) return 0;
   real d = dist - R(2.0) * mg;
   if (d > brk) return 0;
+  if (!(v3dot(n, n) > R(0.5))) return 0;   /* safety net: never accept a non-unit normal */
   *out_dist = d;
   if (!m) return 1;
   real wa[3], wb[3];
   v3madd(wa, pa, n, -mg); v3madd(wb, pb, n, mg);
   manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, d);
+  /* feature stage: only while the manifold is incomplete, or every
+   * FEATURE_PERIOD-th full pass (cached points are refreshed every substep) */
+  if (m->n >= 4 && m->age < FEATURE_PERIOD - 1) { m->age++; return 1; }
+  m->age = 0;
   real t1[3], t2[3], dir[4][3], extA[4], extB[4];
   plane_space(n, t1, t2);
   for (int k = 0; k < 3; ++k) {
@@ -615,7 +622,7 @@ static void collide_all(const orc_world* w, orc_env* e) {
     {
       orc_manifold* m = &e->man[TIDX(b)];
       int lost = manifold_refresh(w, e, 0, b, -1, m);
-      m->acc += e->mot[b]; m->age += 1;
+      m->acc += e->mot[b];
       run[TIDX(b)] = (c->np_max_age <= 0) || m->n == 0 || lost > 0 || m->acc > (real)c->np_gate || (e->sim_steps % c->np_max_age) == 0;
     }
     if (e->arm_enabled) manifold_refresh(w, e, 2, b, -1, &e->man[AIDX(b)]); else e->man[AIDX(b)].n = 0;
@@ -628,14 +635,14 @@ static void collide_all(const orc_world* w, orc_env* e) {
     {
       orc_manifold* m = &e->man[BBIDX(k)];
       int lost = manifold_refresh(w, e, 1, a, b, m);
-      m->acc += e->mot[a] + e->mot[b]; m->age += 1;
+      m->acc += e->mot[a] + e->mot[b];
       run[BBIDX(k)] = (c->np_max_age <= 0) || m->n == 0 || lost > 0 || m->acc > (real)c->np_gate || (e->sim_steps % c->np_max_age) == 0;
     }
   }
   /* body - table */
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!body_on(e, b) || !run[TIDX(b)]) continue;
-    e->man[TIDX(b)].acc = R(0.0); e->man[TIDX(b)].age = 0;
+    e->man[TIDX(b)].acc = R(0.0);
     real r = e->bp[b].radius + brk;
     if (sphere_box_dist2(e->body[b].p, tc, th) >= r * r) continue;
     const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
@@ -650,7 +657,7 @@ static void collide_all(const orc_world* w, orc_env* e) {
   for (int k = 0; k < RV_NBB; ++k) {
     int a = BB_A[k], b = BB_B[k];
     if (!(body_on(e, a) && body_on(e, b)) || !run[BBIDX(k)]) continue;
-    e->man[BBIDX(k)].acc = R(0.0); e->man[BBIDX(k)].age = 0;
+    e->man[BBIDX(k)].acc = R(0.0);
     real d[3]; v3sub(d, e->body[a].p, e->body[b].p);
     real r = e->bp[a].radius + e->bp[b].radius + brk;
     if (v3dot(d, d) >= r * r) continue;
@@ -1165,7 +1172,7 @@ static void execute_action(const orc_world* w, orc_env* e) {
 static void env_step(const orc_world* w, orc_env* e) {
   const rv_config* c = &w->cfg;
   if (e->done) return;
-  e->substeps_last = 0; e->awake_last = 0;
+  e->substeps_last = 0; e->awake_last = 0; e->pairs_last = 0;
   execute_action(w, e);
   e->num_steps++;
   compute_obs(e);
@@ -1235,7 +1242,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   const rv_config* c = &w->cfg;
   orc_rng g; rng_init(&g, c->seed_lo, c->seed_hi, (uint32_t)gid, STREAM_RESET, (uint32_t)e->reset_count);
   e->reset_count++;
-  e->substeps_last = 0; e->awake_last = 0;
+  e->substeps_last = 0; e->awake_last = 0; e->pairs_last = 0;
   e->sim_steps = 0; e->num_steps = 0; e->episode_reward = R(0.0); e->last_reward = R(0.0);
   e->done = 0;
   e->phase = RV_PHASE_INITIAL; e->is_safe = 1; e->is_effective = 1;
@@ -1320,7 +1327,7 @@ void orc_reset(orc_world* w, const uint8_t* mask) {
   stats_begin(w);
 #pragma omp parallel for schedule(dynamic)
   for (int i = 0; i < w->n; ++i) {
-    if (mask && !mask[i]) { w->env[i].substeps_last = 0; w->env[i].awake_last = 0; continue; }
+    if (mask && !mask[i]) { w->env[i].substeps_last = 0; w->env[i].awake_last = 0; w->env[i].pairs_last = 0; continue; }
     env_reset(w, &w->env[i], w->cfg.env_id_offset + i);
   }
   for (int i = 0; i < w->n; ++i) stats_env(w, &w->env[i]);
@@ -1336,7 +1343,7 @@ void orc_step_macro(orc_world* w) {
 #pragma omp parallel for schedule(dynamic)
   for (int i = 0; i < w->n; ++i) {
     orc_env* e = &w->env[i];
-    e->substeps_last = 0; e->awake_last = 0;
+    e->substeps_last = 0; e->awake_last = 0; e->pairs_last = 0;
     if (e->done) continue;
     env_step(w, e);
   }
@@ -1355,7 +1362,7 @@ void orc_step_sub(orc_world* w, int n) {
   stats_begin(w);
 #pragma omp parallel for schedule(dynamic)
   for (int i = 0; i < w->n; ++i) {
-    w->env[i].substeps_last = 0; w->env[i].awake_last = 0;
+    w->env[i].substeps_last = 0; w->env[i].awake_last = 0; w->env[i].pairs_last = 0;
     for (int k = 0; k < n; ++k) sim_substep(w, &w->env[i]);
   }
   for (int i = 0; i < w->n; ++i) stats_env(w, &w->env[i]);
@@ -1365,7 +1372,7 @@ void orc_wait_until_stable(orc_world* w, float lin, float ang, int check_after, 
 #pragma omp parallel for schedule(dynamic)
   for (int i = 0; i < w->n; ++i) {
     orc_env* e = &w->env[i];
-    e->substeps_last = 0; e->awake_last = 0;
+    e->substeps_last = 0; e->awake_last = 0; e->pairs_last = 0;
     unsigned mask = 0;
     for (int b = 0; b < RV_MAXB; ++b) if (e->bp[b].active) mask |= 1u << b;
     wait_until_stable(w, e, mask, (real)lin, (real)ang, check_after, min_stable, max_steps);
@@ -1497,7 +1504,7 @@ void orc_get_link_poses(orc_world* w, double* out) {
 void orc_get_env_counters(orc_world* w, int32_t* out) {
   for (int i = 0; i < w->n; ++i) {
     const orc_env* e = &w->env[i]; int32_t* o = out + (size_t)i * RV_NCOUNTERS;
-    o[8] = e->awake_last; o[9] = e->reset_count;
+    o[8] = e->awake_last; o[9] = e->pairs_last;
     o[0] = e->sim_steps; o[1] = e->num_steps; o[2] = e->num_episodes; o[3] = e->phase; o[4] = e->done; o[5] = e->is_safe; o[6] = e->is_effective; o[7] = e->substeps_last;
   }
 }

@@ -12,6 +12,7 @@ namespace rv {
 
 #define RV_GJK_MAX_ITERS 32
 #define RV_GJK_REL_TOL 1e-4f
+#define RV_GJK_PROGRESS_TOL 1e-6f
 #define RV_EPA_MAX_VERTS 24
 #define RV_EPA_MAX_FACES 48
 #define RV_EPA_MAX_EDGES 32
@@ -42,33 +43,53 @@ struct DevMan {
   float la[4][3], lb[4][3], nrm[4][3];
   float dist[4], ln[4], lt1[4], lt2[4];
   float acc;   // relative motion since the last full narrow phase
-  int age;     // substeps since the last full narrow phase
+  int age;     // full passes since the last feature stage
 };
 
-// Support vertex (by value) of a hull stored as n <= RV_MAXV_REG packed xyz
-// triples: fully unrolled over RV_MAXV_REG slots with the index clamped to n-1
-// (a repeated vertex can never win the strict argmax, so the result equals the
-// plain loop over n vertices).  All loads are independent of the compare chain,
-// so the compiler issues them as one batch instead of one LDS round trip per
-// vertex.
+// Support vertex (by value) of a hull stored as n <= 16 packed xyz triples.
+//
+// Device: the 16 lanes of a group each hold one vertex (index clamped to n-1),
+// take the dot product and run a 4-step DPP row-rotate arg-max all-reduce that
+// carries (value, index, xyz); ties go to the lowest index, which is exactly
+// what the serial first-maximum loop returns, and a clamped duplicate can never
+// beat its original.  Every lane of the group ends up with the same result.
+// Host emulation: the serial loop.
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+template <int N> RV_DEV float row_ror_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
+}
+template <int N> RV_DEV int row_ror_i(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x120 + N, 0xf, 0xf, false); }
+struct SupRed { float val; int idx; float x, y, z; };
+template <int N> RV_DEV SupRed sup_step(SupRed s) {
+  SupRed o;
+  o.val = row_ror_f<N>(s.val); o.idx = row_ror_i<N>(s.idx);
+  o.x = row_ror_f<N>(s.x); o.y = row_ror_f<N>(s.y); o.z = row_ror_f<N>(s.z);
+  bool take = (o.val > s.val) || (o.val == s.val && o.idx < s.idx);
+  return take ? o : s;
+}
 RV_DEV v3 support_v(const float* verts, int n, v3 d, float* proj) {
-  float px[RV_MAXV_REG], py[RV_MAXV_REG], pz[RV_MAXV_REG];
-#pragma unroll
-  for (int i = 0; i < RV_MAXV_REG; ++i) {
-    int j = i < n ? i : n - 1;
-    px[i] = verts[3 * j]; py[i] = verts[3 * j + 1]; pz[i] = verts[3 * j + 2];
-  }
-  v3 best = mk(px[0], py[0], pz[0]);
+  const int sl = (int)threadIdx.x & 15;
+  const int j = sl < n ? sl : n - 1;
+  SupRed s;
+  s.x = verts[3 * j]; s.y = verts[3 * j + 1]; s.z = verts[3 * j + 2];
+  s.val = dot(mk(s.x, s.y, s.z), d); s.idx = j;
+  s = sup_step<8>(s); s = sup_step<4>(s); s = sup_step<2>(s); s = sup_step<1>(s);
+  *proj = s.val;
+  return mk(s.x, s.y, s.z);
+}
+#else
+RV_DEV v3 support_v(const float* verts, int n, v3 d, float* proj) {
+  v3 best = ld3(verts);
   float bd = dot(best, d);
-#pragma unroll
-  for (int i = 1; i < RV_MAXV_REG; ++i) {
-    v3 p = mk(px[i], py[i], pz[i]);
+  for (int i = 1; i < n; ++i) {
+    v3 p = ld3(verts + 3 * i);
     float x = dot(p, d);
     if (x > bd) { bd = x; best = p; }
   }
   *proj = bd;
   return best;
 }
+#endif
 
 RV_DEV int support(const float* verts, int n, v3 d) {
   int best = 0;
@@ -211,9 +232,11 @@ RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const S
     v3 n = cross(sub(ld3(E.W[j]), wi), sub(ld3(E.W[k]), wi));
     if (dot(n, sub(ld3(E.W[o]), wi)) > 0.0f) { int t = j; j = k; k = t; n = scale(n, -1.0f); }
     float ln = len(n);
-    if (!(ln > 0.0f)) ln = 1.0f;
+    int degen = !(ln > 1e-12f);
+    if (degen) ln = 1.0f;
     n = scale(n, 1.0f / ln);
-    E.fi[nf][0] = i; E.fi[nf][1] = j; E.fi[nf][2] = k; st3(E.fn[nf], n); E.fd[nf] = dot(n, wi); E.alive[nf] = 1; ++nf;
+    // a zero-area face has no normal: give it infinite distance so it is never selected
+    E.fi[nf][0] = i; E.fi[nf][1] = j; E.fi[nf][2] = k; st3(E.fn[nf], n); E.fd[nf] = degen ? 1e30f : dot(n, wi); E.alive[nf] = 1; ++nf;
   }
   int bestf = 0;
   for (int it = 0; it < RV_EPA_MAX_ITERS; ++it) {
@@ -251,10 +274,12 @@ RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const S
       v3 wi = ld3(E.W[i]);
       v3 n = cross(sub(ld3(E.W[j]), wi), sub(ld3(E.W[k]), wi));
       float ln = len(n);
-      if (!(ln > 0.0f)) ln = 1.0f;
+      int degen = !(ln > 1e-12f);
+      if (degen) ln = 1.0f;
       n = scale(n, 1.0f / ln);
       float d = dot(n, wi);
       if (d < 0.0f) { int t = i; i = j; j = t; n = scale(n, -1.0f); d = -d; }
+      if (degen) d = 1e30f;
       E.fi[slot][0] = i; E.fi[slot][1] = j; E.fi[slot][2] = k; st3(E.fn[slot], n); E.fd[slot] = d; E.alive[slot] = 1;
     }
     ++nv;
@@ -302,20 +327,27 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
     for (int k = 0; k < 4; ++k) if (k == s.n) { s.w[k] = w; s.a[k] = va; s.b[k] = vb; }
     s.n++;
     if (simplex_solve(s, &v)) { penetrating = 1; break; }
+    float vn = dot(v, v);
+    if (!(vn > 1e-14f)) { penetrating = 2; break; }
+    // no progress: the closest point stopped getting closer (face-face contacts
+    // would otherwise cycle through the vertices of the touching faces)
+    if (have_v && vv - vn <= RV_GJK_PROGRESS_TOL * vv) break;
     have_v = 1;
-    if (!(dot(v, v) > 1e-14f)) { penetrating = 2; break; }
   }
   if (penetrating == 1) {
     v3 nf; float depth;
     epa(A, nA, B, nB, s, &nf, &depth, pa, pb);
-    *n = scale(nf, -1.0f);
-    *dist = -depth;
-    return 1;
+    if (depth < 1e29f) {
+      *n = scale(nf, -1.0f);
+      *dist = -depth;
+      return 1;
+    }
+    penetrating = 2;   // fully degenerate polytope: treat as touching along the guess
   }
   v3 qa = mk(0, 0, 0), qb = mk(0, 0, 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) if (i < s.n) { qa = madd(qa, s.a[i], s.lam[i]); qb = madd(qb, s.b[i], s.lam[i]); }
-  *pa = qa; *pb = qb;
+  if (penetrating != 2 || s.n < 4) { *pa = qa; *pb = qb; }
   if (penetrating == 2) {
     v3 g = guess;
     float gl = len(g);

@@ -76,7 +76,7 @@ struct DevEnv {
   float fpos[RV_NFRAME][3], fquat[RV_NFRAME][4];
   DevMan man[RV_NMAN];
   int flag_arm_table, flag_arm_body[RV_MAXB];
-  int sim_steps, num_steps, num_episodes, done, phase, is_safe, is_effective, reset_count, substeps_last, awake_last;
+  int sim_steps, num_steps, num_episodes, done, phase, is_safe, is_effective, reset_count, substeps_last, awake_last, pairs_last;
   int stepped;      // this env executed an env.step() in the last macro launch
   float episode_reward, last_reward;
   float action[RV_MAXG][4];
@@ -112,17 +112,26 @@ struct Scratch {
   int wake[RV_MAXB];
   float res[16];
   float mot[RV_MAXB];
+  int pairs[4];
   Rng rng;
 };
 
 struct Shared {
   DevEnv e;
   Scratch s;
+  // launch constants staged in LDS: inside the out-of-line substep a pointer
+  // argument is not provably wave-uniform, so reading rv_config / rv_arm
+  // through it would be a vector global load (L2 latency) per field
+  rv_config cfg;
+  rv_arm arm;
+  int n_hulls[RV_MAXB];
+  int n_verts[RV_MAXB][RV_MAXH];
 };
 
 struct Consts {
-  const rv_config* cfg;
-  const rv_scene* scene;
+  const rv_config* cfg;     // LDS copy (Shared::cfg) inside kernels
+  const rv_arm* arm;        // LDS copy (Shared::arm) inside kernels
+  const rv_scene* scene;    // global memory: hull vertices / inertia only
   int stop_after;
 };
 
@@ -166,7 +175,7 @@ RV_DEV void fk_limb(const rv_arm* a, const float* q, LimbFK& F, float* frot_out 
 
 // damped-least-squares IK (bullet_physics.py:1203-1262 call site), lane-serial
 RV_DEV_NOINLINE void arm_ik(const Consts& K, const float* q0, const float* pose, float* out) {
-  const rv_arm* a = &K.scene->arm;
+  const rv_arm* a = K.arm;
   const rv_config* c = K.cfg;
   float q[RV_NLIMB];
 #pragma unroll
@@ -337,7 +346,7 @@ RV_DEV int arm_is_ready_limb(Shared& S, const Consts& K) {
 RV_DEV void robot_move_to_joint_positions(Shared& S, const Consts& K, const float* pos) {
   DevEnv& e = S.e; const rv_config* c = K.cfg;
   arm_reset_targets(e);
-  for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = c->limb_max_velocity_ratio * K.scene->arm.v_max[j];
+  for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = c->limb_max_velocity_ratio * K.arm->v_max[j];
   JTarget& t = e.jt;
   t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = 1;
   for (int i = 0; i < RV_NLIMB; ++i) { t.idx[i] = i; t.pos[i] = pos[i]; }
@@ -348,7 +357,7 @@ RV_DEV void robot_move_to_joint_positions(Shared& S, const Consts& K, const floa
 RV_DEV void robot_move_to_gripper_pose(Shared& S, const Consts& K, const float* pose) {
   DevEnv& e = S.e; const rv_config* c = K.cfg;
   arm_reset_targets(e);
-  for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = c->limb_max_velocity_ratio * K.scene->arm.v_max[j];
+  for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = c->limb_max_velocity_ratio * K.arm->v_max[j];
   LTarget& t = e.lt;
   t.active = 1; t.has_pose = 1; t.nq = 0;
   for (int k = 0; k < 7; ++k) t.pose[k] = pose[k];
@@ -357,7 +366,7 @@ RV_DEV void robot_move_to_gripper_pose(Shared& S, const Consts& K, const float* 
 }
 // SawyerSim.grip (sawyer_sim.py:362-392)
 RV_DEV void robot_grip(Shared& S, const Consts& K, float value) {
-  DevEnv& e = S.e; const rv_arm* a = &K.scene->arm;
+  DevEnv& e = S.e; const rv_arm* a = K.arm;
   value = fclampr(value, 0.01f, 0.99f);
   float lpos = a->q_hi[7] - value * (a->q_hi[7] - a->q_lo[7]);
   float rpos = a->q_lo[8] + value * (a->q_hi[8] - a->q_lo[8]);
@@ -376,6 +385,11 @@ RV_DEV void body_set_mass(DevEnv& e, const Consts& K, int b, float mass) {
   float s2 = e.scale[b] * e.scale[b];
   for (int k = 0; k < 3; ++k) e.inv_inertia[b][k] = 1.0f / (mass * s2 * s->inertia_k[k]);
   e.radius[b] = s->radius * e.scale[b] + K.cfg->margin;
+}
+RV_DEV void cache_shape_meta(Shared& S, const Consts& K, int b) {
+  const rv_shape* s = &K.scene->shapes[S.e.shape[b]];
+  S.n_hulls[b] = s->n_hulls;
+  for (int h = 0; h < RV_MAXH; ++h) S.n_verts[b][h] = s->n_verts[h];
 }
 RV_DEV void table_prepare(Shared& S, const Consts& K, int k) {
   const rv_config* c = K.cfg;
@@ -397,7 +411,7 @@ RV_DEV void point_world(const Shared& S, const Consts& K, int kind, int a, int b
   *wa = to_world_body(S, a, p.la);
   if (kind == 0) *wb = p.lb;
   else if (kind == 1) *wb = to_world_body(S, b, p.lb);
-  else *wb = to_world_frame(S, K.scene->arm.col_frame[p.col], p.lb);
+  else *wb = to_world_frame(S, K.arm->col_frame[p.col], p.lb);
 }
 RV_DEV int manifold_refresh(const Shared& S, const Consts& K, int kind, int a, int b, DevMan& m) {
   float brk = K.cfg->breaking;
@@ -432,13 +446,14 @@ RV_DEV void manifold_add_world(const Shared& S, const Consts& K, int kind, int a
   v3 la = to_local_body(S, a, wa), lb;
   if (kind == 0) lb = wb;
   else if (kind == 1) lb = to_local_body(S, b, wb);
-  else lb = to_local_frame(S, K.scene->arm.col_frame[col], wb);
+  else lb = to_local_frame(S, K.arm->col_frame[col], wb);
   man_add(m, la, lb, n, d, col, K.cfg->breaking);
 }
 
 #define RV_MAN_C 0.932327f
 #define RV_MAN_S 0.361615f
 #define RV_MAN_TAU 0.1f
+#define RV_FEATURE_PERIOD 4
 
 // narrow phase of one convex pair; m == nullptr: distance only
 RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b, int col,
@@ -448,9 +463,17 @@ RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b
   if (!gjk_epa(A, nA, B, nB, guess, brk + 2.0f * mg, &n, &dist, &pa, &pb)) return 0;
   float d = dist - 2.0f * mg;
   if (d > brk) return 0;
+  if (!(dot(n, n) > 0.5f)) return 0;   // safety net: never accept a non-unit normal
   *out_dist = d;
   if (!m) return 1;
   manifold_add_world(S, K, kind, a, b, col, *m, madd(pa, n, -mg), madd(pb, n, mg), n, d);
+  // feature stage: only while the manifold is incomplete, or every
+  // RV_FEATURE_PERIOD-th full pass (cached points are refreshed every substep)
+  {
+    int age = m->age;
+    if (m->n >= 4 && age < RV_FEATURE_PERIOD - 1) { m->age = age + 1; return 1; }
+    m->age = 0;
+  }
   v3 t1, t2, dir[4];
   float extA[4], extB[4];
   plane_space(n, &t1, &t2);
@@ -517,7 +540,7 @@ RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, 
   m3 iib = iia;
   if (kind == 1) { rb = sub(wb, ld3(e.body[b])); imb = e.inv_mass[b]; iib = ldm(S.s.iinv[b]); }
   if (kind == 2) {
-    int f = K.scene->arm.col_frame[p.col];
+    int f = K.arm->col_frame[p.col];
     vb_pt = add(ld3(S.s.fv[f]), cross(ld3(S.s.fw[f]), sub(wb, ld3(e.fpos[f]))));
   }
   float ima = e.inv_mass[a];
@@ -597,7 +620,7 @@ RV_DEV void warm_apply(BV& A, BV* B, float ima, float imb, const Lam& l, const R
 // per-phase costs can be read off as differences (tools/prof_phases.sh)
 RV_DEV void sim_substep(Shared& S, const Consts& K) {
   const rv_config* c = K.cfg;
-  const rv_arm* arm = &K.scene->arm;
+  const rv_arm* arm = K.arm;
   const int arm_on = S.e.arm_enabled;
 
   if (arm_on) {
@@ -733,8 +756,8 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
     for (int item = lane; item < RV_MAXB * RV_MAXH * RV_MAXV; item += 64) {
       int b = item / (RV_MAXH * RV_MAXV), h = (item / RV_MAXV) % RV_MAXH, i = item % RV_MAXV;
       if (!body_on(S.e, b)) continue;
+      if (h >= S.n_hulls[b] || i >= S.n_verts[b][h]) continue;
       const rv_shape* s = &K.scene->shapes[S.e.shape[b]];
-      if (h >= s->n_hulls || i >= s->n_verts[h]) continue;
       float sc = S.e.scale[b];
       v3 l = mk(s->verts[h][i][0] * sc, s->verts[h][i][1] * sc, s->verts[h][i][2] * sc);
       st3(S.s.wv[b][h][i], add(ld3(S.e.body[b]), mulv(S.s.rot[b], l)));
@@ -742,94 +765,104 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
   RV_LANES_END
 
   if (K.stop_after == 2) return;
-  // manifold refresh + narrow phase: one lane per manifold owner (+ arm-table
-  // detection lanes).  The lane's manifold lives in registers for the whole
-  // phase; every role walks its list of convex pairs through ONE collide_pair
-  // call site, so body-table, body-body, arm-body and arm-table queries of a
-  // substep run side by side in the wave.
+  // manifold refresh + narrow phase.  The wave is split into four 16-lane
+  // groups; a group works on one manifold owner at a time (body-table,
+  // body-body, arm-body, arm-table detection: 24 owners, six rounds) and all
+  // of its lanes execute the same scalar program redundantly -- except inside
+  // support_v(), where each lane holds one hull vertex and a DPP all-reduce
+  // picks the extreme one.  Every convex pair of every owner goes through ONE
+  // collide_pair call site.
   RV_LANES_BEGIN
     DevEnv& e = S.e;
+    const int slot = lane >> 4;
+#if !defined(__HIPCC__) || defined(RV_EMULATE)
+    if ((lane & 15) != 0) continue;   // host emulation: one lane per group does the work
+#endif
     float brk = c->breaking;
     v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
     v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
-    int role = -1, a = 0, b = -1, mi = 0, n_outer = 0, n_inner = 0;
-    int clear = 0, live = 0;     // live: manifold is loaded, refreshed and stored
-    const rv_shape* sa = nullptr; const rv_shape* sb = nullptr;
-    v3 guess0 = mk(0.0f, 0.0f, 1.0f);
-    if (lane < RV_MAXB) {
-      a = lane; mi = RV_TIDX(a);
-      if (!body_present(e, a)) clear = 1;
-      else if (!e.asleep[a]) {
-        live = 1;
-        float r = e.radius[a] + brk;
-        if (!(sphere_box_dist2(ld3(e.body[a]), tc, th) >= r * r)) {
-          role = 0; sa = &K.scene->shapes[e.shape[a]]; n_outer = 1; n_inner = sa->n_hulls;
-          guess0 = mk(0.0f, 0.0f, e.body[a][2] - tc.z);
+    int my_pairs = 0;
+    for (int round = 0; round < (RV_NMAN + RV_NCOL + 3) / 4; ++round) {
+      const int owner = round * 4 + slot;
+      int role = -1, a = 0, b = -1, mi = 0, n_outer = 0, n_inner = 0;
+      int clear = 0, live = 0;     // live: manifold is refreshed (and may get new points)
+      v3 guess0 = mk(0.0f, 0.0f, 1.0f);
+      if (owner < RV_MAXB) {
+        a = owner; mi = RV_TIDX(a);
+        if (!body_present(e, a)) clear = 1;
+        else if (!e.asleep[a]) {
+          live = 1;
+          float r = e.radius[a] + brk;
+          if (!(sphere_box_dist2(ld3(e.body[a]), tc, th) >= r * r)) {
+            role = 0; n_outer = 1; n_inner = S.n_hulls[a];
+            guess0 = mk(0.0f, 0.0f, e.body[a][2] - tc.z);
+          }
+        }
+      } else if (owner < RV_MAXB + RV_NBB) {
+        int k = owner - RV_MAXB; a = bb_a(k); b = bb_b(k); mi = RV_BBIDX(k);
+        if (!(body_present(e, a) && body_present(e, b))) clear = 1;
+        else if (!e.asleep[a] && !e.asleep[b]) {
+          live = 1;
+          v3 d = sub(ld3(e.body[a]), ld3(e.body[b]));
+          float r = e.radius[a] + e.radius[b] + brk;
+          if (!(dot(d, d) >= r * r)) {
+            role = 1; n_outer = S.n_hulls[a]; n_inner = S.n_hulls[b]; guess0 = d;
+          }
+        }
+      } else if (owner < RV_NMAN) {
+        a = owner - RV_MAXB - RV_NBB; mi = RV_AIDX(a);
+        if (!body_present(e, a)) clear = 1;
+        else if (!e.asleep[a]) {
+          if (!arm_on) clear = 1;
+          else { live = 1; role = 2; n_outer = RV_NCOL; n_inner = S.n_hulls[a]; }
+        }
+      } else if (owner < RV_NMAN + RV_NCOL) {
+        // arm - table: detection only (push_env.py:839-855)
+        int col = owner - RV_NMAN;
+        if (arm_on) {
+          float r = S.s.colr[col] + brk;
+          float minz = S.s.colv[col][0][2];
+          for (int k = 1; k < 8; ++k) minz = fminr(minz, S.s.colv[col][k][2]);
+          // exact rejection: the flag needs dist < query_dist and dist >= minz - table_z - margin
+          if (!(minz - e.table_z - c->margin >= c->contact_query_dist) &&
+              sphere_box_dist2(ld3(S.s.colc[col]), tc, th) < r * r) { role = 3; a = col; n_outer = 1; n_inner = 1; }
         }
       }
-    } else if (lane < RV_MAXB + RV_NBB) {
-      int k = lane - RV_MAXB; a = bb_a(k); b = bb_b(k); mi = RV_BBIDX(k);
-      if (!(body_present(e, a) && body_present(e, b))) clear = 1;
-      else if (!e.asleep[a] && !e.asleep[b]) {
-        live = 1;
-        v3 d = sub(ld3(e.body[a]), ld3(e.body[b]));
-        float r = e.radius[a] + e.radius[b] + brk;
-        if (!(dot(d, d) >= r * r)) {
-          role = 1; sa = &K.scene->shapes[e.shape[a]]; sb = &K.scene->shapes[e.shape[b]];
-          n_outer = sa->n_hulls; n_inner = sb->n_hulls; guess0 = d;
+      if (clear) e.man[mi].n = 0;
+      if (live) {
+        DevMan& m = e.man[mi];
+        int lost = manifold_refresh(S, K, owner < RV_MAXB ? 0 : (owner < RV_MAXB + RV_NBB ? 1 : 2), a, b, m);
+        if (owner < RV_MAXB + RV_NBB) {
+          // narrow-phase gating (body-table and body-body pairs)
+          float mo = S.s.mot[a];
+          if (b >= 0) mo = mo + S.s.mot[b];
+          float acc = m.acc + mo;
+          int run = (c->np_max_age <= 0) || m.n == 0 || lost > 0 || acc > c->np_gate || (e.sim_steps % c->np_max_age) == 0;
+          if (run) acc = 0.0f; else { n_outer = 0; n_inner = 0; }
+          m.acc = acc;
         }
       }
-    } else if (lane < RV_NMAN) {
-      a = lane - RV_MAXB - RV_NBB; mi = RV_AIDX(a);
-      if (!body_present(e, a)) clear = 1;
-      else if (!e.asleep[a]) {
-        if (!arm_on) clear = 1;
-        else { live = 1; role = 2; sa = &K.scene->shapes[e.shape[a]]; n_outer = RV_NCOL; n_inner = sa->n_hulls; }
-      }
-    } else if (lane < RV_NMAN + RV_NCOL) {
-      // arm - table: detection only (push_env.py:839-855)
-      int col = lane - RV_NMAN;
-      if (arm_on) {
-        float r = S.s.colr[col] + brk;
-        float minz = S.s.colv[col][0][2];
-        for (int k = 1; k < 8; ++k) minz = fminr(minz, S.s.colv[col][k][2]);
-        // exact rejection: the flag needs dist < query_dist and dist >= minz - table_z - margin
-        if (!(minz - e.table_z - c->margin >= c->contact_query_dist) &&
-            sphere_box_dist2(ld3(S.s.colc[col]), tc, th) < r * r) { role = 3; a = col; n_outer = 1; n_inner = 1; }
-      }
-    }
-    if (clear) e.man[mi].n = 0;
-    if (live) {
-      DevMan& m = e.man[mi];
-      int lost = manifold_refresh(S, K, lane < RV_MAXB ? 0 : (lane < RV_MAXB + RV_NBB ? 1 : 2), a, b, m);
-      if (lane < RV_MAXB + RV_NBB) {
-        // narrow-phase gating (body-table and body-body pairs)
-        float mo = S.s.mot[a];
-        if (b >= 0) mo = mo + S.s.mot[b];
-        float acc = m.acc + mo; int age = m.age + 1;
-        int run = (c->np_max_age <= 0) || m.n == 0 || lost > 0 || acc > c->np_gate || (e.sim_steps % c->np_max_age) == 0;
-        if (run) { acc = 0.0f; age = 0; } else { n_outer = 0; n_inner = 0; }
-        m.acc = acc; m.age = age;
+      const int n_pairs = n_outer * n_inner;
+      for (int t = 0; t < n_pairs; ++t) {
+        int io = t / n_inner, ii = t - io * n_inner;
+        const float* A; const float* B; int nA, nB, ckind, col = -1;
+        v3 guess = guess0;
+        if (role == 0) { A = &S.s.wv[a][ii][0][0]; nA = S.n_verts[a][ii]; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
+        else if (role == 1) { A = &S.s.wv[a][io][0][0]; nA = S.n_verts[a][io]; B = &S.s.wv[b][ii][0][0]; nB = S.n_verts[b][ii]; ckind = 1; }
+        else if (role == 2) {
+          col = io;
+          v3 d = sub(ld3(e.body[a]), ld3(S.s.colc[col]));
+          float r = e.radius[a] + S.s.colr[col] + brk;
+          if (dot(d, d) >= r * r) continue;
+          A = &S.s.wv[a][ii][0][0]; nA = S.n_verts[a][ii]; B = &S.s.colv[col][0][0]; nB = 8; ckind = 2; guess = d;
+        } else { col = a; A = &S.s.colv[col][0][0]; nA = 8; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
+        float dd;
+        my_pairs++;
+        int hit = collide_pair(S, K, ckind, role == 3 ? 0 : a, b, col, A, nA, B, nB, guess, role == 3 ? nullptr : &e.man[mi], &dd);
+        if (role == 3 && hit && dd < c->contact_query_dist) S.s.colflag[col] = 1;
       }
     }
-    const int n_pairs = n_outer * n_inner;
-    for (int t = 0; t < n_pairs; ++t) {
-      int io = t / n_inner, ii = t - io * n_inner;
-      const float* A; const float* B; int nA, nB, ckind, col = -1;
-      v3 guess = guess0;
-      if (role == 0) { A = &S.s.wv[a][ii][0][0]; nA = sa->n_verts[ii]; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
-      else if (role == 1) { A = &S.s.wv[a][io][0][0]; nA = sa->n_verts[io]; B = &S.s.wv[b][ii][0][0]; nB = sb->n_verts[ii]; ckind = 1; }
-      else if (role == 2) {
-        col = io;
-        v3 d = sub(ld3(e.body[a]), ld3(S.s.colc[col]));
-        float r = e.radius[a] + S.s.colr[col] + brk;
-        if (dot(d, d) >= r * r) continue;
-        A = &S.s.wv[a][ii][0][0]; nA = sa->n_verts[ii]; B = &S.s.colv[col][0][0]; nB = 8; ckind = 2; guess = d;
-      } else { col = a; A = &S.s.colv[col][0][0]; nA = 8; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
-      float dd;
-      int hit = collide_pair(S, K, ckind, role == 3 ? 0 : a, b, col, A, nA, B, nB, guess, role == 3 ? nullptr : &e.man[mi], &dd);
-      if (role == 3 && hit && dd < c->contact_query_dist) S.s.colflag[col] = 1;
-    }
+    if ((lane & 15) == 0) S.s.pairs[slot] = my_pairs;
   RV_LANES_END
 
   if (K.stop_after == 3) return;
@@ -853,6 +886,8 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
         S.s.u.rows[mi][i] = r;
         m.ln[i] = p.ln * c->warmstart; m.lt1[i] = p.lt1 * c->warmstart; m.lt2[i] = p.lt2 * c->warmstart;
       }
+    } else if (lane == 61) {
+      e.pairs_last += S.s.pairs[0] + S.s.pairs[1] + S.s.pairs[2] + S.s.pairs[3];
     } else if (lane == 56) {
       int f = 0;
       if (arm_on) for (int col = 0; col < RV_NCOL; ++col) f |= S.s.colflag[col];
@@ -1018,7 +1053,15 @@ __shared__ Shared g_shared;
 #else
 static thread_local Shared g_shared;
 #endif
-RV_DEV_NOINLINE void sim_substep_call(Consts K) { sim_substep(g_shared, K); }
+// Consts whose cfg / arm point at the LDS copies (statically known address)
+RV_DEV Consts lds_consts(const rv_scene* scene, int stop_after) {
+  Consts K; K.cfg = &g_shared.cfg; K.arm = &g_shared.arm; K.scene = scene; K.stop_after = stop_after;
+  return K;
+}
+RV_DEV_NOINLINE void sim_substep_call(const rv_scene* scene, int stop_after) {
+  Consts K = lds_consts(scene, stop_after);
+  sim_substep(g_shared, K);
+}
 
 // Simulator.check_stable over a body mask (simulator.py:289-323)
 RV_DEV int bodies_stable(const DevEnv& e, unsigned mask, float lin_thr, float ang_thr) {
@@ -1041,7 +1084,7 @@ RV_DEV void wait_until_stable(Shared& S, const Consts& K, unsigned mask, float l
     if (lane == 0) { S.s.wus_steps = 0; S.s.wus_stable = 0; S.s.loop_break = 0; }
   RV_LANES_END
   for (;;) {
-    sim_substep_call(K);
+    sim_substep_call(K.scene, K.stop_after);
     RV_LANES_BEGIN
       if (lane == 0) {
         S.s.wus_steps++;
@@ -1216,7 +1259,7 @@ RV_DEV void env_step(Shared& S, const Consts& K) {
   RV_LANES_BEGIN
     if (lane == 0) {
       DevEnv& e = S.e; Scratch& s = S.s;
-      e.substeps_last = 0; e.awake_last = 0; e.stepped = 1;
+      e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; e.stepped = 1;
       int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
       for (int g = 0; g < G; ++g) compute_waypoints(c, e.action[g], s.wp[g][0], s.wp[g][1]);
       e.is_safe = 1; e.is_effective = 1;
@@ -1229,7 +1272,7 @@ RV_DEV void env_step(Shared& S, const Consts& K) {
     }
   RV_LANES_END
   while (S.e.phase != RV_PHASE_DONE) {
-    sim_substep_call(K);
+    sim_substep_call(K.scene, K.stop_after);
     if (S.e.sim_steps % c->steps_check != 0) continue;
     RV_LANES_BEGIN
       if (lane == 0) phase_tick(S, K);
@@ -1327,7 +1370,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid) {
     if (lane == 0) {
       S.s.rng = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RESET, (uint32_t)e.reset_count);
       e.reset_count++;
-      e.substeps_last = 0; e.awake_last = 0; e.stepped = 0;
+      e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; e.stepped = 0;
       e.sim_steps = 0; e.num_steps = 0; e.episode_reward = 0.0f; e.last_reward = 0.0f;
       e.done = 0; e.phase = RV_PHASE_INITIAL; e.is_safe = 1; e.is_effective = 1;
       e.arm_enabled = 0;
@@ -1364,6 +1407,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid) {
           float sc = rng_uniform(g, c->scale_range[0], c->scale_range[1]);
           e.active[i] = 1; e.frozen[i] = 0; e.asleep[i] = 0; e.sleep_count[i] = 0; e.shape[i] = shape; e.scale[i] = sc; e.friction[i] = c->drop_friction;
           body_set_mass(e, K, i, c->drop_mass);
+          cache_shape_meta(S, K, i);
           for (int k = 0; k < 3; ++k) e.body[i][k] = S.s.poses[i][k];
           for (int k = 0; k < 4; ++k) e.body[i][3 + k] = S.s.poses[i][3 + k];
           for (int k = 7; k < 13; ++k) e.body[i][k] = 0.0f;
@@ -1391,7 +1435,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid) {
   // ArmEnv._reset_robot (arm_env.py:101-107) -> SawyerSim.reboot (sawyer_sim.py:86-171)
   RV_LANES_BEGIN
     if (lane == 0) {
-      DevEnv& e = S.e; const rv_arm* a = &K.scene->arm;
+      DevEnv& e = S.e; const rv_arm* a = K.arm;
       for (int j = 0; j < RV_NLIMB; ++j) { e.q[j] = c->neutral_positions[j]; e.qd[j] = 0.0f; }
       e.q[7] = a->q_hi[7]; e.q[8] = a->q_lo[8]; e.qd[7] = 0.0f; e.qd[8] = 0.0f;
       for (int j = 0; j < RV_NJ; ++j) { e.motor_on[j] = 0; e.motor_q[j] = e.q[j]; e.motor_kp[j] = c->kp; e.motor_kd[j] = c->kd; e.vmax_cmd[j] = a->v_max[j]; }
@@ -1428,6 +1472,7 @@ RV_DEV void env_enter(Shared& S, const Consts& K) {
     if (lane >= 32 && lane < 32 + RV_MAXB) {
       int b = lane - 32;
       stm(S.s.rot[b], qmat(ldq(S.e.body[b] + 3)));
+      if (S.e.active[b]) cache_shape_meta(S, K, b); else S.n_hulls[b] = 0;
     }
   RV_LANES_END
 }

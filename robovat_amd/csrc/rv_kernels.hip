@@ -38,9 +38,18 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   Shared& S = g_shared;
   const int env = (int)blockIdx.x;
   if (env >= args.n_envs) return;
-  Consts K; K.cfg = args.cfg; K.scene = args.scene; K.stop_after = (MODE == MODE_SUB) ? args.stop_after : 0;
   DevEnv* g = args.envs + env;
   const int lane = (int)threadIdx.x;
+  {
+    // stage the launch constants in LDS
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(args.cfg);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&S.cfg);
+    for (int i = lane; i < (int)(sizeof(rv_config) / 4); i += 64) dst[i] = src[i];
+    src = reinterpret_cast<const uint32_t*>(&args.scene->arm);
+    dst = reinterpret_cast<uint32_t*>(&S.arm);
+    for (int i = lane; i < (int)(sizeof(rv_arm) / 4); i += 64) dst[i] = src[i];
+  }
+  Consts K = lds_consts(args.scene, (MODE == MODE_SUB) ? args.stop_after : 0);
   constexpr int W = (int)(sizeof(DevEnv) / 4);
   bool skip = false;
   if (MODE == MODE_RESET) skip = (args.mask != nullptr) && (args.mask[env] == 0);
@@ -52,7 +61,7 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   __syncthreads();
   if (MODE == MODE_MACRO) skip = (S.e.done != 0);
   if (skip) {
-    if (lane == 0) { g->substeps_last = 0; g->awake_last = 0; g->stepped = 0; }
+    if (lane == 0) { g->substeps_last = 0; g->awake_last = 0; g->pairs_last = 0; g->stepped = 0; }
     return;
   }
   if (MODE != MODE_RESET) env_enter(S, K);
@@ -61,11 +70,11 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   } else if (MODE == MODE_MACRO) {
     env_step(S, K);
   } else if (MODE == MODE_SUB) {
-    if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.stepped = 0; }
+    if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; }
     __syncthreads();
-    for (int k = 0; k < args.n_substeps; ++k) sim_substep_call(K);
+    for (int k = 0; k < args.n_substeps; ++k) sim_substep_call(K.scene, K.stop_after);
   } else {
-    if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.stepped = 0; }
+    if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; }
     __syncthreads();
     wait_until_stable(S, K, 0u, args.lin_thr, args.ang_thr, args.check_after, args.min_stable, args.max_steps);
   }
@@ -108,7 +117,7 @@ __global__ void k_get_body_params(const DevEnv* envs, int n, float* out) {
 }
 __global__ void k_set_body_params(DevEnv* envs, int n, const float* in, const rv_config* cfg, const rv_scene* scene) {
   ENV_THREAD();
-  Consts K; K.cfg = cfg; K.scene = scene; K.stop_after = 0;
+  Consts K; K.cfg = cfg; K.arm = &scene->arm; K.scene = scene; K.stop_after = 0;
   int nb = 0;
   for (int b = 0; b < RV_MAXB; ++b) {
     const float* o = in + ((size_t)i * RV_MAXB + b) * 8;
@@ -154,7 +163,7 @@ __global__ void k_get_link_poses(const DevEnv* envs, int n, float* out) {
 __global__ void k_get_env_counters(const DevEnv* envs, int n, int32_t* out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
   const DevEnv& e = envs[i]; int32_t* o = out + (size_t)i * RV_NCOUNTERS;
-  o[8] = e.awake_last; o[9] = e.reset_count;
+  o[8] = e.awake_last; o[9] = e.pairs_last;
   o[0] = e.sim_steps; o[1] = e.num_steps; o[2] = e.num_episodes; o[3] = e.phase; o[4] = e.done; o[5] = e.is_safe; o[6] = e.is_effective; o[7] = e.substeps_last;
 }
 __global__ void k_set_actions(DevEnv* envs, int n, const float* a, int G) {
@@ -185,7 +194,7 @@ __global__ void k_set_link_target(DevEnv* envs, int n, const float* pose, const 
 }
 __global__ void k_compute_ik(const DevEnv* envs, int n, const float* pose, float* q, const rv_config* cfg, const rv_scene* scene) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
-  Consts K; K.cfg = cfg; K.scene = scene; K.stop_after = 0;
+  Consts K; K.cfg = cfg; K.arm = &scene->arm; K.scene = scene; K.stop_after = 0;
   float p[7], q0[RV_NLIMB], out[RV_NLIMB];
   for (int k = 0; k < 7; ++k) p[k] = pose[(size_t)i * 7 + k];
   for (int j = 0; j < RV_NLIMB; ++j) q0[j] = envs[i].q[j];

@@ -17,15 +17,16 @@ struct EmuWorld {
 
 static void run_env(EmuWorld* w, int i, int mode, int n_sub, float lin, float ang, int ca, int ms, int mx) {
   Shared& S = g_shared;
-  Consts K; K.cfg = &w->cfg; K.scene = &w->scene; K.stop_after = 0;
-  memset(&S.s, 0xFF, sizeof(S.s));  /* LDS is not zero-initialised on the GPU: poison it */
+  memset(&S.s, 0xFF, sizeof(S.s));
+  S.cfg = w->cfg; S.arm = w->scene.arm;
+  Consts K = lds_consts(&w->scene, 0);  /* LDS is not zero-initialised on the GPU: poison it */
   memcpy(&S.e, &w->envs[i], sizeof(DevEnv));
-  if (mode == 1 && S.e.done) { w->envs[i].substeps_last = 0; w->envs[i].awake_last = 0; w->envs[i].stepped = 0; return; }
+  if (mode == 1 && S.e.done) { w->envs[i].substeps_last = 0; w->envs[i].awake_last = 0; w->envs[i].pairs_last = 0; w->envs[i].stepped = 0; return; }
   if (mode != 0) env_enter(S, K);
   if (mode == 0) env_reset(S, K, w->cfg.env_id_offset + i);
   else if (mode == 1) env_step(S, K);
-  else if (mode == 2) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.stepped = 0; for (int k = 0; k < n_sub; ++k) sim_substep_call(K); }
-  else { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.stepped = 0; wait_until_stable(S, K, 0u, lin, ang, ca, ms, mx); }
+  else if (mode == 2) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; for (int k = 0; k < n_sub; ++k) sim_substep_call(K.scene, 0); }
+  else { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; wait_until_stable(S, K, 0u, lin, ang, ca, ms, mx); }
   memcpy(&w->envs[i], &S.e, sizeof(DevEnv));
 }
 
@@ -47,7 +48,7 @@ int emu_sizeof_shared(void) { return (int)sizeof(Shared); }
 void emu_reset(EmuWorld* w, const uint8_t* mask) {
 #pragma omp parallel for schedule(dynamic)
   for (int i = 0; i < w->n; ++i) {
-    if (mask && !mask[i]) { w->envs[i].substeps_last = 0; w->envs[i].awake_last = 0; w->envs[i].stepped = 0; continue; }
+    if (mask && !mask[i]) { w->envs[i].substeps_last = 0; w->envs[i].awake_last = 0; w->envs[i].pairs_last = 0; w->envs[i].stepped = 0; continue; }
     run_env(w, i, 0, 0, 0, 0, 0, 0, 0);
   }
 }
@@ -84,7 +85,7 @@ void emu_get_body_params(EmuWorld* w, float* out) {
   }
 }
 void emu_set_body_params(EmuWorld* w, const float* in) {
-  Consts K; K.cfg = &w->cfg; K.scene = &w->scene; K.stop_after = 0;
+  Consts K; K.cfg = &w->cfg; K.arm = &w->scene.arm; K.scene = &w->scene; K.stop_after = 0;
   for (int i = 0; i < w->n; ++i) {
     DevEnv& e = w->envs[i]; int nb = 0;
     for (int b = 0; b < RV_MAXB; ++b) {
@@ -109,7 +110,7 @@ void emu_get_link_poses(EmuWorld* w, float* out) {
 void emu_get_env_counters(EmuWorld* w, int32_t* out) {
   for (int i = 0; i < w->n; ++i) {
     const DevEnv& e = w->envs[i]; int32_t* o = out + (size_t)i * RV_NCOUNTERS;
-    o[8] = e.awake_last; o[9] = e.reset_count;
+    o[8] = e.awake_last; o[9] = e.pairs_last;
     o[0] = e.sim_steps; o[1] = e.num_steps; o[2] = e.num_episodes; o[3] = e.phase; o[4] = e.done; o[5] = e.is_safe; o[6] = e.is_effective; o[7] = e.substeps_last;
   }
 }
