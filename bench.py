@@ -59,6 +59,9 @@ def main():
     ap.add_argument('--envs-per-gpu', type=int, default=1024)
     ap.add_argument('--seed', type=int, default=1234)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', choices=['rollout', 'lockstep'], default='rollout',
+                    help="rollout: the K timed env.step()s of every env run in ONE rv_rollout launch "
+                         "(on-device RandomPolicy, auto-reset); lockstep: K x (policy -> rv_step_macro)")
     args = ap.parse_args()
 
     import torch
@@ -109,18 +112,36 @@ def main():
             counters.copy_(st)
         return r
 
+    def gather_returns():
+        if dist is not None:
+            # RCCL gather of episode returns + counters
+            dist.all_gather_into_tensor(returns_all.view(-1), world.episode_returns())
+            cnt = world.env_counters().to(torch.int64)
+            st = torch.stack([cnt[:, 5].sum(), cnt[:, 6].sum(), cnt[:, 4].sum(), cnt[:, 1].sum()])
+            dist.all_reduce(st)
+            counters.copy_(st)
+
     for k in range(args.warmup):
         one_step(k)
     barrier()
-    kern_ms, substeps, env_steps, max_sub = 0.0, 0, 0, 0
+    kern_ms, substeps, env_steps, max_sub, awake, launches = 0.0, 0, 0, 0, 0, 0
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(args.warmup + k)
-        # stats/kernel time are read after the step's kernels are queued; the
-        # copies below synchronise the stream, which a Python env loop does anyway
+    if args.mode == 'lockstep':
+        for k in range(args.steps):
+            one_step(args.warmup + k)
+            # stats/kernel time are read after the step's kernels are queued; the
+            # copies below synchronise the stream, which a Python env loop does anyway
+            st = world.stats()
+            kern_ms += world.last_kernel_ms(); launches += 1
+            substeps += st['substeps']; env_steps += st['env_steps']; max_sub = max(max_sub, st['max_substeps'])
+            awake += st['awake_substeps']
+    else:
+        rewards, dones = world.rollout(args.steps, first_macro_index=args.warmup, auto_reset=True, record=True)
+        obs = world.observe()
+        gather_returns()
         st = world.stats()
-        kern_ms += world.last_kernel_ms()
-        substeps += st['substeps']; env_steps += st['env_steps']; max_sub = max(max_sub, st['max_substeps'])
+        kern_ms += world.last_kernel_ms(); launches += 1
+        substeps += st['substeps']; env_steps += st['env_steps']; max_sub = st['max_substeps']; awake += st['awake_substeps']
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -135,8 +156,8 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         # roofline of the dominant kernel (k_env<MACRO>), this rank
-        algo_bytes_per_launch = ALGO_BYTES_PER_ENV_SUBSTEP * (substeps / args.steps)
-        avg_kernel_s = 1e-3 * kern_ms / args.steps
+        algo_bytes_per_launch = ALGO_BYTES_PER_ENV_SUBSTEP * (substeps / launches)
+        avg_kernel_s = 1e-3 * kern_ms / launches
         achieved = algo_bytes_per_launch / avg_kernel_s / 1e9
         out = {
             'metric': 'env steps/sec (PushEnv, batched)',
@@ -149,14 +170,15 @@ def main():
             'config': {'workload': 'PushEnv 4 rigid convex bodies, %d vectorised envs/GPU, random policy '
                                    '(BASELINE.json configs[1])' % n,
                        'envs_per_gpu': n, 'bodies': 4, 'dt': 1e-3, 'solver_iters': int(cfg.solver_iters),
-                       'parallelism': 'env-shards x%d' % world_size},
+                       'parallelism': 'env-shards x%d' % world_size, 'mode': args.mode},
             'sim_steps_per_s': substeps_all / elapsed,
             'substeps_per_env_step': substeps_all / max(env_steps_all, 1.0),
             'max_substeps_in_launch': max_sub,
+            'awake_substep_fraction': awake / max(substeps, 1),
             'reset_substeps': reset_stats['substeps'],
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'k_env<MODE_MACRO>', 'avg_kernel_ms': 1e3 * avg_kernel_s,
+                         'kernel': 'k_env<MODE_ROLLOUT>' if args.mode == 'rollout' else 'k_env<MODE_MACRO>', 'avg_kernel_ms': 1e3 * avg_kernel_s,
                          'algorithmic_bytes_per_env_substep': ALGO_BYTES_PER_ENV_SUBSTEP,
                          'note': 'state is LDS-resident for the whole launch; the kernel is VALU/latency-bound '
                                  '(see DESIGN.md §5), HBM traffic is ~2*sizeof(DevEnv) per env per launch'},

@@ -216,6 +216,16 @@ int  rv_reset(rv_world* w, const uint8_t* d_env_mask);
 int  rv_set_actions(rv_world* w, const float* d_actions);
 int  rv_step_macro(rv_world* w);
 
+/* ---- generate_episode's inner loop (episode_generation.py:44-46) for the
+ *      on-device RandomPolicy: n_steps x { action = policy(obs); env.step(action) }
+ *      per env inside ONE launch, so an env never waits for the slowest env of
+ *      the batch between steps.  Actions are the rv_policy_random() draws for
+ *      macro indices first_macro_index .. +n_steps-1; with auto_reset != 0 an
+ *      env whose episode ended is reset (as rv_reset would) before its next
+ *      step, otherwise it stops.  d_rewards / d_dones: optional [n_steps][N]. */
+int  rv_rollout(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t auto_reset,
+                float* d_rewards, uint8_t* d_dones);
+
 /* ---- RandomPolicy._action (random_policy.py:14-23): U(-1,1)^(G*4) from
  *      Philox keyed by (seed, global env id, macro_index). ---- */
 int  rv_policy_random(rv_world* w, int32_t macro_index, float* d_actions);

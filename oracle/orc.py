@@ -37,7 +37,7 @@ def _lib(double):
         lib.orc_create.restype = C.c_void_p
         lib.orc_create.argtypes = [C.POINTER(abi.rv_config), C.POINTER(abi.rv_scene)]
         for name in ('orc_destroy', 'orc_reset', 'orc_set_actions', 'orc_step_macro', 'orc_step_sub',
-                     'orc_wait_until_stable', 'orc_policy_random', 'orc_policy_heuristic',
+                     'orc_wait_until_stable', 'orc_rollout', 'orc_policy_random', 'orc_policy_heuristic',
                      'orc_get_body_state', 'orc_set_body_state', 'orc_get_body_params',
                      'orc_set_body_params', 'orc_get_joint_state', 'orc_set_joint_state',
                      'orc_get_link_poses', 'orc_get_env_counters', 'orc_set_joint_targets',
@@ -86,6 +86,9 @@ class OracleWorld(object):
 
     def step_macro(self):
         self.lib.orc_step_macro(self.h)
+
+    def rollout(self, n_steps, first_macro_index=0, auto_reset=True):
+        self.lib.orc_rollout(self.h, C.c_int(n_steps), C.c_int(first_macro_index), C.c_int(int(bool(auto_reset))))
 
     def step_sub(self, n):
         self.lib.orc_step_sub(self.h, C.c_int(n))

@@ -1358,6 +1358,36 @@ void orc_step_macro(orc_world* w) {
     }
   }
 }
+/* generate_episode's inner loop with RandomPolicy (see rv_rollout in rovat.h) */
+void orc_rollout(orc_world* w, int n_steps, int first_index, int auto_reset) {
+  stats_begin(w);
+  int G = w->cfg.num_goal_steps > 0 ? w->cfg.num_goal_steps : 1;
+  int* stepped = (int*)calloc((size_t)w->n, sizeof(int));
+  int* succ = (int*)calloc((size_t)w->n, sizeof(int));
+#pragma omp parallel for schedule(dynamic)
+  for (int i = 0; i < w->n; ++i) {
+    orc_env* e = &w->env[i];
+    int gid = w->cfg.env_id_offset + i;
+    int sub = 0, aw = 0, pr = 0;
+    e->substeps_last = 0; e->awake_last = 0; e->pairs_last = 0;
+    for (int k = 0; k < n_steps; ++k) {
+      if (e->done) {
+        if (!auto_reset) break;
+        env_reset(w, e, gid);
+        sub += e->substeps_last; aw += e->awake_last; pr += e->pairs_last;
+      }
+      orc_rng g; rng_init(&g, w->cfg.seed_lo, w->cfg.seed_hi, (uint32_t)gid, STREAM_RANDOM, (uint32_t)(first_index + k));
+      for (int x = 0; x < G * 4; ++x) e->action[x >> 2][x & 3] = rng_uniform(&g, R(-1.0), R(1.0));
+      env_step(w, e);
+      sub += e->substeps_last; aw += e->awake_last; pr += e->pairs_last;
+      stepped[i]++;
+      if (e->done && e->last_reward >= (real)w->cfg.success_thresh) succ[i]++;
+    }
+    e->substeps_last = sub; e->awake_last = aw; e->pairs_last = pr;
+  }
+  for (int i = 0; i < w->n; ++i) { stats_env(w, &w->env[i]); w->stats.env_steps += stepped[i]; }
+  free(stepped); free(succ);
+}
 void orc_step_sub(orc_world* w, int n) {
   stats_begin(w);
 #pragma omp parallel for schedule(dynamic)

@@ -1254,12 +1254,13 @@ RV_DEV void phase_tick(Shared& S, const Consts& K) {
 
 // RobotEnv.step (robot_env.py:239-275) + PushEnv._execute_action
 // (push_env.py:631-733) + PushEnv.step bookkeeping (push_env.py:599-629)
-RV_DEV void env_step(Shared& S, const Consts& K) {
+RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
   const rv_config* c = K.cfg;
   RV_LANES_BEGIN
     if (lane == 0) {
       DevEnv& e = S.e; Scratch& s = S.s;
-      e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; e.stepped = 1;
+      if (zero_counters) { e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; }
+      e.stepped += 1;
       int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
       for (int g = 0; g < G; ++g) compute_waypoints(c, e.action[g], s.wp[g][0], s.wp[g][1]);
       e.is_safe = 1; e.is_effective = 1;
@@ -1363,14 +1364,14 @@ RV_DEV void sample_poses(Shared& S, const Consts& K, int nb) {
 }
 
 // RobotEnv.reset for one env (robot_env.py:204-237)
-RV_DEV void env_reset(Shared& S, const Consts& K, int gid) {
+RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1) {
   const rv_config* c = K.cfg;
   RV_LANES_BEGIN
     DevEnv& e = S.e;
     if (lane == 0) {
       S.s.rng = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RESET, (uint32_t)e.reset_count);
       e.reset_count++;
-      e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; e.stepped = 0;
+      if (zero_counters) { e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; e.stepped = 0; }
       e.sim_steps = 0; e.num_steps = 0; e.episode_reward = 0.0f; e.last_reward = 0.0f;
       e.done = 0; e.phase = RV_PHASE_INITIAL; e.is_safe = 1; e.is_effective = 1;
       e.arm_enabled = 0;
@@ -1459,6 +1460,37 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid) {
       }
     }
   RV_LANES_END
+}
+
+// generate_episode's inner loop with the on-device RandomPolicy
+// (episode_generation.py:44-46, random_policy.py:14-23): n_steps env.step()
+// calls back to back for this env; see rv_rollout() in include/rovat.h.
+RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int first_index, int auto_reset,
+                        float* rewards, uint8_t* dones, int env, int n_envs) {
+  const rv_config* c = K.cfg;
+  RV_LANES_BEGIN
+    if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; }
+  RV_LANES_END
+  for (int k = 0; k < n_steps; ++k) {
+    if (S.e.done) {
+      if (!auto_reset) break;
+      env_reset(S, K, gid, 0);
+    }
+    RV_LANES_BEGIN
+      if (lane == 0) {
+        int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
+        Rng g = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RANDOM, (uint32_t)(first_index + k));
+        for (int x = 0; x < G * 4; ++x) S.e.action[x >> 2][x & 3] = rng_uniform(g, -1.0f, 1.0f);
+      }
+    RV_LANES_END
+    env_step(S, K, 0);
+    RV_LANES_BEGIN
+      if (lane == 0) {
+        if (rewards) rewards[(size_t)k * n_envs + env] = S.e.last_reward;
+        if (dones) dones[(size_t)k * n_envs + env] = (uint8_t)S.e.done;
+      }
+    RV_LANES_END
+  }
 }
 
 // rebuild the per-launch caches that are not part of the persistent block

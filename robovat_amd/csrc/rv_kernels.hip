@@ -19,7 +19,7 @@
 using namespace rv;
 
 // ------------------------------------------------------------------ kernels
-enum { MODE_RESET = 0, MODE_MACRO = 1, MODE_SUB = 2, MODE_WAIT = 3 };
+enum { MODE_RESET = 0, MODE_MACRO = 1, MODE_SUB = 2, MODE_WAIT = 3, MODE_ROLLOUT = 4 };
 
 struct EnvKernelArgs {
   const rv_config* cfg;
@@ -31,6 +31,8 @@ struct EnvKernelArgs {
   float lin_thr, ang_thr;
   int check_after, min_stable, max_steps;
   int stop_after;   // profiling hook (env RV_DEBUG_STOP, MODE_SUB only)
+  int first_index, auto_reset;   // MODE_ROLLOUT
+  float* rewards; uint8_t* dones;
 };
 
 template <int MODE>
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   }
   __syncthreads();
   if (MODE == MODE_MACRO) skip = (S.e.done != 0);
+  if (MODE == MODE_ROLLOUT) skip = (S.e.done != 0) && !args.auto_reset;
   if (skip) {
     if (lane == 0) { g->substeps_last = 0; g->awake_last = 0; g->pairs_last = 0; g->stepped = 0; }
     return;
@@ -68,7 +71,11 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   if (MODE == MODE_RESET) {
     env_reset(S, K, K.cfg->env_id_offset + env);
   } else if (MODE == MODE_MACRO) {
+    if (lane == 0) S.e.stepped = 0;
+    __syncthreads();
     env_step(S, K);
+  } else if (MODE == MODE_ROLLOUT) {
+    env_rollout(S, K, K.cfg->env_id_offset + env, args.n_substeps, args.first_index, args.auto_reset, args.rewards, args.dones, env, args.n_envs);
   } else if (MODE == MODE_SUB) {
     if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; }
     __syncthreads();
@@ -329,7 +336,7 @@ __global__ void k_stats(const DevEnv* envs, int n, rv_macro_stats* st, float suc
     atomicAdd((u64*)&st->awake_substeps, (u64)e.awake_last);
   }
   if (e.stepped) {
-    atomicAdd((u64*)&st->env_steps, (u64)1);
+    atomicAdd((u64*)&st->env_steps, (u64)e.stepped);
     if (!e.is_safe) atomicAdd((u64*)&st->unsafe, (u64)1);
     if (!e.is_effective) atomicAdd((u64*)&st->ineffective, (u64)1);
     if (e.is_safe && e.is_effective) atomicAdd((u64*)&st->useful, (u64)1);
@@ -363,8 +370,10 @@ static inline dim3 grid1(int n) { return dim3((unsigned)((n + 127) / 128)); }
 #define TPB 128
 
 template <int MODE>
-static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, float ang, int ca, int ms, int mx) {
+static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, float ang, int ca, int ms, int mx,
+                      int first_index = 0, int auto_reset = 0, float* rewards = nullptr, uint8_t* dones = nullptr) {
   EnvKernelArgs a;
+  a.first_index = first_index; a.auto_reset = auto_reset; a.rewards = rewards; a.dones = dones;
   a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.mask = mask; a.n_envs = w->n;
   { const char* ds = getenv("RV_DEBUG_STOP"); a.stop_after = ds ? atoi(ds) : 0; }
   a.n_substeps = n_sub; a.lin_thr = lin; a.ang_thr = ang; a.check_after = ca; a.min_stable = ms; a.max_steps = mx;
@@ -430,6 +439,11 @@ int rv_num_envs(const rv_world* w) { return w ? w->n : 0; }
 
 int rv_reset(rv_world* w, const uint8_t* d_env_mask) { WCHK(w); return launch_env<MODE_RESET>(w, d_env_mask, 0, 0, 0, 0, 0, 0); }
 int rv_step_macro(rv_world* w) { WCHK(w); return launch_env<MODE_MACRO>(w, nullptr, 0, 0, 0, 0, 0, 0); }
+int rv_rollout(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t auto_reset, float* d_rewards, uint8_t* d_dones) {
+  WCHK(w);
+  if (n_steps <= 0) return fail(RV_ERR_VALUE, "rv_rollout: n_steps must be positive");
+  return launch_env<MODE_ROLLOUT>(w, nullptr, n_steps, 0, 0, 0, 0, 0, first_macro_index, auto_reset, d_rewards, d_dones);
+}
 int rv_step_sub(rv_world* w, int32_t n) {
   WCHK(w);
   if (n < 0) return fail(RV_ERR_VALUE, "rv_step_sub: negative substep count");

@@ -24,7 +24,8 @@ static void run_env(EmuWorld* w, int i, int mode, int n_sub, float lin, float an
   if (mode == 1 && S.e.done) { w->envs[i].substeps_last = 0; w->envs[i].awake_last = 0; w->envs[i].pairs_last = 0; w->envs[i].stepped = 0; return; }
   if (mode != 0) env_enter(S, K);
   if (mode == 0) env_reset(S, K, w->cfg.env_id_offset + i);
-  else if (mode == 1) env_step(S, K);
+  else if (mode == 1) { S.e.stepped = 0; env_step(S, K); }
+  else if (mode == 4) env_rollout(S, K, w->cfg.env_id_offset + i, n_sub, ca, ms, nullptr, nullptr, i, w->n);
   else if (mode == 2) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; for (int k = 0; k < n_sub; ++k) sim_substep_call(K.scene, 0); }
   else { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; wait_until_stable(S, K, 0u, lin, ang, ca, ms, mx); }
   memcpy(&w->envs[i], &S.e, sizeof(DevEnv));
@@ -55,6 +56,13 @@ void emu_reset(EmuWorld* w, const uint8_t* mask) {
 void emu_step_macro(EmuWorld* w) {
 #pragma omp parallel for schedule(dynamic)
   for (int i = 0; i < w->n; ++i) run_env(w, i, 1, 0, 0, 0, 0, 0, 0);
+}
+void emu_rollout(EmuWorld* w, int n_steps, int first_index, int auto_reset) {
+#pragma omp parallel for schedule(dynamic)
+  for (int i = 0; i < w->n; ++i) {
+    if (w->envs[i].done && !auto_reset) { w->envs[i].substeps_last = 0; w->envs[i].awake_last = 0; w->envs[i].pairs_last = 0; w->envs[i].stepped = 0; continue; }
+    run_env(w, i, 4, n_steps, 0, 0, first_index, auto_reset, 0);
+  }
 }
 void emu_step_sub(EmuWorld* w, int n) {
 #pragma omp parallel for schedule(dynamic)

@@ -84,3 +84,28 @@ def test_masked_reset_only_touches_masked_envs(emu):
     after = e.body_state()
     assert np.array_equal(after[[0, 2]], before[[0, 2]]) and not np.array_equal(after[[1, 3]], before[[1, 3]])
     _check(e, ref)
+
+
+def test_rollout_equals_lockstep_and_oracle(emu):
+    """rv_rollout semantics: K x (RandomPolicy action -> env.step) in one launch
+    gives exactly the lock-step sequence (policy_random -> set_actions ->
+    step_macro, reset of finished envs in between)."""
+    from oracle import orc
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(env_cfg=configs.push_env_config(MAX_STEPS=2), n_envs=5, seed=23, shape_names=names)
+    ref_lock = orc.OracleWorld(cfg, scene); ref_roll = orc.OracleWorld(cfg, scene); e = Emu(emu, cfg, scene)
+    for w in (ref_lock, ref_roll):
+        w.reset()
+    emu.emu_reset(e.h, None)
+    K = 3
+    for k in range(K):
+        done = ref_lock.env_counters()[:, 4].astype(np.uint8)
+        if done.any():
+            ref_lock.reset(done)
+        ref_lock.set_actions(ref_lock.policy_random(10 + k)); ref_lock.step_macro()
+    ref_roll.rollout(K, 10, True)
+    emu.emu_rollout(e.h, K, 10, 1)
+    assert np.array_equal(ref_roll.body_state(), ref_lock.body_state())
+    assert np.array_equal(ref_roll.env_counters()[:, :7], ref_lock.env_counters()[:, :7])
+    _check(e, ref_roll)
+    assert ref_roll.stats()['env_steps'] == K * 5

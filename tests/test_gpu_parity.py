@@ -138,3 +138,14 @@ def test_full_size_properties_config2():
     world2 = _worlds(1024, seed=1234)[0]
     world2.reset(); world2.set_actions(a); world2.step_macro()
     assert np.array_equal(world2.body_state().cpu().numpy(), st2)
+
+
+def test_rollout_matches_oracle_rollout():
+    world, ref, cfg = _worlds(12, seed=31, MAX_STEPS=2)
+    world.reset(); ref.reset()
+    r, d = world.rollout(3, first_macro_index=4, auto_reset=True, record=True)
+    ref.rollout(3, 4, True)
+    _cmp(world, ref, 1e-6)
+    ws, rs = world.stats(), ref.stats()
+    assert ws['env_steps'] == rs['env_steps'] == 36 and ws['substeps'] == rs['substeps']
+    assert np.isfinite(r.cpu().numpy()).all() and d.cpu().numpy().shape == (3, 12)
