@@ -1,0 +1,170 @@
+"""PushEnv on the MI355X backend.
+
+``VecPushEnv`` is the fast path: N envs advance together, ``step(actions)`` is
+one ``rv_step_macro`` launch that runs the whole ``_execute_action`` phase
+machine, the settle, the observations and the reward on the device
+(reference: ``robovat/envs/push/push_env.py:599-937``,
+``robovat/envs/robot_env.py:204-312``).  ``PushEnv`` keeps the reference's
+single-env gym-style API (``reset() -> obs``, ``step(a) -> obs, reward, done,
+None``, same observation keys / dtypes / shapes, ``push_env.py:169-267``) as a
+batch of one.
+"""
+import collections
+
+import numpy as np
+
+from robovat_amd import abi, configs, scenes
+
+
+class Box(object):
+    """Stand-in for ``gym.spaces.Box`` (gym is not a dependency)."""
+
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        self.low = np.broadcast_to(np.asarray(low, dtype=dtype), shape if shape is not None else np.shape(low)).copy()
+        self.high = np.broadcast_to(np.asarray(high, dtype=dtype), self.low.shape).copy()
+        self.shape, self.dtype = self.low.shape, dtype
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+class VecPushEnv(object):
+    """N PushEnv instances on one GPU (env shards [offset, offset + N))."""
+
+    def __init__(self, num_envs, config=None, robot_config=None, device=0, seed=0,
+                 env_id_offset=0, use_point_cloud=False):
+        from robovat_amd import lib
+        self.config = config or configs.push_env_config()
+        self.robot_config = robot_config or configs.sawyer_config()
+        self.scene, self.shape_names = scenes.make_scene()
+        self.rv_config = configs.make_rv_config(self.config, self.robot_config, self.shape_names,
+                                                n_envs=num_envs, env_id_offset=env_id_offset, seed=seed)
+        self.world = lib.World(self.rv_config, self.scene, device=device)
+        self.num_envs = int(num_envs)
+        self.max_movable_bodies = abi.RV_MAXB
+        self.use_point_cloud = bool(use_point_cloud)
+        g = self.rv_config.num_goal_steps
+        self.action_shape = (4,) if g == 0 else (g, 4)
+        self.action_space = Box(-1.0, 1.0, self.action_shape)
+        self._macro_index = 0
+
+    @property
+    def device(self):
+        return self.world.device
+
+    def get_observation(self):
+        return self.world.observe(point_cloud=self.use_point_cloud)
+
+    def reset(self, mask=None):
+        """RobotEnv.reset for every env (or the masked ones)."""
+        self.world.reset(mask)
+        return self.get_observation()
+
+    def step(self, actions):
+        """RobotEnv.step for every env whose episode is not done."""
+        self.world.set_actions(actions)
+        self.world.step_macro()
+        self._macro_index += 1
+        obs = self.get_observation()
+        reward, done = self.world.reward()
+        return obs, reward, done.bool(), None
+
+    def sample_random_actions(self):
+        """RandomPolicy on the device (Philox keyed by global env id and step)."""
+        a = self.world.policy_random(self._macro_index)
+        return a.reshape((self.num_envs,) + self.action_shape)
+
+    def sample_heuristic_actions(self, max_attempts=20000):
+        a = self.world.policy_heuristic(max_attempts)
+        return a.reshape((self.num_envs,) + self.action_shape)
+
+    def rollout(self, n_steps, auto_reset=True, record=True):
+        out = self.world.rollout(n_steps, self._macro_index, auto_reset, record)
+        self._macro_index += int(n_steps)
+        return out
+
+    def stats(self):
+        return self.world.stats()
+
+    def close(self):
+        self.world.close()
+
+
+class PushEnv(object):
+    """Single-env PushEnv with the reference's API (a VecPushEnv of one)."""
+
+    def __init__(self, simulator=None, config=None, debug=False, robot_config=None, device=0, seed=0,
+                 worker_id=0):
+        self._config = config or configs.push_env_config()
+        self._debug = debug
+        self._simulator = simulator
+        self._vec = VecPushEnv(1, self._config, robot_config, device=device, seed=seed, env_id_offset=worker_id,
+                               use_point_cloud=True)
+        self.max_movable_bodies = abi.RV_MAXB
+        self.task_name = self._config.TASK_NAME
+        self.layout_id = self._config.LAYOUT_ID
+        self.num_goal_steps = self._config.NUM_GOAL_STEPS
+        self.action_space = self._vec.action_space
+        self.phase_list = list(abi.PHASES)
+        self._obs_data = self._prev_obs_data = None
+        self._done = True
+        self._episode_reward = self._total_reward = 0.0
+
+    config = property(lambda s: s._config)
+    debug = property(lambda s: s._debug)
+    simulator = property(lambda s: s._simulator)
+    is_simulation = property(lambda s: True)
+    obs_data = property(lambda s: s._obs_data)
+    prev_obs_data = property(lambda s: s._prev_obs_data)
+    done = property(lambda s: s._done)
+    episode_reward = property(lambda s: s._episode_reward)
+    total_reward = property(lambda s: s._total_reward)
+    info = property(lambda s: {'name': 'PushEnv'})
+
+    def _counters(self):
+        return self._vec.world.env_counters().cpu().numpy()[0]
+
+    num_steps = property(lambda s: int(s._counters()[1]))
+    num_episodes = property(lambda s: int(s._counters()[2]))
+
+    def _convert(self, obs):
+        out = collections.OrderedDict()
+        for key in ('num_episodes', 'num_steps', 'layout_id'):
+            out[key] = np.array(obs[key][0].item(), dtype=np.int64)
+        out['body_mask'] = obs['body_mask'][0].cpu().numpy().astype(np.float32)
+        out['point_cloud'] = obs['point_cloud'][0].cpu().numpy().astype(np.float32)
+        if self._config.USE_PRESTIGE_OBS:
+            out['position'] = obs['position'][0].cpu().numpy().astype(np.float32)
+            out['is_safe'] = np.array(obs['is_safe'][0].item(), dtype=np.int64)
+            out['is_effective'] = np.array(obs['is_effective'][0].item(), dtype=np.int64)
+        return out
+
+    def reset(self):
+        self._prev_obs_data = None
+        self._obs_data = self._convert(self._vec.reset())
+        self._done = False
+        self._episode_reward = 0.0
+        return self._obs_data
+
+    def step(self, action):
+        if self._done:
+            raise ValueError('The environment is done. Forget to reset?')
+        action = np.asarray(action, dtype=np.float32).reshape((1,) + self._vec.action_shape)
+        obs, reward, done, _ = self._vec.step(action)
+        self._prev_obs_data, self._obs_data = self._obs_data, self._convert(obs)
+        reward = float(reward[0].item())
+        self._done = bool(done[0].item())
+        self._episode_reward += reward
+        if self._done:
+            self._total_reward += self._episode_reward
+        return self._obs_data, reward, self._done, None
+
+    def get_observation(self):
+        return self._obs_data
+
+    def close(self):
+        self._vec.close()

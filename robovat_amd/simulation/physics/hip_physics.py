@@ -1,0 +1,312 @@
+"""``HipPhysics`` — the drop-in physics plugin backed by ``librovat_hip.so``.
+
+It has the method names / arguments of ``BulletPhysics`` that the PushEnv and
+grasp paths call (``robovat/simulation/physics/bullet_physics.py:89-137,
+143-438, 444-729, 1061-1104, 1203-1304``; list in SURVEY.md §8b) for ONE env:
+each getter reads the device state of env 0, each setter writes it through the
+C ABI.  The batched fast path is ``robovat_amd.envs.VecPushEnv``; this class
+exists so code written against ``Simulator`` / ``Body`` keeps working.
+
+uids: movable bodies are their slot 0..RV_MAXB-1; the table is ``TABLE_UID``,
+the arm ``ARM_UID``; links / joints are ``(ARM_UID, index)`` tuples.
+"""
+import os
+
+import numpy as np
+
+from robovat_amd import abi, configs, scenes
+from robovat_amd.math import Pose
+from robovat_amd.simulation.physics.physics import Physics
+
+TABLE_UID = 100
+ARM_UID = 200
+STATIC_UID = 300     # ground / wall / tiles: visual only
+
+
+class HipPhysics(Physics):
+
+    def __init__(self, time_step=1e-3, use_visualizer=False, worker_id=0, config=None, robot_config=None,
+                 device=0, seed=0):
+        if use_visualizer:
+            raise NotImplementedError('the HIP backend has no debug visualizer')
+        self._env_config = config or configs.push_env_config()
+        self._robot_config = robot_config or configs.sawyer_config()
+        self._env_config.PHYSICS.TIME_STEP = time_step
+        self._time_step = time_step
+        self._worker_id, self._device, self._seed = worker_id, device, seed
+        self._world = None
+        self._gravity = None
+        self._static = {}
+        self.scene, self.shape_names = scenes.make_scene()
+        self._num_steps = None
+
+    # ---- lifecycle (bullet_physics.py:89-137)
+    time_step = property(lambda s: s._time_step)
+    num_steps = property(lambda s: s._num_steps)
+    gravity = property(lambda s: s._gravity)
+    uid = property(lambda s: s._worker_id)
+    world = property(lambda s: s._world)
+
+    def reset(self):
+        from robovat_amd import lib
+        if self._world is not None:
+            self._world.close()
+        cfg = configs.make_rv_config(self._env_config, self._robot_config, self.shape_names, n_envs=1,
+                                     env_id_offset=self._worker_id, seed=self._seed)
+        self._cfg = cfg
+        self._world = lib.World(cfg, self.scene, device=self._device)
+        self._num_steps = None
+        self._static = {}
+
+    def start(self):
+        self._num_steps = 0
+
+    def step(self):
+        self._world.step_sub(1)
+        self._num_steps += 1
+
+    def is_real_time(self):
+        return False
+
+    def time(self):
+        return self._time_step * self._num_steps
+
+    def set_gravity(self, gravity):
+        if abs(gravity[0]) > 0 or abs(gravity[1]) > 0:
+            raise NotImplementedError('only gravity along z is supported')
+        if self._world is not None and abs(gravity[2] - self._cfg.gravity_z) > 1e-5:
+            raise NotImplementedError('gravity is fixed at world creation (PHYSICS.GRAVITY_Z)')
+        self._gravity = list(gravity)
+
+    # ---- helpers
+    def _np(self, t):
+        return t.cpu().numpy()
+
+    def _slot(self, uid):
+        if not isinstance(uid, (int, np.integer)) or not 0 <= uid < abi.RV_MAXB:
+            raise ValueError('not a movable body uid: %r' % (uid,))
+        return int(uid)
+
+    # ---- bodies (bullet_physics.py:143-438)
+    def add_body(self, filename, pose, scale=1.0, is_static=False):
+        name = os.path.splitext(os.path.basename(filename))[0]
+        pose = Pose(pose)
+        if name in self.shape_names:
+            params = self._np(self._world.body_params())
+            free = [b for b in range(abi.RV_MAXB) if params[0, b, 0] == 0]
+            if not free:
+                raise ValueError('all %d movable body slots are in use' % abi.RV_MAXB)
+            b = free[0]
+            table_z = params[0, 0, 6]
+            # URDF template defaults: mass 0.1, lateral friction 1.0 (tools/templates/urdf_template.xml:11-22)
+            params[0, b] = [1, self.shape_names.index(name), scale, 0.1, 1.0, 0, table_z, 0]
+            params[0, 0, 6] = table_z
+            state = self._np(self._world.body_state())
+            state[0, b, :3] = pose.position
+            state[0, b, 3:7] = pose.quaternion
+            state[0, b, 7:] = 0
+            self._world.set_body_params(params)
+            self._world.set_body_state(state)
+            return b
+        if 'table' in name:
+            params = self._np(self._world.body_params())
+            params[0, 0, 6] = pose.position[2]
+            self._world.set_body_params(params)
+            return TABLE_UID
+        if 'sawyer' in name or 'arm' in name:
+            js = np.zeros((1, abi.RV_NJ, 2), np.float32)
+            js[0, :7, 0] = list(self._cfg.neutral_positions)
+            js[0, 7, 0] = self.scene.arm.q_hi[7]
+            js[0, 8, 0] = self.scene.arm.q_lo[8]
+            self._world.set_joint_state(js)
+            return ARM_UID
+        uid = STATIC_UID + len(self._static)
+        self._static[uid] = pose
+        return uid
+
+    def remove_body(self, body_uid):
+        if body_uid in self._static:
+            del self._static[body_uid]
+            return
+        b = self._slot(body_uid)
+        params = self._np(self._world.body_params())
+        params[0, b, 0] = 0
+        self._world.set_body_params(params)
+
+    def _state(self, body_uid):
+        return self._np(self._world.body_state())[0, self._slot(body_uid)]
+
+    def get_body_pose(self, body_uid):
+        if body_uid == TABLE_UID:
+            tz = float(self._np(self._world.body_params())[0, 0, 6])
+            return Pose([[self._cfg.table_center[0], self._cfg.table_center[1], tz], [0, 0, 0]])
+        if body_uid == ARM_UID:
+            return Pose([list(self.scene.arm.base_pos), list(self.scene.arm.base_quat)])
+        if body_uid in self._static:
+            return self._static[body_uid]
+        s = self._state(body_uid)
+        return Pose([s[:3], s[3:7]])
+
+    def get_body_position(self, body_uid):
+        return np.asarray(self.get_body_pose(body_uid).position)
+
+    def get_body_linear_velocity(self, body_uid):
+        return np.array(self._state(body_uid)[7:10], dtype=np.float32)
+
+    def get_body_angular_velocity(self, body_uid):
+        return np.array(self._state(body_uid)[10:13], dtype=np.float32)
+
+    def get_body_mass(self, body_uid):
+        return float(self._np(self._world.body_params())[0, self._slot(body_uid), 3])
+
+    def get_body_dynamics(self, body_uid):
+        p = self._np(self._world.body_params())[0, self._slot(body_uid)]
+        return {'mass': float(p[3]), 'lateral_friction': float(p[4]), 'rolling_friction': 0.0,
+                'spinning_friction': 0.0}
+
+    def get_body_link_indices(self, body_uid):
+        return list(range(abi.RV_NFRAME)) if body_uid == ARM_UID else []
+
+    def get_body_joint_indices(self, body_uid):
+        return list(range(abi.RV_NJ)) if body_uid == ARM_UID else []
+
+    def _set_state(self, body_uid, sl, value):
+        b = self._slot(body_uid)
+        state = self._np(self._world.body_state())
+        state[0, b, sl] = value
+        self._world.set_body_state(state)
+
+    def set_body_pose(self, body_uid, pose):
+        pose = Pose(pose)
+        self.set_body_position(body_uid, pose.position)
+        self.set_body_orientation(body_uid, pose.orientation)
+
+    def set_body_position(self, body_uid, position):
+        self._set_state(body_uid, slice(0, 3), np.asarray(position, np.float32))
+
+    def set_body_orientation(self, body_uid, orientation):
+        from robovat_amd.math import Orientation
+        self._set_state(body_uid, slice(3, 7), np.asarray(Orientation(orientation).quaternion, np.float32))
+
+    def set_body_linear_velocity(self, body_uid, linear_velocity):
+        self._set_state(body_uid, slice(7, 10), np.asarray(linear_velocity, np.float32))
+
+    def set_body_angular_velocity(self, body_uid, angular_velocity):
+        self._set_state(body_uid, slice(10, 13), np.asarray(angular_velocity, np.float32))
+
+    def set_body_mass(self, body_uid, mass):
+        self.set_body_dynamics(body_uid, mass=mass)
+
+    def set_body_dynamics(self, body_uid, mass=None, lateral_friction=None, rolling_friction=None,
+                          spinning_friction=None):
+        b = self._slot(body_uid)
+        params = self._np(self._world.body_params())
+        if mass is not None:
+            params[0, b, 3] = mass
+        if lateral_friction is not None:
+            params[0, b, 4] = lateral_friction
+        state = self._np(self._world.body_state())
+        self._world.set_body_params(params)
+        self._world.set_body_state(state)
+
+    def set_body_color(self, body_uid, rgba, specular):
+        pass   # no renderer
+
+    # ---- links / joints (bullet_physics.py:444-729)
+    def get_link_name(self, link_uid):
+        return scenes.LINK_NAMES[link_uid[1]]
+
+    def get_link_pose(self, link_uid):
+        p = self._np(self._world.link_poses())[0, link_uid[1]]
+        return Pose([p[:3], p[3:7]])
+
+    def get_link_center_of_mass(self, link_uid):
+        return self.get_link_pose(link_uid)
+
+    def get_link_mass(self, link_uid):
+        raise NotImplementedError('This is not implemented in the HIP backend.')
+
+    def set_link_dynamics(self, link_uid, mass=None, lateral_friction=None, rolling_friction=None,
+                          spinning_friction=None):
+        raise NotImplementedError('per-link friction is a world-creation constant (PHYSICS.ARM_FRICTION)')
+
+    def get_joint_name(self, joint_uid):
+        names = scenes.LIMB_JOINT_NAMES + scenes.FINGER_JOINT_NAMES
+        return names[joint_uid[1]]
+
+    def get_joint_dynamics(self, joint_uid):
+        return {'damping': 0.0, 'friction': 0.0}
+
+    def get_joint_limit(self, joint_uid):
+        j = joint_uid[1]
+        a = self.scene.arm
+        return {'lower': a.q_lo[j], 'upper': a.q_hi[j], 'effort': a.a_max[j], 'velocity': a.v_max[j]}
+
+    def get_joint_position(self, joint_uid):
+        return float(self._np(self._world.joint_state())[0, joint_uid[1], 0])
+
+    def get_joint_velocity(self, joint_uid):
+        return float(self._np(self._world.joint_state())[0, joint_uid[1], 1])
+
+    def set_joint_position(self, joint_uid, position):
+        js = self._np(self._world.joint_state())
+        js[0, joint_uid[1], 0] = position
+        js[0, joint_uid[1], 1] = 0.0
+        self._world.set_joint_state(js)
+
+    def get_joint_reaction_force(self, joint_uid):
+        raise NotImplementedError('the kinematic arm has no reaction forces')
+
+    # ---- control (bullet_physics.py:1061-1104) and IK (:1203-1262)
+    def position_control_array(self, body_uid, joint_inds, target_positions, target_velocities=None,
+                               max_velocities=None, max_forces=None, position_gains=None, velocity_gains=None):
+        if max_velocities is not None:
+            raise NotImplementedError('This is not implemented in pybullet.')
+        q = self._np(self._world.joint_state())[0, :7, 0].copy()
+        for j, v in zip(joint_inds, target_positions):
+            if j < 7:
+                q[j] = v
+        self._world.set_joint_targets(q[None])
+
+    def compute_inverse_kinematics(self, link_uid, link_pose, upper_limits=None, lower_limits=None, ranges=None,
+                                   damping=None, neutral_positions=None):
+        pose = Pose(link_pose)
+        p = np.concatenate([np.asarray(pose.position), np.asarray(pose.quaternion)]).astype(np.float32)
+        q = self._np(self._world.compute_ik(p[None]))[0]
+        js = self._np(self._world.joint_state())[0, :, 0]
+        return list(q) + list(js[7:])
+
+    # ---- contacts (bullet_physics.py:1268-1304): the LENGTH of the list is what callers use
+    def get_contact_points(self, a_uid, b_uid=None):
+        def body(uid):
+            if isinstance(uid, (int, np.integer)):
+                return int(uid)
+            if isinstance(uid, (tuple, list)):
+                return int(uid[0])
+            raise ValueError
+        a = body(a_uid)
+        b = None if b_uid is None else body(b_uid)
+        flags = self._np(self._world.query_contacts())[0]
+        counts = self._np(self._world.manifold_counts())[0]
+        if b is not None and a != ARM_UID and b == ARM_UID:
+            a, b = b, a
+        hit = False
+        if a == ARM_UID:
+            if b is None:
+                hit = bool(flags[0] or flags[1])
+            elif b == TABLE_UID:
+                hit = bool(flags[0])
+            elif 0 <= b < abi.RV_MAXB:
+                hit = bool(flags[2 + b])
+        elif 0 <= a < abi.RV_MAXB:
+            if b is None or b == TABLE_UID:
+                hit = counts[a] > 0
+            if (b is None or (0 <= b < abi.RV_MAXB)) and not hit:
+                for k, (x, y) in enumerate([(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]):
+                    if a in (x, y) and (b is None or b in (x, y)) and counts[abi.RV_MAXB + k] > 0:
+                        hit = True
+        return [0.0] if hit else []
+
+    # ---- not on the PushEnv / grasp paths ("implement last / stub")
+    def add_constraint(self, *args, **kwargs):
+        raise NotImplementedError('user constraints are a next-row item (SURVEY.md §8f rank 4)')

@@ -1,0 +1,157 @@
+"""``Simulator`` / ``Body`` with the reference's object-model API
+(``robovat/simulation/simulator.py:20-376``, ``body.py:14-240``): the backend is
+resolved by name with ``getattr(physics, physics_backend)`` exactly like the
+reference (simulator.py:45-49); ``HipPhysics`` is the MI355X plugin."""
+import os.path
+
+import numpy as np
+
+from robovat_amd.math import Pose
+from robovat_amd.simulation import physics
+
+
+class Body(object):
+    """A body handle (body.py:14-240): getters read the backend state."""
+
+    def __init__(self, simulator, filename, pose, scale=1.0, is_static=False, name=None):
+        self._simulator = simulator
+        self._uid = simulator.physics.add_body(filename, pose, scale=scale, is_static=is_static)
+        self.name = name or 'body_%s' % self._uid
+        self._is_static = is_static
+
+    simulator = property(lambda s: s._simulator)
+    physics = property(lambda s: s._simulator.physics)
+    uid = property(lambda s: s._uid)
+    is_static = property(lambda s: s._is_static)
+    pose = property(lambda s: s.physics.get_body_pose(s._uid))
+    position = property(lambda s: s.pose.position)
+    orientation = property(lambda s: s.pose.orientation)
+    euler = property(lambda s: s.pose.euler)
+    quaternion = property(lambda s: s.pose.quaternion)
+    linear_velocity = property(lambda s: s.physics.get_body_linear_velocity(s._uid))
+    angular_velocity = property(lambda s: s.physics.get_body_angular_velocity(s._uid))
+
+    @pose.setter
+    def pose(self, value):
+        self.physics.set_body_pose(self._uid, value)
+
+    def update(self):
+        pass
+
+    def set_dynamics(self, mass=None, lateral_friction=None, rolling_friction=None, spinning_friction=None):
+        self.physics.set_body_dynamics(self._uid, mass=mass, lateral_friction=lateral_friction,
+                                       rolling_friction=rolling_friction, spinning_friction=rolling_friction)
+
+    def set_color(self, rgba=None, specular=None):
+        self.physics.set_body_color(self._uid, rgba, specular)
+
+
+class ControllableBody(Body):
+    """The arm: targets are handed to the device-side ControllableBody state
+    machine (controllable_body.py:263-345 -> rv_set_joint_targets / rv_set_link_target)."""
+
+    def set_target_joint_positions(self, joint_positions, timeout=15.0, threshold=0.008726640):
+        self.physics.world.set_joint_targets(np.asarray(joint_positions, np.float32)[None, :7])
+
+    def set_target_link_pose(self, link_ind, link_pose, timeout=15.0, threshold=0.008726640):
+        pose = Pose(link_pose)
+        p = np.concatenate([np.asarray(pose.position), np.asarray(pose.quaternion)]).astype(np.float32)
+        self.physics.world.set_link_target(p[None])
+
+    def set_max_joint_velocities(self, joint_velocities):
+        pass   # LIMB_MAX_VELOCITY_RATIO is applied on the device
+
+    def reset_targets(self):
+        q = self.physics.world.joint_state().cpu().numpy()[0, :7, 0]
+        self.physics.world.set_joint_targets(q[None])
+
+    @property
+    def joint_positions(self):
+        return list(self.physics.world.joint_state().cpu().numpy()[0, :, 0])
+
+
+class Simulator(object):
+
+    def __init__(self, assets_dir=None, physics_backend='HipPhysics', time_step=1e-3, gravity=[0, 0, -9.8],
+                 worker_id=0, use_visualizer=False, **backend_kwargs):
+        self._assets_dir = os.path.abspath(assets_dir or './')
+        self._gravity = gravity
+        physics_class = getattr(physics, physics_backend)
+        self._physics = physics_class(time_step=time_step, use_visualizer=use_visualizer, worker_id=worker_id,
+                                      **backend_kwargs)
+        self._num_steps = 0
+        self._bodies, self._constraints = dict(), dict()
+
+    assets_dir = property(lambda s: s._assets_dir)
+    physics = property(lambda s: s._physics)
+    bodies = property(lambda s: s._bodies)
+    constraints = property(lambda s: s._constraints)
+    num_steps = property(lambda s: s._num_steps)
+    time_step = property(lambda s: s._physics.time_step)
+
+    def reset(self):
+        self.physics.reset()
+        self.physics.set_gravity(self._gravity)
+        self._bodies, self._constraints = dict(), dict()
+        self._num_steps = 0
+
+    def start(self):
+        self.physics.start()
+        self._num_steps = 0
+
+    def step(self):
+        for body in self.bodies.values():
+            body.update()
+        self.physics.step()
+        self._num_steps += 1
+
+    def add_body(self, filename, pose=None, scale=1.0, is_static=False, is_controllable=False, name=None):
+        if pose is None:
+            pose = [[0, 0, 0], [0, 0, 0]]
+        cls = ControllableBody if is_controllable else Body
+        body = cls(simulator=self, filename=filename, pose=pose, scale=scale, is_static=is_static, name=name)
+        self._bodies[body.name] = body
+        return body
+
+    def remove_body(self, name):
+        self.physics.remove_body(self._bodies[name].uid)
+        del self._bodies[name]
+
+    def receive_robot_commands(self, robot_command, component_type='body'):
+        if component_type != 'body':
+            raise ValueError('Unrecognized component type: %r' % component_type)
+        component = self._bodies[robot_command.component]
+        getattr(component, robot_command.command_type)(**robot_command.arguments)
+
+    def check_contact(self, entity_a, entity_b=None):
+        entities_a = entity_a if isinstance(entity_a, (list, tuple)) else [entity_a]
+        entities_b = entity_b if isinstance(entity_b, (list, tuple)) else [entity_b]
+        for a in entities_a:
+            for b in entities_b:
+                if len(self._physics.get_contact_points(a.uid, None if b is None else b.uid)) > 0:
+                    return True
+        return False
+
+    def check_stable(self, body, linear_velocity_threshold, angular_velocity_threshold):
+        lin = np.linalg.norm(body.linear_velocity)
+        ang = np.linalg.norm(body.angular_velocity)
+        moving_lin = linear_velocity_threshold is not None and lin >= linear_velocity_threshold
+        moving_ang = angular_velocity_threshold is not None and ang >= angular_velocity_threshold
+        return (not moving_lin) and (not moving_ang)
+
+    def wait_until_stable(self, body, linear_velocity_threshold=0.005, angular_velocity_threshold=0.005,
+                          check_after_steps=100, min_stable_steps=100, max_steps=2000):
+        """simulator.py:325-376, one Python-level step at a time (API
+        compatibility; VecPushEnv settles on the device)."""
+        body_list = body if isinstance(body, (list, tuple)) else [body]
+        num_steps = num_stable_steps = 0
+        while True:
+            self.step()
+            num_steps += 1
+            if num_steps < check_after_steps:
+                continue
+            if all(self.check_stable(b, linear_velocity_threshold, angular_velocity_threshold) for b in body_list):
+                num_stable_steps += 1
+            if num_stable_steps >= min_stable_steps or num_steps >= max_steps:
+                break
+        return num_steps

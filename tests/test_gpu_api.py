@@ -1,0 +1,67 @@
+"""Reference-shaped Python API on the GPU: Simulator/HipPhysics plugin seam,
+PushEnv / VecPushEnv observation contract, policies, episode loop."""
+import numpy as np
+import pytest
+
+from robovat_amd import abi, configs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_simulator_plugin_seam_and_body_api():
+    from robovat_amd.simulation import Simulator
+    from robovat_amd.simulation.physics import hip_physics
+    sim = Simulator(physics_backend='HipPhysics', worker_id=3)
+    sim.reset(); sim.start()
+    table = sim.add_body('sim/table/table.urdf', [[0.6, 0, 0.0], [0, 0, 0]], is_static=True, name='table')
+    box = sim.add_body('box.urdf', [[0.6, 0.1, 0.12], [0, 0, 0.4]], scale=1.0, name='movable_0')
+    assert table.uid == hip_physics.TABLE_UID and box.uid == 0
+    n = sim.wait_until_stable(box, max_steps=600)
+    assert 199 <= n <= 600
+    assert abs(box.position.z - 0.031) < 1e-3 and np.linalg.norm(box.linear_velocity) < 5e-3
+    assert box.linear_velocity.dtype == np.float32
+    assert sim.check_contact(box, table) and not sim.check_contact(box, None) is False
+    box.set_dynamics(mass=0.3, lateral_friction=0.4)
+    assert abs(sim.physics.get_body_mass(box.uid) - 0.3) < 1e-6
+    with pytest.raises(ValueError):
+        sim.physics.get_body_linear_velocity('nope')
+    arm = sim.add_body('sawyer.urdf', is_static=True, is_controllable=True, name='sawyer_arm')
+    ee = sim.physics.get_link_pose((arm.uid, 7))
+    q = sim.physics.compute_inverse_kinematics((arm.uid, 7), ee)
+    assert np.allclose(q[:7], arm.joint_positions[:7], atol=1e-3)      # IK at the current pose is a fixed point
+    assert sim.physics.get_joint_limit((arm.uid, 0))['upper'] == pytest.approx(3.0503)
+
+
+def test_push_env_observation_contract_and_episode_loop():
+    from robovat_amd import envs, policies
+    from robovat_amd.io.episode_generation import generate_episode
+    cfg = configs.push_env_config(TASK_NAME='crossing', LAYOUT_ID=0, MAX_STEPS=2)
+    env = envs.PushEnv(config=cfg, seed=3)
+    obs = env.reset()
+    assert list(obs.keys()) == ['num_episodes', 'num_steps', 'layout_id', 'body_mask', 'point_cloud',
+                                'position', 'is_safe', 'is_effective']
+    assert obs['num_steps'].dtype == np.int64 and obs['body_mask'].shape == (abi.RV_MAXB,)
+    assert obs['point_cloud'].shape == (abi.RV_MAXB, cfg.OBS.NUM_POINTS, 3) and obs['point_cloud'].dtype == np.float32
+    assert obs['position'].shape == (abi.RV_MAXB, 3)
+    # analytic point cloud: per-body mean sits near the body position, absent bodies are zeros
+    centre = obs['point_cloud'].mean(axis=1)
+    assert np.abs(centre - obs['position'])[obs['body_mask'] > 0].max() < 0.03
+    episode = generate_episode(env, policies.HeuristicPushPolicy(env))
+    assert 1 <= len(episode['transitions']) <= 2
+    t = episode['transitions'][0]
+    assert t['action'].shape == (4,) and isinstance(t['reward'], float) and t['info'] is None
+    with pytest.raises(ValueError):
+        env.step(np.zeros(4, np.float32))       # done -> "Forget to reset?"
+
+
+def test_vec_env_policies_on_device():
+    from robovat_amd import envs
+    env = envs.VecPushEnv(64, seed=5)
+    obs = env.reset()
+    a = env.sample_heuristic_actions(max_attempts=2000)
+    assert a.shape == (64, 4) and float(a.abs().max()) <= 1.0
+    obs, reward, done, _ = env.step(a)
+    assert reward.shape == (64,) and obs['position'].shape == (64, abi.RV_MAXB, 3)
+    st = env.stats()
+    # the heuristic aims pushes at bodies: far more effective steps than random pushes
+    assert st['env_steps'] == 64 and (st['useful'] + st['unsafe']) > 16
