@@ -114,12 +114,13 @@ def main():
 
     def gather_returns():
         if dist is not None:
-            # RCCL gather of episode returns + counters
-            dist.all_gather_into_tensor(returns_all.view(-1), world.episode_returns())
+            # the only collective of the path: RCCL all-gather of episode returns
+            # + all-reduce of 4 counters (robovat_amd/parallel.py)
+            from robovat_amd import parallel
             cnt = world.env_counters().to(torch.int64)
             st = torch.stack([cnt[:, 5].sum(), cnt[:, 6].sum(), cnt[:, 4].sum(), cnt[:, 1].sum()])
-            dist.all_reduce(st)
-            counters.copy_(st)
+            allr, allc = parallel.gather_returns(world.episode_returns(), st)
+            returns_all.copy_(allr); counters.copy_(allc)
 
     for k in range(args.warmup):
         one_step(k)
