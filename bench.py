@@ -160,6 +160,13 @@ def main():
         algo_bytes_per_launch = ALGO_BYTES_PER_ENV_SUBSTEP * (substeps / launches)
         avg_kernel_s = 1e-3 * kern_ms / launches
         achieved = algo_bytes_per_launch / avg_kernel_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath) and args.mode == 'rollout':
+            # HBM bytes per env-substep measured offline with rocprofv3 PMC passes on this
+            # same command (profiles/r01_d_hbm_traffic.txt), scaled to this launch
+            with open(tpath) as f:
+                traffic = json.load(f)['hbm_bytes_per_env_substep'] * (substeps / launches)
         out = {
             'metric': 'env steps/sec (PushEnv, batched)',
             'value': env_steps_all / elapsed,
@@ -178,7 +185,7 @@ def main():
             'awake_substep_fraction': awake / max(substeps, 1),
             'reset_substeps': reset_stats['substeps'],
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': 'k_env<MODE_ROLLOUT>' if args.mode == 'rollout' else 'k_env<MODE_MACRO>', 'avg_kernel_ms': 1e3 * avg_kernel_s,
                          'algorithmic_bytes_per_env_substep': ALGO_BYTES_PER_ENV_SUBSTEP,
                          'note': 'state is LDS-resident for the whole launch; the kernel is VALU/latency-bound '
