@@ -44,6 +44,7 @@ typedef struct {
 /* JointTarget (controllable_body.py:28-129) */
 typedef struct {
   int active, n_idx, idx[RV_NJ], has_vel, has_stop;
+  int from_ik;   /* the target is the IK solution of the active link target */
   real pos[RV_NJ];
   real start_t, stop_t, pos_thr, vel_thr;
 } orc_jtarget;
@@ -73,6 +74,8 @@ typedef struct {
   real fv[RV_NFRAME][3], fw[RV_NFRAME][3];
   real axis[RV_NLIMB][3];
   real colv[RV_NCOL][8][3], colc[RV_NCOL][3], colr[RV_NCOL];
+  real colmin[RV_NCOL][3], colmax[RV_NCOL][3];   /* world AABB of each collider box */
+  int arm_moving;
   /* per-substep caches */
   real rot[RV_MAXB][9], iinv[RV_MAXB][9];
   real mot[RV_MAXB];
@@ -189,17 +192,24 @@ static void arm_update_kinematics(const orc_world* w, orc_env* e) {
       real l[3] = {cc[0] + ((k & 1) ? hh[0] : -hh[0]), cc[1] + ((k & 2) ? hh[1] : -hh[1]), cc[2] + ((k & 4) ? hh[2] : -hh[2])};
       m3mulv(t, e->frot[f], l); v3add(e->colv[c][k], e->fpos[f], t);
     }
+    for (int x = 0; x < 3; ++x) {
+      real lo = e->colv[c][0][x], hi = e->colv[c][0][x];
+      for (int k = 1; k < 8; ++k) { lo = rmin(lo, e->colv[c][k][x]); hi = rmax(hi, e->colv[c][k][x]); }
+      e->colmin[c][x] = lo; e->colmax[c][x] = hi;
+    }
   }
+  e->arm_moving = 0;
+  for (int j = 0; j < RV_NJ; ++j) if (rabs(e->qd[j]) > R(1e-3)) e->arm_moving = 1;
 }
 
 /* Damped-least-squares IK from the current joint state; restates the call
  * bullet_physics.py:1203-1262 makes (target pose of the end-effector link,
  * restPoses only => no null-space term).  out: 7 limb joint positions. */
-static void arm_ik(const orc_world* w, const orc_env* e, const real* pose, real* out) {
+static void arm_ik(const orc_world* w, const real* seed, const real* pose, real* out) {
   const rv_arm* a = &w->scene.arm;
   const rv_config* c = &w->cfg;
   real q[RV_NLIMB];
-  for (int i = 0; i < RV_NLIMB; ++i) q[i] = e->q[i];
+  for (int i = 0; i < RV_NLIMB; ++i) q[i] = seed[i];
   real fpos[RV_NFRAME][3], fquat[RV_NFRAME][4], frot[RV_NFRAME][9], axis[RV_NLIMB][3];
   for (int it = 0; it < c->ik_iters; ++it) {
     arm_fk_limb(a, q, fpos, fquat, frot, axis);
@@ -261,14 +271,14 @@ static void arm_ik(const orc_world* w, const orc_env* e, const real* pose, real*
 }
 
 /* ------------------------------------------- ControllableBody restated -- */
-static void jt_reset(orc_jtarget* t) { t->active = 0; t->n_idx = 0; t->has_stop = 0; }
+static void jt_reset(orc_jtarget* t) { t->active = 0; t->n_idx = 0; t->has_stop = 0; t->from_ik = 0; }
 static void lt_reset(orc_ltarget* t) { t->active = 0; t->has_pose = 0; t->nq = 0; t->has_stop = 0; }
 
 /* JointTarget.set (controllable_body.py:91-129) */
 static void jt_set(const orc_world* w, orc_env* e, int n, const int* idx, const real* pos, int has_vel,
                    int use_times, real start_t, real stop_t, real pos_thr, real vel_thr, real timeout) {
   orc_jtarget* t = &e->jt;
-  t->active = 1; t->n_idx = n; t->has_vel = has_vel;
+  t->active = 1; t->n_idx = n; t->has_vel = has_vel; t->from_ik = 0;
   for (int i = 0; i < n; ++i) { t->idx[i] = idx[i]; t->pos[i] = pos[i]; }
   if (use_times) { t->start_t = start_t; t->stop_t = stop_t; }
   else { t->start_t = sim_time(w, e); t->stop_t = t->start_t + timeout; }
@@ -316,10 +326,13 @@ static void lt_pop(orc_ltarget* t) {
 /* _update_ik (controllable_body.py:468-499) */
 static void update_ik(const orc_world* w, orc_env* e) {
   real qik[RV_NLIMB];
-  arm_ik(w, e, e->lt.pose, qik);
+  /* seed: the previous IK solution while it is still being tracked (the periodic
+   * re-solve then converges in one iteration), else the current joint state */
+  arm_ik(w, (e->jt.active && e->jt.from_ik) ? e->jt.pos : e->q, e->lt.pose, qik);
   int idx[RV_NLIMB];
   for (int i = 0; i < RV_NLIMB; ++i) idx[i] = i;
   jt_set(w, e, RV_NLIMB, idx, qik, e->lt.nq == 0, 1, e->lt.start_t, e->lt.stop_t, e->lt.pos_thr, e->lt.vel_thr, R(0.0));
+  e->jt.from_ik = 1;
 }
 /* _update_position_control (controllable_body.py:458-466) ->
  * setJointMotorControlArray(POSITION_CONTROL) (bullet_physics.py:1061-1104) */
@@ -599,6 +612,16 @@ static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, 
   return 1;
 }
 
+static real sphere_aabb_dist2(const real* p, const real* lo, const real* hi) {
+  real d2 = R(0.0);
+  for (int k = 0; k < 3; ++k) {
+    real d = R(0.0);
+    if (p[k] < lo[k]) d = lo[k] - p[k];
+    if (p[k] > hi[k]) d = p[k] - hi[k];
+    d2 += d * d;
+  }
+  return d2;
+}
 static real sphere_box_dist2(const real* p, const real* c, const real* h) {
   real d2 = R(0.0);
   for (int k = 0; k < 3; ++k) {
@@ -677,8 +700,8 @@ static void collide_all(const orc_world* w, orc_env* e) {
       for (int b = 0; b < RV_MAXB; ++b) {
         if (!body_on(e, b)) continue;
         real d[3]; v3sub(d, e->body[b].p, e->colc[col]);
-        real r = e->bp[b].radius + e->colr[col] + brk;
-        if (v3dot(d, d) >= r * r) continue;
+        real r = e->bp[b].radius + brk;
+        if (sphere_aabb_dist2(e->body[b].p, e->colmin[col], e->colmax[col]) >= r * r) continue;
         const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
         for (int h = 0; h < s->n_hulls; ++h) {
           real dd;
@@ -897,11 +920,10 @@ static void sim_substep(const orc_world* w, orc_env* e) {
         real r = e->bp[a].radius + e->bp[b].radius + (real)c->breaking;
         if (v3dot(d, d) < r * r) wake[b] = 1;
       }
-      if (e->arm_enabled)
+      if (e->arm_enabled && e->arm_moving)
         for (int col = 0; col < RV_NCOL; ++col) {
-          real d[3]; v3sub(d, e->body[b].p, e->colc[col]);
-          real r = e->bp[b].radius + e->colr[col] + (real)c->breaking;
-          if (v3dot(d, d) < r * r) wake[b] = 1;
+          real r = e->bp[b].radius + (real)c->breaking;
+          if (sphere_aabb_dist2(e->body[b].p, e->colmin[col], e->colmax[col]) < r * r) wake[b] = 1;
         }
     }
     for (int b = 0; b < RV_MAXB; ++b) if (wake[b]) { e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; }
@@ -1556,7 +1578,7 @@ void orc_compute_ik(orc_world* w, const float* pose, double* q) {
   for (int i = 0; i < w->n; ++i) {
     real p[7], out[RV_NLIMB];
     for (int k = 0; k < 7; ++k) p[k] = (real)pose[i * 7 + k];
-    arm_ik(w, &w->env[i], p, out);
+    arm_ik(w, w->env[i].q, p, out);
     for (int j = 0; j < RV_NLIMB; ++j) q[i * RV_NLIMB + j] = out[j];
   }
 }

@@ -98,7 +98,7 @@ PUSH_ENV_CONFIG = {
         'LINEAR_DAMPING': 0.04, 'ANGULAR_DAMPING': 0.04,
         'CONTACT_QUERY_DIST': 0.001, 'ARM_FRICTION': 0.8,
         'SOLVER_TOL': 1e-7,
-        'SLEEP_LINEAR': 0.01, 'SLEEP_ANGULAR': 0.05, 'SLEEP_STEPS': 200,
+        'SLEEP_LINEAR': 0.02, 'SLEEP_ANGULAR': 0.5, 'SLEEP_STEPS': 200,
         'NARROWPHASE_GATE': 5e-4, 'NARROWPHASE_MAX_AGE': 8,
     },
 }

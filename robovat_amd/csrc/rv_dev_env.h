@@ -47,6 +47,7 @@ namespace rv {
 // JointTarget / LinkTarget (controllable_body.py:28-233)
 struct JTarget {
   int active, n_idx, has_vel, has_stop;
+  int from_ik;   // the target is the IK solution of the active link target
   int idx[RV_NJ];
   float pos[RV_NJ];
   float start_t, stop_t, pos_thr, vel_thr;
@@ -96,6 +97,8 @@ struct Row {
 struct Scratch {
   float frot[RV_NFRAME][9], fv[RV_NFRAME][3], fw[RV_NFRAME][3], axis[RV_NLIMB][3];
   float colv[RV_NCOL][8][3], colc[RV_NCOL][3], colr[RV_NCOL];
+  float colmin[RV_NCOL][3], colmax[RV_NCOL][3];   // world AABB of each collider box
+  int arm_moving;
   int colflag[RV_NCOL];
   float rot[RV_MAXB][9], iinv[RV_MAXB][9];
   float wv[RV_MAXB][RV_MAXH][RV_MAXV][3];
@@ -258,7 +261,7 @@ RV_DEV_NOINLINE void arm_ik(const Consts& K, const float* q0, const float* pose,
 }
 
 // --------------------------------------------- ControllableBody restated --
-RV_DEV void jt_reset(JTarget& t) { t.active = 0; t.n_idx = 0; t.has_stop = 0; }
+RV_DEV void jt_reset(JTarget& t) { t.active = 0; t.n_idx = 0; t.has_stop = 0; t.from_ik = 0; }
 RV_DEV void lt_reset(LTarget& t) { t.active = 0; t.has_pose = 0; t.nq = 0; t.has_stop = 0; }
 
 RV_DEV int check_joints_reached(const DevEnv& e) {
@@ -308,9 +311,11 @@ RV_DEV void control_update(Shared& S, const Consts& K) {
     if (e.sim_steps % RV_STEPS_TO_UPDATE_IK == 0 || !e.jt.active) {
       // _update_ik (controllable_body.py:468-499)
       float qik[RV_NLIMB];
-      arm_ik(K, e.q, e.lt.pose, qik);
+      // seed: the previous IK solution while it is still being tracked (the periodic
+      // re-solve then converges in one iteration), else the current joint state
+      arm_ik(K, (e.jt.active && e.jt.from_ik) ? e.jt.pos : e.q, e.lt.pose, qik);
       JTarget& t = e.jt;
-      t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = (e.lt.nq == 0);
+      t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = (e.lt.nq == 0); t.from_ik = 1;
       for (int i = 0; i < RV_NLIMB; ++i) { t.idx[i] = i; t.pos[i] = qik[i]; }
       t.start_t = e.lt.start_t; t.stop_t = e.lt.stop_t; t.has_stop = 1;
       t.pos_thr = e.lt.pos_thr; t.vel_thr = e.lt.vel_thr;
@@ -348,7 +353,7 @@ RV_DEV void robot_move_to_joint_positions(Shared& S, const Consts& K, const floa
   arm_reset_targets(e);
   for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = c->limb_max_velocity_ratio * K.arm->v_max[j];
   JTarget& t = e.jt;
-  t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = 1;
+  t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = 1; t.from_ik = 0;
   for (int i = 0; i < RV_NLIMB; ++i) { t.idx[i] = i; t.pos[i] = pos[i]; }
   t.start_t = sim_time(S, K); t.stop_t = t.start_t + c->limb_timeout; t.has_stop = 1;
   t.pos_thr = c->limb_position_threshold; t.vel_thr = c->velocity_threshold;
@@ -371,7 +376,7 @@ RV_DEV void robot_grip(Shared& S, const Consts& K, float value) {
   float lpos = a->q_hi[7] - value * (a->q_hi[7] - a->q_lo[7]);
   float rpos = a->q_lo[8] + value * (a->q_hi[8] - a->q_lo[8]);
   JTarget& t = e.jt;
-  t.active = 1; t.n_idx = 2; t.has_vel = 1;
+  t.active = 1; t.n_idx = 2; t.has_vel = 1; t.from_ik = 0;
   t.idx[0] = 7; t.idx[1] = 8; t.pos[0] = lpos; t.pos[1] = rpos;
   t.start_t = sim_time(S, K); t.stop_t = t.start_t + 10000.0f; t.has_stop = 1;
   t.pos_thr = 0.008726640f; t.vel_thr = K.cfg->velocity_threshold;
@@ -516,6 +521,13 @@ RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b
   return 1;
 }
 
+RV_DEV float sphere_aabb_dist2(v3 p, const float* lo, const float* hi) {
+  float d2 = 0.0f;
+  float dx = 0.0f; if (p.x < lo[0]) dx = lo[0] - p.x; if (p.x > hi[0]) dx = p.x - hi[0]; d2 += dx * dx;
+  float dy = 0.0f; if (p.y < lo[1]) dy = lo[1] - p.y; if (p.y > hi[1]) dy = p.y - hi[1]; d2 += dy * dy;
+  float dz = 0.0f; if (p.z < lo[2]) dz = lo[2] - p.z; if (p.z > hi[2]) dz = p.z - hi[2]; d2 += dz * dz;
+  return d2;
+}
 RV_DEV float sphere_box_dist2(v3 p, v3 c, v3 h) {
   float d2 = 0.0f;
   float dx = fabsr(p.x - c.x) - h.x; if (dx > 0.0f) d2 += dx * dx;
@@ -699,7 +711,28 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
     }
   RV_LANES_END
 
-  // wake sleeping bodies that an awake body or an arm collider comes near
+  // world AABB of every collider box; is the arm moving?
+  RV_LANES_BEGIN
+    if (arm_on && lane < RV_NCOL) {
+      int col = lane;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        float lo = S.s.colv[col][0][x], hi = lo;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { float v = S.s.colv[col][k][x]; lo = fminr(lo, v); hi = fmaxr(hi, v); }
+        S.s.colmin[col][x] = lo; S.s.colmax[col][x] = hi;
+      }
+    }
+    if (lane == 16) {
+      int mv = 0;
+      if (arm_on) for (int j = 0; j < RV_NJ; ++j) if (fabsr(S.e.qd[j]) > 1e-3f) mv = 1;
+      S.s.arm_moving = mv;
+    }
+  RV_LANES_END
+
+  // wake test: a sleeping body is woken by a MOVING awake body or, while the arm
+  // moves, by an arm collider box coming within the contact-breaking distance.
+  // (Reads only state that no lane changes in this phase.)
   RV_LANES_BEGIN
     if (lane < RV_MAXB) {
       int b = lane; const DevEnv& e = S.e;
@@ -713,11 +746,10 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
           float r = e.radius[a] + e.radius[b] + c->breaking;
           if (dot(d, d) < r * r) wk = 1;
         }
-        if (arm_on)
+        if (arm_on && S.s.arm_moving)
           for (int col = 0; col < RV_NCOL; ++col) {
-            v3 d = sub(pb, ld3(S.s.colc[col]));
-            float r = e.radius[b] + S.s.colr[col] + c->breaking;
-            if (dot(d, d) < r * r) wk = 1;
+            float r = e.radius[b] + c->breaking;
+            if (sphere_aabb_dist2(pb, S.s.colmin[col], S.s.colmax[col]) < r * r) wk = 1;
           }
       }
       S.s.wake[b] = wk;
@@ -852,8 +884,8 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
         else if (role == 2) {
           col = io;
           v3 d = sub(ld3(e.body[a]), ld3(S.s.colc[col]));
-          float r = e.radius[a] + S.s.colr[col] + brk;
-          if (dot(d, d) >= r * r) continue;
+          float r = e.radius[a] + brk;
+          if (sphere_aabb_dist2(ld3(e.body[a]), S.s.colmin[col], S.s.colmax[col]) >= r * r) continue;
           A = &S.s.wv[a][ii][0][0]; nA = S.n_verts[a][ii]; B = &S.s.colv[col][0][0]; nB = 8; ckind = 2; guess = d;
         } else { col = a; A = &S.s.colv[col][0][0]; nA = 8; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
         float dd;

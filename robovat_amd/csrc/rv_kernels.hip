@@ -183,7 +183,7 @@ __global__ void k_set_joint_targets(DevEnv* envs, int n, const float* q, const r
   arm_reset_targets(e);
   for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = cfg->limb_max_velocity_ratio * scene->arm.v_max[j];
   JTarget& t = e.jt;
-  t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = 1;
+  t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = 1; t.from_ik = 0;
   for (int j = 0; j < RV_NLIMB; ++j) { t.idx[j] = j; t.pos[j] = q[(size_t)i * RV_NLIMB + j]; }
   t.start_t = cfg->dt * (float)e.sim_steps; t.stop_t = t.start_t + cfg->limb_timeout; t.has_stop = 1;
   t.pos_thr = cfg->limb_position_threshold; t.vel_thr = cfg->velocity_threshold;
