@@ -412,10 +412,19 @@ static int robot_is_gripper_ready(const orc_world* w, const orc_env* e) { return
 static void arm_motor_step(const orc_world* w, orc_env* e) {
   const rv_arm* a = &w->scene.arm;
   real dt = (real)w->cfg.dt;
+  /* limb joints move synchronised: one common scale keeps every commanded
+   * velocity within its limit, so the path is a straight line in joint space */
+  real sync = R(1.0);
+  for (int j = 0; j < RV_NLIMB; ++j) {
+    if (!e->motor_on[j]) continue;
+    real raw = rabs(e->motor_kp[j] * (e->motor_q[j] - e->q[j]) / dt);
+    if (raw > e->vmax_cmd[j]) sync = rmin(sync, e->vmax_cmd[j] / raw);
+  }
   for (int j = 0; j < RV_NJ; ++j) {
     real vd = R(0.0);
     if (e->motor_on[j]) {
       vd = e->motor_kp[j] * (e->motor_q[j] - e->q[j]) / dt;
+      if (j < RV_NLIMB) vd = vd * sync;
       vd = rclamp(vd, -e->vmax_cmd[j], e->vmax_cmd[j]);
     }
     real dv = rclamp(vd - e->qd[j], -(real)a->a_max[j] * dt, (real)a->a_max[j] * dt);

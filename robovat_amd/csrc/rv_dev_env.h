@@ -115,6 +115,7 @@ struct Scratch {
   int wake[RV_MAXB];
   float res[16];
   float mot[RV_MAXB];
+  float sync;
   int pairs[4];
   Rng rng;
 };
@@ -637,15 +638,30 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
 
   if (arm_on) {
     RV_LANES_BEGIN
-      if (lane == 0) control_update(S, K);
+      if (lane == 0) {
+        control_update(S, K);
+        // limb joints move synchronised: one common scale keeps every commanded
+        // velocity within its limit, so the path is a straight line in joint space
+        const DevEnv& e = S.e; float dt = c->dt;
+        float sync = 1.0f;
+#pragma unroll
+        for (int k = 0; k < RV_NLIMB; ++k) {
+          if (!e.motor_on[k]) continue;
+          float raw = fabsr(e.motor_kp[k] * (e.motor_q[k] - e.q[k]) / dt);
+          if (raw > e.vmax_cmd[k]) sync = fminr(sync, e.vmax_cmd[k] / raw);
+        }
+        S.s.sync = sync;
+      }
     RV_LANES_END
     // joint motors of the kinematic arm
     RV_LANES_BEGIN
       if (lane < RV_NJ) {
         DevEnv& e = S.e; int j = lane; float dt = c->dt;
+        const float sync = S.s.sync;
         float vd = 0.0f;
         if (e.motor_on[j]) {
           vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) / dt;
+          if (j < RV_NLIMB) vd = vd * sync;
           vd = fclampr(vd, -e.vmax_cmd[j], e.vmax_cmd[j]);
         }
         float dv = fclampr(vd - e.qd[j], -arm->a_max[j] * dt, arm->a_max[j] * dt);

@@ -214,7 +214,9 @@ def make_arm(base_pos=(0.0, 0.0, 0.0), base_rpy=(0.0, 0.0, 0.0)):
     arm.q_lo[8], arm.q_hi[8] = -FINGER_STROKE, 0.0
     arm.v_max[7] = arm.v_max[8] = 0.1
     arm.a_max[7] = arm.a_max[8] = 2.0
-    arm.finger_y0[0], arm.finger_y0[1] = 0.012, -0.012
+    # open gap (2 x (0.004 + stroke) - pad thickness) ~ 3.8 cm: narrower than the smallest movable, so a
+    # push cannot straddle a body
+    arm.finger_y0[0], arm.finger_y0[1] = 0.004, -0.004
     # collider boxes: limb link i spans from its frame to the next joint origin
     for i in range(7):
         nxt = np.asarray(SAWYER_JOINT_ORIGINS[i + 1][0])
