@@ -114,6 +114,13 @@ static inline void qnormalize(real* q) {
   real inv = R(1.0) / n;
   q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
 }
+/* rotate v by unit quaternion q: v + w t + u x t with t = 2 (u x v) */
+static inline void qrotv(real* o, const real* q, const real* v) {
+  real t[3], c[3];
+  v3cross(t, q, v); v3scale(t, t, R(2.0));
+  v3cross(c, q, t);
+  o[0] = v[0] + q[3] * t[0] + c[0]; o[1] = v[1] + q[3] * t[1] + c[1]; o[2] = v[2] + q[3] * t[2] + c[2];
+}
 /* rotation matrix (row major) of a unit quaternion */
 static inline void qmat(real* m, const real* q) {
   real x = q[0], y = q[1], z = q[2], w = q[3];

@@ -119,34 +119,31 @@ static int body_on(const orc_env* e, int b) { return e->bp[b].active && !e->bp[b
 static real sim_time(const orc_world* w, const orc_env* e) { return (real)w->cfg.dt * (real)e->sim_steps; }
 
 /* ------------------------------------------------------------------ arm -- */
-static void frame_compose(real* po, real* qo, const real* pp, const real* pq, const real* prot,
-                          const real* lp, const real* lq) {
-  real t[3]; m3mulv(t, prot, lp); v3add(po, pp, t);
-  qmul(qo, pq, lq);
-}
 
-/* forward kinematics of the limb for joint vector q; fills frames 0..7 */
+/* forward kinematics of the limb for joint vector q; fills frames 0..7.
+ * frame_i = frame_{i-1} o (jpos_i, jquat_i o Rz(q_i)); positions are advanced
+ * with a quaternion rotation so the chain carries no matrices */
 static void arm_fk_limb(const rv_arm* a, const real* q, real fpos[][3], real fquat[][4], real frot[][9], real axis[][3]) {
   real pp[3] = {(real)a->base_pos[0], (real)a->base_pos[1], (real)a->base_pos[2]};
   real pq[4] = {(real)a->base_quat[0], (real)a->base_quat[1], (real)a->base_quat[2], (real)a->base_quat[3]};
-  real prot[9]; qmat(prot, pq);
   for (int i = 0; i < RV_NLIMB; ++i) {
     real lp[3] = {(real)a->jpos[i][0], (real)a->jpos[i][1], (real)a->jpos[i][2]};
-    real lq[4] = {(real)a->jquat[i][0], (real)a->jquat[i][1], (real)a->jquat[i][2], (real)a->jquat[i][3]};
-    real po[3], qo[4];
-    frame_compose(po, qo, pp, pq, prot, lp, lq);
+    real jq[4] = {(real)a->jquat[i][0], (real)a->jquat[i][1], (real)a->jquat[i][2], (real)a->jquat[i][3]};
     real s, c; rsincos(q[i] * R(0.5), &s, &c);
     real qz[4] = {R(0.0), R(0.0), s, c};
-    real qf[4]; qmul(qf, qo, qz);
+    real lq[4]; qmul(lq, jq, qz);
+    real t[3], po[3], qf[4];
+    qrotv(t, pq, lp); v3add(po, pp, t);
+    qmul(qf, pq, lq);
     v3cpy(fpos[i], po); fquat[i][0] = qf[0]; fquat[i][1] = qf[1]; fquat[i][2] = qf[2]; fquat[i][3] = qf[3];
     qmat(frot[i], qf);
     axis[i][0] = frot[i][2]; axis[i][1] = frot[i][5]; axis[i][2] = frot[i][8];
     v3cpy(pp, po); pq[0] = qf[0]; pq[1] = qf[1]; pq[2] = qf[2]; pq[3] = qf[3];
-    memcpy(prot, frot[i], sizeof(prot));
   }
   real lp[3] = {(real)a->jpos[7][0], (real)a->jpos[7][1], (real)a->jpos[7][2]};
   real lq[4] = {(real)a->jquat[7][0], (real)a->jquat[7][1], (real)a->jquat[7][2], (real)a->jquat[7][3]};
-  frame_compose(fpos[7], fquat[7], pp, pq, prot, lp, lq);
+  real t[3]; qrotv(t, pq, lp); v3add(fpos[7], pp, t);
+  qmul(fquat[7], pq, lq);
   qmat(frot[7], fquat[7]);
 }
 
@@ -946,9 +943,21 @@ static void sim_substep(const orc_world* w, orc_env* e) {
     e->mot[b] = (v3len(B->v) + v3len(B->w) * e->bp[b].radius) * dt;
   }
   {
-    int aw = 0;
+    int aw = 0, at = 0;
     for (int b = 0; b < RV_MAXB; ++b) aw |= body_on(e, b);
     e->awake_last += aw;
+    if (e->arm_enabled)
+      for (int col = 0; col < RV_NCOL; ++col)
+        if (!(e->colmin[col][2] - e->table_z - (real)c->margin >= (real)c->contact_query_dist)) at = 1;
+    /* quiet substep: every body asleep (or absent) and no arm collider near the
+     * table -> nothing to collide, solve or integrate */
+    if (!aw && !at) {
+      e->flag_arm_table = 0;
+      for (int b = 0; b < RV_MAXB; ++b) e->flag_arm_body[b] = 0;
+      e->sim_steps++;
+      e->substeps_last++;
+      return;
+    }
   }
   bodies_prepare(w, e);
   collide_all(w, e);

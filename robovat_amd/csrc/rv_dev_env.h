@@ -116,6 +116,8 @@ struct Scratch {
   float res[16];
   float mot[RV_MAXB];
   float sync;
+  float lq[RV_NLIMB][4];
+  int at_possible, any_on;
   int pairs[4];
   Rng rng;
 };
@@ -155,26 +157,35 @@ struct LimbFK {
   q4 quat[RV_NLIMB + 1];
   v3 axis[RV_NLIMB];
 };
-RV_DEV void fk_limb(const rv_arm* a, const float* q, LimbFK& F, float* frot_out /* [8][9] or null */) {
+// local joint rotation jquat_i o Rz(q_i)
+RV_DEV q4 joint_local_quat(const rv_arm* a, int i, float qi) {
+  float s, c; sincosr(qi * 0.5f, &s, &c);
+  q4 qz; qz.x = 0.0f; qz.y = 0.0f; qz.z = s; qz.w = c;
+  return qmul(ldq(a->jquat[i]), qz);
+}
+// chain composition given the local joint quaternions lq[0..6]
+RV_DEV void fk_chain(const rv_arm* a, const q4* lq, LimbFK& F) {
   v3 pp = ld3(a->base_pos);
   q4 pq = ldq(a->base_quat);
-  m3 prot = qmat(pq);
 #pragma unroll
   for (int i = 0; i < RV_NLIMB; ++i) {
-    v3 po = add(pp, mulv(prot, ld3(a->jpos[i])));
-    q4 qo = qmul(pq, ldq(a->jquat[i]));
-    float s, c; sincosr(q[i] * 0.5f, &s, &c);
-    q4 qz; qz.x = 0.0f; qz.y = 0.0f; qz.z = s; qz.w = c;
-    q4 qf = qmul(qo, qz);
-    m3 r = qmat(qf);
-    F.pos[i] = po; F.quat[i] = qf;
-    F.axis[i] = mk(r.m[2], r.m[5], r.m[8]);
-    if (frot_out) stm(frot_out + 9 * i, r);
-    pp = po; pq = qf; prot = r;
+    v3 po = add(pp, qrotv(pq, ld3(a->jpos[i])));
+    q4 qf = qmul(pq, lq[i]);
+    F.pos[i] = po; F.quat[i] = qf; F.axis[i] = qaxis_z(qf);
+    pp = po; pq = qf;
   }
-  F.pos[7] = add(pp, mulv(prot, ld3(a->jpos[7])));
+  F.pos[7] = add(pp, qrotv(pq, ld3(a->jpos[7])));
   F.quat[7] = qmul(pq, ldq(a->jquat[7]));
-  if (frot_out) stm(frot_out + 9 * 7, qmat(F.quat[7]));
+}
+RV_DEV void fk_limb(const rv_arm* a, const float* q, LimbFK& F, float* frot_out /* [8][9] or null */) {
+  q4 lq[RV_NLIMB];
+#pragma unroll
+  for (int i = 0; i < RV_NLIMB; ++i) lq[i] = joint_local_quat(a, i, q[i]);
+  fk_chain(a, lq, F);
+  if (frot_out) {
+#pragma unroll
+    for (int i = 0; i <= RV_NLIMB; ++i) stm(frot_out + 9 * i, qmat(F.quat[i]));
+  }
 }
 
 // damped-least-squares IK (bullet_physics.py:1203-1262 call site), lane-serial
@@ -672,12 +683,19 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
         e.q[j] = qn; e.qd[j] = qd;
       }
     RV_LANES_END
-    // forward kinematics + link twists (serial chain)
+    // forward kinematics.  (a) lanes 0-6: local joint quaternions
+    RV_LANES_BEGIN
+      if (lane < RV_NLIMB) stq(S.s.lq[lane], joint_local_quat(arm, lane, S.e.q[lane]));
+    RV_LANES_END
+    // (b) lane 0: the serial chain (quaternion products + rotations) and link twists
     RV_LANES_BEGIN
       if (lane == 0) {
         DevEnv& e = S.e;
+        q4 lq[RV_NLIMB];
+#pragma unroll
+        for (int i = 0; i < RV_NLIMB; ++i) lq[i] = ldq(S.s.lq[i]);
         LimbFK F;
-        fk_limb(arm, e.q, F, &S.s.frot[0][0]);
+        fk_chain(arm, lq, F);
         v3 wprev = mk(0, 0, 0), vprev = mk(0, 0, 0), pprev = ld3(arm->base_pos);
 #pragma unroll
         for (int i = 0; i < RV_NLIMB; ++i) {
@@ -690,18 +708,26 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
         st3(e.fpos[7], F.pos[7]); stq(e.fquat[7], F.quat[7]);
         v3 v7 = add(vprev, cross(wprev, sub(F.pos[7], pprev)));
         st3(S.s.fv[7], v7); st3(S.s.fw[7], wprev);
-        v3 yax = mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          int f = 8 + k;
-          float off = arm->finger_y0[k] + e.q[7 + k];
-          v3 pf = madd(F.pos[7], yax, off);
-          st3(e.fpos[f], pf); stq(e.fquat[f], F.quat[7]);
-          for (int x = 0; x < 9; ++x) S.s.frot[f][x] = S.s.frot[7][x];
-          v3 vf = add(v7, cross(wprev, sub(pf, F.pos[7])));
-          vf = madd(vf, yax, e.qd[7 + k]);
-          st3(S.s.fv[f], vf); st3(S.s.fw[f], wprev);
-        }
+      }
+    RV_LANES_END
+    // (c) lanes 0-7: rotation matrices; lanes 8-9: finger frames and twists
+    RV_LANES_BEGIN
+      DevEnv& e = S.e;
+      if (lane <= RV_NLIMB) stm(S.s.frot[lane], qmat(ldq(e.fquat[lane])));
+      if (lane == 8 || lane == 9) {
+        int k = lane - 8, f = lane;
+        q4 q7 = ldq(e.fquat[7]);
+        m3 r7 = qmat(q7);
+        v3 yax = mk(r7.m[1], r7.m[4], r7.m[7]);
+        v3 p7 = ld3(e.fpos[7]);
+        float off = arm->finger_y0[k] + e.q[7 + k];
+        v3 pf = madd(p7, yax, off);
+        st3(e.fpos[f], pf); stq(e.fquat[f], q7);
+        stm(S.s.frot[f], r7);
+        v3 w7 = ld3(S.s.fw[7]);
+        v3 vf = add(ld3(S.s.fv[7]), cross(w7, sub(pf, p7)));
+        vf = madd(vf, yax, e.qd[7 + k]);
+        st3(S.s.fv[f], vf); st3(S.s.fw[f], w7);
       }
     RV_LANES_END
   }
@@ -743,6 +769,17 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
       int mv = 0;
       if (arm_on) for (int j = 0; j < RV_NJ; ++j) if (fabsr(S.e.qd[j]) > 1e-3f) mv = 1;
       S.s.arm_moving = mv;
+    }
+    if (lane == 17) {
+      // can any arm collider be within the contact-query distance of the table top?
+      int at = 0;
+      if (arm_on)
+        for (int col = 0; col < RV_NCOL; ++col) {
+          float minz = S.s.colv[col][0][2];
+          for (int k = 1; k < 8; ++k) minz = fminr(minz, S.s.colv[col][k][2]);
+          if (!(minz - S.e.table_z - c->margin >= c->contact_query_dist)) at = 1;
+        }
+      S.s.at_possible = at;
     }
   RV_LANES_END
 
@@ -800,6 +837,7 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
       int aw = 0;
       for (int b = 0; b < RV_MAXB; ++b) aw |= body_on(S.e, b);
       S.e.awake_last += aw;
+      S.s.any_on = aw;
     }
     for (int item = lane; item < RV_MAXB * RV_MAXH * RV_MAXV; item += 64) {
       int b = item / (RV_MAXH * RV_MAXV), h = (item / RV_MAXV) % RV_MAXH, i = item % RV_MAXV;
@@ -813,6 +851,16 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
   RV_LANES_END
 
   if (K.stop_after == 2) return;
+  // quiet substep: every body asleep (or absent) and no arm collider near the
+  // table -> nothing to collide, solve or integrate
+  if (!S.s.any_on && !S.s.at_possible) {
+    RV_LANES_BEGIN
+      DevEnv& e = S.e;
+      if (lane == 0) { e.flag_arm_table = 0; e.sim_steps++; e.substeps_last++; }
+      if (lane >= 1 && lane <= RV_MAXB) e.flag_arm_body[lane - 1] = 0;
+    RV_LANES_END
+    return;
+  }
   // manifold refresh + narrow phase.  The wave is split into four 16-lane
   // groups; a group works on one manifold owner at a time (body-table,
   // body-body, arm-body, arm-table detection: 24 owners, six rounds) and all

@@ -97,6 +97,20 @@ RV_DEV q4 qnormalize(q4 q) {
   q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
   return q;
 }
+// rotate v by unit quaternion q: v + w t + u x t with t = 2 (u x v)
+RV_DEV v3 qrotv(q4 q, v3 v) {
+  v3 u = mk(q.x, q.y, q.z);
+  v3 t = scale(cross(u, v), 2.0f);
+  v3 c = cross(u, t);
+  return mk(v.x + q.w * t.x + c.x, v.y + q.w * t.y + c.y, v.z + q.w * t.z + c.z);
+}
+// third column of qmat(q): the joint axis z in the world frame (same expressions as qmat)
+RV_DEV v3 qaxis_z(q4 q) {
+  float x = q.x, y = q.y, z = q.z, w = q.w;
+  float xx = x * x, yy = y * y;
+  float xz = x * z, yz = y * z, wx = w * x, wy = w * y;
+  return mk(2.0f * (xz + wy), 2.0f * (yz - wx), 1.0f - 2.0f * (xx + yy));
+}
 struct m3 { float m[9]; };
 RV_DEV m3 qmat(q4 q) {
   float x = q.x, y = q.y, z = q.z, w = q.w;
