@@ -44,8 +44,12 @@ def _lib(double):
                      'orc_set_link_target', 'orc_compute_ik', 'orc_query_contacts',
                      'orc_get_manifold_counts', 'orc_observe', 'orc_reward',
                      'orc_get_episode_returns', 'orc_get_stats', 'orc_eval_reward',
-                     'orc_eval_waypoints'):
+                     'orc_eval_waypoints', 'orc_set_external_control', 'orc_motor_targets',
+                     'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout'):
             getattr(lib, name).restype = None
+        lib.orc_is_limb_ready.restype = C.c_int
+        lib.orc_is_gripper_ready.restype = C.c_int
+        lib.orc_time.restype = C.c_double
         lib.orc_eval_gjk.restype = C.c_int
         lib.orc_eval_wait_until_stable.restype = C.c_int
         _LIBS[key] = lib
@@ -152,6 +156,40 @@ class OracleWorld(object):
         q = np.zeros((self.n, abi.RV_NLIMB), dtype=np.float64)
         self.lib.orc_compute_ik(self.h, _p(a), _p(q))
         return q
+
+    # ---- control-logic hooks (tests/golden/gen_control_golden.py, tests/test_control_golden.py)
+    def set_external_control(self, on):
+        self.lib.orc_set_external_control(self.h, C.c_int(int(bool(on))))
+
+    def motor_targets(self, idx, pos):
+        i = np.ascontiguousarray(idx, dtype=np.int32); q = np.ascontiguousarray(pos, dtype=np.float64)
+        self.lib.orc_motor_targets(self.h, C.c_int(len(i)), _p(i), _p(q))
+
+    def compute_ik_seeded(self, seed, pose):
+        a = np.ascontiguousarray(pose, dtype=np.float32).reshape(7)
+        q = np.zeros(abi.RV_NLIMB, dtype=np.float64)
+        sd = None if seed is None else np.ascontiguousarray(seed, dtype=np.float64)
+        self.lib.orc_compute_ik_seeded(self.h, None if sd is None else _p(sd), _p(a), _p(q))
+        return q
+
+    def set_link_path(self, poses):
+        a = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 7)
+        self.lib.orc_set_link_path(self.h, C.c_int(a.shape[0]), _p(a))
+
+    def set_link_timeout(self, timeout):
+        self.lib.orc_set_link_timeout(self.h, C.c_double(timeout))
+
+    def grip(self, value):
+        self.lib.orc_grip(self.h, C.c_float(value))
+
+    def is_limb_ready(self, env=0):
+        return bool(self.lib.orc_is_limb_ready(self.h, C.c_int(env)))
+
+    def is_gripper_ready(self, env=0):
+        return bool(self.lib.orc_is_gripper_ready(self.h, C.c_int(env)))
+
+    def time(self, env=0):
+        return float(self.lib.orc_time(self.h, C.c_int(env)))
 
     def query_contacts(self):
         return self._get('orc_query_contacts', (self.n, 2 + abi.RV_MAXB), np.uint8)

@@ -104,6 +104,7 @@ typedef struct orc_world {
   int n;
   orc_env* env;
   rv_macro_stats stats;
+  int ext_control;   /* tests only: ControllableBody.update() is run by the caller */
 } orc_world;
 
 #define TIDX(b) (b)
@@ -909,7 +910,7 @@ static void sim_substep(const orc_world* w, orc_env* e) {
   const rv_config* c = &w->cfg;
   real dt = (real)c->dt;
   if (e->arm_enabled) {
-    control_update(w, e);
+    if (!w->ext_control) control_update(w, e);
     arm_motor_step(w, e);
     arm_update_kinematics(w, e);
   }
@@ -1600,6 +1601,51 @@ void orc_compute_ik(orc_world* w, const float* pose, double* q) {
     for (int j = 0; j < RV_NLIMB; ++j) q[i * RV_NLIMB + j] = out[j];
   }
 }
+/* ---- hooks for tests/golden/gen_control_golden.py: the reference's unmodified
+ * Simulator / SawyerSim / ControllableBody drive THIS arm model through a
+ * Physics plugin, so that control_update() above can be pinned against them. */
+void orc_set_external_control(orc_world* w, int on) { w->ext_control = on; }
+/* position_control_array (bullet_physics.py:1061-1104) */
+void orc_motor_targets(orc_world* w, int n, const int32_t* idx, const double* pos) {
+  for (int i = 0; i < w->n; ++i) {
+    orc_env* e = &w->env[i];
+    for (int j = 0; j < RV_NLIMB; ++j) e->vmax_cmd[j] = (real)w->cfg.limb_max_velocity_ratio * (real)w->scene.arm.v_max[j];
+    for (int k = 0; k < n; ++k) {
+      int j = idx[k];
+      e->motor_on[j] = 1; e->motor_q[j] = (real)pos[k];
+      e->motor_kp[j] = (real)w->cfg.kp; e->motor_kd[j] = (real)w->cfg.kd;
+    }
+  }
+}
+void orc_compute_ik_seeded(orc_world* w, const double* seed, const float* pose, double* q) {
+  real p[7], sd[RV_NLIMB], out[RV_NLIMB];
+  for (int k = 0; k < 7; ++k) p[k] = (real)pose[k];
+  for (int j = 0; j < RV_NLIMB; ++j) sd[j] = seed ? (real)seed[j] : w->env[0].q[j];
+  arm_ik(w, sd, p, out);
+  for (int j = 0; j < RV_NLIMB; ++j) q[j] = out[j];
+}
+/* SawyerSim.move_along_gripper_path -> set_target_link_poses (controllable_body.py:319-345) */
+void orc_set_link_path(orc_world* w, int n_poses, const float* poses) {
+  for (int i = 0; i < w->n; ++i) {
+    orc_env* e = &w->env[i];
+    real p0[7];
+    for (int k = 0; k < 7; ++k) p0[k] = (real)poses[k];
+    robot_move_to_gripper_pose(w, e, p0);
+    e->lt.has_pose = 0; e->lt.nq = n_poses;
+    for (int q = 0; q < n_poses; ++q)
+      for (int k = 0; k < 7; ++k) e->lt.queue[q][k] = (real)poses[q * 7 + k];
+    lt_pop(&e->lt);
+  }
+}
+/* move_to_gripper_pose(..., timeout=t): LinkTarget.set stop_time = start_time + timeout */
+void orc_set_link_timeout(orc_world* w, double timeout) {
+  for (int i = 0; i < w->n; ++i) w->env[i].lt.stop_t = w->env[i].lt.start_t + (real)timeout;
+}
+void orc_grip(orc_world* w, float value) { for (int i = 0; i < w->n; ++i) robot_grip(w, &w->env[i], (real)value); }
+int orc_is_limb_ready(orc_world* w, int env) { return arm_is_ready_limb(w, &w->env[env]); }
+int orc_is_gripper_ready(orc_world* w, int env) { return robot_is_gripper_ready(w, &w->env[env]); }
+double orc_time(orc_world* w, int env) { return (double)sim_time(w, &w->env[env]); }
+
 void orc_query_contacts(orc_world* w, uint8_t* out) {
   for (int i = 0; i < w->n; ++i) {
     const orc_env* e = &w->env[i]; uint8_t* o = out + (size_t)i * (2 + RV_MAXB);
