@@ -45,7 +45,7 @@ def _lib(double):
                      'orc_get_manifold_counts', 'orc_observe', 'orc_reward',
                      'orc_get_episode_returns', 'orc_get_stats', 'orc_eval_reward',
                      'orc_eval_waypoints', 'orc_set_external_control', 'orc_motor_targets',
-                     'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout'):
+                     'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout', 'orc_set_pose_f32'):
             getattr(lib, name).restype = None
         lib.orc_is_limb_ready.restype = C.c_int
         lib.orc_is_gripper_ready.restype = C.c_int
@@ -161,12 +161,15 @@ class OracleWorld(object):
     def set_external_control(self, on):
         self.lib.orc_set_external_control(self.h, C.c_int(int(bool(on))))
 
+    def set_pose_f32(self, on):
+        self.lib.orc_set_pose_f32(self.h, C.c_int(int(bool(on))))
+
     def motor_targets(self, idx, pos):
         i = np.ascontiguousarray(idx, dtype=np.int32); q = np.ascontiguousarray(pos, dtype=np.float64)
         self.lib.orc_motor_targets(self.h, C.c_int(len(i)), _p(i), _p(q))
 
     def compute_ik_seeded(self, seed, pose):
-        a = np.ascontiguousarray(pose, dtype=np.float32).reshape(7)
+        a = np.ascontiguousarray(pose, dtype=np.float64).reshape(7)
         q = np.zeros(abi.RV_NLIMB, dtype=np.float64)
         sd = None if seed is None else np.ascontiguousarray(seed, dtype=np.float64)
         self.lib.orc_compute_ik_seeded(self.h, None if sd is None else _p(sd), _p(a), _p(q))

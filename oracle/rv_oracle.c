@@ -9,7 +9,10 @@
  *   - control / task logic (ControllableBody, SawyerSim, PushEnv phase machine,
  *     wait_until_stable, rewards): restated from the reference Python, pinned
  *     by golden vectors generated from the reference itself
- *     (tests/golden/gen_golden.py).
+ *     (tests/golden/gen_golden.py) and by trajectories the reference's own
+ *     unmodified Simulator / SawyerSim / ControllableBody / PushEnv produce
+ *     when run on this file's physics (tests/golden/gen_control_golden.py,
+ *     gen_push_step_golden.py): reproduced with zero difference.
  *   - physics arithmetic (`pybullet.stepSimulation`, IK): PARITY UNPINNED.
  *     It lives in the third-party wheel pybullet==2.6.5 (requirements.txt:9),
  *     which is neither vendored under the reference tree nor installed here.
@@ -105,6 +108,7 @@ typedef struct orc_world {
   orc_env* env;
   rv_macro_stats stats;
   int ext_control;   /* tests only: ControllableBody.update() is run by the caller */
+  int pose_f32;      /* tests only: emulate the reference's float32 Orientation storage (orientation.py:49) */
 } orc_world;
 
 #define TIDX(b) (b)
@@ -208,6 +212,9 @@ static void arm_ik(const orc_world* w, const real* seed, const real* pose, real*
   const rv_config* c = &w->cfg;
   real q[RV_NLIMB];
   for (int i = 0; i < RV_NLIMB; ++i) q[i] = seed[i];
+#ifdef ORC_TRACE_IK
+  fprintf(stderr, "ik pose %.17g %.17g %.17g %.17g %.17g %.17g %.17g seed %.17g %.17g\n", (double)pose[0], (double)pose[1], (double)pose[2], (double)pose[3], (double)pose[4], (double)pose[5], (double)pose[6], (double)seed[0], (double)seed[3]);
+#endif
   real fpos[RV_NFRAME][3], fquat[RV_NFRAME][4], frot[RV_NFRAME][9], axis[RV_NLIMB][3];
   for (int it = 0; it < c->ik_iters; ++it) {
     arm_fk_limb(a, q, fpos, fquat, frot, axis);
@@ -1131,6 +1138,9 @@ static void execute_action(const orc_world* w, orc_env* e) {
   int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
   real wp[RV_MAXG][2][7];
   for (int g = 0; g < G; ++g) compute_waypoints(c, e->action[g], wp[g][0], wp[g][1]);
+  if (w->pose_f32)   /* Pose([[x, y, z], [pi, 0, 0]]): Euler angles are stored as float32 */
+    for (int g = 0; g < G; ++g) for (int k = 0; k < 2; ++k)
+      euler_to_quat(wp[g][k] + 3, (real)(float)ORC_PI, R(0.0), R(0.0));
   real start_z = (real)c->finger_tip_offset + R(0.5) * ((real)c->cspace_high[2] + (real)c->cspace_low[2]);
   e->is_safe = 1; e->is_effective = 1;
   e->phase = RV_PHASE_INITIAL;
@@ -1173,6 +1183,7 @@ static void execute_action(const orc_world* w, orc_env* e) {
         num_waypoints++;
         real pose[7];
         v3cpy(pose, e->fpos[7]); memcpy(pose + 3, e->fquat[7], sizeof(real) * 4);
+        if (w->pose_f32) for (int i = 3; i < 7; ++i) pose[i] = (real)(float)pose[i];   /* Pose([p, quaternion]) */
         pose[2] = (real)c->gripper_safe_height;
         robot_move_to_gripper_pose(w, e, pose);
       } else if (next == RV_PHASE_OFFSTAGE) {
@@ -1605,6 +1616,7 @@ void orc_compute_ik(orc_world* w, const float* pose, double* q) {
  * Simulator / SawyerSim / ControllableBody drive THIS arm model through a
  * Physics plugin, so that control_update() above can be pinned against them. */
 void orc_set_external_control(orc_world* w, int on) { w->ext_control = on; }
+void orc_set_pose_f32(orc_world* w, int on) { w->pose_f32 = on; }
 /* position_control_array (bullet_physics.py:1061-1104) */
 void orc_motor_targets(orc_world* w, int n, const int32_t* idx, const double* pos) {
   for (int i = 0; i < w->n; ++i) {
@@ -1617,7 +1629,7 @@ void orc_motor_targets(orc_world* w, int n, const int32_t* idx, const double* po
     }
   }
 }
-void orc_compute_ik_seeded(orc_world* w, const double* seed, const float* pose, double* q) {
+void orc_compute_ik_seeded(orc_world* w, const double* seed, const double* pose, double* q) {
   real p[7], sd[RV_NLIMB], out[RV_NLIMB];
   for (int k = 0; k < 7; ++k) p[k] = (real)pose[k];
   for (int j = 0; j < RV_NLIMB; ++j) sd[j] = seed ? (real)seed[j] : w->env[0].q[j];

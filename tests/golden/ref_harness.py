@@ -1,0 +1,212 @@
+"""Harness shared by the golden generators that run the reference's OWN classes
+(build container only; never imported by tests).
+
+`OraclePhysics` is a Physics plugin for the reference's `Simulator`
+(registered through its seam `getattr(physics, physics_backend)`,
+simulator.py:45-49).  Its dynamics are the CPU oracle's (double build): joint
+motors, forward kinematics, IK, rigid bodies and contacts.  With it the
+reference's unmodified Simulator / SawyerSim / ControllableBody / PushEnv
+methods run on top of the oracle's physics, so the oracle's restatement of
+those layers can be compared with the real thing.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import gen_golden as _stubs  # noqa: E402,F401  (installs the pybullet/cv2/gym/easydict stubs, numpy aliases)
+
+from robovat.math import Pose  # noqa: E402
+from robovat.simulation import physics as ref_physics  # noqa: E402
+
+from robovat_amd import abi, configs, scenes  # noqa: E402
+from oracle import orc  # noqa: E402
+
+EasyDict = sys.modules['easydict'].EasyDict
+DT = float(np.float32(1e-3))
+
+
+class OraclePhysics(object):
+    """Physics plugin for the reference's Simulator: one Sawyer-like arm whose
+    dynamics are the oracle's.  Method names/arguments follow
+    robovat/simulation/physics/bullet_physics.py."""
+
+    ARM_UID = 0
+    TABLE_UID = 1
+    BODY_UID0 = 10
+    SEED = 1                     # class attributes: Simulator() constructs the plugin itself
+    ENV_ID = 0
+    CFG_OVERRIDES = {}
+
+    def __init__(self, time_step=1e-3, use_visualizer=False, worker_id=0):
+        self._time_step = DT
+        self._num_steps = None
+        scene, names = scenes.make_scene()
+        env_cfg = configs.push_env_config(**self.CFG_OVERRIDES)
+        cfg = configs.make_rv_config(env_cfg=env_cfg, n_envs=1, env_id_offset=self.ENV_ID, shape_names=names, seed=self.SEED)
+        self.cfg = cfg
+        self.w = orc.OracleWorld(cfg, scene, double=True)
+        self.w.set_external_control(True)
+        self.joint_names = scenes.LIMB_JOINT_NAMES + scenes.FINGER_JOINT_NAMES
+        self.link_names = scenes.LINK_NAMES
+        self.arm = scene.arm
+        self._bodies = 0
+        self.ik_calls = 0
+        # IK seed bookkeeping: the previous solution while it is
+        # the one being position-controlled, else the current joint state
+        self._last_ik = None
+        self._tracking = False
+        self._controlled = False
+
+    # -- lifecycle (bullet_physics.py:89-109, 122-127)
+    time_step = property(lambda self: self._time_step)
+
+    def reset(self):
+        self._num_steps = None
+
+    def start(self):
+        self._num_steps = 0
+
+    def set_gravity(self, g):
+        pass
+
+    def step(self):
+        if not self._controlled:
+            self._tracking = False
+        self._controlled = False
+        self.w.step_sub(1)
+        self._num_steps += 1
+
+    def time(self):
+        return self._time_step * self._num_steps
+
+    # -- bodies: only the arm has joints; base / head / table are inert handles,
+    # 'movable_<b>' names map to the oracle's rigid bodies
+    def add_body(self, filename, pose, scale=1.0, is_static=False):
+        name = os.path.splitext(os.path.basename(filename))[0]
+        if name == 'arm':
+            return self.ARM_UID
+        if name == 'table':
+            return self.TABLE_UID
+        if name.startswith('movable_'):
+            return self.BODY_UID0 + int(name.split('_')[1])
+        self._bodies += 1
+        return 100 + self._bodies
+
+    def remove_body(self, uid):
+        pass
+
+    def get_body_link_indices(self, uid):
+        return list(range(len(self.link_names))) if uid == self.ARM_UID else []
+
+    def get_body_joint_indices(self, uid):
+        return list(range(len(self.joint_names))) if uid == self.ARM_UID else []
+
+    def get_link_name(self, uid):
+        return self.link_names[uid[1]]
+
+    def get_joint_name(self, uid):
+        return self.joint_names[uid[1]]
+
+    def get_joint_limit(self, uid):
+        j = uid[1]
+        return {'lower': float(self.arm.q_lo[j]), 'upper': float(self.arm.q_hi[j]),
+                'effort': 0.0, 'velocity': float(self.arm.v_max[j])}
+
+    def get_joint_position(self, uid):
+        return float(self.w.joint_state()[0, uid[1], 0])
+
+    def get_joint_velocity(self, uid):
+        return float(self.w.joint_state()[0, uid[1], 1])
+
+    def set_joint_position(self, uid, position):
+        s = self.w.joint_state()
+        if s[0, uid[1], 0] == position and s[0, uid[1], 1] == 0.0:
+            return
+        s[0, uid[1], 0] = position
+        s[0, uid[1], 1] = 0.0
+        self.w.set_joint_state(s)
+
+    def get_link_pose(self, uid):
+        p = self.w.link_poses()[0, uid[1]]
+        return Pose([p[:3], p[3:7]])
+
+    def get_body_pose(self, uid):
+        if uid >= self.BODY_UID0 and uid < self.BODY_UID0 + abi.RV_MAXB:
+            s = self.w.body_state()[0, uid - self.BODY_UID0]
+            return Pose([s[0:3], s[3:7]])
+        return Pose([[0, 0, 0], [0, 0, 0]])
+
+    def get_body_linear_velocity(self, uid):
+        return self.w.body_state()[0, uid - self.BODY_UID0, 7:10]
+
+    def get_body_angular_velocity(self, uid):
+        return self.w.body_state()[0, uid - self.BODY_UID0, 10:13]
+
+    # -- contacts (bullet_physics.py:1268-1304); the list holds one entry per touching pair
+    def get_contact_points(self, a_uid, b_uid=None):
+        assert a_uid == self.ARM_UID
+        f = self.w.query_contacts()[0]
+        if b_uid == self.TABLE_UID:
+            return [0.0] if f[0] else []
+        if b_uid is not None and b_uid >= self.BODY_UID0:
+            return [0.0] if f[2 + b_uid - self.BODY_UID0] else []
+        raise ValueError(b_uid)
+
+    # -- control (bullet_physics.py:1061-1104, 1203-1262)
+    def position_control_array(self, body_uid, joint_inds, target_positions, target_velocities=None,
+                               max_velocities=None, max_forces=None, position_gains=None, velocity_gains=None):
+        idx = [int(i) for i in joint_inds]
+        pos = [float(p) for p in target_positions]
+        self.w.motor_targets(idx, pos)
+        self._controlled = True
+        self._tracking = (self._last_ik is not None and idx == list(range(7)) and pos == self._last_ik)
+
+    def compute_inverse_kinematics(self, link_uid, link_pose, upper_limits=None, lower_limits=None,
+                                   ranges=None, damping=None, neutral_positions=None):
+        pose = Pose(link_pose)
+        p7 = np.concatenate([pose.position, pose.quaternion]).astype(np.float64)
+        seed = self._last_ik if self._tracking else None
+        q = self.w.compute_ik_seeded(seed, p7)
+        self.ik_calls += 1
+        self._last_ik = [float(x) for x in q]
+        # Bullet returns every movable joint (controllable_body.py:480-482 truncates)
+        return self._last_ik + [0.0, 0.0]
+
+    def invalidate_ik_seed(self):
+        self._tracking = False
+
+
+ref_physics.OraclePhysics = OraclePhysics
+
+
+
+
+def f32(x):
+    return [float(np.float32(v)) for v in x]
+
+
+def robot_config():
+    """SAWYER_SIM_CONFIG as the reference's EasyDict, floats rounded to float32 (the
+    oracle holds its configuration in the float fields of rv_config)."""
+    def rnd(v):
+        if isinstance(v, float):
+            return float(np.float32(v))
+        if isinstance(v, list):
+            return [rnd(x) for x in v]
+        if isinstance(v, dict):
+            return {k: rnd(x) for k, x in v.items()}
+        return v
+    rc = rnd(dict(configs.SAWYER_SIM_CONFIG))
+    return EasyDict(dict(rc, ARM_URDF='arm.urdf', BASE_URDF='base.urdf', HEAD_URDF='head.urdf'))
+
+
+def pose7(position, euler):
+    p = Pose([f32(position), f32(euler)])
+    return f32(np.concatenate([p.position, p.quaternion]))
