@@ -47,7 +47,8 @@ typedef struct {
 /* JointTarget (controllable_body.py:28-129) */
 typedef struct {
   int active, n_idx, idx[RV_NJ], has_vel, has_stop;
-  int from_ik;   /* the target is the IK solution of the active link target */
+  int from_ik;   /* the target is the IK solution of the active link target: 1 = yes, 2 = yes and
+                  * the solve ended on the residual test (a re-solve from it returns it unchanged) */
   real pos[RV_NJ];
   real start_t, stop_t, pos_thr, vel_thr;
 } orc_jtarget;
@@ -207,10 +208,11 @@ static void arm_update_kinematics(const orc_world* w, orc_env* e) {
 /* Damped-least-squares IK from the current joint state; restates the call
  * bullet_physics.py:1203-1262 makes (target pose of the end-effector link,
  * restPoses only => no null-space term).  out: 7 limb joint positions. */
-static void arm_ik(const orc_world* w, const real* seed, const real* pose, real* out) {
+static int arm_ik(const orc_world* w, const real* seed, const real* pose, real* out) {
   const rv_arm* a = &w->scene.arm;
   const rv_config* c = &w->cfg;
   real q[RV_NLIMB];
+  int conv = 0;
   for (int i = 0; i < RV_NLIMB; ++i) q[i] = seed[i];
 #ifdef ORC_TRACE_IK
   fprintf(stderr, "ik pose %.17g %.17g %.17g %.17g %.17g %.17g %.17g seed %.17g %.17g\n", (double)pose[0], (double)pose[1], (double)pose[2], (double)pose[3], (double)pose[4], (double)pose[5], (double)pose[6], (double)seed[0], (double)seed[3]);
@@ -226,7 +228,7 @@ static void arm_ik(const orc_world* w, const real* seed, const real* pose, real*
     err[3] = qe[0] * sg; err[4] = qe[1] * sg; err[5] = qe[2] * sg;
     real e2 = R(0.0);
     for (int k = 0; k < 6; ++k) e2 += err[k] * err[k];
-    if (e2 < (real)c->ik_residual * (real)c->ik_residual) break;
+    if (e2 < (real)c->ik_residual * (real)c->ik_residual) { conv = 1; break; }
     real J[6][RV_NLIMB];
     for (int j = 0; j < RV_NLIMB; ++j) {
       real d[3], cr[3];
@@ -273,6 +275,7 @@ static void arm_ik(const orc_world* w, const real* seed, const real* pose, real*
     for (int j = 0; j < RV_NLIMB; ++j) q[j] = rclamp(q[j] + dq[j] * sc, (real)a->q_lo[j], (real)a->q_hi[j]);
   }
   for (int i = 0; i < RV_NLIMB; ++i) out[i] = q[i];
+  return conv;
 }
 
 /* ------------------------------------------- ControllableBody restated -- */
@@ -331,13 +334,17 @@ static void lt_pop(orc_ltarget* t) {
 /* _update_ik (controllable_body.py:468-499) */
 static void update_ik(const orc_world* w, orc_env* e) {
   real qik[RV_NLIMB];
-  /* seed: the previous IK solution while it is still being tracked (the periodic
-   * re-solve then converges in one iteration), else the current joint state */
-  arm_ik(w, (e->jt.active && e->jt.from_ik) ? e->jt.pos : e->q, e->lt.pose, qik);
+  /* the tracked target is the converged solution of this very pose: solving again
+   * from it passes the residual test at once and returns it unchanged, and the
+   * link target's times / thresholds have not changed either -> nothing to do */
+  if (e->jt.active && e->jt.from_ik == 2) return;
+  /* seed: the previous IK solution while it is still being tracked, else the
+   * current joint state */
+  int conv = arm_ik(w, (e->jt.active && e->jt.from_ik) ? e->jt.pos : e->q, e->lt.pose, qik);
   int idx[RV_NLIMB];
   for (int i = 0; i < RV_NLIMB; ++i) idx[i] = i;
   jt_set(w, e, RV_NLIMB, idx, qik, e->lt.nq == 0, 1, e->lt.start_t, e->lt.stop_t, e->lt.pos_thr, e->lt.vel_thr, R(0.0));
-  e->jt.from_ik = 1;
+  e->jt.from_ik = conv ? 2 : 1;
 }
 /* _update_position_control (controllable_body.py:458-466) ->
  * setJointMotorControlArray(POSITION_CONTROL) (bullet_physics.py:1061-1104) */
@@ -359,7 +366,10 @@ static void control_update(const orc_world* w, orc_env* e) {
     if (e->sim_steps % STEPS_TO_UPDATE_IK == 0 || !e->jt.active) {
       update_ik(w, e);
       ik_updated = 1;
-      if (check_joints_reached(e)) lt_pop(&e->lt);
+      if (check_joints_reached(e)) {
+        lt_pop(&e->lt);                               /* next pose of the path: solve again */
+        if (e->jt.from_ik == 2) e->jt.from_ik = 1;
+      }
     }
   }
   if (e->jt.active) {

@@ -34,6 +34,24 @@ namespace rv {
 #define RV_LANES_END }
 #endif
 
+// profiling hook: leave the substep after phase group n, still advancing the step
+// counter so that the control schedule (IK every 10 substeps) stays representative
+#ifdef __HIP_DEVICE_COMPILE__
+#define RV_STOP(n) if (K.stop_after == (n)) { if (threadIdx.x == 0) S.e.sim_steps++; __syncthreads(); return; }
+#define RV_STOPL(n) if (K.stop_after == (n)) { if (threadIdx.x == 0) S.e.sim_steps++; __syncthreads(); return 0; }
+#else
+#define RV_STOP(n)
+#define RV_STOPL(n)
+#endif
+
+// RV_PROFILE build only: lane 0 adds the shader-clock time since the last mark to slot i
+#if defined(RV_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void g_shared_prof(int i, unsigned long long t);
+#define RV_PROF(i) { if (threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_shared_prof(i, t_); } }
+#else
+#define RV_PROF(i)
+#endif
+
 #define RV_STREAM_RESET  1u
 #define RV_STREAM_RANDOM 2u
 #define RV_STREAM_HEUR   3u
@@ -47,7 +65,8 @@ namespace rv {
 // JointTarget / LinkTarget (controllable_body.py:28-233)
 struct JTarget {
   int active, n_idx, has_vel, has_stop;
-  int from_ik;   // the target is the IK solution of the active link target
+  int from_ik;   // the target is the IK solution of the active link target: 1 = yes, 2 = yes and the
+                 // solve ended on the residual test (a re-solve from it returns it unchanged)
   int idx[RV_NJ];
   float pos[RV_NJ];
   float start_t, stop_t, pos_thr, vel_thr;
@@ -84,6 +103,9 @@ struct DevEnv {
   float obs_pos[RV_MAXB][3], prev_obs_pos[RV_MAXB][3];
   int num_total_steps, num_unsafe, num_ineffective, num_useful, num_successes;
   int pad_[3];
+#ifdef RV_PROFILE
+  unsigned long long prof[8], prof_t;   // tools/prof_rollout.py: shader-clock time per substep part
+#endif
 };
 static_assert(sizeof(DevEnv) % 4 == 0, "DevEnv is copied word-wise");
 
@@ -117,7 +139,11 @@ struct Scratch {
   float mot[RV_MAXB];
   float sync;
   float lq[RV_NLIMB][4];
-  int at_possible, any_on;
+  float vdraw[RV_NJ], ratio[RV_NJ];      // motor phase: raw commanded velocity, limit factor
+  int jmoving[RV_NJ];
+  float rvec[RV_NLIMB + 1][3];           // FK: link offsets rotated into the world
+  int jt_applied;                        // the motor targets hold the current joint target (per launch)
+  int any_on;
   int pairs[4];
   Rng rng;
 };
@@ -189,10 +215,11 @@ RV_DEV void fk_limb(const rv_arm* a, const float* q, LimbFK& F, float* frot_out 
 }
 
 // damped-least-squares IK (bullet_physics.py:1203-1262 call site), lane-serial
-RV_DEV_NOINLINE void arm_ik(const Consts& K, const float* q0, const float* pose, float* out) {
+RV_DEV_NOINLINE int arm_ik(const Consts& K, const float* q0, const float* pose, float* out) {
   const rv_arm* a = K.arm;
   const rv_config* c = K.cfg;
   float q[RV_NLIMB];
+  int conv = 0;
 #pragma unroll
   for (int i = 0; i < RV_NLIMB; ++i) q[i] = q0[i];
   v3 tp = ld3(pose);
@@ -210,7 +237,7 @@ RV_DEV_NOINLINE void arm_ik(const Consts& K, const float* q0, const float* pose,
     float e2 = 0.0f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) e2 += err[k] * err[k];
-    if (e2 < c->ik_residual * c->ik_residual) break;
+    if (e2 < c->ik_residual * c->ik_residual) { conv = 1; break; }
     float J[6][RV_NLIMB];
 #pragma unroll
     for (int j = 0; j < RV_NLIMB; ++j) {
@@ -270,6 +297,7 @@ RV_DEV_NOINLINE void arm_ik(const Consts& K, const float* q0, const float* pose,
   }
 #pragma unroll
   for (int i = 0; i < RV_NLIMB; ++i) out[i] = q[i];
+  return conv;
 }
 
 // --------------------------------------------- ControllableBody restated --
@@ -314,6 +342,15 @@ RV_DEV void arm_reset_targets(DevEnv& e) { lt_reset(e.lt); jt_reset(e.jt); }
 // ControllableBody.update (controllable_body.py:387-413), one lane
 RV_DEV void control_update(Shared& S, const Consts& K) {
   DevEnv& e = S.e;
+  {
+    // most substeps nothing is due: no done-check (every 100 steps), no IK (every 10
+    // steps), and the motor targets already hold the joint target (jt_applied).
+    // One batch of LDS reads decides that.
+    const int lt_on = e.lt.active, jt_on = e.jt.active, steps = e.sim_steps, applied = S.s.jt_applied;
+    if (!lt_on && !jt_on) return;
+    if (steps % RV_STEPS_TO_CHECK_DONE != 0 && jt_on && applied &&
+        (!lt_on || steps % RV_STEPS_TO_UPDATE_IK != 0)) return;
+  }
   int ik_updated = 0;
   if (e.lt.active) {
     if (e.sim_steps % RV_STEPS_TO_CHECK_DONE == 0)
@@ -321,18 +358,26 @@ RV_DEV void control_update(Shared& S, const Consts& K) {
   }
   if (e.lt.active) {
     if (e.sim_steps % RV_STEPS_TO_UPDATE_IK == 0 || !e.jt.active) {
-      // _update_ik (controllable_body.py:468-499)
-      float qik[RV_NLIMB];
-      // seed: the previous IK solution while it is still being tracked (the periodic
-      // re-solve then converges in one iteration), else the current joint state
-      arm_ik(K, (e.jt.active && e.jt.from_ik) ? e.jt.pos : e.q, e.lt.pose, qik);
-      JTarget& t = e.jt;
-      t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = (e.lt.nq == 0); t.from_ik = 1;
-      for (int i = 0; i < RV_NLIMB; ++i) { t.idx[i] = i; t.pos[i] = qik[i]; }
-      t.start_t = e.lt.start_t; t.stop_t = e.lt.stop_t; t.has_stop = 1;
-      t.pos_thr = e.lt.pos_thr; t.vel_thr = e.lt.vel_thr;
+      // _update_ik (controllable_body.py:468-499).  Skipped when the tracked target is
+      // the converged solution of this very pose: solving again from it passes the
+      // residual test at once and returns it unchanged.
+      if (!(e.jt.active && e.jt.from_ik == 2)) {
+        float qik[RV_NLIMB];
+        // seed: the previous IK solution while it is still being tracked, else the
+        // current joint state
+        int conv = arm_ik(K, (e.jt.active && e.jt.from_ik) ? e.jt.pos : e.q, e.lt.pose, qik);
+        JTarget& t = e.jt;
+        t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = (e.lt.nq == 0); t.from_ik = conv ? 2 : 1;
+        for (int i = 0; i < RV_NLIMB; ++i) { t.idx[i] = i; t.pos[i] = qik[i]; }
+        t.start_t = e.lt.start_t; t.stop_t = e.lt.stop_t; t.has_stop = 1;
+        t.pos_thr = e.lt.pos_thr; t.vel_thr = e.lt.vel_thr;
+        S.s.jt_applied = 0;
+      }
       ik_updated = 1;
-      if (check_joints_reached(e)) lt_pop(e.lt);
+      if (check_joints_reached(e)) {
+        lt_pop(e.lt);                                  // next pose of the path: solve again
+        if (e.jt.from_ik == 2) e.jt.from_ik = 1;
+      }
     }
   }
   if (e.jt.active) {
@@ -346,6 +391,7 @@ RV_DEV void control_update(Shared& S, const Consts& K) {
       e.motor_on[j] = 1; e.motor_q[j] = e.jt.pos[i];
       e.motor_kp[j] = K.cfg->kp; e.motor_kd[j] = K.cfg->kd;
     }
+    S.s.jt_applied = 1;
   }
 }
 // ControllableBody.is_ready(limb joints) (controllable_body.py:565-595)
@@ -366,6 +412,7 @@ RV_DEV void robot_move_to_joint_positions(Shared& S, const Consts& K, const floa
   for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = c->limb_max_velocity_ratio * K.arm->v_max[j];
   JTarget& t = e.jt;
   t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = 1; t.from_ik = 0;
+  S.s.jt_applied = 0;
   for (int i = 0; i < RV_NLIMB; ++i) { t.idx[i] = i; t.pos[i] = pos[i]; }
   t.start_t = sim_time(S, K); t.stop_t = t.start_t + c->limb_timeout; t.has_stop = 1;
   t.pos_thr = c->limb_position_threshold; t.vel_thr = c->velocity_threshold;
@@ -389,6 +436,7 @@ RV_DEV void robot_grip(Shared& S, const Consts& K, float value) {
   float rpos = a->q_lo[8] + value * (a->q_hi[8] - a->q_lo[8]);
   JTarget& t = e.jt;
   t.active = 1; t.n_idx = 2; t.has_vel = 1; t.from_ik = 0;
+  S.s.jt_applied = 0;
   t.idx[0] = 7; t.idx[1] = 8; t.pos[0] = lpos; t.pos[1] = rpos;
   t.start_t = sim_time(S, K); t.stop_t = t.start_t + 10000.0f; t.has_stop = 1;
   t.pos_thr = 0.008726640f; t.vel_thr = K.cfg->velocity_threshold;
@@ -642,36 +690,43 @@ RV_DEV void warm_apply(BV& A, BV* B, float ima, float imb, const Lam& l, const R
 // ControllableBody.update, then the physics step, then num_steps += 1.
 // K.stop_after (profiling hook, 0 = off): return after a given phase group so that
 // per-phase costs can be read off as differences (tools/prof_phases.sh)
-RV_DEV void sim_substep(Shared& S, const Consts& K) {
+RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   const rv_config* c = K.cfg;
   const rv_arm* arm = K.arm;
   const int arm_on = S.e.arm_enabled;
 
   if (arm_on) {
     RV_LANES_BEGIN
-      if (lane == 0) {
-        control_update(S, K);
-        // limb joints move synchronised: one common scale keeps every commanded
-        // velocity within its limit, so the path is a straight line in joint space
-        const DevEnv& e = S.e; float dt = c->dt;
-        float sync = 1.0f;
-#pragma unroll
-        for (int k = 0; k < RV_NLIMB; ++k) {
-          if (!e.motor_on[k]) continue;
-          float raw = fabsr(e.motor_kp[k] * (e.motor_q[k] - e.q[k]) / dt);
-          if (raw > e.vmax_cmd[k]) sync = fminr(sync, e.vmax_cmd[k] / raw);
+      if (lane == 0) control_update(S, K);
+    RV_LANES_END
+    RV_STOPL(10)
+    // joint motors of the kinematic arm, (a) per joint: the raw
+    // commanded velocity and the factor that would bring it within its limit
+    RV_LANES_BEGIN
+      if (lane < RV_NJ) {
+        const DevEnv& e = S.e; int j = lane;
+        float vd = 0.0f, ratio = 1.0f;
+        if (e.motor_on[j]) {
+          vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) / c->dt;
+          float raw = fabsr(vd);
+          if (j < RV_NLIMB && raw > e.vmax_cmd[j]) ratio = e.vmax_cmd[j] / raw;
         }
-        S.s.sync = sync;
+        S.s.vdraw[j] = vd; S.s.ratio[j] = ratio;
       }
     RV_LANES_END
-    // joint motors of the kinematic arm
+    RV_STOPL(11)
+    // (b) limb joints move synchronised: one common scale (the smallest factor)
+    // keeps every commanded velocity within its limit, so the path is a straight
+    // line in joint space.  Then the local joint quaternions of the new positions.
     RV_LANES_BEGIN
       if (lane < RV_NJ) {
         DevEnv& e = S.e; int j = lane; float dt = c->dt;
-        const float sync = S.s.sync;
+        float sync = 1.0f;
+#pragma unroll
+        for (int k = 0; k < RV_NLIMB; ++k) sync = fminr(sync, S.s.ratio[k]);
         float vd = 0.0f;
         if (e.motor_on[j]) {
-          vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) / dt;
+          vd = S.s.vdraw[j];
           if (j < RV_NLIMB) vd = vd * sync;
           vd = fclampr(vd, -e.vmax_cmd[j], e.vmax_cmd[j]);
         }
@@ -681,60 +736,68 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
         if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
         if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
         e.q[j] = qn; e.qd[j] = qd;
+        S.s.jmoving[j] = fabsr(qd) > 1e-3f;
+        if (j < RV_NLIMB) stq(S.s.lq[j], joint_local_quat(arm, j, qn));
       }
     RV_LANES_END
-    // forward kinematics.  (a) lanes 0-6: local joint quaternions
-    RV_LANES_BEGIN
-      if (lane < RV_NLIMB) stq(S.s.lq[lane], joint_local_quat(arm, lane, S.e.q[lane]));
-    RV_LANES_END
-    // (b) lane 0: the serial chain (quaternion products + rotations) and link twists
+    RV_STOPL(12)
+    // forward kinematics.  (a) lane 0: the serial product of the joint quaternions
     RV_LANES_BEGIN
       if (lane == 0) {
         DevEnv& e = S.e;
-        q4 lq[RV_NLIMB];
+        q4 pq = ldq(arm->base_quat);
 #pragma unroll
-        for (int i = 0; i < RV_NLIMB; ++i) lq[i] = ldq(S.s.lq[i]);
-        LimbFK F;
-        fk_chain(arm, lq, F);
-        v3 wprev = mk(0, 0, 0), vprev = mk(0, 0, 0), pprev = ld3(arm->base_pos);
+        for (int i = 0; i < RV_NLIMB; ++i) { pq = qmul(pq, ldq(S.s.lq[i])); stq(e.fquat[i], pq); }
+        stq(e.fquat[7], qmul(pq, ldq(arm->jquat[7])));
+      } else if (lane == 1) {
+        int mv = 0;
 #pragma unroll
-        for (int i = 0; i < RV_NLIMB; ++i) {
-          st3(e.fpos[i], F.pos[i]); stq(e.fquat[i], F.quat[i]); st3(S.s.axis[i], F.axis[i]);
-          v3 fv = add(vprev, cross(wprev, sub(F.pos[i], pprev)));
-          v3 fw = madd(wprev, F.axis[i], e.qd[i]);
-          st3(S.s.fv[i], fv); st3(S.s.fw[i], fw);
-          wprev = fw; vprev = fv; pprev = F.pos[i];
-        }
-        st3(e.fpos[7], F.pos[7]); stq(e.fquat[7], F.quat[7]);
-        v3 v7 = add(vprev, cross(wprev, sub(F.pos[7], pprev)));
-        st3(S.s.fv[7], v7); st3(S.s.fw[7], wprev);
+        for (int j = 0; j < RV_NJ; ++j) mv |= S.s.jmoving[j];
+        S.s.arm_moving = mv;
       }
     RV_LANES_END
-    // (c) lanes 0-7: rotation matrices; lanes 8-9: finger frames and twists
+    RV_STOPL(13)
+    // (b) lanes 0-7: each link's offset rotated into the world, joint axis, rotation matrix
     RV_LANES_BEGIN
       DevEnv& e = S.e;
-      if (lane <= RV_NLIMB) stm(S.s.frot[lane], qmat(ldq(e.fquat[lane])));
-      if (lane == 8 || lane == 9) {
-        int k = lane - 8, f = lane;
+      if (lane <= RV_NLIMB) {
+        int i = lane;
+        q4 par = ldq(i == 0 ? arm->base_quat : e.fquat[i == 0 ? 0 : i - 1]);
+        st3(S.s.rvec[i], qrotv(par, ld3(arm->jpos[i])));
+        q4 qi = ldq(e.fquat[i]);
+        if (i < RV_NLIMB) st3(S.s.axis[i], qaxis_z(qi));
+        stm(S.s.frot[i], qmat(qi));
+      } else if (lane == 8 || lane == 9) {
         q4 q7 = ldq(e.fquat[7]);
-        m3 r7 = qmat(q7);
-        v3 yax = mk(r7.m[1], r7.m[4], r7.m[7]);
-        v3 p7 = ld3(e.fpos[7]);
-        float off = arm->finger_y0[k] + e.q[7 + k];
-        v3 pf = madd(p7, yax, off);
-        st3(e.fpos[f], pf); stq(e.fquat[f], q7);
-        stm(S.s.frot[f], r7);
-        v3 w7 = ld3(S.s.fw[7]);
-        v3 vf = add(ld3(S.s.fv[7]), cross(w7, sub(pf, p7)));
-        vf = madd(vf, yax, e.qd[7 + k]);
-        st3(S.s.fv[f], vf); st3(S.s.fw[f], w7);
+        stm(S.s.frot[lane], qmat(q7));
+        stq(e.fquat[lane], q7);
+      }
+    RV_LANES_END
+    RV_STOPL(14)
+    // (c) lanes 0-9: frame origins = the running sum of the offsets, in chain order
+    // (bit-identical to the serial chain); the two finger frames slide along hand y
+    RV_LANES_BEGIN
+      if (lane < RV_NFRAME) {
+        DevEnv& e = S.e;
+        const int n = lane < 8 ? lane : 7;
+        v3 p = ld3(arm->base_pos);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k <= n) p = add(p, ld3(S.s.rvec[k]));
+        if (lane >= 8) {
+          int k = lane - 8;
+          v3 yax = mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]);
+          float off = arm->finger_y0[k] + e.q[7 + k];
+          p = madd(p, yax, off);
+        }
+        st3(e.fpos[lane], p);
       }
     RV_LANES_END
   }
 
-  if (K.stop_after == 1) return;
+  RV_STOPL(1)
   // collider geometry
   RV_LANES_BEGIN
+    if (lane < RV_MAXB) S.s.wake[lane] = 0;
     if (arm_on) {
       for (int item = lane; item < RV_NCOL * 8; item += 64) {
         int col = item >> 3, k = item & 7;
@@ -752,8 +815,9 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
       }
     }
   RV_LANES_END
+  RV_STOPL(15)
 
-  // world AABB of every collider box; is the arm moving?
+  // world AABB of every collider box
   RV_LANES_BEGIN
     if (arm_on && lane < RV_NCOL) {
       int col = lane;
@@ -765,49 +829,34 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
         S.s.colmin[col][x] = lo; S.s.colmax[col][x] = hi;
       }
     }
-    if (lane == 16) {
-      int mv = 0;
-      if (arm_on) for (int j = 0; j < RV_NJ; ++j) if (fabsr(S.e.qd[j]) > 1e-3f) mv = 1;
-      S.s.arm_moving = mv;
-    }
-    if (lane == 17) {
-      // can any arm collider be within the contact-query distance of the table top?
-      int at = 0;
-      if (arm_on)
-        for (int col = 0; col < RV_NCOL; ++col) {
-          float minz = S.s.colv[col][0][2];
-          for (int k = 1; k < 8; ++k) minz = fminr(minz, S.s.colv[col][k][2]);
-          if (!(minz - S.e.table_z - c->margin >= c->contact_query_dist)) at = 1;
-        }
-      S.s.at_possible = at;
-    }
   RV_LANES_END
+  RV_STOPL(16)
 
   // wake test: a sleeping body is woken by a MOVING awake body or, while the arm
   // moves, by an arm collider box coming within the contact-breaking distance.
-  // (Reads only state that no lane changes in this phase.)
+  // One lane per (body, collider) and per ordered (body, neighbour) pair; a hit
+  // raises the body's flag (cleared two phases ago).
   RV_LANES_BEGIN
-    if (lane < RV_MAXB) {
-      int b = lane; const DevEnv& e = S.e;
-      int wk = 0;
-      if (body_present(e, b) && e.asleep[b]) {
-        v3 pb = ld3(e.body[b]);
-        for (int a = 0; a < RV_MAXB; ++a) {
-          // only a MOVING neighbour wakes a sleeper (resting neighbours would ping-pong)
-          if (a == b || !body_on(e, a) || e.sleep_count[a] > 0) continue;
-          v3 d = sub(ld3(e.body[a]), pb);
-          float r = e.radius[a] + e.radius[b] + c->breaking;
-          if (dot(d, d) < r * r) wk = 1;
-        }
-        if (arm_on && S.s.arm_moving)
-          for (int col = 0; col < RV_NCOL; ++col) {
-            float r = e.radius[b] + c->breaking;
-            if (sphere_aabb_dist2(pb, S.s.colmin[col], S.s.colmax[col]) < r * r) wk = 1;
-          }
+    const DevEnv& e = S.e;
+    if (lane < RV_MAXB * RV_NCOL) {
+      int b = lane / RV_NCOL, col = lane - b * RV_NCOL;
+      if (arm_on && S.s.arm_moving && body_present(e, b) && e.asleep[b]) {
+        float r = e.radius[b] + c->breaking;
+        if (sphere_aabb_dist2(ld3(e.body[b]), S.s.colmin[col], S.s.colmax[col]) < r * r) S.s.wake[b] = 1;
       }
-      S.s.wake[b] = wk;
+    } else if (lane < RV_MAXB * RV_NCOL + RV_MAXB * (RV_MAXB - 1)) {
+      int t = lane - RV_MAXB * RV_NCOL;
+      int b = t / (RV_MAXB - 1), a = t - b * (RV_MAXB - 1);
+      if (a >= b) a++;
+      // only a MOVING neighbour wakes a sleeper (resting neighbours would ping-pong)
+      if (body_present(e, b) && e.asleep[b] && body_on(e, a) && !(e.sleep_count[a] > 0)) {
+        v3 d = sub(ld3(e.body[a]), ld3(e.body[b]));
+        float r = e.radius[a] + e.radius[b] + c->breaking;
+        if (dot(d, d) < r * r) S.s.wake[b] = 1;
+      }
     }
   RV_LANES_END
+  RV_STOPL(17)
 
   // body velocity update + rotations
   RV_LANES_BEGIN
@@ -830,15 +879,65 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
       }
     }
   RV_LANES_END
+  RV_STOPL(18)
 
-  // hull vertices to world frame
+  // uniform: is any body awake?  can any arm collider be within the contact-query
+  // distance of the table top?
+  int any_on = 0, at_possible = 0;
+#pragma unroll
+  for (int b = 0; b < RV_MAXB; ++b) any_on |= body_on(S.e, b);
+  if (arm_on) {
+#pragma unroll
+    for (int col = 0; col < RV_NCOL; ++col)
+      if (!(S.s.colmin[col][2] - S.e.table_z - c->margin >= c->contact_query_dist)) at_possible = 1;
+  }
+  // quiet substep: every body asleep (or absent) and no arm collider near the
+  // table -> nothing to collide, solve or integrate
+  if (!any_on && !at_possible) {
+    RV_LANES_BEGIN
+      DevEnv& e = S.e;
+      if (lane == 0) { e.flag_arm_table = 0; e.sim_steps++; e.substeps_last++; }
+      if (lane >= 1 && lane <= RV_MAXB) e.flag_arm_body[lane - 1] = 0;
+    RV_LANES_END
+    return 0;
+  }
   RV_LANES_BEGIN
-    if (lane == 63) {
-      int aw = 0;
-      for (int b = 0; b < RV_MAXB; ++b) aw |= body_on(S.e, b);
-      S.e.awake_last += aw;
-      S.s.any_on = aw;
+    if (lane == 0) S.s.any_on = any_on;
+  RV_LANES_END
+  return 1;
+}
+
+// The rest of the step: contacts, solver, integration.
+RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
+  const rv_config* c = K.cfg;
+  const rv_arm* arm = K.arm;
+  const int arm_on = S.e.arm_enabled;
+  // link twists (used by the arm-body contact rows) and hull vertices to world frame
+  RV_LANES_BEGIN
+    if (lane == 0 && arm_on) {
+      DevEnv& e = S.e;
+      v3 wprev = mk(0, 0, 0), vprev = mk(0, 0, 0), pprev = ld3(arm->base_pos);
+#pragma unroll
+      for (int i = 0; i < RV_NLIMB; ++i) {
+        v3 pi = ld3(e.fpos[i]);
+        v3 fv = add(vprev, cross(wprev, sub(pi, pprev)));
+        v3 fw = madd(wprev, ld3(S.s.axis[i]), e.qd[i]);
+        st3(S.s.fv[i], fv); st3(S.s.fw[i], fw);
+        wprev = fw; vprev = fv; pprev = pi;
+      }
+      v3 p7 = ld3(e.fpos[7]);
+      v3 v7 = add(vprev, cross(wprev, sub(p7, pprev)));
+      st3(S.s.fv[7], v7); st3(S.s.fw[7], wprev);
+      v3 yax = mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        int f = 8 + k;
+        v3 vf = add(v7, cross(wprev, sub(ld3(e.fpos[f]), p7)));
+        vf = madd(vf, yax, e.qd[7 + k]);
+        st3(S.s.fv[f], vf); st3(S.s.fw[f], wprev);
+      }
     }
+    if (lane == 63) S.e.awake_last += S.s.any_on;
     for (int item = lane; item < RV_MAXB * RV_MAXH * RV_MAXV; item += 64) {
       int b = item / (RV_MAXH * RV_MAXV), h = (item / RV_MAXV) % RV_MAXH, i = item % RV_MAXV;
       if (!body_on(S.e, b)) continue;
@@ -849,18 +948,8 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
       st3(S.s.wv[b][h][i], add(ld3(S.e.body[b]), mulv(S.s.rot[b], l)));
     }
   RV_LANES_END
-
-  if (K.stop_after == 2) return;
-  // quiet substep: every body asleep (or absent) and no arm collider near the
-  // table -> nothing to collide, solve or integrate
-  if (!S.s.any_on && !S.s.at_possible) {
-    RV_LANES_BEGIN
-      DevEnv& e = S.e;
-      if (lane == 0) { e.flag_arm_table = 0; e.sim_steps++; e.substeps_last++; }
-      if (lane >= 1 && lane <= RV_MAXB) e.flag_arm_body[lane - 1] = 0;
-    RV_LANES_END
-    return;
-  }
+  RV_STOP(2)
+  RV_PROF(2)
   // manifold refresh + narrow phase.  The wave is split into four 16-lane
   // groups; a group works on one manifold owner at a time (body-table,
   // body-body, arm-body, arm-table detection: 24 owners, six rounds) and all
@@ -961,7 +1050,8 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
     if ((lane & 15) == 0) S.s.pairs[slot] = my_pairs;
   RV_LANES_END
 
-  if (K.stop_after == 3) return;
+  RV_STOP(3)
+  RV_PROF(3)
   // solver row setup (one lane per contact point) + contact flags
   RV_LANES_BEGIN
     DevEnv& e = S.e;
@@ -998,7 +1088,8 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
     }
   RV_LANES_END
 
-  if (K.stop_after == 4) return;
+  RV_STOP(4)
+  RV_PROF(4)
   // PGS.  Bodies that are not coupled by a body-body contact are independent
   // problems: each body lane runs warm start + all its iterations in ONE phase
   // with rows and impulses in registers, stopping when ITS largest impulse
@@ -1106,7 +1197,8 @@ RV_DEV void sim_substep(Shared& S, const Consts& K) {
     }
   }
 
-  if (K.stop_after == 5) return;
+  RV_STOP(5)
+  RV_PROF(5)
   // integrate positions, freeze fallen bodies, counters
   RV_LANES_BEGIN
     DevEnv& e = S.e;
@@ -1149,14 +1241,22 @@ __shared__ Shared g_shared;
 #else
 static thread_local Shared g_shared;
 #endif
+#if defined(RV_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void g_shared_prof(int i, unsigned long long t) {
+  g_shared.e.prof[i] += t - g_shared.e.prof_t; g_shared.e.prof_t = t;
+}
+#endif
 // Consts whose cfg / arm point at the LDS copies (statically known address)
 RV_DEV Consts lds_consts(const rv_scene* scene, int stop_after) {
   Consts K; K.cfg = &g_shared.cfg; K.arm = &g_shared.arm; K.scene = scene; K.stop_after = stop_after;
   return K;
 }
-RV_DEV_NOINLINE void sim_substep_call(const rv_scene* scene, int stop_after) {
+// The heavy part (contacts, solver) is a function of its own: it needs every
+// register and pays a large callee-saved spill in its prologue, so it is entered
+// only when the light part (arm, wake test, quiet check) says so.
+RV_DEV_NOINLINE void sim_substep_heavy_call(const rv_scene* scene, int stop_after) {
   Consts K = lds_consts(scene, stop_after);
-  sim_substep(g_shared, K);
+  sim_substep_heavy(g_shared, K);
 }
 
 // Simulator.check_stable over a body mask (simulator.py:289-323)
@@ -1173,14 +1273,34 @@ RV_DEV unsigned active_mask(const DevEnv& e) {
   for (int b = 0; b < RV_MAXB; ++b) if (e.active[b]) m |= 1u << b;
   return m;
 }
-// Simulator.wait_until_stable (simulator.py:325-376); mask == 0 => all active
-RV_DEV void wait_until_stable(Shared& S, const Consts& K, unsigned mask, float lin_thr, float ang_thr,
-                              int check_after, int min_stable, int max_steps) {
-  RV_LANES_BEGIN
-    if (lane == 0) { S.s.wus_steps = 0; S.s.wus_stable = 0; S.s.loop_break = 0; }
-  RV_LANES_END
+// Runs substeps inside ONE out-of-line function, so that the call overhead
+// (callee-saved registers) is paid per call and not per substep, and the light
+// part exists once in the instruction stream.
+//   n_fixed > 0 : exactly n_fixed times Simulator.step
+//   n_fixed == 0: Simulator.wait_until_stable (simulator.py:325-376); mask == 0 => all active
+RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_fixed, unsigned mask,
+                                  float lin_thr, float ang_thr, int check_after, int min_stable, int max_steps) {
+  Consts K = lds_consts(scene, stop_after);
+  Shared& S = g_shared;
+  if (n_fixed == 0) {
+    RV_LANES_BEGIN
+      if (lane == 0) { S.s.wus_steps = 0; S.s.wus_stable = 0; S.s.loop_break = 0; }
+    RV_LANES_END
+  }
+  int taken = 0;
   for (;;) {
-    sim_substep_call(K.scene, K.stop_after);
+    RV_PROF(7)
+    if (sim_substep_light(S, K)) {
+      RV_PROF(1)
+      sim_substep_heavy_call(scene, stop_after);
+      RV_PROF(6)
+    } else {
+      RV_PROF(0)
+    }
+    if (n_fixed > 0) {
+      if (++taken >= n_fixed) break;
+      continue;
+    }
     RV_LANES_BEGIN
       if (lane == 0) {
         S.s.wus_steps++;
@@ -1193,6 +1313,14 @@ RV_DEV void wait_until_stable(Shared& S, const Consts& K, unsigned mask, float l
     RV_LANES_END
     if (S.s.loop_break) break;
   }
+}
+RV_DEV void sim_steps_call(const Consts& K, int n) {
+  if (n > 0) sim_run_call(K.scene, K.stop_after, n, 0u, 0.0f, 0.0f, 0, 0, 0);
+}
+RV_DEV void wait_until_stable(Shared& S, const Consts& K, unsigned mask, float lin_thr, float ang_thr,
+                              int check_after, int min_stable, int max_steps) {
+  (void)S;
+  sim_run_call(K.scene, K.stop_after, 0, mask, lin_thr, ang_thr, check_after, min_stable, max_steps);
 }
 
 // ------------------------------------------------- observation / reward --
@@ -1369,8 +1497,8 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
     }
   RV_LANES_END
   while (S.e.phase != RV_PHASE_DONE) {
-    sim_substep_call(K.scene, K.stop_after);
-    if (S.e.sim_steps % c->steps_check != 0) continue;
+    // the phase machine looks at the world every STEPS_CHECK substeps (push_env.py:652-661)
+    sim_steps_call(K, c->steps_check - (S.e.sim_steps % c->steps_check));
     RV_LANES_BEGIN
       if (lane == 0) phase_tick(S, K);
     RV_LANES_END
@@ -1536,6 +1664,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
       for (int j = 0; j < RV_NLIMB; ++j) { e.q[j] = c->neutral_positions[j]; e.qd[j] = 0.0f; }
       e.q[7] = a->q_hi[7]; e.q[8] = a->q_lo[8]; e.qd[7] = 0.0f; e.qd[8] = 0.0f;
       for (int j = 0; j < RV_NJ; ++j) { e.motor_on[j] = 0; e.motor_q[j] = e.q[j]; e.motor_kp[j] = c->kp; e.motor_kd[j] = c->kd; e.vmax_cmd[j] = a->v_max[j]; }
+      S.s.jt_applied = 0;
       arm_reset_targets(e);
       e.gripper_ready_time = 0.0f;
       e.arm_enabled = 1;
@@ -1592,6 +1721,7 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
 // rebuild the per-launch caches that are not part of the persistent block
 RV_DEV void env_enter(Shared& S, const Consts& K) {
   RV_LANES_BEGIN
+    if (lane == 63) S.s.jt_applied = 0;
     if (lane < 8) table_prepare(S, K, lane);
     if (lane >= 8 && lane < 8 + RV_NFRAME) {
       int f = lane - 8;

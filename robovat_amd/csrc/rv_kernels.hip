@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   } else if (MODE == MODE_SUB) {
     if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; }
     __syncthreads();
-    for (int k = 0; k < args.n_substeps; ++k) sim_substep_call(K.scene, K.stop_after);
+    sim_steps_call(K, args.n_substeps);
   } else {
     if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; }
     __syncthreads();
@@ -167,6 +167,12 @@ __global__ void k_get_link_poses(const DevEnv* envs, int n, float* out) {
     for (int k = 0; k < 4; ++k) o[3 + k] = envs[i].fquat[f][k];
   }
 }
+#ifdef RV_PROFILE
+__global__ void k_debug_profile(const DevEnv* envs, int n, unsigned long long* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) for (int k = 0; k < 8; ++k) out[(size_t)i * 8 + k] = envs[i].prof[k];
+}
+#endif
 __global__ void k_get_env_counters(const DevEnv* envs, int n, int32_t* out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
   const DevEnv& e = envs[i]; int32_t* o = out + (size_t)i * RV_NCOUNTERS;
@@ -481,6 +487,10 @@ int rv_set_body_params(rv_world* w, const float* d) { WCHK(w); NEED(d, "rv_set_b
 int rv_get_joint_state(rv_world* w, float* d) { WCHK(w); NEED(d, "rv_get_joint_state"); SIMPLE_LAUNCH(k_get_joint_state, w->d_envs, w->n, d); return RV_OK; }
 int rv_set_joint_state(rv_world* w, const float* d) { WCHK(w); NEED(d, "rv_set_joint_state"); SIMPLE_LAUNCH(k_set_joint_state, w->d_envs, w->n, d, w->d_cfg, w->d_scene); return RV_OK; }
 int rv_get_link_poses(rv_world* w, float* d) { WCHK(w); NEED(d, "rv_get_link_poses"); SIMPLE_LAUNCH(k_get_link_poses, w->d_envs, w->n, d); return RV_OK; }
+#ifdef RV_PROFILE
+// profiling build only (tools/prof_rollout.py): per-env shader-clock time per substep part
+int rv_debug_profile(rv_world* w, unsigned long long* d) { WCHK(w); NEED(d, "rv_debug_profile"); SIMPLE_LAUNCH(k_debug_profile, w->d_envs, w->n, d); return RV_OK; }
+#endif
 int rv_get_env_counters(rv_world* w, int32_t* d) { WCHK(w); NEED(d, "rv_get_env_counters"); SIMPLE_LAUNCH(k_get_env_counters, w->d_envs, w->n, d); return RV_OK; }
 int rv_set_joint_targets(rv_world* w, const float* d) { WCHK(w); NEED(d, "rv_set_joint_targets"); SIMPLE_LAUNCH(k_set_joint_targets, w->d_envs, w->n, d, w->d_cfg, w->d_scene); return RV_OK; }
 int rv_set_link_target(rv_world* w, const float* d) { WCHK(w); NEED(d, "rv_set_link_target"); SIMPLE_LAUNCH(k_set_link_target, w->d_envs, w->n, d, w->d_cfg, w->d_scene); return RV_OK; }

@@ -26,7 +26,7 @@ static void run_env(EmuWorld* w, int i, int mode, int n_sub, float lin, float an
   if (mode == 0) env_reset(S, K, w->cfg.env_id_offset + i);
   else if (mode == 1) { S.e.stepped = 0; env_step(S, K); }
   else if (mode == 4) env_rollout(S, K, w->cfg.env_id_offset + i, n_sub, ca, ms, nullptr, nullptr, i, w->n);
-  else if (mode == 2) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; for (int k = 0; k < n_sub; ++k) sim_substep_call(K.scene, 0); }
+  else if (mode == 2) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; sim_steps_call(K, n_sub); }
   else { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; wait_until_stable(S, K, 0u, lin, ang, ca, ms, mx); }
   memcpy(&w->envs[i], &S.e, sizeof(DevEnv));
 }

@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage (on the GPU box): tools/prof_phases.sh <outname> [prof_sub args...]
+# Times the substep kernel cut off after each phase group (RV_DEBUG_STOP); the
+# per-phase costs are the differences between consecutive lines.
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; shift; mkdir -p $(dirname $OUT)
+ARGS=${@:-"1024 200 link"}
+: > $OUT.txt
+for st in 10 11 12 13 14 1 15 16 17 18 2 0; do
+  echo "== stop $st" >> $OUT.txt
+  RV_DEBUG_STOP=$st timeout 300 python $R/tools/prof_sub.py $ARGS 2>&1 | grep "^sub" >> $OUT.txt
+done
+cat $OUT.txt

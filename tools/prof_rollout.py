@@ -1,0 +1,64 @@
+"""Where does the time of the bench workload go?  (profiling build, -DRV_PROFILE)
+
+    RV_LIB=robovat_amd/librovat_hip_prof.so python tools/prof_rollout.py [n_envs] [steps]
+
+Lane 0 of every env accumulates shader-clock time per substep part; this prints
+the split over all envs and for the slowest env (which sets the launch time).
+Build the profiling library first (here, without a GPU):
+    python tools/prof_rollout.py --build
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROF_LIB = os.path.join(ROOT, 'robovat_amd', 'librovat_hip_prof.so')
+
+if '--build' in sys.argv:
+    from robovat_amd import lib
+    cmd = ['/opt/rocm/bin/hipcc'] + lib.HIPCC_FLAGS + ['-DRV_PROFILE', os.path.join(lib.CSRC, 'rv_kernels.hip'), '-o', PROF_LIB]
+    subprocess.run(cmd, check=True)
+    print('built', PROF_LIB)
+    sys.exit(0)
+
+os.environ['RV_LIB'] = PROF_LIB
+import numpy as np
+import torch
+from robovat_amd import configs, scenes, lib
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+scene, names = scenes.make_scene()
+cfg = configs.make_rv_config(n_envs=n, seed=1234, shape_names=names)
+w = lib.World(cfg, scene, 0)
+L = lib.load()
+
+
+def prof():
+    out = torch.zeros((n, 8), dtype=torch.int64, device=w.device)
+    rc = L.rv_debug_profile(w.h, C.c_void_p(out.data_ptr()))
+    assert rc == 0
+    w.synchronize()
+    return out.cpu().numpy().astype(np.float64)
+
+
+w.reset(); w.synchronize()
+w.rollout(1, first_macro_index=0, auto_reset=True, record=False); w.synchronize()
+p0 = prof()
+w.rollout(steps, first_macro_index=1, auto_reset=True, record=False); w.synchronize()
+ms = w.last_kernel_ms()
+p = prof() - p0
+st = w.stats()
+names_ = ['quiet substeps (light part only)', 'light part of non-quiet substeps', 'heavy: twists + hull vertices',
+          'heavy: narrow phase', 'heavy: row setup', 'heavy: solver', 'heavy: integrate + return', 'between substeps']
+tot = p[:, :7].sum(axis=1)
+slow = int(np.argmax(tot))
+clk = tot.max() / (ms * 1e-3)
+print('rollout of %d steps x %d envs: %.1f ms; slowest env = %.3g clocks => counter at %.1f MHz' % (steps, n, ms, tot.max(), clk / 1e6))
+print('substeps %d, awake fraction %.3f' % (st['substeps'], st['awake_substeps'] / max(st['substeps'], 1)))
+print('%-36s %10s %10s' % ('part', 'mean env', 'slowest'))
+for k in range(8):
+    print('%-36s %9.1f%% %9.1f%%' % (names_[k], 100 * p[:, k].mean() / tot.mean(), 100 * p[slow, k] / tot[slow]))
+print('mean env busy time / slowest env = %.3f' % (tot.mean() / tot.max()))
