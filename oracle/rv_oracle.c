@@ -964,9 +964,16 @@ static void sim_substep(const orc_world* w, orc_env* e) {
     int aw = 0, at = 0;
     for (int b = 0; b < RV_MAXB; ++b) aw |= body_on(e, b);
     e->awake_last += aw;
-    if (e->arm_enabled)
-      for (int col = 0; col < RV_NCOL; ++col)
-        if (!(e->colmin[col][2] - e->table_z - (real)c->margin >= (real)c->contact_query_dist)) at = 1;
+    if (e->arm_enabled) {
+      /* the two rejection tests of the arm-table detector in collide_all() */
+      real tc[3] = {(real)c->table_center[0], (real)c->table_center[1], e->table_z - R(0.5) * (real)c->table_thickness};
+      real th[3] = {(real)c->table_half[0], (real)c->table_half[1], R(0.5) * (real)c->table_thickness};
+      for (int col = 0; col < RV_NCOL; ++col) {
+        real r = e->colr[col] + (real)c->breaking;
+        if (!(e->colmin[col][2] - e->table_z - (real)c->margin >= (real)c->contact_query_dist) &&
+            sphere_box_dist2(e->colc[col], tc, th) < r * r) at = 1;
+      }
+    }
     /* quiet substep: every body asleep (or absent) and no arm collider near the
      * table -> nothing to collide, solve or integrate */
     if (!aw && !at) {

@@ -143,6 +143,10 @@ struct Scratch {
   int jmoving[RV_NJ];
   float rvec[RV_NLIMB + 1][3];           // FK: link offsets rotated into the world
   int jt_applied;                        // the motor targets hold the current joint target (per launch)
+  int atflag[RV_NCOL];                   // collider box may be within the contact-query distance of the table
+  int kin_fresh;                         // FK / collider scratch matches the joint state (per launch)
+  int coast_unsafe[3];
+  float jlen[RV_NLIMB + 1], colext[RV_NCOL];   // |jpos_i|; collider extent from its frame origin
   int any_on;
   int pairs[4];
   Rng rng;
@@ -690,112 +694,126 @@ RV_DEV void warm_apply(BV& A, BV* B, float ima, float imb, const Lam& l, const R
 // ControllableBody.update, then the physics step, then num_steps += 1.
 // K.stop_after (profiling hook, 0 = off): return after a given phase group so that
 // per-phase costs can be read off as differences (tools/prof_phases.sh)
-RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
+// ---- arm phase groups (shared by the regular substep and the coasting path) ----
+// ControllableBody.update + joint motors.  with_lq: also the local joint quaternions
+// of the new positions and the per-joint "moving" flags (input of the FK phases).
+// count_step: lane 0 advances the step counters (coasting substeps end here).
+RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, const int count_step) {
   const rv_config* c = K.cfg;
   const rv_arm* arm = K.arm;
-  const int arm_on = S.e.arm_enabled;
-
-  if (arm_on) {
-    RV_LANES_BEGIN
-      if (lane == 0) control_update(S, K);
-    RV_LANES_END
-    RV_STOPL(10)
-    // joint motors of the kinematic arm, (a) per joint: the raw
-    // commanded velocity and the factor that would bring it within its limit
-    RV_LANES_BEGIN
-      if (lane < RV_NJ) {
-        const DevEnv& e = S.e; int j = lane;
-        float vd = 0.0f, ratio = 1.0f;
-        if (e.motor_on[j]) {
-          vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) / c->dt;
-          float raw = fabsr(vd);
-          if (j < RV_NLIMB && raw > e.vmax_cmd[j]) ratio = e.vmax_cmd[j] / raw;
-        }
-        S.s.vdraw[j] = vd; S.s.ratio[j] = ratio;
+  RV_LANES_BEGIN
+    if (lane == 0) control_update(S, K);
+  RV_LANES_END
+  // joint motors of the kinematic arm, (a) per joint: the raw
+  // commanded velocity and the factor that would bring it within its limit
+  RV_LANES_BEGIN
+    if (lane < RV_NJ) {
+      const DevEnv& e = S.e; int j = lane;
+      float vd = 0.0f, ratio = 1.0f;
+      if (e.motor_on[j]) {
+        vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) / c->dt;
+        float raw = fabsr(vd);
+        if (j < RV_NLIMB && raw > e.vmax_cmd[j]) ratio = e.vmax_cmd[j] / raw;
       }
-    RV_LANES_END
-    RV_STOPL(11)
-    // (b) limb joints move synchronised: one common scale (the smallest factor)
-    // keeps every commanded velocity within its limit, so the path is a straight
-    // line in joint space.  Then the local joint quaternions of the new positions.
-    RV_LANES_BEGIN
-      if (lane < RV_NJ) {
-        DevEnv& e = S.e; int j = lane; float dt = c->dt;
-        float sync = 1.0f;
+      S.s.vdraw[j] = vd; S.s.ratio[j] = ratio;
+    }
+  RV_LANES_END
+  // (b) limb joints move synchronised: one common scale (the smallest factor)
+  // keeps every commanded velocity within its limit, so the path is a straight
+  // line in joint space.
+  RV_LANES_BEGIN
+    if (lane < RV_NJ) {
+      DevEnv& e = S.e; int j = lane; float dt = c->dt;
+      float sync = 1.0f;
 #pragma unroll
-        for (int k = 0; k < RV_NLIMB; ++k) sync = fminr(sync, S.s.ratio[k]);
-        float vd = 0.0f;
-        if (e.motor_on[j]) {
-          vd = S.s.vdraw[j];
-          if (j < RV_NLIMB) vd = vd * sync;
-          vd = fclampr(vd, -e.vmax_cmd[j], e.vmax_cmd[j]);
-        }
-        float dv = fclampr(vd - e.qd[j], -arm->a_max[j] * dt, arm->a_max[j] * dt);
-        float qd = e.qd[j] + dv;
-        float qn = e.q[j] + qd * dt;
-        if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
-        if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
-        e.q[j] = qn; e.qd[j] = qd;
+      for (int k = 0; k < RV_NLIMB; ++k) sync = fminr(sync, S.s.ratio[k]);
+      float vd = 0.0f;
+      if (e.motor_on[j]) {
+        vd = S.s.vdraw[j];
+        if (j < RV_NLIMB) vd = vd * sync;
+        vd = fclampr(vd, -e.vmax_cmd[j], e.vmax_cmd[j]);
+      }
+      float dv = fclampr(vd - e.qd[j], -arm->a_max[j] * dt, arm->a_max[j] * dt);
+      float qd = e.qd[j] + dv;
+      float qn = e.q[j] + qd * dt;
+      if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
+      if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
+      e.q[j] = qn; e.qd[j] = qd;
+      if (with_lq) {
         S.s.jmoving[j] = fabsr(qd) > 1e-3f;
         if (j < RV_NLIMB) stq(S.s.lq[j], joint_local_quat(arm, j, qn));
       }
-    RV_LANES_END
-    RV_STOPL(12)
-    // forward kinematics.  (a) lane 0: the serial product of the joint quaternions
-    RV_LANES_BEGIN
-      if (lane == 0) {
-        DevEnv& e = S.e;
-        q4 pq = ldq(arm->base_quat);
-#pragma unroll
-        for (int i = 0; i < RV_NLIMB; ++i) { pq = qmul(pq, ldq(S.s.lq[i])); stq(e.fquat[i], pq); }
-        stq(e.fquat[7], qmul(pq, ldq(arm->jquat[7])));
-      } else if (lane == 1) {
-        int mv = 0;
-#pragma unroll
-        for (int j = 0; j < RV_NJ; ++j) mv |= S.s.jmoving[j];
-        S.s.arm_moving = mv;
-      }
-    RV_LANES_END
-    RV_STOPL(13)
-    // (b) lanes 0-7: each link's offset rotated into the world, joint axis, rotation matrix
-    RV_LANES_BEGIN
+      if (count_step && j == 0) { e.sim_steps++; e.substeps_last++; }
+    }
+  RV_LANES_END
+}
+// local joint quaternions / moving flags from the stored joint state (kinematics refresh)
+RV_DEV void arm_lq_phase(Shared& S, const Consts& K) {
+  RV_LANES_BEGIN
+    if (lane < RV_NJ) {
+      const DevEnv& e = S.e; int j = lane;
+      S.s.jmoving[j] = fabsr(e.qd[j]) > 1e-3f;
+      if (j < RV_NLIMB) stq(S.s.lq[j], joint_local_quat(K.arm, j, e.q[j]));
+    }
+  RV_LANES_END
+}
+// forward kinematics from the local joint quaternions S.s.lq
+RV_DEV void arm_fk_phases(Shared& S, const Consts& K) {
+  const rv_arm* arm = K.arm;
+  // (a) lane 0: the serial product of the joint quaternions
+  RV_LANES_BEGIN
+    if (lane == 0) {
       DevEnv& e = S.e;
-      if (lane <= RV_NLIMB) {
-        int i = lane;
-        q4 par = ldq(i == 0 ? arm->base_quat : e.fquat[i == 0 ? 0 : i - 1]);
-        st3(S.s.rvec[i], qrotv(par, ld3(arm->jpos[i])));
-        q4 qi = ldq(e.fquat[i]);
-        if (i < RV_NLIMB) st3(S.s.axis[i], qaxis_z(qi));
-        stm(S.s.frot[i], qmat(qi));
-      } else if (lane == 8 || lane == 9) {
-        q4 q7 = ldq(e.fquat[7]);
-        stm(S.s.frot[lane], qmat(q7));
-        stq(e.fquat[lane], q7);
-      }
-    RV_LANES_END
-    RV_STOPL(14)
-    // (c) lanes 0-9: frame origins = the running sum of the offsets, in chain order
-    // (bit-identical to the serial chain); the two finger frames slide along hand y
-    RV_LANES_BEGIN
-      if (lane < RV_NFRAME) {
-        DevEnv& e = S.e;
-        const int n = lane < 8 ? lane : 7;
-        v3 p = ld3(arm->base_pos);
+      q4 pq = ldq(arm->base_quat);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (k <= n) p = add(p, ld3(S.s.rvec[k]));
-        if (lane >= 8) {
-          int k = lane - 8;
-          v3 yax = mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]);
-          float off = arm->finger_y0[k] + e.q[7 + k];
-          p = madd(p, yax, off);
-        }
-        st3(e.fpos[lane], p);
+      for (int i = 0; i < RV_NLIMB; ++i) { pq = qmul(pq, ldq(S.s.lq[i])); stq(e.fquat[i], pq); }
+      stq(e.fquat[7], qmul(pq, ldq(arm->jquat[7])));
+    } else if (lane == 1) {
+      int mv = 0;
+#pragma unroll
+      for (int j = 0; j < RV_NJ; ++j) mv |= S.s.jmoving[j];
+      S.s.arm_moving = mv;
+    }
+  RV_LANES_END
+  // (b) lanes 0-7: each link's offset rotated into the world, joint axis, rotation matrix
+  RV_LANES_BEGIN
+    DevEnv& e = S.e;
+    if (lane <= RV_NLIMB) {
+      int i = lane;
+      q4 par = ldq(i == 0 ? arm->base_quat : e.fquat[i == 0 ? 0 : i - 1]);
+      st3(S.s.rvec[i], qrotv(par, ld3(arm->jpos[i])));
+      q4 qi = ldq(e.fquat[i]);
+      if (i < RV_NLIMB) st3(S.s.axis[i], qaxis_z(qi));
+      stm(S.s.frot[i], qmat(qi));
+    } else if (lane == 8 || lane == 9) {
+      q4 q7 = ldq(e.fquat[7]);
+      stm(S.s.frot[lane], qmat(q7));
+      stq(e.fquat[lane], q7);
+    }
+  RV_LANES_END
+  // (c) lanes 0-9: frame origins = the running sum of the offsets, in chain order
+  // (bit-identical to the serial chain); the two finger frames slide along hand y
+  RV_LANES_BEGIN
+    if (lane < RV_NFRAME) {
+      DevEnv& e = S.e;
+      const int n = lane < 8 ? lane : 7;
+      v3 p = ld3(arm->base_pos);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (k <= n) p = add(p, ld3(S.s.rvec[k]));
+      if (lane >= 8) {
+        int k = lane - 8;
+        v3 yax = mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]);
+        float off = arm->finger_y0[k] + e.q[7 + k];
+        p = madd(p, yax, off);
       }
-    RV_LANES_END
-  }
-
-  RV_STOPL(1)
-  // collider geometry
+      st3(e.fpos[lane], p);
+    }
+  RV_LANES_END
+}
+// collider boxes in the world, their AABBs and the arm-table gate
+RV_DEV void arm_collider_phases(Shared& S, const Consts& K, const int arm_on) {
+  const rv_config* c = K.cfg;
+  const rv_arm* arm = K.arm;
   RV_LANES_BEGIN
     if (lane < RV_MAXB) S.s.wake[lane] = 0;
     if (arm_on) {
@@ -815,21 +833,127 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
       }
     }
   RV_LANES_END
-  RV_STOPL(15)
-
-  // world AABB of every collider box
+  // world AABB of every collider box; can the box be within the contact-query
+  // distance of the table?  (the two rejection tests of the arm-table detector)
   RV_LANES_BEGIN
     if (arm_on && lane < RV_NCOL) {
       int col = lane;
+      float lo3[3];
 #pragma unroll
       for (int x = 0; x < 3; ++x) {
         float lo = S.s.colv[col][0][x], hi = lo;
 #pragma unroll
         for (int k = 1; k < 8; ++k) { float v = S.s.colv[col][k][x]; lo = fminr(lo, v); hi = fmaxr(hi, v); }
         S.s.colmin[col][x] = lo; S.s.colmax[col][x] = hi;
+        lo3[x] = lo;
+      }
+      v3 tc = mk(c->table_center[0], c->table_center[1], S.e.table_z - 0.5f * c->table_thickness);
+      v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
+      float r = S.s.colr[col] + c->breaking;
+      S.s.atflag[col] = (!(lo3[2] - S.e.table_z - c->margin >= c->contact_query_dist) &&
+                         sphere_box_dist2(ld3(S.s.colc[col]), tc, th) < r * r) ? 1 : 0;
+    }
+    if (lane == 63) S.s.kin_fresh = arm_on;
+  RV_LANES_END
+}
+
+#ifdef RV_EMU_COUNT
+static long rv_emu_coasted = 0;
+#endif
+// ---- coasting: substeps that provably cannot touch anything -------------------
+// While every body sleeps and every collider box is farther from the table and
+// from the bodies than the arm can travel in m substeps, those m substeps reduce
+// to control + joint motors; FK / colliders are refreshed once at the end.  The
+// bound is rigorous (joint travel from |qd|, v_max and a_max; vertex travel <=
+// sum of joint travel x reach), so the result is bit-identical to stepping.
+// Returns m (0: step normally).  Needs fresh kinematics (S.s.kin_fresh).
+RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining) {
+  const rv_config* c = K.cfg;
+  const rv_arm* arm = K.arm;
+  if (K.stop_after != 0 || !S.e.arm_enabled || !S.s.kin_fresh || remaining < 2) return 0;
+  {
+    int any_on = 0;
+#pragma unroll
+    for (int b = 0; b < RV_MAXB; ++b) any_on |= body_on(S.e, b);
+    if (any_on) return 0;
+  }
+  const int m0 = remaining < 16 ? remaining : 16;
+  RV_LANES_BEGIN
+    if (lane < 3) S.s.coast_unsafe[lane] = 0;
+  RV_LANES_END
+  RV_LANES_BEGIN
+    if (lane < RV_NCOL) {
+      const DevEnv& e = S.e;
+      const int col = lane, f = arm->col_frame[col];
+      const int fl = f < 7 ? f : 7;                 // last limb frame the box depends on
+      const float dt = c->dt;
+      v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
+      v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
+      // clearances now
+      const float zc = S.s.colmin[col][2] - e.table_z - c->margin - c->contact_query_dist;
+      const float sc = fsqrtr(sphere_box_dist2(ld3(S.s.colc[col]), tc, th)) - (S.s.colr[col] + c->breaking);
+      float tclear = zc > sc ? zc : sc;             // either test rejecting is enough
+      float bclear = 1e30f;
+      for (int b = 0; b < RV_MAXB; ++b) {
+        if (!body_present(e, b)) continue;
+        float d = fsqrtr(sphere_aabb_dist2(ld3(e.body[b]), S.s.colmin[col], S.s.colmax[col])) - (e.radius[b] + c->breaking);
+        bclear = fminr(bclear, d);
+      }
+      for (int k = 0; k < 3; ++k) {
+        const int m = m0 >> k;
+        if (m < 2) { S.s.coast_unsafe[k] = 1; continue; }
+        const float mf = (float)m;
+        // vertex travel bound over m substeps
+        float delta = 0.0f, reach = S.s.colext[col];
+        for (int j = fl; j >= 0; --j) {
+          if (j < RV_NLIMB) {
+            float q0 = fabsr(e.qd[j]);
+            float vcap = fmaxr(q0, e.vmax_cmd[j]);
+            float vacc = q0 + mf * arm->a_max[j] * dt;
+            delta += reach * (mf * dt * fminr(vcap, vacc));
+          }
+          reach += S.s.jlen[j];
+        }
+        if (f >= 8) {
+          int j = f - 1;                            // finger joint 7 / 8 slides the box
+          float q0 = fabsr(e.qd[j]);
+          delta += mf * dt * fminr(fmaxr(q0, e.vmax_cmd[j]), q0 + mf * arm->a_max[j] * dt);
+        }
+        delta = delta * 1.02f + 1e-4f;
+        if (!(tclear > delta) || !(bclear > 2.0f * delta)) S.s.coast_unsafe[k] = 1;
       }
     }
   RV_LANES_END
+  for (int k = 0; k < 3; ++k) if (!S.s.coast_unsafe[k]) return m0 >> k;
+  return 0;
+}
+// m coasting substeps, then the kinematics of the final joint state
+RV_DEV void coast_substeps(Shared& S, const Consts& K, const int m) {
+#ifdef RV_EMU_COUNT
+  rv_emu_coasted += m;
+#endif
+  for (int i = 0; i < m; ++i) arm_motor_phases(S, K, 0, 1);
+  arm_lq_phase(S, K);
+  arm_fk_phases(S, K);
+  arm_collider_phases(S, K, 1);
+  RV_LANES_BEGIN
+    DevEnv& e = S.e;
+    if (lane == 0) e.flag_arm_table = 0;
+    if (lane >= 1 && lane <= RV_MAXB) e.flag_arm_body[lane - 1] = 0;
+  RV_LANES_END
+}
+
+RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
+  const rv_config* c = K.cfg;
+  const int arm_on = S.e.arm_enabled;
+
+  if (arm_on) {
+    arm_motor_phases(S, K, 1, 0);
+    RV_STOPL(12)
+    arm_fk_phases(S, K);
+  }
+  RV_STOPL(1)
+  arm_collider_phases(S, K, arm_on);
   RV_STOPL(16)
 
   // wake test: a sleeping body is woken by a MOVING awake body or, while the arm
@@ -888,8 +1012,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   for (int b = 0; b < RV_MAXB; ++b) any_on |= body_on(S.e, b);
   if (arm_on) {
 #pragma unroll
-    for (int col = 0; col < RV_NCOL; ++col)
-      if (!(S.s.colmin[col][2] - S.e.table_z - c->margin >= c->contact_query_dist)) at_possible = 1;
+    for (int col = 0; col < RV_NCOL; ++col) at_possible |= S.s.atflag[col];
   }
   // quiet substep: every body asleep (or absent) and no arm collider near the
   // table -> nothing to collide, solve or integrate
@@ -1288,8 +1411,54 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_f
     RV_LANES_END
   }
   int taken = 0;
+  int coast_wait = 0;     // regular substeps to take before coasting is considered again
   for (;;) {
     RV_PROF(7)
+    if (n_fixed > 0 && coast_wait == 0) {
+      const int m = coast_budget(S, K, n_fixed - taken);
+      if (m >= 2) {
+        coast_substeps(S, K, m);
+        RV_PROF(0)
+        taken += m;
+        if (taken >= n_fixed) break;
+        continue;
+      }
+      coast_wait = 8;     // awake bodies / close to something: step normally for a while
+    }
+    if (n_fixed == 0 && coast_wait == 0) {
+      // wait_until_stable with every body asleep: the stability verdict cannot change
+      // while coasting, so the loop's counters can be advanced m substeps at once
+      const unsigned mk_ = mask ? mask : active_mask(S.e);
+      const int st_ok = bodies_stable(S.e, mk_, lin_thr, ang_thr);
+      int T = 0;
+      {
+        int st = S.s.wus_steps, sb = S.s.wus_stable, fin = 0;
+        while (T < 16 && !fin) {
+          ++T; ++st;
+          if (st >= check_after) { if (st_ok) ++sb; if (sb >= min_stable || st >= max_steps) fin = 1; }
+        }
+      }
+      const int m = coast_budget(S, K, T);
+      if (m >= 2) {
+        coast_substeps(S, K, m);
+        RV_LANES_BEGIN
+          if (lane == 0) {
+            for (int i = 0; i < m; ++i) {
+              S.s.wus_steps++;
+              if (S.s.wus_steps >= check_after) {
+                if (st_ok) S.s.wus_stable++;
+                if (S.s.wus_stable >= min_stable || S.s.wus_steps >= max_steps) S.s.loop_break = 1;
+              }
+            }
+          }
+        RV_LANES_END
+        RV_PROF(0)
+        if (S.s.loop_break) break;
+        continue;
+      }
+      coast_wait = 8;
+    }
+    if (coast_wait > 0) --coast_wait;
     if (sim_substep_light(S, K)) {
       RV_PROF(1)
       sim_substep_heavy_call(scene, stop_after);
@@ -1721,8 +1890,15 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
 // rebuild the per-launch caches that are not part of the persistent block
 RV_DEV void env_enter(Shared& S, const Consts& K) {
   RV_LANES_BEGIN
-    if (lane == 63) S.s.jt_applied = 0;
+    if (lane == 63) { S.s.jt_applied = 0; S.s.kin_fresh = 0; }
     if (lane < 8) table_prepare(S, K, lane);
+    if (lane >= 48 && lane < 48 + RV_NLIMB + 1) { int i = lane - 48; S.s.jlen[i] = len(ld3(K.arm->jpos[i])); }
+    if (lane >= 20 && lane < 20 + RV_NCOL) {
+      const rv_arm* a = K.arm; int col = lane - 20; int f = a->col_frame[col];
+      float ext = len(ld3(a->col_center[col])) + len(ld3(a->col_half[col]));
+      if (f >= 8) ext += fabsr(a->finger_y0[f - 8]) + fmaxr(fabsr(a->q_lo[f - 1]), fabsr(a->q_hi[f - 1]));
+      S.s.colext[col] = ext;
+    }
     if (lane >= 8 && lane < 8 + RV_NFRAME) {
       int f = lane - 8;
       stm(S.s.frot[f], qmat(ldq(S.e.fquat[f])));

@@ -5,7 +5,7 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; shift; mkdir -p $(dirname $OUT)
 ARGS=${@:-"1024 200 link"}
 : > $OUT.txt
-for st in 10 11 12 13 14 1 15 16 17 18 2 0; do
+for st in 12 1 16 17 18 2 0; do
   echo "== stop $st" >> $OUT.txt
   RV_DEBUG_STOP=$st timeout 300 python $R/tools/prof_sub.py $ARGS 2>&1 | grep "^sub" >> $OUT.txt
 done
