@@ -54,11 +54,13 @@ def cpu_baseline(cfg_kwargs, scene, names, seconds_hint=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--envs-per-gpu', type=int, default=1024)
     ap.add_argument('--seed', type=int, default=1234)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-async', action='store_true',
+                    help='skip the extra (untimed-for-`value`) asynchronous rollout reported under "async_rollout"')
     ap.add_argument('--mode', choices=['rollout', 'lockstep'], default='rollout',
                     help="rollout: the K timed env.step()s of every env run in ONE rv_rollout launch "
                          "(on-device RandomPolicy, auto-reset); lockstep: K x (policy -> rv_step_macro)")
@@ -154,6 +156,28 @@ def main():
     elapsed = float(t.item())
     substeps_all, env_steps_all = float(tot[0].item()), float(tot[1].item())
 
+    # extra leg, NOT part of `value`: the same number of env.step() calls (K per env on
+    # average) run asynchronously -- every env steps at its own pace while a shared pool
+    # lasts, as the reference's independent worker processes do (tools/parallel_run.py)
+    async_out = None
+    if args.mode == 'rollout' and not args.no_async:
+        barrier()
+        ta = time.perf_counter()
+        taken = world.rollout_async(args.steps * n, first_macro_index=args.warmup + args.steps)
+        barrier()
+        ea = time.perf_counter() - ta
+        sa = world.stats()
+        tt = torch.tensor([ea], dtype=torch.float64, device=world.device)
+        ts = torch.tensor([float(sa['env_steps']), float(sa['substeps'])], dtype=torch.float64, device=world.device)
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(ts)
+        async_out = {'value': float(ts[0].item()) / float(tt.item()), 'unit': 'env_steps/s',
+                     'env_steps': int(ts[0].item()), 'sim_steps_per_s': float(ts[1].item()) / float(tt.item()),
+                     'steps_per_env_min_max': [int(taken.min().item()), int(taken.max().item())],
+                     'note': 'rv_rollout_async: K*N env.step() calls shared by the N envs of each GPU '
+                             '(work-conserving); not the headline because per-env step counts vary'}
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         # roofline of the dominant kernel (k_env<MACRO>), this rank
@@ -191,6 +215,8 @@ def main():
                          'note': 'state is LDS-resident for the whole launch; the kernel is VALU/latency-bound '
                                  '(see DESIGN.md §5), HBM traffic is ~2*sizeof(DevEnv) per env per launch'},
         }
+        if async_out is not None:
+            out['async_rollout'] = async_out
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg_kwargs, scene, names)
         print(json.dumps(out))

@@ -225,6 +225,15 @@ int  rv_step_macro(rv_world* w);
  *      step, otherwise it stops.  d_rewards / d_dones: optional [n_steps][N]. */
 int  rv_rollout(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t auto_reset,
                 float* d_rewards, uint8_t* d_dones);
+/* ---- the same loop run the way the reference runs it at scale: every env is an
+ *      independent worker (tools/parallel_run.py:54-90 starts one process per
+ *      env, none waits for another).  The N envs share a pool of
+ *      total_env_steps env.step() calls; each env takes its next step (auto-reset
+ *      when its episode ended) while the pool lasts.  The k-th step an env takes
+ *      uses macro index first_macro_index + k, so every env's trajectory is the
+ *      prefix of the rv_rollout trajectory of the same length.
+ *      d_steps_taken: optional [N], the number of steps each env took. ---- */
+int  rv_rollout_async(rv_world* w, int32_t total_env_steps, int32_t first_macro_index, int32_t* d_steps_taken);
 
 /* ---- RandomPolicy._action (random_policy.py:14-23): U(-1,1)^(G*4) from
  *      Philox keyed by (seed, global env id, macro_index). ---- */

@@ -45,7 +45,8 @@ def _lib(double):
                      'orc_get_manifold_counts', 'orc_observe', 'orc_reward',
                      'orc_get_episode_returns', 'orc_get_stats', 'orc_eval_reward',
                      'orc_eval_waypoints', 'orc_set_external_control', 'orc_motor_targets',
-                     'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout', 'orc_set_pose_f32'):
+                     'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout', 'orc_set_pose_f32',
+                     'orc_rollout_counts'):
             getattr(lib, name).restype = None
         lib.orc_is_limb_ready.restype = C.c_int
         lib.orc_is_gripper_ready.restype = C.c_int
@@ -93,6 +94,11 @@ class OracleWorld(object):
 
     def rollout(self, n_steps, first_macro_index=0, auto_reset=True):
         self.lib.orc_rollout(self.h, C.c_int(n_steps), C.c_int(first_macro_index), C.c_int(int(bool(auto_reset))))
+
+    def rollout_counts(self, counts, first_macro_index=0):
+        c = np.ascontiguousarray(counts, dtype=np.int32)
+        assert c.shape == (self.n,)
+        self.lib.orc_rollout_counts(self.h, _p(c), C.c_int(first_macro_index))
 
     def step_sub(self, n):
         self.lib.orc_step_sub(self.h, C.c_int(n))

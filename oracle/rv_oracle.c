@@ -1428,7 +1428,11 @@ void orc_step_macro(orc_world* w) {
   }
 }
 /* generate_episode's inner loop with RandomPolicy (see rv_rollout in rovat.h) */
-void orc_rollout(orc_world* w, int n_steps, int first_index, int auto_reset) {
+static void rollout_impl(orc_world* w, int n_steps, const int32_t* counts, int first_index, int auto_reset);
+void orc_rollout(orc_world* w, int n_steps, int first_index, int auto_reset) { rollout_impl(w, n_steps, NULL, first_index, auto_reset); }
+/* checker for rv_rollout_async: env i takes counts[i] steps (auto-reset) */
+void orc_rollout_counts(orc_world* w, const int32_t* counts, int first_index) { rollout_impl(w, 0, counts, first_index, 1); }
+static void rollout_impl(orc_world* w, int n_steps_all, const int32_t* counts, int first_index, int auto_reset) {
   stats_begin(w);
   int G = w->cfg.num_goal_steps > 0 ? w->cfg.num_goal_steps : 1;
   int* stepped = (int*)calloc((size_t)w->n, sizeof(int));
@@ -1439,6 +1443,7 @@ void orc_rollout(orc_world* w, int n_steps, int first_index, int auto_reset) {
     int gid = w->cfg.env_id_offset + i;
     int sub = 0, aw = 0, pr = 0;
     e->substeps_last = 0; e->awake_last = 0; e->pairs_last = 0;
+    const int n_steps = counts ? counts[i] : n_steps_all;
     for (int k = 0; k < n_steps; ++k) {
       if (e->done) {
         if (!auto_reset) break;

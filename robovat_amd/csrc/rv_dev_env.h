@@ -1859,13 +1859,31 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
 // generate_episode's inner loop with the on-device RandomPolicy
 // (episode_generation.py:44-46, random_policy.py:14-23): n_steps env.step()
 // calls back to back for this env; see rv_rollout() in include/rovat.h.
+// budget != nullptr: asynchronous rollout.  The envs of the launch share a pool of
+// env.step() calls; each env takes its next step while the pool lasts, so fast
+// envs take more steps than slow ones and no SIMD idles (the reference's worker
+// processes are just as independent, tools/parallel_run.py:54-90).  The k-th step
+// an env takes in the launch uses macro index first_index + k as before.
 RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int first_index, int auto_reset,
-                        float* rewards, uint8_t* dones, int env, int n_envs) {
+                        float* rewards, uint8_t* dones, int env, int n_envs, int* budget = nullptr) {
   const rv_config* c = K.cfg;
   RV_LANES_BEGIN
     if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; }
   RV_LANES_END
-  for (int k = 0; k < n_steps; ++k) {
+  for (int k = 0; budget != nullptr || k < n_steps; ++k) {
+    if (budget != nullptr) {
+      RV_LANES_BEGIN
+        if (lane == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          int left = atomicSub(budget, 1);
+#else
+          int left = (*budget)--;
+#endif
+          S.s.loop_break = !(left > 0);
+        }
+      RV_LANES_END
+      if (S.s.loop_break) break;
+    }
     if (S.e.done) {
       if (!auto_reset) break;
       env_reset(S, K, gid, 0);

@@ -33,6 +33,8 @@ struct EnvKernelArgs {
   int stop_after;   // profiling hook (env RV_DEBUG_STOP, MODE_SUB only)
   int first_index, auto_reset;   // MODE_ROLLOUT
   float* rewards; uint8_t* dones;
+  int* budget;                   // MODE_ROLLOUT, asynchronous: shared pool of env.step() calls
+  int32_t* steps_taken;          // optional [N]
 };
 
 template <int MODE>
@@ -75,7 +77,8 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
     __syncthreads();
     env_step(S, K);
   } else if (MODE == MODE_ROLLOUT) {
-    env_rollout(S, K, K.cfg->env_id_offset + env, args.n_substeps, args.first_index, args.auto_reset, args.rewards, args.dones, env, args.n_envs);
+    env_rollout(S, K, K.cfg->env_id_offset + env, args.n_substeps, args.first_index, args.auto_reset, args.rewards, args.dones, env, args.n_envs, args.budget);
+    if (lane == 0 && args.steps_taken) args.steps_taken[env] = S.e.stepped;
   } else if (MODE == MODE_SUB) {
     if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; }
     __syncthreads();
@@ -363,6 +366,7 @@ struct rv_world {
   rv_scene* d_scene;
   DevEnv* d_envs;
   rv_macro_stats* d_stats;
+  int* d_budget;
   hipEvent_t ev0, ev1;
   bool timed;
 };
@@ -377,8 +381,10 @@ static inline dim3 grid1(int n) { return dim3((unsigned)((n + 127) / 128)); }
 
 template <int MODE>
 static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, float ang, int ca, int ms, int mx,
-                      int first_index = 0, int auto_reset = 0, float* rewards = nullptr, uint8_t* dones = nullptr) {
+                      int first_index = 0, int auto_reset = 0, float* rewards = nullptr, uint8_t* dones = nullptr,
+                      int* budget = nullptr, int32_t* steps_taken = nullptr) {
   EnvKernelArgs a;
+  a.budget = budget; a.steps_taken = steps_taken;
   a.first_index = first_index; a.auto_reset = auto_reset; a.rewards = rewards; a.dones = dones;
   a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.mask = mask; a.n_envs = w->n;
   { const char* ds = getenv("RV_DEBUG_STOP"); a.stop_after = ds ? atoi(ds) : 0; }
@@ -417,6 +423,7 @@ int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world*
   HIPCHK(hipMalloc(&w->d_scene, sizeof(rv_scene)));
   HIPCHK(hipMalloc(&w->d_envs, sizeof(DevEnv) * (size_t)w->n));
   HIPCHK(hipMalloc(&w->d_stats, sizeof(rv_macro_stats)));
+  HIPCHK(hipMalloc(&w->d_budget, sizeof(int)));
   HIPCHK(hipMemcpy(w->d_cfg, cfg, sizeof(rv_config), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(w->d_scene, scene, sizeof(rv_scene), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(w->d_stats, 0, sizeof(rv_macro_stats)));
@@ -433,7 +440,7 @@ int rv_destroy(rv_world* w) {
   if (!w) return RV_OK;
   hipSetDevice(w->device);
   hipStreamSynchronize(w->stream);
-  hipFree(w->d_cfg); hipFree(w->d_scene); hipFree(w->d_envs); hipFree(w->d_stats);
+  hipFree(w->d_cfg); hipFree(w->d_scene); hipFree(w->d_envs); hipFree(w->d_stats); hipFree(w->d_budget);
   hipEventDestroy(w->ev0); hipEventDestroy(w->ev1);
   delete w;
   return RV_OK;
@@ -449,6 +456,12 @@ int rv_rollout(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t 
   WCHK(w);
   if (n_steps <= 0) return fail(RV_ERR_VALUE, "rv_rollout: n_steps must be positive");
   return launch_env<MODE_ROLLOUT>(w, nullptr, n_steps, 0, 0, 0, 0, 0, first_macro_index, auto_reset, d_rewards, d_dones);
+}
+int rv_rollout_async(rv_world* w, int32_t total_env_steps, int32_t first_macro_index, int32_t* d_steps_taken) {
+  WCHK(w);
+  if (total_env_steps <= 0) return fail(RV_ERR_VALUE, "rv_rollout_async: total_env_steps must be positive");
+  HIPCHK(hipMemcpyAsync(w->d_budget, &total_env_steps, sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+  return launch_env<MODE_ROLLOUT>(w, nullptr, 0, 0, 0, 0, 0, 0, first_macro_index, 1, nullptr, nullptr, w->d_budget, d_steps_taken);
 }
 int rv_step_sub(rv_world* w, int32_t n) {
   WCHK(w);

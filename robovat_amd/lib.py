@@ -23,7 +23,7 @@ HIPCC_FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off'
 SYMBOLS = [
     'rv_create', 'rv_destroy', 'rv_last_error', 'rv_set_stream', 'rv_synchronize',
     'rv_num_envs', 'rv_reset', 'rv_set_actions', 'rv_step_macro', 'rv_policy_random',
-    'rv_policy_heuristic', 'rv_rollout', 'rv_step_sub', 'rv_wait_until_stable', 'rv_get_body_state',
+    'rv_policy_heuristic', 'rv_rollout', 'rv_rollout_async', 'rv_step_sub', 'rv_wait_until_stable', 'rv_get_body_state',
     'rv_set_body_state', 'rv_get_body_params', 'rv_set_body_params',
     'rv_get_joint_state', 'rv_set_joint_state', 'rv_get_link_poses',
     'rv_get_env_counters', 'rv_set_joint_targets', 'rv_set_link_target',
@@ -79,6 +79,7 @@ def load():
     lib.rv_step_macro.argtypes = [vp]
     lib.rv_step_sub.argtypes = [vp, i32]
     lib.rv_rollout.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.rv_rollout_async.argtypes = [vp, i32, i32, vp]
     lib.rv_wait_until_stable.argtypes = [vp, f32, f32, i32, i32, i32]
     lib.rv_policy_random.argtypes = [vp, i32, vp]
     lib.rv_policy_heuristic.argtypes = [vp, i32, vp]
@@ -176,6 +177,13 @@ class World(object):
         check(self.lib.rv_rollout(self.h, int(n_steps), int(first_macro_index), int(bool(auto_reset)),
                                   self._ptr(r) if record else None, self._ptr(d) if record else None))
         return r, d
+
+    def rollout_async(self, total_env_steps, first_macro_index=0):
+        """total_env_steps x (RandomPolicy action -> env.step) shared by all envs: every env
+        keeps stepping (auto-reset) while the pool lasts.  Returns steps taken per env."""
+        taken = self._new((self.n,), self.torch.int32)
+        check(self.lib.rv_rollout_async(self.h, int(total_env_steps), int(first_macro_index), self._ptr(taken)))
+        return taken
 
     def step_sub(self, n):
         check(self.lib.rv_step_sub(self.h, int(n)))

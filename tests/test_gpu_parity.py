@@ -149,3 +149,19 @@ def test_rollout_matches_oracle_rollout():
     ws, rs = world.stats(), ref.stats()
     assert ws['env_steps'] == rs['env_steps'] == 36 and ws['substeps'] == rs['substeps']
     assert np.isfinite(r.cpu().numpy()).all() and d.cpu().numpy().shape == (3, 12)
+
+
+def test_async_rollout_is_a_prefix_of_the_lockstep_trajectories():
+    """rv_rollout_async: the envs share a pool of env.step() calls.  How many steps
+    each env gets depends on timing, but WHAT it computes does not: the oracle run
+    with the same per-env step counts must give bit-identical states."""
+    world, ref, cfg = _worlds(96, seed=77, MAX_STEPS=3)
+    world.reset(); ref.reset()
+    total = 96 * 4
+    taken = world.rollout_async(total, first_macro_index=2).cpu().numpy()
+    # every env that asked while the pool lasted got its step: exactly `total` steps overall
+    assert taken.sum() == total and taken.min() >= 1
+    ref.rollout_counts(taken, 2)
+    _cmp(world, ref, 1e-6)
+    ws, rs = world.stats(), ref.stats()
+    assert ws['env_steps'] == rs['env_steps'] == total and ws['substeps'] == rs['substeps']
