@@ -120,6 +120,11 @@ typedef struct rv_config {
    * sleep until something comes near it (0 steps = never sleep) */
   float    sleep_lin, sleep_ang;
   int32_t  sleep_steps;
+  /* a body that only oscillates in place (rocking on an edge) is at rest too: it
+   * also goes to sleep when its pose stayed within sleep_pos_win metres and
+   * sleep_rot_win (largest quaternion component change) of where it was when the
+   * window opened, for sleep_steps substeps (0 = velocity test only) */
+  float    sleep_pos_win, sleep_rot_win;
   /* narrow-phase gating: a pair's full GJK/feature pass is re-run only after
    * its bodies moved np_gate metres (linear + angular*radius) since the last
    * pass, when a cached point was lost, or every np_max_age-th substep; cached

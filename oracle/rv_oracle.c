@@ -41,6 +41,8 @@ typedef struct { real p[3], q[4], v[3], w[3]; } orc_body;
 typedef struct {
   int active, frozen, shape;
   int asleep, sleep_count;
+  int still_count; real still_ref[7];   /* pose window of the in-place oscillation test */
+  real aabb[6];                         /* world box (lo, hi) of the hulls + margin, taken when the body fell asleep */
   real scale, mass, inv_mass, inv_inertia[3], friction, radius;
 } orc_bparam;
 
@@ -76,6 +78,7 @@ typedef struct {
   real gripper_ready_time;
   real fpos[RV_NFRAME][3], fquat[RV_NFRAME][4], frot[RV_NFRAME][9];
   real fv[RV_NFRAME][3], fw[RV_NFRAME][3];
+  real arm_mot;                  /* largest travel of an arm collider vertex in this substep */
   real axis[RV_NLIMB][3];
   real colv[RV_NCOL][8][3], colc[RV_NCOL][3], colr[RV_NCOL];
   real colmin[RV_NCOL][3], colmax[RV_NCOL][3];   /* world AABB of each collider box */
@@ -157,21 +160,6 @@ static void arm_fk_limb(const rv_arm* a, const real* q, real fpos[][3], real fqu
 static void arm_update_kinematics(const orc_world* w, orc_env* e) {
   const rv_arm* a = &w->scene.arm;
   arm_fk_limb(a, e->q, e->fpos, e->fquat, e->frot, e->axis);
-  /* twists (base is static) */
-  real wprev[3] = {R(0.0), R(0.0), R(0.0)}, vprev[3] = {R(0.0), R(0.0), R(0.0)};
-  real pprev[3] = {(real)a->base_pos[0], (real)a->base_pos[1], (real)a->base_pos[2]};
-  for (int i = 0; i < RV_NLIMB; ++i) {
-    real d[3], c[3];
-    v3sub(d, e->fpos[i], pprev); v3cross(c, wprev, d);
-    v3add(e->fv[i], vprev, c);
-    v3madd(e->fw[i], wprev, e->axis[i], e->qd[i]);
-    v3cpy(wprev, e->fw[i]); v3cpy(vprev, e->fv[i]); v3cpy(pprev, e->fpos[i]);
-  }
-  {
-    real d[3], c[3];
-    v3sub(d, e->fpos[7], pprev); v3cross(c, wprev, d);
-    v3add(e->fv[7], vprev, c); v3cpy(e->fw[7], wprev);
-  }
   real yax[3] = {e->frot[7][1], e->frot[7][4], e->frot[7][7]};
   for (int k = 0; k < 2; ++k) {
     int f = 8 + k;
@@ -179,11 +167,32 @@ static void arm_update_kinematics(const orc_world* w, orc_env* e) {
     v3madd(e->fpos[f], e->fpos[7], yax, off);
     memcpy(e->fquat[f], e->fquat[7], sizeof(real) * 4);
     memcpy(e->frot[f], e->frot[7], sizeof(real) * 9);
-    real d[3], c[3];
-    v3sub(d, e->fpos[f], e->fpos[7]); v3cross(c, e->fw[7], d);
-    v3add(e->fv[f], e->fv[7], c);
-    v3madd(e->fv[f], e->fv[f], yax, e->qd[7 + k]);
-    v3cpy(e->fw[f], e->fw[7]);
+  }
+  /* twists (base is static), frame by frame: w_f = sum_k axis_k qd_k,
+   * v_f = sum_k (axis_k qd_k) x (p_f - p_k) over the joints k upstream of f;
+   * the fingers add their slide along the hand's y axis */
+  e->arm_mot = R(0.0);
+  for (int f = 0; f < RV_NFRAME; ++f) {
+    int kmax = f < RV_NLIMB ? f : RV_NLIMB - 1;
+    real fw[3] = {R(0.0), R(0.0), R(0.0)}, fv[3] = {R(0.0), R(0.0), R(0.0)};
+    for (int k = 0; k <= kmax; ++k) {
+      real u[3], d[3], c[3];
+      v3scale(u, e->axis[k], e->qd[k]);
+      v3add(fw, fw, u);
+      v3sub(d, e->fpos[f], e->fpos[k]); v3cross(c, u, d);
+      v3add(fv, fv, c);
+    }
+    if (f >= 8) v3madd(fv, fv, yax, e->qd[f - 1]);
+    v3cpy(e->fv[f], fv); v3cpy(e->fw[f], fw);
+    /* how far can a collider vertex riding on this frame travel in one substep */
+    real ext = R(0.0);
+    for (int c = 0; c < RV_NCOL; ++c) {
+      if (a->col_frame[c] != f) continue;
+      real cc[3] = {(real)a->col_center[c][0], (real)a->col_center[c][1], (real)a->col_center[c][2]};
+      real hh[3] = {(real)a->col_half[c][0], (real)a->col_half[c][1], (real)a->col_half[c][2]};
+      ext = rmax(ext, v3len(cc) + v3len(hh));
+    }
+    e->arm_mot = rmax(e->arm_mot, (v3len(fv) + v3len(fw) * ext) * (real)w->cfg.dt);
   }
   for (int c = 0; c < RV_NCOL; ++c) {
     int f = a->col_frame[c];
@@ -646,6 +655,17 @@ static real sphere_aabb_dist2(const real* p, const real* lo, const real* hi) {
   }
   return d2;
 }
+/* squared distance between two axis-aligned boxes */
+static real aabb_aabb_dist2(const real* lo_a, const real* hi_a, const real* lo_b, const real* hi_b) {
+  real d2 = R(0.0);
+  for (int k = 0; k < 3; ++k) {
+    real d = R(0.0);
+    if (hi_a[k] < lo_b[k]) d = lo_b[k] - hi_a[k];
+    if (hi_b[k] < lo_a[k]) d = lo_a[k] - hi_b[k];
+    d2 += d * d;
+  }
+  return d2;
+}
 static real sphere_box_dist2(const real* p, const real* c, const real* h) {
   real d2 = R(0.0);
   for (int k = 0; k < 3; ++k) {
@@ -672,7 +692,14 @@ static void collide_all(const orc_world* w, orc_env* e) {
       m->acc += e->mot[b];
       run[TIDX(b)] = (c->np_max_age <= 0) || m->n == 0 || lost > 0 || m->acc > (real)c->np_gate || (e->sim_steps % c->np_max_age) == 0;
     }
-    if (e->arm_enabled) manifold_refresh(w, e, 2, b, -1, &e->man[AIDX(b)]); else e->man[AIDX(b)].n = 0;
+    if (e->arm_enabled) {
+      /* arm - body pairs are gated the same way, on the body's plus the arm's travel */
+      orc_manifold* m = &e->man[AIDX(b)];
+      int lost = manifold_refresh(w, e, 2, b, -1, m);
+      m->acc += e->mot[b] + e->arm_mot;
+      run[AIDX(b)] = (c->np_max_age <= 0) || m->n == 0 || lost > 0 || m->acc > (real)c->np_gate || (e->sim_steps % c->np_max_age) == 0;
+      if (run[AIDX(b)]) m->acc = R(0.0);
+    } else e->man[AIDX(b)].n = 0;
   }
   for (int k = 0; k < RV_NBB; ++k) {
     int a = BB_A[k], b = BB_B[k];
@@ -722,7 +749,7 @@ static void collide_all(const orc_world* w, orc_env* e) {
   if (e->arm_enabled) {
     for (int col = 0; col < RV_NCOL; ++col) {
       for (int b = 0; b < RV_MAXB; ++b) {
-        if (!body_on(e, b)) continue;
+        if (!body_on(e, b) || !run[AIDX(b)]) continue;
         real d[3]; v3sub(d, e->body[b].p, e->colc[col]);
         real r = e->bp[b].radius + brk;
         if (sphere_aabb_dist2(e->body[b].p, e->colmin[col], e->colmax[col]) >= r * r) continue;
@@ -944,13 +971,39 @@ static void sim_substep(const orc_world* w, orc_env* e) {
         real r = e->bp[a].radius + e->bp[b].radius + (real)c->breaking;
         if (v3dot(d, d) < r * r) wake[b] = 1;
       }
-      if (e->arm_enabled && e->arm_moving)
+      if (e->arm_enabled && e->arm_moving) {
+        /* the arm wakes a sleeper when one of its boxes comes within the contact-
+         * breaking distance of the body's hulls (= when a contact point would be
+         * created); boxes whose AABB is farther than that from the body's are skipped */
+        int nearf[RV_NCOL], near = 0;
         for (int col = 0; col < RV_NCOL; ++col) {
-          real r = e->bp[b].radius + (real)c->breaking;
-          if (sphere_aabb_dist2(e->body[b].p, e->colmin[col], e->colmax[col]) < r * r) wake[b] = 1;
+          real r = (real)c->breaking;
+          nearf[col] = aabb_aabb_dist2(e->bp[b].aabb, e->bp[b].aabb + 3, e->colmin[col], e->colmax[col]) < r * r;
+          near |= nearf[col];
         }
+        if (near) {
+          const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
+          real m[9]; qmat(m, e->body[b].q);
+          real wv[RV_MAXH][RV_MAXV][3];
+          for (int h = 0; h < s->n_hulls; ++h)
+            for (int i = 0; i < s->n_verts[h]; ++i) {
+              real l[3] = {(real)s->verts[h][i][0] * e->bp[b].scale, (real)s->verts[h][i][1] * e->bp[b].scale, (real)s->verts[h][i][2] * e->bp[b].scale};
+              real t[3]; m3mulv(t, m, l); v3add(wv[h][i], e->body[b].p, t);
+            }
+          real mg = (real)c->margin, brk = (real)c->breaking;
+          for (int col = 0; col < RV_NCOL && !wake[b]; ++col) {
+            if (!nearf[col]) continue;
+            real d[3]; v3sub(d, e->body[b].p, e->colc[col]);
+            for (int h = 0; h < s->n_hulls && !wake[b]; ++h) {
+              real n[3], dist, pa[3], pb[3];
+              if (orc_gjk_epa((const real(*)[3])wv[h], s->n_verts[h], (const real(*)[3])e->colv[col], 8, d, brk + R(2.0) * mg, n, &dist, pa, pb))
+                if (!(dist - R(2.0) * mg > brk)) wake[b] = 1;
+            }
+          }
+        }
+      }
     }
-    for (int b = 0; b < RV_MAXB; ++b) if (wake[b]) { e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; }
+    for (int b = 0; b < RV_MAXB; ++b) if (wake[b]) { e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].still_count = 0; }
   }
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!body_on(e, b)) continue;
@@ -1004,9 +1057,39 @@ static void sim_substep(const orc_world* w, orc_env* e) {
     if (c->sleep_steps > 0) {
       if (vv < (real)c->sleep_lin * (real)c->sleep_lin && ww < (real)c->sleep_ang * (real)c->sleep_ang) e->bp[b].sleep_count++;
       else e->bp[b].sleep_count = 0;
-      if (e->bp[b].sleep_count >= c->sleep_steps) {
+      /* in-place oscillation: the pose has not left a small window around where it
+       * was when the window opened */
+      if ((real)c->sleep_pos_win > R(0.0)) {
+        orc_bparam* P = &e->bp[b];
+        int inside = 0;
+        if (P->still_count > 0) {
+          real dp[3]; v3sub(dp, B->p, P->still_ref);
+          real dqm = R(0.0);
+          for (int k = 0; k < 4; ++k) dqm = rmax(dqm, rabs(B->q[k] - P->still_ref[3 + k]));
+          inside = v3dot(dp, dp) < (real)c->sleep_pos_win * (real)c->sleep_pos_win && dqm < (real)c->sleep_rot_win;
+        }
+        if (inside) P->still_count++;
+        else {
+          P->still_count = 1;
+          v3cpy(P->still_ref, B->p);
+          for (int k = 0; k < 4; ++k) P->still_ref[3 + k] = B->q[k];
+        }
+      }
+      if (e->bp[b].sleep_count >= c->sleep_steps || e->bp[b].still_count >= c->sleep_steps) {
         e->bp[b].asleep = 1;
         v3set(B->v, R(0.0), R(0.0), R(0.0)); v3set(B->w, R(0.0), R(0.0), R(0.0));
+        /* world box of the resting hulls: what the arm has to come near to wake the body */
+        const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
+        real m[9]; qmat(m, B->q);
+        real* bx = e->bp[b].aabb;
+        for (int k = 0; k < 3; ++k) { bx[k] = R(1e30); bx[3 + k] = R(-1e30); }
+        for (int h = 0; h < s->n_hulls; ++h)
+          for (int i = 0; i < s->n_verts[h]; ++i) {
+            real l[3] = {(real)s->verts[h][i][0] * e->bp[b].scale, (real)s->verts[h][i][1] * e->bp[b].scale, (real)s->verts[h][i][2] * e->bp[b].scale};
+            real t[3], p[3]; m3mulv(t, m, l); v3add(p, B->p, t);
+            for (int k = 0; k < 3; ++k) { bx[k] = rmin(bx[k], p[k]); bx[3 + k] = rmax(bx[3 + k], p[k]); }
+          }
+        for (int k = 0; k < 3; ++k) { bx[k] -= (real)c->margin; bx[3 + k] += (real)c->margin; }
       }
     }
   }
@@ -1327,7 +1410,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   e->n_bodies = nb;
   for (;;) {
     real poses[RV_MAXB][7];
-    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; }
+    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].still_count = 0; }
     for (int i = 0; i < RV_NMAN; ++i) e->man[i].n = 0;
     sample_poses(w, e, &g, nb, poses);
     for (int i = 0; i < nb; ++i) {
@@ -1336,7 +1419,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
                              : c->movable_shapes[rng_randint(&g, c->n_movable_shapes)];
       real scale = rng_uniform(&g, (real)c->scale_range[0], (real)c->scale_range[1]);
       orc_bparam* p = &e->bp[i];
-      p->active = 1; p->frozen = 0; p->asleep = 0; p->sleep_count = 0; p->shape = shape; p->scale = scale; p->friction = (real)c->drop_friction;
+      p->active = 1; p->frozen = 0; p->asleep = 0; p->sleep_count = 0; p->still_count = 0; p->shape = shape; p->scale = scale; p->friction = (real)c->drop_friction;
       body_set_mass(w, e, i, (real)c->drop_mass);
       v3cpy(e->body[i].p, poses[i]); memcpy(e->body[i].q, poses[i] + 3, sizeof(real) * 4);
       v3set(e->body[i].v, R(0.0), R(0.0), R(0.0)); v3set(e->body[i].w, R(0.0), R(0.0), R(0.0));
@@ -1555,7 +1638,7 @@ void orc_set_body_state(orc_world* w, const double* in) {
       for (int k = 0; k < 3; ++k) { B->p[k] = (real)o[k]; B->v[k] = (real)o[7 + k]; B->w[k] = (real)o[10 + k]; }
       for (int k = 0; k < 4; ++k) B->q[k] = (real)o[3 + k];
       w->env[i].man[TIDX(b)].n = 0; w->env[i].man[AIDX(b)].n = 0;
-      w->env[i].bp[b].asleep = 0; w->env[i].bp[b].sleep_count = 0;
+      w->env[i].bp[b].asleep = 0; w->env[i].bp[b].sleep_count = 0; w->env[i].bp[b].still_count = 0;
     }
   for (int i = 0; i < w->n; ++i) for (int k = 0; k < RV_NBB; ++k) w->env[i].man[BBIDX(k)].n = 0;
 }
@@ -1573,7 +1656,7 @@ void orc_set_body_params(orc_world* w, const double* in) {
     for (int b = 0; b < RV_MAXB; ++b) {
       const double* o = in + ((size_t)i * RV_MAXB + b) * 8;
       orc_bparam* p = &e->bp[b];
-      p->active = (int)o[0]; p->shape = (int)o[1]; p->scale = (real)o[2]; p->friction = (real)o[4]; p->frozen = (int)o[5]; p->asleep = 0; p->sleep_count = 0;
+      p->active = (int)o[0]; p->shape = (int)o[1]; p->scale = (real)o[2]; p->friction = (real)o[4]; p->frozen = (int)o[5]; p->asleep = 0; p->sleep_count = 0; p->still_count = 0;
       if (b == 0) { e->table_z = (real)o[6]; table_prepare(w, e); }
       if (p->active) body_set_mass(w, e, b, (real)o[3]);
     }

@@ -75,6 +75,7 @@ class rv_config(C.Structure):
         ('lin_damp', f32), ('ang_damp', f32),
         ('contact_query_dist', f32),
         ('solver_tol', f32), ('sleep_lin', f32), ('sleep_ang', f32), ('sleep_steps', i32),
+        ('sleep_pos_win', f32), ('sleep_rot_win', f32),
         ('np_gate', f32), ('np_max_age', i32),
         ('table_center', f32 * 2), ('table_half', f32 * 2),
         ('table_thickness', f32), ('table_z', f32),

@@ -99,6 +99,7 @@ PUSH_ENV_CONFIG = {
         'CONTACT_QUERY_DIST': 0.001, 'ARM_FRICTION': 0.8,
         'SOLVER_TOL': 1e-7,
         'SLEEP_LINEAR': 0.02, 'SLEEP_ANGULAR': 0.5, 'SLEEP_STEPS': 200,
+        'SLEEP_POSITION_WINDOW': 1e-3, 'SLEEP_ROTATION_WINDOW': 0.01,
         'NARROWPHASE_GATE': 5e-4, 'NARROWPHASE_MAX_AGE': 8,
     },
 }
@@ -167,6 +168,7 @@ def make_rv_config(env_cfg=None, robot_cfg=None, shape_names=None, n_envs=1,
     c.contact_query_dist = ph.CONTACT_QUERY_DIST
     c.solver_tol = ph.SOLVER_TOL
     c.sleep_lin, c.sleep_ang, c.sleep_steps = ph.SLEEP_LINEAR, ph.SLEEP_ANGULAR, int(ph.SLEEP_STEPS)
+    c.sleep_pos_win, c.sleep_rot_win = ph.SLEEP_POSITION_WINDOW, ph.SLEEP_ROTATION_WINDOW
     c.np_gate, c.np_max_age = ph.NARROWPHASE_GATE, int(ph.NARROWPHASE_MAX_AGE)
     tb = env_cfg.SIM.TABLE
     abi.assign(c.table_center, tb.POSE[0][:2])

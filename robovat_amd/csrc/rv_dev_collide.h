@@ -303,8 +303,11 @@ RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const S
 }
 
 // GJK distance with EPA fallback.  Returns 0 when farther apart than max_dist.
+// lb_out (optional): a rigorous lower bound of the distance between the two hulls
+// (the largest separating-plane bound seen), valid also when the query misses.
 RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, float max_dist,
-                   v3* n, float* dist, v3* pa, v3* pb) {
+                   v3* n, float* dist, v3* pa, v3* pb, float* lb_out = nullptr) {
+  float lb = 0.0f;
   Simplex s; s.n = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { s.w[i] = mk(0, 0, 0); s.a[i] = mk(0, 0, 0); s.b[i] = mk(0, 0, 0); s.lam[i] = 0.0f; }
@@ -316,6 +319,7 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
     v3 va = support_v(A, nA, scale(v, -1.0f), &pja), vb = support_v(B, nB, v, &pjb);
     v3 w = sub(va, vb);
     float vv = dot(v, v), vw = dot(v, w);
+    if (lb_out && vw > 0.0f) { float l = vw / fsqrtr(vv); if (l > lb) lb = l; *lb_out = lb; }
     if (vw > 0.0f && vw * vw > max_dist * max_dist * vv) return 0;
     int dup = 0;
 #pragma unroll

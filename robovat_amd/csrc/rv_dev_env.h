@@ -83,6 +83,8 @@ struct DevEnv {
   float body[RV_MAXB][RV_BODY_STRIDE];
   int active[RV_MAXB], frozen[RV_MAXB], shape[RV_MAXB];
   int asleep[RV_MAXB], sleep_count[RV_MAXB];
+  int still_count[RV_MAXB]; float still_ref[RV_MAXB][7];   // pose window of the in-place oscillation test
+  float baabb[RV_MAXB][6];   // world box (lo, hi) of the hulls + margin, taken when the body fell asleep
   float scale[RV_MAXB], mass[RV_MAXB], inv_mass[RV_MAXB], inv_inertia[RV_MAXB][3], friction[RV_MAXB], radius[RV_MAXB];
   float table_z;
   int n_bodies;
@@ -145,8 +147,11 @@ struct Scratch {
   int jt_applied;                        // the motor targets hold the current joint target (per launch)
   int atflag[RV_NCOL];                   // collider box may be within the contact-query distance of the table
   int kin_fresh;                         // FK / collider scratch matches the joint state (per launch)
+  int nearf[RV_MAXB][RV_NCOL], bnear[RV_MAXB], near_any;   // wake test stage 1 -> stage 2
+  float sep[RV_MAXB][RV_NCOL], coltravel[RV_NCOL];          // distance-bound culling of the wake queries
   int coast_unsafe[3];
   float jlen[RV_NLIMB + 1], colext[RV_NCOL];   // |jpos_i|; collider extent from its frame origin
+  float fext[RV_NFRAME], fmot[RV_NFRAME];     // per frame: largest collider extent; vertex travel this substep
   int any_on;
   int pairs[4];
   Rng rng;
@@ -592,6 +597,18 @@ RV_DEV float sphere_aabb_dist2(v3 p, const float* lo, const float* hi) {
   float dz = 0.0f; if (p.z < lo[2]) dz = lo[2] - p.z; if (p.z > hi[2]) dz = p.z - hi[2]; d2 += dz * dz;
   return d2;
 }
+// squared distance between two axis-aligned boxes
+RV_DEV float aabb_aabb_dist2(const float* lo_a, const float* hi_a, const float* lo_b, const float* hi_b) {
+  float d2 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float d = 0.0f;
+    if (hi_a[k] < lo_b[k]) d = lo_b[k] - hi_a[k];
+    if (hi_b[k] < lo_a[k]) d = lo_a[k] - hi_b[k];
+    d2 += d * d;
+  }
+  return d2;
+}
 RV_DEV float sphere_box_dist2(v3 p, v3 c, v3 h) {
   float d2 = 0.0f;
   float dx = fabsr(p.x - c.x) - h.x; if (dx > 0.0f) d2 += dx * dx;
@@ -815,7 +832,8 @@ RV_DEV void arm_collider_phases(Shared& S, const Consts& K, const int arm_on) {
   const rv_config* c = K.cfg;
   const rv_arm* arm = K.arm;
   RV_LANES_BEGIN
-    if (lane < RV_MAXB) S.s.wake[lane] = 0;
+    if (lane < RV_MAXB) { S.s.wake[lane] = 0; S.s.bnear[lane] = 0; }
+    if (lane == 8) S.s.near_any = 0;
     if (arm_on) {
       for (int item = lane; item < RV_NCOL * 8; item += 64) {
         int col = item >> 3, k = item & 7;
@@ -852,6 +870,17 @@ RV_DEV void arm_collider_phases(Shared& S, const Consts& K, const int arm_on) {
       float r = S.s.colr[col] + c->breaking;
       S.s.atflag[col] = (!(lo3[2] - S.e.table_z - c->margin >= c->contact_query_dist) &&
                          sphere_box_dist2(ld3(S.s.colc[col]), tc, th) < r * r) ? 1 : 0;
+      // how far a vertex of this box can have moved in this substep (joint travel x reach)
+      {
+        const DevEnv& e = S.e; const int f = arm->col_frame[col]; const int fl = f < 7 ? f : 7;
+        float tr = 0.0f, reach = S.s.colext[col];
+        for (int j = fl; j >= 0; --j) {
+          if (j < RV_NLIMB) tr += reach * (fabsr(e.qd[j]) * c->dt);
+          reach += S.s.jlen[j];
+        }
+        if (f >= 8) tr += fabsr(e.qd[f - 1]) * c->dt;
+        S.s.coltravel[col] = tr * 1.02f + 1e-7f;
+      }
     }
     if (lane == 63) S.s.kin_fresh = arm_on;
   RV_LANES_END
@@ -896,7 +925,7 @@ RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining) {
       float bclear = 1e30f;
       for (int b = 0; b < RV_MAXB; ++b) {
         if (!body_present(e, b)) continue;
-        float d = fsqrtr(sphere_aabb_dist2(ld3(e.body[b]), S.s.colmin[col], S.s.colmax[col])) - (e.radius[b] + c->breaking);
+        float d = fsqrtr(aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col])) - c->breaking;
         bclear = fminr(bclear, d);
       }
       for (int k = 0; k < 3; ++k) {
@@ -940,6 +969,7 @@ RV_DEV void coast_substeps(Shared& S, const Consts& K, const int m) {
     DevEnv& e = S.e;
     if (lane == 0) e.flag_arm_table = 0;
     if (lane >= 1 && lane <= RV_MAXB) e.flag_arm_body[lane - 1] = 0;
+    if (lane >= 8 && lane < 8 + RV_MAXB * RV_NCOL) { int t = lane - 8; S.s.sep[t / RV_NCOL][t % RV_NCOL] = 0.0f; }   // the arm moved unobserved
   RV_LANES_END
 }
 
@@ -956,18 +986,28 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   arm_collider_phases(S, K, arm_on);
   RV_STOPL(16)
 
-  // wake test: a sleeping body is woken by a MOVING awake body or, while the arm
-  // moves, by an arm collider box coming within the contact-breaking distance.
-  // One lane per (body, collider) and per ordered (body, neighbour) pair; a hit
-  // raises the body's flag (cleared two phases ago).
+  // wake test.  A sleeping body is woken by a MOVING awake body nearby, or by the
+  // moving arm when one of its boxes comes within the contact-breaking distance of
+  // the body's hulls (= when a contact point would be created).  Stage 1, one lane
+  // per (body, box) and per ordered (body, neighbour) pair: boxes whose AABB is
+  // within that distance of the sleeper's cached AABB are flagged for stage 2.
   RV_LANES_BEGIN
     const DevEnv& e = S.e;
     if (lane < RV_MAXB * RV_NCOL) {
       int b = lane / RV_NCOL, col = lane - b * RV_NCOL;
+      int nr = 0;
+      // sep: a lower bound of (hull distance - contact range) left over from the last
+      // distance query, minus the box's travel since (a sleeper does not move); while it
+      // is positive the query cannot hit and is skipped.  Exact: only the work changes.
+      float sep = S.s.sep[b][col] - S.s.coltravel[col];
       if (arm_on && S.s.arm_moving && body_present(e, b) && e.asleep[b]) {
-        float r = e.radius[b] + c->breaking;
-        if (sphere_aabb_dist2(ld3(e.body[b]), S.s.colmin[col], S.s.colmax[col]) < r * r) S.s.wake[b] = 1;
+        float r = c->breaking;
+        nr = aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col]) < r * r;
+        if (nr && sep > 0.0f) nr = 0;
       }
+      S.s.sep[b][col] = sep > 0.0f ? sep : 0.0f;
+      S.s.nearf[b][col] = nr;
+      if (nr) { S.s.bnear[b] = 1; S.s.near_any = 1; }
     } else if (lane < RV_MAXB * RV_NCOL + RV_MAXB * (RV_MAXB - 1)) {
       int t = lane - RV_MAXB * RV_NCOL;
       int b = t / (RV_MAXB - 1), a = t - b * (RV_MAXB - 1);
@@ -980,13 +1020,53 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
       }
     }
   RV_LANES_END
+  const int near_any = S.s.near_any;
+  if (near_any) {
+    // stage 2a: world hull vertices of the flagged sleepers
+    RV_LANES_BEGIN
+      for (int item = lane; item < RV_MAXB * RV_MAXH * RV_MAXV; item += 64) {
+        int b = item / (RV_MAXH * RV_MAXV), h = (item / RV_MAXV) % RV_MAXH, i = item % RV_MAXV;
+        if (!S.s.bnear[b]) continue;
+        if (h >= S.n_hulls[b] || i >= S.n_verts[b][h]) continue;
+        const rv_shape* s = &K.scene->shapes[S.e.shape[b]];
+        float sc = S.e.scale[b];
+        v3 l = mk(s->verts[h][i][0] * sc, s->verts[h][i][1] * sc, s->verts[h][i][2] * sc);
+        st3(S.s.wv[b][h][i], add(ld3(S.e.body[b]), mulv(qmat(ldq(S.e.body[b] + 3)), l)));
+      }
+    RV_LANES_END
+    // stage 2b: one 16-lane group per body runs the distance queries, box by box
+    RV_LANES_BEGIN
+      const DevEnv& e = S.e;
+      const int b = lane >> 4;
+#if !defined(__HIPCC__) || defined(RV_EMULATE)
+      if ((lane & 15) != 0) continue;   // host emulation: one lane per group does the work
+#endif
+      if (S.s.bnear[b] && !S.s.wake[b]) {
+        const float mg = c->margin, brk = c->breaking;
+        int hit = 0;
+        for (int col = 0; col < RV_NCOL && !hit; ++col) {
+          if (!S.s.nearf[b][col]) continue;
+          v3 d = sub(ld3(e.body[b]), ld3(S.s.colc[col]));
+          float lbmin = 1e30f;
+          for (int h = 0; h < S.n_hulls[b] && !hit; ++h) {
+            v3 n, pa, pb; float dist, lb = 0.0f;
+            if (gjk_epa(&S.s.wv[b][h][0][0], S.n_verts[b][h], &S.s.colv[col][0][0], 8, d, brk + 2.0f * mg, &n, &dist, &pa, &pb, &lb))
+              if (!(dist - 2.0f * mg > brk)) hit = 1;
+            lbmin = fminr(lbmin, lb);
+          }
+          if (!hit && (lane & 15) == 0) S.s.sep[b][col] = fmaxr(lbmin - 2.0f * mg - brk - 1e-5f, 0.0f);
+        }
+        if (hit) S.s.wake[b] = 1;
+      }
+    RV_LANES_END
+  }
   RV_STOPL(17)
 
   // body velocity update + rotations
   RV_LANES_BEGIN
     if (lane < RV_MAXB) {
       int b = lane; DevEnv& e = S.e;
-      if (S.s.wake[b]) { e.asleep[b] = 0; e.sleep_count[b] = 0; }
+      if (S.s.wake[b]) { e.asleep[b] = 0; e.sleep_count[b] = 0; e.still_count[b] = 0; }
       if (body_on(e, b)) {
         float dt = c->dt;
         e.body[b][9] += c->gravity_z * dt;
@@ -1037,28 +1117,24 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   const int arm_on = S.e.arm_enabled;
   // link twists (used by the arm-body contact rows) and hull vertices to world frame
   RV_LANES_BEGIN
-    if (lane == 0 && arm_on) {
-      DevEnv& e = S.e;
-      v3 wprev = mk(0, 0, 0), vprev = mk(0, 0, 0), pprev = ld3(arm->base_pos);
+    if (lane < RV_NFRAME && arm_on) {
+      // twists (base is static), frame by frame: w_f = sum_k axis_k qd_k,
+      // v_f = sum_k (axis_k qd_k) x (p_f - p_k) over the joints upstream of f; the
+      // fingers add their slide along the hand's y axis.  fmot: how far a collider
+      // vertex riding on the frame can travel in this substep.
+      const DevEnv& e = S.e; const int f = lane;
+      const int kmax = f < RV_NLIMB ? f : RV_NLIMB - 1;
+      v3 pf = ld3(e.fpos[f]);
+      v3 fw = mk(0, 0, 0), fv = mk(0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < RV_NLIMB; ++i) {
-        v3 pi = ld3(e.fpos[i]);
-        v3 fv = add(vprev, cross(wprev, sub(pi, pprev)));
-        v3 fw = madd(wprev, ld3(S.s.axis[i]), e.qd[i]);
-        st3(S.s.fv[i], fv); st3(S.s.fw[i], fw);
-        wprev = fw; vprev = fv; pprev = pi;
+      for (int k = 0; k < RV_NLIMB; ++k) if (k <= kmax) {
+        v3 u = scale(ld3(S.s.axis[k]), e.qd[k]);
+        fw = add(fw, u);
+        fv = add(fv, cross(u, sub(pf, ld3(e.fpos[k]))));
       }
-      v3 p7 = ld3(e.fpos[7]);
-      v3 v7 = add(vprev, cross(wprev, sub(p7, pprev)));
-      st3(S.s.fv[7], v7); st3(S.s.fw[7], wprev);
-      v3 yax = mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        int f = 8 + k;
-        v3 vf = add(v7, cross(wprev, sub(ld3(e.fpos[f]), p7)));
-        vf = madd(vf, yax, e.qd[7 + k]);
-        st3(S.s.fv[f], vf); st3(S.s.fw[f], wprev);
-      }
+      if (f >= 8) fv = madd(fv, mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]), e.qd[f - 1]);
+      st3(S.s.fv[f], fv); st3(S.s.fw[f], fw);
+      S.s.fmot[f] = (len(fv) + len(fw) * S.s.fext[f]) * c->dt;
     }
     if (lane == 63) S.e.awake_last += S.s.any_on;
     for (int item = lane; item < RV_MAXB * RV_MAXH * RV_MAXV; item += 64) {
@@ -1091,7 +1167,15 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
     int my_pairs = 0;
     for (int round = 0; round < (RV_NMAN + RV_NCOL + 3) / 4; ++round) {
-      const int owner = round * 4 + slot;
+      // schedule: a body's table pair and its arm pairs share a round (they are the
+      // two owners that are busy while the body is pushed), so the wave runs both
+      // convex queries in lockstep.  Owners write disjoint manifolds: any order gives
+      // the same result.  ids: T(b) = b, BB(k) = 4 + k, A(b) = 10 + b, AT(col) = 14 + col
+      int owner;
+      if (round < 2) owner = ((slot & 1) ? RV_MAXB + RV_NBB : 0) + 2 * round + (slot >> 1);
+      else if (round == 2) owner = RV_MAXB + slot;
+      else if (round == 3) owner = slot < 2 ? RV_MAXB + 4 + slot : RV_NMAN + (slot - 2);
+      else owner = RV_NMAN + 2 + (round - 4) * 4 + slot;
       int role = -1, a = 0, b = -1, mi = 0, n_outer = 0, n_inner = 0;
       int clear = 0, live = 0;     // live: manifold is refreshed (and may get new points)
       v3 guess0 = mk(0.0f, 0.0f, 1.0f);
@@ -1140,9 +1224,15 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       if (live) {
         DevMan& m = e.man[mi];
         int lost = manifold_refresh(S, K, owner < RV_MAXB ? 0 : (owner < RV_MAXB + RV_NBB ? 1 : 2), a, b, m);
-        if (owner < RV_MAXB + RV_NBB) {
-          // narrow-phase gating (body-table and body-body pairs)
+        {
+          // narrow-phase gating on the travel of the two shapes since the last full pass
           float mo = S.s.mot[a];
+          if (owner >= RV_MAXB + RV_NBB) {
+            float am = 0.0f;
+#pragma unroll
+            for (int f = 0; f < RV_NFRAME; ++f) am = fmaxr(am, S.s.fmot[f]);
+            mo = mo + am;
+          }
           if (b >= 0) mo = mo + S.s.mot[b];
           float acc = m.acc + mo;
           int run = (c->np_max_age <= 0) || m.n == 0 || lost > 0 || acc > c->np_gate || (e.sim_steps % c->np_max_age) == 0;
@@ -1345,9 +1435,36 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         if (c->sleep_steps > 0) {   // deactivation counter
           if (dot(v, v) < c->sleep_lin * c->sleep_lin && dot(w, w) < c->sleep_ang * c->sleep_ang) e.sleep_count[b]++;
           else e.sleep_count[b] = 0;
-          if (e.sleep_count[b] >= c->sleep_steps) {
+          // in-place oscillation: the pose has not left a small window around where
+          // it was when the window opened
+          if (c->sleep_pos_win > 0.0f) {
+            int inside = 0;
+            if (e.still_count[b] > 0) {
+              v3 dp = sub(p, ld3(e.still_ref[b]));
+              float dqm = fmaxr(fmaxr(fmaxr(fmaxr(0.0f, fabsr(q.x - e.still_ref[b][3])), fabsr(q.y - e.still_ref[b][4])),
+                                      fabsr(q.z - e.still_ref[b][5])), fabsr(q.w - e.still_ref[b][6]));
+              inside = dot(dp, dp) < c->sleep_pos_win * c->sleep_pos_win && dqm < c->sleep_rot_win;
+            }
+            if (inside) e.still_count[b]++;
+            else { e.still_count[b] = 1; st3(e.still_ref[b], p); stq(e.still_ref[b] + 3, q); }
+          }
+          if (e.sleep_count[b] >= c->sleep_steps || e.still_count[b] >= c->sleep_steps) {
             e.asleep[b] = 1;
             st3(e.body[b] + 7, mk(0, 0, 0)); st3(e.body[b] + 10, mk(0, 0, 0));
+            // world box of the resting hulls: what the arm has to come near to wake the body
+            const rv_shape* sh = &K.scene->shapes[e.shape[b]];
+            const m3 m = qmat(q);
+            const float sc = e.scale[b];
+            float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+            for (int h = 0; h < S.n_hulls[b]; ++h)
+              for (int i = 0; i < S.n_verts[b][h]; ++i) {
+                v3 l = mk(sh->verts[h][i][0] * sc, sh->verts[h][i][1] * sc, sh->verts[h][i][2] * sc);
+                v3 pw = add(p, mulv(m, l));
+                lo[0] = fminr(lo[0], pw.x); lo[1] = fminr(lo[1], pw.y); lo[2] = fminr(lo[2], pw.z);
+                hi[0] = fmaxr(hi[0], pw.x); hi[1] = fmaxr(hi[1], pw.y); hi[2] = fmaxr(hi[2], pw.z);
+              }
+            for (int k = 0; k < 3; ++k) { e.baabb[b][k] = lo[k] - c->margin; e.baabb[b][3 + k] = hi[k] + c->margin; }
+            for (int col = 0; col < RV_NCOL; ++col) S.s.sep[b][col] = 0.0f;   // new resting pose
           }
         }
       }
@@ -1785,7 +1902,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
     RV_LANES_BEGIN
       DevEnv& e = S.e;
       if (lane == 0) {
-        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; }
+        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.still_count[b] = 0; }
         sample_poses(S, K, e.n_bodies);
       }
       if (lane >= 1 && lane <= RV_NMAN) e.man[lane - 1].n = 0;
@@ -1799,7 +1916,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
           int shape = use_target ? c->target_shapes[rng_randint(g, c->n_target_shapes)]
                                  : c->movable_shapes[rng_randint(g, c->n_movable_shapes)];
           float sc = rng_uniform(g, c->scale_range[0], c->scale_range[1]);
-          e.active[i] = 1; e.frozen[i] = 0; e.asleep[i] = 0; e.sleep_count[i] = 0; e.shape[i] = shape; e.scale[i] = sc; e.friction[i] = c->drop_friction;
+          e.active[i] = 1; e.frozen[i] = 0; e.asleep[i] = 0; e.sleep_count[i] = 0; e.still_count[i] = 0; e.shape[i] = shape; e.scale[i] = sc; e.friction[i] = c->drop_friction;
           body_set_mass(e, K, i, c->drop_mass);
           cache_shape_meta(S, K, i);
           for (int k = 0; k < 3; ++k) e.body[i][k] = S.s.poses[i][k];
@@ -1909,6 +2026,7 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
 RV_DEV void env_enter(Shared& S, const Consts& K) {
   RV_LANES_BEGIN
     if (lane == 63) { S.s.jt_applied = 0; S.s.kin_fresh = 0; }
+    if (lane < RV_MAXB * RV_NCOL) S.s.sep[lane / RV_NCOL][lane % RV_NCOL] = 0.0f;
     if (lane < 8) table_prepare(S, K, lane);
     if (lane >= 48 && lane < 48 + RV_NLIMB + 1) { int i = lane - 48; S.s.jlen[i] = len(ld3(K.arm->jpos[i])); }
     if (lane >= 20 && lane < 20 + RV_NCOL) {
@@ -1920,6 +2038,10 @@ RV_DEV void env_enter(Shared& S, const Consts& K) {
     if (lane >= 8 && lane < 8 + RV_NFRAME) {
       int f = lane - 8;
       stm(S.s.frot[f], qmat(ldq(S.e.fquat[f])));
+      float ext = 0.0f;
+      for (int col = 0; col < RV_NCOL; ++col)
+        if (K.arm->col_frame[col] == f) ext = fmaxr(ext, len(ld3(K.arm->col_center[col])) + len(ld3(K.arm->col_half[col])));
+      S.s.fext[f] = ext;
     }
     if (lane >= 32 && lane < 32 + RV_MAXB) {
       int b = lane - 32;

@@ -62,3 +62,9 @@ print('%-36s %10s %10s' % ('part', 'mean env', 'slowest'))
 for k in range(8):
     print('%-36s %9.1f%% %9.1f%%' % (names_[k], 100 * p[:, k].mean() / tot.mean(), 100 * p[slow, k] / tot[slow]))
 print('mean env busy time / slowest env = %.3f' % (tot.mean() / tot.max()))
+cnt = w.env_counters().cpu().numpy()
+order = np.argsort(-tot)[:6]
+print('slowest envs: id, ms, substeps, awake, pairs')
+for i in order:
+    print('  %4d %7.1f %7d %6d %6d   parts%% %s' % (i, tot[i] / clk * 1e3, cnt[i, 7], cnt[i, 8], cnt[i, 9],
+          np.round(100 * p[i, :7] / tot[i], 1)))
