@@ -106,7 +106,7 @@ struct DevEnv {
   int num_total_steps, num_unsafe, num_ineffective, num_useful, num_successes;
   int pad_[3];
 #ifdef RV_PROFILE
-  unsigned long long prof[8], prof_t;   // tools/prof_rollout.py: shader-clock time per substep part
+  unsigned long long prof[12], prof_t;   // tools/prof_rollout.py: shader-clock time per substep part
 #endif
 };
 static_assert(sizeof(DevEnv) % 4 == 0, "DevEnv is copied word-wise");
@@ -149,6 +149,7 @@ struct Scratch {
   int kin_fresh;                         // FK / collider scratch matches the joint state (per launch)
   int nearf[RV_MAXB][RV_NCOL], bnear[RV_MAXB], near_any;   // wake test stage 1 -> stage 2
   float sep[RV_MAXB][RV_NCOL], coltravel[RV_NCOL];          // distance-bound culling of the wake queries
+  float cdelta[3][RV_NCOL];                                 // coasting: box travel bound per candidate length
   int coast_unsafe[3];
   float jlen[RV_NLIMB + 1], colext[RV_NCOL];   // |jpos_i|; collider extent from its frame origin
   float fext[RV_NFRAME], fmot[RV_NFRAME];     // per frame: largest collider extent; vertex travel this substep
@@ -896,7 +897,7 @@ static long rv_emu_coasted = 0;
 // bound is rigorous (joint travel from |qd|, v_max and a_max; vertex travel <=
 // sum of joint travel x reach), so the result is bit-identical to stepping.
 // Returns m (0: step normally).  Needs fresh kinematics (S.s.kin_fresh).
-RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining) {
+RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining, int* kidx) {
   const rv_config* c = K.cfg;
   const rv_arm* arm = K.arm;
   if (K.stop_after != 0 || !S.e.arm_enabled || !S.s.kin_fresh || remaining < 2) return 0;
@@ -926,6 +927,7 @@ RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining) {
       for (int b = 0; b < RV_MAXB; ++b) {
         if (!body_present(e, b)) continue;
         float d = fsqrtr(aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col])) - c->breaking;
+        d = fmaxr(d, S.s.sep[b][col]);     // the distance bound left by the last wake query, if better
         bclear = fminr(bclear, d);
       }
       for (int k = 0; k < 3; ++k) {
@@ -949,15 +951,16 @@ RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining) {
           delta += mf * dt * fminr(fmaxr(q0, e.vmax_cmd[j]), q0 + mf * arm->a_max[j] * dt);
         }
         delta = delta * 1.02f + 1e-4f;
+        S.s.cdelta[k][col] = delta;
         if (!(tclear > delta) || !(bclear > 2.0f * delta)) S.s.coast_unsafe[k] = 1;
       }
     }
   RV_LANES_END
-  for (int k = 0; k < 3; ++k) if (!S.s.coast_unsafe[k]) return m0 >> k;
+  for (int k = 0; k < 3; ++k) if (!S.s.coast_unsafe[k]) { *kidx = k; return m0 >> k; }
   return 0;
 }
 // m coasting substeps, then the kinematics of the final joint state
-RV_DEV void coast_substeps(Shared& S, const Consts& K, const int m) {
+RV_DEV void coast_substeps(Shared& S, const Consts& K, const int m, const int kidx) {
 #ifdef RV_EMU_COUNT
   rv_emu_coasted += m;
 #endif
@@ -969,7 +972,10 @@ RV_DEV void coast_substeps(Shared& S, const Consts& K, const int m) {
     DevEnv& e = S.e;
     if (lane == 0) e.flag_arm_table = 0;
     if (lane >= 1 && lane <= RV_MAXB) e.flag_arm_body[lane - 1] = 0;
-    if (lane >= 8 && lane < 8 + RV_MAXB * RV_NCOL) { int t = lane - 8; S.s.sep[t / RV_NCOL][t % RV_NCOL] = 0.0f; }   // the arm moved unobserved
+    if (lane >= 8 && lane < 8 + RV_MAXB * RV_NCOL) {   // the boxes travelled at most cdelta meanwhile
+      int t = lane - 8, b = t / RV_NCOL, col = t - b * RV_NCOL;
+      S.s.sep[b][col] = fmaxr(S.s.sep[b][col] - S.s.cdelta[kidx][col], 0.0f);
+    }
   RV_LANES_END
 }
 
@@ -1513,15 +1519,26 @@ RV_DEV unsigned active_mask(const DevEnv& e) {
   for (int b = 0; b < RV_MAXB; ++b) if (e.active[b]) m |= 1u << b;
   return m;
 }
+RV_DEV void phase_tick(Shared& S, const Consts& K);
 // Runs substeps inside ONE out-of-line function, so that the call overhead
-// (callee-saved registers) is paid per call and not per substep, and the light
-// part exists once in the instruction stream.
+// (callee-saved registers: ~140 VGPRs saved and restored per call) is paid per call
+// and not per substep, and the light part exists once in the instruction stream.
 //   n_fixed > 0 : exactly n_fixed times Simulator.step
 //   n_fixed == 0: Simulator.wait_until_stable (simulator.py:325-376); mask == 0 => all active
-RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_fixed, unsigned mask,
+//   n_fixed < 0 : the phase loop of PushEnv._execute_action (push_env.py:648-719: step
+//                 until the next multiple of STEPS_CHECK, phase_tick, until 'done'),
+//                 followed by its closing wait_until_stable -- one call per env.step()
+RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_arg, unsigned mask,
                                   float lin_thr, float ang_thr, int check_after, int min_stable, int max_steps) {
   Consts K = lds_consts(scene, stop_after);
   Shared& S = g_shared;
+  int phase_mode = n_arg < 0;
+  for (;;) {                  // one pass, except in phase mode
+  int n_fixed = n_arg;
+  if (phase_mode) {
+    if (S.e.phase == RV_PHASE_DONE) { phase_mode = 0; n_fixed = 0; }   // -> closing wait_until_stable
+    else n_fixed = K.cfg->steps_check - (S.e.sim_steps % K.cfg->steps_check);
+  }
   if (n_fixed == 0) {
     RV_LANES_BEGIN
       if (lane == 0) { S.s.wus_steps = 0; S.s.wus_stable = 0; S.s.loop_break = 0; }
@@ -1532,9 +1549,10 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_f
   for (;;) {
     RV_PROF(7)
     if (n_fixed > 0 && coast_wait == 0) {
-      const int m = coast_budget(S, K, n_fixed - taken);
+      int kidx = 0;
+      const int m = coast_budget(S, K, n_fixed - taken, &kidx);
       if (m >= 2) {
-        coast_substeps(S, K, m);
+        coast_substeps(S, K, m, kidx);
         RV_PROF(0)
         taken += m;
         if (taken >= n_fixed) break;
@@ -1555,9 +1573,10 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_f
           if (st >= check_after) { if (st_ok) ++sb; if (sb >= min_stable || st >= max_steps) fin = 1; }
         }
       }
-      const int m = coast_budget(S, K, T);
+      int kidx = 0;
+      const int m = coast_budget(S, K, T, &kidx);
       if (m >= 2) {
-        coast_substeps(S, K, m);
+        coast_substeps(S, K, m, kidx);
         RV_LANES_BEGIN
           if (lane == 0) {
             for (int i = 0; i < m; ++i) {
@@ -1598,6 +1617,14 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_f
       }
     RV_LANES_END
     if (S.s.loop_break) break;
+  }
+  if (!phase_mode) break;
+  // the phase machine looks at the world every STEPS_CHECK substeps (push_env.py:652-661)
+  RV_PROF(8)
+  RV_LANES_BEGIN
+    if (lane == 0) phase_tick(S, K);
+  RV_LANES_END
+  RV_PROF(9)
   }
 }
 RV_DEV void sim_steps_call(const Consts& K, int n) {
@@ -1782,14 +1809,8 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
       }
     }
   RV_LANES_END
-  while (S.e.phase != RV_PHASE_DONE) {
-    // the phase machine looks at the world every STEPS_CHECK substeps (push_env.py:652-661)
-    sim_steps_call(K, c->steps_check - (S.e.sim_steps % c->steps_check));
-    RV_LANES_BEGIN
-      if (lane == 0) phase_tick(S, K);
-    RV_LANES_END
-  }
-  wait_until_stable(S, K, 0u, 0.005f, 0.005f, 100, 100, 2000);
+  // phase loop + closing wait_until_stable, in one out-of-line call
+  sim_run_call(K.scene, K.stop_after, -1, 0u, 0.005f, 0.005f, 100, 100, 2000);
   RV_LANES_BEGIN
     if (lane == 0) {
       DevEnv& e = S.e; Scratch& s = S.s;
