@@ -150,6 +150,8 @@ struct Scratch {
   int nearf[RV_MAXB][RV_NCOL], bnear[RV_MAXB], near_any;   // wake test stage 1 -> stage 2
   float sep[RV_MAXB][RV_NCOL], coltravel[RV_NCOL];          // distance-bound culling of the wake queries
   float cdelta[3][RV_NCOL];                                 // coasting: box travel bound per candidate length
+  float clr_t[RV_NCOL], clr_b[RV_NCOL]; int clr_valid;      // coasting: clearances left (table, bodies)
+  float jtravel[RV_NJ];                                     // coasting: joint path lengths of the chunk
   int coast_unsafe[3];
   float jlen[RV_NLIMB + 1], colext[RV_NCOL];   // |jpos_i|; collider extent from its frame origin
   float fext[RV_NFRAME], fmot[RV_NFRAME];     // per frame: largest collider extent; vertex travel this substep
@@ -761,7 +763,10 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
         S.s.jmoving[j] = fabsr(qd) > 1e-3f;
         if (j < RV_NLIMB) stq(S.s.lq[j], joint_local_quat(arm, j, qn));
       }
-      if (count_step && j == 0) { e.sim_steps++; e.substeps_last++; }
+      if (count_step) {
+        S.s.jtravel[j] += fabsr(qd) * dt;      // coasting: path length of the joint
+        if (j == 0) { e.sim_steps++; e.substeps_last++; }
+      }
     }
   RV_LANES_END
 }
@@ -883,7 +888,7 @@ RV_DEV void arm_collider_phases(Shared& S, const Consts& K, const int arm_on) {
         S.s.coltravel[col] = tr * 1.02f + 1e-7f;
       }
     }
-    if (lane == 63) S.s.kin_fresh = arm_on;
+    if (lane == 63) { S.s.kin_fresh = arm_on; S.s.clr_valid = 0; }   // left-over clearances are for coasting chains only
   RV_LANES_END
 }
 
@@ -900,7 +905,9 @@ static long rv_emu_coasted = 0;
 RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining, int* kidx) {
   const rv_config* c = K.cfg;
   const rv_arm* arm = K.arm;
-  if (K.stop_after != 0 || !S.e.arm_enabled || !S.s.kin_fresh || remaining < 2) return 0;
+  if (K.stop_after != 0 || !S.e.arm_enabled || remaining < 2) return 0;
+  const int fresh = S.s.kin_fresh;
+  if (!fresh && !S.s.clr_valid) return 0;
   {
     int any_on = 0;
 #pragma unroll
@@ -917,19 +924,27 @@ RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining, int* ki
       const int col = lane, f = arm->col_frame[col];
       const int fl = f < 7 ? f : 7;                 // last limb frame the box depends on
       const float dt = c->dt;
-      v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
-      v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
-      // clearances now
-      const float zc = S.s.colmin[col][2] - e.table_z - c->margin - c->contact_query_dist;
-      const float sc = fsqrtr(sphere_box_dist2(ld3(S.s.colc[col]), tc, th)) - (S.s.colr[col] + c->breaking);
-      float tclear = zc > sc ? zc : sc;             // either test rejecting is enough
-      float bclear = 1e30f;
-      for (int b = 0; b < RV_MAXB; ++b) {
-        if (!body_present(e, b)) continue;
-        float d = fsqrtr(aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col])) - c->breaking;
-        d = fmaxr(d, S.s.sep[b][col]);     // the distance bound left by the last wake query, if better
-        bclear = fminr(bclear, d);
+      // clearances: measured on fresh kinematics, else what the previous coasting
+      // chunks left of them (each chunk subtracts its travel bound)
+      float tclear, bclear;
+      if (fresh) {
+        v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
+        v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
+        const float zc = S.s.colmin[col][2] - e.table_z - c->margin - c->contact_query_dist;
+        const float sc = fsqrtr(sphere_box_dist2(ld3(S.s.colc[col]), tc, th)) - (S.s.colr[col] + c->breaking);
+        tclear = zc > sc ? zc : sc;                 // either test rejecting is enough
+        bclear = 1e30f;
+        for (int b = 0; b < RV_MAXB; ++b) {
+          if (!body_present(e, b)) continue;
+          float d = fsqrtr(aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col])) - c->breaking;
+          d = fmaxr(d, S.s.sep[b][col]);   // the distance bound left by the last wake query, if better
+          bclear = fminr(bclear, d);
+        }
+        S.s.clr_t[col] = tclear; S.s.clr_b[col] = bclear;
+      } else {
+        tclear = S.s.clr_t[col]; bclear = S.s.clr_b[col];
       }
+      if (lane == 0) S.s.clr_valid = 1;
       for (int k = 0; k < 3; ++k) {
         const int m = m0 >> k;
         if (m < 2) { S.s.coast_unsafe[k] = 1; continue; }
@@ -957,26 +972,156 @@ RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining, int* ki
     }
   RV_LANES_END
   for (int k = 0; k < 3; ++k) if (!S.s.coast_unsafe[k]) { *kidx = k; return m0 >> k; }
-  return 0;
+  return fresh ? 0 : -1;      // -1: the left-over clearances do not suffice; measure again and retry
 }
+// r substeps of the joint motors alone (arm_motor_phases (a)+(b) with a no-op control).
+// Device: lane j < 9 keeps joint j in registers; the common scale of the limb joints
+// is a 16-lane DPP min all-reduce (min is exact, so the order does not matter).
+// Host emulation: the same arithmetic, joint by joint.
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+template <int N> RV_DEV float row_ror_min(float x) {
+  float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
+  return o < x ? o : x;
+}
+RV_DEV void motors_only_substeps(Shared& S, const Consts& K, const int r) {
+  const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
+  DevEnv& e = S.e;
+  const int lane = (int)threadIdx.x;
+  const int j = lane < RV_NJ ? lane : RV_NJ - 1;
+  const bool mine = lane < RV_NJ;
+  const float dt = c->dt;
+  float q = e.q[j], qd = e.qd[j];
+  const int on = e.motor_on[j];
+  const float kp = e.motor_kp[j], mq = e.motor_q[j], vmax = e.vmax_cmd[j];
+  const float amax_dt = arm->a_max[j] * dt, lo = arm->q_lo[j], hi = arm->q_hi[j];
+  float trav = 0.0f;
+  for (int i = 0; i < r; ++i) {
+    float vd = 0.0f, ratio = 1.0f;
+    if (on) {
+      vd = kp * (mq - q) / dt;
+      float raw = fabsr(vd);
+      if (j < RV_NLIMB && raw > vmax) ratio = vmax / raw;
+    }
+    if (!mine) ratio = 1.0f;
+    float sync = fminr(1.0f, ratio);
+    sync = row_ror_min<8>(sync); sync = row_ror_min<4>(sync); sync = row_ror_min<2>(sync); sync = row_ror_min<1>(sync);
+    float vdd = 0.0f;
+    if (on) {
+      vdd = vd;
+      if (j < RV_NLIMB) vdd = vdd * sync;
+      vdd = fclampr(vdd, -vmax, vmax);
+    }
+    float dv = fclampr(vdd - qd, -amax_dt, amax_dt);
+    float qdn = qd + dv;
+    float qn = q + qdn * dt;
+    if (qn < lo) { qn = lo; qdn = 0.0f; }
+    if (qn > hi) { qn = hi; qdn = 0.0f; }
+    q = qn; qd = qdn;
+    trav += fabsr(qdn) * dt;
+  }
+  if (mine) { e.q[j] = q; e.qd[j] = qd; S.s.jtravel[j] += trav; }
+  if (lane == 0) { e.sim_steps += r; e.substeps_last += r; }
+  __syncthreads();
+}
+#else
+RV_DEV void motors_only_substeps(Shared& S, const Consts& K, const int r) {
+  const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
+  DevEnv& e = S.e;
+  const float dt = c->dt;
+  for (int i = 0; i < r; ++i) {
+    float vdr[RV_NJ], sync = 1.0f;
+    for (int j = 0; j < RV_NJ; ++j) {
+      float vd = 0.0f, ratio = 1.0f;
+      if (e.motor_on[j]) {
+        vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) / dt;
+        float raw = fabsr(vd);
+        if (j < RV_NLIMB && raw > e.vmax_cmd[j]) ratio = e.vmax_cmd[j] / raw;
+      }
+      vdr[j] = vd;
+      sync = fminr(sync, ratio);
+    }
+    for (int j = 0; j < RV_NJ; ++j) {
+      float vdd = 0.0f;
+      if (e.motor_on[j]) {
+        vdd = vdr[j];
+        if (j < RV_NLIMB) vdd = vdd * sync;
+        vdd = fclampr(vdd, -e.vmax_cmd[j], e.vmax_cmd[j]);
+      }
+      float dv = fclampr(vdd - e.qd[j], -arm->a_max[j] * dt, arm->a_max[j] * dt);
+      float qd = e.qd[j] + dv;
+      float qn = e.q[j] + qd * dt;
+      if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
+      if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
+      e.q[j] = qn; e.qd[j] = qd;
+      S.s.jtravel[j] += fabsr(qd) * dt;
+    }
+    e.sim_steps++; e.substeps_last++;
+  }
+}
+#endif
+
 // m coasting substeps, then the kinematics of the final joint state
+// upper bound of the distance a vertex of collider box col travelled, from the joint
+// path lengths accumulated while coasting
+RV_DEV float col_travelled(const Shared& S, const Consts& K, const int col) {
+  const int f = K.arm->col_frame[col]; const int fl = f < 7 ? f : 7;
+  float tr = 0.0f, reach = S.s.colext[col];
+  for (int j = fl; j >= 0; --j) {
+    if (j < RV_NLIMB) tr += reach * S.s.jtravel[j];
+    reach += S.s.jlen[j];
+  }
+  if (f >= 8) tr += S.s.jtravel[f - 1];
+  return tr * 1.02f + 1e-6f;
+}
 RV_DEV void coast_substeps(Shared& S, const Consts& K, const int m, const int kidx) {
 #ifdef RV_EMU_COUNT
   rv_emu_coasted += m;
 #endif
-  for (int i = 0; i < m; ++i) arm_motor_phases(S, K, 0, 1);
-  arm_lq_phase(S, K);
-  arm_fk_phases(S, K);
-  arm_collider_phases(S, K, 1);
+  RV_LANES_BEGIN
+    if (lane < RV_NJ) S.s.jtravel[lane] = 0.0f;
+  RV_LANES_END
+  for (int i = 0; i < m;) {
+    // substeps in which ControllableBody.update has nothing to do (no done-check, no
+    // IK, motor targets already applied) leave only the joint motors: run those r
+    // substeps in registers, without LDS round trips
+    int r = 0;
+    {
+      const int lt_on = S.e.lt.active, jt_on = S.e.jt.active, steps = S.e.sim_steps, applied = S.s.jt_applied;
+      while (i + r < m) {
+        const int st = steps + r;
+        const int noop = (!lt_on && !jt_on) ||
+                         (st % RV_STEPS_TO_CHECK_DONE != 0 && jt_on && applied && (!lt_on || st % RV_STEPS_TO_UPDATE_IK != 0));
+        if (!noop) break;
+        ++r;
+      }
+    }
+    if (r >= 2) { motors_only_substeps(S, K, r); i += r; }
+    else { arm_motor_phases(S, K, 0, 1); i += 1; }
+  }
+  // FK / colliders are NOT refreshed here: consecutive chunks run on the clearances left
+  // over (arm_refresh_kinematics is called by whoever needs frames or fresh clearances)
   RV_LANES_BEGIN
     DevEnv& e = S.e;
     if (lane == 0) e.flag_arm_table = 0;
     if (lane >= 1 && lane <= RV_MAXB) e.flag_arm_body[lane - 1] = 0;
-    if (lane >= 8 && lane < 8 + RV_MAXB * RV_NCOL) {   // the boxes travelled at most cdelta meanwhile
+    // what the boxes really travelled (joint path lengths x reach; never more than the
+    // bound the chunk was admitted with) comes off the distance bounds and clearances
+    if (lane >= 8 && lane < 8 + RV_MAXB * RV_NCOL) {
       int t = lane - 8, b = t / RV_NCOL, col = t - b * RV_NCOL;
-      S.s.sep[b][col] = fmaxr(S.s.sep[b][col] - S.s.cdelta[kidx][col], 0.0f);
+      S.s.sep[b][col] = fmaxr(S.s.sep[b][col] - col_travelled(S, K, col), 0.0f);
     }
+    if (lane >= 48 && lane < 48 + RV_NCOL) {
+      int col = lane - 48; float d = col_travelled(S, K, col);
+      S.s.clr_t[col] = S.s.clr_t[col] - d; S.s.clr_b[col] = S.s.clr_b[col] - 2.0f * d;
+    }
+    if (lane == 63) S.s.kin_fresh = 0;
   RV_LANES_END
+}
+// frames, colliders and AABBs of the current joint state (after coasting)
+RV_DEV void arm_refresh_kinematics(Shared& S, const Consts& K) {
+  arm_lq_phase(S, K);
+  arm_fk_phases(S, K);
+  arm_collider_phases(S, K, 1);
 }
 
 RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
@@ -1550,10 +1695,12 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
     RV_PROF(7)
     if (n_fixed > 0 && coast_wait == 0) {
       int kidx = 0;
-      const int m = coast_budget(S, K, n_fixed - taken, &kidx);
+      int m = coast_budget(S, K, n_fixed - taken, &kidx);
+      if (m < 0) { arm_refresh_kinematics(S, K); m = coast_budget(S, K, n_fixed - taken, &kidx); }
+      RV_PROF(10)
       if (m >= 2) {
         coast_substeps(S, K, m, kidx);
-        RV_PROF(0)
+        RV_PROF(11)
         taken += m;
         if (taken >= n_fixed) break;
         continue;
@@ -1574,7 +1721,8 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
         }
       }
       int kidx = 0;
-      const int m = coast_budget(S, K, T, &kidx);
+      int m = coast_budget(S, K, T, &kidx);
+      if (m < 0) { arm_refresh_kinematics(S, K); m = coast_budget(S, K, T, &kidx); }
       if (m >= 2) {
         coast_substeps(S, K, m, kidx);
         RV_LANES_BEGIN
@@ -1619,13 +1767,17 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
     if (S.s.loop_break) break;
   }
   if (!phase_mode) break;
-  // the phase machine looks at the world every STEPS_CHECK substeps (push_env.py:652-661)
+  // the phase machine looks at the world every STEPS_CHECK substeps (push_env.py:652-661);
+  // it reads the end-effector frame only in these situations
+  if (!S.s.kin_fresh && S.e.arm_enabled &&
+      (S.e.phase == RV_PHASE_START || S.e.phase == RV_PHASE_MOTION || S.s.interrupt)) arm_refresh_kinematics(S, K);
   RV_PROF(8)
   RV_LANES_BEGIN
     if (lane == 0) phase_tick(S, K);
   RV_LANES_END
   RV_PROF(9)
   }
+  if (!S.s.kin_fresh && S.e.arm_enabled) arm_refresh_kinematics(S, K);   // leave with frames that match the joints
 }
 RV_DEV void sim_steps_call(const Consts& K, int n) {
   if (n > 0) sim_run_call(K.scene, K.stop_after, n, 0u, 0.0f, 0.0f, 0, 0, 0);
@@ -2046,7 +2198,7 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
 // rebuild the per-launch caches that are not part of the persistent block
 RV_DEV void env_enter(Shared& S, const Consts& K) {
   RV_LANES_BEGIN
-    if (lane == 63) { S.s.jt_applied = 0; S.s.kin_fresh = 0; }
+    if (lane == 63) { S.s.jt_applied = 0; S.s.kin_fresh = 0; S.s.clr_valid = 0; }
     if (lane < RV_MAXB * RV_NCOL) S.s.sep[lane / RV_NCOL][lane % RV_NCOL] = 0.0f;
     if (lane < 8) table_prepare(S, K, lane);
     if (lane >= 48 && lane < 48 + RV_NLIMB + 1) { int i = lane - 48; S.s.jlen[i] = len(ld3(K.arm->jpos[i])); }

@@ -109,3 +109,17 @@ def test_rollout_equals_lockstep_and_oracle(emu):
     assert np.array_equal(ref_roll.env_counters()[:, :7], ref_lock.env_counters()[:, :7])
     _check(e, ref_roll)
     assert ref_roll.stats()['env_steps'] == K * 5
+
+
+def test_long_rollout_with_resets_is_bit_exact(emu):
+    """Several episodes per env in one launch (auto-reset), enough envs and steps to
+    exercise coasting chains, lazy kinematics, the wake queries and their distance
+    bounds across resets."""
+    from oracle import orc
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(env_cfg=configs.push_env_config(MAX_STEPS=3), n_envs=24, seed=77, shape_names=names)
+    ref = orc.OracleWorld(cfg, scene); e = Emu(emu, cfg, scene)
+    ref.reset(); emu.emu_reset(e.h, None)
+    ref.rollout(8, 2, True)
+    emu.emu_rollout(e.h, 8, 2, 1)
+    _check(e, ref)

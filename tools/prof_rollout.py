@@ -53,14 +53,14 @@ p = prof() - p0
 st = w.stats()
 names_ = ['quiet substeps (light part only)', 'light part of non-quiet substeps', 'heavy: twists + hull vertices',
           'heavy: narrow phase', 'heavy: row setup', 'heavy: solver', 'heavy: integrate + return', 'between substeps',
-          'end of a STEPS_CHECK chunk', 'phase_tick', '-', '-']
+          'end of a STEPS_CHECK chunk', 'phase_tick', 'coast: budget (+refresh)', 'coast: control + motors']
 tot = p[:, :7].sum(axis=1)
 slow = int(np.argmax(tot))
 clk = tot.max() / (ms * 1e-3)
 print('rollout of %d steps x %d envs: %.1f ms; slowest env = %.3g clocks => counter at %.1f MHz' % (steps, n, ms, tot.max(), clk / 1e6))
 print('substeps %d, awake fraction %.3f' % (st['substeps'], st['awake_substeps'] / max(st['substeps'], 1)))
 print('%-36s %10s %10s' % ('part', 'mean env', 'slowest'))
-for k in range(10):
+for k in range(12):
     print('%-36s %9.1f%% %9.1f%%' % (names_[k], 100 * p[:, k].mean() / tot.mean(), 100 * p[slow, k] / tot[slow]))
 print('mean env busy time / slowest env = %.3f' % (tot.mean() / tot.max()))
 cnt = w.env_counters().cpu().numpy()
