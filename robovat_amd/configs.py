@@ -97,7 +97,7 @@ PUSH_ENV_CONFIG = {
         'BREAKING': 0.01, 'WARMSTART': 0.85, 'MAX_PUSHOUT': 0.5,
         'LINEAR_DAMPING': 0.04, 'ANGULAR_DAMPING': 0.04,
         'CONTACT_QUERY_DIST': 0.001, 'ARM_FRICTION': 0.8,
-        'SOLVER_TOL': 1e-7,
+        'SOLVER_TOL': 1e-5,
         'SLEEP_LINEAR': 0.02, 'SLEEP_ANGULAR': 0.5, 'SLEEP_STEPS': 200,
         'SLEEP_POSITION_WINDOW': 1e-3, 'SLEEP_ROTATION_WINDOW': 0.01,
         'NARROWPHASE_GATE': 5e-4, 'NARROWPHASE_MAX_AGE': 8,
