@@ -54,7 +54,7 @@ def cpu_baseline(cfg_kwargs, scene, names, seconds_hint=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=50)   # BASELINE configs[1]: 50 macro-steps per env
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--envs-per-gpu', type=int, default=1024)
     ap.add_argument('--seed', type=int, default=1234)

@@ -966,7 +966,8 @@ static void sim_substep(const orc_world* w, orc_env* e) {
       if (!(e->bp[b].active && !e->bp[b].frozen && e->bp[b].asleep)) continue;
       for (int a = 0; a < RV_MAXB; ++a) {
         /* only a MOVING neighbour wakes a sleeper (resting neighbours would ping-pong) */
-        if (a == b || !body_on(e, a) || e->bp[a].sleep_count > 0) continue;
+        /* ... and moving means: left its 1 mm pose window within the last 50 substeps */
+        if (a == b || !body_on(e, a) || e->bp[a].sleep_count > 0 || e->bp[a].still_count >= 50) continue;
         real d[3]; v3sub(d, e->body[a].p, e->body[b].p);
         real r = e->bp[a].radius + e->bp[b].radius + (real)c->breaking;
         if (v3dot(d, d) < r * r) wake[b] = 1;

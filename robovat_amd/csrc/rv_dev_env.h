@@ -1164,7 +1164,8 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
       int b = t / (RV_MAXB - 1), a = t - b * (RV_MAXB - 1);
       if (a >= b) a++;
       // only a MOVING neighbour wakes a sleeper (resting neighbours would ping-pong)
-      if (body_present(e, b) && e.asleep[b] && body_on(e, a) && !(e.sleep_count[a] > 0)) {
+      // ... and moving means: left its 1 mm pose window within the last 50 substeps
+      if (body_present(e, b) && e.asleep[b] && body_on(e, a) && !(e.sleep_count[a] > 0) && !(e.still_count[a] >= 50)) {
         v3 d = sub(ld3(e.body[a]), ld3(e.body[b]));
         float r = e.radius[a] + e.radius[b] + c->breaking;
         if (dot(d, d) < r * r) S.s.wake[b] = 1;
