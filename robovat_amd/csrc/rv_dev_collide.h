@@ -59,23 +59,27 @@ template <int N> RV_DEV float row_ror_f(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
 }
 template <int N> RV_DEV int row_ror_i(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x120 + N, 0xf, 0xf, false); }
-struct SupRed { float val; int idx; float x, y, z; };
-template <int N> RV_DEV SupRed sup_step(SupRed s) {
-  SupRed o;
-  o.val = row_ror_f<N>(s.val); o.idx = row_ror_i<N>(s.idx);
-  o.x = row_ror_f<N>(s.x); o.y = row_ror_f<N>(s.y); o.z = row_ror_f<N>(s.z);
-  bool take = (o.val > s.val) || (o.val == s.val && o.idx < s.idx);
-  return take ? o : s;
+// two-stage reduction: the largest projection (4 DPP max steps), then the lowest lane
+// index that attains it (4 DPP min steps) -- exactly the serial first-maximum -- and one
+// broadcast LDS read of the winning vertex
+template <int N> RV_DEV float row_ror_fmax(float x) {
+  float o = row_ror_f<N>(x);
+  return o > x ? o : x;
+}
+template <int N> RV_DEV int row_ror_imin(int x) {
+  int o = row_ror_i<N>(x);
+  return o < x ? o : x;
 }
 RV_DEV v3 support_v(const float* verts, int n, v3 d, float* proj) {
   const int sl = (int)threadIdx.x & 15;
   const int j = sl < n ? sl : n - 1;
-  SupRed s;
-  s.x = verts[3 * j]; s.y = verts[3 * j + 1]; s.z = verts[3 * j + 2];
-  s.val = dot(mk(s.x, s.y, s.z), d); s.idx = j;
-  s = sup_step<8>(s); s = sup_step<4>(s); s = sup_step<2>(s); s = sup_step<1>(s);
-  *proj = s.val;
-  return mk(s.x, s.y, s.z);
+  const float val = dot(mk(verts[3 * j], verts[3 * j + 1], verts[3 * j + 2]), d);
+  float m = val;
+  m = row_ror_fmax<8>(m); m = row_ror_fmax<4>(m); m = row_ror_fmax<2>(m); m = row_ror_fmax<1>(m);
+  int idx = (val == m) ? j : 16;
+  idx = row_ror_imin<8>(idx); idx = row_ror_imin<4>(idx); idx = row_ror_imin<2>(idx); idx = row_ror_imin<1>(idx);
+  *proj = m;
+  return mk(verts[3 * idx], verts[3 * idx + 1], verts[3 * idx + 2]);
 }
 #else
 RV_DEV v3 support_v(const float* verts, int n, v3 d, float* proj) {
