@@ -42,6 +42,7 @@ typedef struct {
   int active, frozen, shape;
   int asleep, sleep_count;
   int still_count; real still_ref[7];   /* pose window of the in-place oscillation test */
+  int undisturbed;                      /* woken, but has not left the pose window it was sleeping in */
   real aabb[6];                         /* world box (lo, hi) of the hulls + margin, taken when the body fell asleep */
   real scale, mass, inv_mass, inv_inertia[3], friction, radius;
 } orc_bparam;
@@ -1004,7 +1005,14 @@ static void sim_substep(const orc_world* w, orc_env* e) {
         }
       }
     }
-    for (int b = 0; b < RV_MAXB; ++b) if (wake[b]) { e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].still_count = 0; }
+    for (int b = 0; b < RV_MAXB; ++b) if (wake[b]) {
+      orc_bparam* P = &e->bp[b];
+      P->asleep = 0; P->sleep_count = 0;
+      /* open the pose window at the pose it was resting in */
+      P->still_count = 1; P->undisturbed = 1;
+      v3cpy(P->still_ref, e->body[b].p);
+      for (int k = 0; k < 4; ++k) P->still_ref[3 + k] = e->body[b].q[k];
+    }
   }
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!body_on(e, b)) continue;
@@ -1071,12 +1079,16 @@ static void sim_substep(const orc_world* w, orc_env* e) {
         }
         if (inside) P->still_count++;
         else {
+          P->undisturbed = 0;
           P->still_count = 1;
           v3cpy(P->still_ref, B->p);
           for (int k = 0; k < 4; ++k) P->still_ref[3 + k] = B->q[k];
         }
       }
-      if (e->bp[b].sleep_count >= c->sleep_steps || e->bp[b].still_count >= c->sleep_steps) {
+      /* a sleeper that was woken but never left the pose it was resting in goes back to
+       * sleep after a quarter of the usual wait */
+      int quick = e->bp[b].undisturbed && 4 * e->bp[b].still_count >= c->sleep_steps && 4 * e->bp[b].sleep_count >= c->sleep_steps;
+      if (e->bp[b].sleep_count >= c->sleep_steps || e->bp[b].still_count >= c->sleep_steps || quick) {
         e->bp[b].asleep = 1;
         v3set(B->v, R(0.0), R(0.0), R(0.0)); v3set(B->w, R(0.0), R(0.0), R(0.0));
         /* world box of the resting hulls: what the arm has to come near to wake the body */
@@ -1411,7 +1423,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   e->n_bodies = nb;
   for (;;) {
     real poses[RV_MAXB][7];
-    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].still_count = 0; }
+    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; }
     for (int i = 0; i < RV_NMAN; ++i) e->man[i].n = 0;
     sample_poses(w, e, &g, nb, poses);
     for (int i = 0; i < nb; ++i) {
@@ -1420,7 +1432,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
                              : c->movable_shapes[rng_randint(&g, c->n_movable_shapes)];
       real scale = rng_uniform(&g, (real)c->scale_range[0], (real)c->scale_range[1]);
       orc_bparam* p = &e->bp[i];
-      p->active = 1; p->frozen = 0; p->asleep = 0; p->sleep_count = 0; p->still_count = 0; p->shape = shape; p->scale = scale; p->friction = (real)c->drop_friction;
+      p->active = 1; p->frozen = 0; p->asleep = 0; p->sleep_count = 0; p->still_count = 0; p->undisturbed = 0; p->undisturbed = 0; p->shape = shape; p->scale = scale; p->friction = (real)c->drop_friction;
       body_set_mass(w, e, i, (real)c->drop_mass);
       v3cpy(e->body[i].p, poses[i]); memcpy(e->body[i].q, poses[i] + 3, sizeof(real) * 4);
       v3set(e->body[i].v, R(0.0), R(0.0), R(0.0)); v3set(e->body[i].w, R(0.0), R(0.0), R(0.0));
@@ -1639,7 +1651,7 @@ void orc_set_body_state(orc_world* w, const double* in) {
       for (int k = 0; k < 3; ++k) { B->p[k] = (real)o[k]; B->v[k] = (real)o[7 + k]; B->w[k] = (real)o[10 + k]; }
       for (int k = 0; k < 4; ++k) B->q[k] = (real)o[3 + k];
       w->env[i].man[TIDX(b)].n = 0; w->env[i].man[AIDX(b)].n = 0;
-      w->env[i].bp[b].asleep = 0; w->env[i].bp[b].sleep_count = 0; w->env[i].bp[b].still_count = 0;
+      w->env[i].bp[b].asleep = 0; w->env[i].bp[b].sleep_count = 0; w->env[i].bp[b].still_count = 0; w->env[i].bp[b].undisturbed = 0;
     }
   for (int i = 0; i < w->n; ++i) for (int k = 0; k < RV_NBB; ++k) w->env[i].man[BBIDX(k)].n = 0;
 }
@@ -1657,7 +1669,7 @@ void orc_set_body_params(orc_world* w, const double* in) {
     for (int b = 0; b < RV_MAXB; ++b) {
       const double* o = in + ((size_t)i * RV_MAXB + b) * 8;
       orc_bparam* p = &e->bp[b];
-      p->active = (int)o[0]; p->shape = (int)o[1]; p->scale = (real)o[2]; p->friction = (real)o[4]; p->frozen = (int)o[5]; p->asleep = 0; p->sleep_count = 0; p->still_count = 0;
+      p->active = (int)o[0]; p->shape = (int)o[1]; p->scale = (real)o[2]; p->friction = (real)o[4]; p->frozen = (int)o[5]; p->asleep = 0; p->sleep_count = 0; p->still_count = 0; p->undisturbed = 0;
       if (b == 0) { e->table_z = (real)o[6]; table_prepare(w, e); }
       if (p->active) body_set_mass(w, e, b, (real)o[3]);
     }

@@ -100,7 +100,7 @@ PUSH_ENV_CONFIG = {
         'SOLVER_TOL': 1e-5,
         'SLEEP_LINEAR': 0.02, 'SLEEP_ANGULAR': 0.5, 'SLEEP_STEPS': 200,
         'SLEEP_POSITION_WINDOW': 1e-3, 'SLEEP_ROTATION_WINDOW': 0.01,
-        'NARROWPHASE_GATE': 5e-4, 'NARROWPHASE_MAX_AGE': 8,
+        'NARROWPHASE_GATE': 1e-3, 'NARROWPHASE_MAX_AGE': 8,
     },
 }
 

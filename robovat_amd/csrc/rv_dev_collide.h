@@ -81,7 +81,23 @@ RV_DEV v3 support_v(const float* verts, int n, v3 d, float* proj) {
   *proj = m;
   return mk(verts[3 * idx], verts[3 * idx + 1], verts[3 * idx + 2]);
 }
+// largest projection only (no witness vertex)
+RV_DEV float support_proj(const float* verts, int n, v3 d) {
+  const int sl = (int)threadIdx.x & 15;
+  const int j = sl < n ? sl : n - 1;
+  float m = dot(mk(verts[3 * j], verts[3 * j + 1], verts[3 * j + 2]), d);
+  m = row_ror_fmax<8>(m); m = row_ror_fmax<4>(m); m = row_ror_fmax<2>(m); m = row_ror_fmax<1>(m);
+  return m;
+}
 #else
+RV_DEV float support_proj(const float* verts, int n, v3 d) {
+  float bd = dot(ld3(verts), d);
+  for (int i = 1; i < n; ++i) {
+    float x = dot(ld3(verts + 3 * i), d);
+    if (x > bd) bd = x;
+  }
+  return bd;
+}
 RV_DEV v3 support_v(const float* verts, int n, v3 d, float* proj) {
   v3 best = ld3(verts);
   float bd = dot(best, d);

@@ -84,6 +84,7 @@ struct DevEnv {
   int active[RV_MAXB], frozen[RV_MAXB], shape[RV_MAXB];
   int asleep[RV_MAXB], sleep_count[RV_MAXB];
   int still_count[RV_MAXB]; float still_ref[RV_MAXB][7];   // pose window of the in-place oscillation test
+  int undisturbed[RV_MAXB];   // woken, but has not left the pose window it was sleeping in
   float baabb[RV_MAXB][6];   // world box (lo, hi) of the hulls + margin, taken when the body fell asleep
   float scale[RV_MAXB], mass[RV_MAXB], inv_mass[RV_MAXB], inv_inertia[RV_MAXB][3], friction[RV_MAXB], radius[RV_MAXB];
   float table_z;
@@ -560,9 +561,8 @@ RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b
   dir[3] = mk(-dir[1].x, -dir[1].y, -dir[1].z);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float pj;
-    support_v(A, nA, dir[j], &pj); extA[j] = pj + mg;
-    support_v(B, nB, dir[j], &pj); extB[j] = pj + mg;
+    extA[j] = support_proj(A, nA, dir[j]) + mg;
+    extB[j] = support_proj(B, nB, dir[j]) + mg;
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -1218,7 +1218,12 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   RV_LANES_BEGIN
     if (lane < RV_MAXB) {
       int b = lane; DevEnv& e = S.e;
-      if (S.s.wake[b]) { e.asleep[b] = 0; e.sleep_count[b] = 0; e.still_count[b] = 0; }
+      if (S.s.wake[b]) {
+        e.asleep[b] = 0; e.sleep_count[b] = 0;
+        // open the pose window at the pose it was resting in
+        e.still_count[b] = 1; e.undisturbed[b] = 1;
+        st3(e.still_ref[b], ld3(e.body[b])); stq(e.still_ref[b] + 3, ldq(e.body[b] + 3));
+      }
       if (body_on(e, b)) {
         float dt = c->dt;
         e.body[b][9] += c->gravity_z * dt;
@@ -1598,9 +1603,12 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
               inside = dot(dp, dp) < c->sleep_pos_win * c->sleep_pos_win && dqm < c->sleep_rot_win;
             }
             if (inside) e.still_count[b]++;
-            else { e.still_count[b] = 1; st3(e.still_ref[b], p); stq(e.still_ref[b] + 3, q); }
+            else { e.undisturbed[b] = 0; e.still_count[b] = 1; st3(e.still_ref[b], p); stq(e.still_ref[b] + 3, q); }
           }
-          if (e.sleep_count[b] >= c->sleep_steps || e.still_count[b] >= c->sleep_steps) {
+          // a sleeper that was woken but never left the pose it was resting in goes back
+          // to sleep after a quarter of the usual wait
+          const int quick = e.undisturbed[b] && 4 * e.still_count[b] >= c->sleep_steps && 4 * e.sleep_count[b] >= c->sleep_steps;
+          if (e.sleep_count[b] >= c->sleep_steps || e.still_count[b] >= c->sleep_steps || quick) {
             e.asleep[b] = 1;
             st3(e.body[b] + 7, mk(0, 0, 0)); st3(e.body[b] + 10, mk(0, 0, 0));
             // world box of the resting hulls: what the arm has to come near to wake the body
@@ -2076,7 +2084,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
     RV_LANES_BEGIN
       DevEnv& e = S.e;
       if (lane == 0) {
-        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.still_count[b] = 0; }
+        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; }
         sample_poses(S, K, e.n_bodies);
       }
       if (lane >= 1 && lane <= RV_NMAN) e.man[lane - 1].n = 0;
@@ -2090,7 +2098,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
           int shape = use_target ? c->target_shapes[rng_randint(g, c->n_target_shapes)]
                                  : c->movable_shapes[rng_randint(g, c->n_movable_shapes)];
           float sc = rng_uniform(g, c->scale_range[0], c->scale_range[1]);
-          e.active[i] = 1; e.frozen[i] = 0; e.asleep[i] = 0; e.sleep_count[i] = 0; e.still_count[i] = 0; e.shape[i] = shape; e.scale[i] = sc; e.friction[i] = c->drop_friction;
+          e.active[i] = 1; e.frozen[i] = 0; e.asleep[i] = 0; e.sleep_count[i] = 0; e.still_count[i] = 0; e.undisturbed[i] = 0; e.shape[i] = shape; e.scale[i] = sc; e.friction[i] = c->drop_friction;
           body_set_mass(e, K, i, c->drop_mass);
           cache_shape_meta(S, K, i);
           for (int k = 0; k < 3; ++k) e.body[i][k] = S.s.poses[i][k];

@@ -83,7 +83,7 @@ void emu_set_body_state(EmuWorld* w, const float* in) {
   for (int i = 0; i < w->n; ++i) {
     for (int b = 0; b < RV_MAXB; ++b) for (int k = 0; k < 13; ++k) w->envs[i].body[b][k] = in[((size_t)i * RV_MAXB + b) * 13 + k];
     for (int m = 0; m < RV_NMAN; ++m) w->envs[i].man[m].n = 0;
-    for (int b = 0; b < RV_MAXB; ++b) { w->envs[i].asleep[b] = 0; w->envs[i].sleep_count[b] = 0; w->envs[i].still_count[b] = 0; }
+    for (int b = 0; b < RV_MAXB; ++b) { w->envs[i].asleep[b] = 0; w->envs[i].sleep_count[b] = 0; w->envs[i].still_count[b] = 0; w->envs[i].undisturbed[b] = 0; }
   }
 }
 void emu_get_body_params(EmuWorld* w, float* out) {
@@ -98,7 +98,7 @@ void emu_set_body_params(EmuWorld* w, const float* in) {
     DevEnv& e = w->envs[i]; int nb = 0;
     for (int b = 0; b < RV_MAXB; ++b) {
       const float* o = in + ((size_t)i * RV_MAXB + b) * 8;
-      e.active[b] = (int)o[0]; e.shape[b] = (int)o[1]; e.scale[b] = o[2]; e.friction[b] = o[4]; e.frozen[b] = (int)o[5]; e.asleep[b] = 0; e.sleep_count[b] = 0; e.still_count[b] = 0;
+      e.active[b] = (int)o[0]; e.shape[b] = (int)o[1]; e.scale[b] = o[2]; e.friction[b] = o[4]; e.frozen[b] = (int)o[5]; e.asleep[b] = 0; e.sleep_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0;
       if (b == 0) e.table_z = o[6];
       if (e.active[b]) { body_set_mass(e, K, b, o[3]); nb++; }
     }
