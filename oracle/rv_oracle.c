@@ -911,40 +911,40 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
         }
       }
   }
-  int any_bb = 0;
-  for (int k = 0; k < RV_NBB; ++k) if (use[BBIDX(k)]) any_bb += e->man[BBIDX(k)].n;
-  if (!any_bb) {
-    /* no body-body coupling: every body is an independent problem and stops
-     * on its own residual */
-    for (int b = 0; b < RV_MAXB; ++b) {
-      if (!use[TIDX(b)]) continue;
-      orc_manifold* mt = &e->man[TIDX(b)];
-      orc_manifold* ma = &e->man[AIDX(b)];
-      if (mt->n + ma->n == 0) continue;
-      for (int it = 0; it < c->solver_iters; ++it) {
-        real res = R(0.0);
-        for (int i = 0; i < mt->n; ++i) res = rmax(res, point_solve(e, 0, b, -1, mt, i, &rows[TIDX(b)][i]));
-        for (int i = 0; i < ma->n; ++i) res = rmax(res, point_solve(e, 2, b, -1, ma, i, &rows[AIDX(b)][i]));
-        if (res < (real)c->solver_tol) break;
-      }
+  /* islands: awake bodies coupled (transitively) by body-body manifolds that hold
+   * points.  An island is an independent problem: its rows are visited body by body
+   * (table rows, arm rows), then pair by pair in colour-round order, and it stops on
+   * its own residual. */
+  int label[RV_MAXB];
+  for (int b = 0; b < RV_MAXB; ++b) label[b] = b;
+  for (int pass = 0; pass < RV_MAXB; ++pass)
+    for (int k = 0; k < RV_NBB; ++k) {
+      if (!use[BBIDX(k)] || e->man[BBIDX(k)].n == 0) continue;
+      int la = label[BB_A[k]], lb = label[BB_B[k]];
+      int lo = la < lb ? la : lb;
+      label[BB_A[k]] = lo; label[BB_B[k]] = lo;
     }
-    return;
-  }
-  for (int it = 0; it < c->solver_iters; ++it) {
-    real res = R(0.0);
-    for (int b = 0; b < RV_MAXB; ++b) {
-      orc_manifold* m = &e->man[TIDX(b)];
-      if (use[TIDX(b)]) for (int i = 0; i < m->n; ++i) res = rmax(res, point_solve(e, 0, b, -1, m, i, &rows[TIDX(b)][i]));
-      m = &e->man[AIDX(b)];
-      if (use[AIDX(b)]) for (int i = 0; i < m->n; ++i) res = rmax(res, point_solve(e, 2, b, -1, m, i, &rows[AIDX(b)][i]));
-    }
-    for (int rd = 0; rd < 3; ++rd)
-      for (int x = 0; x < 2; ++x) {
-        int k = BB_ROUND[rd][x];
-        orc_manifold* m = &e->man[BBIDX(k)];
-        if (use[BBIDX(k)]) for (int i = 0; i < m->n; ++i) res = rmax(res, point_solve(e, 1, BB_A[k], BB_B[k], m, i, &rows[BBIDX(k)][i]));
+  for (int root = 0; root < RV_MAXB; ++root) {
+    if (!use[TIDX(root)] || label[root] != root) continue;
+    for (int it = 0; it < c->solver_iters; ++it) {
+      real res = R(0.0);
+      int rows_seen = 0;
+      for (int b = root; b < RV_MAXB; ++b) {
+        if (!use[TIDX(b)] || label[b] != root) continue;
+        orc_manifold* m = &e->man[TIDX(b)];
+        for (int i = 0; i < m->n; ++i) { res = rmax(res, point_solve(e, 0, b, -1, m, i, &rows[TIDX(b)][i])); rows_seen++; }
+        m = &e->man[AIDX(b)];
+        for (int i = 0; i < m->n; ++i) { res = rmax(res, point_solve(e, 2, b, -1, m, i, &rows[AIDX(b)][i])); rows_seen++; }
       }
-    if (res < (real)c->solver_tol) break;   /* residual-based early exit */
+      for (int rd = 0; rd < 3; ++rd)
+        for (int x = 0; x < 2; ++x) {
+          int k = BB_ROUND[rd][x];
+          if (!use[BBIDX(k)] || label[BB_A[k]] != root) continue;
+          orc_manifold* m = &e->man[BBIDX(k)];
+          for (int i = 0; i < m->n; ++i) { res = rmax(res, point_solve(e, 1, BB_A[k], BB_B[k], m, i, &rows[BBIDX(k)][i])); rows_seen++; }
+        }
+      if (rows_seen == 0 || res < (real)c->solver_tol) break;   /* residual-based early exit */
+    }
   }
 }
 

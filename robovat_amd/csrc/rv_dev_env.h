@@ -1460,25 +1460,35 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
 
   RV_STOP(4)
   RV_PROF(4)
-  // PGS.  Bodies that are not coupled by a body-body contact are independent
-  // problems: each body lane runs warm start + all its iterations in ONE phase
-  // with rows and impulses in registers, stopping when ITS largest impulse
-  // change drops below solver_tol.  With body-body contacts the iterations are
-  // interleaved with colour rounds and the stop test uses the env-wide residual.
-  int n_rows = 0, any_bb = 0;
-  for (int b = 0; b < RV_MAXB; ++b)
-    if (body_on(S.e, b)) n_rows += S.e.man[RV_TIDX(b)].n + S.e.man[RV_AIDX(b)].n;
-  for (int k = 0; k < RV_NBB; ++k)
-    if (body_on(S.e, bb_a(k)) && body_on(S.e, bb_b(k))) any_bb += S.e.man[RV_BBIDX(k)].n;
-  n_rows += any_bb;
-  if (n_rows > 0 && !any_bb) {
-    RV_LANES_BEGIN
-      if (lane < RV_MAXB) {
-        int b = lane; DevEnv& e = S.e;
+  // PGS over islands: awake bodies coupled (transitively) by body-body manifolds
+  // that hold points.  An island is an independent problem solved by ONE lane (its
+  // lowest body): a lone body keeps rows' impulses and its velocity in registers; a
+  // coupled island visits its bodies' table / arm rows, then its pairs in colour-round
+  // order, velocities and impulses in LDS -- no barriers inside the iteration loop.
+  // Every island stops on its own residual.
+  int label[RV_MAXB];
+#pragma unroll
+  for (int b = 0; b < RV_MAXB; ++b) label[b] = b;
+  for (int pass = 0; pass < RV_MAXB; ++pass)
+#pragma unroll
+    for (int k = 0; k < RV_NBB; ++k) {
+      const int a_ = bb_a(k), b_ = bb_b(k);
+      if (!(body_on(S.e, a_) && body_on(S.e, b_)) || S.e.man[RV_BBIDX(k)].n == 0) continue;
+      const int lo = label[a_] < label[b_] ? label[a_] : label[b_];
+      label[a_] = lo; label[b_] = lo;
+    }
+  RV_LANES_BEGIN
+    if (lane < RV_MAXB && body_on(S.e, lane) && label[lane] == lane) {
+      const int root = lane; DevEnv& e = S.e;
+      int members = 0;
+#pragma unroll
+      for (int b = 0; b < RV_MAXB; ++b) members += (body_on(e, b) && label[b] == root);
+      if (members == 1) {
+        const int b = root;
         DevMan& mt = e.man[RV_TIDX(b)];
         DevMan& ma = e.man[RV_AIDX(b)];
         const int nt = mt.n, na = ma.n;
-        if (body_on(e, b) && nt + na > 0) {
+        if (nt + na > 0) {
           BV A = ld_bv(e, b); float ima = e.inv_mass[b];
           Lam lt[4], la[4];
 #pragma unroll
@@ -1507,65 +1517,46 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
             if (i < na) { ma.ln[i] = la[i].n; ma.lt1[i] = la[i].t1; ma.lt2[i] = la[i].t2; }
           }
         }
-      }
-    RV_LANES_END
-  } else if (n_rows > 0) {
-    for (int it = -1; it < c->solver_iters; ++it) {
-      RV_LANES_BEGIN
-        if (lane < 16) S.s.res[lane] = 0.0f;
-        if (lane < RV_MAXB) {
-          int b = lane; DevEnv& e = S.e;
-          DevMan& mt = e.man[RV_TIDX(b)];
-          DevMan& ma = e.man[RV_AIDX(b)];
-          if (body_on(e, b) && mt.n + ma.n > 0) {
-            BV A = ld_bv(e, b); float ima = e.inv_mass[b];
-            float res = 0.0f;
-            for (int i = 0; i < mt.n; ++i) {
-              Row r = S.s.u.rows[RV_TIDX(b)][i];
-              Lam l; l.n = mt.ln[i]; l.t1 = mt.lt1[i]; l.t2 = mt.lt2[i];
-              if (it < 0) warm_apply(A, nullptr, ima, 0.0f, l, r);
-              else { res = fmaxr(res, point_solve(A, nullptr, ima, 0.0f, l, r)); mt.ln[i] = l.n; mt.lt1[i] = l.t1; mt.lt2[i] = l.t2; }
-            }
-            for (int i = 0; i < ma.n; ++i) {
-              Row r = S.s.u.rows[RV_AIDX(b)][i];
-              Lam l; l.n = ma.ln[i]; l.t1 = ma.lt1[i]; l.t2 = ma.lt2[i];
-              if (it < 0) warm_apply(A, nullptr, ima, 0.0f, l, r);
-              else { res = fmaxr(res, point_solve(A, nullptr, ima, 0.0f, l, r)); ma.ln[i] = l.n; ma.lt1[i] = l.t1; ma.lt2[i] = l.t2; }
+      } else {
+        for (int it = -1; it < c->solver_iters; ++it) {   // it == -1: warm start
+          float res = 0.0f;
+          for (int b = root; b < RV_MAXB; ++b) {
+            if (!(body_on(e, b) && label[b] == root)) continue;
+            BV A = ld_bv(e, b); const float ima = e.inv_mass[b];
+            for (int kind = 0; kind < 2; ++kind) {
+              DevMan& m = e.man[kind == 0 ? RV_TIDX(b) : RV_AIDX(b)];
+              const int mi = kind == 0 ? RV_TIDX(b) : RV_AIDX(b);
+              for (int i = 0; i < m.n; ++i) {
+                Row r = S.s.u.rows[mi][i];
+                Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
+                if (it < 0) warm_apply(A, nullptr, ima, 0.0f, l, r);
+                else { res = fmaxr(res, point_solve(A, nullptr, ima, 0.0f, l, r)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
+              }
             }
             st_bv(e, b, A);
-            S.s.res[b] = res;
           }
-        }
-      RV_LANES_END
-      for (int rd = 0; rd < 3; ++rd) {
-        RV_LANES_BEGIN
-          if (lane < 2) {
-            int k = bb_round_pair(rd, lane); DevEnv& e = S.e;
-            DevMan& m = e.man[RV_BBIDX(k)];
-            int a = bb_a(k), b = bb_b(k);
-            if (m.n > 0 && body_on(e, a) && body_on(e, b)) {
-              BV A = ld_bv(e, a), B = ld_bv(e, b);
-              float ima = e.inv_mass[a], imb = e.inv_mass[b];
-              float res = 0.0f;
+          for (int rd = 0; rd < 3; ++rd)
+            for (int x = 0; x < 2; ++x) {
+              const int k = bb_round_pair(rd, x);
+              const int a_ = bb_a(k), b_ = bb_b(k);
+              if (!(body_on(e, a_) && body_on(e, b_)) || label[a_] != root) continue;
+              DevMan& m = e.man[RV_BBIDX(k)];
+              if (m.n == 0) continue;
+              BV A = ld_bv(e, a_), B = ld_bv(e, b_);
+              const float ima = e.inv_mass[a_], imb = e.inv_mass[b_];
               for (int i = 0; i < m.n; ++i) {
                 Row r = S.s.u.rows[RV_BBIDX(k)][i];
                 Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
                 if (it < 0) warm_apply(A, &B, ima, imb, l, r);
                 else { res = fmaxr(res, point_solve(A, &B, ima, imb, l, r)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
               }
-              st_bv(e, a, A); st_bv(e, b, B);
-              S.s.res[4 + rd * 2 + lane] = res;
+              st_bv(e, a_, A); st_bv(e, b_, B);
             }
-          }
-        RV_LANES_END
-      }
-      if (it >= 0) {
-        float res = 0.0f;
-        for (int k = 0; k < 10; ++k) res = fmaxr(res, S.s.res[k]);
-        if (res < c->solver_tol) break;
+          if (it >= 0 && res < c->solver_tol) break;
+        }
       }
     }
-  }
+  RV_LANES_END
 
   RV_STOP(5)
   RV_PROF(5)
