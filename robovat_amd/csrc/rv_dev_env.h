@@ -2052,6 +2052,8 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
   RV_LANES_BEGIN
     DevEnv& e = S.e;
     if (lane == 0) {
+      // per-launch scratch state that a reset kernel does not get from env_enter
+      S.s.jt_applied = 0; S.s.kin_fresh = 0; S.s.clr_valid = 0;
       S.s.rng = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RESET, (uint32_t)e.reset_count);
       e.reset_count++;
       if (zero_counters) { e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; e.stepped = 0; }
