@@ -168,3 +168,18 @@ def test_async_rollout_is_a_prefix_of_the_lockstep_trajectories():
     _cmp(world, ref, 1e-6)
     ws, rs = world.stats(), ref.stats()
     assert ws['env_steps'] == rs['env_steps'] == total and ws['substeps'] == rs['substeps']
+
+
+def test_wide_rollout_matches_oracle_bit_for_bit():
+    """512 envs x 8 steps in one launch (coasting, lazy kinematics, wake queries with
+    distance-bound culling, island solver, register-resident motor runs, resets): every
+    body state, joint state, counter and manifold size equals the float oracle's."""
+    world, ref, cfg = _worlds(512, seed=2024, MAX_STEPS=5)
+    world.reset(); ref.reset()
+    world.rollout(8, first_macro_index=0, auto_reset=True, record=False)
+    ref.rollout(8, 0, True)
+    err = _cmp(world, ref, 0.0)
+    assert err == 0.0
+    ws, rs = world.stats(), ref.stats()
+    for k in ('env_steps', 'substeps', 'awake_substeps', 'max_substeps'):
+        assert ws[k] == rs[k], k
