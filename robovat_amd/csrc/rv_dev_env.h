@@ -47,9 +47,14 @@ namespace rv {
 // RV_PROFILE build only: lane 0 adds the shader-clock time since the last mark to slot i
 #if defined(RV_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void g_shared_prof(int i, unsigned long long t);
+__device__ __forceinline__ void g_shared_profg(int g, int i, unsigned long long t);
 #define RV_PROF(i) { if (threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_shared_prof(i, t_); } }
+// per-group marks inside the narrow phase: the first lane of 16-lane group g adds the time
+// since ITS last mark to slot 12 + i (g = 0: table owners of bodies 0/2, g = 1: their arm owners)
+#define RV_PROFG(i) { if (((int)threadIdx.x & 15) == 0 && (int)threadIdx.x < 32) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_shared_profg(((int)threadIdx.x >> 4), (i), t_); } }
 #else
 #define RV_PROF(i)
+#define RV_PROFG(i)
 #endif
 
 #define RV_STREAM_RESET  1u
@@ -107,7 +112,7 @@ struct DevEnv {
   int num_total_steps, num_unsafe, num_ineffective, num_useful, num_successes;
   int pad_[3];
 #ifdef RV_PROFILE
-  unsigned long long prof[12], prof_t;   // tools/prof_rollout.py: shader-clock time per substep part
+  unsigned long long prof[24], prof_t, prof_t2[4];   // tools/prof_rollout.py: shader-clock time per substep part
 #endif
 };
 static_assert(sizeof(DevEnv) % 4 == 0, "DevEnv is copied word-wise");
@@ -538,13 +543,17 @@ RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b
                         const float* A, int nA, const float* B, int nB, v3 guess, DevMan* m, float* out_dist) {
   float mg = K.cfg->margin, brk = K.cfg->breaking;
   v3 n, pa, pb; float dist;
-  if (!gjk_epa(A, nA, B, nB, guess, brk + 2.0f * mg, &n, &dist, &pa, &pb)) return 0;
+  RV_PROFG(0)
+  const int hit_ = gjk_epa(A, nA, B, nB, guess, brk + 2.0f * mg, &n, &dist, &pa, &pb);
+  RV_PROFG(1)
+  if (!hit_) return 0;
   float d = dist - 2.0f * mg;
   if (d > brk) return 0;
   if (!(dot(n, n) > 0.5f)) return 0;   // safety net: never accept a non-unit normal
   *out_dist = d;
   if (!m) return 1;
   manifold_add_world(S, K, kind, a, b, col, *m, madd(pa, n, -mg), madd(pb, n, mg), n, d);
+  RV_PROFG(2)
   // feature stage: only while the manifold is incomplete, or every
   // RV_FEATURE_PERIOD-th full pass (cached points are refreshed every substep)
   {
@@ -590,6 +599,7 @@ RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b
       if (ok) manifold_add_world(S, K, kind, a, b, col, *m, madd(pt, n, -mg), madd(vb, n, mg), n, gap);
     }
   }
+  RV_PROFG(3)
   return 1;
 }
 
@@ -1319,6 +1329,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
 #if !defined(__HIPCC__) || defined(RV_EMULATE)
     if ((lane & 15) != 0) continue;   // host emulation: one lane per group does the work
 #endif
+    RV_PROFG(5)   // (profiling build) time outside the narrow phase goes to a dump slot
     float brk = c->breaking;
     v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
     v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
@@ -1380,7 +1391,9 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       if (clear) e.man[mi].n = 0;
       if (live) {
         DevMan& m = e.man[mi];
+        RV_PROFG(0)
         int lost = manifold_refresh(S, K, owner < RV_MAXB ? 0 : (owner < RV_MAXB + RV_NBB ? 1 : 2), a, b, m);
+        RV_PROFG(4)
         {
           // narrow-phase gating on the travel of the two shapes since the last full pass
           float mo = S.s.mot[a];
@@ -1635,6 +1648,9 @@ static thread_local Shared g_shared;
 #if defined(RV_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void g_shared_prof(int i, unsigned long long t) {
   g_shared.e.prof[i] += t - g_shared.e.prof_t; g_shared.e.prof_t = t;
+}
+__device__ __forceinline__ void g_shared_profg(int g, int i, unsigned long long t) {
+  g_shared.e.prof[12 + g * 6 + i] += t - g_shared.e.prof_t2[g]; g_shared.e.prof_t2[g] = t;
 }
 #endif
 // Consts whose cfg / arm point at the LDS copies (statically known address)

@@ -37,7 +37,7 @@ L = lib.load()
 
 
 def prof():
-    out = torch.zeros((n, 12), dtype=torch.int64, device=w.device)
+    out = torch.zeros((n, 24), dtype=torch.int64, device=w.device)
     rc = L.rv_debug_profile(w.h, C.c_void_p(out.data_ptr()))
     assert rc == 0
     w.synchronize()
@@ -63,6 +63,12 @@ print('%-36s %10s %10s' % ('part', 'mean env', 'slowest'))
 for k in range(12):
     print('%-36s %9.1f%% %9.1f%%' % (names_[k], 100 * p[:, k].mean() / tot.mean(), 100 * p[slow, k] / tot[slow]))
 print('mean env busy time / slowest env = %.3f' % (tot.mean() / tot.max()))
+gn = ['other (culling, loop, idle rounds)', 'GJK/EPA', 'first manifold point', 'feature stage', 'manifold refresh', '-']
+for g, gname in ((0, 'group 0: table owners of bodies 0/2 (+ BB, AT owners)'), (1, 'group 1: arm owners of bodies 0/2 (+ BB, AT owners)')):
+    gt = p[:, 12 + 6 * g: 18 + 6 * g]
+    print(gname + ': share of the narrow-phase slot, mean env / slowest env')
+    for k in range(5):
+        print('   %-36s %6.1f%% %6.1f%%' % (gn[k], 100 * gt[:, k].mean() / p[:, 3].mean(), 100 * gt[slow, k] / p[slow, 3]))
 cnt = w.env_counters().cpu().numpy()
 order = np.argsort(-tot)[:6]
 print('slowest envs: id, ms, substeps, awake, pairs')
