@@ -65,3 +65,18 @@ def test_vec_env_policies_on_device():
     st = env.stats()
     # the heuristic aims pushes at bodies: far more effective steps than random pushes
     assert st['env_steps'] == 64 and (st['useful'] + st['unsafe']) > 16
+
+
+def test_rollout_async_argument_errors_and_accounting():
+    import numpy as np
+    from robovat_amd import configs, scenes, lib
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(n_envs=8, seed=5, shape_names=names)
+    w = lib.World(cfg, scene, device=0)
+    w.reset()
+    with pytest.raises(ValueError):
+        w.rollout_async(0)
+    taken = w.rollout_async(24, first_macro_index=0).cpu().numpy()
+    st = w.stats()
+    assert taken.sum() == 24 == st['env_steps'] and (taken >= 1).all()
+    w.close()
