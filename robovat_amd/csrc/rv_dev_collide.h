@@ -1,10 +1,12 @@
 // rv_dev_collide.h — GJK / EPA narrow phase and persistent 4-point contact
 // manifolds for the CDNA4 env kernel.
 //
-// One lane owns one manifold slot and runs the convex queries of its pair(s);
-// the simplex lives in registers (all array indices are compile-time after
-// unrolling), hull vertices are read from the env's LDS block, the rarely
-// needed EPA polytope lives in an LDS workspace guarded by a wave-level lock.
+// A 16-lane group owns one manifold slot at a time and runs the convex queries
+// of its pair(s): one scalar program executed redundantly by the group, except
+// in support_v() where every lane holds one hull vertex and DPP all-reduces pick
+// the extreme one.  The simplex lives in registers (all array indices are
+// compile-time after unrolling), hull vertices are read from the env's LDS
+// block, the rarely needed EPA polytope lives in per-lane private memory.
 #pragma once
 #include "rv_dev_math.h"
 
@@ -238,7 +240,7 @@ RV_DEV int simplex_solve(Simplex& s, v3* vout) {
   return 0;
 }
 
-// EPA on an origin-enclosing tetrahedron; polytope in the LDS workspace E.
+// EPA on an origin-enclosing tetrahedron; polytope in the private workspace E.
 RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const Simplex& s,
                          v3* out_nf, float* out_depth, v3* pa, v3* pb) {
   EpaWork E;  // private (scratch) memory: deep penetration is rare, LDS is not spent on it
