@@ -51,10 +51,10 @@ struct DevMan {
 // Support vertex (by value) of a hull stored as n <= 16 packed xyz triples.
 //
 // Device: the 16 lanes of a group each hold one vertex (index clamped to n-1),
-// take the dot product and run a 4-step DPP row-rotate arg-max all-reduce that
-// carries (value, index, xyz); ties go to the lowest index, which is exactly
-// what the serial first-maximum loop returns, and a clamped duplicate can never
-// beat its original.  Every lane of the group ends up with the same result.
+// take the dot product and run two 4-step DPP row-rotate all-reduces: the largest
+// projection, then the lowest lane index attaining it -- exactly what the serial
+// first-maximum loop returns (a clamped duplicate can never beat its original).
+// Every lane of the group ends up with the same result.
 // Host emulation: the serial loop.
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
 template <int N> RV_DEV float row_ror_f(float x) {
