@@ -1,0 +1,1 @@
+"""robovat_amd."""

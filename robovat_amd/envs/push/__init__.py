@@ -1,0 +1,1 @@
+"""PushEnv: host classes around the device phase machine."""

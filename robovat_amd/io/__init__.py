@@ -1,0 +1,1 @@
+"""Episode generation loop (host side)."""
