@@ -195,7 +195,11 @@ LINK_NAMES = (['right_l%d' % i for i in range(7)] +
               ['right_hand', 'right_gripper_l_finger_tip',
                'right_gripper_r_finger_tip'])
 FINGER_TIP_OFFSET = 0.14
-_LINK_RADIUS = [0.07, 0.07, 0.06, 0.06, 0.05, 0.05, 0.045]
+# half-width added around each link's segment.  Link 0 is the round base housing that
+# only turns about the vertical axis: its box is the one INSCRIBED in the 7 cm housing
+# (0.07 / sqrt 2), because the corners of a circumscribed box would sweep through space
+# the housing never enters and brush bodies resting at the near table edge (x = 0.22)
+_LINK_RADIUS = [0.05, 0.07, 0.06, 0.06, 0.05, 0.05, 0.045]
 
 
 def make_arm(base_pos=(0.0, 0.0, 0.0), base_rpy=(0.0, 0.0, 0.0)):
