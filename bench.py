@@ -188,7 +188,7 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath) and args.mode == 'rollout':
             # HBM bytes per env-substep measured offline with rocprofv3 PMC passes on this
-            # same command (profiles/r01_h_hbm_traffic.txt), scaled to this launch
+            # same command (profiles/r01_i_hbm_traffic.txt), scaled to this launch
             with open(tpath) as f:
                 traffic = json.load(f)['hbm_bytes_per_env_substep'] * (substeps / launches)
         out = {
