@@ -1479,14 +1479,17 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   // coupled island visits its bodies' table / arm rows, then its pairs in colour-round
   // order, velocities and impulses in LDS -- no barriers inside the iteration loop.
   // Every island stops on its own residual.
-  int label[RV_MAXB];
+  int label[RV_MAXB], on_[RV_MAXB], act_[RV_NBB];
 #pragma unroll
-  for (int b = 0; b < RV_MAXB; ++b) label[b] = b;
+  for (int b = 0; b < RV_MAXB; ++b) { label[b] = b; on_[b] = body_on(S.e, b); }
+#pragma unroll
+  for (int k = 0; k < RV_NBB; ++k) act_[k] = on_[bb_a(k)] && on_[bb_b(k)] && S.e.man[RV_BBIDX(k)].n != 0;
+#pragma unroll
   for (int pass = 0; pass < RV_MAXB; ++pass)
 #pragma unroll
     for (int k = 0; k < RV_NBB; ++k) {
       const int a_ = bb_a(k), b_ = bb_b(k);
-      if (!(body_on(S.e, a_) && body_on(S.e, b_)) || S.e.man[RV_BBIDX(k)].n == 0) continue;
+      if (!act_[k]) continue;
       const int lo = label[a_] < label[b_] ? label[a_] : label[b_];
       label[a_] = lo; label[b_] = lo;
     }
