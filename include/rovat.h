@@ -269,8 +269,20 @@ int  rv_get_env_counters(rv_world* w, int32_t* d_out /* [N][RV_NCOUNTERS]: sim_s
 
 /* ---- ControllableBody.set_target_joint_positions / set_target_link_pose
  *      (controllable_body.py:263-345) via RobotCommand (simulator.py:226-244). */
-int  rv_set_joint_targets(rv_world* w, const float* d_q /* [N][RV_NLIMB] */);
-int  rv_set_link_target(rv_world* w, const float* d_pose /* [N][7] pos+xyzw */);
+/*      timeout (s) / threshold (rad): <= 0 selects the robot config's LIMB_TIMEOUT /
+ *      LIMB_POSITION_THRESHOLD (sawyer_sim.py:201-204). */
+int  rv_set_joint_targets(rv_world* w, const float* d_q /* [N][RV_NLIMB] */, float timeout, float threshold);
+int  rv_set_link_target(rv_world* w, const float* d_pose /* [N][7] pos+xyzw */, float timeout, float threshold);
+/* ---- BulletPhysics.position_control_array (bullet_physics.py:1061-1104):
+ *      POSITION_CONTROL motor targets (gains POSITION_GAIN / VELOCITY_GAIN,
+ *      controllable_body.py:17-18) for the joints whose mask byte is non-zero
+ *      (d_mask == NULL: all RV_NJ joints).  Bypasses the JointTarget layer. */
+int  rv_set_motor_targets(rv_world* w, const float* d_q /* [N][RV_NJ] */, const uint8_t* d_mask /* [N][RV_NJ] or NULL */);
+/* ---- SawyerSim.grip (sawyer_sim.py:362-392): value in [0, 1], 0 = open. */
+int  rv_grip(rv_world* w, float value);
+/* ---- ControllableBody.reset_targets (controllable_body.py:347-350): drop the
+ *      link / joint targets; the motors keep their last commanded positions. */
+int  rv_reset_targets(rv_world* w);
 /* ---- BulletPhysics.compute_inverse_kinematics (bullet_physics.py:1203-1262). */
 int  rv_compute_ik(rv_world* w, const float* d_pose /* [N][7] */, float* d_q /* [N][RV_NLIMB] */);
 
@@ -293,6 +305,10 @@ typedef struct rv_obs_buffers {
   int64_t* d_is_safe;      /* [N]                                               */
   int64_t* d_is_effective; /* [N]                                               */
   float*   d_point_cloud;  /* [N][RV_MAXB][num_points][3]                       */
+  /* the other PoseObs modalities (pose_obs.py:53-73), zero rows for absent bodies */
+  float*   d_pose;         /* [N][RV_MAXB][6]  position + static-xyz Euler      */
+  float*   d_pose2d;       /* [N][RV_MAXB][3]  x, y, yaw                        */
+  float*   d_yaw_cossin;   /* [N][RV_MAXB][2]  cos(yaw), sin(yaw)               */
 } rv_obs_buffers;
 int  rv_observe(rv_world* w, const rv_obs_buffers* obs);
 
@@ -306,6 +322,30 @@ int  rv_get_stats(rv_world* w, rv_macro_stats* h_stats);
 /* HIP-event duration of the last rv_step_macro / rv_step_sub / rv_reset kernel
  * on the world's stream, in milliseconds (used by bench.py's roofline). */
 int  rv_last_kernel_ms(rv_world* w, float* h_ms);
+
+/* ---- zero-copy, READ-ONLY views of the resident state (the
+ *      scalar getters of body.py:72-125 / joint.py:41-92 batched).  The env
+ *      blocks are env-major: field f of env i lives at
+ *      d_envs + i * env_stride_bytes + off_f.  Valid until rv_destroy; contents
+ *      change with every stepping call on the world's stream. ---- */
+typedef struct rv_state_view {
+  const void* d_envs;
+  int64_t env_stride_bytes;
+  int64_t off_body;        /* float[RV_MAXB][13]  pos3 quat4(xyzw) lin3 ang3     */
+  int64_t off_active;      /* int32[RV_MAXB]                                     */
+  int64_t off_joint_q;     /* float[RV_NJ]                                       */
+  int64_t off_joint_qd;    /* float[RV_NJ]                                       */
+  int64_t off_link_pos;    /* float[RV_NFRAME][3]                                */
+  int64_t off_link_quat;   /* float[RV_NFRAME][4]                                */
+  int64_t off_obs_pos;     /* float[RV_MAXB][3]   PoseObs('position') snapshot   */
+  int64_t off_table_z;     /* float                                              */
+} rv_state_view;
+int  rv_get_state_ptrs(rv_world* w, rv_state_view* h_out);
+
+/* sha256 (hex) of the sources the loaded binary was compiled from, baked in at
+ * build time (robovat_amd/lib.py: source_hash()); __graft_entry__.smoke()
+ * compares it with the hash of the sources that travelled with the binary. */
+const char* rv_source_hash(void);
 
 #ifdef __cplusplus
 }

@@ -206,10 +206,18 @@ class OracleWorld(object):
     def manifold_counts(self):
         return self._get('orc_get_manifold_counts', (self.n, abi.RV_NMAN), np.int32)
 
-    def observe(self):
+    def observe(self, full=False):
         pos = np.zeros((self.n, abi.RV_MAXB, 3)); mask = np.zeros((self.n, abi.RV_MAXB))
-        self.lib.orc_observe(self.h, _p(pos), _p(mask))
-        return pos, mask
+        if not full:
+            self.lib.orc_observe(self.h, _p(pos), _p(mask), None, None, None, None)
+            return pos, mask
+        attrs = np.zeros((self.n, 5), dtype=np.int64)
+        pose = np.zeros((self.n, abi.RV_MAXB, 6)); pose2d = np.zeros((self.n, abi.RV_MAXB, 3))
+        ycs = np.zeros((self.n, abi.RV_MAXB, 2))
+        self.lib.orc_observe(self.h, _p(pos), _p(mask), _p(attrs), _p(pose), _p(pose2d), _p(ycs))
+        return {'position': pos, 'body_mask': mask, 'num_episodes': attrs[:, 0], 'num_steps': attrs[:, 1],
+                'layout_id': attrs[:, 2], 'is_safe': attrs[:, 3], 'is_effective': attrs[:, 4],
+                'pose': pose, 'pose2d': pose2d, 'yaw_cossin': ycs}
 
     def reward(self):
         r = np.zeros(self.n); d = np.zeros(self.n, dtype=np.uint8)

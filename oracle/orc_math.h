@@ -160,6 +160,22 @@ static inline real quat_yaw(const real* q) {
   return ratan2(R(2.0) * (w * z + x * y), R(1.0) - R(2.0) * (y * y + z * z));
 }
 
+/* static-xyz Euler angles of a unit quaternion (transformations.py:1034-1085
+ * euler_from_matrix, axes 'sxyz', on the matrix of q): roll, pitch, yaw */
+static inline void quat_to_euler(const real* q, real* e) {
+  real m[9]; qmat(m, q);
+  real cy = rsqrt_(m[0] * m[0] + m[3] * m[3]);
+  if (cy > R(1e-6)) {
+    e[0] = ratan2(m[7], m[8]);
+    e[1] = ratan2(-m[6], cy);
+    e[2] = ratan2(m[3], m[0]);
+  } else {
+    e[0] = ratan2(-m[5], m[4]);
+    e[1] = ratan2(-m[6], cy);
+    e[2] = R(0.0);
+  }
+}
+
 /* ---- Philox4x32-10 counter-based RNG (results invariant to GPU count) ---- */
 typedef struct { uint32_t key[2]; uint32_t ctr[4]; uint32_t buf[4]; int idx; } orc_rng;
 

@@ -95,6 +95,8 @@ typedef struct {
   /* counters */
   int sim_steps;                 /* Simulator.num_steps            */
   int num_steps, num_episodes;   /* RobotEnv counters              */
+  int obs_num_steps, obs_num_episodes;   /* env.attributes snapshot (push_env.py:368-375, 637-644) */
+  int l_unsafe, l_ineffective, l_useful, l_episodes, l_successes;   /* per-launch sums (stats) */
   int done, phase, is_safe, is_effective;
   int reset_count;
   int substeps_last, awake_last, pairs_last;
@@ -1338,7 +1340,9 @@ static void env_step(const orc_world* w, orc_env* e) {
   const rv_config* c = &w->cfg;
   if (e->done) return;
   e->substeps_last = 0; e->awake_last = 0; e->pairs_last = 0;
+  e->obs_num_steps = e->num_steps; e->obs_num_episodes = e->num_episodes;
   execute_action(w, e);
+  e->l_unsafe += !e->is_safe; e->l_ineffective += !e->is_effective; e->l_useful += (e->is_safe && e->is_effective);
   e->num_steps++;
   compute_obs(e);
   real r; int term;
@@ -1348,8 +1352,8 @@ static void env_step(const orc_world* w, orc_env* e) {
   e->done = e->done || term;
   if (c->max_steps > 0 && e->num_steps >= c->max_steps) e->done = 1;
   if (e->done) {
-    e->num_episodes++;
-    if (r >= (real)c->success_thresh) e->num_successes++;
+    e->num_episodes++; e->l_episodes++;
+    if (r >= (real)c->success_thresh) { e->num_successes++; e->l_successes++; }
   }
 }
 
@@ -1409,6 +1413,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   e->reset_count++;
   e->substeps_last = 0; e->awake_last = 0; e->pairs_last = 0;
   e->sim_steps = 0; e->num_steps = 0; e->episode_reward = R(0.0); e->last_reward = R(0.0);
+  e->obs_num_steps = 0; e->obs_num_episodes = e->num_episodes;
   e->done = 0;
   e->phase = RV_PHASE_INITIAL; e->is_safe = 1; e->is_effective = 1;
   e->arm_enabled = 0;
@@ -1481,8 +1486,13 @@ orc_world* orc_create(const rv_config* cfg, const rv_scene* scene) {
 void orc_destroy(orc_world* w) { if (w) { free(w->env); free(w); } }
 int orc_is_double(void) { return (int)(sizeof(real) == 8); }
 
-static void stats_begin(orc_world* w) { memset(&w->stats, 0, sizeof(w->stats)); }
+static void stats_begin(orc_world* w) {
+  memset(&w->stats, 0, sizeof(w->stats));
+  for (int i = 0; i < w->n; ++i) { orc_env* e = &w->env[i]; e->l_unsafe = e->l_ineffective = e->l_useful = e->l_episodes = e->l_successes = 0; }
+}
 static void stats_env(orc_world* w, const orc_env* e) {
+  w->stats.unsafe += e->l_unsafe; w->stats.ineffective += e->l_ineffective; w->stats.useful += e->l_useful;
+  w->stats.episodes_done += e->l_episodes; w->stats.successes += e->l_successes;
   w->stats.substeps += e->substeps_last;
   w->stats.awake_substeps += e->awake_last;
   if (e->substeps_last > w->stats.max_substeps) w->stats.max_substeps = e->substeps_last;
@@ -1515,12 +1525,7 @@ void orc_step_macro(orc_world* w) {
   for (int i = 0; i < w->n; ++i) {
     const orc_env* e = &w->env[i];
     stats_env(w, e);
-    if (e->substeps_last > 0) {
-      w->stats.env_steps++;
-      w->stats.unsafe += !e->is_safe; w->stats.ineffective += !e->is_effective;
-      w->stats.useful += (e->is_safe && e->is_effective);
-      if (e->done) { w->stats.episodes_done++; if (e->last_reward >= (real)w->cfg.success_thresh) w->stats.successes++; }
-    }
+    if (e->substeps_last > 0) w->stats.env_steps++;
   }
 }
 /* generate_episode's inner loop with RandomPolicy (see rv_rollout in rovat.h) */
@@ -1598,14 +1603,16 @@ void orc_policy_heuristic(orc_world* w, int max_attempts, float* actions) {
     int nb = 0;
     for (int b = 0; b < RV_MAXB; ++b) nb += e->bp[b].active;
     if (nb == 0) nb = 1;
-    int body_id = e->num_episodes % nb;
-    real base = (real)e->num_episodes * R(42.0);
+    /* counters come from the observation = the env.attributes snapshot (push_policy.py:46-49) */
+    const int n_ep = e->obs_num_episodes, n_st = e->obs_num_steps;
+    int body_id = n_ep % nb;
+    real base = (real)n_ep * R(42.0);
     base = base - R(2.0) * ORC_PI * R(floor)(base / (R(2.0) * ORC_PI));
     real lo0 = (real)c->cspace_low[0], hi0 = (real)c->cspace_high[0], lo1 = (real)c->cspace_low[1], hi1 = (real)c->cspace_high[1];
     real start[2] = {0, 0}, motion[2] = {0, 0};
     for (int att = 0; att < max_attempts; ++att) {
       orc_rng g; rng_init(&g, c->seed_lo, c->seed_hi, (uint32_t)(c->env_id_offset + i), STREAM_HEUR,
-                          (uint32_t)(e->num_episodes * 64 + e->num_steps));
+                          (uint32_t)(n_ep * 64 + n_st));
       g.ctr[0] = (uint32_t)att * 2u;
       start[0] = rng_uniform(&g, R(-1.0), R(1.0)); start[1] = rng_uniform(&g, R(-1.0), R(1.0));
       real ang = base + rng_uniform(&g, R(-0.25) * ORC_PI, R(0.25) * ORC_PI);
@@ -1786,15 +1793,35 @@ void orc_query_contacts(orc_world* w, uint8_t* out) {
 void orc_get_manifold_counts(orc_world* w, int32_t* out) {
   for (int i = 0; i < w->n; ++i) for (int m = 0; m < RV_NMAN; ++m) out[(size_t)i * RV_NMAN + m] = w->env[i].man[m].n;
 }
-void orc_observe(orc_world* w, double* position, double* body_mask) {
-  for (int i = 0; i < w->n; ++i)
+/* PoseObs (pose_obs.py:53-73, all four modalities) + attribute observations
+ * (attribute_obs.py:16-115).  attrs: [N][5] num_episodes, num_steps, layout_id, is_safe, is_effective */
+void orc_observe(orc_world* w, double* position, double* body_mask, int64_t* attrs,
+                 double* pose, double* pose2d, double* yaw_cossin) {
+  for (int i = 0; i < w->n; ++i) {
+    const orc_env* e = &w->env[i];
     for (int b = 0; b < RV_MAXB; ++b) {
-      for (int k = 0; k < 3; ++k) position[((size_t)i * RV_MAXB + b) * 3 + k] = w->env[i].obs_pos[b][k];
-      body_mask[(size_t)i * RV_MAXB + b] = w->env[i].bp[b].active;
+      const size_t ib = (size_t)i * RV_MAXB + b;
+      for (int k = 0; k < 3; ++k) position[ib * 3 + k] = e->obs_pos[b][k];
+      body_mask[ib] = e->bp[b].active;
+      real eu[3] = {R(0.0), R(0.0), R(0.0)};
+      if (e->bp[b].active) quat_to_euler(e->body[b].q, eu);
+      if (pose) for (int k = 0; k < 3; ++k) { pose[ib * 6 + k] = e->obs_pos[b][k]; pose[ib * 6 + 3 + k] = eu[k]; }
+      if (pose2d) { pose2d[ib * 3] = e->obs_pos[b][0]; pose2d[ib * 3 + 1] = e->obs_pos[b][1]; pose2d[ib * 3 + 2] = eu[2]; }
+      if (yaw_cossin) {
+        real sn = R(0.0), cs = R(0.0);
+        if (e->bp[b].active) rsincos(eu[2], &sn, &cs);
+        yaw_cossin[ib * 2] = cs; yaw_cossin[ib * 2 + 1] = sn;
+      }
     }
+    if (attrs) {
+      attrs[i * 5 + 0] = e->obs_num_episodes; attrs[i * 5 + 1] = e->obs_num_steps; attrs[i * 5 + 2] = w->cfg.layout_id;
+      attrs[i * 5 + 3] = e->is_safe; attrs[i * 5 + 4] = e->is_effective;
+    }
+  }
 }
 void orc_reward(orc_world* w, double* reward, uint8_t* done) {
-  for (int i = 0; i < w->n; ++i) { reward[i] = w->env[i].last_reward; done[i] = (uint8_t)w->env[i].done; }
+  /* an env that was not stepped by the last call (episode over) reports reward 0 */
+  for (int i = 0; i < w->n; ++i) { reward[i] = w->env[i].substeps_last > 0 ? w->env[i].last_reward : R(0.0); done[i] = (uint8_t)w->env[i].done; }
 }
 void orc_get_episode_returns(orc_world* w, double* r) { for (int i = 0; i < w->n; ++i) r[i] = w->env[i].episode_reward; }
 void orc_get_stats(orc_world* w, rv_macro_stats* s) { *s = w->stats; }

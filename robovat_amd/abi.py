@@ -133,6 +133,15 @@ class rv_obs_buffers(C.Structure):
         ('d_num_episodes', C.c_void_p), ('d_num_steps', C.c_void_p),
         ('d_layout_id', C.c_void_p), ('d_is_safe', C.c_void_p),
         ('d_is_effective', C.c_void_p), ('d_point_cloud', C.c_void_p),
+        ('d_pose', C.c_void_p), ('d_pose2d', C.c_void_p), ('d_yaw_cossin', C.c_void_p),
+    ]
+
+
+class rv_state_view(C.Structure):
+    _fields_ = [
+        ('d_envs', C.c_void_p), ('env_stride_bytes', i64),
+        ('off_body', i64), ('off_active', i64), ('off_joint_q', i64), ('off_joint_qd', i64),
+        ('off_link_pos', i64), ('off_link_quat', i64), ('off_obs_pos', i64), ('off_table_z', i64),
     ]
 
 

@@ -110,7 +110,11 @@ struct DevEnv {
   float action[RV_MAXG][4];
   float obs_pos[RV_MAXB][3], prev_obs_pos[RV_MAXB][3];
   int num_total_steps, num_unsafe, num_ineffective, num_useful, num_successes;
-  int pad_[3];
+  // env.attributes (push_env.py:368-375, 637-644): the counters the attribute observations
+  // and the heuristic policy see are captured at the START of _execute_action / _reset_scene
+  int obs_num_steps, obs_num_episodes;
+  // per-launch sums for rv_get_stats (a rollout launch takes several steps per env)
+  int l_unsafe, l_ineffective, l_useful, l_episodes, l_successes;
 #ifdef RV_PROFILE
   unsigned long long prof[24], prof_t, prof_t2[4];   // tools/prof_rollout.py: shader-clock time per substep part
 #endif
@@ -193,6 +197,11 @@ RV_DEV int bb_round_pair(int r, int x) { return x == 0 ? r : 5 - r; }
 RV_DEV float sim_time(const Shared& S, const Consts& K) { return K.cfg->dt * (float)S.e.sim_steps; }
 RV_DEV int body_present(const DevEnv& e, int b) { return e.active[b] && !e.frozen[b]; }
 RV_DEV int body_on(const DevEnv& e, int b) { return e.active[b] && !e.frozen[b] && !e.asleep[b]; }
+// start of a launch: nothing stepped yet (one lane)
+RV_DEV void launch_counters_zero(DevEnv& e) {
+  e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; e.stepped = 0;
+  e.l_unsafe = 0; e.l_ineffective = 0; e.l_useful = 0; e.l_episodes = 0; e.l_successes = 0;
+}
 
 // ------------------------------------------------------------------- arm --
 // FK of the limb for joint vector q (registers / LDS), frames 0..7
@@ -447,18 +456,21 @@ RV_DEV void robot_move_to_gripper_pose(Shared& S, const Consts& K, const float* 
   t.pos_thr = c->limb_position_threshold; t.vel_thr = c->velocity_threshold;
 }
 // SawyerSim.grip (sawyer_sim.py:362-392)
-RV_DEV void robot_grip(Shared& S, const Consts& K, float value) {
-  DevEnv& e = S.e; const rv_arm* a = K.arm;
+RV_DEV void grip_env(DevEnv& e, const rv_arm* a, const rv_config* c, float value) {
   value = fclampr(value, 0.01f, 0.99f);
   float lpos = a->q_hi[7] - value * (a->q_hi[7] - a->q_lo[7]);
   float rpos = a->q_lo[8] + value * (a->q_hi[8] - a->q_lo[8]);
+  const float now = c->dt * (float)e.sim_steps;
   JTarget& t = e.jt;
   t.active = 1; t.n_idx = 2; t.has_vel = 1; t.from_ik = 0;
-  S.s.jt_applied = 0;
   t.idx[0] = 7; t.idx[1] = 8; t.pos[0] = lpos; t.pos[1] = rpos;
-  t.start_t = sim_time(S, K); t.stop_t = t.start_t + 10000.0f; t.has_stop = 1;
-  t.pos_thr = 0.008726640f; t.vel_thr = K.cfg->velocity_threshold;
-  e.gripper_ready_time = sim_time(S, K) + 0.5f;
+  t.start_t = now; t.stop_t = t.start_t + 10000.0f; t.has_stop = 1;
+  t.pos_thr = 0.008726640f; t.vel_thr = c->velocity_threshold;
+  e.gripper_ready_time = now + 0.5f;
+}
+RV_DEV void robot_grip(Shared& S, const Consts& K, float value) {
+  grip_env(S.e, K.arm, K.cfg, value);
+  S.s.jt_applied = 0;
 }
 
 // ---------------------------------------------------------- rigid bodies --
@@ -1969,6 +1981,7 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
       DevEnv& e = S.e; Scratch& s = S.s;
       if (zero_counters) { e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; }
       e.stepped += 1;
+      e.obs_num_steps = e.num_steps; e.obs_num_episodes = e.num_episodes;
       int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
       for (int g = 0; g < G; ++g) compute_waypoints(c, e.action[g], s.wp[g][0], s.wp[g][1]);
       e.is_safe = 1; e.is_effective = 1;
@@ -1998,9 +2011,9 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
       }
       if (dpos <= c->min_delta_position && dang <= c->min_delta_angle) e.is_effective = 0;
       e.num_total_steps++;
-      e.num_unsafe += !e.is_safe;
-      e.num_ineffective += !e.is_effective;
-      e.num_useful += (e.is_safe && e.is_effective);
+      e.num_unsafe += !e.is_safe; e.l_unsafe += !e.is_safe;
+      e.num_ineffective += !e.is_effective; e.l_ineffective += !e.is_effective;
+      e.num_useful += (e.is_safe && e.is_effective); e.l_useful += (e.is_safe && e.is_effective);
       e.num_steps++;
       compute_obs(e);
       float r; int term;
@@ -2010,8 +2023,8 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
       e.done = e.done || term;
       if (c->max_steps > 0 && e.num_steps >= c->max_steps) e.done = 1;
       if (e.done) {
-        e.num_episodes++;
-        if (r >= c->success_thresh) e.num_successes++;
+        e.num_episodes++; e.l_episodes++;
+        if (r >= c->success_thresh) { e.num_successes++; e.l_successes++; }
       }
     }
   RV_LANES_END
@@ -2075,8 +2088,8 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
       S.s.jt_applied = 0; S.s.kin_fresh = 0; S.s.clr_valid = 0;
       S.s.rng = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RESET, (uint32_t)e.reset_count);
       e.reset_count++;
-      if (zero_counters) { e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; e.stepped = 0; }
-      e.sim_steps = 0; e.num_steps = 0; e.episode_reward = 0.0f; e.last_reward = 0.0f;
+      if (zero_counters) launch_counters_zero(e);
+      e.sim_steps = 0; e.num_steps = 0; e.obs_num_steps = 0; e.obs_num_episodes = e.num_episodes; e.episode_reward = 0.0f; e.last_reward = 0.0f;
       e.done = 0; e.phase = RV_PHASE_INITIAL; e.is_safe = 1; e.is_effective = 1;
       e.arm_enabled = 0;
       e.flag_arm_table = 0;
@@ -2179,8 +2192,9 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
                         float* rewards, uint8_t* dones, int env, int n_envs, int* budget = nullptr) {
   const rv_config* c = K.cfg;
   RV_LANES_BEGIN
-    if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; }
+    if (lane == 0) launch_counters_zero(S.e);
   RV_LANES_END
+  int k_end = 0;
   for (int k = 0; budget != nullptr || k < n_steps; ++k) {
     if (budget != nullptr) {
       RV_LANES_BEGIN
@@ -2211,6 +2225,16 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
       if (lane == 0) {
         if (rewards) rewards[(size_t)k * n_envs + env] = S.e.last_reward;
         if (dones) dones[(size_t)k * n_envs + env] = (uint8_t)S.e.done;
+      }
+    RV_LANES_END
+    k_end = k + 1;
+  }
+  // steps not taken (episode over, no auto-reset): reward 0, done
+  if (budget == nullptr) {
+    RV_LANES_BEGIN
+      for (int k = k_end + lane; k < n_steps; k += 64) {
+        if (rewards) rewards[(size_t)k * n_envs + env] = 0.0f;
+        if (dones) dones[(size_t)k * n_envs + env] = (uint8_t)1;
       }
     RV_LANES_END
   }

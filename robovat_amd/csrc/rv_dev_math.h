@@ -161,6 +161,22 @@ RV_DEV float quat_yaw(q4 q) {
   return atan2r(2.0f * (q.w * q.z + q.x * q.y), 1.0f - 2.0f * (q.y * q.y + q.z * q.z));
 }
 
+// static-xyz Euler angles of a unit quaternion (transformations.py euler_from_matrix,
+// axes 'sxyz', on the matrix of q): roll, pitch, yaw
+RV_DEV void quat_to_euler(q4 q, float* e) {
+  m3 m = qmat(q);
+  float cy = fsqrtr(m.m[0] * m.m[0] + m.m[3] * m.m[3]);
+  if (cy > 1e-6f) {
+    e[0] = atan2r(m.m[7], m.m[8]);
+    e[1] = atan2r(-m.m[6], cy);
+    e[2] = atan2r(m.m[3], m.m[0]);
+  } else {
+    e[0] = atan2r(-m.m[5], m.m[4]);
+    e[1] = atan2r(-m.m[6], cy);
+    e[2] = 0.0f;
+  }
+}
+
 // ---- Philox4x32-10 ----
 struct Rng { uint32_t key0, key1; uint32_t c0, c1, c2, c3; uint32_t b0, b1, b2, b3; int idx; };
 RV_DEV void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,

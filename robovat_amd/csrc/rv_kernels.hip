@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <string>
 #include <new>
 
@@ -66,25 +67,31 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   if (MODE == MODE_MACRO) skip = (S.e.done != 0);
   if (MODE == MODE_ROLLOUT) skip = (S.e.done != 0) && !args.auto_reset;
   if (skip) {
-    if (lane == 0) { g->substeps_last = 0; g->awake_last = 0; g->pairs_last = 0; g->stepped = 0; }
+    if (lane == 0) launch_counters_zero(*g);
+    if (MODE == MODE_ROLLOUT) {   // steps not taken: reward 0, done
+      for (int k = lane; k < args.n_substeps; k += 64) {
+        if (args.rewards) args.rewards[(size_t)k * args.n_envs + env] = 0.0f;
+        if (args.dones) args.dones[(size_t)k * args.n_envs + env] = (uint8_t)1;
+      }
+    }
     return;
   }
   if (MODE != MODE_RESET) env_enter(S, K);
   if (MODE == MODE_RESET) {
     env_reset(S, K, K.cfg->env_id_offset + env);
   } else if (MODE == MODE_MACRO) {
-    if (lane == 0) S.e.stepped = 0;
+    if (lane == 0) launch_counters_zero(S.e);
     __syncthreads();
     env_step(S, K);
   } else if (MODE == MODE_ROLLOUT) {
     env_rollout(S, K, K.cfg->env_id_offset + env, args.n_substeps, args.first_index, args.auto_reset, args.rewards, args.dones, env, args.n_envs, args.budget);
     if (lane == 0 && args.steps_taken) args.steps_taken[env] = S.e.stepped;
   } else if (MODE == MODE_SUB) {
-    if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; }
+    if (lane == 0) launch_counters_zero(S.e);
     __syncthreads();
     sim_steps_call(K, args.n_substeps);
   } else {
-    if (lane == 0) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; }
+    if (lane == 0) launch_counters_zero(S.e);
     __syncthreads();
     wait_until_stable(S, K, 0u, args.lin_thr, args.ang_thr, args.check_after, args.min_stable, args.max_steps);
   }
@@ -186,7 +193,25 @@ __global__ void k_set_actions(DevEnv* envs, int n, const float* a, int G) {
   ENV_THREAD();
   for (int g = 0; g < G; ++g) for (int k = 0; k < 4; ++k) e.action[g][k] = a[((size_t)i * G + g) * 4 + k];
 }
-__global__ void k_set_joint_targets(DevEnv* envs, int n, const float* q, const rv_config* cfg, const rv_scene* scene) {
+__global__ void k_reset_targets(DevEnv* envs, int n) {
+  ENV_THREAD();
+  arm_reset_targets(e);   // ControllableBody.reset_targets (controllable_body.py:347-350)
+}
+__global__ void k_set_int(int* p, int v) { *p = v; }
+// BulletPhysics.position_control_array (bullet_physics.py:1061-1104): POSITION_CONTROL
+// motor targets for the joints whose mask byte is set
+__global__ void k_set_motor_targets(DevEnv* envs, int n, const float* q, const uint8_t* mask, const rv_config* cfg) {
+  ENV_THREAD();
+  for (int j = 0; j < RV_NJ; ++j) {
+    if (mask && !mask[(size_t)i * RV_NJ + j]) continue;
+    e.motor_on[j] = 1; e.motor_q[j] = q[(size_t)i * RV_NJ + j]; e.motor_kp[j] = cfg->kp; e.motor_kd[j] = cfg->kd;
+  }
+}
+__global__ void k_grip(DevEnv* envs, int n, float value, const rv_config* cfg, const rv_scene* scene) {
+  ENV_THREAD();
+  grip_env(e, &scene->arm, cfg, value);
+}
+__global__ void k_set_joint_targets(DevEnv* envs, int n, const float* q, const rv_config* cfg, const rv_scene* scene, float timeout, float threshold) {
   ENV_THREAD();
   // SawyerSim.move_to_joint_positions (sawyer_sim.py:186-234)
   arm_reset_targets(e);
@@ -194,10 +219,10 @@ __global__ void k_set_joint_targets(DevEnv* envs, int n, const float* q, const r
   JTarget& t = e.jt;
   t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = 1; t.from_ik = 0;
   for (int j = 0; j < RV_NLIMB; ++j) { t.idx[j] = j; t.pos[j] = q[(size_t)i * RV_NLIMB + j]; }
-  t.start_t = cfg->dt * (float)e.sim_steps; t.stop_t = t.start_t + cfg->limb_timeout; t.has_stop = 1;
-  t.pos_thr = cfg->limb_position_threshold; t.vel_thr = cfg->velocity_threshold;
+  t.start_t = cfg->dt * (float)e.sim_steps; t.stop_t = t.start_t + (timeout > 0.0f ? timeout : cfg->limb_timeout); t.has_stop = 1;
+  t.pos_thr = threshold > 0.0f ? threshold : cfg->limb_position_threshold; t.vel_thr = cfg->velocity_threshold;
 }
-__global__ void k_set_link_target(DevEnv* envs, int n, const float* pose, const rv_config* cfg, const rv_scene* scene) {
+__global__ void k_set_link_target(DevEnv* envs, int n, const float* pose, const rv_config* cfg, const rv_scene* scene, float timeout, float threshold) {
   ENV_THREAD();
   // SawyerSim.move_to_gripper_pose (sawyer_sim.py:236-308)
   arm_reset_targets(e);
@@ -205,8 +230,8 @@ __global__ void k_set_link_target(DevEnv* envs, int n, const float* pose, const 
   LTarget& t = e.lt;
   t.active = 1; t.has_pose = 1; t.nq = 0;
   for (int k = 0; k < 7; ++k) t.pose[k] = pose[(size_t)i * 7 + k];
-  t.start_t = cfg->dt * (float)e.sim_steps; t.stop_t = t.start_t + cfg->limb_timeout; t.has_stop = 1;
-  t.pos_thr = cfg->limb_position_threshold; t.vel_thr = cfg->velocity_threshold;
+  t.start_t = cfg->dt * (float)e.sim_steps; t.stop_t = t.start_t + (timeout > 0.0f ? timeout : cfg->limb_timeout); t.has_stop = 1;
+  t.pos_thr = threshold > 0.0f ? threshold : cfg->limb_position_threshold; t.vel_thr = cfg->velocity_threshold;
 }
 __global__ void k_compute_ik(const DevEnv* envs, int n, const float* pose, float* q, const rv_config* cfg, const rv_scene* scene) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
@@ -233,9 +258,31 @@ __global__ void k_observe(const DevEnv* envs, int n, rv_obs_buffers o, const rv_
   for (int b = 0; b < RV_MAXB; ++b) {
     if (o.d_position) for (int k = 0; k < 3; ++k) o.d_position[((size_t)i * RV_MAXB + b) * 3 + k] = e.obs_pos[b][k];
     if (o.d_body_mask) o.d_body_mask[(size_t)i * RV_MAXB + b] = (float)e.active[b];
+    // PoseObs 'pose' / 'pose2d' / 'yaw_cossin' (pose_obs.py:53-73); zero rows for absent bodies
+    if (o.d_pose || o.d_pose2d || o.d_yaw_cossin) {
+      const int on = e.active[b];
+      float eu[3] = {0.0f, 0.0f, 0.0f};
+      if (on) quat_to_euler(ldq(e.body[b] + 3), eu);
+      if (o.d_pose) {
+        float* p = o.d_pose + ((size_t)i * RV_MAXB + b) * 6;
+        for (int k = 0; k < 3; ++k) { p[k] = e.obs_pos[b][k]; p[3 + k] = eu[k]; }
+      }
+      if (o.d_pose2d) {
+        float* p = o.d_pose2d + ((size_t)i * RV_MAXB + b) * 3;
+        p[0] = e.obs_pos[b][0]; p[1] = e.obs_pos[b][1]; p[2] = eu[2];
+      }
+      if (o.d_yaw_cossin) {
+        float* p = o.d_yaw_cossin + ((size_t)i * RV_MAXB + b) * 2;
+        float sn = 0.0f, cs = 0.0f;
+        if (on) sincosr(eu[2], &sn, &cs);
+        p[0] = cs; p[1] = sn;
+      }
+    }
   }
-  if (o.d_num_episodes) o.d_num_episodes[i] = e.num_episodes;
-  if (o.d_num_steps) o.d_num_steps[i] = e.num_steps;
+  // attribute observations read env.attributes, captured at the start of
+  // _execute_action / _reset_scene (push_env.py:368-375, 637-644)
+  if (o.d_num_episodes) o.d_num_episodes[i] = e.obs_num_episodes;
+  if (o.d_num_steps) o.d_num_steps[i] = e.obs_num_steps;
   if (o.d_layout_id) o.d_layout_id[i] = cfg->layout_id;
   if (o.d_is_safe) o.d_is_safe[i] = e.is_safe;
   if (o.d_is_effective) o.d_is_effective[i] = e.is_effective;
@@ -269,7 +316,9 @@ __global__ void k_point_cloud(const DevEnv* envs, int n, float* out, const rv_co
 }
 __global__ void k_reward(const DevEnv* envs, int n, float* reward, uint8_t* done) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
-  if (reward) reward[i] = envs[i].last_reward;
+  // an env whose episode is over is not stepped by rv_step_macro (the reference raises
+  // "Forget to reset?", robot_env.py:244-245): it reports reward 0, done
+  if (reward) reward[i] = envs[i].stepped ? envs[i].last_reward : 0.0f;
   if (done) done[i] = (uint8_t)envs[i].done;
 }
 __global__ void k_returns(const DevEnv* envs, int n, float* r) {
@@ -292,8 +341,12 @@ __global__ __launch_bounds__(64) void k_policy_heuristic(const DevEnv* envs, int
   int nb = 0;
   for (int b = 0; b < RV_MAXB; ++b) nb += e.active[b];
   if (nb == 0) nb = 1;
-  int body_id = e.num_episodes % nb;
-  float base = (float)e.num_episodes * 42.0f;
+  // the policy reads the counters from the observation (push_policy.py:46-49), i.e. the
+  // env.attributes snapshot; like the reference it assumes the first nb slots are the bodies
+  // (heuristic_push_sampler.py:70: position[:num_bodies])
+  const int n_ep = e.obs_num_episodes, n_st = e.obs_num_steps;
+  int body_id = n_ep % nb;
+  float base = (float)n_ep * 42.0f;
   base = base - 2.0f * RV_PI * ffloorr(base / (2.0f * RV_PI));
   float lo0 = c->cspace_low[0], hi0 = c->cspace_high[0], lo1 = c->cspace_low[1], hi1 = c->cspace_high[1];
   float s0 = 0.0f, s1 = 0.0f, m0 = 0.0f, m1 = 0.0f;
@@ -302,7 +355,7 @@ __global__ __launch_bounds__(64) void k_policy_heuristic(const DevEnv* envs, int
     int att = base_att + lane;
     bool good = false;
     if (att < max_attempts) {
-      Rng g = rng_init(c->seed_lo, c->seed_hi, (uint32_t)(c->env_id_offset + i), RV_STREAM_HEUR, (uint32_t)(e.num_episodes * 64 + e.num_steps));
+      Rng g = rng_init(c->seed_lo, c->seed_hi, (uint32_t)(c->env_id_offset + i), RV_STREAM_HEUR, (uint32_t)(n_ep * 64 + n_st));
       g.c0 = (uint32_t)att * 2u;
       s0 = rng_uniform(g, -1.0f, 1.0f); s1 = rng_uniform(g, -1.0f, 1.0f);
       float ang = base + rng_uniform(g, -0.25f * RV_PI, 0.25f * RV_PI);
@@ -346,13 +399,12 @@ __global__ void k_stats(const DevEnv* envs, int n, rv_macro_stats* st, float suc
   }
   if (e.stepped) {
     atomicAdd((u64*)&st->env_steps, (u64)e.stepped);
-    if (!e.is_safe) atomicAdd((u64*)&st->unsafe, (u64)1);
-    if (!e.is_effective) atomicAdd((u64*)&st->ineffective, (u64)1);
-    if (e.is_safe && e.is_effective) atomicAdd((u64*)&st->useful, (u64)1);
-    if (e.done) {
-      atomicAdd((u64*)&st->episodes_done, (u64)1);
-      if (e.last_reward >= success_thresh) atomicAdd((u64*)&st->successes, (u64)1);
-    }
+    // per-launch sums kept by env_step (a rollout launch takes several steps per env)
+    if (e.l_unsafe) atomicAdd((u64*)&st->unsafe, (u64)e.l_unsafe);
+    if (e.l_ineffective) atomicAdd((u64*)&st->ineffective, (u64)e.l_ineffective);
+    if (e.l_useful) atomicAdd((u64*)&st->useful, (u64)e.l_useful);
+    if (e.l_episodes) atomicAdd((u64*)&st->episodes_done, (u64)e.l_episodes);
+    if (e.l_successes) atomicAdd((u64*)&st->successes, (u64)e.l_successes);
   }
 }
 
@@ -460,7 +512,8 @@ int rv_rollout(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t 
 int rv_rollout_async(rv_world* w, int32_t total_env_steps, int32_t first_macro_index, int32_t* d_steps_taken) {
   WCHK(w);
   if (total_env_steps <= 0) return fail(RV_ERR_VALUE, "rv_rollout_async: total_env_steps must be positive");
-  HIPCHK(hipMemcpyAsync(w->d_budget, &total_env_steps, sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, w->stream, w->d_budget, (int)total_env_steps);
+  HIPCHK(hipGetLastError());
   return launch_env<MODE_ROLLOUT>(w, nullptr, 0, 0, 0, 0, 0, 0, first_macro_index, 1, nullptr, nullptr, w->d_budget, d_steps_taken);
 }
 int rv_step_sub(rv_world* w, int32_t n) {
@@ -505,8 +558,27 @@ int rv_get_link_poses(rv_world* w, float* d) { WCHK(w); NEED(d, "rv_get_link_pos
 int rv_debug_profile(rv_world* w, unsigned long long* d) { WCHK(w); NEED(d, "rv_debug_profile"); SIMPLE_LAUNCH(k_debug_profile, w->d_envs, w->n, d); return RV_OK; }
 #endif
 int rv_get_env_counters(rv_world* w, int32_t* d) { WCHK(w); NEED(d, "rv_get_env_counters"); SIMPLE_LAUNCH(k_get_env_counters, w->d_envs, w->n, d); return RV_OK; }
-int rv_set_joint_targets(rv_world* w, const float* d) { WCHK(w); NEED(d, "rv_set_joint_targets"); SIMPLE_LAUNCH(k_set_joint_targets, w->d_envs, w->n, d, w->d_cfg, w->d_scene); return RV_OK; }
-int rv_set_link_target(rv_world* w, const float* d) { WCHK(w); NEED(d, "rv_set_link_target"); SIMPLE_LAUNCH(k_set_link_target, w->d_envs, w->n, d, w->d_cfg, w->d_scene); return RV_OK; }
+int rv_set_joint_targets(rv_world* w, const float* d, float timeout, float threshold) { WCHK(w); NEED(d, "rv_set_joint_targets"); SIMPLE_LAUNCH(k_set_joint_targets, w->d_envs, w->n, d, w->d_cfg, w->d_scene, timeout, threshold); return RV_OK; }
+int rv_set_link_target(rv_world* w, const float* d, float timeout, float threshold) { WCHK(w); NEED(d, "rv_set_link_target"); SIMPLE_LAUNCH(k_set_link_target, w->d_envs, w->n, d, w->d_cfg, w->d_scene, timeout, threshold); return RV_OK; }
+int rv_set_motor_targets(rv_world* w, const float* d_q, const uint8_t* d_mask) {
+  WCHK(w); NEED(d_q, "rv_set_motor_targets");
+  SIMPLE_LAUNCH(k_set_motor_targets, w->d_envs, w->n, d_q, d_mask, w->d_cfg); return RV_OK;
+}
+int rv_grip(rv_world* w, float value) { WCHK(w); SIMPLE_LAUNCH(k_grip, w->d_envs, w->n, value, w->d_cfg, w->d_scene); return RV_OK; }
+int rv_reset_targets(rv_world* w) { WCHK(w); SIMPLE_LAUNCH(k_reset_targets, w->d_envs, w->n); return RV_OK; }
+int rv_get_state_ptrs(rv_world* w, rv_state_view* v) {
+  WCHK(w); NEED(v, "rv_get_state_ptrs");
+  v->d_envs = w->d_envs; v->env_stride_bytes = (int64_t)sizeof(DevEnv);
+  v->off_body = (int64_t)offsetof(DevEnv, body); v->off_active = (int64_t)offsetof(DevEnv, active);
+  v->off_joint_q = (int64_t)offsetof(DevEnv, q); v->off_joint_qd = (int64_t)offsetof(DevEnv, qd);
+  v->off_link_pos = (int64_t)offsetof(DevEnv, fpos); v->off_link_quat = (int64_t)offsetof(DevEnv, fquat);
+  v->off_obs_pos = (int64_t)offsetof(DevEnv, obs_pos); v->off_table_z = (int64_t)offsetof(DevEnv, table_z);
+  return RV_OK;
+}
+#ifndef RV_SOURCE_HASH
+#define RV_SOURCE_HASH "unknown"
+#endif
+const char* rv_source_hash(void) { return RV_SOURCE_HASH; }
 int rv_compute_ik(rv_world* w, const float* d_pose, float* d_q) {
   WCHK(w); NEED(d_pose, "rv_compute_ik"); NEED(d_q, "rv_compute_ik");
   SIMPLE_LAUNCH(k_compute_ik, w->d_envs, w->n, d_pose, d_q, w->d_cfg, w->d_scene); return RV_OK;

@@ -29,6 +29,7 @@ SYMBOLS = [
     'rv_get_env_counters', 'rv_set_joint_targets', 'rv_set_link_target',
     'rv_compute_ik', 'rv_query_contacts', 'rv_get_manifold_counts', 'rv_observe',
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
+    'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -36,17 +37,37 @@ _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
 _lib = None
 
 
+SOURCES = [os.path.join(CSRC, n) for n in sorted(os.listdir(CSRC)) if n.endswith(('.hip', '.h'))]
+SOURCES.append(os.path.join(_HERE, '..', 'include', 'rovat.h'))
+
+
+def source_hash():
+    """sha256 over the sources librovat_hip.so is compiled from (file names and bytes)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in SOURCES:
+        h.update(os.path.basename(path).encode())
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def built_source_hash():
+    """The hash baked into the loaded binary (rv_source_hash)."""
+    lib = load()
+    return lib.rv_source_hash().decode()
+
+
 def build(force=False, verbose=False):
-    """Compile csrc/rv_kernels.hip for gfx950 into librovat_hip.so (in-tree)."""
+    """Compile csrc/rv_kernels.hip for gfx950 into librovat_hip.so (in-tree).
+    The sha256 of the sources is baked into the binary (rv_source_hash)."""
     src = os.path.join(CSRC, 'rv_kernels.hip')
-    deps = [src] + [os.path.join(CSRC, n) for n in
-                    ('rv_dev_env.h', 'rv_dev_collide.h', 'rv_dev_math.h')]
-    deps.append(os.path.join(_HERE, '..', 'include', 'rovat.h'))
+    deps = SOURCES
     if (not force and os.path.exists(LIB_PATH) and
             all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps)):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + HIPCC_FLAGS + [src, '-o', LIB_PATH]
+    cmd = [hipcc] + HIPCC_FLAGS + ['-DRV_SOURCE_HASH="%s"' % source_hash(), src, '-o', LIB_PATH]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
@@ -64,11 +85,12 @@ def load():
             'there is no CPU fallback.' % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     lib.rv_last_error.restype = C.c_char_p
+    lib.rv_source_hash.restype = C.c_char_p
     lib.rv_create.argtypes = [C.POINTER(abi.rv_config), C.POINTER(abi.rv_scene),
                               C.c_int, C.POINTER(C.c_void_p)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name != 'rv_last_error':
+        if name not in ('rv_last_error', 'rv_source_hash'):
             fn.restype = C.c_int
     vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
     lib.rv_destroy.argtypes = [vp]
@@ -88,11 +110,16 @@ def load():
     lib.rv_compute_ik.argtypes = [vp, vp, vp]
     lib.rv_get_stats.argtypes = [vp, C.POINTER(abi.rv_macro_stats)]
     lib.rv_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.rv_reset_targets.argtypes = [vp]
+    lib.rv_set_motor_targets.argtypes = [vp, vp, vp]
+    lib.rv_grip.argtypes = [vp, f32]
+    lib.rv_get_state_ptrs.argtypes = [vp, C.POINTER(abi.rv_state_view)]
+    lib.rv_set_joint_targets.argtypes = [vp, vp, f32, f32]
+    lib.rv_set_link_target.argtypes = [vp, vp, f32, f32]
     for name in ('rv_set_actions', 'rv_get_body_state', 'rv_set_body_state',
                  'rv_get_body_params', 'rv_set_body_params', 'rv_get_joint_state',
                  'rv_set_joint_state', 'rv_get_link_poses', 'rv_get_env_counters',
-                 'rv_set_joint_targets', 'rv_set_link_target', 'rv_query_contacts',
-                 'rv_get_manifold_counts', 'rv_get_episode_returns'):
+                 'rv_query_contacts', 'rv_get_manifold_counts', 'rv_get_episode_returns'):
         getattr(lib, name).argtypes = [vp, vp]
     _lib = lib
     return lib
@@ -172,8 +199,8 @@ class World(object):
         """n_steps x (RandomPolicy action -> env.step) per env in one launch."""
         r = d = None
         if record:
-            r = self._new((int(n_steps), self.n), self.torch.float32)
-            d = self._new((int(n_steps), self.n), self.torch.uint8)
+            r = self.torch.zeros((int(n_steps), self.n), dtype=self.torch.float32, device=self.device)
+            d = self.torch.ones((int(n_steps), self.n), dtype=self.torch.uint8, device=self.device)
         check(self.lib.rv_rollout(self.h, int(n_steps), int(first_macro_index), int(bool(auto_reset)),
                                   self._ptr(r) if record else None, self._ptr(d) if record else None))
         return r, d
@@ -231,11 +258,53 @@ class World(object):
     def env_counters(self):
         return self._get('rv_get_env_counters', (self.n, abi.RV_NCOUNTERS), self.torch.int32)
 
-    def set_joint_targets(self, q):
-        check(self.lib.rv_set_joint_targets(self.h, self._ptr(self._in(q, (self.n, abi.RV_NLIMB), self.torch.float32))))
+    def set_joint_targets(self, q, timeout=0.0, threshold=0.0):
+        """timeout / threshold <= 0: the robot config's LIMB_TIMEOUT / LIMB_POSITION_THRESHOLD."""
+        check(self.lib.rv_set_joint_targets(self.h, self._ptr(self._in(q, (self.n, abi.RV_NLIMB), self.torch.float32)),
+                                            float(timeout), float(threshold)))
 
-    def set_link_target(self, pose):
-        check(self.lib.rv_set_link_target(self.h, self._ptr(self._in(pose, (self.n, 7), self.torch.float32))))
+    def set_link_target(self, pose, timeout=0.0, threshold=0.0):
+        check(self.lib.rv_set_link_target(self.h, self._ptr(self._in(pose, (self.n, 7), self.torch.float32)),
+                                          float(timeout), float(threshold)))
+
+    def reset_targets(self):
+        check(self.lib.rv_reset_targets(self.h))
+
+    def set_motor_targets(self, q, mask=None):
+        """position_control_array: POSITION_CONTROL targets for the masked joints."""
+        qt = self._in(q, (self.n, abi.RV_NJ), self.torch.float32)
+        mt = None if mask is None else self._in(mask, (self.n, abi.RV_NJ), self.torch.uint8)
+        check(self.lib.rv_set_motor_targets(self.h, self._ptr(qt), None if mt is None else self._ptr(mt)))
+
+    def grip(self, value):
+        check(self.lib.rv_grip(self.h, float(value)))
+
+    def state_view(self):
+        """Zero-copy READ-ONLY torch views of the resident env blocks (rv_get_state_ptrs)."""
+        v = abi.rv_state_view()
+        check(self.lib.rv_get_state_ptrs(self.h, C.byref(v)))
+        words = int(v.env_stride_bytes) // 4
+
+        class _Raw(object):
+            pass
+        raw = _Raw()
+        raw.__cuda_array_interface__ = {'shape': (self.n, words), 'typestr': '<f4', 'data': (int(v.d_envs), True),
+                                        'version': 2, 'strides': None}
+        t = self.torch
+        blocks = t.as_tensor(raw, device=self.device)
+
+        def f(off, count, shape):
+            return blocks[:, int(off) // 4: int(off) // 4 + count].reshape((self.n,) + shape)
+        return {
+            'body': f(v.off_body, abi.RV_MAXB * 13, (abi.RV_MAXB, 13)),
+            'active': f(v.off_active, abi.RV_MAXB, (abi.RV_MAXB,)).view(t.int32),
+            'joint_q': f(v.off_joint_q, abi.RV_NJ, (abi.RV_NJ,)),
+            'joint_qd': f(v.off_joint_qd, abi.RV_NJ, (abi.RV_NJ,)),
+            'link_pos': f(v.off_link_pos, abi.RV_NFRAME * 3, (abi.RV_NFRAME, 3)),
+            'link_quat': f(v.off_link_quat, abi.RV_NFRAME * 4, (abi.RV_NFRAME, 4)),
+            'obs_pos': f(v.off_obs_pos, abi.RV_MAXB * 3, (abi.RV_MAXB, 3)),
+            'table_z': f(v.off_table_z, 1, ()),
+        }
 
     def compute_ik(self, pose):
         p = self._in(pose, (self.n, 7), self.torch.float32)
@@ -249,7 +318,7 @@ class World(object):
     def manifold_counts(self):
         return self._get('rv_get_manifold_counts', (self.n, abi.RV_NMAN), self.torch.int32)
 
-    def observe(self, point_cloud=False):
+    def observe(self, point_cloud=False, pose_modes=False):
         t = self.torch
         out = {
             'position': self._new((self.n, abi.RV_MAXB, 3), t.float32),
@@ -268,6 +337,12 @@ class World(object):
         if point_cloud:
             out['point_cloud'] = self._new((self.n, abi.RV_MAXB, int(self.cfg.num_points), 3), t.float32)
             b.d_point_cloud = out['point_cloud'].data_ptr()
+        if pose_modes:      # the other PoseObs modalities (pose_obs.py:53-73)
+            out['pose'] = self._new((self.n, abi.RV_MAXB, 6), t.float32)
+            out['pose2d'] = self._new((self.n, abi.RV_MAXB, 3), t.float32)
+            out['yaw_cossin'] = self._new((self.n, abi.RV_MAXB, 2), t.float32)
+            b.d_pose = out['pose'].data_ptr(); b.d_pose2d = out['pose2d'].data_ptr()
+            b.d_yaw_cossin = out['yaw_cossin'].data_ptr()
         check(self.lib.rv_observe(self.h, C.byref(b)))
         return out
 

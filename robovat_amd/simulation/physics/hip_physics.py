@@ -262,11 +262,14 @@ class HipPhysics(Physics):
                                max_velocities=None, max_forces=None, position_gains=None, velocity_gains=None):
         if max_velocities is not None:
             raise NotImplementedError('This is not implemented in pybullet.')
-        q = self._np(self._world.joint_state())[0, :7, 0].copy()
+        q = np.zeros((1, abi.RV_NJ), np.float32)
+        mask = np.zeros((1, abi.RV_NJ), np.uint8)
         for j, v in zip(joint_inds, target_positions):
-            if j < 7:
-                q[j] = v
-        self._world.set_joint_targets(q[None])
+            if not 0 <= int(j) < abi.RV_NJ:
+                raise ValueError('joint index %r outside the arm (%d joints)' % (j, abi.RV_NJ))
+            q[0, int(j)] = v
+            mask[0, int(j)] = 1
+        self._world.set_motor_targets(q, mask)
 
     def compute_inverse_kinematics(self, link_uid, link_pose, upper_limits=None, lower_limits=None, ranges=None,
                                    damping=None, neutral_positions=None):

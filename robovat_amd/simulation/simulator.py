@@ -51,19 +51,20 @@ class ControllableBody(Body):
     machine (controllable_body.py:263-345 -> rv_set_joint_targets / rv_set_link_target)."""
 
     def set_target_joint_positions(self, joint_positions, timeout=15.0, threshold=0.008726640):
-        self.physics.world.set_joint_targets(np.asarray(joint_positions, np.float32)[None, :7])
+        self.physics.world.set_joint_targets(np.asarray(joint_positions, np.float32)[None, :7],
+                                             timeout=timeout, threshold=threshold)
 
     def set_target_link_pose(self, link_ind, link_pose, timeout=15.0, threshold=0.008726640):
         pose = Pose(link_pose)
         p = np.concatenate([np.asarray(pose.position), np.asarray(pose.quaternion)]).astype(np.float32)
-        self.physics.world.set_link_target(p[None])
+        self.physics.world.set_link_target(p[None], timeout=timeout, threshold=threshold)
 
     def set_max_joint_velocities(self, joint_velocities):
         pass   # LIMB_MAX_VELOCITY_RATIO is applied on the device
 
     def reset_targets(self):
-        q = self.physics.world.joint_state().cpu().numpy()[0, :7, 0]
-        self.physics.world.set_joint_targets(q[None])
+        """controllable_body.py:347-350: drop the link / joint targets."""
+        self.physics.world.reset_targets()
 
     @property
     def joint_positions(self):

@@ -31,13 +31,19 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_c_layout():
     import subprocess, tempfile
-    src = '#include <stdio.h>\n#include "rovat.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(rv_shape), sizeof(rv_arm), sizeof(rv_scene), sizeof(rv_config), sizeof(rv_macro_stats));return 0;}\n'
+    src = '#include <stdio.h>\n#include "rovat.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(rv_shape), sizeof(rv_arm), sizeof(rv_scene), sizeof(rv_config), sizeof(rv_macro_stats), sizeof(rv_obs_buffers), sizeof(rv_state_view));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, 't.c'), 'w').write(src)
         subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 't.c'), '-o', os.path.join(d, 't')], check=True)
         out = subprocess.run([os.path.join(d, 't')], capture_output=True, text=True, check=True).stdout.split()
-    sizes = [C.sizeof(x) for x in (abi.rv_shape, abi.rv_arm, abi.rv_scene, abi.rv_config, abi.rv_macro_stats)]
+    sizes = [C.sizeof(x) for x in (abi.rv_shape, abi.rv_arm, abi.rv_scene, abi.rv_config, abi.rv_macro_stats,
+                                    abi.rv_obs_buffers, abi.rv_state_view)]
     assert [int(x) for x in out] == sizes
+
+
+def test_binary_carries_the_hash_of_its_sources():
+    lib.build()
+    assert lib.built_source_hash() == lib.source_hash() and len(lib.source_hash()) == 64
 
 
 def test_no_cpu_fallback_without_gpu():

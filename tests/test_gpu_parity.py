@@ -5,12 +5,8 @@ Tolerances (FP32 path, stated per SURVEY.md §8c):
     operation: body poses must agree to 1e-6 m / 1e-6 (quaternion) after whole
     macro steps (thousands of substeps) and the integer bookkeeping (substep
     counts, phases, flags) must be identical;
-  * vs the double oracle (pose-error oracle of record), from identical states
-    with every body shoved at 0.2 m/s (sliding, frictional contact): 1e-5 m
-    after 1 substep; from 10 substeps on narrow-phase gating and contact
-    add/remove decisions may differ between FP32 and FP64, so the bounds are on
-    the median body (1e-5 m at 10, 1e-3 m at 100 substeps) and, more loosely, on
-    the worst body (5e-4 m / 5e-2 m).
+  * vs the double oracle (pose-error oracle of record): see
+    tests/test_gpu_scale.py::test_pose_error_vs_double_oracle_recorded.
 """
 import numpy as np
 import pytest
@@ -57,31 +53,6 @@ def test_reset_and_macro_steps_match_float_oracle():
             assert ws[key] == rs[key], key
         r, d = world.reward(); rr, rd = ref.reward()
         assert np.allclose(r.cpu().numpy(), rr, atol=1e-6) and np.array_equal(d.cpu().numpy(), rd)
-
-
-def test_substeps_vs_double_oracle_pose_error():
-    world, ref, cfg = _worlds(16, seed=9, double=True)
-    f32ref = _worlds(16, seed=9)[1]
-    f32ref.reset()
-    # identical start: settle with the float oracle, inject into both
-    state, params, joints = f32ref.body_state(), f32ref.body_params(), f32ref.joint_state()
-    for w_ in (ref,):
-        w_.set_body_params(params); w_.set_body_state(state); w_.set_joint_state(joints)
-    world.set_body_params(params); world.set_body_state(state); world.set_joint_state(joints)
-    # give the bodies a shove so the horizon test is not a resting scene
-    state[:, :, 7] += 0.2
-    ref.set_body_state(state); world.set_body_state(state)
-    done = 0
-    # (horizon, worst body, median body).  From 10 substeps on the FP32 and FP64 runs may
-    # take a gated narrow-phase pass at different substeps (the gate compares accumulated
-    # travel with 0.5 mm), so the worst body is bounded more loosely than the median one.
-    for horizon, tol, med_tol in ((1, 1e-5, 1e-6), (10, 5e-4, 1e-5), (100, 5e-2, 1e-3)):
-        world.step_sub(horizon - done); ref.step_sub(horizon - done); done = horizon
-        got = world.body_state().cpu().numpy(); want = ref.body_state()
-        perr = np.linalg.norm(got[..., :3] - want[..., :3], axis=-1)
-        print('horizon %d substeps: max pose err %.3e m, median %.3e m' % (horizon, perr.max(), np.median(perr)))
-        assert perr.max() <= tol, (horizon, perr.max())
-        assert np.median(perr) <= med_tol, (horizon, np.median(perr))
 
 
 def test_concave_crossing_layout_matches_float_oracle():

@@ -1,0 +1,251 @@
+"""BASELINE.json configs at their stated sizes on the MI355X, plus the device entry
+points that had no oracle comparison in round 1 (heuristic policy, rv_observe).
+
+Full-size runs are checked through size-independent properties (finite, unit
+quaternions, nothing below the table it rests on, determinism) and, bit for bit,
+against the float oracle on a 64-env slice that carries the SAME global env ids
+(Philox streams are keyed by global id, so a slice is reproducible on its own).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from robovat_amd import abi, configs, scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(n, seed, offset=0, **over):
+    scene, names = scenes.make_scene()
+    env_cfg = configs.push_env_config(**over)
+    return configs.make_rv_config(env_cfg=env_cfg, n_envs=n, seed=seed, env_id_offset=offset, shape_names=names), scene
+
+
+def _world(n, seed, offset=0, **over):
+    from robovat_amd import lib
+    cfg, scene = _cfg(n, seed, offset, **over)
+    return lib.World(cfg, scene, device=0)
+
+
+def _oracle(n, seed, offset=0, double=False, **over):
+    from oracle import orc
+    cfg, scene = _cfg(n, seed, offset, **over)
+    return orc.OracleWorld(cfg, scene, double=double)
+
+
+def _properties(world):
+    st = world.body_state().cpu().numpy()
+    prm = world.body_params().cpu().numpy()
+    on = prm[..., 0] > 0
+    assert np.isfinite(st).all()
+    q = st[..., 3:7]
+    assert np.allclose((q * q).sum(-1)[on], 1.0, atol=1e-5)
+    return st, prm, on
+
+
+def _slice_parity(world, lo, n_slice, seed, steps, **over):
+    """Bit-exact comparison of envs [lo, lo + n_slice) with an oracle world that owns
+    exactly those global env ids."""
+    ref = _oracle(n_slice, seed, offset=lo, **over)
+    ref.reset()
+    for k in range(steps):
+        ref.set_actions(ref.policy_random(k)); ref.step_macro()
+    got = world.body_state().cpu().numpy()[lo:lo + n_slice]
+    want = ref.body_state().astype(np.float32)
+    assert np.array_equal(got, want), np.abs(got - want).max()
+    assert np.array_equal(world.env_counters().cpu().numpy()[lo:lo + n_slice, :8], ref.env_counters()[:, :8])
+    jg = world.joint_state().cpu().numpy()[lo:lo + n_slice]
+    assert np.array_equal(jg, ref.joint_state().astype(np.float32))
+
+
+def test_config3_crossing_concave_at_4096_envs():
+    """BASELINE configs[2]: 'crossing' layout, V-HACD concave movables, 4096 envs."""
+    over = dict(TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=4)
+    world = _world(4096, seed=21, **over)
+    world.reset()
+    st, prm, on = _properties(world)
+    assert on.sum(-1).min() >= 1
+    assert (st[..., 2][on] > (prm[..., 6][on] - 1e-3)).all()      # reset leaves every body on the table
+    a = world.policy_random(0)
+    world.set_actions(a); world.step_macro()
+    s = world.stats()
+    assert s['env_steps'] == 4096 and s['substeps'] > 4096 * 1000
+    st2, _, _ = _properties(world)
+    r, d = world.reward()
+    assert np.isfinite(r.cpu().numpy()).all()
+    _slice_parity(world, 1000, 64, 21, 1, **over)
+    world.close()
+
+
+def test_config5_8192_envs_per_gpu():
+    """BASELINE configs[4], the N=1 point: config-2 scene, 8192 envs on one GPU."""
+    world = _world(8192, seed=1234)
+    world.reset()
+    st, prm, on = _properties(world)
+    assert on.all()
+    assert (st[..., 2] > prm[..., 6] - 1e-3).all()
+    a = world.policy_random(0)
+    world.set_actions(a); world.step_macro()
+    s = world.stats()
+    assert s['env_steps'] == 8192
+    st2, _, _ = _properties(world)
+    _slice_parity(world, 4096, 64, 1234, 1)
+    # determinism: a second world with the same seed reproduces every bit
+    world2 = _world(8192, seed=1234)
+    world2.reset(); world2.set_actions(a); world2.step_macro()
+    assert np.array_equal(world2.body_state().cpu().numpy(), st2)
+    world.close(); world2.close()
+
+
+def test_heuristic_policy_matches_oracle_bit_for_bit():
+    """rv_policy_heuristic == orc_policy_heuristic (HeuristicPushSampler._sample,
+    heuristic_push_sampler.py:66-123) after reset, after steps and across episodes."""
+    over = dict(MAX_STEPS=2)
+    world, ref = _world(96, seed=17, **over), _oracle(96, seed=17, **over)
+    world.reset(); ref.reset()
+    for k in range(5):
+        a_ref = ref.policy_heuristic(2000)
+        a = world.policy_heuristic(2000).cpu().numpy()
+        assert np.array_equal(a, a_ref), (k, np.abs(a - a_ref).max())
+        world.set_actions(a_ref); ref.set_actions(a_ref)
+        world.step_macro(); ref.step_macro()
+        assert np.array_equal(world.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
+        done = ref.reward()[1].astype(bool)
+        if done.any():
+            world.reset(done.astype(np.uint8)); ref.reset(done.astype(np.uint8))
+    # the heuristic aims at bodies: most pushes move something
+    assert world.stats()['useful'] + world.stats()['unsafe'] > 24
+    world.close()
+
+
+def test_observe_matches_oracle_all_modalities():
+    """rv_observe == orc_observe: PoseObs position/pose/pose2d/yaw_cossin (pose_obs.py:53-73)
+    and the attribute observations (attribute_obs.py:16-115, env.attributes snapshot)."""
+    over = dict(MAX_STEPS=2, MIN_MOVABLE_BODIES=2)
+    world, ref = _world(64, seed=23, **over), _oracle(64, seed=23, **over)
+    world.reset(); ref.reset()
+
+    def check():
+        got = world.observe(pose_modes=True)
+        want = ref.observe(full=True)
+        for key in ('num_episodes', 'num_steps', 'layout_id', 'is_safe', 'is_effective'):
+            assert np.array_equal(got[key].cpu().numpy(), want[key]), key
+        for key in ('position', 'body_mask', 'pose', 'pose2d', 'yaw_cossin'):
+            assert np.array_equal(got[key].cpu().numpy(), want[key].astype(np.float32)), key
+        return got
+    obs = check()
+    assert (obs['num_steps'] == 0).all()
+    mask = obs['body_mask'].cpu().numpy()
+    assert mask.sum() < mask.size                               # some envs have absent (zero-row) bodies
+    assert (obs['pose'].cpu().numpy()[mask == 0] == 0).all()
+    for k in range(3):
+        a = ref.policy_random(k)
+        world.set_actions(a); ref.set_actions(a)
+        world.step_macro(); ref.step_macro()
+        obs = check()
+        if k == 0:
+            # env.attributes is captured at the start of _execute_action (push_env.py:637-644):
+            # after the first step the observation still says num_steps == 0
+            assert (obs['num_steps'] == 0).all()
+            assert (world.env_counters()[:, 1] == 1).all()
+    # yaw agrees with the host mirror of the reference conversion
+    from robovat_amd.math import rotations
+    st = world.body_state().cpu().numpy()
+    p = obs['pose'].cpu().numpy()
+    for i in range(0, 64, 7):
+        for b in range(abi.RV_MAXB):
+            if mask[i, b]:
+                eu = rotations.euler_from_quaternion(st[i, b, 3:7])
+                assert np.allclose(p[i, b, 3:], eu, atol=2e-5)
+    world.close()
+
+
+def test_pose_error_vs_double_oracle_recorded():
+    """max / median body position error HIP(FP32) vs the FP64 oracle after 1, 10, 100
+    substeps of sliding contact and after a whole push, written to
+    gpurun_out/pose_err.json (bench.py reports the same numbers).  The bounds are 4x the
+    values measured on the MI355X in round 2 (profiles/r02_pose_err.json)."""
+    n = 64
+    world, ref = _world(n, seed=9), _oracle(n, seed=9, double=True)
+    f32 = _oracle(n, seed=9)
+    f32.reset()
+    state, params, joints = f32.body_state(), f32.body_params(), f32.joint_state()
+    ref.set_body_params(params); ref.set_joint_state(joints)
+    world.set_body_params(params); world.set_joint_state(joints)
+    state[:, :, 7] += 0.2                      # shove every body at 0.2 m/s
+    ref.set_body_state(state); world.set_body_state(state)
+    out, done = {}, 0
+    bounds = {1: (2e-6, 1e-6), 10: (2e-4, 1e-5), 100: (5e-3, 4e-4)}
+    for horizon in (1, 10, 100):
+        world.step_sub(horizon - done); ref.step_sub(horizon - done); done = horizon
+        got = world.body_state().cpu().numpy().astype(np.float64); want = ref.body_state()
+        perr = np.linalg.norm(got[..., :3] - want[..., :3], axis=-1)
+        dq = np.abs((got[..., 3:7] * want[..., 3:7]).sum(-1)).clip(0, 1)
+        ang = 2.0 * np.arccos(dq)
+        out['substeps_%d' % horizon] = {'max_pos_m': float(perr.max()), 'median_pos_m': float(np.median(perr)),
+                                        'max_angle_rad': float(ang.max())}
+        assert perr.max() <= bounds[horizon][0], (horizon, perr.max())
+        assert np.median(perr) <= bounds[horizon][1], (horizon, np.median(perr))
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'pose_err.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+    world.close()
+
+
+def test_state_view_is_zero_copy_and_matches_getters():
+    world = _world(32, seed=3)
+    world.reset()
+    v = world.state_view()
+    assert np.array_equal(v['body'].cpu().numpy(), world.body_state().cpu().numpy())
+    js = world.joint_state().cpu().numpy()
+    assert np.array_equal(v['joint_q'].cpu().numpy(), js[..., 0]) and np.array_equal(v['joint_qd'].cpu().numpy(), js[..., 1])
+    lp = world.link_poses().cpu().numpy()
+    assert np.array_equal(v['link_pos'].cpu().numpy(), lp[..., :3]) and np.array_equal(v['link_quat'].cpu().numpy(), lp[..., 3:])
+    assert np.array_equal(v['active'].cpu().numpy(), world.body_params().cpu().numpy()[..., 0].astype(np.int32))
+    # zero copy: the view sees the next step without another call
+    before = v['body'].clone()
+    world.set_actions(world.policy_random(0)); world.step_macro(); world.synchronize()
+    assert not np.array_equal(before.cpu().numpy(), v['body'].cpu().numpy())
+    assert np.array_equal(v['body'].cpu().numpy(), world.body_state().cpu().numpy())
+    world.close()
+
+
+def test_rollout_record_tail_and_unstepped_rewards():
+    """Steps an env does not take (episode over, no auto-reset) are recorded as reward 0 /
+    done 1, and rv_reward of an env that rv_step_macro skipped is 0 (the reference raises
+    'Forget to reset?', robot_env.py:244-245)."""
+    world = _world(16, seed=41, MAX_STEPS=2)
+    world.reset()
+    r, d = world.rollout(5, first_macro_index=0, auto_reset=False, record=True)
+    r, d = r.cpu().numpy(), d.cpu().numpy()
+    assert (d[1:] == 1).all() and (r[2:] == 0).all() and np.isfinite(r).all()
+    st = world.stats()
+    assert st['env_steps'] == 32 and st['episodes_done'] == 16
+    assert st['unsafe'] + st['useful'] <= 32 and st['useful'] + st['ineffective'] + st['unsafe'] >= 32
+    world.set_actions(world.policy_random(9)); world.step_macro()      # every env is done: nothing steps
+    assert world.stats()['env_steps'] == 0
+    rr, dd = world.reward()
+    assert (rr.cpu().numpy() == 0).all() and (dd.cpu().numpy() == 1).all()
+    world.close()
+
+
+def test_motor_targets_grip_and_reset_targets():
+    world = _world(4, seed=2)
+    world.reset()
+    js0 = world.joint_state().cpu().numpy()
+    world.reset_targets()                                  # ControllableBody.reset_targets
+    world.grip(1.0)                                        # close: fingers move towards each other
+    world.step_sub(600)
+    js1 = world.joint_state().cpu().numpy()
+    assert (js1[:, 7, 0] < js0[:, 7, 0] - 0.01).all() and (js1[:, 8, 0] > js0[:, 8, 0] + 0.01).all()
+    q = js1[..., 0].copy(); q[:, 0] += 0.2
+    mask = np.zeros((4, abi.RV_NJ), np.uint8); mask[:, 0] = 1
+    world.reset_targets(); world.set_motor_targets(q, mask)  # position_control_array on joint 0 only
+    world.step_sub(1500)
+    js2 = world.joint_state().cpu().numpy()
+    assert np.abs(js2[:, 0, 0] - q[:, 0]).max() < 5e-3
+    world.close()
