@@ -288,7 +288,7 @@ class World(object):
         class _Raw(object):
             pass
         raw = _Raw()
-        raw.__cuda_array_interface__ = {'shape': (self.n, words), 'typestr': '<f4', 'data': (int(v.d_envs), True),
+        raw.__cuda_array_interface__ = {'shape': (self.n, words), 'typestr': '<f4', 'data': (int(v.d_envs), False),
                                         'version': 2, 'strides': None}
         t = self.torch
         blocks = t.as_tensor(raw, device=self.device)
