@@ -32,6 +32,8 @@ extern "C" {
 #define RV_MAXB        4   /* max movable bodies per env (MAX_MOVABLE_BODIES)      */
 #define RV_MAXH        4   /* convex hulls per shape (V-HACD parts)                */
 #define RV_MAXV       16   /* vertices per convex hull                             */
+#define RV_MAXP       28   /* faces per convex hull (2 V - 4 for V = 16)           */
+#define RV_PC_MAXPIX 4096  /* visible pixels of one body kept for point-cloud sampling */
 #define RV_MAX_SHAPES 16   /* shape templates per scene                            */
 #define RV_NJ          9   /* arm joints: 7 limb (right_j0..j6) + 2 finger         */
 #define RV_NLIMB       7
@@ -75,6 +77,10 @@ typedef struct rv_shape {
   float   verts[RV_MAXH][RV_MAXV][3];
   float   inertia_k[3]; /* principal inertia per unit mass at unit scale        */
   float   radius;       /* bounding radius about the COM at unit scale          */
+  /* face planes n.x <= d of every hull (same frame, unit scale), for the depth /
+   * segmentation render behind SegmentedPointCloudObs (bullet_camera.py:188-235) */
+  int32_t n_planes[RV_MAXH];
+  float   planes[RV_MAXH][RV_MAXP][4];
 } rv_shape;
 
 /* Kinematic description of the Sawyer-like arm (replaces the URDF tree that
@@ -184,9 +190,18 @@ typedef struct rv_config {
   int32_t  num_goal_steps;       /* 0 = None                                   */
   int32_t  max_steps;            /* 0 = None (robot_env.py:214)                */
   float    success_thresh;
-  /* observation (camera_obs.py:127-238) */
+  /* observation (camera_obs.py:127-238): SegmentedPointCloudObs over the simulated
+   * Kinect2 depth camera (push_env.py:50-55; bullet_camera.py:18-23).  Extrinsics as in
+   * the reference: x_cam = cam_rotation * x_world + cam_translation (camera.py:76-79),
+   * intrinsics fx, fy, cx, cy, skew (bullet_camera.py:47-51). */
   int32_t  num_points;
-  float    camera_pos[3];
+  int32_t  cam_height, cam_width;
+  float    cam_intrinsics[5];
+  float    cam_rotation[9];
+  float    cam_translation[3];
+  float    cam_near;
+  int32_t  use_crop;             /* OBS.CROP_MIN / CROP_MAX (camera_obs.py:187-192)  */
+  float    crop_min[3], crop_max[3];
 } rv_config;
 
 /* Per-launch statistics of rv_step_macro / rv_reset (device-side reductions of
@@ -230,6 +245,14 @@ int  rv_step_macro(rv_world* w);
  *      step, otherwise it stops.  d_rewards / d_dones: optional [n_steps][N]. */
 int  rv_rollout(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t auto_reset,
                 float* d_rewards, uint8_t* d_dones);
+/* The same rollout returning what every env.step() of the loop returns
+ * (robot_env.py:275: observation, reward, done): per-step observation rows
+ * [n_steps][N]... in the layouts of rv_obs_buffers (NULL members are skipped;
+ * steps not taken are zero rows).  The segmented point clouds of all steps are
+ * rendered from per-step pose snapshots right after the stepping kernel. */
+struct rv_obs_buffers;
+int  rv_rollout_record(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t auto_reset,
+                       float* d_rewards, uint8_t* d_dones, const struct rv_obs_buffers* step_obs /* host struct of device pointers */);
 /* ---- the same loop run the way the reference runs it at scale: every env is an
  *      independent worker (tools/parallel_run.py:54-90 starts one process per
  *      env, none waits for another).  The N envs share a pool of

@@ -46,7 +46,7 @@ def _lib(double):
                      'orc_get_episode_returns', 'orc_get_stats', 'orc_eval_reward',
                      'orc_eval_waypoints', 'orc_set_external_control', 'orc_motor_targets',
                      'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout', 'orc_set_pose_f32',
-                     'orc_rollout_counts'):
+                     'orc_rollout_counts', 'orc_render', 'orc_point_cloud'):
             getattr(lib, name).restype = None
         lib.orc_is_limb_ready.restype = C.c_int
         lib.orc_is_gripper_ready.restype = C.c_int
@@ -218,6 +218,19 @@ class OracleWorld(object):
         return {'position': pos, 'body_mask': mask, 'num_episodes': attrs[:, 0], 'num_steps': attrs[:, 1],
                 'layout_id': attrs[:, 2], 'is_safe': attrs[:, 3], 'is_effective': attrs[:, 4],
                 'pose': pose, 'pose2d': pose2d, 'yaw_cossin': ycs}
+
+    def render(self, env=0):
+        """Depth (eye z, 0 = nothing) and segmentation image (body index, RV_MAXB = table,
+        255 = nothing) of one env, as the point-cloud oracle sees it."""
+        h, w = int(self.cfg.cam_height), int(self.cfg.cam_width)
+        depth = np.zeros((h, w), dtype=np.float32); seg = np.zeros((h, w), dtype=np.uint8)
+        self.lib.orc_render(self.h, C.c_int(env), _p(depth), _p(seg))
+        return depth, seg
+
+    def point_cloud(self):
+        out = np.zeros((self.n, abi.RV_MAXB, int(self.cfg.num_points), 3), dtype=np.float32)
+        self.lib.orc_point_cloud(self.h, _p(out))
+        return out
 
     def reward(self):
         r = np.zeros(self.n); d = np.zeros(self.n, dtype=np.uint8)

@@ -1819,6 +1819,196 @@ void orc_observe(orc_world* w, double* position, double* body_mask, int64_t* att
     }
   }
 }
+/* -------------------------------------------------- SegmentedPointCloudObs --
+ * Restatement of the chain BulletCamera._frames (bullet_camera.py:188-235: depth +
+ * segmentation render, depth linearised to eye z) -> Camera.deproject_depth_image
+ * (camera.py:213-244) -> convert_segment_ids / group_by_labels
+ * (point_cloud_utils.py:110-157; downsample :23-39: with replacement iff the body has
+ * fewer than num_points pixels, zeros if it has none).  The render is a ray cast of the
+ * convex hulls (face planes of rv_shape) and the table; the arm is off-stage when the
+ * reference takes the observation and is not rendered.  Sampling: the num_points smallest
+ * per-pixel Philox keys (a uniformly random subset) or num_points draws with replacement. */
+#define STREAM_PC 7u
+static void pc_pixel_dir_cam(const rv_config* c, real u, real v, real* d) {
+  const real fx = (real)c->cam_intrinsics[0], fy = (real)c->cam_intrinsics[1], cx = (real)c->cam_intrinsics[2], cy = (real)c->cam_intrinsics[3], sk = (real)c->cam_intrinsics[4];
+  real y = (v - cy) / fy;
+  real x = (u - cx - sk * y) / fx;
+  d[0] = x; d[1] = y; d[2] = R(1.0);
+}
+static void pc_cam_rot(const rv_config* c, real* Rm) { for (int i = 0; i < 9; ++i) Rm[i] = (real)c->cam_rotation[i]; }
+static void pc_cam_position(const rv_config* c, real* o) {
+  real Rm[9], t[3] = {(real)c->cam_translation[0], (real)c->cam_translation[1], (real)c->cam_translation[2]}, p[3];
+  pc_cam_rot(c, Rm); m3tmulv(p, Rm, t);
+  o[0] = -p[0]; o[1] = -p[1]; o[2] = -p[2];
+}
+static int pc_ray_hull(const float (*planes)[4], int n, real sc, real margin, const real* o, const real* d, real* t_hit) {
+  real t0 = R(0.0), t1 = R(1e30);
+  for (int i = 0; i < n; ++i) {
+    real nn[3] = {(real)planes[i][0], (real)planes[i][1], (real)planes[i][2]};
+    real off = (real)planes[i][3] * sc + margin;
+    real den = v3dot(nn, d);
+    real num = off - v3dot(nn, o);
+    if (den < R(0.0)) { real t = num / den; if (t > t0) t0 = t; }
+    else if (den > R(0.0)) { real t = num / den; if (t < t1) t1 = t; }
+    else if (num < R(0.0)) return 0;
+  }
+  if (t0 > t1) return 0;
+  *t_hit = t0;
+  return 1;
+}
+static int pc_ray_table(const rv_config* c, real table_z, const real* o, const real* d, real* t_hit) {
+  const real lo[3] = {(real)c->table_center[0] - (real)c->table_half[0], (real)c->table_center[1] - (real)c->table_half[1], table_z - (real)c->table_thickness};
+  const real hi[3] = {(real)c->table_center[0] + (real)c->table_half[0], (real)c->table_center[1] + (real)c->table_half[1], table_z};
+  real t0 = R(0.0), t1 = R(1e30);
+  for (int k = 0; k < 3; ++k) {
+    if (d[k] != R(0.0)) {
+      real a = (lo[k] - o[k]) / d[k], b = (hi[k] - o[k]) / d[k];
+      real tn = a < b ? a : b, tf = a < b ? b : a;
+      if (tn > t0) t0 = tn;
+      if (tf < t1) t1 = tf;
+    } else if (o[k] < lo[k] || o[k] > hi[k]) return 0;
+  }
+  if (t0 > t1) return 0;
+  *t_hit = t0;
+  return 1;
+}
+/* nearest hit of a pixel ray: body index, RV_MAXB = table, -1 = nothing */
+static int pc_render_pixel(const orc_world* w, const orc_env* e, real rot[][9], const real* cam_o, const real* dw, real* depth) {
+  const rv_config* c = &w->cfg;
+  real best = R(1e30); int who = -1;
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (!e->bp[b].active) continue;
+    const rv_shape* sh = &w->scene.shapes[e->bp[b].shape];
+    real rel[3]; v3sub(rel, cam_o, e->body[b].p);
+    real r = (real)sh->radius * e->bp[b].scale + (real)c->margin;
+    real dd = v3dot(dw, dw), rd = v3dot(rel, dw);
+    real perp2 = v3dot(rel, rel) - rd * rd / dd;
+    if (perp2 > r * r) continue;
+    real ol[3], dl[3];
+    m3tmulv(ol, rot[b], rel); m3tmulv(dl, rot[b], dw);
+    for (int h = 0; h < sh->n_hulls; ++h) {
+      real t;
+      if (pc_ray_hull(sh->planes[h], sh->n_planes[h], e->bp[b].scale, (real)c->margin, ol, dl, &t) && t < best) { best = t; who = b; }
+    }
+  }
+  real tt;
+  if (pc_ray_table(c, e->table_z, cam_o, dw, &tt) && tt < best) { best = tt; who = RV_MAXB; }
+  *depth = best;
+  return who;
+}
+static void pc_deproject(const rv_config* c, const real* cam_o, real u, real v, real z, real* out) {
+  real d[3], pc[3], Rm[9], pw[3];
+  pc_pixel_dir_cam(c, u, v, d);
+  pc[0] = d[0] * z; pc[1] = d[1] * z; pc[2] = d[2] * z;
+  pc_cam_rot(c, Rm); m3tmulv(pw, Rm, pc);
+  v3add(out, cam_o, pw);
+}
+static int pc_crop_ok(const rv_config* c, const real* p) {
+  if (!c->use_crop) return 1;
+  return p[0] >= (real)c->crop_min[0] && p[1] >= (real)c->crop_min[1] && p[2] >= (real)c->crop_min[2] &&
+         p[0] <= (real)c->crop_max[0] && p[1] <= (real)c->crop_max[1] && p[2] <= (real)c->crop_max[2];
+}
+static uint32_t pc_hash(const rv_config* c, uint32_t gid, uint32_t rng_arg, uint32_t ctr) {
+  uint32_t cc[4] = {ctr, rng_arg, gid, STREAM_PC}, kk[2] = {c->seed_lo, c->seed_hi}, out[4];
+  philox4x32_10(cc, kk, out);
+  return out[0];
+}
+static void pc_body_rots(const orc_env* e, real rot[][9]) { for (int b = 0; b < RV_MAXB; ++b) qmat(rot[b], e->body[b].q); }
+/* the full depth / segmentation image of one env (tests: input of the reference-shaped
+ * deproject -> convert_segment_ids -> group_by_labels pipeline).  segmask: body index,
+ * RV_MAXB = table, 255 = nothing; depth 0 where nothing is hit */
+void orc_render(orc_world* w, int env, float* depth, uint8_t* segmask) {
+  const rv_config* c = &w->cfg; const orc_env* e = &w->env[env];
+  real rot[RV_MAXB][9], cam_o[3], Rm[9];
+  pc_body_rots(e, rot); pc_cam_position(c, cam_o); pc_cam_rot(c, Rm);
+  for (int v = 0; v < c->cam_height; ++v)
+    for (int u = 0; u < c->cam_width; ++u) {
+      real dc[3], dw[3], dep;
+      pc_pixel_dir_cam(c, (real)u, (real)v, dc); m3tmulv(dw, Rm, dc);
+      int who = pc_render_pixel(w, e, rot, cam_o, dw, &dep);
+      if (who >= 0 && !(dep > (real)c->cam_near)) who = -1;
+      depth[(size_t)v * c->cam_width + u] = who >= 0 ? (float)dep : 0.0f;
+      segmask[(size_t)v * c->cam_width + u] = who >= 0 ? (uint8_t)who : (uint8_t)255;
+    }
+}
+static int cmp_u32(const void* a, const void* b) { uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? -1 : (x > y); }
+/* out: [N][RV_MAXB][num_points][3] */
+void orc_point_cloud(orc_world* w, float* out) {
+  const rv_config* c = &w->cfg; const int P = c->num_points;
+#pragma omp parallel for schedule(dynamic)
+  for (int i = 0; i < w->n; ++i) {
+    const orc_env* e = &w->env[i];
+    const uint32_t gid = (uint32_t)(c->env_id_offset + i);
+    const uint32_t rng_arg = (uint32_t)e->reset_count * 4096u + (uint32_t)e->num_steps;
+    real rot[RV_MAXB][9], cam_o[3], Rm[9];
+    pc_body_rots(e, rot); pc_cam_position(c, cam_o); pc_cam_rot(c, Rm);
+    uint32_t* pix = (uint32_t*)malloc(sizeof(uint32_t) * RV_PC_MAXPIX * 3);
+    uint32_t* key = pix + RV_PC_MAXPIX; uint32_t* sorted = key + RV_PC_MAXPIX;
+    real* dep = (real*)malloc(sizeof(real) * RV_PC_MAXPIX);
+    for (int b = 0; b < RV_MAXB; ++b) {
+      float* o = out + ((size_t)i * RV_MAXB + b) * (size_t)P * 3;
+      int n = 0;
+      if (e->bp[b].active) {
+        const rv_shape* sh = &w->scene.shapes[e->bp[b].shape];
+        real mu = R(1e30), xu = R(-1e30), mv = R(1e30), xv = R(-1e30), mz = R(1e30);
+        for (int h = 0; h < sh->n_hulls; ++h)
+          for (int k = 0; k < sh->n_verts[h]; ++k) {
+            const real sc = e->bp[b].scale;
+            real l[3] = {(real)sh->verts[h][k][0] * sc, (real)sh->verts[h][k][1] * sc, (real)sh->verts[h][k][2] * sc}, rw[3], pw[3], pc[3];
+            m3mulv(rw, rot[b], l); v3add(pw, e->body[b].p, rw);
+            m3mulv(pc, Rm, pw); pc[0] += (real)c->cam_translation[0]; pc[1] += (real)c->cam_translation[1]; pc[2] += (real)c->cam_translation[2];
+            real z = pc[2];
+            real u = ((real)c->cam_intrinsics[0] * pc[0] + (real)c->cam_intrinsics[4] * pc[1]) / pc[2] + (real)c->cam_intrinsics[2];
+            real v = (real)c->cam_intrinsics[1] * pc[1] / pc[2] + (real)c->cam_intrinsics[3];
+            if (z < mz) mz = z;
+            if (z > (real)c->cam_near) { if (u < mu) mu = u; if (u > xu) xu = u; if (v < mv) mv = v; if (v > xv) xv = v; }
+          }
+        if (mz > (real)c->cam_near) {
+          const real W1 = (real)(c->cam_width - 1), H1 = (real)(c->cam_height - 1);
+          const int u0 = (int)rclamp(R(floor)(mu) - R(1.0), R(0.0), W1), u1 = (int)rclamp(R(floor)(xu) + R(2.0), R(0.0), W1);
+          const int v0 = (int)rclamp(R(floor)(mv) - R(1.0), R(0.0), H1), v1 = (int)rclamp(R(floor)(xv) + R(2.0), R(0.0), H1);
+          const int ww = u1 - u0 + 1, hh = v1 - v0 + 1;
+          const int total = (xu < R(0.0) || xv < R(0.0) || mu > W1 || mv > H1) ? 0 : ww * hh;
+          for (int idx = 0; idx < total; ++idx) {
+            const int u = u0 + idx % ww, v = v0 + idx / ww;
+            real dc[3], dw[3], d, pt[3];
+            pc_pixel_dir_cam(c, (real)u, (real)v, dc); m3tmulv(dw, Rm, dc);
+            int who = pc_render_pixel(w, e, rot, cam_o, dw, &d);
+            if (!(who == b && d > (real)c->cam_near)) continue;
+            pc_deproject(c, cam_o, (real)u, (real)v, d, pt);
+            if (!pc_crop_ok(c, pt)) continue;
+            if (n < RV_PC_MAXPIX) { pix[n] = ((uint32_t)v << 16) | (uint32_t)u; dep[n] = d; }
+            n++;
+          }
+          if (n > RV_PC_MAXPIX) n = RV_PC_MAXPIX;
+        }
+      }
+      if (n == 0) { for (int j = 0; j < P * 3; ++j) o[j] = 0.0f; continue; }
+      if (n < P) {
+        for (int j = 0; j < P; ++j) {
+          uint32_t k = pc_hash(c, gid, rng_arg, ((uint32_t)b << 16) | (uint32_t)j) % (uint32_t)n;
+          real pt[3]; pc_deproject(c, cam_o, (real)(pix[k] & 0xffffu), (real)(pix[k] >> 16), dep[k], pt);
+          o[3 * j] = (float)pt[0]; o[3 * j + 1] = (float)pt[1]; o[3 * j + 2] = (float)pt[2];
+        }
+        continue;
+      }
+      for (int k = 0; k < n; ++k) { key[k] = pc_hash(c, gid, rng_arg, 0x80000000u | ((uint32_t)b << 16) | (uint32_t)k); sorted[k] = key[k]; }
+      qsort(sorted, (size_t)n, sizeof(uint32_t), cmp_u32);
+      const uint32_t T = sorted[P - 1];
+      int n_lt = 0; for (int k = 0; k < n; ++k) n_lt += key[k] < T;
+      int need = P - n_lt, outn = 0;
+      for (int k = 0; k < n && outn < P; ++k) {
+        int sel = key[k] < T;
+        if (!sel && key[k] == T && need > 0) { sel = 1; need--; }
+        if (!sel) continue;
+        real pt[3]; pc_deproject(c, cam_o, (real)(pix[k] & 0xffffu), (real)(pix[k] >> 16), dep[k], pt);
+        o[3 * outn] = (float)pt[0]; o[3 * outn + 1] = (float)pt[1]; o[3 * outn + 2] = (float)pt[2];
+        outn++;
+      }
+    }
+    free(pix); free(dep);
+  }
+}
 void orc_reward(orc_world* w, double* reward, uint8_t* done) {
   /* an env that was not stepped by the last call (episode over) reports reward 0 */
   for (int i = 0; i < w->n; ++i) { reward[i] = w->env[i].substeps_last > 0 ? w->env[i].last_reward : R(0.0); done[i] = (uint8_t)w->env[i].done; }

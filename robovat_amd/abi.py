@@ -8,6 +8,8 @@ import ctypes as C
 RV_MAXB = 4
 RV_MAXH = 4
 RV_MAXV = 16
+RV_MAXP = 28
+RV_PC_MAXPIX = 4096
 RV_MAX_SHAPES = 16
 RV_NJ = 9
 RV_NLIMB = 7
@@ -37,6 +39,8 @@ class rv_shape(C.Structure):
         ('verts', ((f32 * 3) * RV_MAXV) * RV_MAXH),
         ('inertia_k', f32 * 3),
         ('radius', f32),
+        ('n_planes', i32 * RV_MAXH),
+        ('planes', ((f32 * 4) * RV_MAXP) * RV_MAXH),
     ]
 
 
@@ -115,7 +119,13 @@ class rv_config(C.Structure):
         ('num_goal_steps', i32), ('max_steps', i32),
         ('success_thresh', f32),
         ('num_points', i32),
-        ('camera_pos', f32 * 3),
+        ('cam_height', i32), ('cam_width', i32),
+        ('cam_intrinsics', f32 * 5),
+        ('cam_rotation', f32 * 9),
+        ('cam_translation', f32 * 3),
+        ('cam_near', f32),
+        ('use_crop', i32),
+        ('crop_min', f32 * 3), ('crop_max', f32 * 3),
     ]
 
 

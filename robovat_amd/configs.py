@@ -16,6 +16,20 @@ from robovat_amd import abi
 from robovat_amd.envs.push import push_layouts
 
 
+def _look_at(eye, target, up=(0.0, 0.0, 1.0)):
+    """Extrinsics (R, t) with x_cam = R x_world + t of a camera at ``eye`` looking at
+    ``target`` (camera z forward, x right, y down -- the Hartley-Zisserman frame the
+    reference's intrinsics use, bullet_camera.py:28-83)."""
+    eye, target, up = (np.asarray(v, dtype=np.float64) for v in (eye, target, up))
+    z = target - eye
+    z /= np.linalg.norm(z)
+    x = np.cross(z, up)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    rot = np.stack([x, y, z])
+    return rot.tolist(), (-rot @ eye).tolist()
+
+
 class AttrDict(dict):
     """Minimal EasyDict stand-in (attribute access, recursive)."""
 
@@ -87,10 +101,16 @@ PUSH_ENV_CONFIG = {
         },
     },
     'DROP': {'MASS': 0.1, 'FRICTION': 1.0, 'SAFE_HEIGHT': 0.2},
-    'OBS': {'NUM_POINTS': 256},
+    'OBS': {'NUM_POINTS': 256, 'CROP_MIN': None, 'CROP_MAX': None},
     'USE_PRESTIGE_OBS': True,
     'USE_VISUALIZATION_OBS': False,
-    'KINECT2': {'DEPTH': {'TRANSLATION': [0.6, 0.0, 1.2]}},
+    # simulated Kinect2 depth camera (push_env.py:50-55).  Extrinsics in the reference's form
+    # x_cam = ROTATION x_world + TRANSLATION (camera.py:76-79); BUILD-CHOSEN: the camera stands
+    # across the table from the robot, 0.95 m above the table top, looking at the table centre
+    'KINECT2': {'DEPTH': dict(zip(('ROTATION', 'TRANSLATION'), _look_at((1.45, 0.0, 0.95), (0.6, 0.0, 0.0))),
+                              HEIGHT=424, WIDTH=512,
+                              INTRINSICS=[[365.0, 0.0, 256.0], [0.0, 365.0, 212.0], [0.0, 0.0, 1.0]],
+                              INTRINSICS_NOISE=None, TRANSLATION_NOISE=None, ROTATION_NOISE=None)},
     'PHYSICS': {
         'TIME_STEP': 1e-3, 'GRAVITY_Z': -9.8,
         'SOLVER_ITERS': 8, 'ERP': 0.2, 'SLOP': 0.0005, 'MARGIN': 0.001,
@@ -247,7 +267,17 @@ def make_rv_config(env_cfg=None, robot_cfg=None, shape_names=None, n_envs=1,
     c.max_steps = int(env_cfg.MAX_STEPS or 0)
     c.success_thresh = env_cfg.SUCCESS_THRESH
     c.num_points = env_cfg.OBS.NUM_POINTS
-    abi.assign(c.camera_pos, env_cfg.KINECT2.DEPTH.TRANSLATION)
+    cam = env_cfg.KINECT2.DEPTH
+    c.cam_height, c.cam_width = int(cam.HEIGHT), int(cam.WIDTH)
+    k = np.asarray(cam.INTRINSICS, dtype=np.float64).reshape(3, 3)
+    abi.assign(c.cam_intrinsics, [k[0, 0], k[1, 1], k[0, 2], k[1, 2], k[0, 1]])
+    abi.assign(c.cam_rotation, np.asarray(cam.ROTATION, dtype=np.float64).reshape(9).tolist())
+    abi.assign(c.cam_translation, np.asarray(cam.TRANSLATION, dtype=np.float64).reshape(3).tolist())
+    c.cam_near = 0.02                                    # bullet_camera.py:18
+    if env_cfg.OBS.get('CROP_MIN') is not None and env_cfg.OBS.get('CROP_MAX') is not None:
+        c.use_crop = 1
+        abi.assign(c.crop_min, list(env_cfg.OBS.CROP_MIN))
+        abi.assign(c.crop_max, list(env_cfg.OBS.CROP_MAX))
     return c
 
 

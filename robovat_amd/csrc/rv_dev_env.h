@@ -23,6 +23,7 @@
 #pragma once
 #include "../../include/rovat.h"
 #include "rv_dev_collide.h"
+#include "rv_dev_obs.h"
 
 namespace rv {
 
@@ -1827,6 +1828,60 @@ RV_DEV void compute_obs(DevEnv& e) {
       e.obs_pos[b][k] = e.active[b] ? e.body[b][k] : 0.0f;
     }
 }
+// pose snapshot for the point-cloud render (rv_dev_obs.h)
+RV_DEV void obs_snap_fill(const DevEnv& e, ObsSnap& s) {
+  for (int b = 0; b < RV_MAXB; ++b) {
+    for (int k = 0; k < 7; ++k) s.pose[b][k] = e.body[b][k];
+    s.scale[b] = e.scale[b];
+    s.shape[b] = e.active[b] ? e.shape[b] : -1;
+  }
+  s.table_z = e.table_z;
+  s.rng_arg = (uint32_t)e.reset_count * 4096u + (uint32_t)e.num_steps;
+}
+// one observation row: PoseObs in its four modalities (pose_obs.py:53-73), the attribute
+// observations (attribute_obs.py:16-115; env.attributes snapshot), body mask.  NULL members
+// are skipped.  e == nullptr writes the zero row of a step that was not taken.
+RV_DEV void obs_write_row(const DevEnv* e, const rv_obs_buffers& o, size_t row, const rv_config* cfg) {
+  for (int b = 0; b < RV_MAXB; ++b) {
+    const size_t ib = row * RV_MAXB + b;
+    const int on = e ? e->active[b] : 0;
+    float pos[3] = {0.0f, 0.0f, 0.0f}, eu[3] = {0.0f, 0.0f, 0.0f};
+    if (e) for (int k = 0; k < 3; ++k) pos[k] = e->obs_pos[b][k];
+    if (o.d_position) for (int k = 0; k < 3; ++k) o.d_position[ib * 3 + k] = pos[k];
+    if (o.d_body_mask) o.d_body_mask[ib] = (float)on;
+    if (o.d_pose || o.d_pose2d || o.d_yaw_cossin) {
+      if (on) quat_to_euler(ldq(e->body[b] + 3), eu);
+      if (o.d_pose) for (int k = 0; k < 3; ++k) { o.d_pose[ib * 6 + k] = pos[k]; o.d_pose[ib * 6 + 3 + k] = eu[k]; }
+      if (o.d_pose2d) { o.d_pose2d[ib * 3] = pos[0]; o.d_pose2d[ib * 3 + 1] = pos[1]; o.d_pose2d[ib * 3 + 2] = eu[2]; }
+      if (o.d_yaw_cossin) {
+        float sn = 0.0f, cs = 0.0f;
+        if (on) sincosr(eu[2], &sn, &cs);
+        o.d_yaw_cossin[ib * 2] = cs; o.d_yaw_cossin[ib * 2 + 1] = sn;
+      }
+    }
+  }
+  if (o.d_num_episodes) o.d_num_episodes[row] = e ? e->obs_num_episodes : 0;
+  if (o.d_num_steps) o.d_num_steps[row] = e ? e->obs_num_steps : 0;
+  if (o.d_layout_id) o.d_layout_id[row] = e ? cfg->layout_id : 0;
+  if (o.d_is_safe) o.d_is_safe[row] = e ? e->is_safe : 0;
+  if (o.d_is_effective) o.d_is_effective[row] = e ? e->is_effective : 0;
+}
+// what a rollout records per env.step(): reward, done, observation row, pose snapshot
+struct RolloutRec {
+  float* rewards; uint8_t* dones;
+  rv_obs_buffers obs; int has_obs;
+  ObsSnap* snaps;
+};
+RV_DEV void rollout_record(const RolloutRec& r, const DevEnv* e, size_t row, const rv_config* cfg) {
+  if (r.rewards) r.rewards[row] = e ? e->last_reward : 0.0f;
+  if (r.dones) r.dones[row] = (uint8_t)(e ? e->done : 1);
+  if (r.has_obs) obs_write_row(e, r.obs, row, cfg);
+  if (r.snaps) {
+    if (e) obs_snap_fill(*e, r.snaps[row]);
+    else for (int b = 0; b < RV_MAXB; ++b) r.snaps[row].shape[b] = -1;
+  }
+}
+
 RV_DEV int on_tiles(const float* xy, const float (*tiles)[2], int n, float size, const float* offset, float max_dist) {
   for (int i = 0; i < n; ++i) {
     float tx = offset[0] + tiles[i][0] * size;
@@ -2189,7 +2244,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
 // processes are just as independent, tools/parallel_run.py:54-90).  The k-th step
 // an env takes in the launch uses macro index first_index + k as before.
 RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int first_index, int auto_reset,
-                        float* rewards, uint8_t* dones, int env, int n_envs, int* budget = nullptr) {
+                        const RolloutRec& rec, int env, int n_envs, int* budget = nullptr) {
   const rv_config* c = K.cfg;
   RV_LANES_BEGIN
     if (lane == 0) launch_counters_zero(S.e);
@@ -2222,20 +2277,14 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
     RV_LANES_END
     env_step(S, K, 0);
     RV_LANES_BEGIN
-      if (lane == 0) {
-        if (rewards) rewards[(size_t)k * n_envs + env] = S.e.last_reward;
-        if (dones) dones[(size_t)k * n_envs + env] = (uint8_t)S.e.done;
-      }
+      if (lane == 0 && budget == nullptr) rollout_record(rec, &S.e, (size_t)k * n_envs + env, c);
     RV_LANES_END
     k_end = k + 1;
   }
   // steps not taken (episode over, no auto-reset): reward 0, done
   if (budget == nullptr) {
     RV_LANES_BEGIN
-      for (int k = k_end + lane; k < n_steps; k += 64) {
-        if (rewards) rewards[(size_t)k * n_envs + env] = 0.0f;
-        if (dones) dones[(size_t)k * n_envs + env] = (uint8_t)1;
-      }
+      for (int k = k_end + lane; k < n_steps; k += 64) rollout_record(rec, nullptr, (size_t)k * n_envs + env, c);
     RV_LANES_END
   }
 }

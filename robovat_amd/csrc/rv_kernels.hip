@@ -16,6 +16,7 @@
 
 #include "../../include/rovat.h"
 #include "rv_dev_env.h"
+#include "rv_dev_obs.h"
 
 using namespace rv;
 
@@ -33,7 +34,7 @@ struct EnvKernelArgs {
   int check_after, min_stable, max_steps;
   int stop_after;   // profiling hook (env RV_DEBUG_STOP, MODE_SUB only)
   int first_index, auto_reset;   // MODE_ROLLOUT
-  float* rewards; uint8_t* dones;
+  RolloutRec rec;                // MODE_ROLLOUT: what every env.step() returns
   int* budget;                   // MODE_ROLLOUT, asynchronous: shared pool of env.step() calls
   int32_t* steps_taken;          // optional [N]
 };
@@ -68,12 +69,8 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   if (MODE == MODE_ROLLOUT) skip = (S.e.done != 0) && !args.auto_reset;
   if (skip) {
     if (lane == 0) launch_counters_zero(*g);
-    if (MODE == MODE_ROLLOUT) {   // steps not taken: reward 0, done
-      for (int k = lane; k < args.n_substeps; k += 64) {
-        if (args.rewards) args.rewards[(size_t)k * args.n_envs + env] = 0.0f;
-        if (args.dones) args.dones[(size_t)k * args.n_envs + env] = (uint8_t)1;
-      }
-    }
+    if (MODE == MODE_ROLLOUT && args.budget == nullptr)   // steps not taken: reward 0, done, zero rows
+      for (int k = lane; k < args.n_substeps; k += 64) rollout_record(args.rec, nullptr, (size_t)k * args.n_envs + env, &S.cfg);
     return;
   }
   if (MODE != MODE_RESET) env_enter(S, K);
@@ -84,7 +81,7 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
     __syncthreads();
     env_step(S, K);
   } else if (MODE == MODE_ROLLOUT) {
-    env_rollout(S, K, K.cfg->env_id_offset + env, args.n_substeps, args.first_index, args.auto_reset, args.rewards, args.dones, env, args.n_envs, args.budget);
+    env_rollout(S, K, K.cfg->env_id_offset + env, args.n_substeps, args.first_index, args.auto_reset, args.rec, env, args.n_envs, args.budget);
     if (lane == 0 && args.steps_taken) args.steps_taken[env] = S.e.stepped;
   } else if (MODE == MODE_SUB) {
     if (lane == 0) launch_counters_zero(S.e);
@@ -254,65 +251,117 @@ __global__ void k_manifold_counts(const DevEnv* envs, int n, int32_t* out) {
 }
 __global__ void k_observe(const DevEnv* envs, int n, rv_obs_buffers o, const rv_config* cfg) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
-  const DevEnv& e = envs[i];
-  for (int b = 0; b < RV_MAXB; ++b) {
-    if (o.d_position) for (int k = 0; k < 3; ++k) o.d_position[((size_t)i * RV_MAXB + b) * 3 + k] = e.obs_pos[b][k];
-    if (o.d_body_mask) o.d_body_mask[(size_t)i * RV_MAXB + b] = (float)e.active[b];
-    // PoseObs 'pose' / 'pose2d' / 'yaw_cossin' (pose_obs.py:53-73); zero rows for absent bodies
-    if (o.d_pose || o.d_pose2d || o.d_yaw_cossin) {
-      const int on = e.active[b];
-      float eu[3] = {0.0f, 0.0f, 0.0f};
-      if (on) quat_to_euler(ldq(e.body[b] + 3), eu);
-      if (o.d_pose) {
-        float* p = o.d_pose + ((size_t)i * RV_MAXB + b) * 6;
-        for (int k = 0; k < 3; ++k) { p[k] = e.obs_pos[b][k]; p[3 + k] = eu[k]; }
-      }
-      if (o.d_pose2d) {
-        float* p = o.d_pose2d + ((size_t)i * RV_MAXB + b) * 3;
-        p[0] = e.obs_pos[b][0]; p[1] = e.obs_pos[b][1]; p[2] = eu[2];
-      }
-      if (o.d_yaw_cossin) {
-        float* p = o.d_yaw_cossin + ((size_t)i * RV_MAXB + b) * 2;
-        float sn = 0.0f, cs = 0.0f;
-        if (on) sincosr(eu[2], &sn, &cs);
-        p[0] = cs; p[1] = sn;
+  obs_write_row(&envs[i], o, (size_t)i, cfg);
+}
+__global__ void k_obs_snap(const DevEnv* envs, int n, ObsSnap* snaps) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  obs_snap_fill(envs[i], snaps[i]);
+}
+RV_DEV float wave_min(float x) { for (int o = 32; o > 0; o >>= 1) { float y = __shfl_xor(x, o); x = y < x ? y : x; } return x; }
+RV_DEV float wave_max(float x) { for (int o = 32; o > 0; o >>= 1) { float y = __shfl_xor(x, o); x = y > x ? y : x; } return x; }
+// SegmentedPointCloudObs (camera_obs.py:182-238): one wave per (observation, body); see rv_dev_obs.h
+__global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_snaps, int n_envs, float* out,
+                                                    const rv_config* c, const rv_scene* scene) {
+  __shared__ uint32_t s_pix[RV_PC_MAXPIX];
+  __shared__ float s_dep[RV_PC_MAXPIX];
+  __shared__ uint32_t s_key[RV_PC_MAXPIX];
+  __shared__ float s_rot[RV_MAXB][9];
+  const int lane = (int)threadIdx.x;
+  const int si = (int)blockIdx.x / RV_MAXB, b = (int)blockIdx.x % RV_MAXB;
+  if (si >= n_snaps) return;
+  const ObsSnap& s = snaps[si];
+  const int P = c->num_points;
+  float* o = out + ((size_t)si * RV_MAXB + b) * (size_t)P * 3;
+  const uint32_t gid = (uint32_t)(c->env_id_offset + si % n_envs);
+  if (lane < RV_MAXB) { m3 m = qmat(ldq(s.pose[lane] + 3)); stm(s_rot[lane], m); }
+  __syncthreads();
+  int n = 0;
+  const v3 cam_o = cam_position(c);
+  if (s.shape[b] >= 0) {
+    // screen rectangle of the body
+    const rv_shape* sh = &scene->shapes[s.shape[b]];
+    float mu = 1e30f, xu = -1e30f, mv = 1e30f, xv = -1e30f, mz = 1e30f;
+    {
+      const int h = lane >> 4, i = lane & 15;
+      if (h < sh->n_hulls && i < sh->n_verts[h]) {
+        const float sc = s.scale[b];
+        v3 pw = add(ld3(s.pose[b]), mulv(s_rot[b], mk(sh->verts[h][i][0] * sc, sh->verts[h][i][1] * sc, sh->verts[h][i][2] * sc)));
+        float u, v, z;
+        project_vertex(c, pw, &u, &v, &z);
+        mz = z;
+        if (z > c->cam_near) { mu = xu = u; mv = xv = v; }
       }
     }
+    mu = wave_min(mu); xu = wave_max(xu); mv = wave_min(mv); xv = wave_max(xv); mz = wave_min(mz);
+    if (mz > c->cam_near) {
+      const float W1 = (float)(c->cam_width - 1), H1 = (float)(c->cam_height - 1);
+      const int u0 = (int)fclampr(ffloorr(mu) - 1.0f, 0.0f, W1), u1 = (int)fclampr(ffloorr(xu) + 2.0f, 0.0f, W1);
+      const int v0 = (int)fclampr(ffloorr(mv) - 1.0f, 0.0f, H1), v1 = (int)fclampr(ffloorr(xv) + 2.0f, 0.0f, H1);
+      const int w = u1 - u0 + 1, hh = v1 - v0 + 1;
+      const int total = (xu < 0.0f || xv < 0.0f || mu > W1 || mv > H1) ? 0 : w * hh;
+      for (int base = 0; base < total; base += 64) {
+        const int idx = base + lane;
+        bool vis = false; float dep = 0.0f; int u = 0, v = 0;
+        if (idx < total) {
+          u = u0 + idx % w; v = v0 + idx / w;
+          v3 dw = cam_to_world_dir(c, pixel_dir_cam(c, (float)u, (float)v));
+          int who = render_pixel(c, scene, s, s_rot, cam_o, dw, &dep);
+          vis = (who == b) && dep > c->cam_near && crop_ok(c, deproject(c, cam_o, (float)u, (float)v, dep));
+        }
+        const unsigned long long bal = __ballot(vis);
+        const int pos = n + (int)__popcll(bal & ((1ull << lane) - 1ull));
+        if (vis && pos < RV_PC_MAXPIX) { s_pix[pos] = ((uint32_t)v << 16) | (uint32_t)u; s_dep[pos] = dep; }
+        n += (int)__popcll(bal);
+      }
+      if (n > RV_PC_MAXPIX) n = RV_PC_MAXPIX;
+    }
   }
-  // attribute observations read env.attributes, captured at the start of
-  // _execute_action / _reset_scene (push_env.py:368-375, 637-644)
-  if (o.d_num_episodes) o.d_num_episodes[i] = e.obs_num_episodes;
-  if (o.d_num_steps) o.d_num_steps[i] = e.obs_num_steps;
-  if (o.d_layout_id) o.d_layout_id[i] = cfg->layout_id;
-  if (o.d_is_safe) o.d_is_safe[i] = e.is_safe;
-  if (o.d_is_effective) o.d_is_effective[i] = e.is_effective;
-}
-// SegmentedPointCloudObs (camera_obs.py:182-238), analytic stand-in for the
-// render -> deproject -> group_by_labels chain: P points per body drawn inside
-// the body's hulls (convex combinations of hull vertices), zeros for absent
-// bodies (point_cloud_utils.py:134-157).  One thread per (env, body, point).
-__global__ void k_point_cloud(const DevEnv* envs, int n, float* out, const rv_config* cfg, const rv_scene* scene) {
-  const int P = cfg->num_points;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)n * RV_MAXB * P) return;
-  const int p = (int)(t % P); const int b = (int)((t / P) % RV_MAXB); const int i = (int)(t / ((size_t)P * RV_MAXB));
-  const DevEnv& e = envs[i];
-  float* o = out + t * 3;
-  if (!e.active[b]) { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; return; }
-  const rv_shape* s = &scene->shapes[e.shape[b]];
-  Rng g = rng_init(cfg->seed_lo, cfg->seed_hi, (uint32_t)(cfg->env_id_offset + i), 7u, (uint32_t)(b * 65536 + p));
-  int h = rng_randint(g, s->n_hulls);
-  int nv = s->n_verts[h];
-  int i0 = rng_randint(g, nv), i1 = rng_randint(g, nv), i2 = rng_randint(g, nv);
-  float u = rng_uniform01(g), v = rng_uniform01(g);
-  if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
-  float w0 = 1.0f - u - v;
-  float sc = e.scale[b];
-  v3 l = mk((s->verts[h][i0][0] * w0 + s->verts[h][i1][0] * u + s->verts[h][i2][0] * v) * sc,
-            (s->verts[h][i0][1] * w0 + s->verts[h][i1][1] * u + s->verts[h][i2][1] * v) * sc,
-            (s->verts[h][i0][2] * w0 + s->verts[h][i1][2] * u + s->verts[h][i2][2] * v) * sc);
-  m3 r = qmat(ldq(e.body[b] + 3));
-  st3(o, add(ld3(e.body[b]), mulv(r, l)));
+  __syncthreads();
+  if (n == 0) {                                  // group_by_labels: zeros when the body has no pixel
+    for (int j = lane; j < P * 3; j += 64) o[j] = 0.0f;
+    return;
+  }
+  if (n < P) {                                   // downsample: with replacement iff fewer than num_points
+    for (int j = lane; j < P; j += 64) {
+      const uint32_t i = pc_hash(c, gid, s.rng_arg, RV_PC_DRAW_CTR(b, j)) % (uint32_t)n;
+      const uint32_t px = s_pix[i];
+      st3(o + 3 * j, deproject(c, cam_o, (float)(px & 0xffffu), (float)(px >> 16), s_dep[i]));
+    }
+    return;
+  }
+  // uniformly random P-subset: the P smallest keys.  Radix select of the P-th smallest key T
+  for (int i = lane; i < n; i += 64) s_key[i] = pc_hash(c, gid, s.rng_arg, RV_PC_KEY_CTR(b, i));
+  __syncthreads();
+  uint32_t prefix = 0u, mask = 0u; int k = P;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t m2 = mask | (1u << bit);
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const bool z = i < n && (s_key[i] & m2) == prefix;     // high bits match and this bit is 0
+      cnt += (int)__popcll(__ballot(z));
+    }
+    if (k > cnt) { k -= cnt; prefix |= (1u << bit); }
+    mask = m2;
+  }
+  const uint32_t T = prefix;       // k = how many keys equal to T are still needed (scan order)
+  int outn = 0, ties = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const uint32_t key = i < n ? s_key[i] : 0xffffffffu;
+    const bool lt = i < n && key < T;
+    const bool eq = i < n && key == T;
+    const unsigned long long beq = __ballot(eq);
+    const int tie_rank = ties + (int)__popcll(beq & ((1ull << lane) - 1ull));
+    const bool sel = lt || (eq && tie_rank < k);
+    const unsigned long long bs = __ballot(sel);
+    const int pos = outn + (int)__popcll(bs & ((1ull << lane) - 1ull));
+    if (sel && pos < P) {
+      const uint32_t px = s_pix[i];
+      st3(o + 3 * pos, deproject(c, cam_o, (float)(px & 0xffffu), (float)(px >> 16), s_dep[i]));
+    }
+    outn += (int)__popcll(bs); ties += (int)__popcll(beq);
+  }
 }
 __global__ void k_reward(const DevEnv* envs, int n, float* reward, uint8_t* done) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
@@ -419,6 +468,7 @@ struct rv_world {
   DevEnv* d_envs;
   rv_macro_stats* d_stats;
   int* d_budget;
+  ObsSnap* d_snaps; size_t n_snaps_cap;   // pose snapshots for the point-cloud render
   hipEvent_t ev0, ev1;
   bool timed;
 };
@@ -433,11 +483,13 @@ static inline dim3 grid1(int n) { return dim3((unsigned)((n + 127) / 128)); }
 
 template <int MODE>
 static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, float ang, int ca, int ms, int mx,
-                      int first_index = 0, int auto_reset = 0, float* rewards = nullptr, uint8_t* dones = nullptr,
+                      int first_index = 0, int auto_reset = 0, const RolloutRec* rec = nullptr,
                       int* budget = nullptr, int32_t* steps_taken = nullptr) {
   EnvKernelArgs a;
   a.budget = budget; a.steps_taken = steps_taken;
-  a.first_index = first_index; a.auto_reset = auto_reset; a.rewards = rewards; a.dones = dones;
+  a.first_index = first_index; a.auto_reset = auto_reset;
+  memset(&a.rec, 0, sizeof(a.rec));
+  if (rec) a.rec = *rec;
   a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.mask = mask; a.n_envs = w->n;
   { const char* ds = getenv("RV_DEBUG_STOP"); a.stop_after = ds ? atoi(ds) : 0; }
   a.n_substeps = n_sub; a.lin_thr = lin; a.ang_thr = ang; a.check_after = ca; a.min_stable = ms; a.max_steps = mx;
@@ -448,6 +500,20 @@ static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, fl
   HIPCHK(hipEventRecord(w->ev1, w->stream));
   w->timed = true;
   hipLaunchKernelGGL(k_stats, grid1(w->n), dim3(TPB), 0, w->stream, w->d_envs, w->n, w->d_stats, w->cfg.success_thresh);
+  HIPCHK(hipGetLastError());
+  return RV_OK;
+}
+
+static int ensure_snaps(rv_world* w, size_t n) {
+  if (w->n_snaps_cap >= n) return RV_OK;
+  if (w->d_snaps) { HIPCHK(hipStreamSynchronize(w->stream)); HIPCHK(hipFree(w->d_snaps)); w->d_snaps = nullptr; w->n_snaps_cap = 0; }
+  HIPCHK(hipMalloc(&w->d_snaps, sizeof(ObsSnap) * n));
+  w->n_snaps_cap = n;
+  return RV_OK;
+}
+static int launch_point_cloud(rv_world* w, size_t n_snaps, float* d_out) {
+  hipLaunchKernelGGL(k_point_cloud, dim3((unsigned)(n_snaps * RV_MAXB)), dim3(64), 0, w->stream,
+                     w->d_snaps, (int)n_snaps, w->n, d_out, w->d_cfg, w->d_scene);
   HIPCHK(hipGetLastError());
   return RV_OK;
 }
@@ -471,6 +537,7 @@ int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world*
   rv_world* w = new (std::nothrow) rv_world();
   if (!w) return fail(RV_ERR_STATE, "rv_create: out of host memory");
   w->cfg = *cfg; w->device = device; w->n = cfg->n_envs; w->stream = nullptr; w->timed = false;
+  w->d_snaps = nullptr; w->n_snaps_cap = 0;
   HIPCHK(hipMalloc(&w->d_cfg, sizeof(rv_config)));
   HIPCHK(hipMalloc(&w->d_scene, sizeof(rv_scene)));
   HIPCHK(hipMalloc(&w->d_envs, sizeof(DevEnv) * (size_t)w->n));
@@ -490,10 +557,11 @@ int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world*
 
 int rv_destroy(rv_world* w) {
   if (!w) return RV_OK;
-  hipSetDevice(w->device);
-  hipStreamSynchronize(w->stream);
-  hipFree(w->d_cfg); hipFree(w->d_scene); hipFree(w->d_envs); hipFree(w->d_stats); hipFree(w->d_budget);
-  hipEventDestroy(w->ev0); hipEventDestroy(w->ev1);
+  (void)hipSetDevice(w->device);
+  (void)hipStreamSynchronize(w->stream);
+  (void)hipFree(w->d_cfg); (void)hipFree(w->d_scene); (void)hipFree(w->d_envs); (void)hipFree(w->d_stats); (void)hipFree(w->d_budget);
+  if (w->d_snaps) (void)hipFree(w->d_snaps);
+  (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1);
   delete w;
   return RV_OK;
 }
@@ -507,14 +575,39 @@ int rv_step_macro(rv_world* w) { WCHK(w); return launch_env<MODE_MACRO>(w, nullp
 int rv_rollout(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t auto_reset, float* d_rewards, uint8_t* d_dones) {
   WCHK(w);
   if (n_steps <= 0) return fail(RV_ERR_VALUE, "rv_rollout: n_steps must be positive");
-  return launch_env<MODE_ROLLOUT>(w, nullptr, n_steps, 0, 0, 0, 0, 0, first_macro_index, auto_reset, d_rewards, d_dones);
+  RolloutRec rec; memset(&rec, 0, sizeof(rec));
+  rec.rewards = d_rewards; rec.dones = d_dones;
+  return launch_env<MODE_ROLLOUT>(w, nullptr, n_steps, 0, 0, 0, 0, 0, first_macro_index, auto_reset, &rec);
+}
+int rv_rollout_record(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t auto_reset,
+                      float* d_rewards, uint8_t* d_dones, const rv_obs_buffers* step_obs) {
+  WCHK(w);
+  if (n_steps <= 0) return fail(RV_ERR_VALUE, "rv_rollout_record: n_steps must be positive");
+  RolloutRec rec; memset(&rec, 0, sizeof(rec));
+  rec.rewards = d_rewards; rec.dones = d_dones;
+  float* d_pc = nullptr;
+  if (step_obs) {
+    rec.obs = *step_obs; rec.has_obs = 1; d_pc = step_obs->d_point_cloud;
+    rec.obs.d_point_cloud = nullptr;
+  }
+  const size_t rows = (size_t)n_steps * (size_t)w->n;
+  if (d_pc) {
+    if (w->cfg.num_points <= 0 || w->cfg.num_points > RV_PC_MAXPIX) return fail(RV_ERR_VALUE, "rv_rollout_record: num_points outside [1, RV_PC_MAXPIX]");
+    int rc = ensure_snaps(w, rows); if (rc != RV_OK) return rc;
+    rec.snaps = w->d_snaps;
+  }
+  int rc = launch_env<MODE_ROLLOUT>(w, nullptr, n_steps, 0, 0, 0, 0, 0, first_macro_index, auto_reset, &rec);
+  if (rc != RV_OK) return rc;
+  // the segmented point clouds of all n_steps x N observations, rendered together
+  if (d_pc) return launch_point_cloud(w, rows, d_pc);
+  return RV_OK;
 }
 int rv_rollout_async(rv_world* w, int32_t total_env_steps, int32_t first_macro_index, int32_t* d_steps_taken) {
   WCHK(w);
   if (total_env_steps <= 0) return fail(RV_ERR_VALUE, "rv_rollout_async: total_env_steps must be positive");
   hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, w->stream, w->d_budget, (int)total_env_steps);
   HIPCHK(hipGetLastError());
-  return launch_env<MODE_ROLLOUT>(w, nullptr, 0, 0, 0, 0, 0, 0, first_macro_index, 1, nullptr, nullptr, w->d_budget, d_steps_taken);
+  return launch_env<MODE_ROLLOUT>(w, nullptr, 0, 0, 0, 0, 0, 0, first_macro_index, 1, nullptr, w->d_budget, d_steps_taken);
 }
 int rv_step_sub(rv_world* w, int32_t n) {
   WCHK(w);
@@ -589,10 +682,10 @@ int rv_observe(rv_world* w, const rv_obs_buffers* obs) {
   WCHK(w); NEED(obs, "rv_observe");
   SIMPLE_LAUNCH(k_observe, w->d_envs, w->n, *obs, w->d_cfg);
   if (obs->d_point_cloud) {
-    if (w->cfg.num_points <= 0) return fail(RV_ERR_VALUE, "rv_observe: num_points must be positive");
-    size_t total = (size_t)w->n * RV_MAXB * (size_t)w->cfg.num_points;
-    hipLaunchKernelGGL(k_point_cloud, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, w->stream, w->d_envs, w->n, obs->d_point_cloud, w->d_cfg, w->d_scene);
-    HIPCHK(hipGetLastError());
+    if (w->cfg.num_points <= 0 || w->cfg.num_points > RV_PC_MAXPIX) return fail(RV_ERR_VALUE, "rv_observe: num_points outside [1, RV_PC_MAXPIX]");
+    int rc = ensure_snaps(w, (size_t)w->n); if (rc != RV_OK) return rc;
+    SIMPLE_LAUNCH(k_obs_snap, w->d_envs, w->n, w->d_snaps);
+    rc = launch_point_cloud(w, w->n, obs->d_point_cloud); if (rc != RV_OK) return rc;
   }
   return RV_OK;
 }

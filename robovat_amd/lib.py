@@ -30,6 +30,7 @@ SYMBOLS = [
     'rv_compute_ik', 'rv_query_contacts', 'rv_get_manifold_counts', 'rv_observe',
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
+    'rv_rollout_record',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -102,6 +103,7 @@ def load():
     lib.rv_step_sub.argtypes = [vp, i32]
     lib.rv_rollout.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.rv_rollout_async.argtypes = [vp, i32, i32, vp]
+    lib.rv_rollout_record.argtypes = [vp, i32, i32, i32, vp, vp, C.POINTER(abi.rv_obs_buffers)]
     lib.rv_wait_until_stable.argtypes = [vp, f32, f32, i32, i32, i32]
     lib.rv_policy_random.argtypes = [vp, i32, vp]
     lib.rv_policy_heuristic.argtypes = [vp, i32, vp]
@@ -204,6 +206,44 @@ class World(object):
         check(self.lib.rv_rollout(self.h, int(n_steps), int(first_macro_index), int(bool(auto_reset)),
                                   self._ptr(r) if record else None, self._ptr(d) if record else None))
         return r, d
+
+    def _obs_buffers(self, lead, point_cloud, pose_modes):
+        """Zeroed observation tensors with leading shape ``lead`` + the rv_obs_buffers of their pointers."""
+        t = self.torch
+
+        def z(shape, dtype):
+            return t.zeros(tuple(lead) + shape, dtype=dtype, device=self.device)
+        out = {
+            'position': z((abi.RV_MAXB, 3), t.float32), 'body_mask': z((abi.RV_MAXB,), t.float32),
+            'num_episodes': z((), t.int64), 'num_steps': z((), t.int64), 'layout_id': z((), t.int64),
+            'is_safe': z((), t.int64), 'is_effective': z((), t.int64),
+        }
+        b = abi.rv_obs_buffers()
+        b.d_position = out['position'].data_ptr(); b.d_body_mask = out['body_mask'].data_ptr()
+        b.d_num_episodes = out['num_episodes'].data_ptr(); b.d_num_steps = out['num_steps'].data_ptr()
+        b.d_layout_id = out['layout_id'].data_ptr(); b.d_is_safe = out['is_safe'].data_ptr()
+        b.d_is_effective = out['is_effective'].data_ptr()
+        if point_cloud:
+            out['point_cloud'] = z((abi.RV_MAXB, int(self.cfg.num_points), 3), t.float32)
+            b.d_point_cloud = out['point_cloud'].data_ptr()
+        if pose_modes:      # the other PoseObs modalities (pose_obs.py:53-73)
+            out['pose'] = z((abi.RV_MAXB, 6), t.float32)
+            out['pose2d'] = z((abi.RV_MAXB, 3), t.float32)
+            out['yaw_cossin'] = z((abi.RV_MAXB, 2), t.float32)
+            b.d_pose = out['pose'].data_ptr(); b.d_pose2d = out['pose2d'].data_ptr()
+            b.d_yaw_cossin = out['yaw_cossin'].data_ptr()
+        return out, b
+
+    def rollout_record(self, n_steps, first_macro_index=0, auto_reset=True, point_cloud=True, pose_modes=False):
+        """The rollout returning what every env.step() returns: per-step observation rows
+        [n_steps, N, ...], rewards and dones (rv_rollout_record)."""
+        k = int(n_steps)
+        obs, b = self._obs_buffers((k, self.n), point_cloud, pose_modes)
+        r = self.torch.zeros((k, self.n), dtype=self.torch.float32, device=self.device)
+        d = self.torch.ones((k, self.n), dtype=self.torch.uint8, device=self.device)
+        check(self.lib.rv_rollout_record(self.h, k, int(first_macro_index), int(bool(auto_reset)),
+                                         self._ptr(r), self._ptr(d), C.byref(b)))
+        return obs, r, d
 
     def rollout_async(self, total_env_steps, first_macro_index=0):
         """total_env_steps x (RandomPolicy action -> env.step) shared by all envs: every env
@@ -319,30 +359,7 @@ class World(object):
         return self._get('rv_get_manifold_counts', (self.n, abi.RV_NMAN), self.torch.int32)
 
     def observe(self, point_cloud=False, pose_modes=False):
-        t = self.torch
-        out = {
-            'position': self._new((self.n, abi.RV_MAXB, 3), t.float32),
-            'body_mask': self._new((self.n, abi.RV_MAXB), t.float32),
-            'num_episodes': self._new((self.n,), t.int64),
-            'num_steps': self._new((self.n,), t.int64),
-            'layout_id': self._new((self.n,), t.int64),
-            'is_safe': self._new((self.n,), t.int64),
-            'is_effective': self._new((self.n,), t.int64),
-        }
-        b = abi.rv_obs_buffers()
-        b.d_position = out['position'].data_ptr(); b.d_body_mask = out['body_mask'].data_ptr()
-        b.d_num_episodes = out['num_episodes'].data_ptr(); b.d_num_steps = out['num_steps'].data_ptr()
-        b.d_layout_id = out['layout_id'].data_ptr(); b.d_is_safe = out['is_safe'].data_ptr()
-        b.d_is_effective = out['is_effective'].data_ptr()
-        if point_cloud:
-            out['point_cloud'] = self._new((self.n, abi.RV_MAXB, int(self.cfg.num_points), 3), t.float32)
-            b.d_point_cloud = out['point_cloud'].data_ptr()
-        if pose_modes:      # the other PoseObs modalities (pose_obs.py:53-73)
-            out['pose'] = self._new((self.n, abi.RV_MAXB, 6), t.float32)
-            out['pose2d'] = self._new((self.n, abi.RV_MAXB, 3), t.float32)
-            out['yaw_cossin'] = self._new((self.n, abi.RV_MAXB, 2), t.float32)
-            b.d_pose = out['pose'].data_ptr(); b.d_pose2d = out['pose2d'].data_ptr()
-            b.d_yaw_cossin = out['yaw_cossin'].data_ptr()
+        out, b = self._obs_buffers((self.n,), point_cloud, pose_modes)
         check(self.lib.rv_observe(self.h, C.byref(b)))
         return out
 

@@ -58,6 +58,18 @@ def _mass_properties(hulls):
     return vol, com, inertia
 
 
+def hull_planes(verts, tol=1e-6):
+    """Face planes (n, d) with n.x <= d of a convex hull, coplanar triangles merged."""
+    from scipy.spatial import ConvexHull
+    hull = ConvexHull(verts)
+    planes = []
+    for eq in hull.equations:              # n.x + off <= 0 inside
+        n, d = eq[:3], -eq[3]
+        if not any(np.dot(n, q[:3]) > 1.0 - tol and abs(d - q[3]) < tol for q in planes):
+            planes.append(np.array([n[0], n[1], n[2], d]))
+    return np.array(planes)
+
+
 def make_shape(hulls):
     """Build an ``rv_shape`` from a list of [n, 3] vertex arrays."""
     hulls = [np.asarray(h, dtype=np.float64) for h in hulls]
@@ -83,6 +95,12 @@ def make_shape(hulls):
             for k in range(3):
                 shape.verts[h][i][k] = float(v[k])
         radius = max(radius, float(np.linalg.norm(local, axis=1).max()))
+        planes = hull_planes(local)
+        assert len(planes) <= abi.RV_MAXP, len(planes)
+        shape.n_planes[h] = len(planes)
+        for i, pl in enumerate(planes):
+            for k in range(4):
+                shape.planes[h][i][k] = float(pl[k])
     for k in range(3):
         shape.inertia_k[k] = float(evals[k] / vol)
     shape.radius = radius

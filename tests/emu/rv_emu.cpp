@@ -24,8 +24,8 @@ static void run_env(EmuWorld* w, int i, int mode, int n_sub, float lin, float an
   if (mode == 1 && S.e.done) { w->envs[i].substeps_last = 0; w->envs[i].awake_last = 0; w->envs[i].pairs_last = 0; w->envs[i].stepped = 0; return; }
   if (mode != 0) env_enter(S, K);
   if (mode == 0) env_reset(S, K, w->cfg.env_id_offset + i);
-  else if (mode == 1) { S.e.stepped = 0; env_step(S, K); }
-  else if (mode == 4) env_rollout(S, K, w->cfg.env_id_offset + i, n_sub, ca, ms, nullptr, nullptr, i, w->n);
+  else if (mode == 1) { launch_counters_zero(S.e); env_step(S, K); }
+  else if (mode == 4) { RolloutRec rec; memset(&rec, 0, sizeof(rec)); env_rollout(S, K, w->cfg.env_id_offset + i, n_sub, ca, ms, rec, i, w->n); }
   else if (mode == 2) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; sim_steps_call(K, n_sub); }
   else { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; wait_until_stable(S, K, 0u, lin, ang, ca, ms, mx); }
   memcpy(&w->envs[i], &S.e, sizeof(DevEnv));

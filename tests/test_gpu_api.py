@@ -43,9 +43,10 @@ def test_push_env_observation_contract_and_episode_loop():
     assert obs['num_steps'].dtype == np.int64 and obs['body_mask'].shape == (abi.RV_MAXB,)
     assert obs['point_cloud'].shape == (abi.RV_MAXB, cfg.OBS.NUM_POINTS, 3) and obs['point_cloud'].dtype == np.float32
     assert obs['position'].shape == (abi.RV_MAXB, 3)
-    # analytic point cloud: per-body mean sits near the body position, absent bodies are zeros
+    # rendered point cloud: the visible surface of each body lies around its position, absent bodies are zeros
     centre = obs['point_cloud'].mean(axis=1)
-    assert np.abs(centre - obs['position'])[obs['body_mask'] > 0].max() < 0.03
+    assert np.abs(centre - obs['position'])[obs['body_mask'] > 0].max() < 0.08
+    assert (obs['point_cloud'][obs['body_mask'] == 0] == 0).all()
     episode = generate_episode(env, policies.HeuristicPushPolicy(env))
     assert 1 <= len(episode['transitions']) <= 2
     t = episode['transitions'][0]

@@ -262,3 +262,43 @@ def test_motor_targets_grip_and_reset_targets():
     js2 = world.joint_state().cpu().numpy()
     assert np.abs(js2[:, 0, 0] - q[:, 0]).max() < 5e-3
     world.close()
+
+
+@pytest.mark.parametrize('over', [dict(MAX_STEPS=3), dict(TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=3, MIN_MOVABLE_BODIES=2)])
+def test_point_cloud_matches_oracle_bit_for_bit(over):
+    """k_point_cloud (SegmentedPointCloudObs, camera_obs.py:182-238) == orc_point_cloud after
+    reset and after steps; the oracle itself is checked against the reference-shaped
+    render -> deproject -> group pipeline in tests/test_camera_golden.py."""
+    world, ref = _world(48, seed=29, **over), _oracle(48, seed=29, **over)
+    world.reset(); ref.reset()
+    for k in range(3):
+        got = world.observe(point_cloud=True)['point_cloud'].cpu().numpy()
+        want = ref.point_cloud()
+        assert got.shape == want.shape == (48, abi.RV_MAXB, 256, 3)
+        assert np.array_equal(got, want), (k, np.abs(got - want).max())
+        mask = ref.observe()[1]
+        assert (got[mask == 0] == 0).all() and np.abs(got[mask > 0]).sum() > 0
+        a = ref.policy_random(k)
+        world.set_actions(a); ref.set_actions(a); world.step_macro(); ref.step_macro()
+    world.close()
+
+
+def test_rollout_record_returns_every_steps_observation():
+    """rv_rollout_record rows == the observations a lock-step loop of env.step() returns."""
+    over = dict(MAX_STEPS=2)
+    w1, w2 = _world(24, seed=31, **over), _world(24, seed=31, **over)
+    w1.reset(); w2.reset()
+    obs, r, d = w1.rollout_record(3, first_macro_index=0, auto_reset=False, point_cloud=True, pose_modes=True)
+    for k in range(3):
+        w2.set_actions(w2.policy_random(k)); w2.step_macro()
+        stepped = (w2.env_counters()[:, 7] > 0).cpu().numpy()
+        o2 = w2.observe(point_cloud=True, pose_modes=True)
+        r2, d2 = w2.reward()
+        for key in o2:
+            a, b = obs[key][k].cpu().numpy(), o2[key].cpu().numpy()
+            assert np.array_equal(a[stepped], b[stepped]), (k, key)
+            assert (a[~stepped] == 0).all(), (k, key)            # steps not taken are zero rows
+        assert np.array_equal(r[k].cpu().numpy()[stepped], r2.cpu().numpy()[stepped])
+        assert np.array_equal(d[k].cpu().numpy(), d2.cpu().numpy())
+    assert (~stepped).all()                                       # MAX_STEPS=2: nobody takes a third step
+    w1.close(); w2.close()
