@@ -4,13 +4,21 @@
 Workload (BASELINE.json configs[1]): PushEnv, 4 rigid convex movables, 1024
 vectorised envs per GPU, random policy (Philox U(-1,1)^4 keyed by global env
 id and macro-step index), TASK_NAME=None.  One "step" = one batched
-`env.step()`: policy -> rv_set_actions -> rv_step_macro (the whole
-pre/start/motion/post/offstage phase machine plus settle, thousands of 1 ms
-physics substeps per env, on device) -> rv_observe + rv_reward.  Inputs are
-resident in HBM; `value` = env steps per second over all ranks.
+`env.step()`: policy -> the whole pre/start/motion/post/offstage phase machine
+plus settle (thousands of 1 ms physics substeps per env, on device) ->
+observation (position, body mask, attributes, segmented point cloud) + reward +
+done.  Inputs are resident in HBM; `value` = env steps per second over all ranks.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+`value` (mode "rollout", the default) times ONE `rv_rollout_record` launch in which
+every env takes its K steps back to back -- policy on the device, auto-reset, the
+observation / reward / done of EVERY step written to [K][N] buffers and all K*N
+point clouds rendered -- i.e. a single-launch rollout, not a host-driven loop.  The
+host-driven loop (K x (policy -> rv_set_actions -> rv_step_macro -> rv_observe with
+point cloud -> rv_reward), every env waiting for the slowest env of each step) is
+reported beside it as "lockstep_env_step" (or is `value` with --mode lockstep).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -23,47 +31,114 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_SUBSTEP = 3056   # 2*(52*4 + 8*9 + 208*6)
+# 2 * (52 B_dyn + 8 J + 208 M) bytes per env-substep
+ALGO_BYTES = {'config2': 3056, 'config3': 5552}
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_PER_SIMD_CYCLE = 0.5      # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
 
 
-def cpu_baseline(cfg_kwargs, scene, names, seconds_hint=20.0):
-    """Time the CPU oracle (kind 'port': pybullet, the reference's physics, is
-    not importable) on a bounded sample of the same workload."""
-    from robovat_amd import configs
+def cpu_legs(cfg_kwargs, scene, names, quick=False):
+    """Everything that runs the CPU oracle (kind 'port': pybullet, the reference's physics,
+    is not importable here): the same-workload baseline, BASELINE config 1 (1 env,
+    HeuristicPushPolicy, 20 episodes; one thread and one worker per core as
+    tools/parallel_run.py would start them) and the FP32-vs-FP64 pose error."""
+    import numpy as np
+    from robovat_amd import configs, lib
     from oracle import orc
     cores = os.cpu_count() or 1
+    out = {}
+    # (i) same workload as the GPU leg, OpenMP over envs
     n = max(4, 2 * cores)
     cfg = configs.make_rv_config(n_envs=n, shape_names=names, **cfg_kwargs)
     w = orc.OracleWorld(cfg, scene, double=False)
     w.reset()
-    t_all, steps, sub = 0.0, 0, 0
-    k = 0
-    while t_all < seconds_hint / 4 and k < 4:
+    t_all, steps, sub, k = 0.0, 0, 0, 0
+    while t_all < 5.0 and k < 4:
         w.set_actions(w.policy_random(k))
         t0 = time.perf_counter(); w.step_macro(); t_all += time.perf_counter() - t0
         st = w.stats(); steps += st['env_steps']; sub += st['substeps']; k += 1
-    return {
+    out['cpu_baseline'] = {
         'value': steps / t_all, 'unit': 'env_steps/s', 'cores': cores, 'kind': 'port',
         'sim_steps_per_s': sub / t_all,
         'sample': '%d envs x %d macro steps of the same workload, float C oracle, OpenMP over envs '
                   '(pybullet not importable -> reference loop skipped)' % (n, k),
     }
+    # (ii) BASELINE config 1: run_env.py --env PushEnv --policy HeuristicPushPolicy, 20 episodes
+    max_steps, episodes = 5, 20
+
+    def config1(n_workers):
+        env_cfg = configs.push_env_config(MAX_STEPS=max_steps)
+        c1 = configs.make_rv_config(env_cfg=env_cfg, n_envs=n_workers, shape_names=names, seed=0)
+        w1 = orc.OracleWorld(c1, scene, double=False)
+        t0 = time.perf_counter()
+        steps = sub = 0
+        for _ in range(episodes):
+            w1.reset(); sub += w1.stats()['substeps']
+            for _ in range(max_steps):
+                w1.set_actions(w1.policy_heuristic(20000)); w1.step_macro()
+                st = w1.stats(); steps += st['env_steps']; sub += st['substeps']
+        el = time.perf_counter() - t0
+        return {'workers': n_workers, 'episodes_per_worker': episodes, 'env_steps_per_s': steps / el,
+                'sim_steps_per_s': sub / el, 'seconds': el}
+    out['config1_cpu'] = {'workload': 'PushEnv + HeuristicPushPolicy, 1 env per worker, TASK_NAME=None, MAX_STEPS=%d, %d episodes, '
+                                      'float C oracle (pybullet not importable)' % (max_steps, episodes),
+                          'one_thread': config1(1)}
+    if not quick:
+        out['config1_cpu']['one_worker_per_core'] = config1(cores)
+    # (iii) pose error of the HIP path (FP32) against the FP64 oracle from identical states
+    n = 64
+    cfg = configs.make_rv_config(n_envs=n, shape_names=names, seed=9)
+    f32, f64 = orc.OracleWorld(cfg, scene, double=False), orc.OracleWorld(cfg, scene, double=True)
+    world = lib.World(cfg, scene, device=0)
+    f32.reset()
+    state, params, joints = f32.body_state(), f32.body_params(), f32.joint_state()
+    for x in (f64, world):
+        x.set_body_params(params); x.set_joint_state(joints)
+    state[:, :, 7] += 0.2
+    f64.set_body_state(state); world.set_body_state(state)
+    pe, done = {'oracle': 'oracle/rv_oracle.c, -DORC_DOUBLE build (FP64 restatement)',
+                'pybullet_parity': 'unmeasured (module not available)',
+                'scene': '%d envs x 4 bodies settled on the table, every body shoved at 0.2 m/s' % n}, 0
+
+    def err(tag):
+        from robovat_amd.math import rotations
+        got = world.body_state().cpu().numpy().astype(np.float64); want = f64.body_state()
+        perr = np.linalg.norm(got[..., :3] - want[..., :3], axis=-1)
+        ang = rotations.quaternion_angle(got[..., 3:7], want[..., 3:7])
+        pe[tag] = {'max_pos_m': float(perr.max()), 'median_pos_m': float(np.median(perr)),
+                   'max_angle_rad': float(ang.max()), 'median_angle_rad': float(np.median(ang))}
+    for horizon in (1, 10, 100):
+        world.step_sub(horizon - done); f64.step_sub(horizon - done); done = horizon
+        err('substeps_%d' % horizon)
+    # end of a push: one whole env.step() from identical settled states
+    f32.reset()
+    state, params, joints = f32.body_state(), f32.body_params(), f32.joint_state()
+    w2, r2 = lib.World(cfg, scene, device=0), orc.OracleWorld(cfg, scene, double=True)
+    w2.reset(); r2.reset()
+    for x in (w2, r2):
+        x.set_body_params(params); x.set_body_state(state)
+    a = f32.policy_heuristic(2000)
+    w2.set_actions(a); r2.set_actions(a); w2.step_macro(); r2.step_macro()
+    world, f64 = w2, r2
+    err('end_of_push')
+    out['pose_err'] = pe
+    w2.close()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)   # BASELINE configs[1]: 50 macro-steps per env
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--envs-per-gpu', type=int, default=1024)
     ap.add_argument('--seed', type=int, default=1234)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-async', action='store_true',
-                    help='skip the extra (untimed-for-`value`) asynchronous rollout reported under "async_rollout"')
-    ap.add_argument('--mode', choices=['rollout', 'lockstep'], default='rollout',
-                    help="rollout: the K timed env.step()s of every env run in ONE rv_rollout launch "
-                         "(on-device RandomPolicy, auto-reset); lockstep: K x (policy -> rv_step_macro)")
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip every CPU-oracle leg')
+    ap.add_argument('--no-extra-legs', action='store_true',
+                    help='only the headline: skip lockstep_env_step, async_rollout, config3_4096, config5_8192')
+    ap.add_argument('--no-async', action='store_true')
+    ap.add_argument('--quick', action='store_true', help='shorter CPU legs')
+    ap.add_argument('--mode', choices=['rollout', 'lockstep'], default='rollout')
     args = ap.parse_args()
 
     import torch
@@ -86,8 +161,6 @@ def main():
     scene, names = scenes.make_scene()
     n = args.envs_per_gpu
     cfg_kwargs = dict(seed=args.seed)
-    cfg = configs.make_rv_config(n_envs=n, env_id_offset=rank * n, shape_names=names, **cfg_kwargs)
-    world = lib.World(cfg, scene, device=local_rank)
 
     def barrier():
         torch.cuda.synchronize()
@@ -95,135 +168,186 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def make_world(n_envs, **over):
+        env_cfg = configs.push_env_config(**over)
+        c = configs.make_rv_config(env_cfg=env_cfg, n_envs=n_envs, env_id_offset=rank * n_envs, shape_names=names, **cfg_kwargs)
+        return lib.World(c, scene, device=local_rank), c
+
+    def gather_returns(world):
+        """The only collective of the path: RCCL all-gather of episode returns + all-reduce of
+        4 counters (robovat_amd/parallel.py)."""
+        if dist is None:
+            return
+        from robovat_amd import parallel
+        cnt = world.env_counters().to(torch.int64)
+        st = torch.stack([cnt[:, 5].sum(), cnt[:, 6].sum(), cnt[:, 4].sum(), cnt[:, 1].sum()])
+        parallel.gather_returns(world.episode_returns(), st)
+
+    def lockstep_step(world, k):
+        """The literal host-driven env.step() for the whole batch."""
+        world.set_actions(world.policy_random(k))
+        world.step_macro()
+        obs = world.observe(point_cloud=True)
+        r, d = world.reward()
+        gather_returns(world)
+        return obs, r, d
+
+    def all_sum(*vals):
+        t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device='cuda')
+        if dist is not None:
+            dist.all_reduce(t)
+        return [float(x) for x in t]
+
+    def all_max(v):
+        t = torch.tensor([float(v)], dtype=torch.float64, device='cuda')
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def time_rollout(world, k_steps, first):
+        """K env.step() per env in one launch, every step's observation recorded."""
+        barrier()
+        t0 = time.perf_counter()
+        obs, r, d = world.rollout_record(k_steps, first_macro_index=first, auto_reset=True, point_cloud=True)
+        gather_returns(world)
+        st = world.stats()
+        barrier()
+        el = all_max(time.perf_counter() - t0)
+        return el, st, world.last_kernel_ms(), 1
+
+    def time_lockstep(world, k_steps, first):
+        barrier()
+        t0 = time.perf_counter()
+        kern_ms, tot = 0.0, {'substeps': 0, 'env_steps': 0, 'max_substeps': 0, 'awake_substeps': 0}
+        for k in range(k_steps):
+            lockstep_step(world, first + k)
+            st = world.stats()     # synchronises, as a Python env loop that reads rewards does
+            kern_ms += world.last_kernel_ms()
+            for key in ('substeps', 'env_steps', 'awake_substeps'):
+                tot[key] += st[key]
+            tot['max_substeps'] = max(tot['max_substeps'], st['max_substeps'])
+        barrier()
+        el = all_max(time.perf_counter() - t0)
+        return el, tot, kern_ms, k_steps
+
+    def leg_summary(el, st, k_steps, n_envs):
+        es, ss = all_sum(st['env_steps'], st['substeps'])
+        return {'value': es / el, 'unit': 'env_steps/s', 'sim_steps_per_s': ss / el, 'ms_per_step': 1e3 * el / k_steps,
+                'envs_per_gpu': n_envs, 'steps': k_steps}
+
+    world, cfg = make_world(n)
     world.reset()
     reset_stats = world.stats()
-    returns_all = torch.zeros((world_size, n), dtype=torch.float32, device=world.device)
-    counters = torch.zeros(4, dtype=torch.int64, device=world.device)
-
-    def one_step(k):
-        a = world.policy_random(k)
-        world.set_actions(a)
-        world.step_macro()
-        obs = world.observe()
-        r, d = world.reward()
-        if dist is not None:
-            # RCCL gather of episode returns + counters
-            dist.all_gather_into_tensor(returns_all.view(-1), world.episode_returns())
-            st = torch.stack([obs['is_safe'].sum(), obs['is_effective'].sum(), d.sum().to(torch.int64), obs['num_steps'].sum()])
-            dist.all_reduce(st)
-            counters.copy_(st)
-        return r
-
-    def gather_returns():
-        if dist is not None:
-            # the only collective of the path: RCCL all-gather of episode returns
-            # + all-reduce of 4 counters (robovat_amd/parallel.py)
-            from robovat_amd import parallel
-            cnt = world.env_counters().to(torch.int64)
-            st = torch.stack([cnt[:, 5].sum(), cnt[:, 6].sum(), cnt[:, 4].sum(), cnt[:, 1].sum()])
-            allr, allc = parallel.gather_returns(world.episode_returns(), st)
-            returns_all.copy_(allr); counters.copy_(allc)
-
     for k in range(args.warmup):
-        one_step(k)
-    barrier()
-    kern_ms, substeps, env_steps, max_sub, awake, launches = 0.0, 0, 0, 0, 0, 0
-    t0 = time.perf_counter()
-    if args.mode == 'lockstep':
-        for k in range(args.steps):
-            one_step(args.warmup + k)
-            # stats/kernel time are read after the step's kernels are queued; the
-            # copies below synchronise the stream, which a Python env loop does anyway
-            st = world.stats()
-            kern_ms += world.last_kernel_ms(); launches += 1
-            substeps += st['substeps']; env_steps += st['env_steps']; max_sub = max(max_sub, st['max_substeps'])
-            awake += st['awake_substeps']
+        lockstep_step(world, k)
+    timer = time_rollout if args.mode == 'rollout' else time_lockstep
+    elapsed, st, kern_ms, launches = timer(world, args.steps, args.warmup)
+    env_steps_all, substeps_all = all_sum(st['env_steps'], st['substeps'])
+    next_index = args.warmup + args.steps
+
+    extra = {}
+    if not args.no_extra_legs:
+        other = time_lockstep if args.mode == 'rollout' else time_rollout
+        el2, st2, _, _ = other(world, args.steps, next_index); next_index += args.steps
+        name = 'lockstep_env_step' if args.mode == 'rollout' else 'single_launch_rollout'
+        extra[name] = leg_summary(el2, st2, args.steps, n)
+        extra[name]['note'] = ('host loop: K x (policy -> rv_set_actions -> rv_step_macro -> rv_observe incl. point cloud -> rv_reward); '
+                               'every step waits for the slowest env of the batch' if args.mode == 'rollout' else
+                               'one rv_rollout_record launch, observations of every step recorded')
+        if not args.no_async:
+            barrier()
+            ta = time.perf_counter()
+            taken = world.rollout_async(args.steps * n, first_macro_index=next_index)
+            barrier()
+            ea = all_max(time.perf_counter() - ta)
+            extra['async_rollout'] = leg_summary(ea, world.stats(), args.steps, n)
+            extra['async_rollout'].update({
+                'steps_per_env_min_max': [int(taken.min().item()), int(taken.max().item())],
+                'note': 'rv_rollout_async: K*N env.step() calls shared by the N envs of each GPU (work-conserving, no '
+                        'observations recorded); per-env step counts vary'})
+        world.close()
+        # BASELINE configs[2]: 'crossing' layout, V-HACD concave movables, 4096 envs
+        w3, _ = make_world(4096, TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)
+        w3.reset()
+        k3 = min(args.steps, 10)
+        el3, st3, km3, _ = time_rollout(w3, k3, 0)
+        extra['config3_4096'] = leg_summary(el3, st3, k3, 4096)
+        extra['config3_4096'].update({'workload': "PushEnv 'crossing' layout 0, V-HACD concave movables, PushReward, MAX_STEPS=10",
+                                      'roofline_frac_nominal': ALGO_BYTES['config3'] * st3['substeps'] / (1e-3 * km3) / 1e9 / HBM_PEAK_GBS})
+        w3.close()
+        # BASELINE configs[4], per-GPU point: config-2 scene, 8192 envs per GPU
+        w5, _ = make_world(8192)
+        w5.reset()
+        el5, st5, km5, _ = time_rollout(w5, k3, 0)
+        extra['config5_8192'] = leg_summary(el5, st5, k3, 8192)
+        extra['config5_8192'].update({'workload': 'config-2 scene, 8192 envs per GPU',
+                                      'roofline_frac_nominal': ALGO_BYTES['config2'] * st5['substeps'] / (1e-3 * km5) / 1e9 / HBM_PEAK_GBS})
+        ea5 = None
+        if not args.no_async:
+            barrier(); ta = time.perf_counter()
+            w5.rollout_async(k3 * 8192, first_macro_index=k3)
+            barrier(); ea5 = all_max(time.perf_counter() - ta)
+            extra['config5_8192']['async_value'] = all_sum(w5.stats()['env_steps'])[0] / ea5
+        w5.close()
     else:
-        rewards, dones = world.rollout(args.steps, first_macro_index=args.warmup, auto_reset=True, record=True)
-        obs = world.observe()
-        gather_returns()
-        st = world.stats()
-        kern_ms += world.last_kernel_ms(); launches += 1
-        substeps += st['substeps']; env_steps += st['env_steps']; max_sub = st['max_substeps']; awake += st['awake_substeps']
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=world.device)
-    tot = torch.tensor([float(substeps), float(env_steps)], dtype=torch.float64, device=world.device)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot)
-    elapsed = float(t.item())
-    substeps_all, env_steps_all = float(tot[0].item()), float(tot[1].item())
-
-    # extra leg, NOT part of `value`: the same number of env.step() calls (K per env on
-    # average) run asynchronously -- every env steps at its own pace while a shared pool
-    # lasts, as the reference's independent worker processes do (tools/parallel_run.py)
-    async_out = None
-    if args.mode == 'rollout' and not args.no_async:
-        barrier()
-        ta = time.perf_counter()
-        taken = world.rollout_async(args.steps * n, first_macro_index=args.warmup + args.steps)
-        barrier()
-        ea = time.perf_counter() - ta
-        sa = world.stats()
-        tt = torch.tensor([ea], dtype=torch.float64, device=world.device)
-        ts = torch.tensor([float(sa['env_steps']), float(sa['substeps'])], dtype=torch.float64, device=world.device)
-        if dist is not None:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dist.all_reduce(ts)
-        async_out = {'value': float(ts[0].item()) / float(tt.item()), 'unit': 'env_steps/s',
-                     'env_steps': int(ts[0].item()), 'sim_steps_per_s': float(ts[1].item()) / float(tt.item()),
-                     'steps_per_env_min_max': [int(taken.min().item()), int(taken.max().item())],
-                     'note': 'rv_rollout_async: K*N env.step() calls shared by the N envs of each GPU '
-                             '(work-conserving); not the headline because per-env step counts vary'}
+        world.close()
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        # roofline of the dominant kernel (k_env<MACRO>), this rank
-        algo_bytes_per_launch = ALGO_BYTES_PER_ENV_SUBSTEP * (substeps / launches)
+        algo = ALGO_BYTES['config2']
         avg_kernel_s = 1e-3 * kern_ms / launches
-        achieved = algo_bytes_per_launch / avg_kernel_s / 1e9
-        traffic = None
+        per_launch = st['substeps'] / launches
+        achieved = algo * per_launch / avg_kernel_s / 1e9
+        awake_only = algo * (st['awake_substeps'] / launches) / avg_kernel_s / 1e9
+        traffic, issue = None, None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath) and args.mode == 'rollout':
-            # HBM bytes per env-substep measured offline with rocprofv3 PMC passes on this
-            # same command (profiles/r01_i_hbm_traffic.txt), scaled to this launch
+        if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f)['hbm_bytes_per_env_substep'] * (substeps / launches)
+                tj = json.load(f)
+            if args.mode == 'rollout':
+                # measured offline with rocprofv3 PMC passes on this same command, scaled to this launch
+                traffic = tj['hbm_bytes_per_env_substep'] * per_launch
+                issue = tj.get('issue')
         out = {
             'metric': 'env steps/sec (PushEnv, batched)',
             'value': env_steps_all / elapsed,
             'unit': 'env_steps/s',
             'n_gpus': world_size, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step,
+            'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'PushEnv 4 rigid convex bodies, %d vectorised envs/GPU, random policy '
                                    '(BASELINE.json configs[1])' % n,
                        'envs_per_gpu': n, 'bodies': 4, 'dt': 1e-3, 'solver_iters': int(cfg.solver_iters),
-                       'parallelism': 'env-shards x%d' % world_size, 'mode': args.mode},
+                       'parallelism': 'env-shards x%d' % world_size,
+                       'mode': 'single-launch rollout: K env.step() per env in one rv_rollout_record launch, observation (incl. '
+                               '%d-point segmented point cloud per body), reward and done of every step recorded' % int(cfg.num_points)
+                               if args.mode == 'rollout' else 'lock-step host loop of batched env.step()'},
             'sim_steps_per_s': substeps_all / elapsed,
             'substeps_per_env_step': substeps_all / max(env_steps_all, 1.0),
-            'max_substeps_in_launch': max_sub,
-            'awake_substep_fraction': awake / max(substeps, 1),
+            'awake_sim_steps_per_s': st['awake_substeps'] / elapsed,
+            'max_substeps_in_launch': st['max_substeps'],
+            'awake_substep_fraction': st['awake_substeps'] / max(st['substeps'], 1),
             'reset_substeps': reset_stats['substeps'],
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'k_env<MODE_ROLLOUT>' if args.mode == 'rollout' else 'k_env<MODE_MACRO>', 'avg_kernel_ms': 1e3 * avg_kernel_s,
-                         'algorithmic_bytes_per_env_substep': ALGO_BYTES_PER_ENV_SUBSTEP,
-                         'note': 'state is LDS-resident for the whole launch; the kernel is VALU/latency-bound '
-                                 '(see DESIGN.md §5), HBM traffic is ~2*sizeof(DevEnv) per env per launch'},
+                         'kernel': 'k_env<MODE_ROLLOUT>' if args.mode == 'rollout' else 'k_env<MODE_MACRO>',
+                         'avg_kernel_ms': 1e3 * avg_kernel_s,
+                         'algorithmic_bytes_per_env_substep': algo,
+                         'achieved_awake_substeps_only': awake_only,
+                         'issue_side': issue,
+                         'note': 'nominal figure of the contract: algorithmic bytes x ALL env-substeps / kernel time.  The state is '
+                                 'LDS-resident for the whole launch, so the measured HBM traffic (`traffic`) is ~1 % of it, and ~96 % of '
+                                 'the substeps are coasting/quiet ones that touch no body (`achieved_awake_substeps_only` counts the '
+                                 'rest).  The kernel is VALU-issue / dependent-latency bound: see `issue_side` (rocprofv3 SQ counters, '
+                                 'profiles/) and DESIGN.md section 4'},
         }
-        if async_out is not None:
-            out['async_rollout'] = async_out
-        if not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg_kwargs, scene, names)
+        out.update(extra)
+        if not args.no_cpu_baseline and world_size == 1:
+            out.update(cpu_legs(cfg_kwargs, scene, names, quick=args.quick))
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    world.close()
 
 
 if __name__ == '__main__':

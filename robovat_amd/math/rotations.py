@@ -85,3 +85,16 @@ def quaternion_multiply(a, b):
                      aw * by - ax * bz + ay * bw + az * bx,
                      aw * bz + ax * by - ay * bx + az * bw,
                      aw * bw - ax * bx - ay * by - az * bz], dtype=np.float64)
+
+
+def quaternion_angle(a, b):
+    """Geodesic angle (rad) between unit quaternions ``a`` and ``b`` (arrays [..., 4], xyzw),
+    accurate for tiny angles: 2 atan2(|vec(a b*)|, |w(a b*)|)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    ax, ay, az, aw = (a[..., i] for i in range(4))
+    bx, by, bz, bw = (-b[..., 0], -b[..., 1], -b[..., 2], b[..., 3])
+    x = aw * bx + ax * bw + ay * bz - az * by
+    y = aw * by - ax * bz + ay * bw + az * bx
+    z = aw * bz + ax * by - ay * bx + az * bw
+    w = aw * bw - ax * bx - ay * by - az * bz
+    return 2.0 * np.arctan2(np.sqrt(x * x + y * y + z * z), np.abs(w))
