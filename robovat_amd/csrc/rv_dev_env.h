@@ -168,6 +168,11 @@ struct Scratch {
   float fext[RV_NFRAME], fmot[RV_NFRAME];     // per frame: largest collider extent; vertex travel this substep
   int any_on;
   int pairs[4];
+  // narrow-phase work list (per substep): refreshed distances / break flags per cached point,
+  // (body, collider box) proximity flags, the owners that have convex queries to run
+  float rf_dist[RV_NMAN * 4]; int rf_rm[RV_NMAN * 4];
+  int cn[RV_MAXB][RV_NCOL];
+  int ow_run[RV_NMAN + RV_NCOL], olist[RV_NMAN + RV_NCOL], n_olist;
   Rng rng;
 };
 
@@ -509,29 +514,27 @@ RV_DEV void point_world(const Shared& S, const Consts& K, int kind, int a, int b
   else if (kind == 1) *wb = to_world_body(S, b, p.lb);
   else *wb = to_world_frame(S, K.arm->col_frame[p.col], p.lb);
 }
-RV_DEV int manifold_refresh(const Shared& S, const Consts& K, int kind, int a, int b, DevMan& m) {
-  float brk = K.cfg->breaking;
-  const int n0 = m.n;
-  // distances of all cached points first (independent work), removals after
-  float dist[4]; int rm[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    dist[i] = 0.0f; rm[i] = 0;
-    if (i < n0) {
-      ManPoint p;
-      p.la = ld3(m.la[i]); p.lb = ld3(m.lb[i]); p.nrm = ld3(m.nrm[i]); p.col = m.col[i];
-      v3 wa, wb;
-      point_world(S, K, kind, a, b, p, &wa, &wb);
-      float d = dot(sub(wa, wb), p.nrm);
-      dist[i] = d;
-      if (d > brk) rm[i] = 1;
-      else {
-        v3 proj = madd(wa, p.nrm, -d);
-        v3 dr = sub(wb, proj);
-        if (dot(dr, dr) > brk * brk) rm[i] = 1;
-      }
-    }
+// refresh of ONE cached point: its current distance, and whether it broke (too far apart
+// along the normal, or the two anchors drifted apart tangentially)
+RV_DEV void refresh_point(const Shared& S, const Consts& K, int kind, int a, int b, const DevMan& m, int i, float* dist, int* rm) {
+  const float brk = K.cfg->breaking;
+  ManPoint p;
+  p.la = ld3(m.la[i]); p.lb = ld3(m.lb[i]); p.nrm = ld3(m.nrm[i]); p.col = m.col[i];
+  v3 wa, wb;
+  point_world(S, K, kind, a, b, p, &wa, &wb);
+  float d = dot(sub(wa, wb), p.nrm);
+  int r = 0;
+  if (d > brk) r = 1;
+  else {
+    v3 proj = madd(wa, p.nrm, -d);
+    v3 dr = sub(wb, proj);
+    if (dot(dr, dr) > brk * brk) r = 1;
   }
+  *dist = d; *rm = r;
+}
+// store the refreshed distances, drop the broken points (highest slot first); returns how many were lost
+RV_DEV int refresh_apply(DevMan& m, const float* dist, const int* rm) {
+  const int n0 = m.n;
 #pragma unroll
   for (int i = 0; i < 4; ++i) if (i < n0) m.dist[i] = dist[i];
 #pragma unroll
@@ -641,6 +644,67 @@ RV_DEV float sphere_box_dist2(v3 p, v3 c, v3 h) {
   float dy = fabsr(p.y - c.y) - h.y; if (dy > 0.0f) d2 += dy * dy;
   float dz = fabsr(p.z - c.z) - h.z; if (dz > 0.0f) d2 += dz * dz;
   return d2;
+}
+
+// ---- manifold owners of the narrow phase ----
+// ids: T(b) = b (body - table), BB(k) = 4 + k (body - body), A(b) = 10 + b (arm - body),
+// AT(col) = 14 + col (arm collider box - table, detection only: push_env.py:839-855)
+struct OwnerInfo {
+  int role;            // -1 nothing to query, 0 body-table, 1 body-body, 2 arm-body, 3 arm-table detector
+  int kind;            // manifold kind (0 / 1 / 2) for point_world
+  int a, b, mi;        // bodies (b = -1: none), manifold slot
+  int clear, live;     // clear: drop the manifold; live: its cached points are refreshed
+  int n_outer, n_inner;
+  v3 guess0;
+};
+RV_DEV void owner_decode(const Shared& S, const Consts& K, int owner, int arm_on, OwnerInfo& o) {
+  const rv_config* c = K.cfg; const DevEnv& e = S.e;
+  const float brk = c->breaking;
+  v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
+  v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
+  o.role = -1; o.kind = 0; o.a = 0; o.b = -1; o.mi = 0; o.clear = 0; o.live = 0; o.n_outer = 0; o.n_inner = 0;
+  o.guess0 = mk(0.0f, 0.0f, 1.0f);
+  if (owner < RV_MAXB) {
+    const int a = owner; o.a = a; o.mi = RV_TIDX(a); o.kind = 0;
+    if (!body_present(e, a)) o.clear = 1;
+    else if (!e.asleep[a]) {
+      o.live = 1;
+      float r = e.radius[a] + brk;
+      if (!(sphere_box_dist2(ld3(e.body[a]), tc, th) >= r * r)) {
+        o.role = 0; o.n_outer = 1; o.n_inner = S.n_hulls[a];
+        o.guess0 = mk(0.0f, 0.0f, e.body[a][2] - tc.z);
+      }
+    }
+  } else if (owner < RV_MAXB + RV_NBB) {
+    const int k = owner - RV_MAXB, a = bb_a(k), b = bb_b(k);
+    o.a = a; o.b = b; o.mi = RV_BBIDX(k); o.kind = 1;
+    if (!(body_present(e, a) && body_present(e, b))) o.clear = 1;
+    else if (!e.asleep[a] && !e.asleep[b]) {
+      o.live = 1;
+      v3 d = sub(ld3(e.body[a]), ld3(e.body[b]));
+      float r = e.radius[a] + e.radius[b] + brk;
+      if (!(dot(d, d) >= r * r)) { o.role = 1; o.n_outer = S.n_hulls[a]; o.n_inner = S.n_hulls[b]; o.guess0 = d; }
+    }
+  } else if (owner < RV_NMAN) {
+    const int a = owner - RV_MAXB - RV_NBB;
+    o.a = a; o.mi = RV_AIDX(a); o.kind = 2;
+    if (!body_present(e, a)) o.clear = 1;
+    else if (!e.asleep[a]) {
+      if (!arm_on) o.clear = 1;
+      else { o.live = 1; o.role = 2; o.n_outer = RV_NCOL; o.n_inner = S.n_hulls[a]; }
+    }
+  } else if (owner < RV_NMAN + RV_NCOL) {
+    const int col = owner - RV_NMAN;
+    o.a = col;
+    if (arm_on) {
+      float r = S.s.colr[col] + brk;
+      float minz = S.s.colv[col][0][2];
+      for (int k = 1; k < 8; ++k) minz = fminr(minz, S.s.colv[col][k][2]);
+      // exact rejection: the flag needs dist < query_dist and dist >= minz - table_z - margin
+      if (!(minz - e.table_z - c->margin >= c->contact_query_dist) &&
+          sphere_box_dist2(ld3(S.s.colc[col]), tc, th) < r * r) { o.role = 3; o.n_outer = 1; o.n_inner = 1; }
+    }
+  }
 }
 
 // ------------------------------------------------------------------ PGS --
@@ -1329,13 +1393,75 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   RV_LANES_END
   RV_STOP(2)
   RV_PROF(2)
-  // manifold refresh + narrow phase.  The wave is split into four 16-lane
-  // groups; a group works on one manifold owner at a time (body-table,
-  // body-body, arm-body, arm-table detection: 24 owners, six rounds) and all
-  // of its lanes execute the same scalar program redundantly -- except inside
-  // support_v(), where each lane holds one hull vertex and a DPP all-reduce
-  // picks the extreme one.  Every convex pair of every owner goes through ONE
-  // collide_pair call site.
+  // manifold refresh + narrow phase.  24 manifold owners (4 body-table, 6 body-body, 4
+  // arm-body, 10 arm-table detectors) write disjoint manifolds, so the schedule is free:
+  //  (0) one lane per cached point: refreshed distance / break test;
+  //      one lane per (body, collider box): bounding-sphere / box proximity;
+  //  (1) one lane per owner: drop broken points, motion gate -> does the owner run convex
+  //      queries in this substep?
+  //  (2) lane 0: the compact list of owners that do;
+  //  (3) the wave splits into four 16-lane groups that take owners off the list.  All lanes
+  //      of a group execute the same scalar program redundantly -- except inside support_v(),
+  //      where each lane holds one hull vertex and a DPP all-reduce picks the extreme one.
+  //      Every convex pair of every owner goes through ONE collide_pair call site.
+  RV_LANES_BEGIN
+    const DevEnv& e = S.e;
+    if (lane < RV_NMAN * 4) {
+      const int mi = lane >> 2, i = lane & 3;
+      OwnerInfo o;
+      owner_decode(S, K, mi, arm_on, o);
+      float d = 0.0f; int rm = 0;
+      if (o.live && i < e.man[mi].n) refresh_point(S, K, o.kind, o.a, o.b, e.man[mi], i, &d, &rm);
+      S.s.rf_dist[lane] = d; S.s.rf_rm[lane] = rm;
+    }
+  RV_LANES_END
+  RV_LANES_BEGIN
+    DevEnv& e = S.e;
+    if (lane < RV_NMAN + RV_NCOL) {
+      const int owner = lane;
+      OwnerInfo o;
+      owner_decode(S, K, owner, arm_on, o);
+      if (o.clear) e.man[o.mi].n = 0;
+      int n_pairs = o.n_outer * o.n_inner;
+      if (o.live) {
+        DevMan& m = e.man[o.mi];
+        const int lost = refresh_apply(m, &S.s.rf_dist[o.mi * 4], &S.s.rf_rm[o.mi * 4]);
+        // narrow-phase gating on the travel of the two shapes since the last full pass
+        float mo = S.s.mot[o.a];
+        if (owner >= RV_MAXB + RV_NBB) {
+          float am = 0.0f;
+#pragma unroll
+          for (int f = 0; f < RV_NFRAME; ++f) am = fmaxr(am, S.s.fmot[f]);
+          mo = mo + am;
+        }
+        if (o.b >= 0) mo = mo + S.s.mot[o.b];
+        float acc = m.acc + mo;
+        const int run = (c->np_max_age <= 0) || m.n == 0 || lost > 0 || acc > c->np_gate || (e.sim_steps % c->np_max_age) == 0;
+        if (run) acc = 0.0f; else n_pairs = 0;
+        m.acc = acc;
+      }
+      S.s.ow_run[owner] = n_pairs > 0;
+    }
+    if (lane >= RV_NMAN + RV_NCOL && lane < RV_NMAN + RV_NCOL + RV_MAXB * RV_NCOL / 2) {
+      // (body, box) proximity for the arm-body owners, two pairs per lane
+      for (int t = (lane - RV_NMAN - RV_NCOL) * 2; t < (lane - RV_NMAN - RV_NCOL) * 2 + 2; ++t) {
+        const int b = t / RV_NCOL, col = t - b * RV_NCOL;
+        int near = 0;
+        if (arm_on && body_on(e, b)) {
+          const float r = e.radius[b] + c->breaking;
+          near = !(sphere_aabb_dist2(ld3(e.body[b]), S.s.colmin[col], S.s.colmax[col]) >= r * r);
+        }
+        S.s.cn[b][col] = near;
+      }
+    }
+  RV_LANES_END
+  RV_LANES_BEGIN
+    if (lane == 0) {
+      int n = 0;
+      for (int o = 0; o < RV_NMAN + RV_NCOL; ++o) if (S.s.ow_run[o]) S.s.olist[n++] = o;
+      S.s.n_olist = n;
+    }
+  RV_LANES_END
   RV_LANES_BEGIN
     DevEnv& e = S.e;
     const int slot = lane >> 4;
@@ -1343,99 +1469,25 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     if ((lane & 15) != 0) continue;   // host emulation: one lane per group does the work
 #endif
     RV_PROFG(5)   // (profiling build) time outside the narrow phase goes to a dump slot
-    float brk = c->breaking;
-    v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
-    v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
     int my_pairs = 0;
-    for (int round = 0; round < (RV_NMAN + RV_NCOL + 3) / 4; ++round) {
-      // schedule: a body's table pair and its arm pairs share a round (they are the
-      // two owners that are busy while the body is pushed), so the wave runs both
-      // convex queries in lockstep.  Owners write disjoint manifolds: any order gives
-      // the same result.  ids: T(b) = b, BB(k) = 4 + k, A(b) = 10 + b, AT(col) = 14 + col
-      int owner;
-      if (round < 2) owner = ((slot & 1) ? RV_MAXB + RV_NBB : 0) + 2 * round + (slot >> 1);
-      else if (round == 2) owner = RV_MAXB + slot;
-      else if (round == 3) owner = slot < 2 ? RV_MAXB + 4 + slot : RV_NMAN + (slot - 2);
-      else owner = RV_NMAN + 2 + (round - 4) * 4 + slot;
-      int role = -1, a = 0, b = -1, mi = 0, n_outer = 0, n_inner = 0;
-      int clear = 0, live = 0;     // live: manifold is refreshed (and may get new points)
-      v3 guess0 = mk(0.0f, 0.0f, 1.0f);
-      if (owner < RV_MAXB) {
-        a = owner; mi = RV_TIDX(a);
-        if (!body_present(e, a)) clear = 1;
-        else if (!e.asleep[a]) {
-          live = 1;
-          float r = e.radius[a] + brk;
-          if (!(sphere_box_dist2(ld3(e.body[a]), tc, th) >= r * r)) {
-            role = 0; n_outer = 1; n_inner = S.n_hulls[a];
-            guess0 = mk(0.0f, 0.0f, e.body[a][2] - tc.z);
-          }
-        }
-      } else if (owner < RV_MAXB + RV_NBB) {
-        int k = owner - RV_MAXB; a = bb_a(k); b = bb_b(k); mi = RV_BBIDX(k);
-        if (!(body_present(e, a) && body_present(e, b))) clear = 1;
-        else if (!e.asleep[a] && !e.asleep[b]) {
-          live = 1;
-          v3 d = sub(ld3(e.body[a]), ld3(e.body[b]));
-          float r = e.radius[a] + e.radius[b] + brk;
-          if (!(dot(d, d) >= r * r)) {
-            role = 1; n_outer = S.n_hulls[a]; n_inner = S.n_hulls[b]; guess0 = d;
-          }
-        }
-      } else if (owner < RV_NMAN) {
-        a = owner - RV_MAXB - RV_NBB; mi = RV_AIDX(a);
-        if (!body_present(e, a)) clear = 1;
-        else if (!e.asleep[a]) {
-          if (!arm_on) clear = 1;
-          else { live = 1; role = 2; n_outer = RV_NCOL; n_inner = S.n_hulls[a]; }
-        }
-      } else if (owner < RV_NMAN + RV_NCOL) {
-        // arm - table: detection only (push_env.py:839-855)
-        int col = owner - RV_NMAN;
-        if (arm_on) {
-          float r = S.s.colr[col] + brk;
-          float minz = S.s.colv[col][0][2];
-          for (int k = 1; k < 8; ++k) minz = fminr(minz, S.s.colv[col][k][2]);
-          // exact rejection: the flag needs dist < query_dist and dist >= minz - table_z - margin
-          if (!(minz - e.table_z - c->margin >= c->contact_query_dist) &&
-              sphere_box_dist2(ld3(S.s.colc[col]), tc, th) < r * r) { role = 3; a = col; n_outer = 1; n_inner = 1; }
-        }
-      }
-      if (clear) e.man[mi].n = 0;
-      if (live) {
-        DevMan& m = e.man[mi];
-        RV_PROFG(0)
-        int lost = manifold_refresh(S, K, owner < RV_MAXB ? 0 : (owner < RV_MAXB + RV_NBB ? 1 : 2), a, b, m);
-        RV_PROFG(4)
-        {
-          // narrow-phase gating on the travel of the two shapes since the last full pass
-          float mo = S.s.mot[a];
-          if (owner >= RV_MAXB + RV_NBB) {
-            float am = 0.0f;
-#pragma unroll
-            for (int f = 0; f < RV_NFRAME; ++f) am = fmaxr(am, S.s.fmot[f]);
-            mo = mo + am;
-          }
-          if (b >= 0) mo = mo + S.s.mot[b];
-          float acc = m.acc + mo;
-          int run = (c->np_max_age <= 0) || m.n == 0 || lost > 0 || acc > c->np_gate || (e.sim_steps % c->np_max_age) == 0;
-          if (run) acc = 0.0f; else { n_outer = 0; n_inner = 0; }
-          m.acc = acc;
-        }
-      }
-      const int n_pairs = n_outer * n_inner;
+    const int n_list = S.s.n_olist;
+    for (int idx = slot; idx < n_list; idx += 4) {
+      const int owner = S.s.olist[idx];
+      OwnerInfo o;
+      owner_decode(S, K, owner, arm_on, o);
+      const int role = o.role, a = o.a, b = o.b, mi = o.mi, n_inner = o.n_inner;
+      const int n_pairs = o.n_outer * o.n_inner;
       for (int t = 0; t < n_pairs; ++t) {
         int io = t / n_inner, ii = t - io * n_inner;
         const float* A; const float* B; int nA, nB, ckind, col = -1;
-        v3 guess = guess0;
+        v3 guess = o.guess0;
         if (role == 0) { A = &S.s.wv[a][ii][0][0]; nA = S.n_verts[a][ii]; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
         else if (role == 1) { A = &S.s.wv[a][io][0][0]; nA = S.n_verts[a][io]; B = &S.s.wv[b][ii][0][0]; nB = S.n_verts[b][ii]; ckind = 1; }
         else if (role == 2) {
           col = io;
-          v3 d = sub(ld3(e.body[a]), ld3(S.s.colc[col]));
-          float r = e.radius[a] + brk;
-          if (sphere_aabb_dist2(ld3(e.body[a]), S.s.colmin[col], S.s.colmax[col]) >= r * r) continue;
-          A = &S.s.wv[a][ii][0][0]; nA = S.n_verts[a][ii]; B = &S.s.colv[col][0][0]; nB = 8; ckind = 2; guess = d;
+          if (!S.s.cn[a][col]) continue;
+          A = &S.s.wv[a][ii][0][0]; nA = S.n_verts[a][ii]; B = &S.s.colv[col][0][0]; nB = 8; ckind = 2;
+          guess = sub(ld3(e.body[a]), ld3(S.s.colc[col]));
         } else { col = a; A = &S.s.colv[col][0][0]; nA = 8; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
         float dd;
         my_pairs++;
