@@ -870,6 +870,93 @@ static real point_solve(orc_env* e, int kind, int a, int b, orc_manifold* m, int
   return res;
 }
 
+/* PGS in impulse space.  The rows of ALL islands of the env in the order the sequential
+ * Gauss-Seidel visits them: body by body (ascending) the points of its table manifold, then of
+ * its arm manifold; then the body-body manifolds in colour-round order; per point the normal
+ * row, then the two friction rows.  Row r acts on body a_r with J = (+dir, +rxa) and, for a
+ * body-body row, on b_r with (-dir, -rxb); an impulse dl on row s changes the velocity of a_s
+ * by P0_s dl = (dir_s / m_a, aa_s) dl and of b_s by P1_s dl = -(dir_s / m_b, ab_s) dl.  Row
+ * velocities g_r = J_r u - vbc_r evolve as g += A[:, s] dl, A_rs = J_r[a_s].P0_s + J_r[b_s].P1_s.
+ * Same order, clamps and per-island residual test as the velocity-space solver below (which
+ * remains the fallback for more than SOLVE_ROWS rows); velocities are rebuilt at the end. */
+#define SOLVE_ROWS 120
+typedef struct { int mi, i, k, a, b, isl; } orc_rowid;
+typedef struct { real l[3], a[3]; } orc_j6;
+static real dotj(const orc_j6* j, const real* pl, const real* pa) { return v3dot(j->l, pl) + v3dot(j->a, pa); }
+static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const orc_rowid* id, int n_rows, const int* use, const int* big, const int* label) {
+  const rv_config* c = &w->cfg;
+  static __thread real A[SOLVE_ROWS][SOLVE_ROWS];
+  real g[SOLVE_ROWS], lam[SOLVE_ROWS], invk[SOLVE_ROWS], bias[SOLVE_ROWS], mu[SOLVE_ROWS];
+  orc_j6 jx[SOLVE_ROWS][RV_MAXB];
+  for (int r = 0; r < n_rows; ++r) {
+    const orc_row* rw = &rows[id[r].mi][id[r].i]; const orc_manifold* mm = &e->man[id[r].mi];
+    const int k = id[r].k, ra = id[r].a, rb = id[r].b, pi = id[r].i;
+    memset(jx[r], 0, sizeof(jx[r]));
+    invk[r] = rw->invk[k]; mu[r] = rw->mu; bias[r] = k == 0 ? rw->target : R(0.0);
+    lam[r] = k == 0 ? mm->ln[pi] : (k == 1 ? mm->lt1[pi] : mm->lt2[pi]);
+    real gg = v3dot(rw->dir[k], e->body[ra].v) + v3dot(rw->rxa[k], e->body[ra].w);
+    v3cpy(jx[r][ra].l, rw->dir[k]); v3cpy(jx[r][ra].a, rw->rxa[k]);
+    if (rb >= 0) {
+      gg -= v3dot(rw->dir[k], e->body[rb].v) + v3dot(rw->rxb[k], e->body[rb].w);
+      for (int x = 0; x < 3; ++x) { jx[r][rb].l[x] = -rw->dir[k][x]; jx[r][rb].a[x] = -rw->rxb[k][x]; }
+    } else gg -= rw->vbc[k];
+    g[r] = gg;
+  }
+  for (int r = 0; r < n_rows; ++r)
+    for (int s2 = 0; s2 < n_rows; ++s2) {
+      const orc_row* q = &rows[id[s2].mi][id[s2].i];
+      const int ks = id[s2].k, as = id[s2].a, bs = id[s2].b;
+      real pl[3] = {q->dir[ks][0] * e->bp[as].inv_mass, q->dir[ks][1] * e->bp[as].inv_mass, q->dir[ks][2] * e->bp[as].inv_mass};
+      real a_ = dotj(&jx[r][as], pl, q->aa[ks]);
+      if (bs >= 0) {
+        real t[3] = {q->dir[ks][0] * e->bp[bs].inv_mass, q->dir[ks][1] * e->bp[bs].inv_mass, q->dir[ks][2] * e->bp[bs].inv_mass};
+        real nl_[3] = {-t[0], -t[1], -t[2]}, na_[3] = {-q->ab[ks][0], -q->ab[ks][1], -q->ab[ks][2]};
+        a_ = a_ + dotj(&jx[r][bs], nl_, na_);
+      }
+      A[r][s2] = a_;
+    }
+  for (int s2 = 0; s2 < n_rows; ++s2) for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s2] * lam[s2];
+  int isl_rows = 0, done = 0;
+  for (int s2 = 0; s2 < n_rows; ++s2) isl_rows |= 1 << id[s2].isl;
+  for (int it = 0; it < c->solver_iters; ++it) {
+    real res[RV_MAXB] = {R(0.0), R(0.0), R(0.0), R(0.0)}, lim = R(0.0);
+    for (int s2 = 0; s2 < n_rows; ++s2) {
+      const int isl = id[s2].isl;
+      if ((done >> isl) & 1) continue;
+      real nl;
+      if (id[s2].k == 0) nl = rmax(lam[s2] + (bias[s2] - g[s2]) * invk[s2], R(0.0));
+      else nl = rclamp(lam[s2] + (-g[s2] * invk[s2]), -lim, lim);
+      const real d = nl - lam[s2];
+      lam[s2] = nl;
+      if (id[s2].k == 0) lim = mu[s2] * nl;
+      res[isl] = rmax(res[isl], rabs(d));
+      for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s2] * d;
+    }
+    for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < (real)c->solver_tol) done |= 1 << x;
+    if ((done & isl_rows) == isl_rows) break;
+  }
+  for (int s2 = 0; s2 < n_rows; ++s2) {
+    orc_manifold* mm = &e->man[id[s2].mi];
+    if (id[s2].k == 0) mm->ln[id[s2].i] = lam[s2]; else if (id[s2].k == 1) mm->lt1[id[s2].i] = lam[s2]; else mm->lt2[id[s2].i] = lam[s2];
+  }
+  for (int X = 0; X < RV_MAXB; ++X) {
+    if (!use[TIDX(X)] || big[label[X]]) continue;
+    for (int cc = 0; cc < 6; ++cc) {
+      real acc = cc < 3 ? e->body[X].v[cc] : e->body[X].w[cc - 3];
+      for (int s2 = 0; s2 < n_rows; ++s2) {
+        const int as = id[s2].a, bs = id[s2].b, ks = id[s2].k;
+        if (as != X && bs != X) continue;
+        const orc_row* q = &rows[id[s2].mi][id[s2].i];
+        real coef;
+        if (as == X) coef = cc < 3 ? q->dir[ks][cc] * e->bp[X].inv_mass : q->aa[ks][cc - 3];
+        else coef = cc < 3 ? -(q->dir[ks][cc] * e->bp[X].inv_mass) : -q->ab[ks][cc - 3];
+        acc = acc + coef * lam[s2];
+      }
+      if (cc < 3) e->body[X].v[cc] = acc; else e->body[X].w[cc - 3] = acc;
+    }
+  }
+}
+
 static void solve_contacts(const orc_world* w, orc_env* e) {
   const rv_config* c = &w->cfg;
   orc_row rows[RV_NMAN][4];
@@ -877,46 +964,8 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
   int use[RV_NMAN];
   for (int b = 0; b < RV_MAXB; ++b) { use[TIDX(b)] = body_on(e, b); use[AIDX(b)] = body_on(e, b); }
   for (int k = 0; k < RV_NBB; ++k) use[BBIDX(k)] = body_on(e, BB_A[k]) && body_on(e, BB_B[k]);
-  /* setup + warm start, in the order the iterations visit the points */
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int b = 0; b < RV_MAXB; ++b) {
-      for (int kind = 0; kind <= 2; kind += 2) {
-        int mi = kind == 0 ? TIDX(b) : AIDX(b);
-        orc_manifold* m = &e->man[mi];
-        if (!use[mi]) continue;
-        for (int i = 0; i < m->n; ++i) {
-          if (pass == 0) {
-            row_setup(w, e, kind, b, -1, m, i, &rows[mi][i]);
-            m->ln[i] *= (real)c->warmstart; m->lt1[i] *= (real)c->warmstart; m->lt2[i] *= (real)c->warmstart;
-          } else {
-            row_apply(e, kind, b, -1, &rows[mi][i], 0, m->ln[i]);
-            row_apply(e, kind, b, -1, &rows[mi][i], 1, m->lt1[i]);
-            row_apply(e, kind, b, -1, &rows[mi][i], 2, m->lt2[i]);
-          }
-        }
-      }
-    }
-    for (int rd = 0; rd < 3; ++rd)
-      for (int x = 0; x < 2; ++x) {
-        int k = BB_ROUND[rd][x]; int mi = BBIDX(k);
-        orc_manifold* m = &e->man[mi];
-        if (!use[mi]) continue;
-        for (int i = 0; i < m->n; ++i) {
-          if (pass == 0) {
-            row_setup(w, e, 1, BB_A[k], BB_B[k], m, i, &rows[mi][i]);
-            m->ln[i] *= (real)c->warmstart; m->lt1[i] *= (real)c->warmstart; m->lt2[i] *= (real)c->warmstart;
-          } else {
-            row_apply(e, 1, BB_A[k], BB_B[k], &rows[mi][i], 0, m->ln[i]);
-            row_apply(e, 1, BB_A[k], BB_B[k], &rows[mi][i], 1, m->lt1[i]);
-            row_apply(e, 1, BB_A[k], BB_B[k], &rows[mi][i], 2, m->lt2[i]);
-          }
-        }
-      }
-  }
   /* islands: awake bodies coupled (transitively) by body-body manifolds that hold
-   * points.  An island is an independent problem: its rows are visited body by body
-   * (table rows, arm rows), then pair by pair in colour-round order, and it stops on
-   * its own residual. */
+   * points.  An island is an independent problem and stops on its own residual. */
   int label[RV_MAXB];
   for (int b = 0; b < RV_MAXB; ++b) label[b] = b;
   for (int pass = 0; pass < RV_MAXB; ++pass)
@@ -926,8 +975,64 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
       int lo = la < lb ? la : lb;
       label[BB_A[k]] = lo; label[BB_B[k]] = lo;
     }
+  /* islands of one or two bodies are solved in impulse space (solve_rows); bigger ones by the
+   * velocity-space Gauss-Seidel below */
+  int big[RV_MAXB];
+  for (int b = 0; b < RV_MAXB; ++b) {
+    int members = 0;
+    for (int x = 0; x < RV_MAXB; ++x) members += (use[TIDX(x)] && label[x] == b);
+    big[b] = use[TIDX(b)] && label[b] == b && members > 2;
+  }
+  /* row setup (+ warm-start scaling of the kept impulses) and the row list in visiting order */
+  orc_rowid id[SOLVE_ROWS]; int n_rows = 0;
+  for (int b = 0; b < RV_MAXB; ++b)
+    for (int kind = 0; kind <= 2; kind += 2) {
+      int mi = kind == 0 ? TIDX(b) : AIDX(b);
+      orc_manifold* m = &e->man[mi];
+      if (!use[mi]) continue;
+      for (int i = 0; i < m->n; ++i) {
+        row_setup(w, e, kind, b, -1, m, i, &rows[mi][i]);
+        m->ln[i] *= (real)c->warmstart; m->lt1[i] *= (real)c->warmstart; m->lt2[i] *= (real)c->warmstart;
+        if (!big[label[b]]) for (int k3 = 0; k3 < 3; ++k3) { orc_rowid x = {mi, i, k3, b, -1, label[b]}; id[n_rows++] = x; }
+      }
+    }
+  for (int rd = 0; rd < 3; ++rd)
+    for (int x = 0; x < 2; ++x) {
+      int k = BB_ROUND[rd][x]; int mi = BBIDX(k);
+      orc_manifold* m = &e->man[mi];
+      if (!use[mi]) continue;
+      for (int i = 0; i < m->n; ++i) {
+        row_setup(w, e, 1, BB_A[k], BB_B[k], m, i, &rows[mi][i]);
+        m->ln[i] *= (real)c->warmstart; m->lt1[i] *= (real)c->warmstart; m->lt2[i] *= (real)c->warmstart;
+        if (!big[label[BB_A[k]]]) for (int k3 = 0; k3 < 3; ++k3) { orc_rowid y = {mi, i, k3, BB_A[k], BB_B[k], label[BB_A[k]]}; id[n_rows++] = y; }
+      }
+    }
+  if (n_rows > 0) solve_rows(w, e, rows, id, n_rows, use, big, label);
+  /* big islands: warm start first */
+  for (int b = 0; b < RV_MAXB; ++b)
+    for (int kind = 0; kind <= 2; kind += 2) {
+      int mi = kind == 0 ? TIDX(b) : AIDX(b);
+      orc_manifold* m = &e->man[mi];
+      if (!use[mi] || !big[label[b]]) continue;
+      for (int i = 0; i < m->n; ++i) {
+        row_apply(e, kind, b, -1, &rows[mi][i], 0, m->ln[i]);
+        row_apply(e, kind, b, -1, &rows[mi][i], 1, m->lt1[i]);
+        row_apply(e, kind, b, -1, &rows[mi][i], 2, m->lt2[i]);
+      }
+    }
+  for (int rd = 0; rd < 3; ++rd)
+    for (int x = 0; x < 2; ++x) {
+      int k = BB_ROUND[rd][x]; int mi = BBIDX(k);
+      orc_manifold* m = &e->man[mi];
+      if (!use[mi] || !big[label[BB_A[k]]]) continue;
+      for (int i = 0; i < m->n; ++i) {
+        row_apply(e, 1, BB_A[k], BB_B[k], &rows[mi][i], 0, m->ln[i]);
+        row_apply(e, 1, BB_A[k], BB_B[k], &rows[mi][i], 1, m->lt1[i]);
+        row_apply(e, 1, BB_A[k], BB_B[k], &rows[mi][i], 2, m->lt2[i]);
+      }
+    }
   for (int root = 0; root < RV_MAXB; ++root) {
-    if (!use[TIDX(root)] || label[root] != root) continue;
+    if (!big[root]) continue;
     for (int it = 0; it < c->solver_iters; ++it) {
       real res = R(0.0);
       int rows_seen = 0;

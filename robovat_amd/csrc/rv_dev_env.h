@@ -52,7 +52,7 @@ __device__ __forceinline__ void g_shared_profg(int g, int i, unsigned long long 
 #define RV_PROF(i) { if (threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_shared_prof(i, t_); } }
 // per-group marks inside the narrow phase: the first lane of 16-lane group g adds the time
 // since ITS last mark to slot 12 + i (g = 0: table owners of bodies 0/2, g = 1: their arm owners)
-#define RV_PROFG(i) { if (((int)threadIdx.x & 15) == 0 && (int)threadIdx.x < 32) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_shared_profg(((int)threadIdx.x >> 4), (i), t_); } }
+#define RV_PROFG(i) { if ((int)threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_shared_profg(0, (i), t_); } }
 #else
 #define RV_PROF(i)
 #define RV_PROFG(i)
@@ -136,10 +136,14 @@ struct Scratch {
   int arm_moving;
   int colflag[RV_NCOL];
   float rot[RV_MAXB][9], iinv[RV_MAXB][9];
-  float wv[RV_MAXB][RV_MAXH][RV_MAXV][3];
   float tablev[8][3];
+  // solver rows + world hull vertices (rebuilt before every use: the solver borrows them as
+  // scratch for the velocity update)
   struct {
-    Row rows[RV_NMAN][4];
+    struct {
+      Row rows[RV_NMAN][4];
+      float wv[RV_MAXB][RV_MAXH][RV_MAXV][3];
+    } r;
   } u;
   // macro-step locals that must survive across phases
   float wp[RV_MAXG][2][7];
@@ -173,6 +177,9 @@ struct Scratch {
   float rf_dist[RV_NMAN * 4]; int rf_rm[RV_NMAN * 4];
   int cn[RV_MAXB][RV_NCOL];
   int ow_run[RV_NMAN + RV_NCOL], olist[RV_NMAN + RV_NCOL], n_olist;
+#if !defined(__HIPCC__) || defined(RV_EMULATE)
+  int rowmap[120], n_rows;   // host emulation of the impulse-space solver: rows in visiting order
+#endif
   Rng rng;
 };
 
@@ -796,6 +803,257 @@ RV_DEV void warm_apply(BV& A, BV* B, float ima, float imb, const Lam& l, const R
   row_apply(A, B, ima, imb, r, 0, l.n); row_apply(A, B, ima, imb, r, 1, l.t1); row_apply(A, B, ima, imb, r, 2, l.t2);
 }
 
+// ---- PGS in impulse space, one lane per solver row -------------------------------------
+// The rows of ALL islands of the env, in the order the sequential Gauss-Seidel visits them:
+// body by body (ascending) the points of its table manifold, then of its arm manifold; then
+// the body-body manifolds in colour-round order; per point the normal row, then the two
+// friction rows.  Row r has J_r on body a_r (+dir, +rxa) and, for a body-body row, on b_r
+// (-dir, -rxb); an impulse dl on row s changes the velocity of a_s by P0_s dl = (dir_s / m_a,
+// aa_s) dl and of b_s by P1_s dl = -(dir_s / m_b, ab_s) dl.  So the row velocities
+// g_r = J_r u - vbc_r evolve as g += A[:, s] dl with the Delassus matrix A_rs = J_r[a_s].P0_s +
+// J_r[b_s].P1_s (zero when rows r and s share no body: islands stay independent by themselves).
+// The iterates are those of the velocity-space solver (same order, clamps, per-island residual
+// test); what changes is the cost of a row step: lane r keeps g_r, lambda_r and its row of A in
+// registers, so a step is a handful of VALU instructions and one v_readlane broadcast instead
+// of ~40 dependent instructions and a 56-word LDS row fetch.  The body velocities are rebuilt
+// once at the end, u = u0 + sum_s P_s lambda_s.  More than RV_SOLVE_ROWS rows (three or four
+// bodies in mutual contact): the env falls back to the velocity-space solver.
+// Host emulation / oracle: the same arithmetic on arrays.
+#define RV_SOLVE_ROWS 120
+#define RV_ROW_PACK(mi, i, k, a, b, isl) ((mi) | ((i) << 8) | ((k) << 12) | ((a) << 16) | (((b) + 1) << 20) | ((isl) << 24))
+#define RV_ROW_MI(x)  ((x) & 255)
+#define RV_ROW_I(x)   (((x) >> 8) & 15)
+#define RV_ROW_K(x)   (((x) >> 12) & 15)
+#define RV_ROW_A(x)   (((x) >> 16) & 15)
+#define RV_ROW_B(x)   ((((x) >> 20) & 15) - 1)
+#define RV_ROW_ISL(x) (((x) >> 24) & 15)
+#if !defined(__HIPCC__) || defined(RV_EMULATE)
+// the row list of the islands of one or two bodies (host emulation)
+RV_DEV int solver_row_list(Shared& S, const int* label, const int* on_, const int* act_, const int* big_) {
+  DevEnv& e = S.e;
+  int n = 0;
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (!on_[b] || big_[label[b]]) continue;
+    for (int kind = 0; kind < 2; ++kind) {
+      const int mi = kind == 0 ? RV_TIDX(b) : RV_AIDX(b);
+      const int np_ = e.man[mi].n;
+      if (n + 3 * np_ > RV_SOLVE_ROWS) return -1;
+      for (int i = 0; i < np_; ++i) for (int k = 0; k < 3; ++k) S.s.rowmap[n++] = RV_ROW_PACK(mi, i, k, b, -1, label[b]);
+    }
+  }
+  for (int rd = 0; rd < 3; ++rd)
+    for (int x = 0; x < 2; ++x) {
+      const int kp = bb_round_pair(rd, x);
+      if (!act_[kp] || big_[label[bb_a(kp)]]) continue;
+      const int np_ = e.man[RV_BBIDX(kp)].n;
+      if (n + 3 * np_ > RV_SOLVE_ROWS) return -1;
+      for (int i = 0; i < np_; ++i) for (int k = 0; k < 3; ++k) S.s.rowmap[n++] = RV_ROW_PACK(RV_BBIDX(kp), i, k, bb_a(kp), bb_b(kp), label[bb_a(kp)]);
+    }
+  return n;
+}
+#endif
+struct J6 { v3 l, a; };
+RV_DEV float dotj(const J6& j, v3 pl, v3 pa) { return dot(j.l, pl) + dot(j.a, pa); }
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+RV_DEV float rdlane(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
+RV_DEV v3 rdlane3(v3 x, int l) { return mk(rdlane(x.x, l), rdlane(x.y, l), rdlane(x.z, l)); }
+// One island of one body (Y < 0) or of two bodies X < Y, with a STATIC lane layout so that every
+// index below is a compile-time constant (row data, the lane's row of A and the sweep live in
+// registers; the unrolled sweep is ~13 instructions per row):
+//   lanes  0..23  body X: table points 0..3, arm points 0..3, x 3 rows
+//   lanes 24..47  body Y likewise
+//   lanes 48..59  the X-Y manifold, points 0..3 x 3 rows
+// which is the visiting order of the row list.  JX / JY: the lane's row acting on X / Y;
+// PX / PY: what a unit impulse on the lane's row does to X / Y.
+RV_DEV int isl_row_on(int s, int ntx, int nax, int nty, int nay, int nxy) {
+  const int blk = s < 24 ? 0 : (s < 48 ? 1 : 2);
+  const int p = (s - 24 * blk) / 3;
+  return blk == 0 ? (p < 4 ? p < ntx : p - 4 < nax) : (blk == 1 ? (p < 4 ? p < nty : p - 4 < nay) : p < nxy);
+}
+RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, const int kxy) {
+  DevEnv& e = S.e; const rv_config* c = K.cfg;
+  const int lane = (int)threadIdx.x;
+  const int ntx = __builtin_amdgcn_readfirstlane(e.man[RV_TIDX(X)].n), nax = __builtin_amdgcn_readfirstlane(e.man[RV_AIDX(X)].n);
+  int nty = 0, nay = 0, nxy = 0;
+  if (Y >= 0) {
+    nty = __builtin_amdgcn_readfirstlane(e.man[RV_TIDX(Y)].n); nay = __builtin_amdgcn_readfirstlane(e.man[RV_AIDX(Y)].n);
+    nxy = __builtin_amdgcn_readfirstlane(e.man[RV_BBIDX(kxy)].n);
+  }
+  if (ntx + nax + nty + nay + nxy == 0) return;
+  const int L = lane < 60 ? lane : 59;
+  const int blk = L < 24 ? 0 : (L < 48 ? 1 : 2);
+  const int p = (L - 24 * blk) / 3, k = (L - 24 * blk) - 3 * p, slot = p & 3;
+  const int Yc = Y >= 0 ? Y : X;
+  const int mi = blk == 0 ? (p < 4 ? RV_TIDX(X) : RV_AIDX(X)) : (blk == 1 ? (p < 4 ? RV_TIDX(Yc) : RV_AIDX(Yc)) : RV_BBIDX(kxy));
+  const bool act = lane < 60 && isl_row_on(L, ntx, nax, nty, nay, nxy);
+  const Row& R = S.s.u.r.rows[mi][slot];
+  DevMan& mm = e.man[mi];
+  J6 JX, JY, PX, PY;
+  JX.l = JX.a = JY.l = JY.a = PX.l = PX.a = PY.l = PY.a = mk(0, 0, 0);
+  float invk = 0.0f, bias = 0.0f, mu = 0.0f, lam = 0.0f, g = 0.0f;
+  if (act) {
+    const v3 dir = ld3(R.dir[k]), rxa = ld3(R.rxa[k]);
+    invk = R.invk[k]; mu = R.mu; bias = k == 0 ? R.target : 0.0f;
+    lam = k == 0 ? mm.ln[slot] : (k == 1 ? mm.lt1[slot] : mm.lt2[slot]);
+    const int ba = blk == 1 ? Yc : X;          // body a of the row's manifold
+    g = dot(dir, ld3(e.body[ba] + 7)) + dot(rxa, ld3(e.body[ba] + 10));
+    const v3 pl = scale(dir, e.inv_mass[ba]), pa = ld3(R.aa[k]);
+    if (blk == 0) { JX.l = dir; JX.a = rxa; PX.l = pl; PX.a = pa; g -= R.vbc[k]; }
+    else if (blk == 1) { JY.l = dir; JY.a = rxa; PY.l = pl; PY.a = pa; g -= R.vbc[k]; }
+    else {
+      const v3 rxb = ld3(R.rxb[k]);
+      g -= dot(dir, ld3(e.body[Yc] + 7)) + dot(rxb, ld3(e.body[Yc] + 10));
+      JX.l = dir; JX.a = rxa; PX.l = pl; PX.a = pa;
+      JY.l = mk(-dir.x, -dir.y, -dir.z); JY.a = mk(-rxb.x, -rxb.y, -rxb.z);
+      const v3 t = scale(dir, e.inv_mass[Yc]), ab = ld3(R.ab[k]);
+      PY.l = mk(-t.x, -t.y, -t.z); PY.a = mk(-ab.x, -ab.y, -ab.z);
+    }
+  }
+  // this lane's row of the Delassus matrix
+  float A[60];
+#pragma unroll
+  for (int s = 0; s < 60; ++s) {
+    float a_ = 0.0f;
+    if ((s < 24 || Y >= 0) && isl_row_on(s, ntx, nax, nty, nay, nxy)) {
+      if (s < 24) a_ = dotj(JX, rdlane3(PX.l, s), rdlane3(PX.a, s));
+      else if (s < 48) a_ = dotj(JY, rdlane3(PY.l, s), rdlane3(PY.a, s));
+      else a_ = dotj(JX, rdlane3(PX.l, s), rdlane3(PX.a, s)) + dotj(JY, rdlane3(PY.l, s), rdlane3(PY.a, s));
+    }
+    A[s] = a_;
+  }
+  // warm start: the impulses kept from the last substep act first
+#pragma unroll
+  for (int s = 0; s < 60; ++s) if ((s < 24 || Y >= 0) && isl_row_on(s, ntx, nax, nty, nay, nxy)) g = g + A[s] * rdlane(lam, s);
+  const int iters = c->solver_iters; const float tol = c->solver_tol;
+  for (int it = 0; it < iters; ++it) {
+    float res = 0.0f;
+#pragma unroll
+    for (int pp = 0; pp < 20; ++pp) {
+      if (!((pp < 8 || Y >= 0) && isl_row_on(3 * pp, ntx, nax, nty, nay, nxy))) continue;
+      float lim = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const int s = 3 * pp + kk;
+        float nl;
+        if (kk == 0) nl = fmaxr(lam + (bias - g) * invk, 0.0f);
+        else nl = fclampr(lam + (-g * invk), -lim, lim);
+        const float d = nl - lam;
+        if (lane == s) lam = nl;
+        const float sd = rdlane(d, s);
+        if (kk == 0) lim = rdlane(mu * nl, s);   // friction bound of the point: mu x its normal impulse
+        res = fmaxr(res, fabsr(sd));
+        g = g + A[s] * sd;
+      }
+    }
+    if (res < tol) break;
+  }
+  // impulses back to the manifolds; what every row adds to X and Y goes through LDS (the hull-vertex
+  // scratch is dead here), one lane per velocity component sums it in row order
+  float* cb = &S.s.u.r.wv[0][0][0][0];
+  if (act) {
+    if (k == 0) mm.ln[slot] = lam; else if (k == 1) mm.lt1[slot] = lam; else mm.lt2[slot] = lam;
+    float* o = cb + 12 * lane;
+    o[0] = PX.l.x * lam; o[1] = PX.l.y * lam; o[2] = PX.l.z * lam; o[3] = PX.a.x * lam; o[4] = PX.a.y * lam; o[5] = PX.a.z * lam;
+    o[6] = PY.l.x * lam; o[7] = PY.l.y * lam; o[8] = PY.l.z * lam; o[9] = PY.a.x * lam; o[10] = PY.a.y * lam; o[11] = PY.a.z * lam;
+  }
+  __syncthreads();
+  if (lane < 12 && (lane < 6 || Y >= 0)) {
+    const int isy = lane >= 6, cc = lane - 6 * isy, bd = isy ? Yc : X;
+    float acc = e.body[bd][7 + cc];
+    for (int s = isy ? 24 : 0; s < 60; ++s) {
+      if (!isy && s == 24) s = 48;                       // X: its own rows, then the pair rows
+      if (isl_row_on(s, ntx, nax, nty, nay, nxy)) acc = acc + cb[12 * s + 6 * isy + cc];
+    }
+    e.body[bd][7 + cc] = acc;
+  }
+  __syncthreads();
+}
+#else
+RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
+  DevEnv& e = S.e; const rv_config* c = K.cfg;
+  static thread_local float A[RV_SOLVE_ROWS][RV_SOLVE_ROWS];
+  float g[RV_SOLVE_ROWS], lam[RV_SOLVE_ROWS], invk[RV_SOLVE_ROWS], bias[RV_SOLVE_ROWS], mu[RV_SOLVE_ROWS];
+  J6 jx[RV_SOLVE_ROWS][RV_MAXB];
+  for (int r = 0; r < n_rows; ++r) {
+    const int rm = S.s.rowmap[r];
+    const int mi = RV_ROW_MI(rm), pi = RV_ROW_I(rm), k = RV_ROW_K(rm), ra = RV_ROW_A(rm), rb = RV_ROW_B(rm);
+    const Row& R = S.s.u.r.rows[mi][pi];
+    const DevMan& mm = e.man[mi];
+    for (int x = 0; x < RV_MAXB; ++x) { jx[r][x].l = mk(0, 0, 0); jx[r][x].a = mk(0, 0, 0); }
+    const v3 dir = ld3(R.dir[k]), rxa = ld3(R.rxa[k]);
+    invk[r] = R.invk[k]; mu[r] = R.mu; bias[r] = k == 0 ? R.target : 0.0f;
+    lam[r] = k == 0 ? mm.ln[pi] : (k == 1 ? mm.lt1[pi] : mm.lt2[pi]);
+    float gg = dot(dir, ld3(e.body[ra] + 7)) + dot(rxa, ld3(e.body[ra] + 10));
+    v3 nd = mk(0, 0, 0), nrxb = mk(0, 0, 0);
+    if (rb >= 0) {
+      const v3 rxb = ld3(R.rxb[k]);
+      gg -= dot(dir, ld3(e.body[rb] + 7)) + dot(rxb, ld3(e.body[rb] + 10));
+      nd = mk(-dir.x, -dir.y, -dir.z); nrxb = mk(-rxb.x, -rxb.y, -rxb.z);
+    } else gg -= R.vbc[k];
+    g[r] = gg;
+    jx[r][ra].l = dir; jx[r][ra].a = rxa;
+    if (rb >= 0) { jx[r][rb].l = nd; jx[r][rb].a = nrxb; }
+  }
+  for (int r = 0; r < n_rows; ++r)
+    for (int s = 0; s < n_rows; ++s) {
+      const int q = S.s.rowmap[s];
+      const Row& Q = S.s.u.r.rows[RV_ROW_MI(q)][RV_ROW_I(q)];
+      const int ks = RV_ROW_K(q), as = RV_ROW_A(q), bs = RV_ROW_B(q);
+      const v3 ds = ld3(Q.dir[ks]);
+      float a_ = dotj(jx[r][as], scale(ds, e.inv_mass[as]), ld3(Q.aa[ks]));
+      if (bs >= 0) {
+        const v3 t = scale(ds, e.inv_mass[bs]), ab = ld3(Q.ab[ks]);
+        a_ = a_ + dotj(jx[r][bs], mk(-t.x, -t.y, -t.z), mk(-ab.x, -ab.y, -ab.z));
+      }
+      A[r][s] = a_;
+    }
+  for (int s = 0; s < n_rows; ++s) for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s] * lam[s];
+  int isl_rows = 0, done = 0;
+  for (int s = 0; s < n_rows; ++s) isl_rows |= 1 << RV_ROW_ISL(S.s.rowmap[s]);
+  for (int it = 0; it < c->solver_iters; ++it) {
+    float res[RV_MAXB] = {0.0f, 0.0f, 0.0f, 0.0f}, lim = 0.0f;
+    for (int s = 0; s < n_rows; ++s) {
+      const int q = S.s.rowmap[s];
+      const int isl = RV_ROW_ISL(q);
+      if ((done >> isl) & 1) continue;
+      float nl;
+      if (RV_ROW_K(q) == 0) nl = fmaxr(lam[s] + (bias[s] - g[s]) * invk[s], 0.0f);
+      else nl = fclampr(lam[s] + (-g[s] * invk[s]), -lim, lim);
+      const float d = nl - lam[s];
+      lam[s] = nl;
+      if (RV_ROW_K(q) == 0) lim = mu[s] * nl;
+      res[isl] = fmaxr(res[isl], fabsr(d));
+      for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s] * d;
+    }
+    for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < c->solver_tol) done |= 1 << x;
+    if ((done & isl_rows) == isl_rows) break;
+  }
+  for (int s = 0; s < n_rows; ++s) {
+    const int q = S.s.rowmap[s];
+    DevMan& mm = e.man[RV_ROW_MI(q)];
+    const int pi = RV_ROW_I(q), ks = RV_ROW_K(q);
+    if (ks == 0) mm.ln[pi] = lam[s]; else if (ks == 1) mm.lt1[pi] = lam[s]; else mm.lt2[pi] = lam[s];
+  }
+  for (int X = 0; X < RV_MAXB; ++X) {
+    if (!body_on(e, X)) continue;
+    for (int cc = 0; cc < 6; ++cc) {
+      float acc = e.body[X][7 + cc];
+      for (int s = 0; s < n_rows; ++s) {
+        const int q = S.s.rowmap[s];
+        const int as = RV_ROW_A(q), bs = RV_ROW_B(q), ks = RV_ROW_K(q);
+        if (as != X && bs != X) continue;
+        const Row& Q = S.s.u.r.rows[RV_ROW_MI(q)][RV_ROW_I(q)];
+        float coef;
+        if (as == X) coef = cc < 3 ? Q.dir[ks][cc] * e.inv_mass[X] : Q.aa[ks][cc - 3];
+        else coef = cc < 3 ? -(Q.dir[ks][cc] * e.inv_mass[X]) : -Q.ab[ks][cc - 3];
+        acc = acc + coef * lam[s];
+      }
+      e.body[X][7 + cc] = acc;
+    }
+  }
+}
+#endif
+
 // ---------------------------------------------------- Simulator.step -----
 // One dt of Simulator.step (simulator.py:94-103): the arm's
 // ControllableBody.update, then the physics step, then num_steps += 1.
@@ -1270,7 +1528,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
         const rv_shape* s = &K.scene->shapes[S.e.shape[b]];
         float sc = S.e.scale[b];
         v3 l = mk(s->verts[h][i][0] * sc, s->verts[h][i][1] * sc, s->verts[h][i][2] * sc);
-        st3(S.s.wv[b][h][i], add(ld3(S.e.body[b]), mulv(qmat(ldq(S.e.body[b] + 3)), l)));
+        st3(S.s.u.r.wv[b][h][i], add(ld3(S.e.body[b]), mulv(qmat(ldq(S.e.body[b] + 3)), l)));
       }
     RV_LANES_END
     // stage 2b: one 16-lane group per body runs the distance queries, box by box
@@ -1289,7 +1547,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
           float lbmin = 1e30f;
           for (int h = 0; h < S.n_hulls[b] && !hit; ++h) {
             v3 n, pa, pb; float dist, lb = 0.0f;
-            if (gjk_epa(&S.s.wv[b][h][0][0], S.n_verts[b][h], &S.s.colv[col][0][0], 8, d, brk + 2.0f * mg, &n, &dist, &pa, &pb, &lb))
+            if (gjk_epa(&S.s.u.r.wv[b][h][0][0], S.n_verts[b][h], &S.s.colv[col][0][0], 8, d, brk + 2.0f * mg, &n, &dist, &pa, &pb, &lb))
               if (!(dist - 2.0f * mg > brk)) hit = 1;
             lbmin = fminr(lbmin, lb);
           }
@@ -1380,7 +1638,11 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       st3(S.s.fv[f], fv); st3(S.s.fw[f], fw);
       S.s.fmot[f] = (len(fv) + len(fw) * S.s.fext[f]) * c->dt;
     }
+#ifdef RV_DIAG_AWAKE_BODIES   // diagnostic build (tools/diag_lockstep.py): count awake BODIES per substep
+    if (lane == 63) { int nb_ = 0; for (int b = 0; b < RV_MAXB; ++b) nb_ += body_on(S.e, b); S.e.awake_last += nb_ * 65536 + S.s.any_on; }
+#else
     if (lane == 63) S.e.awake_last += S.s.any_on;
+#endif
     for (int item = lane; item < RV_MAXB * RV_MAXH * RV_MAXV; item += 64) {
       int b = item / (RV_MAXH * RV_MAXV), h = (item / RV_MAXV) % RV_MAXH, i = item % RV_MAXV;
       if (!body_on(S.e, b)) continue;
@@ -1388,7 +1650,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       const rv_shape* s = &K.scene->shapes[S.e.shape[b]];
       float sc = S.e.scale[b];
       v3 l = mk(s->verts[h][i][0] * sc, s->verts[h][i][1] * sc, s->verts[h][i][2] * sc);
-      st3(S.s.wv[b][h][i], add(ld3(S.e.body[b]), mulv(S.s.rot[b], l)));
+      st3(S.s.u.r.wv[b][h][i], add(ld3(S.e.body[b]), mulv(S.s.rot[b], l)));
     }
   RV_LANES_END
   RV_STOP(2)
@@ -1462,6 +1724,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       S.s.n_olist = n;
     }
   RV_LANES_END
+  RV_PROF(18)
   RV_LANES_BEGIN
     DevEnv& e = S.e;
     const int slot = lane >> 4;
@@ -1481,12 +1744,12 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         int io = t / n_inner, ii = t - io * n_inner;
         const float* A; const float* B; int nA, nB, ckind, col = -1;
         v3 guess = o.guess0;
-        if (role == 0) { A = &S.s.wv[a][ii][0][0]; nA = S.n_verts[a][ii]; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
-        else if (role == 1) { A = &S.s.wv[a][io][0][0]; nA = S.n_verts[a][io]; B = &S.s.wv[b][ii][0][0]; nB = S.n_verts[b][ii]; ckind = 1; }
+        if (role == 0) { A = &S.s.u.r.wv[a][ii][0][0]; nA = S.n_verts[a][ii]; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
+        else if (role == 1) { A = &S.s.u.r.wv[a][io][0][0]; nA = S.n_verts[a][io]; B = &S.s.u.r.wv[b][ii][0][0]; nB = S.n_verts[b][ii]; ckind = 1; }
         else if (role == 2) {
           col = io;
           if (!S.s.cn[a][col]) continue;
-          A = &S.s.wv[a][ii][0][0]; nA = S.n_verts[a][ii]; B = &S.s.colv[col][0][0]; nB = 8; ckind = 2;
+          A = &S.s.u.r.wv[a][ii][0][0]; nA = S.n_verts[a][ii]; B = &S.s.colv[col][0][0]; nB = 8; ckind = 2;
           guess = sub(ld3(e.body[a]), ld3(S.s.colc[col]));
         } else { col = a; A = &S.s.colv[col][0][0]; nA = 8; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
         float dd;
@@ -1517,7 +1780,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         p.ln = m.ln[i]; p.lt1 = m.lt1[i]; p.lt2 = m.lt2[i];
         Row r;
         row_setup(S, K, kind, a, b, p, r);
-        S.s.u.rows[mi][i] = r;
+        S.s.u.r.rows[mi][i] = r;
         m.ln[i] = p.ln * c->warmstart; m.lt1[i] = p.lt1 * c->warmstart; m.lt2[i] = p.lt2 * c->warmstart;
       }
     } else if (lane == 61) {
@@ -1539,11 +1802,8 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   RV_STOP(4)
   RV_PROF(4)
   // PGS over islands: awake bodies coupled (transitively) by body-body manifolds
-  // that hold points.  An island is an independent problem solved by ONE lane (its
-  // lowest body): a lone body keeps rows' impulses and its velocity in registers; a
-  // coupled island visits its bodies' table / arm rows, then its pairs in colour-round
-  // order, velocities and impulses in LDS -- no barriers inside the iteration loop.
-  // Every island stops on its own residual.
+  // that hold points.  Every island stops on its own residual.  All rows of the env are
+  // solved by the whole wave in impulse space, one lane per row (solve_rows above).
   int label[RV_MAXB], on_[RV_MAXB], act_[RV_NBB];
 #pragma unroll
   for (int b = 0; b < RV_MAXB; ++b) { label[b] = b; on_[b] = body_on(S.e, b); }
@@ -1558,47 +1818,43 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       const int lo = label[a_] < label[b_] ? label[a_] : label[b_];
       label[a_] = lo; label[b_] = lo;
     }
+  // members of every island; islands of one or two bodies go to the impulse-space solver
+  int mem_[RV_MAXB], big_[RV_MAXB];
+#pragma unroll
+  for (int b = 0; b < RV_MAXB; ++b) {
+    int m_ = 0;
+#pragma unroll
+    for (int x = 0; x < RV_MAXB; ++x) m_ += (on_[x] && label[x] == b);
+    mem_[b] = (on_[b] && label[b] == b) ? m_ : 0;
+    big_[b] = mem_[b] > 2;
+  }
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#pragma unroll
+  for (int b = 0; b < RV_MAXB; ++b) {
+    const int m_ = __builtin_amdgcn_readfirstlane(mem_[b]);
+    if (m_ == 1) solve_island2(S, K, b, -1, 0);
+    else if (m_ == 2) {
+      int y_ = -1;
+#pragma unroll
+      for (int x = RV_MAXB - 1; x > 0; --x) if (x > b && on_[x] && label[x] == b) y_ = x;
+      y_ = __builtin_amdgcn_readfirstlane(y_);
+      int kxy = 0;
+#pragma unroll
+      for (int kk = 0; kk < RV_NBB; ++kk) if (bb_a(kk) == b && bb_b(kk) == y_) kxy = kk;
+      solve_island2(S, K, b, y_, __builtin_amdgcn_readfirstlane(kxy));
+    }
+  }
+#else
   RV_LANES_BEGIN
-    if (lane < RV_MAXB && body_on(S.e, lane) && label[lane] == lane) {
+    if (lane == 0) S.s.n_rows = solver_row_list(S, label, on_, act_, big_);
+  RV_LANES_END
+  if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows);
+#endif
+  // islands of three or four bodies: velocity-space Gauss-Seidel, one lane per island
+  RV_LANES_BEGIN
+    if (lane < RV_MAXB && big_[lane]) {
       const int root = lane; DevEnv& e = S.e;
-      int members = 0;
-#pragma unroll
-      for (int b = 0; b < RV_MAXB; ++b) members += (body_on(e, b) && label[b] == root);
-      if (members == 1) {
-        const int b = root;
-        DevMan& mt = e.man[RV_TIDX(b)];
-        DevMan& ma = e.man[RV_AIDX(b)];
-        const int nt = mt.n, na = ma.n;
-        if (nt + na > 0) {
-          BV A = ld_bv(e, b); float ima = e.inv_mass[b];
-          Lam lt[4], la[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            lt[i].n = mt.ln[i]; lt[i].t1 = mt.lt1[i]; lt[i].t2 = mt.lt2[i];
-            la[i].n = ma.ln[i]; la[i].t1 = ma.lt1[i]; la[i].t2 = ma.lt2[i];
-          }
-          // rows are re-read from LDS by value (one batched load per point);
-          // only the impulses and the body velocity stay in registers
-#pragma unroll
-          for (int i = 0; i < 4; ++i) if (i < nt) { Row r = S.s.u.rows[RV_TIDX(b)][i]; warm_apply(A, nullptr, ima, 0.0f, lt[i], r); }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) if (i < na) { Row r = S.s.u.rows[RV_AIDX(b)][i]; warm_apply(A, nullptr, ima, 0.0f, la[i], r); }
-          for (int it = 0; it < c->solver_iters; ++it) {
-            float res = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) if (i < nt) { Row r = S.s.u.rows[RV_TIDX(b)][i]; res = fmaxr(res, point_solve(A, nullptr, ima, 0.0f, lt[i], r)); }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) if (i < na) { Row r = S.s.u.rows[RV_AIDX(b)][i]; res = fmaxr(res, point_solve(A, nullptr, ima, 0.0f, la[i], r)); }
-            if (res < c->solver_tol) break;
-          }
-          st_bv(e, b, A);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (i < nt) { mt.ln[i] = lt[i].n; mt.lt1[i] = lt[i].t1; mt.lt2[i] = lt[i].t2; }
-            if (i < na) { ma.ln[i] = la[i].n; ma.lt1[i] = la[i].t1; ma.lt2[i] = la[i].t2; }
-          }
-        }
-      } else {
+      {
         for (int it = -1; it < c->solver_iters; ++it) {   // it == -1: warm start
           float res = 0.0f;
           for (int b = root; b < RV_MAXB; ++b) {
@@ -1608,7 +1864,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
               DevMan& m = e.man[kind == 0 ? RV_TIDX(b) : RV_AIDX(b)];
               const int mi = kind == 0 ? RV_TIDX(b) : RV_AIDX(b);
               for (int i = 0; i < m.n; ++i) {
-                Row r = S.s.u.rows[mi][i];
+                Row r = S.s.u.r.rows[mi][i];
                 Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
                 if (it < 0) warm_apply(A, nullptr, ima, 0.0f, l, r);
                 else { res = fmaxr(res, point_solve(A, nullptr, ima, 0.0f, l, r)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
@@ -1626,7 +1882,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
               BV A = ld_bv(e, a_), B = ld_bv(e, b_);
               const float ima = e.inv_mass[a_], imb = e.inv_mass[b_];
               for (int i = 0; i < m.n; ++i) {
-                Row r = S.s.u.rows[RV_BBIDX(k)][i];
+                Row r = S.s.u.r.rows[RV_BBIDX(k)][i];
                 Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
                 if (it < 0) warm_apply(A, &B, ima, imb, l, r);
                 else { res = fmaxr(res, point_solve(A, &B, ima, imb, l, r)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }

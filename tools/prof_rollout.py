@@ -54,17 +54,18 @@ st = w.stats()
 names_ = ['quiet substeps (light part only)', 'light part of non-quiet substeps', 'heavy: twists + hull vertices',
           'heavy: narrow phase', 'heavy: row setup', 'heavy: solver', 'heavy: integrate + return', 'between substeps',
           'end of a STEPS_CHECK chunk', 'phase_tick', 'coast: budget (+refresh)', 'coast: control + motors']
-tot = p[:, :7].sum(axis=1)
+names_.append('heavy: narrow phase prep (refresh, gate, list)')
+tot = p[:, :7].sum(axis=1) + p[:, 18]
 slow = int(np.argmax(tot))
 clk = tot.max() / (ms * 1e-3)
 print('rollout of %d steps x %d envs: %.1f ms; slowest env = %.3g clocks => counter at %.1f MHz' % (steps, n, ms, tot.max(), clk / 1e6))
 print('substeps %d, awake fraction %.3f' % (st['substeps'], st['awake_substeps'] / max(st['substeps'], 1)))
 print('%-36s %10s %10s' % ('part', 'mean env', 'slowest'))
-for k in range(12):
-    print('%-36s %9.1f%% %9.1f%%' % (names_[k], 100 * p[:, k].mean() / tot.mean(), 100 * p[slow, k] / tot[slow]))
+for k in list(range(12)) + [18]:
+    print('%-46s %9.1f%% %9.1f%%' % (names_[k if k < 12 else 12], 100 * p[:, k].mean() / tot.mean(), 100 * p[slow, k] / tot[slow]))
 print('mean env busy time / slowest env = %.3f' % (tot.mean() / tot.max()))
 gn = ['other (culling, loop, idle rounds)', 'GJK/EPA', 'first manifold point', 'feature stage', 'manifold refresh', '-']
-for g, gname in ((0, 'group 0: table owners of bodies 0/2 (+ BB, AT owners)'), (1, 'group 1: arm owners of bodies 0/2 (+ BB, AT owners)')):
+for g, gname in ((0, 'group 0 of the query stage'),):
     gt = p[:, 12 + 6 * g: 18 + 6 * g]
     print(gname + ': share of the narrow-phase slot, mean env / slowest env')
     for k in range(5):
@@ -74,4 +75,4 @@ order = np.argsort(-tot)[:6]
 print('slowest envs: id, ms, substeps, awake, pairs')
 for i in order:
     print('  %4d %7.1f %7d %6d %6d   parts%% %s' % (i, tot[i] / clk * 1e3, cnt[i, 7], cnt[i, 8], cnt[i, 9],
-          np.round(100 * p[i, :7] / tot[i], 1)))
+          np.round(100 * np.append(p[i, :7], p[i, 18]) / tot[i], 1)))
