@@ -157,7 +157,7 @@ struct Scratch {
   float sync;
   float lq[RV_NLIMB][4];
   float vdraw[RV_NJ], ratio[RV_NJ];      // motor phase: raw commanded velocity, limit factor
-  int jmoving[RV_NJ];
+  int jmoving[RV_NJ], jchg[RV_NJ];
   float rvec[RV_NLIMB + 1][3];           // FK: link offsets rotated into the world
   int jt_applied;                        // the motor targets hold the current joint target (per launch)
   int atflag[RV_NCOL];                   // collider box may be within the contact-query distance of the table
@@ -1103,6 +1103,7 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
       float qn = e.q[j] + qd * dt;
       if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
       if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
+      if (with_lq) S.s.jchg[j] = (qn != e.q[j]) || (qd != 0.0f);   // did the joint state change at all?
       e.q[j] = qn; e.qd[j] = qd;
       if (with_lq) {
         S.s.jmoving[j] = fabsr(qd) > 1e-3f;
@@ -1473,13 +1474,32 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   const rv_config* c = K.cfg;
   const int arm_on = S.e.arm_enabled;
 
+  // An arm that did not move (every joint at rest: the settle after a push, the wait for the
+  // bodies to come to rest) has the frames, collider boxes and table flags of the last substep:
+  // only the per-substep flags are reset.  Exact: the skipped phases would recompute the same values.
+  int arm_static = 0;
   if (arm_on) {
     arm_motor_phases(S, K, 1, 0);
     RV_STOPL(12)
-    arm_fk_phases(S, K);
+    if (S.s.kin_fresh && K.stop_after == 0) {
+      arm_static = 1;
+#pragma unroll
+      for (int j = 0; j < RV_NJ; ++j) if (S.s.jchg[j]) arm_static = 0;
+    }
+    if (!arm_static) arm_fk_phases(S, K);
   }
   RV_STOPL(1)
-  arm_collider_phases(S, K, arm_on);
+  if (arm_static) {
+    RV_LANES_BEGIN
+      if (lane < RV_MAXB) { S.s.wake[lane] = 0; S.s.bnear[lane] = 0; }
+      if (lane == 8) S.s.near_any = 0;
+      if (lane == 9) S.s.arm_moving = 0;
+      if (lane >= 16 && lane < 16 + RV_NCOL) { S.s.colflag[lane - 16] = 0; S.s.coltravel[lane - 16] = 0.0f * 1.02f + 1e-7f; }
+      if (lane == 63) S.s.clr_valid = 0;
+    RV_LANES_END
+  } else {
+    arm_collider_phases(S, K, arm_on);
+  }
   RV_STOPL(16)
 
   // wake test.  A sleeping body is woken by a MOVING awake body nearby, or by the
@@ -1670,10 +1690,15 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     const DevEnv& e = S.e;
     if (lane < RV_NMAN * 4) {
       const int mi = lane >> 2, i = lane & 3;
-      OwnerInfo o;
-      owner_decode(S, K, mi, arm_on, o);
+      // whose manifold, and is it refreshed?  (the same conditions as owner_decode's `live`)
+      int kind, a, b = -1, live;
+      if (mi < RV_MAXB) { kind = 0; a = mi; live = body_present(e, a) && !e.asleep[a]; }
+      else if (mi < RV_MAXB + RV_NBB) {
+        kind = 1; a = bb_a(mi - RV_MAXB); b = bb_b(mi - RV_MAXB);
+        live = body_present(e, a) && body_present(e, b) && !e.asleep[a] && !e.asleep[b];
+      } else { kind = 2; a = mi - RV_MAXB - RV_NBB; live = body_present(e, a) && !e.asleep[a] && arm_on; }
       float d = 0.0f; int rm = 0;
-      if (o.live && i < e.man[mi].n) refresh_point(S, K, o.kind, o.a, o.b, e.man[mi], i, &d, &rm);
+      if (live && i < e.man[mi].n) refresh_point(S, K, kind, a, b, e.man[mi], i, &d, &rm);
       S.s.rf_dist[lane] = d; S.s.rf_rm[lane] = rm;
     }
   RV_LANES_END
