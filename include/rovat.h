@@ -59,6 +59,16 @@ extern "C" {
 #define RV_TASK_INSERTION 2
 #define RV_TASK_CROSSING  3
 
+#define RV_ENV_PUSH  0
+#define RV_ENV_GRASP 1
+/* phases of Grasp4DofEnv._execute_action (grasp_4dof_env.py:300-308) */
+#define RV_GPHASE_INITIAL  0
+#define RV_GPHASE_OVERHEAD 1
+#define RV_GPHASE_PRESTART 2
+#define RV_GPHASE_START    3
+#define RV_GPHASE_END      4
+#define RV_GPHASE_POSTEND  5
+#define RV_GPHASE_DONE     6
 /* phases of PushEnv._execute_action (push_env.py:121-127) */
 #define RV_PHASE_INITIAL  0
 #define RV_PHASE_PRE      1
@@ -202,6 +212,20 @@ typedef struct rv_config {
   float    cam_near;
   int32_t  use_crop;             /* OBS.CROP_MIN / CROP_MAX (camera_obs.py:187-192)  */
   float    crop_min[3], crop_max[3];
+  /* Grasp4DofEnv (grasp_4dof_env.py:63-345) and the force-limited gripper it needs */
+  int32_t  env_type;             /* RV_ENV_PUSH / RV_ENV_GRASP                        */
+  int32_t  finger_dynamics;      /* 1: the two finger joints are dynamic DOFs of the
+                                  * contact solver, driven by POSITION_CONTROL motor rows
+                                  * limited to finger_max_force (bullet_physics.py:1061-1104:
+                                  * default max force = joint effort)                 */
+  float    finger_mass, finger_max_force;
+  float    grasp_cuboid_low[3], grasp_cuboid_high[3];   /* ACTION.CUBOID (:144-150)   */
+  float    overhead_positions[RV_NLIMB];                /* ARM.OVERHEAD_POSITIONS     */
+  int32_t  max_action_steps;                            /* SIM.MAX_ACTION_STEPS (:333)*/
+  float    end_effector_step;                           /* sawyer_sim.py:264          */
+  /* lateral friction the env gives the finger tips / the table while it descends and
+   * while it lifts (grasp_4dof_env.py:262-270, 282-293)                              */
+  float    grasp_mu_descend[2], grasp_mu_lift[2];
 } rv_config;
 
 /* Per-launch statistics of rv_step_macro / rv_reset (device-side reductions of
@@ -334,6 +358,12 @@ typedef struct rv_obs_buffers {
   float*   d_yaw_cossin;   /* [N][RV_MAXB][2]  cos(yaw), sin(yaw)               */
 } rv_obs_buffers;
 int  rv_observe(rv_world* w, const rv_obs_buffers* obs);
+
+/* ---- CameraObs 'depth' / 'segmask' (camera_obs.py:33-88; BulletCamera._frames,
+ *      bullet_camera.py:188-235) of the simulated depth camera: eye-space depth (0 where
+ *      nothing is hit) and segmentation (body index, RV_MAXB = table, 255 = nothing).
+ *      The arm is not rendered.  Either pointer may be NULL. */
+int  rv_render(rv_world* w, float* d_depth /* [N][cam_height][cam_width] */, uint8_t* d_segmask /* same shape */);
 
 /* ---- PushReward.get_reward (push_reward.py:377-405, 272-374) of the last
  *      macro step, and RobotEnv done flag (robot_env.py:257-259). ---- */

@@ -46,7 +46,7 @@ def _lib(double):
                      'orc_get_episode_returns', 'orc_get_stats', 'orc_eval_reward',
                      'orc_eval_waypoints', 'orc_set_external_control', 'orc_motor_targets',
                      'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout', 'orc_set_pose_f32',
-                     'orc_rollout_counts', 'orc_render', 'orc_point_cloud'):
+                     'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction'):
             getattr(lib, name).restype = None
         lib.orc_is_limb_ready.restype = C.c_int
         lib.orc_is_gripper_ready.restype = C.c_int
@@ -190,6 +190,9 @@ class OracleWorld(object):
 
     def grip(self, value):
         self.lib.orc_grip(self.h, C.c_float(value))
+
+    def set_friction(self, mu_finger=-1.0, mu_table=-1.0):
+        self.lib.orc_set_friction(self.h, C.c_double(mu_finger), C.c_double(mu_table))
 
     def is_limb_ready(self, env=0):
         return bool(self.lib.orc_is_limb_ready(self.h, C.c_int(env)))

@@ -96,6 +96,10 @@ typedef struct {
   int sim_steps;                 /* Simulator.num_steps            */
   int num_steps, num_episodes;   /* RobotEnv counters              */
   int obs_num_steps, obs_num_episodes;   /* env.attributes snapshot (push_env.py:368-375, 637-644) */
+  /* lateral friction of the finger tips / the table (Link.set_dynamics, grasp_4dof_env.py:262-293) */
+  real mu_finger, mu_table;
+  int num_action_steps;                  /* Grasp4DofEnv: substeps spent in the 'start' phase */
+  real fing_dv[2], fing_vt[2], fing_qd0[2];   /* finger motors this substep: velocity step, commanded velocity, velocity after it */
   int l_unsafe, l_ineffective, l_useful, l_episodes, l_successes;   /* per-launch sums (stats) */
   int done, phase, is_safe, is_effective;
   int reset_count;
@@ -185,7 +189,8 @@ static void arm_update_kinematics(const orc_world* w, orc_env* e) {
       v3sub(d, e->fpos[f], e->fpos[k]); v3cross(c, u, d);
       v3add(fv, fv, c);
     }
-    if (f >= 8) v3madd(fv, fv, yax, e->qd[f - 1]);
+    /* the slide of a finger along the hand's y axis (a solver DOF of its own in finger_dynamics mode) */
+    if (f >= 8 && !w->cfg.finger_dynamics) v3madd(fv, fv, yax, e->qd[f - 1]);
     v3cpy(e->fv[f], fv); v3cpy(e->fw[f], fw);
     /* how far can a collider vertex riding on this frame travel in one substep */
     real ext = R(0.0);
@@ -195,7 +200,9 @@ static void arm_update_kinematics(const orc_world* w, orc_env* e) {
       real hh[3] = {(real)a->col_half[c][0], (real)a->col_half[c][1], (real)a->col_half[c][2]};
       ext = rmax(ext, v3len(cc) + v3len(hh));
     }
-    e->arm_mot = rmax(e->arm_mot, (v3len(fv) + v3len(fw) * ext) * (real)w->cfg.dt);
+    real fm = (v3len(fv) + v3len(fw) * ext) * (real)w->cfg.dt;
+    if (f >= 8 && w->cfg.finger_dynamics) fm += rabs(e->qd[f - 1]) * (real)w->cfg.dt;
+    e->arm_mot = rmax(e->arm_mot, fm);
   }
   for (int c = 0; c < RV_NCOL; ++c) {
     int f = a->col_frame[c];
@@ -459,6 +466,7 @@ static void arm_motor_step(const orc_world* w, orc_env* e) {
     real qn = e->q[j] + qd * dt;
     if (qn < (real)a->q_lo[j]) { qn = (real)a->q_lo[j]; qd = R(0.0); }
     if (qn > (real)a->q_hi[j]) { qn = (real)a->q_hi[j]; qd = R(0.0); }
+    if (j >= RV_NLIMB) { e->fing_dv[j - RV_NLIMB] = dv; e->fing_vt[j - RV_NLIMB] = vd; e->fing_qd0[j - RV_NLIMB] = qd; }
     e->q[j] = qn; e->qd[j] = qd;
   }
 }
@@ -789,6 +797,7 @@ typedef struct {
   real invk[3];
   real vbc[3];        /* dir . (kinematic surface velocity) */
   real target, mu;
+  real jf[3]; int fidx;   /* dynamic finger (rv_config.finger_dynamics): Jacobian on finger joint 7 + fidx; -1: none */
 } orc_row;
 
 static void row_setup(const orc_world* w, orc_env* e, int kind, int a, int b, const orc_manifold* m, int i, orc_row* r) {
@@ -808,6 +817,9 @@ static void row_setup(const orc_world* w, orc_env* e, int kind, int a, int b, co
     real d[3], cr[3];
     v3sub(d, wb, e->fpos[f]); v3cross(cr, e->fw[f], d); v3add(vb_pt, e->fv[f], cr);
   }
+  /* a point on a finger pad of the force-limited gripper: the finger joint is a solver DOF */
+  const int fing = c->finger_dynamics && kind == 2 && m->col[i] >= 8;
+  const real fy[3] = {e->frot[7][1], e->frot[7][4], e->frot[7][7]};
   for (int k = 0; k < 3; ++k) {
     v3cross(r->rxa[k], ra, r->dir[k]);
     m3mulv(r->aa[k], e->iinv[a], r->rxa[k]);
@@ -820,13 +832,17 @@ static void row_setup(const orc_world* w, orc_env* e, int kind, int a, int b, co
       r->rxb[k][0] = r->rxb[k][1] = r->rxb[k][2] = R(0.0);
       r->ab[k][0] = r->ab[k][1] = r->ab[k][2] = R(0.0);
     }
+    real jf = R(0.0);
+    if (fing) { jf = -v3dot(r->dir[k], fy); kk += jf * jf / (real)c->finger_mass; }
     r->invk[k] = R(1.0) / kk;
     r->vbc[k] = v3dot(r->dir[k], vb_pt);
+    r->jf[k] = jf;
   }
+  r->fidx = fing ? m->col[i] - 8 : -1;
   real dist = m->dist[i];
   if (dist > R(0.0)) r->target = -dist / dt;
   else r->target = rmin((real)c->erp * rmax(-dist - (real)c->slop, R(0.0)) / dt, (real)c->max_pushout);
-  real mub = (kind == 0) ? (real)c->table_friction : (kind == 1 ? e->bp[b].friction : (real)c->arm_friction);
+  real mub = (kind == 0) ? e->mu_table : (kind == 1 ? e->bp[b].friction : (m->col[i] >= 8 ? e->mu_finger : (real)c->arm_friction));
   r->mu = e->bp[a].friction * mub;
 }
 
@@ -868,6 +884,95 @@ static real point_solve(orc_env* e, int kind, int a, int b, orc_manifold* m, int
   res = rmax(res, rabs(dl));
   row_apply(e, kind, a, b, r, 2, dl);
   return res;
+}
+
+/* PGS with the force-limited gripper (rv_config.finger_dynamics; Grasp4DofEnv).  The two finger
+ * joints are dynamic 1-DoF bodies of mass finger_mass sliding along the hand's y axis: contact rows
+ * on a finger pad (collider boxes 8 / 9) carry jf = -(dir . y) on the finger velocity, and each
+ * finger has a POSITION_CONTROL motor row (bullet_physics.py:1061-1104) that pulls its velocity to
+ * the commanded one with at most finger_max_force (the joint motors have already spent m * fing_dv
+ * of that budget on the free motion).  Velocity-space Gauss-Seidel over all awake bodies and both
+ * fingers as one system. */
+static real point_solve_g(orc_env* e, int a, orc_manifold* m, int i, const orc_row* r, real* qf, real imf) {
+  const int fi = r->fidx;
+  real jv = row_jv(e, 0, a, -1, r, 0);
+  if (fi >= 0) jv += r->jf[0] * qf[fi];
+  real dl = (r->target - jv) * r->invk[0];
+  real ln = rmax(m->ln[i] + dl, R(0.0));
+  dl = ln - m->ln[i]; m->ln[i] = ln;
+  real res = rabs(dl);
+  row_apply(e, 0, a, -1, r, 0, dl);
+  if (fi >= 0) qf[fi] += r->jf[0] * dl * imf;
+  real lim = r->mu * ln;
+  jv = row_jv(e, 0, a, -1, r, 1);
+  if (fi >= 0) jv += r->jf[1] * qf[fi];
+  dl = -jv * r->invk[1];
+  real l1 = rclamp(m->lt1[i] + dl, -lim, lim);
+  dl = l1 - m->lt1[i]; m->lt1[i] = l1;
+  res = rmax(res, rabs(dl));
+  row_apply(e, 0, a, -1, r, 1, dl);
+  if (fi >= 0) qf[fi] += r->jf[1] * dl * imf;
+  jv = row_jv(e, 0, a, -1, r, 2);
+  if (fi >= 0) jv += r->jf[2] * qf[fi];
+  dl = -jv * r->invk[2];
+  real l2 = rclamp(m->lt2[i] + dl, -lim, lim);
+  dl = l2 - m->lt2[i]; m->lt2[i] = l2;
+  res = rmax(res, rabs(dl));
+  row_apply(e, 0, a, -1, r, 2, dl);
+  if (fi >= 0) qf[fi] += r->jf[2] * dl * imf;
+  return res;
+}
+static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4], const int* use) {
+  const rv_config* c = &w->cfg; const rv_arm* arm = &w->scene.arm;
+  const real mf = (real)c->finger_mass, imf = R(1.0) / (real)c->finger_mass, fdt = (real)c->finger_max_force * (real)c->dt;
+  real qf[2] = {e->qd[RV_NLIMB], e->qd[RV_NLIMB + 1]}, lam_m[2] = {R(0.0), R(0.0)};
+  for (int it = -1; it < c->solver_iters; ++it) {
+    real res = R(0.0);
+    for (int b = 0; b < RV_MAXB; ++b) {
+      if (!use[TIDX(b)]) continue;
+      for (int kind = 0; kind <= 2; kind += 2) {
+        const int mi = kind == 0 ? TIDX(b) : AIDX(b);
+        orc_manifold* m = &e->man[mi];
+        for (int i = 0; i < m->n; ++i) {
+          const orc_row* r = &rows[mi][i];
+          if (it < 0) {
+            row_apply(e, 0, b, -1, r, 0, m->ln[i]); row_apply(e, 0, b, -1, r, 1, m->lt1[i]); row_apply(e, 0, b, -1, r, 2, m->lt2[i]);
+            if (r->fidx >= 0) { qf[r->fidx] += r->jf[0] * m->ln[i] * imf; qf[r->fidx] += r->jf[1] * m->lt1[i] * imf; qf[r->fidx] += r->jf[2] * m->lt2[i] * imf; }
+          } else res = rmax(res, point_solve_g(e, b, m, i, r, qf, imf));
+        }
+      }
+    }
+    for (int rd = 0; rd < 3; ++rd)
+      for (int x = 0; x < 2; ++x) {
+        const int k = BB_ROUND[rd][x], mi = BBIDX(k);
+        orc_manifold* m = &e->man[mi];
+        if (!use[mi]) continue;
+        for (int i = 0; i < m->n; ++i) {
+          if (it < 0) {
+            row_apply(e, 1, BB_A[k], BB_B[k], &rows[mi][i], 0, m->ln[i]); row_apply(e, 1, BB_A[k], BB_B[k], &rows[mi][i], 1, m->lt1[i]);
+            row_apply(e, 1, BB_A[k], BB_B[k], &rows[mi][i], 2, m->lt2[i]);
+          } else res = rmax(res, point_solve(e, 1, BB_A[k], BB_B[k], m, i, &rows[mi][i]));
+        }
+      }
+    if (it < 0) continue;
+    for (int f = 0; f < 2; ++f) {
+      const real i0 = mf * e->fing_dv[f];
+      real dl = (e->fing_vt[f] - qf[f]) * mf;
+      const real ln = rclamp(lam_m[f] + dl, -fdt - i0, fdt - i0);
+      dl = ln - lam_m[f]; lam_m[f] = ln;
+      qf[f] += dl * imf;
+      res = rmax(res, rabs(dl));
+    }
+    if (res < (real)c->solver_tol) break;
+  }
+  for (int f = 0; f < 2; ++f) {
+    const int j = RV_NLIMB + f;
+    real qd = qf[f];
+    real qn = e->q[j] + (qd - e->fing_qd0[f]) * (real)c->dt;
+    if (qn < (real)arm->q_lo[j]) { qn = (real)arm->q_lo[j]; qd = R(0.0); }
+    if (qn > (real)arm->q_hi[j]) { qn = (real)arm->q_hi[j]; qd = R(0.0); }
+    e->q[j] = qn; e->qd[j] = qd;
+  }
 }
 
 /* PGS in impulse space.  The rows of ALL islands of the env in the order the sequential
@@ -1007,6 +1112,7 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
         if (!big[label[BB_A[k]]]) for (int k3 = 0; k3 < 3; ++k3) { orc_rowid y = {mi, i, k3, BB_A[k], BB_B[k], label[BB_A[k]]}; id[n_rows++] = y; }
       }
     }
+  if (c->finger_dynamics && e->arm_enabled) { solve_with_fingers(w, e, rows, use); return; }
   if (n_rows > 0) solve_rows(w, e, rows, id, n_rows, use, big, label);
   /* big islands: warm start first */
   for (int b = 0; b < RV_MAXB; ++b)
@@ -1195,7 +1301,9 @@ static void sim_substep(const orc_world* w, orc_env* e) {
       /* a sleeper that was woken but never left the pose it was resting in goes back to
        * sleep after a quarter of the usual wait */
       int quick = e->bp[b].undisturbed && 4 * e->bp[b].still_count >= c->sleep_steps && 4 * e->bp[b].sleep_count >= c->sleep_steps;
-      if (e->bp[b].sleep_count >= c->sleep_steps || e->bp[b].still_count >= c->sleep_steps || quick) {
+      /* a body the force-limited gripper holds stays active (its island contains the moving fingers) */
+      int held = c->finger_dynamics && e->man[AIDX(b)].n > 0;
+      if (!held && (e->bp[b].sleep_count >= c->sleep_steps || e->bp[b].still_count >= c->sleep_steps || quick)) {
         e->bp[b].asleep = 1;
         v3set(B->v, R(0.0), R(0.0), R(0.0)); v3set(B->w, R(0.0), R(0.0), R(0.0));
         /* world box of the resting hulls: what the arm has to come near to wake the body */
@@ -1462,6 +1570,105 @@ static void env_step(const orc_world* w, orc_env* e) {
   }
 }
 
+/* ------------------------------------------------------- Grasp4DofEnv ---- */
+/* SawyerSim.move_along_gripper_path -> set_target_link_poses (sawyer_sim.py:310-360,
+ * controllable_body.py:319-345): the poses are reached one after the other */
+static void robot_move_along_gripper_path(const orc_world* w, orc_env* e, real poses[][7], int n) {
+  robot_move_to_gripper_pose(w, e, poses[0]);
+  e->lt.has_pose = 0; e->lt.nq = n;
+  for (int q = 0; q < n; ++q) memcpy(e->lt.queue[q], poses[q], sizeof(real) * 7);
+  lt_pop(&e->lt);
+}
+/* SawyerSim.move_to_gripper_pose(pose, straight_line=True) (sawyer_sim.py:259-276) */
+static void robot_move_straight(const orc_world* w, orc_env* e, const real* pose) {
+  const rv_config* c = &w->cfg;
+  real d[3]; v3sub(d, pose, e->fpos[7]);
+  int num = (int)(v3len(d) / (real)c->end_effector_step);
+  if (num > RV_MAXQ - 1) num = RV_MAXQ - 1;
+  real wps[RV_MAXQ][7];
+  for (int i = 0; i < num; ++i) {
+    real sc = (real)i / (real)num;
+    v3madd(wps[i], e->fpos[7], d, sc);
+    for (int k = 3; k < 7; ++k) wps[i][k] = pose[k];
+  }
+  memcpy(wps[num], pose, sizeof(real) * 7);
+  robot_move_along_gripper_path(w, e, wps, num + 1);
+}
+/* Grasp4DofEnv._execute_action (grasp_4dof_env.py:213-345) */
+static void execute_grasp(const orc_world* w, orc_env* e) {
+  const rv_config* c = &w->cfg;
+  real start[7];
+  start[0] = e->action[0][0]; start[1] = e->action[0][1]; start[2] = e->action[0][2] + (real)c->finger_tip_offset;
+  euler_to_quat(start + 3, R(0.0), w->pose_f32 ? (real)(float)ORC_PI : ORC_PI, w->pose_f32 ? (real)(float)e->action[0][3] : e->action[0][3]);
+  e->is_safe = 1; e->is_effective = 1;
+  e->phase = RV_GPHASE_INITIAL; e->num_action_steps = 0;
+  while (e->phase != RV_GPHASE_DONE) {
+    sim_substep(w, e);
+    if (e->phase == RV_GPHASE_START) e->num_action_steps++;
+    /* _is_phase_ready (:322-345) */
+    int ready = 0;
+    if (e->phase == RV_GPHASE_START && e->num_action_steps >= c->max_action_steps) ready = 1;
+    else if ((e->phase == RV_GPHASE_START || e->phase == RV_GPHASE_END) && e->flag_arm_table) ready = 1;
+    else if (arm_is_ready_limb(w, e) && robot_is_gripper_ready(w, e)) ready = 1;
+    if (!ready) continue;
+    e->phase = e->phase + 1;
+    if (e->phase == RV_GPHASE_OVERHEAD) {
+      real q[RV_NLIMB];
+      for (int j = 0; j < RV_NLIMB; ++j) q[j] = (real)c->overhead_positions[j];
+      robot_move_to_joint_positions(w, e, q);
+    } else if (e->phase == RV_GPHASE_PRESTART) {
+      real pose[7]; memcpy(pose, start, sizeof(pose));
+      pose[2] = (real)c->gripper_safe_height;
+      robot_move_to_gripper_pose(w, e, pose);
+    } else if (e->phase == RV_GPHASE_START) {
+      robot_move_straight(w, e, start);
+      e->mu_finger = (real)c->grasp_mu_descend[0]; e->mu_table = (real)c->grasp_mu_descend[1];
+    } else if (e->phase == RV_GPHASE_END) {
+      robot_grip(w, e, R(1.0));
+    } else if (e->phase == RV_GPHASE_POSTEND) {
+      real pose[7];
+      v3cpy(pose, e->fpos[7]); memcpy(pose + 3, e->fquat[7], sizeof(real) * 4);
+      if (w->pose_f32) for (int i = 3; i < 7; ++i) pose[i] = (real)(float)pose[i];
+      pose[2] = (real)c->gripper_safe_height;
+      robot_move_straight(w, e, pose);
+      e->mu_finger = (real)c->grasp_mu_lift[0]; e->mu_table = (real)c->grasp_mu_lift[1];
+    }
+  }
+}
+/* RobotEnv.step for Grasp4DofEnv + GraspReward.get_reward (grasp_reward.py:49-68) */
+static void genv_step(const orc_world* w, orc_env* e) {
+  if (e->done) return;
+  e->substeps_last = 0; e->awake_last = 0; e->pairs_last = 0;
+  e->obs_num_steps = e->num_steps; e->obs_num_episodes = e->num_episodes;
+  execute_grasp(w, e);
+  e->num_steps++;
+  compute_obs(e);
+  unsigned mask = 0;
+  for (int b = 0; b < RV_MAXB; ++b) if (e->bp[b].active) mask |= 1u << b;
+  wait_until_stable(w, e, mask, R(0.005), R(0.005), 100, 100, 2000);
+  const int success = arm_touches_movables(e);
+  const real r = success ? R(1.0) : R(0.0);
+  e->is_effective = success;
+  e->num_total_steps++;
+  e->num_useful += success; e->l_useful += success;
+  e->num_ineffective += !success; e->l_ineffective += !success;
+  e->last_reward = r; e->episode_reward += r;
+  e->done = 1;
+  e->num_episodes++; e->l_episodes++;
+  if (success) { e->num_successes++; e->l_successes++; }
+}
+static void step_env(const orc_world* w, orc_env* e) { if (w->cfg.env_type == RV_ENV_GRASP) genv_step(w, e); else env_step(w, e); }
+/* RandomPolicy._action = action_space.sample() (see random_action in rv_dev_env.h) */
+static void random_action(const rv_config* c, int gid, int macro_index, real* a) {
+  int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
+  orc_rng g; rng_init(&g, c->seed_lo, c->seed_hi, (uint32_t)gid, STREAM_RANDOM, (uint32_t)macro_index);
+  for (int x = 0; x < G * 4; ++x) a[x] = rng_uniform(&g, R(-1.0), R(1.0));
+  if (c->env_type == RV_ENV_GRASP) {
+    for (int k = 0; k < 3; ++k) a[k] = (real)c->grasp_cuboid_low[k] + ((real)c->grasp_cuboid_high[k] - (real)c->grasp_cuboid_low[k]) * (R(0.5) * (a[k] + R(1.0)));
+    a[3] = ORC_PI * (a[3] + R(1.0));
+  }
+}
+
 /* --------------------------------------------------------------- reset --- */
 /* PushEnv._sample_body_poses / _sample_body_poses_on_tiles, intent version
  * (push_env.py:473-597; SURVEY.md Appendix B-7 documents why the reference's
@@ -1522,6 +1729,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   e->done = 0;
   e->phase = RV_PHASE_INITIAL; e->is_safe = 1; e->is_effective = 1;
   e->arm_enabled = 0;
+  e->mu_finger = (real)c->arm_friction; e->mu_table = (real)c->table_friction; e->num_action_steps = 0;
   for (int i = 0; i < RV_NMAN; ++i) e->man[i].n = 0;
   e->flag_arm_table = 0;
   for (int b = 0; b < RV_MAXB; ++b) e->flag_arm_body[b] = 0;
@@ -1531,6 +1739,22 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   /* PushEnv._reset_scene / _load_movable_bodies (push_env.py:331-471) */
   int nb = c->n_bodies_min + rng_randint(&g, c->n_bodies_max - c->n_bodies_min + 1);
   e->n_bodies = nb;
+  if (c->env_type == RV_ENV_GRASP) {
+    /* Grasp4DofEnv._reset_scene (grasp_4dof_env.py:166-198) */
+    real poses[RV_MAXB][7];
+    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; }
+    e->n_bodies = 1;
+    sample_poses(w, e, &g, 1, poses);
+    int shape = c->movable_shapes[rng_randint(&g, c->n_movable_shapes)];
+    real scale = rng_uniform(&g, (real)c->scale_range[0], (real)c->scale_range[1]);
+    real mass = rng_uniform(&g, (real)c->mass_range[0], (real)c->mass_range[1]);
+    real fr = rng_uniform(&g, (real)c->friction_range[0], (real)c->friction_range[1]);
+    orc_bparam* p = &e->bp[0];
+    p->active = 1; p->shape = shape; p->scale = scale; p->friction = fr;
+    body_set_mass(w, e, 0, mass);
+    v3cpy(e->body[0].p, poses[0]); memcpy(e->body[0].q, poses[0] + 3, sizeof(real) * 4);
+    v3set(e->body[0].v, R(0.0), R(0.0), R(0.0)); v3set(e->body[0].w, R(0.0), R(0.0), R(0.0));
+  } else
   for (;;) {
     real poses[RV_MAXB][7];
     for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; }
@@ -1571,6 +1795,12 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   real off[RV_NLIMB];
   for (int j = 0; j < RV_NLIMB; ++j) off[j] = (real)c->offstage_positions[j];
   robot_move_to_joint_positions(w, e, off);
+  if (c->env_type == RV_ENV_GRASP) {
+    /* Grasp4DofEnv._reset_robot (grasp_4dof_env.py:206-211): robot.reset(OFFSTAGE) = move, then grip(0)
+     * whose finger target replaces the limb target (one JointTarget per body) */
+    robot_move_to_joint_positions(w, e, off);
+    robot_grip(w, e, R(0.0));
+  }
   e->has_prev = 0;
   compute_obs(e);
   memcpy(e->prev_obs_pos, e->obs_pos, sizeof(e->obs_pos));
@@ -1585,6 +1815,7 @@ orc_world* orc_create(const rv_config* cfg, const rv_scene* scene) {
     for (int b = 0; b < RV_MAXB; ++b) w->env[i].body[b].q[3] = R(1.0);
     for (int f = 0; f < RV_NFRAME; ++f) w->env[i].fquat[f][3] = R(1.0);
     w->env[i].done = 1; /* RobotEnv.__init__: self._done = True (robot_env.py:66) */
+    w->env[i].mu_finger = (real)cfg->arm_friction; w->env[i].mu_table = (real)cfg->table_friction;
   }
   return w;
 }
@@ -1625,7 +1856,7 @@ void orc_step_macro(orc_world* w) {
     orc_env* e = &w->env[i];
     e->substeps_last = 0; e->awake_last = 0; e->pairs_last = 0;
     if (e->done) continue;
-    env_step(w, e);
+    step_env(w, e);
   }
   for (int i = 0; i < w->n; ++i) {
     const orc_env* e = &w->env[i];
@@ -1640,7 +1871,6 @@ void orc_rollout(orc_world* w, int n_steps, int first_index, int auto_reset) { r
 void orc_rollout_counts(orc_world* w, const int32_t* counts, int first_index) { rollout_impl(w, 0, counts, first_index, 1); }
 static void rollout_impl(orc_world* w, int n_steps_all, const int32_t* counts, int first_index, int auto_reset) {
   stats_begin(w);
-  int G = w->cfg.num_goal_steps > 0 ? w->cfg.num_goal_steps : 1;
   int* stepped = (int*)calloc((size_t)w->n, sizeof(int));
   int* succ = (int*)calloc((size_t)w->n, sizeof(int));
 #pragma omp parallel for schedule(dynamic)
@@ -1656,9 +1886,8 @@ static void rollout_impl(orc_world* w, int n_steps_all, const int32_t* counts, i
         env_reset(w, e, gid);
         sub += e->substeps_last; aw += e->awake_last; pr += e->pairs_last;
       }
-      orc_rng g; rng_init(&g, w->cfg.seed_lo, w->cfg.seed_hi, (uint32_t)gid, STREAM_RANDOM, (uint32_t)(first_index + k));
-      for (int x = 0; x < G * 4; ++x) e->action[x >> 2][x & 3] = rng_uniform(&g, R(-1.0), R(1.0));
-      env_step(w, e);
+      random_action(&w->cfg, gid, first_index + k, &e->action[0][0]);
+      step_env(w, e);
       sub += e->substeps_last; aw += e->awake_last; pr += e->pairs_last;
       stepped[i]++;
       if (e->done && e->last_reward >= (real)w->cfg.success_thresh) succ[i]++;
@@ -1692,8 +1921,9 @@ void orc_wait_until_stable(orc_world* w, float lin, float ang, int check_after, 
 void orc_policy_random(orc_world* w, int macro_index, float* actions) {
   int G = w->cfg.num_goal_steps > 0 ? w->cfg.num_goal_steps : 1;
   for (int i = 0; i < w->n; ++i) {
-    orc_rng g; rng_init(&g, w->cfg.seed_lo, w->cfg.seed_hi, (uint32_t)(w->cfg.env_id_offset + i), STREAM_RANDOM, (uint32_t)macro_index);
-    for (int k = 0; k < G * 4; ++k) actions[i * G * 4 + k] = (float)rng_uniform(&g, R(-1.0), R(1.0));
+    real a[RV_MAXG * 4];
+    random_action(&w->cfg, w->cfg.env_id_offset + i, macro_index, a);
+    for (int k = 0; k < G * 4; ++k) actions[i * G * 4 + k] = (float)a[k];
   }
 }
 
@@ -1866,17 +2096,19 @@ void orc_compute_ik_seeded(orc_world* w, const double* seed, const double* pose,
   arm_ik(w, sd, p, out);
   for (int j = 0; j < RV_NLIMB; ++j) q[j] = out[j];
 }
-/* SawyerSim.move_along_gripper_path -> set_target_link_poses (controllable_body.py:319-345) */
 void orc_set_link_path(orc_world* w, int n_poses, const float* poses) {
   for (int i = 0; i < w->n; ++i) {
-    orc_env* e = &w->env[i];
-    real p0[7];
-    for (int k = 0; k < 7; ++k) p0[k] = (real)poses[k];
-    robot_move_to_gripper_pose(w, e, p0);
-    e->lt.has_pose = 0; e->lt.nq = n_poses;
-    for (int q = 0; q < n_poses; ++q)
-      for (int k = 0; k < 7; ++k) e->lt.queue[q][k] = (real)poses[q * 7 + k];
-    lt_pop(&e->lt);
+    real wps[RV_MAXQ][7];
+    for (int q = 0; q < n_poses; ++q) for (int k = 0; k < 7; ++k) wps[q][k] = (real)poses[q * 7 + k];
+    robot_move_along_gripper_path(w, &w->env[i], wps, n_poses);
+  }
+}
+/* Link.set_dynamics / Body.set_dynamics lateral friction of the finger tips and the table
+ * (grasp_4dof_env.py:262-293); negative = leave unchanged */
+void orc_set_friction(orc_world* w, double mu_finger, double mu_table) {
+  for (int i = 0; i < w->n; ++i) {
+    if (mu_finger >= 0.0) w->env[i].mu_finger = (real)mu_finger;
+    if (mu_table >= 0.0) w->env[i].mu_table = (real)mu_table;
   }
 }
 /* move_to_gripper_pose(..., timeout=t): LinkTarget.set stop_time = start_time + timeout */

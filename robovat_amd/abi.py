@@ -28,6 +28,8 @@ RV_TASK_NONE, RV_TASK_CLEARING, RV_TASK_INSERTION, RV_TASK_CROSSING = 0, 1, 2, 3
 TASK_IDS = {None: 0, 'data_collection': 0, 'clearing': 1, 'insertion': 2,
             'crossing': 3}
 PHASES = ['initial', 'pre', 'start', 'motion', 'post', 'offstage', 'done']
+GRASP_PHASES = ['initial', 'overhead', 'prestart', 'start', 'end', 'postend', 'done']
+RV_ENV_PUSH, RV_ENV_GRASP = 0, 1
 
 f32, i32, u32, i64 = C.c_float, C.c_int32, C.c_uint32, C.c_int64
 
@@ -126,6 +128,12 @@ class rv_config(C.Structure):
         ('cam_near', f32),
         ('use_crop', i32),
         ('crop_min', f32 * 3), ('crop_max', f32 * 3),
+        ('env_type', i32), ('finger_dynamics', i32),
+        ('finger_mass', f32), ('finger_max_force', f32),
+        ('grasp_cuboid_low', f32 * 3), ('grasp_cuboid_high', f32 * 3),
+        ('overhead_positions', f32 * RV_NLIMB),
+        ('max_action_steps', i32), ('end_effector_step', f32),
+        ('grasp_mu_descend', f32 * 2), ('grasp_mu_lift', f32 * 2),
     ]
 
 

@@ -124,6 +124,36 @@ PUSH_ENV_CONFIG = {
     },
 }
 
+def _grasp_env_config():
+    """Grasp4DofEnv (configs/envs/grasp_4dof_env.yaml is not distributed; keys from
+    grasp_4dof_env.py:63-345; values BUILD-CHOSEN)."""
+    cfg = copy.deepcopy(PUSH_ENV_CONFIG)
+    cfg['ENV_NAME'] = 'Grasp4DofEnv'
+    cfg['MAX_STEPS'] = 1
+    cfg['ACTION'] = {'TYPE': 'CUBOID',
+                     # grasp centre x, y, fingertip height z (world frame); the angle is U[0, 2 pi)
+                     'CUBOID': {'LOW': [0.56, -0.04, 0.012], 'HIGH': [0.64, 0.04, 0.012]},
+                     'CSPACE': PUSH_ENV_CONFIG['ACTION']['CSPACE'], 'MOTION': PUSH_ENV_CONFIG['ACTION']['MOTION'],
+                     'MIN_DELTA_POSITION': 0.01, 'MIN_DELTA_ANGLE': 0.05}
+    cfg['ARM']['OVERHEAD_POSITIONS'] = [0.0, -1.18, 0.0, 2.18, 0.0, 0.57, 3.3161]
+    cfg['ARM']['GRIPPER_SAFE_HEIGHT'] = 0.30
+    cfg['SIM']['MAX_ACTION_STEPS'] = 4000
+    cfg['SIM']['GRASPABLE'] = {
+        'PATHS': ['grasp_cube', 'grasp_bar', 'grasp_cyl'],
+        'POSE': {'X': [0.58, 0.62], 'Y': [-0.02, 0.02], 'Z': [0.04, 0.04],
+                 'ROLL': [0.0, 0.0], 'PITCH': [0.0, 0.0], 'YAW': [-math.pi, math.pi]},
+        'SCALE': [0.9, 1.1], 'MASS': [0.05, 0.2], 'FRICTION': [0.5, 1.0],
+        'RESAMPLE_N_EPISODES': 1, 'USE_RANDOM_SAMPLE': True,
+        # lateral friction the env gives (finger tips, table) while it descends / lifts
+        # (grasp_4dof_env.py:262-270, 282-293)
+        'FRICTION_DESCEND': [0.001, 100.0], 'FRICTION_LIFT': [100.0, 1.0],
+    }
+    cfg['MIN_MOVABLE_BODIES'] = cfg['MAX_MOVABLE_BODIES'] = 1
+    cfg['OBSERVATION'] = {'TYPE': 'depth'}
+    cfg['PHYSICS'].update({'FINGER_DYNAMICS': True, 'FINGER_MASS': 0.1, 'FINGER_MAX_FORCE': 20.0})
+    return cfg
+
+
 SAWYER_SIM_CONFIG = {
     'LIMB_JOINT_NAMES': ['right_j%d' % i for i in range(7)],
     'LIMB_NEUTRAL_POSITIONS': [0.0, -1.18, 0.0, 2.18, 0.0, 0.57, 3.3161],
@@ -149,6 +179,17 @@ HEURISTIC_PUSH_POLICY_CONFIG = {
 
 def push_env_config(**overrides):
     cfg = AttrDict(copy.deepcopy(PUSH_ENV_CONFIG))
+    for k, v in overrides.items():
+        node = cfg
+        parts = k.split('.')
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = AttrDict(v) if isinstance(v, dict) else v
+    return cfg
+
+
+def grasp_env_config(**overrides):
+    cfg = AttrDict(_grasp_env_config())
     for k, v in overrides.items():
         node = cfg
         parts = k.split('.')
@@ -202,7 +243,24 @@ def make_rv_config(env_cfg=None, robot_cfg=None, shape_names=None, n_envs=1,
     c.n_bodies_min = env_cfg.MIN_MOVABLE_BODIES
     c.n_bodies_max = env_cfg.MAX_MOVABLE_BODIES
     assert 1 <= c.n_bodies_min <= c.n_bodies_max <= abi.RV_MAXB
-    mv = env_cfg.MOVABLE[env_cfg.MOVABLE_NAME.upper()]
+    grasp = env_cfg.get('ENV_NAME') == 'Grasp4DofEnv'
+    if grasp:
+        gr = env_cfg.SIM.GRASPABLE
+        mv = AttrDict({'SCALE': gr.SCALE, 'MASS': gr.MASS, 'FRICTION': gr.FRICTION, 'MARGIN': 0.0, 'POSE': gr.POSE,
+                       'PATHS': gr.PATHS, 'TARGET_PATHS': gr.PATHS})
+        c.env_type = abi.RV_ENV_GRASP
+        abi.assign(c.grasp_cuboid_low, env_cfg.ACTION.CUBOID.LOW)
+        abi.assign(c.grasp_cuboid_high, env_cfg.ACTION.CUBOID.HIGH)
+        abi.assign(c.overhead_positions, env_cfg.ARM.OVERHEAD_POSITIONS)
+        c.max_action_steps = int(env_cfg.SIM.MAX_ACTION_STEPS)
+        abi.assign(c.grasp_mu_descend, gr.FRICTION_DESCEND)
+        abi.assign(c.grasp_mu_lift, gr.FRICTION_LIFT)
+    else:
+        mv = env_cfg.MOVABLE[env_cfg.MOVABLE_NAME.upper()]
+    c.finger_dynamics = int(bool(ph.get('FINGER_DYNAMICS', False)))
+    c.finger_mass = float(ph.get('FINGER_MASS', 0.1))
+    c.finger_max_force = float(ph.get('FINGER_MAX_FORCE', 20.0))
+    c.end_effector_step = robot_cfg.END_EFFECTOR_STEP
     abi.assign(c.scale_range, _rng(mv.SCALE))
     abi.assign(c.mass_range, _rng(mv.MASS))
     abi.assign(c.friction_range, _rng(mv.FRICTION))

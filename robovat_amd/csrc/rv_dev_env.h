@@ -116,6 +116,10 @@ struct DevEnv {
   int obs_num_steps, obs_num_episodes;
   // per-launch sums for rv_get_stats (a rollout launch takes several steps per env)
   int l_unsafe, l_ineffective, l_useful, l_episodes, l_successes;
+  // lateral friction of the finger tips / the table (Link.set_dynamics, grasp_4dof_env.py:262-293);
+  // PushEnv leaves them at PHYSICS.ARM_FRICTION / SIM.TABLE.FRICTION
+  float mu_finger, mu_table;
+  int num_action_steps;       // Grasp4DofEnv: substeps spent in the 'start' phase
 #ifdef RV_PROFILE
   unsigned long long prof[24], prof_t, prof_t2[4];   // tools/prof_rollout.py: shader-clock time per substep part
 #endif
@@ -127,6 +131,9 @@ struct Row {
   float dir[3][3], rxa[3][3], rxb[3][3], aa[3][3], ab[3][3];
   float invk[3], vbc[3];
   float target, mu;
+  // dynamic finger (rv_config.finger_dynamics): the row also acts on finger joint 7 + fidx with
+  // Jacobian jf = -(dir . slide axis); fidx = -1: no finger involved
+  float jf[3]; int fidx;
 };
 
 struct Scratch {
@@ -147,6 +154,7 @@ struct Scratch {
   } u;
   // macro-step locals that must survive across phases
   float wp[RV_MAXG][2][7];
+  float gstart[7];                       // Grasp4DofEnv: the grasp pose of this step
   float start_pos[RV_MAXB][3], start_yaw[RV_MAXB];
   float poses[RV_MAXB][7];
   int num_waypoints, interrupt, has_budget, max_phase_steps;
@@ -157,6 +165,7 @@ struct Scratch {
   float sync;
   float lq[RV_NLIMB][4];
   float vdraw[RV_NJ], ratio[RV_NJ];      // motor phase: raw commanded velocity, limit factor
+  float fing_dv[2], fing_vt[2], fing_qd0[2];   // finger motors this substep: velocity step taken, commanded velocity, velocity after it
   int jmoving[RV_NJ], jchg[RV_NJ];
   float rvec[RV_NLIMB + 1][3];           // FK: link offsets rotated into the world
   int jt_applied;                        // the motor targets hold the current joint target (per launch)
@@ -733,6 +742,9 @@ RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, 
     int f = K.arm->col_frame[p.col];
     vb_pt = add(ld3(S.s.fv[f]), cross(ld3(S.s.fw[f]), sub(wb, ld3(e.fpos[f]))));
   }
+  // a point on a finger pad of the force-limited gripper: the finger joint is a solver DOF
+  const int fing = c->finger_dynamics && kind == 2 && p.col >= 8;
+  const v3 fy = mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]);   // slide axis = hand y
   float ima = e.inv_mass[a];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -746,14 +758,18 @@ RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, 
       ab = mulv(iib, rxb);
       kk += imb + dot(rxb, ab);
     }
+    float jf = 0.0f;
+    if (fing) { jf = -dot(dk, fy); kk += jf * jf / c->finger_mass; }
     st3(r.dir[k], dk); st3(r.rxa[k], rxa); st3(r.aa[k], aa); st3(r.rxb[k], rxb); st3(r.ab[k], ab);
     r.invk[k] = 1.0f / kk;
     r.vbc[k] = dot(dk, vb_pt);
+    r.jf[k] = jf;
   }
+  r.fidx = fing ? p.col - 8 : -1;
   float dist = p.dist;
   if (dist > 0.0f) r.target = -dist / dt;
   else r.target = fminr(c->erp * fmaxr(-dist - c->slop, 0.0f) / dt, c->max_pushout);
-  float mub = (kind == 0) ? c->table_friction : (kind == 1 ? e.friction[b] : c->arm_friction);
+  float mub = (kind == 0) ? e.mu_table : (kind == 1 ? e.friction[b] : (p.col >= 8 ? e.mu_finger : c->arm_friction));
   r.mu = e.friction[a] * mub;
 }
 
@@ -801,6 +817,104 @@ RV_DEV float point_solve(BV& A, BV* B, float ima, float imb, Lam& l, const Row& 
 }
 RV_DEV void warm_apply(BV& A, BV* B, float ima, float imb, const Lam& l, const Row& r) {
   row_apply(A, B, ima, imb, r, 0, l.n); row_apply(A, B, ima, imb, r, 1, l.t1); row_apply(A, B, ima, imb, r, 2, l.t2);
+}
+
+// ---- PGS with the force-limited gripper (rv_config.finger_dynamics; Grasp4DofEnv) ----------
+// The two finger joints are dynamic 1-DoF bodies of mass finger_mass sliding along the hand's
+// y axis: contact rows on a finger pad (collider boxes 8 / 9) carry the Jacobian entry
+// jf = -(dir . y) on the finger velocity, and each finger has a POSITION_CONTROL motor row
+// (bullet_physics.py:1061-1104) that pulls its velocity to the commanded one with at most
+// finger_max_force: the joint motors of the light part have already spent m * fing_dv of that
+// budget on the free motion, the row may add the rest.  Velocity-space Gauss-Seidel over ALL
+// awake bodies and both fingers as one system, one lane (a grasp scene has one body).
+RV_DEV float point_solve_g(BV& A, float ima, Lam& l, const Row& r, float* qf, float imf) {
+  const int fi = r.fidx;
+  float jv = row_jv(A, nullptr, r, 0);
+  if (fi >= 0) jv += r.jf[0] * qf[fi];
+  float dl = (r.target - jv) * r.invk[0];
+  float ln = fmaxr(l.n + dl, 0.0f);
+  dl = ln - l.n; l.n = ln;
+  float res = fabsr(dl);
+  row_apply(A, nullptr, ima, 0.0f, r, 0, dl);
+  if (fi >= 0) qf[fi] += r.jf[0] * dl * imf;
+  float lim = r.mu * ln;
+  jv = row_jv(A, nullptr, r, 1);
+  if (fi >= 0) jv += r.jf[1] * qf[fi];
+  dl = -jv * r.invk[1];
+  float l1 = fclampr(l.t1 + dl, -lim, lim);
+  dl = l1 - l.t1; l.t1 = l1;
+  res = fmaxr(res, fabsr(dl));
+  row_apply(A, nullptr, ima, 0.0f, r, 1, dl);
+  if (fi >= 0) qf[fi] += r.jf[1] * dl * imf;
+  jv = row_jv(A, nullptr, r, 2);
+  if (fi >= 0) jv += r.jf[2] * qf[fi];
+  dl = -jv * r.invk[2];
+  float l2 = fclampr(l.t2 + dl, -lim, lim);
+  dl = l2 - l.t2; l.t2 = l2;
+  res = fmaxr(res, fabsr(dl));
+  row_apply(A, nullptr, ima, 0.0f, r, 2, dl);
+  if (fi >= 0) qf[fi] += r.jf[2] * dl * imf;
+  return res;
+}
+RV_DEV void solve_with_fingers(Shared& S, const Consts& K) {
+  DevEnv& e = S.e; const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
+  const float mf = c->finger_mass, imf = 1.0f / c->finger_mass, fdt = c->finger_max_force * c->dt;
+  float qf[2] = {e.qd[RV_NLIMB], e.qd[RV_NLIMB + 1]}, lam_m[2] = {0.0f, 0.0f};
+  for (int it = -1; it < c->solver_iters; ++it) {   // it == -1: warm start
+    float res = 0.0f;
+    for (int b = 0; b < RV_MAXB; ++b) {
+      if (!body_on(e, b)) continue;
+      BV A = ld_bv(e, b); const float ima = e.inv_mass[b];
+      for (int kind = 0; kind < 2; ++kind) {
+        const int mi = kind == 0 ? RV_TIDX(b) : RV_AIDX(b);
+        DevMan& m = e.man[mi];
+        for (int i = 0; i < m.n; ++i) {
+          Row r = S.s.u.r.rows[mi][i];
+          Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
+          if (it < 0) {
+            warm_apply(A, nullptr, ima, 0.0f, l, r);
+            if (r.fidx >= 0) { qf[r.fidx] += r.jf[0] * l.n * imf; qf[r.fidx] += r.jf[1] * l.t1 * imf; qf[r.fidx] += r.jf[2] * l.t2 * imf; }
+          } else { res = fmaxr(res, point_solve_g(A, ima, l, r, qf, imf)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
+        }
+      }
+      st_bv(e, b, A);
+    }
+    for (int rd = 0; rd < 3; ++rd)
+      for (int x = 0; x < 2; ++x) {
+        const int k = bb_round_pair(rd, x);
+        const int a_ = bb_a(k), b_ = bb_b(k);
+        if (!(body_on(e, a_) && body_on(e, b_))) continue;
+        DevMan& m = e.man[RV_BBIDX(k)];
+        if (m.n == 0) continue;
+        BV A = ld_bv(e, a_), B = ld_bv(e, b_);
+        const float ima = e.inv_mass[a_], imb = e.inv_mass[b_];
+        for (int i = 0; i < m.n; ++i) {
+          Row r = S.s.u.r.rows[RV_BBIDX(k)][i];
+          Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
+          if (it < 0) warm_apply(A, &B, ima, imb, l, r);
+          else { res = fmaxr(res, point_solve(A, &B, ima, imb, l, r)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
+        }
+        st_bv(e, a_, A); st_bv(e, b_, B);
+      }
+    if (it < 0) continue;
+    for (int f = 0; f < 2; ++f) {      // motor rows
+      const float i0 = mf * S.s.fing_dv[f];
+      float dl = (S.s.fing_vt[f] - qf[f]) * mf;
+      const float ln = fclampr(lam_m[f] + dl, -fdt - i0, fdt - i0);
+      dl = ln - lam_m[f]; lam_m[f] = ln;
+      qf[f] += dl * imf;
+      res = fmaxr(res, fabsr(dl));
+    }
+    if (res < c->solver_tol) break;
+  }
+  for (int f = 0; f < 2; ++f) {        // the fingers move with the solved velocity
+    const int j = RV_NLIMB + f;
+    float qd = qf[f];
+    float qn = e.q[j] + (qd - S.s.fing_qd0[f]) * c->dt;
+    if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
+    if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
+    e.q[j] = qn; e.qd[j] = qd;
+  }
 }
 
 // ---- PGS in impulse space, one lane per solver row -------------------------------------
@@ -1103,6 +1217,7 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
       float qn = e.q[j] + qd * dt;
       if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
       if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
+      if (j >= RV_NLIMB) { S.s.fing_dv[j - RV_NLIMB] = dv; S.s.fing_vt[j - RV_NLIMB] = vd; S.s.fing_qd0[j - RV_NLIMB] = qd; }
       if (with_lq) S.s.jchg[j] = (qn != e.q[j]) || (qd != 0.0f);   // did the joint state change at all?
       e.q[j] = qn; e.qd[j] = qd;
       if (with_lq) {
@@ -1654,9 +1769,11 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         fw = add(fw, u);
         fv = add(fv, cross(u, sub(pf, ld3(e.fpos[k]))));
       }
-      if (f >= 8) fv = madd(fv, mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]), e.qd[f - 1]);
+      // the slide of a finger along the hand's y axis (a solver DOF of its own in finger_dynamics mode)
+      if (f >= 8 && !c->finger_dynamics) fv = madd(fv, mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]), e.qd[f - 1]);
       st3(S.s.fv[f], fv); st3(S.s.fw[f], fw);
       S.s.fmot[f] = (len(fv) + len(fw) * S.s.fext[f]) * c->dt;
+      if (f >= 8 && c->finger_dynamics) S.s.fmot[f] += fabsr(e.qd[f - 1]) * c->dt;
     }
 #ifdef RV_DIAG_AWAKE_BODIES   // diagnostic build (tools/diag_lockstep.py): count awake BODIES per substep
     if (lane == 63) { int nb_ = 0; for (int b = 0; b < RV_MAXB; ++b) nb_ += body_on(S.e, b); S.e.awake_last += nb_ * 65536 + S.s.any_on; }
@@ -1853,10 +1970,16 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     mem_[b] = (on_[b] && label[b] == b) ? m_ : 0;
     big_[b] = mem_[b] > 2;
   }
+  const int with_fingers = c->finger_dynamics && arm_on;
+  if (with_fingers) {
+    RV_LANES_BEGIN
+      if (lane == 0) solve_with_fingers(S, K);
+    RV_LANES_END
+  }
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
 #pragma unroll
   for (int b = 0; b < RV_MAXB; ++b) {
-    const int m_ = __builtin_amdgcn_readfirstlane(mem_[b]);
+    const int m_ = with_fingers ? 0 : __builtin_amdgcn_readfirstlane(mem_[b]);
     if (m_ == 1) solve_island2(S, K, b, -1, 0);
     else if (m_ == 2) {
       int y_ = -1;
@@ -1871,13 +1994,13 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   }
 #else
   RV_LANES_BEGIN
-    if (lane == 0) S.s.n_rows = solver_row_list(S, label, on_, act_, big_);
+    if (lane == 0) S.s.n_rows = with_fingers ? 0 : solver_row_list(S, label, on_, act_, big_);
   RV_LANES_END
   if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows);
 #endif
   // islands of three or four bodies: velocity-space Gauss-Seidel, one lane per island
   RV_LANES_BEGIN
-    if (lane < RV_MAXB && big_[lane]) {
+    if (!with_fingers && lane < RV_MAXB && big_[lane]) {
       const int root = lane; DevEnv& e = S.e;
       {
         for (int it = -1; it < c->solver_iters; ++it) {   // it == -1: warm start
@@ -1961,7 +2084,9 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
           // a sleeper that was woken but never left the pose it was resting in goes back
           // to sleep after a quarter of the usual wait
           const int quick = e.undisturbed[b] && 4 * e.still_count[b] >= c->sleep_steps && 4 * e.sleep_count[b] >= c->sleep_steps;
-          if (e.sleep_count[b] >= c->sleep_steps || e.still_count[b] >= c->sleep_steps || quick) {
+          // a body the force-limited gripper holds stays active (its island contains the moving fingers)
+          const int held = c->finger_dynamics && e.man[RV_AIDX(b)].n > 0;
+          if (!held && (e.sleep_count[b] >= c->sleep_steps || e.still_count[b] >= c->sleep_steps || quick)) {
             e.asleep[b] = 1;
             st3(e.body[b] + 7, mk(0, 0, 0)); st3(e.body[b] + 10, mk(0, 0, 0));
             // world box of the resting hulls: what the arm has to come near to wake the body
@@ -2030,6 +2155,7 @@ RV_DEV unsigned active_mask(const DevEnv& e) {
   return m;
 }
 RV_DEV void phase_tick(Shared& S, const Consts& K);
+RV_DEV void gphase_tick(Shared& S, const Consts& K);
 // Runs substeps inside ONE out-of-line function, so that the call overhead
 // (callee-saved registers: ~140 VGPRs saved and restored per call) is paid per call
 // and not per substep, and the light part exists once in the instruction stream.
@@ -2043,11 +2169,14 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
   Consts K = lds_consts(scene, stop_after);
   Shared& S = g_shared;
   int phase_mode = n_arg < 0;
+  const int grasp_mode = n_arg == -2;     // Grasp4DofEnv: its phase machine looks at the world after EVERY substep
   for (;;) {                  // one pass, except in phase mode
   int n_fixed = n_arg;
   if (phase_mode) {
-    if (S.e.phase == RV_PHASE_DONE) { phase_mode = 0; n_fixed = 0; }   // -> closing wait_until_stable
-    else n_fixed = K.cfg->steps_check - (S.e.sim_steps % K.cfg->steps_check);
+    if (S.e.phase == RV_PHASE_DONE) {
+      if (grasp_mode) break;              // (the reward's wait_until_stable comes after the observation)
+      phase_mode = 0; n_fixed = 0;        // -> closing wait_until_stable
+    } else n_fixed = grasp_mode ? 1 : K.cfg->steps_check - (S.e.sim_steps % K.cfg->steps_check);
   }
   if (n_fixed == 0) {
     RV_LANES_BEGIN
@@ -2138,7 +2267,7 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
       (S.e.phase == RV_PHASE_START || S.e.phase == RV_PHASE_MOTION || S.s.interrupt)) arm_refresh_kinematics(S, K);
   RV_PROF(8)
   RV_LANES_BEGIN
-    if (lane == 0) phase_tick(S, K);
+    if (lane == 0) { if (grasp_mode) gphase_tick(S, K); else phase_tick(S, K); }
   RV_LANES_END
   RV_PROF(9)
   }
@@ -2418,6 +2547,112 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
   RV_LANES_END
 }
 
+// ------------------------------------------------------------- Grasp4DofEnv --
+// SawyerSim.move_along_gripper_path -> set_target_link_poses (sawyer_sim.py:310-360,
+// controllable_body.py:319-345): the poses are reached one after the other
+RV_DEV void robot_move_along_gripper_path(Shared& S, const Consts& K, const float (*poses)[7], int n) {
+  DevEnv& e = S.e; const rv_config* c = K.cfg;
+  arm_reset_targets(e);
+  for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = c->limb_max_velocity_ratio * K.arm->v_max[j];
+  LTarget& t = e.lt;
+  t.active = 1; t.has_pose = 0; t.nq = n;
+  for (int q = 0; q < n; ++q) for (int k = 0; k < 7; ++k) t.queue[q][k] = poses[q][k];
+  t.start_t = sim_time(S, K); t.stop_t = t.start_t + c->limb_timeout; t.has_stop = 1;
+  t.pos_thr = c->limb_position_threshold; t.vel_thr = c->velocity_threshold;
+  lt_pop(t);
+}
+// SawyerSim.move_to_gripper_pose(pose, straight_line=True) (sawyer_sim.py:259-276): way points
+// every END_EFFECTOR_STEP along the segment from the current end-effector position, all with
+// the orientation of the target
+RV_DEV void robot_move_straight(Shared& S, const Consts& K, const float* pose) {
+  DevEnv& e = S.e; const rv_config* c = K.cfg;
+  v3 p0 = ld3(e.fpos[7]), d = sub(ld3(pose), p0);
+  int num = (int)(len(d) / c->end_effector_step);
+  if (num > RV_MAXQ - 1) num = RV_MAXQ - 1;
+  float wps[RV_MAXQ][7];
+  for (int i = 0; i < num; ++i) {
+    float sc = (float)i / (float)num;
+    st3(wps[i], madd(p0, d, sc));
+    for (int k = 3; k < 7; ++k) wps[i][k] = pose[k];
+  }
+  for (int k = 0; k < 7; ++k) wps[num][k] = pose[k];
+  robot_move_along_gripper_path(S, K, wps, num + 1);
+}
+// one pass of the loop of Grasp4DofEnv._execute_action (grasp_4dof_env.py:234-293) after
+// simulator.step(): _is_phase_ready (:322-345), _get_next_phase (:295-320) and the commands
+// of the phase that starts; lane 0
+RV_DEV void gphase_tick(Shared& S, const Consts& K) {
+  DevEnv& e = S.e; Scratch& s = S.s; const rv_config* c = K.cfg;
+  if (e.phase == RV_GPHASE_START) e.num_action_steps++;
+  int ready = 0;
+  if (e.phase == RV_GPHASE_START && e.num_action_steps >= c->max_action_steps) ready = 1;     // the grasping motion is stuck
+  else if ((e.phase == RV_GPHASE_START || e.phase == RV_GPHASE_END) && e.flag_arm_table) ready = 1;   // the gripper contacts the table
+  else if (arm_is_ready_limb(S, K) && sim_time(S, K) >= e.gripper_ready_time) ready = 1;
+  if (!ready) return;
+  e.phase = e.phase + 1;
+  if (e.phase == RV_GPHASE_OVERHEAD) {
+    float q[RV_NLIMB];
+    for (int j = 0; j < RV_NLIMB; ++j) q[j] = c->overhead_positions[j];
+    robot_move_to_joint_positions(S, K, q);
+  } else if (e.phase == RV_GPHASE_PRESTART) {
+    float pose[7];
+    for (int k = 0; k < 7; ++k) pose[k] = s.gstart[k];
+    pose[2] = c->gripper_safe_height;
+    robot_move_to_gripper_pose(S, K, pose);
+  } else if (e.phase == RV_GPHASE_START) {
+    robot_move_straight(S, K, s.gstart);
+    e.mu_finger = c->grasp_mu_descend[0]; e.mu_table = c->grasp_mu_descend[1];   // "prevent problems caused by unrealistic frictions"
+  } else if (e.phase == RV_GPHASE_END) {
+    robot_grip(S, K, 1.0f);
+  } else if (e.phase == RV_GPHASE_POSTEND) {
+    float pose[7];
+    for (int k = 0; k < 3; ++k) pose[k] = e.fpos[7][k];
+    for (int k = 0; k < 4; ++k) pose[3 + k] = e.fquat[7][k];
+    pose[2] = c->gripper_safe_height;
+    robot_move_straight(S, K, pose);
+    e.mu_finger = c->grasp_mu_lift[0]; e.mu_table = c->grasp_mu_lift[1];
+  }
+}
+// RobotEnv.step (robot_env.py:239-275) for Grasp4DofEnv: _execute_action (grasp_4dof_env.py:213-293),
+// observation, GraspReward.get_reward (grasp_reward.py:49-68: wait until the object is stable, success =
+// the arm still touches it; the episode ends after one grasp)
+RV_DEV void genv_step(Shared& S, const Consts& K, int zero_counters = 1) {
+  const rv_config* c = K.cfg;
+  RV_LANES_BEGIN
+    if (lane == 0) {
+      DevEnv& e = S.e; Scratch& s = S.s;
+      if (zero_counters) { e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; }
+      e.stepped += 1;
+      e.obs_num_steps = e.num_steps; e.obs_num_episodes = e.num_episodes;
+      // start = Pose([[x, y, z + FINGER_TIP_OFFSET], [0, pi, angle]])
+      s.gstart[0] = e.action[0][0]; s.gstart[1] = e.action[0][1]; s.gstart[2] = e.action[0][2] + c->finger_tip_offset;
+      stq(s.gstart + 3, euler_to_quat(0.0f, RV_PI, e.action[0][3]));
+      e.is_safe = 1; e.is_effective = 1;
+      e.phase = RV_GPHASE_INITIAL; e.num_action_steps = 0;
+    }
+  RV_LANES_END
+  sim_run_call(K.scene, K.stop_after, -2, 0u, 0.0f, 0.0f, 0, 0, 0);
+  RV_LANES_BEGIN
+    if (lane == 0) { S.e.num_steps++; compute_obs(S.e); }
+  RV_LANES_END
+  wait_until_stable(S, K, 0u, 0.005f, 0.005f, 100, 100, 2000);
+  RV_LANES_BEGIN
+    if (lane == 0) {
+      DevEnv& e = S.e;
+      const int success = arm_touches_movables(e);
+      const float r = success ? 1.0f : 0.0f;
+      e.is_effective = success;
+      e.num_total_steps++;
+      e.num_useful += success; e.l_useful += success;
+      e.num_ineffective += !success; e.l_ineffective += !success;
+      e.last_reward = r; e.episode_reward += r;
+      e.done = 1;                         // terminate_after_grasp
+      e.num_episodes++; e.l_episodes++;
+      if (success) { e.num_successes++; e.l_successes++; }
+    }
+  RV_LANES_END
+}
+
 // --------------------------------------------------------------- reset ---
 // rejection sampling of one layout (push_env.py:473-597, intent version), lane 0
 RV_DEV void sample_poses(Shared& S, const Consts& K, int nb) {
@@ -2480,6 +2715,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
       e.sim_steps = 0; e.num_steps = 0; e.obs_num_steps = 0; e.obs_num_episodes = e.num_episodes; e.episode_reward = 0.0f; e.last_reward = 0.0f;
       e.done = 0; e.phase = RV_PHASE_INITIAL; e.is_safe = 1; e.is_effective = 1;
       e.arm_enabled = 0;
+      e.mu_finger = c->arm_friction; e.mu_table = c->table_friction; e.num_action_steps = 0;
       e.flag_arm_table = 0;
       for (int b = 0; b < RV_MAXB; ++b) e.flag_arm_body[b] = 0;
       // ArmEnv._reset_scene (arm_env.py:78-99)
@@ -2492,6 +2728,29 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
   RV_LANES_BEGIN
     if (lane < 8) table_prepare(S, K, lane);
   RV_LANES_END
+  if (c->env_type == RV_ENV_GRASP) {
+    // Grasp4DofEnv._reset_scene (grasp_4dof_env.py:166-198): one graspable object at
+    // Pose.uniform(SIM.GRASPABLE.POSE) with a uniform scale, then wait_until_stable(graspable)
+    RV_LANES_BEGIN
+      DevEnv& e = S.e;
+      if (lane == 0) {
+        Rng& g = S.s.rng;
+        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; }
+        e.n_bodies = 1;
+        sample_poses(S, K, 1);
+        int shape = c->movable_shapes[rng_randint(g, c->n_movable_shapes)];
+        float sc = rng_uniform(g, c->scale_range[0], c->scale_range[1]);
+        float mass = rng_uniform(g, c->mass_range[0], c->mass_range[1]);
+        float fr = rng_uniform(g, c->friction_range[0], c->friction_range[1]);
+        e.active[0] = 1; e.shape[0] = shape; e.scale[0] = sc; e.friction[0] = fr;
+        body_set_mass(e, K, 0, mass);
+        cache_shape_meta(S, K, 0);
+        for (int k = 0; k < 7; ++k) e.body[0][k] = S.s.poses[0][k];
+        for (int k = 7; k < 13; ++k) e.body[0][k] = 0.0f;
+        S.s.valid = 1;
+      }
+    RV_LANES_END
+  }
   // PushEnv._load_movable_bodies (push_env.py:399-471)
   while (!S.s.valid) {
     RV_LANES_BEGIN
@@ -2553,6 +2812,13 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
       float off[RV_NLIMB];
       for (int j = 0; j < RV_NLIMB; ++j) off[j] = c->offstage_positions[j];
       robot_move_to_joint_positions(S, K, off);
+      if (c->env_type == RV_ENV_GRASP) {
+        // Grasp4DofEnv._reset_robot (grasp_4dof_env.py:206-211): robot.reset(OFFSTAGE_POSITIONS) =
+        // move_to_joint_positions, then grip(0) -- whose finger target REPLACES the limb target
+        // (one JointTarget per body, controllable_body.py:263-300)
+        robot_move_to_joint_positions(S, K, off);
+        robot_grip(S, K, 0.0f);
+      }
       compute_obs(e);
       for (int b = 0; b < RV_MAXB; ++b) for (int k = 0; k < 3; ++k) e.prev_obs_pos[b][k] = e.obs_pos[b][k];
       // link frames of the rebooted arm, for getters before the first substep
@@ -2568,6 +2834,18 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
   RV_LANES_END
 }
 
+// RandomPolicy._action (random_policy.py:14-23) = action_space.sample(): PushEnv U(-1,1)^(G*4)
+// (push_env.py:253-267); Grasp4DofEnv uniform in ACTION.CUBOID x [0, 2 pi] (grasp_4dof_env.py:144-150).
+// Philox keyed by (seed, global env id, macro index).
+RV_DEV void random_action(const rv_config* c, int gid, int macro_index, float* a /* [G][4] */) {
+  int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
+  Rng g = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RANDOM, (uint32_t)macro_index);
+  for (int x = 0; x < G * 4; ++x) a[x] = rng_uniform(g, -1.0f, 1.0f);
+  if (c->env_type == RV_ENV_GRASP) {
+    for (int k = 0; k < 3; ++k) a[k] = c->grasp_cuboid_low[k] + (c->grasp_cuboid_high[k] - c->grasp_cuboid_low[k]) * (0.5f * (a[k] + 1.0f));
+    a[3] = RV_PI * (a[3] + 1.0f);
+  }
+}
 // generate_episode's inner loop with the on-device RandomPolicy
 // (episode_generation.py:44-46, random_policy.py:14-23): n_steps env.step()
 // calls back to back for this env; see rv_rollout() in include/rovat.h.
@@ -2602,13 +2880,9 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
       env_reset(S, K, gid, 0);
     }
     RV_LANES_BEGIN
-      if (lane == 0) {
-        int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
-        Rng g = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RANDOM, (uint32_t)(first_index + k));
-        for (int x = 0; x < G * 4; ++x) S.e.action[x >> 2][x & 3] = rng_uniform(g, -1.0f, 1.0f);
-      }
+      if (lane == 0) random_action(c, gid, first_index + k, &S.e.action[0][0]);
     RV_LANES_END
-    env_step(S, K, 0);
+    if (c->env_type == RV_ENV_GRASP) genv_step(S, K, 0); else env_step(S, K, 0);
     RV_LANES_BEGIN
       if (lane == 0 && budget == nullptr) rollout_record(rec, &S.e, (size_t)k * n_envs + env, c);
     RV_LANES_END

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   } else if (MODE == MODE_MACRO) {
     if (lane == 0) launch_counters_zero(S.e);
     __syncthreads();
-    env_step(S, K);
+    if (K.cfg->env_type == RV_ENV_GRASP) genv_step(S, K); else env_step(S, K);
   } else if (MODE == MODE_ROLLOUT) {
     env_rollout(S, K, K.cfg->env_id_offset + env, args.n_substeps, args.first_index, args.auto_reset, args.rec, env, args.n_envs, args.budget);
     if (lane == 0 && args.steps_taken) args.steps_taken[env] = S.e.stepped;
@@ -102,13 +102,14 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
 
 #define ENV_THREAD() const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return; DevEnv& e = envs[i];
 
-__global__ void k_init(DevEnv* envs, int n) {
+__global__ void k_init(DevEnv* envs, int n, float mu_finger, float mu_table) {
   ENV_THREAD();
   uint32_t* p = reinterpret_cast<uint32_t*>(&e);
   for (int k = 0; k < (int)(sizeof(DevEnv) / 4); ++k) p[k] = 0u;
   for (int b = 0; b < RV_MAXB; ++b) e.body[b][6] = 1.0f;
   for (int f = 0; f < RV_NFRAME; ++f) e.fquat[f][3] = 1.0f;
   e.done = 1;  // RobotEnv.__init__: self._done = True (robot_env.py:66)
+  e.mu_finger = mu_finger; e.mu_table = mu_table;
 }
 __global__ void k_get_body_state(const DevEnv* envs, int n, float* out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
@@ -363,6 +364,25 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
     outn += (int)__popcll(bs); ties += (int)__popcll(beq);
   }
 }
+// CameraObs 'depth' / 'segmask' (camera_obs.py:33-88 over BulletCamera._frames,
+// bullet_camera.py:188-235): the same ray cast as the point cloud, one thread per pixel.
+// depth: eye z, 0 where nothing is hit; segmask: body index, RV_MAXB = table, 255 = nothing
+__global__ void k_render(const ObsSnap* snaps, int n, float* depth, uint8_t* seg, const rv_config* c, const rv_scene* scene) {
+  const int H = c->cam_height, W = c->cam_width;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * H * W) return;
+  const int i = (int)(t / ((size_t)H * W)); const int px = (int)(t % ((size_t)H * W));
+  const int v = px / W, u = px - v * W;
+  const ObsSnap& s = snaps[i];
+  float rot[RV_MAXB][9];
+  for (int b = 0; b < RV_MAXB; ++b) { m3 m = qmat(ldq(s.pose[b] + 3)); stm(rot[b], m); }
+  const v3 cam_o = cam_position(c);
+  float d;
+  int who = render_pixel(c, scene, s, rot, cam_o, cam_to_world_dir(c, pixel_dir_cam(c, (float)u, (float)v)), &d);
+  if (who >= 0 && !(d > c->cam_near)) who = -1;
+  if (depth) depth[t] = who >= 0 ? d : 0.0f;
+  if (seg) seg[t] = who >= 0 ? (uint8_t)who : (uint8_t)255;
+}
 __global__ void k_reward(const DevEnv* envs, int n, float* reward, uint8_t* done) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
   // an env whose episode is over is not stepped by rv_step_macro (the reference raises
@@ -377,8 +397,7 @@ __global__ void k_returns(const DevEnv* envs, int n, float* r) {
 __global__ void k_policy_random(int n, const rv_config* cfg, int macro_index, float* actions) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
   int G = cfg->num_goal_steps > 0 ? cfg->num_goal_steps : 1;
-  Rng g = rng_init(cfg->seed_lo, cfg->seed_hi, (uint32_t)(cfg->env_id_offset + i), RV_STREAM_RANDOM, (uint32_t)macro_index);
-  for (int k = 0; k < G * 4; ++k) actions[(size_t)i * G * 4 + k] = rng_uniform(g, -1.0f, 1.0f);
+  random_action(cfg, cfg->env_id_offset + i, macro_index, actions + (size_t)i * G * 4);
 }
 // HeuristicPushSampler._sample (heuristic_push_sampler.py:66-123): one wave
 // per env, 64 candidate pushes per round; the lowest successful attempt wins.
@@ -548,7 +567,7 @@ int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world*
   HIPCHK(hipMemset(w->d_stats, 0, sizeof(rv_macro_stats)));
   HIPCHK(hipEventCreate(&w->ev0));
   HIPCHK(hipEventCreate(&w->ev1));
-  hipLaunchKernelGGL(k_init, grid1(w->n), dim3(TPB), 0, w->stream, w->d_envs, w->n);
+  hipLaunchKernelGGL(k_init, grid1(w->n), dim3(TPB), 0, w->stream, w->d_envs, w->n, cfg->arm_friction, cfg->table_friction);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(w->stream));
   *out = w;
@@ -687,6 +706,16 @@ int rv_observe(rv_world* w, const rv_obs_buffers* obs) {
     SIMPLE_LAUNCH(k_obs_snap, w->d_envs, w->n, w->d_snaps);
     rc = launch_point_cloud(w, w->n, obs->d_point_cloud); if (rc != RV_OK) return rc;
   }
+  return RV_OK;
+}
+int rv_render(rv_world* w, float* d_depth, uint8_t* d_segmask) {
+  WCHK(w);
+  if (!d_depth && !d_segmask) return fail(RV_ERR_VALUE, "rv_render: no output buffer");
+  int rc = ensure_snaps(w, (size_t)w->n); if (rc != RV_OK) return rc;
+  SIMPLE_LAUNCH(k_obs_snap, w->d_envs, w->n, w->d_snaps);
+  const size_t total = (size_t)w->n * (size_t)w->cfg.cam_height * (size_t)w->cfg.cam_width;
+  hipLaunchKernelGGL(k_render, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, w->stream, w->d_snaps, w->n, d_depth, d_segmask, w->d_cfg, w->d_scene);
+  HIPCHK(hipGetLastError());
   return RV_OK;
 }
 int rv_reward(rv_world* w, float* d_reward, uint8_t* d_done) { WCHK(w); SIMPLE_LAUNCH(k_reward, w->d_envs, w->n, d_reward, d_done); return RV_OK; }

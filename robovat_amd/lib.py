@@ -30,7 +30,7 @@ SYMBOLS = [
     'rv_compute_ik', 'rv_query_contacts', 'rv_get_manifold_counts', 'rv_observe',
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
-    'rv_rollout_record',
+    'rv_rollout_record', 'rv_render',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -113,6 +113,7 @@ def load():
     lib.rv_get_stats.argtypes = [vp, C.POINTER(abi.rv_macro_stats)]
     lib.rv_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.rv_reset_targets.argtypes = [vp]
+    lib.rv_render.argtypes = [vp, vp, vp]
     lib.rv_set_motor_targets.argtypes = [vp, vp, vp]
     lib.rv_grip.argtypes = [vp, f32]
     lib.rv_get_state_ptrs.argtypes = [vp, C.POINTER(abi.rv_state_view)]
@@ -362,6 +363,14 @@ class World(object):
         out, b = self._obs_buffers((self.n,), point_cloud, pose_modes)
         check(self.lib.rv_observe(self.h, C.byref(b)))
         return out
+
+    def render(self, segmask=True):
+        """Depth image [N, H, W] (eye z, 0 = nothing hit) and segmentation mask of the simulated camera."""
+        h, w = int(self.cfg.cam_height), int(self.cfg.cam_width)
+        depth = self._new((self.n, h, w), self.torch.float32)
+        seg = self._new((self.n, h, w), self.torch.uint8) if segmask else None
+        check(self.lib.rv_render(self.h, self._ptr(depth), self._ptr(seg) if segmask else None))
+        return depth, seg
 
     def reward(self):
         r = self._new((self.n,), self.torch.float32)

@@ -172,6 +172,12 @@ def default_shape_hulls():
     if os.path.exists(FIXTURE_PATH):
         for name, hulls in sorted(load_vhacd_fixtures().items()):
             shapes.append((name, hulls))
+    # graspables of BASELINE config 4: narrower than the open gripper (3.8 cm between the pads)
+    shapes += [
+        ('grasp_cube', [box_hull(0.014, 0.014, 0.014)]),
+        ('grasp_bar', [box_hull(0.012, 0.035, 0.015)]),
+        ('grasp_cyl', [cylinder_hull(0.014, 0.02, 8)]),
+    ]
     return shapes
 
 
@@ -220,7 +226,9 @@ FINGER_TIP_OFFSET = 0.14
 _LINK_RADIUS = [0.05, 0.07, 0.06, 0.06, 0.05, 0.05, 0.045]
 
 
-def make_arm(base_pos=(0.0, 0.0, 0.0), base_rpy=(0.0, 0.0, 0.0)):
+def make_arm(base_pos=(0.0, 0.0, 0.0), base_rpy=(0.0, 0.0, 0.0), finger_accel=2.0):
+    """``finger_accel``: acceleration limit of the finger joints (m/s^2); with the force-limited
+    gripper (PHYSICS.FINGER_DYNAMICS) it is FINGER_MAX_FORCE / FINGER_MASS."""
     arm = abi.rv_arm()
     abi.assign(arm.base_pos, base_pos)
     abi.assign(arm.base_quat, _rpy_quat(*base_rpy).tolist())
@@ -235,7 +243,7 @@ def make_arm(base_pos=(0.0, 0.0, 0.0), base_rpy=(0.0, 0.0, 0.0)):
     arm.q_lo[7], arm.q_hi[7] = 0.0, FINGER_STROKE
     arm.q_lo[8], arm.q_hi[8] = -FINGER_STROKE, 0.0
     arm.v_max[7] = arm.v_max[8] = 0.1
-    arm.a_max[7] = arm.a_max[8] = 2.0
+    arm.a_max[7] = arm.a_max[8] = float(finger_accel)
     # open gap (2 x (0.004 + stroke) - pad thickness) ~ 3.8 cm: narrower than the smallest movable, so a
     # push cannot straddle a body
     arm.finger_y0[0], arm.finger_y0[1] = 0.004, -0.004
@@ -256,9 +264,10 @@ def make_arm(base_pos=(0.0, 0.0, 0.0), base_rpy=(0.0, 0.0, 0.0)):
     return arm
 
 
-def make_scene(shape_hulls=None):
+def make_scene(shape_hulls=None, env_cfg=None):
     """Build the ``rv_scene`` (shape templates + arm).  Returns
-    (scene, names)."""
+    (scene, names).  ``env_cfg``: the env config, for the settings that live in the scene
+    (the finger acceleration limit of the force-limited gripper)."""
     if shape_hulls is None:
         shape_hulls = default_shape_hulls()
     assert len(shape_hulls) <= abi.RV_MAX_SHAPES
@@ -268,5 +277,8 @@ def make_scene(shape_hulls=None):
     for i, (name, hulls) in enumerate(shape_hulls):
         scene.shapes[i] = make_shape(hulls)
         names.append(name)
-    scene.arm = make_arm()
+    accel = 2.0
+    if env_cfg is not None and env_cfg.PHYSICS.get('FINGER_DYNAMICS'):
+        accel = env_cfg.PHYSICS.FINGER_MAX_FORCE / env_cfg.PHYSICS.FINGER_MASS
+    scene.arm = make_arm(finger_accel=accel)
     return scene, names

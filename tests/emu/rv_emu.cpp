@@ -24,7 +24,7 @@ static void run_env(EmuWorld* w, int i, int mode, int n_sub, float lin, float an
   if (mode == 1 && S.e.done) { w->envs[i].substeps_last = 0; w->envs[i].awake_last = 0; w->envs[i].pairs_last = 0; w->envs[i].stepped = 0; return; }
   if (mode != 0) env_enter(S, K);
   if (mode == 0) env_reset(S, K, w->cfg.env_id_offset + i);
-  else if (mode == 1) { launch_counters_zero(S.e); env_step(S, K); }
+  else if (mode == 1) { launch_counters_zero(S.e); if (K.cfg->env_type == RV_ENV_GRASP) genv_step(S, K); else env_step(S, K); }
   else if (mode == 4) { RolloutRec rec; memset(&rec, 0, sizeof(rec)); env_rollout(S, K, w->cfg.env_id_offset + i, n_sub, ca, ms, rec, i, w->n); }
   else if (mode == 2) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; sim_steps_call(K, n_sub); }
   else { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; wait_until_stable(S, K, 0u, lin, ang, ca, ms, mx); }
@@ -40,6 +40,7 @@ EmuWorld* emu_create(const rv_config* cfg, const rv_scene* scene) {
     for (int b = 0; b < RV_MAXB; ++b) w->envs[i].body[b][6] = 1.0f;
     for (int f = 0; f < RV_NFRAME; ++f) w->envs[i].fquat[f][3] = 1.0f;
     w->envs[i].done = 1;
+    w->envs[i].mu_finger = cfg->arm_friction; w->envs[i].mu_table = cfg->table_friction;
   }
   return w;
 }

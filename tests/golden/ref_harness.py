@@ -43,12 +43,16 @@ class OraclePhysics(object):
     SEED = 1                     # class attributes: Simulator() constructs the plugin itself
     ENV_ID = 0
     CFG_OVERRIDES = {}
+    ENV_KIND = 'push'            # 'grasp': Grasp4DofEnv config + the force-limited gripper
 
     def __init__(self, time_step=1e-3, use_visualizer=False, worker_id=0):
         self._time_step = DT
         self._num_steps = None
-        scene, names = scenes.make_scene()
-        env_cfg = configs.push_env_config(**self.CFG_OVERRIDES)
+        if self.ENV_KIND == 'grasp':
+            env_cfg = configs.grasp_env_config(**self.CFG_OVERRIDES)
+        else:
+            env_cfg = configs.push_env_config(**self.CFG_OVERRIDES)
+        scene, names = scenes.make_scene(env_cfg=env_cfg)
         cfg = configs.make_rv_config(env_cfg=env_cfg, n_envs=1, env_id_offset=self.ENV_ID, shape_names=names, seed=self.SEED)
         self.cfg = cfg
         self.w = orc.OracleWorld(cfg, scene, double=True)
@@ -148,6 +152,20 @@ class OraclePhysics(object):
 
     def get_body_angular_velocity(self, uid):
         return self.w.body_state()[0, uid - self.BODY_UID0, 10:13]
+
+    # -- dynamics (bullet_physics.py:263-330, 510-560): Grasp4DofEnv changes the lateral friction of the
+    # finger tips and of the table between its phases (grasp_4dof_env.py:262-293)
+    def set_link_dynamics(self, link_uid, mass=None, lateral_friction=None, rolling_friction=None,
+                          spinning_friction=None, **kwargs):
+        assert self.link_names[link_uid[1]].endswith('finger_tip'), link_uid
+        if lateral_friction is not None:
+            self.w.set_friction(mu_finger=float(np.float32(lateral_friction)))
+
+    def set_body_dynamics(self, uid, mass=None, lateral_friction=None, rolling_friction=None,
+                          spinning_friction=None, **kwargs):
+        assert uid == self.TABLE_UID, uid
+        if lateral_friction is not None:
+            self.w.set_friction(mu_table=float(np.float32(lateral_friction)))
 
     # -- contacts (bullet_physics.py:1268-1304); the list holds one entry per touching pair
     def get_contact_points(self, a_uid, b_uid=None):

@@ -123,3 +123,33 @@ def test_long_rollout_with_resets_is_bit_exact(emu):
     ref.rollout(8, 2, True)
     emu.emu_rollout(e.h, 8, 2, 1)
     _check(e, ref)
+
+
+def test_grasp_env_is_bit_exact_vs_float_oracle(emu):
+    """Grasp4DofEnv (BASELINE config 4) through the emulated kernel: reset, aimed and random
+    grasps (force-limited gripper, per-substep phase machine, friction switches, GraspReward),
+    then a rollout with auto-reset -- equal to the float oracle bit for bit."""
+    from oracle import orc
+    from robovat_amd.math import rotations
+    env_cfg = configs.grasp_env_config()
+    scene, names = scenes.make_scene(env_cfg=env_cfg)
+    cfg = configs.make_rv_config(env_cfg=env_cfg, n_envs=8, seed=3, shape_names=names)
+    ref = orc.OracleWorld(cfg, scene, double=False)
+    e = Emu(emu, cfg, scene)
+    ref.reset(); emu.emu_reset(e.h, None)
+    _check(e, ref)
+    a = ref.policy_random(0)
+    st = ref.body_state()
+    for i in range(0, 8, 2):         # every other env: a grasp aimed at the object
+        a[i, 0, :2] = st[i, 0, :2]
+        a[i, 0, 3] = rotations.euler_from_quaternion(st[i, 0, 3:7])[2]
+    ref.set_actions(a); emu.emu_set_actions(e.h, a.ctypes.data_as(C.c_void_p))
+    ref.step_macro(); emu.emu_step_macro(e.h)
+    _check(e, ref)
+    r = np.zeros(8, np.float32); d = np.zeros(8, np.uint8)
+    emu.emu_reward(e.h, r.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p))
+    rr, rd = ref.reward()
+    assert np.array_equal(r, rr.astype(np.float32)) and np.array_equal(d, rd) and d.all()
+    assert 0 < r.sum() < 8                       # some grasps hold, some miss
+    ref.rollout(2, 1, True); emu.emu_rollout(e.h, 2, 1, 1)
+    _check(e, ref)

