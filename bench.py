@@ -289,6 +289,23 @@ def main():
             barrier(); ea5 = all_max(time.perf_counter() - ta)
             extra['config5_8192']['async_value'] = all_sum(w5.stats()['env_steps'])[0] / ea5
         w5.close()
+        # BASELINE configs[3]: Grasp4DofEnv, 2048 envs, one graspable, force-limited gripper, random CUBOID grasps
+        genv = configs.grasp_env_config()
+        gscene, gnames = scenes.make_scene(env_cfg=genv)
+        gc = configs.make_rv_config(env_cfg=genv, n_envs=2048, env_id_offset=rank * 2048, shape_names=gnames, **cfg_kwargs)
+        w4 = lib.World(gc, gscene, device=local_rank)
+        w4.reset()
+        barrier(); t4 = time.perf_counter()
+        w4.rollout(k3, first_macro_index=0, auto_reset=True, record=True)
+        st4 = w4.stats()
+        barrier(); el4 = all_max(time.perf_counter() - t4)
+        extra['config4_grasp_2048'] = leg_summary(el4, st4, k3, 2048)
+        extra['config4_grasp_2048'].update({
+            'workload': 'Grasp4DofEnv, ACTION.TYPE=CUBOID random grasps, one graspable hull, 7-DoF FK / DLS IK every 10 substeps, '
+                        'two force-limited prismatic fingers in the contact solver; every env.step() is a whole episode (reset included)',
+            'grasp_success_rate': st4['successes'] / max(st4['env_steps'], 1),
+            'roofline_frac_nominal': 1912 * st4['substeps'] / (1e-3 * w4.last_kernel_ms()) / 1e9 / HBM_PEAK_GBS})
+        w4.close()
     else:
         world.close()
 

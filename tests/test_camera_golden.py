@@ -66,6 +66,18 @@ def test_segment_ids_and_grouping_rules(golden):
             assert (g['distinct_samples'][i] == g['num_samples']) == (n >= g['num_samples'])
 
 
+def test_grasp2d_from_vector_and_4dof(golden):
+    from robovat_amd.envs.grasp.grasp_2d import Grasp2D
+    assert len(golden['grasp2d']) >= 20
+    for g in golden['grasp2d']:
+        cam = Camera(height=424, width=512, intrinsics=g['intrinsics'], translation=g['translation'], rotation=g['rotation'])
+        gr = Grasp2D.from_vector(np.array(g['vector']), camera=cam)
+        assert np.allclose(gr.center, g['center']) and abs(gr.angle - g['angle']) < 1e-12 and gr.depth == g['depth']
+        assert abs(gr.width - g['width']) < 1e-9 and abs(gr.width_pixel - g['width_pixel']) < 1e-9
+        assert np.allclose(gr.as_4dof(), g['as_4dof'], atol=1e-6)
+        assert np.allclose(gr.vector, g['vector_back'], atol=1e-9)
+
+
 def _oracle_world(n, seed, **over):
     from oracle import orc
     scene, names = scenes.make_scene()
