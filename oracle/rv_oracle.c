@@ -1038,6 +1038,11 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
       for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s2] * d;
     }
     for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < (real)c->solver_tol) done |= 1 << x;
+#ifdef ORC_DEBUG_SOLVE
+    fprintf(stderr, "it %d res %g %g %g %g | lam", it, (double)res[0], (double)res[1], (double)res[2], (double)res[3]);
+    for (int s2 = 0; s2 < n_rows; ++s2) fprintf(stderr, " %.4g", (double)lam[s2]);
+    fprintf(stderr, "\n");
+#endif
     if ((done & isl_rows) == isl_rows) break;
   }
   for (int s2 = 0; s2 < n_rows; ++s2) {
