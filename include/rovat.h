@@ -226,6 +226,13 @@ typedef struct rv_config {
   /* lateral friction the env gives the finger tips / the table while it descends and
    * while it lifts (grasp_4dof_env.py:262-270, 282-293)                              */
   float    grasp_mu_descend[2], grasp_mu_lift[2];
+  /* the ground the table stands on (arm_env.py:85-88): a body that leaves the table lands on
+   * it; below ground_z - fall_depth a body is frozen (safety net) */
+  float    ground_z, ground_friction;
+  /* rolling / spinning friction of a body on its support (urdf_template.xml:11-16: 0.001;
+   * Body.set_dynamics passes spinning = rolling, body.py:229): a resisting angular impulse of at
+   * most rolling_friction x (normal impulse of the body - table manifold) per substep */
+  float    rolling_friction;
 } rv_config;
 
 /* Per-launch statistics of rv_step_macro / rv_reset (device-side reductions of

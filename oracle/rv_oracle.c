@@ -88,7 +88,7 @@ typedef struct {
   real rot[RV_MAXB][9], iinv[RV_MAXB][9];
   real mot[RV_MAXB];
   real wv[RV_MAXB][RV_MAXH][RV_MAXV][3];
-  real tablev[8][3];
+  real tablev[8][3], groundv[8][3];
   /* contacts */
   orc_manifold man[RV_NMAN];
   int flag_arm_table, flag_arm_body[RV_MAXB];
@@ -133,6 +133,12 @@ static const int BB_ROUND[3][2] = {{0, 5}, {1, 4}, {2, 3}};
 
 static int body_on(const orc_env* e, int b) { return e->bp[b].active && !e->bp[b].frozen && !e->bp[b].asleep; }
 static real sim_time(const orc_world* w, const orc_env* e) { return (real)w->cfg.dt * (real)e->sim_steps; }
+
+/* a body entirely below the table slab can only touch the ground: its "table" manifold then
+ * holds its contacts with the ground */
+static int body_below_table(const orc_world* w, const orc_env* e, int b) {
+  return e->body[b].p[2] + e->bp[b].radius < e->table_z - (real)w->cfg.table_thickness;
+}
 
 /* ------------------------------------------------------------------ arm -- */
 
@@ -512,6 +518,10 @@ static void table_prepare(const orc_world* w, orc_env* e) {
     e->tablev[k][0] = (real)c->table_center[0] + ((k & 1) ? hx : -hx);
     e->tablev[k][1] = (real)c->table_center[1] + ((k & 2) ? hy : -hy);
     e->tablev[k][2] = (k & 4) ? ztop : zbot;
+    /* the ground: a 20 m x 20 m slab, 1 m thick, under the table */
+    e->groundv[k][0] = (real)c->table_center[0] + ((k & 1) ? R(10.0) : R(-10.0));
+    e->groundv[k][1] = (real)c->table_center[1] + ((k & 2) ? R(10.0) : R(-10.0));
+    e->groundv[k][2] = (k & 4) ? (real)c->ground_z - mg : (real)c->ground_z - R(1.0) + mg;
   }
 }
 
@@ -608,15 +618,21 @@ static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, 
    * FEATURE_PERIOD-th full pass (cached points are refreshed every substep) */
   if (m->n >= 4 && m->age < FEATURE_PERIOD - 1) { m->age++; return 1; }
   m->age = 0;
-  real t1[3], t2[3], dir[4][3], extA[4], extB[4];
+  /* candidate vertices are picked along four tangent directions rotated off the plane axes (a box
+   * aligned with them would offer a whole edge); a candidate is kept only inside the other hull's
+   * extent along those four AND along the four plane axes themselves (an octagon: exact for a box
+   * whose edges follow the axes, e.g. the table -- a body overhanging the table edge gets no
+   * support beyond the edge) */
+  real t1[3], t2[3], dir[8][3], extA[8], extB[8];
   plane_space(n, t1, t2);
   for (int k = 0; k < 3; ++k) {
     dir[0][k] = MAN_C * t1[k] + MAN_S * t2[k];
     dir[1][k] = MAN_C * t2[k] - MAN_S * t1[k];
     dir[2][k] = -dir[0][k];
     dir[3][k] = -dir[1][k];
+    dir[4][k] = t1[k]; dir[5][k] = t2[k]; dir[6][k] = -t1[k]; dir[7][k] = -t2[k];
   }
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 8; ++j) {
     extA[j] = v3dot(A[orc_support(A, nA, dir[j])], dir[j]) + mg;
     extB[j] = v3dot(B[orc_support(B, nB, dir[j])], dir[j]) + mg;
   }
@@ -631,7 +647,7 @@ static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, 
     if (gap <= brk) {
       real pt[3]; v3madd(pt, va, n, -sep);
       int ok = 1;
-      for (int j = 0; j < 4; ++j) if (v3dot(pt, dir[j]) > extB[j]) ok = 0;
+      for (int j = 0; j < 8; ++j) if (v3dot(pt, dir[j]) > extB[j]) ok = 0;
       if (ok) {
         v3madd(wa, va, n, -mg); v3madd(wb, pt, n, mg);
         manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, gap);
@@ -646,7 +662,7 @@ static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, 
     if (gap <= brk) {
       real pt[3]; v3madd(pt, vb, n, sep);
       int ok = 1;
-      for (int j = 0; j < 4; ++j) if (v3dot(pt, dir[j]) > extA[j]) ok = 0;
+      for (int j = 0; j < 8; ++j) if (v3dot(pt, dir[j]) > extA[j]) ok = 0;
       if (ok) {
         v3madd(wa, pt, n, -mg); v3madd(wb, vb, n, mg);
         manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, gap);
@@ -729,13 +745,18 @@ static void collide_all(const orc_world* w, orc_env* e) {
     if (!body_on(e, b) || !run[TIDX(b)]) continue;
     e->man[TIDX(b)].acc = R(0.0);
     real r = e->bp[b].radius + brk;
-    if (sphere_box_dist2(e->body[b].p, tc, th) >= r * r) continue;
+    const int below = body_below_table(w, e, b);
+    real guess[3] = {R(0.0), R(0.0), R(1.0)};
+    if (below) {
+      if (e->body[b].p[2] - (real)c->ground_z >= r) continue;
+    } else {
+      if (sphere_box_dist2(e->body[b].p, tc, th) >= r * r) continue;
+      guess[2] = e->body[b].p[2] - tc[2];
+    }
     const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
-    real guess[3]; v3sub(guess, e->body[b].p, tc);
-    guess[0] = R(0.0); guess[1] = R(0.0);
     for (int h = 0; h < s->n_hulls; ++h) {
       real d;
-      collide_pair(w, e, 0, b, -1, -1, (const real(*)[3])e->wv[b][h], s->n_verts[h], (const real(*)[3])e->tablev, 8, guess, &e->man[TIDX(b)], &d);
+      collide_pair(w, e, 0, b, -1, -1, (const real(*)[3])e->wv[b][h], s->n_verts[h], (const real(*)[3])(below ? e->groundv : e->tablev), 8, guess, &e->man[TIDX(b)], &d);
     }
   }
   /* body - body */
@@ -842,7 +863,7 @@ static void row_setup(const orc_world* w, orc_env* e, int kind, int a, int b, co
   real dist = m->dist[i];
   if (dist > R(0.0)) r->target = -dist / dt;
   else r->target = rmin((real)c->erp * rmax(-dist - (real)c->slop, R(0.0)) / dt, (real)c->max_pushout);
-  real mub = (kind == 0) ? e->mu_table : (kind == 1 ? e->bp[b].friction : (m->col[i] >= 8 ? e->mu_finger : (real)c->arm_friction));
+  real mub = (kind == 0) ? (body_below_table(w, e, a) ? (real)c->ground_friction : e->mu_table) : (kind == 1 ? e->bp[b].friction : (m->col[i] >= 8 ? e->mu_finger : (real)c->arm_friction));
   r->mu = e->bp[a].friction * mub;
 }
 
@@ -1270,13 +1291,29 @@ static void sim_substep(const orc_world* w, orc_env* e) {
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!body_on(e, b)) continue;
     orc_body* B = &e->body[b];
+    /* rolling / spinning friction on the support: a resisting angular impulse of at most
+     * rolling_friction x (normal impulse of the table manifold), never reversing the spin */
+    if ((real)c->rolling_friction > R(0.0) && e->man[TIDX(b)].n > 0) {
+      const orc_manifold* mt = &e->man[TIDX(b)];
+      real nimp = R(0.0);
+      for (int i = 0; i < mt->n; ++i) nimp += mt->ln[i];
+      real wl = v3len(B->w);
+      if (wl > R(0.0) && nimp > R(0.0)) {
+        real dir[3], iw[3];
+        v3scale(dir, B->w, R(1.0) / wl);
+        m3mulv(iw, e->iinv[b], dir);
+        real k = v3dot(dir, iw);
+        real j = rmin((real)c->rolling_friction * nimp, wl / k);
+        v3madd(B->w, B->w, iw, -j);
+      }
+    }
     real vv = v3dot(B->v, B->v), ww = v3dot(B->w, B->w);
     v3madd(B->p, B->p, B->v, dt);
     real wq[4] = {B->w[0], B->w[1], B->w[2], R(0.0)}, dq[4];
     qmul(dq, wq, B->q);
     for (int k = 0; k < 4; ++k) B->q[k] += R(0.5) * dt * dq[k];
     qnormalize(B->q);
-    if (B->p[2] < e->table_z - (real)c->fall_depth) {
+    if (B->p[2] < (real)c->ground_z - (real)c->fall_depth) {
       e->bp[b].frozen = 1;
       v3set(B->v, R(0.0), R(0.0), R(0.0)); v3set(B->w, R(0.0), R(0.0), R(0.0));
     }

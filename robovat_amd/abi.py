@@ -134,6 +134,7 @@ class rv_config(C.Structure):
         ('overhead_positions', f32 * RV_NLIMB),
         ('max_action_steps', i32), ('end_effector_step', f32),
         ('grasp_mu_descend', f32 * 2), ('grasp_mu_lift', f32 * 2),
+        ('ground_z', f32), ('ground_friction', f32), ('rolling_friction', f32),
     ]
 
 

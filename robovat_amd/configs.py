@@ -71,6 +71,8 @@ PUSH_ENV_CONFIG = {
     'SIM': {
         'TABLE': {'POSE': [[0.6, 0.0, 0.0], [0, 0, 0]], 'HALF_EXTENTS': [0.38, 0.61],
                   'THICKNESS': 0.05, 'FRICTION': 1.0},
+        # the ground the table stands on (arm_env.py:85-88); z relative to the nominal table top
+        'GROUND': {'Z': -0.75, 'FRICTION': 1.0},
         'STEPS_CHECK': 10,
         'MAX_PHASE_STEPS': 2000,
         'MAX_MOTION_STEPS': 3000,
@@ -121,6 +123,8 @@ PUSH_ENV_CONFIG = {
         'SLEEP_LINEAR': 0.02, 'SLEEP_ANGULAR': 0.5, 'SLEEP_STEPS': 200,
         'SLEEP_POSITION_WINDOW': 1e-3, 'SLEEP_ROTATION_WINDOW': 0.01,
         'NARROWPHASE_GATE': 1e-3, 'NARROWPHASE_MAX_AGE': 8,
+        # rolling = spinning friction of the movables (tools/templates/urdf_template.xml:11-16; body.py:229)
+        'ROLLING_FRICTION': 0.001,
     },
 }
 
@@ -240,6 +244,9 @@ def make_rv_config(env_cfg=None, robot_cfg=None, shape_names=None, n_envs=1,
     c.table_friction = tb.FRICTION
     c.arm_friction = ph.ARM_FRICTION
     c.fall_depth = env_cfg.SIM.FALL_DEPTH
+    c.ground_z = tb.POSE[0][2] + env_cfg.SIM.GROUND.Z
+    c.ground_friction = env_cfg.SIM.GROUND.FRICTION
+    c.rolling_friction = float(ph.get('ROLLING_FRICTION', 0.0))
     c.n_bodies_min = env_cfg.MIN_MOVABLE_BODIES
     c.n_bodies_max = env_cfg.MAX_MOVABLE_BODIES
     assert 1 <= c.n_bodies_min <= c.n_bodies_max <= abi.RV_MAXB

@@ -143,7 +143,7 @@ struct Scratch {
   int arm_moving;
   int colflag[RV_NCOL];
   float rot[RV_MAXB][9], iinv[RV_MAXB][9];
-  float tablev[8][3];
+  float tablev[8][3], groundv[8][3];
   // solver rows + world hull vertices (rebuilt before every use: the solver borrows them as
   // scratch for the velocity update)
   struct {
@@ -516,6 +516,15 @@ RV_DEV void table_prepare(Shared& S, const Consts& K, int k) {
   S.s.tablev[k][0] = c->table_center[0] + ((k & 1) ? hx : -hx);
   S.s.tablev[k][1] = c->table_center[1] + ((k & 2) ? hy : -hy);
   S.s.tablev[k][2] = (k & 4) ? ztop : zbot;
+  // the ground: a 20 m x 20 m slab, 1 m thick, under the table
+  S.s.groundv[k][0] = c->table_center[0] + ((k & 1) ? 10.0f : -10.0f);
+  S.s.groundv[k][1] = c->table_center[1] + ((k & 2) ? 10.0f : -10.0f);
+  S.s.groundv[k][2] = (k & 4) ? c->ground_z - mg : c->ground_z - 1.0f + mg;
+}
+// a body that is entirely below the table slab can only touch the ground: its "table"
+// manifold then holds its contacts with the ground
+RV_DEV int body_below_table(const DevEnv& e, const rv_config* c, int b) {
+  return e.body[b][2] + e.radius[b] < e.table_z - c->table_thickness;
 }
 
 RV_DEV v3 to_local_body(const Shared& S, int b, v3 wp) { return tmulv(S.s.rot[b], sub(wp, ld3(S.e.body[b]))); }
@@ -593,15 +602,21 @@ RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b
     if (m->n >= 4 && age < RV_FEATURE_PERIOD - 1) { m->age = age + 1; return 1; }
     m->age = 0;
   }
-  v3 t1, t2, dir[4];
-  float extA[4], extB[4];
+  // candidate vertices are picked along four tangent directions rotated off the plane axes (a box
+  // aligned with them would offer a whole edge); a candidate is kept only inside the other hull's
+  // extent along those four AND along the four plane axes themselves (an octagon: exact for a box
+  // whose edges follow the axes, e.g. the table -- a body overhanging the table edge gets no
+  // support beyond the edge)
+  v3 t1, t2, dir[8];
+  float extA[8], extB[8];
   plane_space(n, &t1, &t2);
   dir[0] = mk(RV_MAN_C * t1.x + RV_MAN_S * t2.x, RV_MAN_C * t1.y + RV_MAN_S * t2.y, RV_MAN_C * t1.z + RV_MAN_S * t2.z);
   dir[1] = mk(RV_MAN_C * t2.x - RV_MAN_S * t1.x, RV_MAN_C * t2.y - RV_MAN_S * t1.y, RV_MAN_C * t2.z - RV_MAN_S * t1.z);
   dir[2] = mk(-dir[0].x, -dir[0].y, -dir[0].z);
   dir[3] = mk(-dir[1].x, -dir[1].y, -dir[1].z);
+  dir[4] = t1; dir[5] = t2; dir[6] = mk(-t1.x, -t1.y, -t1.z); dir[7] = mk(-t2.x, -t2.y, -t2.z);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 8; ++j) {
     extA[j] = support_proj(A, nA, dir[j]) + mg;
     extB[j] = support_proj(B, nB, dir[j]) + mg;
   }
@@ -616,7 +631,7 @@ RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b
       v3 pt = madd(va, n, -sep);
       int ok = 1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) if (dot(pt, dir[j]) > extB[j]) ok = 0;
+      for (int j = 0; j < 8; ++j) if (dot(pt, dir[j]) > extB[j]) ok = 0;
       if (ok) manifold_add_world(S, K, kind, a, b, col, *m, madd(va, n, -mg), madd(pt, n, mg), n, gap);
     }
     sd = madd(dir[k], n, 1.0f / RV_MAN_TAU);
@@ -627,7 +642,7 @@ RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b
       v3 pt = madd(vb, n, sep);
       int ok = 1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) if (dot(pt, dir[j]) > extA[j]) ok = 0;
+      for (int j = 0; j < 8; ++j) if (dot(pt, dir[j]) > extA[j]) ok = 0;
       if (ok) manifold_add_world(S, K, kind, a, b, col, *m, madd(pt, n, -mg), madd(vb, n, mg), n, gap);
     }
   }
@@ -686,7 +701,9 @@ RV_DEV void owner_decode(const Shared& S, const Consts& K, int owner, int arm_on
     else if (!e.asleep[a]) {
       o.live = 1;
       float r = e.radius[a] + brk;
-      if (!(sphere_box_dist2(ld3(e.body[a]), tc, th) >= r * r)) {
+      if (body_below_table(e, c, a)) {
+        if (!(e.body[a][2] - c->ground_z >= r)) { o.role = 0; o.n_outer = 1; o.n_inner = S.n_hulls[a]; }
+      } else if (!(sphere_box_dist2(ld3(e.body[a]), tc, th) >= r * r)) {
         o.role = 0; o.n_outer = 1; o.n_inner = S.n_hulls[a];
         o.guess0 = mk(0.0f, 0.0f, e.body[a][2] - tc.z);
       }
@@ -769,7 +786,7 @@ RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, 
   float dist = p.dist;
   if (dist > 0.0f) r.target = -dist / dt;
   else r.target = fminr(c->erp * fmaxr(-dist - c->slop, 0.0f) / dt, c->max_pushout);
-  float mub = (kind == 0) ? e.mu_table : (kind == 1 ? e.friction[b] : (p.col >= 8 ? e.mu_finger : c->arm_friction));
+  float mub = (kind == 0) ? (body_below_table(e, c, a) ? c->ground_friction : e.mu_table) : (kind == 1 ? e.friction[b] : (p.col >= 8 ? e.mu_finger : c->arm_friction));
   r.mu = e.friction[a] * mub;
 }
 
@@ -1886,7 +1903,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         int io = t / n_inner, ii = t - io * n_inner;
         const float* A; const float* B; int nA, nB, ckind, col = -1;
         v3 guess = o.guess0;
-        if (role == 0) { A = &S.s.u.r.wv[a][ii][0][0]; nA = S.n_verts[a][ii]; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
+        if (role == 0) { A = &S.s.u.r.wv[a][ii][0][0]; nA = S.n_verts[a][ii]; B = body_below_table(e, c, a) ? &S.s.groundv[0][0] : &S.s.tablev[0][0]; nB = 8; ckind = 0; }
         else if (role == 1) { A = &S.s.u.r.wv[a][io][0][0]; nA = S.n_verts[a][io]; B = &S.s.u.r.wv[b][ii][0][0]; nB = S.n_verts[b][ii]; ckind = 1; }
         else if (role == 2) {
           col = io;
@@ -2052,6 +2069,22 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       int b = lane;
       if (body_on(e, b)) {
         float dt = c->dt;
+        // rolling / spinning friction on the support: a resisting angular impulse of at most
+        // rolling_friction x (normal impulse of the table manifold), never reversing the spin
+        if (c->rolling_friction > 0.0f && e.man[RV_TIDX(b)].n > 0) {
+          const DevMan& mt = e.man[RV_TIDX(b)];
+          float nimp = 0.0f;
+          for (int i = 0; i < mt.n; ++i) nimp += mt.ln[i];
+          v3 w0 = ld3(e.body[b] + 10);
+          float wl = len(w0);
+          if (wl > 0.0f && nimp > 0.0f) {
+            v3 dir = scale(w0, 1.0f / wl);
+            v3 iw = mulv(S.s.iinv[b], dir);
+            float k = dot(dir, iw);
+            float j = fminr(c->rolling_friction * nimp, wl / k);
+            st3(e.body[b] + 10, madd(w0, iw, -j));
+          }
+        }
         v3 v = ld3(e.body[b] + 7), w = ld3(e.body[b] + 10);
         v3 p = madd(ld3(e.body[b]), v, dt);
         st3(e.body[b], p);
@@ -2061,7 +2094,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         q.x += 0.5f * dt * dq.x; q.y += 0.5f * dt * dq.y; q.z += 0.5f * dt * dq.z; q.w += 0.5f * dt * dq.w;
         q = qnormalize(q);
         stq(e.body[b] + 3, q);
-        if (p.z < e.table_z - c->fall_depth) {
+        if (p.z < c->ground_z - c->fall_depth) {
           e.frozen[b] = 1;
           st3(e.body[b] + 7, mk(0, 0, 0)); st3(e.body[b] + 10, mk(0, 0, 0));
         }
