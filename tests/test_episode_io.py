@@ -1,0 +1,75 @@
+"""Episode files: the reference's HDF5 group layout (hdf5_utils.py:16-95, run_env.py:229-247)."""
+import numpy as np
+
+from robovat_amd.io import hdf5_utils as H
+
+
+def _episode(rng, n):
+    return {'hostname': 'box', 'timestamp': '2020-01-01-00-00-00',
+            'transitions': [{'state': {'position': rng.rand(4, 3).astype(np.float32), 'point_cloud': rng.rand(4, 256, 3).astype(np.float32),
+                                       'num_steps': np.array(t, np.int64)},
+                             'action': rng.rand(4).astype(np.float32), 'reward': float(t), 'info': None} for t in range(n)]}
+
+
+def test_layout_and_round_trip(tmp_path):
+    rng = np.random.RandomState(0)
+    eps = [_episode(rng, 3), _episode(rng, 1)]
+    path = str(tmp_path / 'episodes_x.hdf5')
+    with H.open_store(path) as f:
+        names = [H.append_episode(f, e) for e in eps]
+    with H.open_store(path, 'r') as f:
+        top = dict(f.items())
+        assert sorted(top) == sorted(names) and len(names[0]) == 36          # one UUID group per episode
+        g = dict(top[names[0]].items())
+        assert sorted(g) == ['hostname', 'timestamp', 'transitions[]']       # a list is '<key>[]' ...
+        tr = dict(g['transitions[]'].items())
+        assert sorted(tr) == ['0', '1', '2']                                 # ... of groups named by the index
+        t0 = dict(tr['0'].items())
+        assert sorted(t0) == ['action', 'info', 'reward', 'state']
+        back = [H.read_data_from_hdf5(top[n]) for n in names]
+    for e, b in zip(eps, back):
+        assert b['hostname'] == e['hostname'] and len(b['transitions']) == len(e['transitions'])
+        for te, tb in zip(e['transitions'], b['transitions']):
+            assert tb['info'] is None and tb['reward'] == te['reward']       # None <-> 'None'
+            assert np.array_equal(tb['action'], te['action'])
+            for k in te['state']:
+                assert np.array_equal(tb['state'][k], te['state'][k])
+
+
+def test_write_calls_follow_the_reference_rules():
+    """Against a recording h5py-like group: gzip-9 for >= 100 elements, plain datasets below, 'None' strings."""
+    calls = []
+
+    class G(object):
+        def __init__(self, path):
+            self.path = path
+
+        def create_group(self, k):
+            calls.append(('group', self.path + '/' + k)); return G(self.path + '/' + k)
+
+        def create_dataset(self, k, data=None, **kw):
+            calls.append(('dataset', self.path + '/' + k, np.asarray(data).size, kw))
+
+        def __setitem__(self, k, v):
+            calls.append(('set', self.path + '/' + k, v))
+    H.write_data_to_hdf5(G(''), {'a': np.zeros(100), 'b': np.zeros(99), 'c': None, 'd': {'e': 1.5}, 'l': [{'x': 1}, np.ones(3)]})
+    assert ('dataset', '/a', 100, {'compression': 'gzip', 'compression_opts': 9}) in calls
+    assert ('dataset', '/b', 99, {}) in calls and ('set', '/c', 'None') in calls
+    assert ('group', '/d') in calls and ('group', '/l[]') in calls and ('group', '/l[]/0') in calls and ('group', '/l[]/1') in calls
+
+
+def test_episodes_from_rollout_buffers():
+    K, N = 4, 3
+    rng = np.random.RandomState(1)
+    first = {'position': rng.rand(N, 4, 3)}
+    obs = {'position': rng.rand(K, N, 4, 3)}
+    actions, rewards = rng.rand(K, N, 4), rng.rand(K, N)
+    dones = np.zeros((K, N), np.uint8); dones[1, 0] = 1; dones[3, 1] = 1
+    eps = H.episodes_from_rollout(first, obs, actions, rewards, dones)
+    by_env = {}
+    for e in eps:
+        by_env.setdefault(e['env'], []).append(e)
+    assert [len(e['transitions']) for e in by_env[0]] == [2, 1]       # done after 2 steps; step 2 unobserved start -> step 3 only
+    assert [len(e['transitions']) for e in by_env[1]] == [4] and [len(e['transitions']) for e in by_env[2]] == [4]
+    t = by_env[2][0]['transitions']
+    assert np.array_equal(t[0]['state']['position'], first['position'][2]) and np.array_equal(t[1]['state']['position'], obs['position'][0, 2])

@@ -25,6 +25,8 @@ def main():
     ap.add_argument('--task', default=None)
     ap.add_argument('--layout_id', type=int, default=0)
     ap.add_argument('--max_steps', type=int, default=4)
+    ap.add_argument('--output_dir', default=None, help='save the episodes (HDF5 layout of the reference, run_env.py:229-247)')
+    ap.add_argument('--num_episodes_per_file', type=int, default=1000)
     args = ap.parse_args()
     import numpy as np
     from robovat_amd import configs, envs, policies
@@ -35,9 +37,18 @@ def main():
         env = envs.PushEnv(config=cfg, seed=args.seed, worker_id=args.worker_id)
         policy = getattr(policies, args.policy)(env)
         t0 = time.time()
+        from robovat_amd.io import hdf5_utils
+        in_file, path = 0, None
         for i, episode in generate_episodes(env, policy, args.num_steps, args.num_episodes):
             r = sum(t['reward'] for t in episode['transitions'])
             print('episode %d: %d steps, return %.3f, %.2f s' % (i, len(episode['transitions']), r, time.time() - t0))
+            if args.output_dir:
+                if in_file == 0:
+                    os.makedirs(args.output_dir, exist_ok=True)
+                    path = os.path.join(args.output_dir, 'episodes_%s.hdf5' % time.strftime('%Y-%m-%d-%H-%M-%S'))
+                with hdf5_utils.open_store(path) as fout:
+                    hdf5_utils.append_episode(fout, episode)
+                in_file = (in_file + 1) % args.num_episodes_per_file
     else:
         env = envs.VecPushEnv(args.num_envs, config=cfg, seed=args.seed)
         env.reset()
