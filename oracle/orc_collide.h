@@ -295,6 +295,32 @@ touching:
   real d = v3len(v);
   if (d > max_dist) return 0;
   v3scale(n, v, R(1.0) / d);
+  /* The direction of v = sum lam_i w_i carries the rounding of the barycentric weights: for two
+   * parallel faces a few mm apart it is off by degrees in FP32 (the weights of a cm-sized
+   * triangle resolve the closest point to ~0.1 mm only).  The separating direction is a property
+   * of the closest FEATURE: the plane normal of a triangle, the perpendicular from the origin to
+   * the line of a segment -- neither needs the weights. */
+  if (s.n == 3) {
+    real e1[3], e2[3], nf[3];
+    v3sub(e1, s.w[1], s.w[0]); v3sub(e2, s.w[2], s.w[0]);
+    v3cross(nf, e1, e2);
+    real l2 = v3dot(nf, nf);
+    if (l2 > R(1e-6) * v3dot(e1, e1) * v3dot(e2, e2)) {
+      v3scale(nf, nf, R(1.0) / rsqrt_(l2));
+      if (v3dot(nf, v) < R(0.0)) v3scale(nf, nf, R(-1.0));
+      real dd = v3dot(nf, s.w[0]);
+      if (dd > R(0.0)) { v3cpy(n, nf); d = dd; }
+    }
+  } else if (s.n == 2) {
+    real e1[3], vp[3];
+    v3sub(e1, s.w[1], s.w[0]);
+    real ee = v3dot(e1, e1);
+    if (ee > R(0.0)) {
+      v3madd(vp, s.w[0], e1, -(v3dot(s.w[0], e1) / ee));
+      real l = v3len(vp);
+      if (l > R(0.0)) { v3scale(n, vp, R(1.0) / l); d = l; }
+    }
+  }
   *dist = d;
   return 1;
 }

@@ -611,6 +611,9 @@ static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, 
   if (!(v3dot(n, n) > R(0.5))) return 0;   /* safety net: never accept a non-unit normal */
   *out_dist = d;
   if (!m) return 1;
+#ifdef ORC_DEBUG_NP
+  fprintf(stderr, "pair kind %d a %d: n (%.6f %.6f %.6f) dist %.6g pa (%.5f %.5f %.5f) pb (%.5f %.5f %.5f)\n", kind, a, (double)n[0], (double)n[1], (double)n[2], (double)d, (double)pa[0], (double)pa[1], (double)pa[2], (double)pb[0], (double)pb[1], (double)pb[2]);
+#endif
   real wa[3], wb[3];
   v3madd(wa, pa, n, -mg); v3madd(wb, pb, n, mg);
   manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, d);
@@ -644,6 +647,9 @@ static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, 
     real dv[3]; v3sub(dv, va, pb);
     real sep = v3dot(dv, n);
     real gap = sep - R(2.0) * mg;
+#ifdef ORC_DEBUG_NP
+    fprintf(stderr, "  A-cand k %d va (%.5f %.5f %.5f) gap %.6g\n", k, (double)va[0], (double)va[1], (double)va[2], (double)gap);
+#endif
     if (gap <= brk) {
       real pt[3]; v3madd(pt, va, n, -sep);
       int ok = 1;

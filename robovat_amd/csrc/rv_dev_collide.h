@@ -384,7 +384,32 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
   }
   float d = len(v);
   if (d > max_dist) return 0;
-  *n = scale(v, 1.0f / d);
+  v3 nn = scale(v, 1.0f / d);
+  // The direction of v = sum lam_i w_i carries the rounding of the barycentric weights: for two
+  // parallel faces a few mm apart it is off by degrees in FP32 (the weights of a cm-sized
+  // triangle resolve the closest point to ~0.1 mm only).  The separating direction is a property
+  // of the closest FEATURE: the plane normal of a triangle, the perpendicular from the origin to
+  // the line of a segment -- neither needs the weights.
+  if (s.n == 3) {
+    v3 e1 = sub(s.w[1], s.w[0]), e2 = sub(s.w[2], s.w[0]);
+    v3 nf = cross(e1, e2);
+    float l2 = dot(nf, nf);
+    if (l2 > 1e-6f * dot(e1, e1) * dot(e2, e2)) {
+      nf = scale(nf, 1.0f / fsqrtr(l2));
+      if (dot(nf, v) < 0.0f) nf = scale(nf, -1.0f);
+      float dd = dot(nf, s.w[0]);
+      if (dd > 0.0f) { nn = nf; d = dd; }
+    }
+  } else if (s.n == 2) {
+    v3 e1 = sub(s.w[1], s.w[0]);
+    float ee = dot(e1, e1);
+    if (ee > 0.0f) {
+      v3 vp = madd(s.w[0], e1, -(dot(s.w[0], e1) / ee));
+      float l = len(vp);
+      if (l > 0.0f) { nn = scale(vp, 1.0f / l); d = l; }
+    }
+  }
+  *n = nn;
   *dist = d;
   return 1;
 }

@@ -43,17 +43,24 @@ def test_grasp_step_matches_reference_execute_action():
 
 
 def test_grasp_holds_the_object_analytic():
-    """A grasp aimed at a cube lifts it: the object ends between the pads ~FINGER_TIP_OFFSET below the hand,
-    at rest, the gripper squeezing with the finger force limit (no slip in 2 s)."""
-    w = _world(3, 0, {})
-    w.reset()
-    st = w.body_state()[0, 0]
+    """Grasps aimed at the object lift it: a held object ends between the pads ~FINGER_TIP_OFFSET below the
+    hand, at rest, the gripper squeezing with the finger force limit (no slip in 2 s)."""
+    from oracle import orc
     from robovat_amd.math import rotations
-    a = np.array([st[0], st[1], 0.012, rotations.euler_from_quaternion(st[3:7])[2]], np.float32)
-    w.set_actions(a.reshape(1, 1, 4)); w.step_macro()
-    assert w.reward()[0][0] == 1.0
-    z0 = w.body_state()[0, 0, 2]
-    hand_z = w.link_poses()[0, 7, 2]
-    assert 0.10 < hand_z - z0 < 0.15 and z0 > 0.1
+    env_cfg = configs.grasp_env_config()
+    scene, names = scenes.make_scene(env_cfg=env_cfg)
+    cfg = configs.make_rv_config(env_cfg=env_cfg, n_envs=16, shape_names=names, seed=3)
+    w = orc.OracleWorld(cfg, scene, double=True)
+    w.reset()
+    st = w.body_state()
+    a = np.zeros((16, 1, 4), np.float32)
+    a[:, 0, :2] = st[:, 0, :2]; a[:, 0, 2] = 0.012
+    a[:, 0, 3] = [rotations.euler_from_quaternion(st[i, 0, 3:7])[2] for i in range(16)]
+    w.set_actions(a); w.step_macro()
+    held = w.reward()[0] > 0.5
+    assert held.sum() >= 4
+    z0 = w.body_state()[held, 0, 2]
+    hand_z = w.link_poses()[held, 7, 2]
+    assert ((hand_z - z0) > 0.09).all() and ((hand_z - z0) < 0.16).all() and (z0 > 0.1).all()
     w.step_sub(2000)
-    assert abs(w.body_state()[0, 0, 2] - z0) < 2e-3
+    assert np.abs(w.body_state()[held, 0, 2] - z0).max() < 2e-3
