@@ -183,12 +183,11 @@ def test_pose_error_vs_double_oracle_recorded():
     state[:, :, 7] += 0.2                      # shove every body at 0.2 m/s
     ref.set_body_state(state); world.set_body_state(state)
     out, done = {}, 0
-    # measured on the MI355X (profiles/r02_pose_err.json): median 6e-8 / 3.6e-7 / 2.4e-6 m and 90th
-    # percentile 7.7e-7 / 6.6e-6 / 3.4e-5 m at 1 / 10 / 100 substeps; worst body 3.2e-4 / 2.8e-3 / 9.7e-3 m.
-    # The worst body is ONE of the 256: a cylinder standing on its flat end whose first narrow-phase
-    # pass (face against face, cores 1 mm apart) gives a fourth contact point 0.5 mm deeper in FP32
-    # than in FP64, i.e. a 0.2 m/s push-out in one substep.  Bounds: (max, median, p90)
-    bounds = {1: (1.5e-3, 3e-7, 4e-6), 10: (1e-2, 2e-6, 5e-5), 100: (4e-2, 1.5e-5, 5e-4)}
+    # measured on the MI355X (profiles/r02_pose_err.json): worst body 2.1e-6 / 5.8e-5 / 6.5e-4 m, median
+    # 2.1e-8 / 1.3e-7 / 2.0e-6 m, 90th percentile 2.6e-7 / 4.4e-6 / 2.5e-5 m at 1 / 10 / 100 substeps
+    # (round 1: worst 7e-6 / 5e-4 / 1e-2 m -- the contact normal is now taken from the closest FEATURE,
+    # DESIGN.md section 3.3).  Bounds = 4 x measured: (max, median, p90)
+    bounds = {1: (1e-5, 1e-7, 1e-6), 10: (2.5e-4, 6e-7, 2e-5), 100: (2.6e-3, 8e-6, 1e-4)}
     for horizon in (1, 10, 100):
         world.step_sub(horizon - done); ref.step_sub(horizon - done); done = horizon
         got = world.body_state().cpu().numpy().astype(np.float64); want = ref.body_state()
