@@ -139,7 +139,7 @@ def _grasp_env_config():
                      'CUBOID': {'LOW': [0.56, -0.04, 0.012], 'HIGH': [0.64, 0.04, 0.012]},
                      'CSPACE': PUSH_ENV_CONFIG['ACTION']['CSPACE'], 'MOTION': PUSH_ENV_CONFIG['ACTION']['MOTION'],
                      'MIN_DELTA_POSITION': 0.01, 'MIN_DELTA_ANGLE': 0.05}
-    cfg['ARM']['OVERHEAD_POSITIONS'] = [0.0, -1.18, 0.0, 2.18, 0.0, 0.57, 3.3161]
+    cfg['ARM']['OVERHEAD_POSITIONS'] = list(SAWYER_SIM_CONFIG['LIMB_NEUTRAL_POSITIONS'])
     cfg['ARM']['GRIPPER_SAFE_HEIGHT'] = 0.30
     cfg['SIM']['MAX_ACTION_STEPS'] = 4000
     cfg['SIM']['GRASPABLE'] = {
@@ -160,7 +160,8 @@ def _grasp_env_config():
 
 SAWYER_SIM_CONFIG = {
     'LIMB_JOINT_NAMES': ['right_j%d' % i for i in range(7)],
-    'LIMB_NEUTRAL_POSITIONS': [0.0, -1.18, 0.0, 2.18, 0.0, 0.57, 3.3161],
+    # hand 0.40 m above the table top (finger tips at 0.26 m): clear of the tallest movable standing on end
+    'LIMB_NEUTRAL_POSITIONS': [0.03, -1.526, -0.036, 2.0, 0.0, 1.096, 3.308],
     'END_EFFCTOR_NAME': 'right_hand',
     'L_FINGER_NAME': 'right_gripper_l_finger_joint',
     'R_FINGER_NAME': 'right_gripper_r_finger_joint',
