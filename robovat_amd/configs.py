@@ -116,7 +116,7 @@ PUSH_ENV_CONFIG = {
     'PHYSICS': {
         'TIME_STEP': 1e-3, 'GRAVITY_Z': -9.8,
         'SOLVER_ITERS': 8, 'ERP': 0.2, 'SLOP': 0.0005, 'MARGIN': 0.001,
-        'BREAKING': 0.01, 'WARMSTART': 0.85, 'MAX_PUSHOUT': 0.5,
+        'BREAKING': 0.02, 'WARMSTART': 0.85, 'MAX_PUSHOUT': 0.5,    # BREAKING = Bullet's gContactBreakingThreshold
         'LINEAR_DAMPING': 0.04, 'ANGULAR_DAMPING': 0.04,
         'CONTACT_QUERY_DIST': 0.001, 'ARM_FRICTION': 0.8,
         'SOLVER_TOL': 1e-5,

@@ -61,6 +61,12 @@ __device__ __forceinline__ void g_shared_profg(int g, int i, unsigned long long 
 #define RV_STREAM_RESET  1u
 #define RV_STREAM_RANDOM 2u
 #define RV_STREAM_HEUR   3u
+#ifdef RV_EMU_COUNT
+static long rv_emu_cnt[32];      // ad-hoc event counters of the host emulation (tools only)
+#define RV_CNT(i, n) rv_emu_cnt[i] += (n);
+#else
+#define RV_CNT(i, n)
+#endif
 #define RV_STEPS_TO_CHECK_DONE 100   // controllable_body.py:21
 #define RV_STEPS_TO_UPDATE_IK  10    // controllable_body.py:24
 
@@ -176,6 +182,8 @@ struct Scratch {
   float cdelta[3][RV_NCOL];                                 // coasting: box travel bound per candidate length
   float clr_t[RV_NCOL], clr_b[RV_NCOL]; int clr_valid;      // coasting: clearances left (table, bodies)
   float jtravel[RV_NJ];                                     // coasting: joint path lengths of the chunk
+  float ccoef[RV_NCOL][RV_NJ];                              // coasting: lever of joint j on collider box col (col_travelled's weights)
+  int fused_n, fused_pending;
   int coast_unsafe[3];
   float jlen[RV_NLIMB + 1], colext[RV_NCOL];   // |jpos_i|; collider extent from its frame origin
   float fext[RV_NFRAME], fmot[RV_NFRAME];     // per frame: largest collider extent; vertex travel this substep
@@ -273,7 +281,9 @@ RV_DEV_NOINLINE int arm_ik(const Consts& K, const float* q0, const float* pose, 
   for (int i = 0; i < RV_NLIMB; ++i) q[i] = q0[i];
   v3 tp = ld3(pose);
   q4 tq = ldq(pose + 3);
+  RV_CNT(0, 1)
   for (int it = 0; it < c->ik_iters; ++it) {
+    RV_CNT(1, 1)
     LimbFK F;
     fk_limb(a, q, F, nullptr);
     float err[6];
@@ -1380,6 +1390,24 @@ static long rv_emu_coasted = 0;
 // bound is rigorous (joint travel from |qd|, v_max and a_max; vertex travel <=
 // sum of joint travel x reach), so the result is bit-identical to stepping.
 // Returns m (0: step normally).  Needs fresh kinematics (S.s.kin_fresh).
+// clearances of collider box col on fresh kinematics: how far the box is from the contact range
+// of the table and of the nearest body
+RV_DEV void coast_measure_clearances(Shared& S, const Consts& K, const int col) {
+  const rv_config* c = K.cfg; const DevEnv& e = S.e;
+  v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
+  v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
+  const float zc = S.s.colmin[col][2] - e.table_z - c->margin - c->contact_query_dist;
+  const float sc = fsqrtr(sphere_box_dist2(ld3(S.s.colc[col]), tc, th)) - (S.s.colr[col] + c->breaking);
+  const float tclear = zc > sc ? zc : sc;                 // either test rejecting is enough
+  float bclear = 1e30f;
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (!body_present(e, b)) continue;
+    float d = fsqrtr(aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col])) - c->breaking;
+    d = fmaxr(d, S.s.sep[b][col]);   // the distance bound left by the last wake query, if better
+    bclear = fminr(bclear, d);
+  }
+  S.s.clr_t[col] = tclear; S.s.clr_b[col] = bclear;
+}
 RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining, int* kidx) {
   const rv_config* c = K.cfg;
   const rv_arm* arm = K.arm;
@@ -1404,24 +1432,8 @@ RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining, int* ki
       const float dt = c->dt;
       // clearances: measured on fresh kinematics, else what the previous coasting
       // chunks left of them (each chunk subtracts its travel bound)
-      float tclear, bclear;
-      if (fresh) {
-        v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
-        v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
-        const float zc = S.s.colmin[col][2] - e.table_z - c->margin - c->contact_query_dist;
-        const float sc = fsqrtr(sphere_box_dist2(ld3(S.s.colc[col]), tc, th)) - (S.s.colr[col] + c->breaking);
-        tclear = zc > sc ? zc : sc;                 // either test rejecting is enough
-        bclear = 1e30f;
-        for (int b = 0; b < RV_MAXB; ++b) {
-          if (!body_present(e, b)) continue;
-          float d = fsqrtr(aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col])) - c->breaking;
-          d = fmaxr(d, S.s.sep[b][col]);   // the distance bound left by the last wake query, if better
-          bclear = fminr(bclear, d);
-        }
-        S.s.clr_t[col] = tclear; S.s.clr_b[col] = bclear;
-      } else {
-        tclear = S.s.clr_t[col]; bclear = S.s.clr_b[col];
-      }
+      if (fresh) coast_measure_clearances(S, K, col);
+      const float tclear = S.s.clr_t[col], bclear = S.s.clr_b[col];
       if (lane == 0) S.s.clr_valid = 1;
       for (int k = 0; k < 3; ++k) {
         const int m = m0 >> k;
@@ -1551,10 +1563,31 @@ RV_DEV float col_travelled(const Shared& S, const Consts& K, const int col) {
   if (f >= 8) tr += S.s.jtravel[f - 1];
   return tr * 1.02f + 1e-6f;
 }
+// after coasted substeps: FK / colliders are NOT refreshed: consecutive chunks run on the clearances left
+// over (arm_refresh_kinematics is called by whoever needs frames or fresh clearances)
+RV_DEV void coast_finish(Shared& S, const Consts& K) {
+  RV_LANES_BEGIN
+    DevEnv& e = S.e;
+    if (lane == 0) e.flag_arm_table = 0;
+    if (lane >= 1 && lane <= RV_MAXB) e.flag_arm_body[lane - 1] = 0;
+    // what the boxes really travelled (joint path lengths x reach; never more than the
+    // bound the chunk was admitted with) comes off the distance bounds and clearances
+    if (lane >= 8 && lane < 8 + RV_MAXB * RV_NCOL) {
+      int t = lane - 8, b = t / RV_NCOL, col = t - b * RV_NCOL;
+      S.s.sep[b][col] = fmaxr(S.s.sep[b][col] - col_travelled(S, K, col), 0.0f);
+    }
+    if (lane >= 48 && lane < 48 + RV_NCOL) {
+      int col = lane - 48; float d = col_travelled(S, K, col);
+      S.s.clr_t[col] = S.s.clr_t[col] - d; S.s.clr_b[col] = S.s.clr_b[col] - 2.0f * d;
+    }
+    if (lane == 63) S.s.kin_fresh = 0;
+  RV_LANES_END
+}
 RV_DEV void coast_substeps(Shared& S, const Consts& K, const int m, const int kidx) {
 #ifdef RV_EMU_COUNT
   rv_emu_coasted += m;
 #endif
+  RV_CNT(8, m)
   RV_LANES_BEGIN
     if (lane < RV_NJ) S.s.jtravel[lane] = 0.0f;
   RV_LANES_END
@@ -1576,24 +1609,278 @@ RV_DEV void coast_substeps(Shared& S, const Consts& K, const int m, const int ki
     if (r >= 2) { motors_only_substeps(S, K, r); i += r; }
     else { arm_motor_phases(S, K, 0, 1); i += 1; }
   }
-  // FK / colliders are NOT refreshed here: consecutive chunks run on the clearances left
-  // over (arm_refresh_kinematics is called by whoever needs frames or fresh clearances)
+  coast_finish(S, K);
+}
+
+// ---- fused coasting of the phase loop ---------------------------------------
+// While the arm moves through free space the phase loop of PushEnv._execute_action is, substep
+// after substep: ControllableBody.update finds nothing to change (the IK solution it tracks has
+// converged, nothing is reached, nothing timed out), the joint motors advance, and every
+// STEPS_CHECK substeps the phase machine finds the robot "not ready".  coast_fused() runs exactly
+// those substeps with the joint state in registers (lane j = joint j), for as long as
+//   * ControllableBody.update(st) provably has no effect            (ctl_update_noop)
+//   * the tick after a substep provably has no effect                (ctl_tick_noop)
+//   * no collider box can have come within contact range of anything: the joint path lengths,
+//     weighted with the largest lever of each joint, stay below the smallest clearance left.
+// It stops BEFORE the first substep / AT the first tick that needs the real code, so the state it
+// leaves is the state plain stepping would have at that point (bit for bit).
+struct CoastCtl {
+  int lt_on, jt_on, applied, from_ik, lt_has_stop, lt_more, jt_has_stop, jt_limb;
+  float lt_stop, jt_stop, dt;
+  int interrupt, has_budget, max_phase_steps;
+};
+RV_DEV int ctl_link_done(const CoastCtl& C, int st) {        // check_link_target_done at step st
+  if (!C.lt_has_stop) return 1;
+  if (C.dt * (float)st >= C.lt_stop) return 1;
+  if (!C.lt_more) return 1;
+  return 0;
+}
+RV_DEV int ctl_joint_done(const CoastCtl& C, int st, int reached) {   // check_joint_target_done
+  if (!C.jt_has_stop) return 1;
+  if (C.dt * (float)st >= C.jt_stop) return 1;
+  if (reached) return 1;
+  return 0;
+}
+// does control_update() at step st have anything to do at all?
+RV_DEV int ctl_update_due(const CoastCtl& C, int st) {
+  if (!C.lt_on && !C.jt_on) return 0;
+  if (st % RV_STEPS_TO_CHECK_DONE != 0 && C.jt_on && C.applied && (!C.lt_on || st % RV_STEPS_TO_UPDATE_IK != 0)) return 0;
+  return 1;
+}
+// ... and if it has: does it leave everything as it is?  reached = check_joints_reached now
+RV_DEV int ctl_update_noop(const CoastCtl& C, int st, int reached) {
+  if (!(C.jt_on && C.applied)) return 0;
+  int ik_updated = 0;
+  if (C.lt_on) {
+    if (st % RV_STEPS_TO_CHECK_DONE == 0 && ctl_link_done(C, st)) return 0;
+    if (st % RV_STEPS_TO_UPDATE_IK == 0) {
+      if (C.from_ik != 2) return 0;          // the IK would be solved again
+      ik_updated = 1;
+      if (reached) return 0;                 // next pose of the path
+    }
+  }
+  if (st % RV_STEPS_TO_CHECK_DONE == 0 || ik_updated) if (ctl_joint_done(C, st, reached)) return 0;
+  return 1;                                  // (the motor targets are written again with the values they hold)
+}
+// phase_tick() at step st: not ready, nothing reset, no interrupt (the contact flags are clear
+// while coasting, so check_safety passes in the phases the loop visits)
+RV_DEV int ctl_tick_noop(const CoastCtl& C, int st, int reached) {
+  if (C.interrupt || !C.has_budget || st >= C.max_phase_steps) return 0;
+  if (C.lt_on && ctl_link_done(C, st)) return 0;
+  if (C.jt_on && ctl_joint_done(C, st, reached)) return 0;
+  return C.lt_on || (C.jt_on && C.jt_limb);
+}
+RV_DEV CoastCtl coast_ctl_load(const Shared& S, const Consts& K) {
+  const DevEnv& e = S.e;
+  CoastCtl C;
+  C.lt_on = e.lt.active; C.jt_on = e.jt.active; C.applied = S.s.jt_applied; C.from_ik = e.jt.from_ik;
+  C.lt_has_stop = e.lt.has_stop; C.lt_more = e.lt.has_pose || e.lt.nq != 0; C.jt_has_stop = e.jt.has_stop;
+  C.jt_limb = 0;
+  for (int i = 0; i < e.jt.n_idx; ++i) if (e.jt.idx[i] < RV_NLIMB) C.jt_limb = 1;
+  C.lt_stop = e.lt.stop_t; C.jt_stop = e.jt.stop_t; C.dt = K.cfg->dt;
+  C.interrupt = S.s.interrupt; C.has_budget = S.s.has_budget; C.max_phase_steps = S.s.max_phase_steps;
+  return C;
+}
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+template <int N> RV_DEV float row_ror_add(float x) {
+  float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
+  return o + x;
+}
+RV_DEV int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+RV_DEV float unif(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
+#endif
+// returns the number of substeps taken; *tick_pending (why it stopped): 0 ControllableBody.update has
+// work to do, 1 the clearance is used up, 2 at a tick the phase machine must see
+RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, int* tick_pending) {
+  const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
+  *tick_pending = 0;
+  if (K.stop_after != 0 || !S.e.arm_enabled) return 0;
+  const int fresh = S.s.kin_fresh;
+  if (!fresh && !S.s.clr_valid) return 0;
+  {
+    int any_on = 0;
+#pragma unroll
+    for (int b = 0; b < RV_MAXB; ++b) any_on |= body_on(S.e, b);
+    if (any_on) return 0;
+  }
+  if (!fresh) {       // clearances left over by the last chunk: anything left at all?
+    float cmin = 1e30f;
+    for (int col = 0; col < RV_NCOL; ++col) cmin = fminr(cmin, fminr(S.s.clr_t[col], 0.5f * S.s.clr_b[col]));
+    if (!(cmin > 2e-4f)) { RV_CNT(11, 1) *tick_pending = 1; return 0; }
+  }
   RV_LANES_BEGIN
-    DevEnv& e = S.e;
-    if (lane == 0) e.flag_arm_table = 0;
-    if (lane >= 1 && lane <= RV_MAXB) e.flag_arm_body[lane - 1] = 0;
-    // what the boxes really travelled (joint path lengths x reach; never more than the
-    // bound the chunk was admitted with) comes off the distance bounds and clearances
-    if (lane >= 8 && lane < 8 + RV_MAXB * RV_NCOL) {
-      int t = lane - 8, b = t / RV_NCOL, col = t - b * RV_NCOL;
-      S.s.sep[b][col] = fmaxr(S.s.sep[b][col] - col_travelled(S, K, col), 0.0f);
-    }
-    if (lane >= 48 && lane < 48 + RV_NCOL) {
-      int col = lane - 48; float d = col_travelled(S, K, col);
-      S.s.clr_t[col] = S.s.clr_t[col] - d; S.s.clr_b[col] = S.s.clr_b[col] - 2.0f * d;
-    }
-    if (lane == 63) S.s.kin_fresh = 0;
+    if (fresh && lane < RV_NCOL) coast_measure_clearances(S, K, lane);
+    if (lane == 63) S.s.clr_valid = 1;
+    if (lane >= 32 && lane < 32 + RV_NJ) S.s.jtravel[lane - 32] = 0.0f;
   RV_LANES_END
+  const int st0 = S.e.sim_steps;
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+  CoastCtl C = coast_ctl_load(S, K);
+  C.lt_on = uni(C.lt_on); C.jt_on = uni(C.jt_on); C.applied = uni(C.applied); C.from_ik = uni(C.from_ik);
+  C.lt_has_stop = uni(C.lt_has_stop); C.lt_more = uni(C.lt_more); C.jt_has_stop = uni(C.jt_has_stop); C.jt_limb = uni(C.jt_limb);
+  C.lt_stop = unif(C.lt_stop); C.jt_stop = unif(C.jt_stop); C.dt = unif(C.dt);
+  C.interrupt = uni(C.interrupt); C.has_budget = uni(C.has_budget); C.max_phase_steps = uni(C.max_phase_steps);
+  DevEnv& e = S.e;
+  const int lane = (int)threadIdx.x;
+  const int j = lane < RV_NJ ? lane : RV_NJ - 1;
+  const bool mine = lane < RV_NJ;
+  const float dt = C.dt;
+  float q = e.q[j], qd = e.qd[j];
+  const int on = e.motor_on[j];
+  const float kp = e.motor_kp[j], mq = e.motor_q[j], vmax = e.vmax_cmd[j];
+  const float amax_dt = arm->a_max[j] * dt, lo = arm->q_lo[j], hi = arm->q_hi[j];
+  // lanes 16 .. 16 + RV_NCOL - 1 watch one collider box each
+  const bool iscol = lane >= 16 && lane < 16 + RV_NCOL;
+  const int col = iscol ? lane - 16 : 0;
+  float cf[RV_NJ];
+#pragma unroll
+  for (int k = 0; k < RV_NJ; ++k) cf[k] = S.s.ccoef[col][k];
+  const float clt = S.s.clr_t[col], clb = S.s.clr_b[col];
+  // this lane's joint in the joint target
+  int tgt = 0; float tpos = 0.0f;
+  {
+    const int n_idx = uni(e.jt.n_idx);
+    for (int i = 0; i < n_idx; ++i) if (e.jt.idx[i] == lane) { tgt = 1; tpos = e.jt.pos[i]; }
+  }
+  const float pos_thr = unif(e.jt.pos_thr), vel_thr = unif(e.jt.vel_thr);
+  const int has_vel = uni(e.jt.has_vel);
+  float trav = 0.0f;
+  RV_PROF(21)
+  int st = uni(st0), pending = 0;    // pending: 0 update due, 1 clearance used up, 2 tick
+  for (;;) {
+    if (ctl_update_due(C, st)) {
+      int reached = 1;
+      if (C.jt_on) {
+        const bool ok = fabsr(tpos - q) < pos_thr && (!has_vel || fabsr(0.0f - qd) < vel_thr);
+        reached = __builtin_amdgcn_ballot_w64(tgt && !ok) == 0;
+      }
+      if (!ctl_update_noop(C, st, reached)) break;
+    }
+    float vd = 0.0f, ratio = 1.0f;
+    if (on) {
+      vd = kp * (mq - q) / dt;
+      float raw = fabsr(vd);
+      if (j < RV_NLIMB && raw > vmax) ratio = vmax / raw;
+    }
+    if (!mine) ratio = 1.0f;
+    float sync = fminr(1.0f, ratio);
+    sync = row_ror_min<8>(sync); sync = row_ror_min<4>(sync); sync = row_ror_min<2>(sync); sync = row_ror_min<1>(sync);
+    float vdd = 0.0f;
+    if (on) {
+      vdd = vd;
+      if (j < RV_NLIMB) vdd = vdd * sync;
+      vdd = fclampr(vdd, -vmax, vmax);
+    }
+    float dv = fclampr(vdd - qd, -amax_dt, amax_dt);
+    float qdn = qd + dv;
+    float qn = q + qdn * dt;
+    if (qn < lo) { qn = lo; qdn = 0.0f; }
+    if (qn > hi) { qn = hi; qdn = 0.0f; }
+    const float travn = trav + fabsr(qdn) * dt;
+    // the boxes after this substep: still out of reach of everything?
+    float T = 0.0f;
+#pragma unroll
+    for (int k = 0; k < RV_NJ; ++k) T = T + cf[k] * rdlane(travn, k);
+    const float D = T * 1.02f + 1e-4f;
+    if (__builtin_amdgcn_ballot_w64(iscol && !(clt > D && clb > 2.0f * D)) != 0) { pending = 1; break; }   // no: this substep is not taken
+    q = qn; qd = qdn; trav = travn; ++st;
+    if (st % steps_check == 0) {
+      int reached = 1;
+      if (C.jt_on) {
+        const bool ok = fabsr(tpos - q) < pos_thr && (!has_vel || fabsr(0.0f - qd) < vel_thr);
+        reached = __builtin_amdgcn_ballot_w64(tgt && !ok) == 0;
+      }
+      if (!ctl_tick_noop(C, st, reached)) { pending = 2; break; }
+    }
+  }
+  const int n = st - uni(st0);
+  if (n > 0) {
+    if (mine) { e.q[j] = q; e.qd[j] = qd; S.s.jtravel[j] = trav; }
+    if (lane == 0) { e.sim_steps += n; e.substeps_last += n; }
+  }
+  if (lane == 0) { S.s.fused_n = n; S.s.fused_pending = pending; }
+  __syncthreads();
+  RV_PROF(22)
+#else
+  {
+    DevEnv& e = S.e;
+    const CoastCtl C = coast_ctl_load(S, K);
+    const float dt = c->dt;
+    float trav[RV_NJ];
+    for (int j = 0; j < RV_NJ; ++j) trav[j] = 0.0f;
+    int st = st0, pending = 0;
+    for (;;) {
+      if (ctl_update_due(C, st) && !ctl_update_noop(C, st, check_joints_reached(e))) { RV_CNT(4, 1) break; }
+      float vdr[RV_NJ], sync = 1.0f, qn_[RV_NJ], qdn_[RV_NJ], tn_[RV_NJ];
+      for (int j = 0; j < RV_NJ; ++j) {
+        float vd = 0.0f, ratio = 1.0f;
+        if (e.motor_on[j]) {
+          vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) / dt;
+          float raw = fabsr(vd);
+          if (j < RV_NLIMB && raw > e.vmax_cmd[j]) ratio = e.vmax_cmd[j] / raw;
+        }
+        vdr[j] = vd;
+        sync = fminr(sync, ratio);
+      }
+      for (int j = 0; j < RV_NJ; ++j) {
+        float vdd = 0.0f;
+        if (e.motor_on[j]) {
+          vdd = vdr[j];
+          if (j < RV_NLIMB) vdd = vdd * sync;
+          vdd = fclampr(vdd, -e.vmax_cmd[j], e.vmax_cmd[j]);
+        }
+        float dv = fclampr(vdd - e.qd[j], -arm->a_max[j] * dt, arm->a_max[j] * dt);
+        float qd = e.qd[j] + dv;
+        float qn = e.q[j] + qd * dt;
+        if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
+        if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
+        qn_[j] = qn; qdn_[j] = qd; tn_[j] = trav[j] + fabsr(qd) * dt;
+      }
+      int out_of_reach = 1;
+      for (int col = 0; col < RV_NCOL; ++col) {
+        float Tc = 0.0f;
+        for (int j = 0; j < RV_NJ; ++j) Tc = Tc + S.s.ccoef[col][j] * tn_[j];
+        const float D = Tc * 1.02f + 1e-4f;
+        if (!(S.s.clr_t[col] > D && S.s.clr_b[col] > 2.0f * D)) {
+          out_of_reach = 0;
+#ifdef RV_EMU_COUNT
+          if (getenv("RV_EMU_TRACE")) fprintf(stderr, "  violator col %d frame %d: clr_t %.4f clr_b %.4f D %.4f\n", col, arm->col_frame[col], S.s.clr_t[col], S.s.clr_b[col], D);
+#endif
+        }
+      }
+      if (!out_of_reach) { RV_CNT(5, 1) pending = 1; break; }
+      for (int j = 0; j < RV_NJ; ++j) { e.q[j] = qn_[j]; e.qd[j] = qdn_[j]; trav[j] = tn_[j]; }
+      ++st;
+      if (st % steps_check == 0 && !ctl_tick_noop(C, st, check_joints_reached(e))) { pending = 2; break; }
+    }
+    const int n = st - st0;
+    for (int j = 0; j < RV_NJ; ++j) S.s.jtravel[j] = trav[j];
+    e.sim_steps += n; e.substeps_last += n;
+    S.s.fused_n = n; S.s.fused_pending = pending;
+    RV_CNT(2, 1) RV_CNT(3, n) RV_CNT(6, pending == 2) RV_CNT(7, n == 0)
+#ifdef RV_EMU_COUNT
+    if (fresh && getenv("RV_EMU_TRACE")) {
+      int wc = 0; float w = 1e30f; int wt = 0;
+      for (int col = 0; col < RV_NCOL; ++col) {
+        float a = S.s.clr_t[col], b2 = 0.5f * S.s.clr_b[col];
+        if (a < w) { w = a; wc = col; wt = 0; } if (b2 < w) { w = b2; wc = col; wt = 1; }
+      }
+      float T = 0; for (int j = 0; j < RV_NJ; ++j) T += S.s.ccoef[wc][j] * trav[j];
+      fprintf(stderr, "fused fresh phase %d n %d why %d (col %d %s %.4f) T %.4f  qd %.2f %.2f %.2f %.2f %.2f %.2f %.2f\n", e.phase, n, pending, wc, wt ? "body" : "table", w, T,
+              e.qd[0], e.qd[1], e.qd[2], e.qd[3], e.qd[4], e.qd[5], e.qd[6]);
+    }
+#endif
+  }
+#endif
+  const int n_taken = S.s.fused_n;
+  *tick_pending = S.s.fused_pending;
+  if (n_taken == 0) return 0;
+#ifdef RV_EMU_COUNT
+  rv_emu_coasted += n_taken;
+#endif
+  coast_finish(S, K);
+  RV_PROF(19)
+  return n_taken;
 }
 // frames, colliders and AABBs of the current joint state (after coasting)
 RV_DEV void arm_refresh_kinematics(Shared& S, const Consts& K) {
@@ -1987,6 +2274,11 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     mem_[b] = (on_[b] && label[b] == b) ? m_ : 0;
     big_[b] = mem_[b] > 2;
   }
+#ifdef RV_EMU_COUNT
+  { int n1 = 0, n2 = 0, n3 = 0; for (int b = 0; b < RV_MAXB; ++b) { n1 += mem_[b] == 1; n2 += mem_[b] == 2; n3 += mem_[b] > 2; }
+    rv_emu_cnt[13] += n1; rv_emu_cnt[16] += n2; rv_emu_cnt[17] += n3;
+    rv_emu_cnt[14] += (n3 > 0); rv_emu_cnt[15] += (n1 + n2 >= 2); }
+#endif
   const int with_fingers = c->finger_dynamics && arm_on;
   if (with_fingers) {
     RV_LANES_BEGIN
@@ -2220,6 +2512,23 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
   int coast_wait = 0;     // regular substeps to take before coasting is considered again
   for (;;) {
     RV_PROF(7)
+    if (phase_mode && !grasp_mode && coast_wait == 0) {
+      // free-space motion: as many substeps (and ticks that change nothing) as provably possible
+      int why = 0, n = 0;
+      for (;;) {
+        n += coast_fused(S, K, K.cfg->steps_check, &why);
+        RV_PROF(11)
+        if (why != 1 || S.s.kin_fresh) break;     // (fresh clearances that buy nothing: close to something)
+        arm_refresh_kinematics(S, K);             // clearance used up: measure again, go on
+        RV_PROF(10)
+        RV_CNT(12, 1)
+      }
+      RV_PROF(11)
+      if (n > 0) {
+        if (why == 2) break;               // the phase machine has something to do at this tick
+        n_fixed = K.cfg->steps_check - (S.e.sim_steps % K.cfg->steps_check); taken = 0;
+      }
+    }
     if (n_fixed > 0 && coast_wait == 0) {
       int kidx = 0;
       int m = coast_budget(S, K, n_fixed - taken, &kidx);
@@ -2270,7 +2579,9 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
       coast_wait = 8;
     }
     if (coast_wait > 0) --coast_wait;
+    RV_CNT(9, 1)
     if (sim_substep_light(S, K)) {
+      RV_CNT(10, 1)
       RV_PROF(1)
       sim_substep_heavy_call(scene, stop_after);
       RV_PROF(6)
@@ -2543,8 +2854,10 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
       }
     }
   RV_LANES_END
+  RV_PROF(21)
   // phase loop + closing wait_until_stable, in one out-of-line call
   sim_run_call(K.scene, K.stop_after, -1, 0u, 0.005f, 0.005f, 100, 100, 2000);
+  RV_PROF(9)
   RV_LANES_BEGIN
     if (lane == 0) {
       DevEnv& e = S.e; Scratch& s = S.s;
@@ -2578,6 +2891,7 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
       }
     }
   RV_LANES_END
+  RV_PROF(22)
 }
 
 // ------------------------------------------------------------- Grasp4DofEnv --
@@ -2811,6 +3125,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
           for (int k = 7; k < 13; ++k) e.body[i][k] = 0.0f;
         }
       RV_LANES_END
+      RV_PROF(19)
       wait_until_stable(S, K, 1u << i, 0.1f, 0.1f, 100, 100, 500);
       RV_LANES_BEGIN
         if (lane == 0) {
@@ -2829,6 +3144,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
       }
     RV_LANES_END
   }
+  RV_PROF(19)
   wait_until_stable(S, K, 0u, 0.005f, 0.005f, 100, 100, 2000);
   // ArmEnv._reset_robot (arm_env.py:101-107) -> SawyerSim.reboot (sawyer_sim.py:86-171)
   RV_LANES_BEGIN
@@ -2911,14 +3227,17 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
     if (S.e.done) {
       if (!auto_reset) break;
       env_reset(S, K, gid, 0);
+      RV_PROF(19)
     }
     RV_LANES_BEGIN
       if (lane == 0) random_action(c, gid, first_index + k, &S.e.action[0][0]);
     RV_LANES_END
+    RV_PROF(20)
     if (c->env_type == RV_ENV_GRASP) genv_step(S, K, 0); else env_step(S, K, 0);
     RV_LANES_BEGIN
       if (lane == 0 && budget == nullptr) rollout_record(rec, &S.e, (size_t)k * n_envs + env, c);
     RV_LANES_END
+    RV_PROF(23)
     k_end = k + 1;
   }
   // steps not taken (episode over, no auto-reset): reward 0, done
@@ -2954,6 +3273,20 @@ RV_DEV void env_enter(Shared& S, const Consts& K) {
       int b = lane - 32;
       stm(S.s.rot[b], qmat(ldq(S.e.body[b] + 3)));
       if (S.e.active[b]) cache_shape_meta(S, K, b); else S.n_hulls[b] = 0;
+    }
+  RV_LANES_END
+  RV_LANES_BEGIN
+    if (lane < RV_NCOL) {
+      // col_travelled() as weights: travel of box col = sum_j ccoef[col][j] * (path length of joint j)
+      const rv_arm* a = K.arm; const int col = lane;
+      const int f = a->col_frame[col]; const int fl = f < 7 ? f : 7;
+      for (int j = 0; j < RV_NJ; ++j) S.s.ccoef[col][j] = 0.0f;
+      float reach = S.s.colext[col];
+      for (int j = fl; j >= 0; --j) {
+        if (j < RV_NLIMB) S.s.ccoef[col][j] = reach;
+        reach += S.s.jlen[j];
+      }
+      if (f >= 8) S.s.ccoef[col][f - 1] = 1.0f;
     }
   RV_LANES_END
 }

@@ -5,6 +5,7 @@
 // the *kernel's* decomposition (lanes, phases, LDS layout) against the oracle
 // before a GPU is available.  It is never loaded by the product package.
 #define RV_EMULATE 1
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "../../robovat_amd/csrc/rv_dev_env.h"
@@ -32,6 +33,9 @@ static void run_env(EmuWorld* w, int i, int mode, int n_sub, float lin, float an
 }
 
 extern "C" {
+#ifdef RV_EMU_COUNT
+void emu_get_counts(long* out) { for (int i = 0; i < 32; ++i) out[i] = rv_emu_cnt[i]; }
+#endif
 EmuWorld* emu_create(const rv_config* cfg, const rv_scene* scene) {
   EmuWorld* w = (EmuWorld*)calloc(1, sizeof(EmuWorld));
   w->cfg = *cfg; w->scene = *scene; w->n = cfg->n_envs;

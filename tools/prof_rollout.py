@@ -63,6 +63,11 @@ print('substeps %d, awake fraction %.3f' % (st['substeps'], st['awake_substeps']
 print('%-36s %10s %10s' % ('part', 'mean env', 'slowest'))
 for k in list(range(12)) + [18]:
     print('%-46s %9.1f%% %9.1f%%' % (names_[k if k < 12 else 12], 100 * p[:, k].mean() / tot.mean(), 100 * p[slow, k] / tot[slow]))
+xn = {19: 'fused: finish', 20: 'random_action', 21: 'fused: entry (clearances, loads)', 22: 'fused: substep loop', 23: 'rollout_record'}
+for k in sorted(xn):
+    print('%-46s %9.1f%% %9.1f%%' % (xn[k], 100 * p[:, k].mean() / tot.mean(), 100 * p[slow, k] / tot[slow]))
+allt = p[:, :12].sum(axis=1) + p[:, 18:24].sum(axis=1)
+print('all slots / (slots 0-6,18): mean %.3f slowest %.3f' % (allt.mean() / tot.mean(), allt[slow] / tot[slow]))
 print('mean env busy time / slowest env = %.3f' % (tot.mean() / tot.max()))
 gn = ['other (culling, loop, idle rounds)', 'GJK/EPA', 'first manifold point', 'feature stage', 'manifold refresh', '-']
 for g, gname in ((0, 'group 0 of the query stage'),):

@@ -25,16 +25,17 @@ import numpy as np  # noqa: E402
 
 VARIANTS = [
     ('shipped', {}),
+    ('rolling / spinning friction 0 (round-1 value; urdf_template: 0.001 = shipped)', {'PHYSICS.ROLLING_FRICTION': 0.0}),
     ('solver: 50 iterations, no early exit', {'PHYSICS.SOLVER_ITERS': 50, 'PHYSICS.SOLVER_TOL': 0.0}),
     ('sleep: 0.8 m/s, 1 rad/s, 2 s, velocity rule only',
      {'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0, 'PHYSICS.SLEEP_STEPS': 2000, 'PHYSICS.SLEEP_POSITION_WINDOW': 0.0}),
     ('sleep: shipped thresholds, velocity rule only', {'PHYSICS.SLEEP_POSITION_WINDOW': 0.0}),
     ('no deactivation at all', {'PHYSICS.SLEEP_STEPS': 0}),
-    ('contact breaking threshold 0.02', {'PHYSICS.BREAKING': 0.02}),
+    ('contact breaking threshold 0.01 (round-1 value; Bullet: 0.02 = shipped)', {'PHYSICS.BREAKING': 0.01}),
     ('narrow phase every substep (no gating)', {'PHYSICS.NARROWPHASE_MAX_AGE': 0}),
-    ('all Bullet defaults (solver + sleep + breaking, no gating)',
+    ('all Bullet defaults (solver + sleep, no gating)',
      {'PHYSICS.SOLVER_ITERS': 50, 'PHYSICS.SOLVER_TOL': 0.0, 'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0,
-      'PHYSICS.SLEEP_STEPS': 2000, 'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.BREAKING': 0.02, 'PHYSICS.NARROWPHASE_MAX_AGE': 0}),
+      'PHYSICS.SLEEP_STEPS': 2000, 'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.NARROWPHASE_MAX_AGE': 0}),
 ]
 
 
@@ -83,11 +84,11 @@ def main():
     print('# tools/sensitivity.py: BASELINE config 2, %d envs x %d env.step() (random policy, seed %d, one rv_rollout_record launch)'
           % (args.envs, args.steps, args.seed))
     print('# displacement = sum over the bodies of an env of the xy distance moved by one env.step(), mm')
-    hdr = '%-58s %7s %7s %7s | %8s %7s %7s %7s | %8s %8s %7s | %9s' % (
+    hdr = '%-78s %7s %7s %7s | %8s %7s %7s %7s | %8s %8s %7s | %9s' % (
         'variant', 'useful', 'unsafe', 'ineff', 'mean', 'p50', 'p90', 'p99', 'off-tbl', 'sub/step', 'awake', 'steps/s')
     print(hdr)
     for name, over, r in rows:
-        print('%-58s %7.3f %7.3f %7.3f | %8.2f %7.2f %7.2f %7.2f | %8.4f %8.0f %7.3f | %9.0f' % (
+        print('%-78s %7.3f %7.3f %7.3f | %8.2f %7.2f %7.2f %7.2f | %8.4f %8.0f %7.3f | %9.0f' % (
             name, r['useful'], r['unsafe'], r['ineffective'], r['disp_mean_mm'], r['disp_p50_mm'], r['disp_p90_mm'],
             r['disp_p99_mm'], r['bodies_off_table'], r['substeps_per_env_step'], r['awake_frac'], r['env_steps_per_s']))
     if args.json:
