@@ -169,6 +169,8 @@ struct Scratch {
   float res[16];
   float mot[RV_MAXB];
   float sync;
+  // ControllableBody._update_ik as a wave-wide solve: seed / solution, Jacobian, flags
+  float ik_q[RV_NLIMB], ik_J[6][RV_NLIMB]; int ik_need, ik_conv;
   float lq[RV_NLIMB][4];
   float vdraw[RV_NJ], ratio[RV_NJ];      // motor phase: raw commanded velocity, limit factor
   float fing_dv[2], fing_vt[2], fing_qd0[2];   // finger motors this substep: velocity step taken, commanded velocity, velocity after it
@@ -398,9 +400,34 @@ RV_DEV void lt_pop(LTarget& t) {
 }
 RV_DEV void arm_reset_targets(DevEnv& e) { lt_reset(e.lt); jt_reset(e.jt); }
 
-// ControllableBody.update (controllable_body.py:387-413), one lane
-RV_DEV void control_update(Shared& S, const Consts& K) {
+// ControllableBody.update (controllable_body.py:387-413).  One lane runs it, in two parts around the
+// IK solve, which is a job for the whole wave (arm_ik_wave): control_update_a() either finishes the
+// update or leaves S.s.ik_need = 1 with the seed in S.s.ik_q; control_update_b() takes the solution.
+RV_DEV void control_update_tail(Shared& S, const Consts& K, const int ik_updated) {
   DevEnv& e = S.e;
+  if (ik_updated) {
+    if (check_joints_reached(e)) {
+      lt_pop(e.lt);                                  // next pose of the path: solve again
+      if (e.jt.from_ik == 2) e.jt.from_ik = 1;
+    }
+  }
+  if (e.jt.active) {
+    if (e.sim_steps % RV_STEPS_TO_CHECK_DONE == 0 || ik_updated)
+      if (check_joint_target_done(S, K)) jt_reset(e.jt);
+  }
+  if (e.jt.active) {
+    // _update_position_control (controllable_body.py:458-466)
+    for (int i = 0; i < e.jt.n_idx; ++i) {
+      int j = e.jt.idx[i];
+      e.motor_on[j] = 1; e.motor_q[j] = e.jt.pos[i];
+      e.motor_kp[j] = K.cfg->kp; e.motor_kd[j] = K.cfg->kd;
+    }
+    S.s.jt_applied = 1;
+  }
+}
+RV_DEV void control_update_a(Shared& S, const Consts& K) {
+  DevEnv& e = S.e;
+  S.s.ik_need = 0;
   {
     // most substeps nothing is due: no done-check (every 100 steps), no IK (every 10
     // steps), and the motor targets already hold the joint target (jt_applied).
@@ -421,36 +448,144 @@ RV_DEV void control_update(Shared& S, const Consts& K) {
       // the converged solution of this very pose: solving again from it passes the
       // residual test at once and returns it unchanged.
       if (!(e.jt.active && e.jt.from_ik == 2)) {
-        float qik[RV_NLIMB];
         // seed: the previous IK solution while it is still being tracked, else the
         // current joint state
-        int conv = arm_ik(K, (e.jt.active && e.jt.from_ik) ? e.jt.pos : e.q, e.lt.pose, qik);
-        JTarget& t = e.jt;
-        t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = (e.lt.nq == 0); t.from_ik = conv ? 2 : 1;
-        for (int i = 0; i < RV_NLIMB; ++i) { t.idx[i] = i; t.pos[i] = qik[i]; }
-        t.start_t = e.lt.start_t; t.stop_t = e.lt.stop_t; t.has_stop = 1;
-        t.pos_thr = e.lt.pos_thr; t.vel_thr = e.lt.vel_thr;
-        S.s.jt_applied = 0;
+        const float* seed = (e.jt.active && e.jt.from_ik) ? e.jt.pos : e.q;
+        for (int i = 0; i < RV_NLIMB; ++i) S.s.ik_q[i] = seed[i];
+        S.s.ik_need = 1;
+        return;
       }
       ik_updated = 1;
-      if (check_joints_reached(e)) {
-        lt_pop(e.lt);                                  // next pose of the path: solve again
-        if (e.jt.from_ik == 2) e.jt.from_ik = 1;
+    }
+  }
+  control_update_tail(S, K, ik_updated);
+}
+RV_DEV void control_update_b(Shared& S, const Consts& K) {
+  DevEnv& e = S.e;
+  JTarget& t = e.jt;
+  t.active = 1; t.n_idx = RV_NLIMB; t.has_vel = (e.lt.nq == 0); t.from_ik = S.s.ik_conv ? 2 : 1;
+  for (int i = 0; i < RV_NLIMB; ++i) { t.idx[i] = i; t.pos[i] = S.s.ik_q[i]; }
+  t.start_t = e.lt.start_t; t.stop_t = e.lt.stop_t; t.has_stop = 1;
+  t.pos_thr = e.lt.pos_thr; t.vel_thr = e.lt.vel_thr;
+  S.s.jt_applied = 0;
+  control_update_tail(S, K, 1);
+}
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+RV_DEV float ik_rdlane(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
+// arm_ik() by the whole wave, same arithmetic in the same order (bit-identical result):
+// lane j < 7 owns joint j (its angle, its local quaternion, its Jacobian column); every lane runs
+// the chain product and the 6x6 solve on broadcast values; lane 6 r + s sums A[r][s].
+RV_DEV void arm_ik_wave(Shared& S, const Consts& K) {
+  const rv_arm* a = K.arm; const rv_config* c = K.cfg;
+  const int lane = (int)threadIdx.x;
+  const int j = lane < RV_NLIMB ? lane : RV_NLIMB - 1;
+  float q = S.s.ik_q[j];
+  const float qlo = a->q_lo[j], qhi = a->q_hi[j];
+  const v3 tp = ld3(S.e.lt.pose);
+  const q4 tq = ldq(S.e.lt.pose + 3);
+  const float lam2 = c->ik_damping * c->ik_damping;
+  const float res2 = c->ik_residual * c->ik_residual;
+  const int iters = __builtin_amdgcn_readfirstlane(c->ik_iters);
+  const int ar = lane < 36 ? lane / 6 : 0, as = lane < 36 ? lane - 6 * (lane / 6) : 0;
+  int conv = 0;
+  for (int it = 0; it < iters; ++it) {
+    // FK: the local quaternion of joint j on lane j, broadcast; the chain on every lane
+    const q4 lqm = joint_local_quat(a, j, q);
+    q4 lq[RV_NLIMB];
+#pragma unroll
+    for (int i = 0; i < RV_NLIMB; ++i) { lq[i].x = ik_rdlane(lqm.x, i); lq[i].y = ik_rdlane(lqm.y, i); lq[i].z = ik_rdlane(lqm.z, i); lq[i].w = ik_rdlane(lqm.w, i); }
+    LimbFK F;
+    fk_chain(a, lq, F);
+    float err[6];
+    v3 ep = sub(tp, F.pos[7]);
+    err[0] = ep.x; err[1] = ep.y; err[2] = ep.z;
+    q4 qc; qc.x = -F.quat[7].x; qc.y = -F.quat[7].y; qc.z = -F.quat[7].z; qc.w = F.quat[7].w;
+    q4 qe = qmul(tq, qc);
+    float sg = qe.w < 0.0f ? -2.0f : 2.0f;
+    err[3] = qe.x * sg; err[4] = qe.y * sg; err[5] = qe.z * sg;
+    float e2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) e2 += err[k] * err[k];
+    if (e2 < res2) { conv = 1; break; }
+    // Jacobian column of joint j
+    v3 axj = F.axis[0], pj = F.pos[0];
+#pragma unroll
+    for (int i = 1; i < RV_NLIMB; ++i) if (j == i) { axj = F.axis[i]; pj = F.pos[i]; }
+    const v3 cr = cross(axj, sub(F.pos[7], pj));
+    const float Jc[6] = {cr.x, cr.y, cr.z, axj.x, axj.y, axj.z};
+    __syncthreads();                       // (the previous iteration's readers of ik_J are done)
+    if (lane < RV_NLIMB) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) S.s.ik_J[r][lane] = Jc[r];
+    }
+    __syncthreads();
+    float Ars;
+    {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < RV_NLIMB; ++k) acc += S.s.ik_J[ar][k] * S.s.ik_J[as][k];
+      Ars = acc + (ar == as ? lam2 : 0.0f);
+    }
+    // Cholesky and the two triangular solves on broadcast values
+    float L[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 <= r; ++s2) {
+        float acc = ik_rdlane(Ars, 6 * r + s2);
+#pragma unroll
+        for (int k = 0; k < s2; ++k) acc -= L[r][k] * L[s2][k];
+        if (r == s2) L[r][r] = fsqrtr(fmaxr(acc, 1e-12f));
+        else L[r][s2] = acc / L[s2][s2];
       }
+    float y[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float acc = err[r];
+#pragma unroll
+      for (int k = 0; k < r; ++k) acc -= L[r][k] * y[k];
+      y[r] = acc / L[r][r];
     }
-  }
-  if (e.jt.active) {
-    if (e.sim_steps % RV_STEPS_TO_CHECK_DONE == 0 || ik_updated)
-      if (check_joint_target_done(S, K)) jt_reset(e.jt);
-  }
-  if (e.jt.active) {
-    // _update_position_control (controllable_body.py:458-466)
-    for (int i = 0; i < e.jt.n_idx; ++i) {
-      int j = e.jt.idx[i];
-      e.motor_on[j] = 1; e.motor_q[j] = e.jt.pos[i];
-      e.motor_kp[j] = K.cfg->kp; e.motor_kd[j] = K.cfg->kd;
+#pragma unroll
+    for (int r = 5; r >= 0; --r) {
+      float acc = y[r];
+#pragma unroll
+      for (int k = r + 1; k < 6; ++k) acc -= L[k][r] * y[k];
+      y[r] = acc / L[r][r];
     }
-    S.s.jt_applied = 1;
+    float dq = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) dq += Jc[r] * y[r];
+    float mx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < RV_NLIMB; ++i) mx = fmaxr(mx, fabsr(ik_rdlane(dq, i)));
+    const float sc = mx > c->ik_max_step ? c->ik_max_step / mx : 1.0f;
+    q = fclampr(q + dq * sc, qlo, qhi);
+  }
+  __syncthreads();
+  if (lane < RV_NLIMB) S.s.ik_q[lane] = q;
+  if (lane == 0) S.s.ik_conv = conv;
+  __syncthreads();
+}
+#endif
+// ControllableBody.update for the env: every lane calls it
+RV_DEV void control_update_phases(Shared& S, const Consts& K) {
+  RV_LANES_BEGIN
+    if (lane == 0) control_update_a(S, K);
+  RV_LANES_END
+  if (S.s.ik_need) {
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+    arm_ik_wave(S, K);
+#else
+    {
+      float qik[RV_NLIMB];
+      S.s.ik_conv = arm_ik(K, S.s.ik_q, S.e.lt.pose, qik);
+      for (int i = 0; i < RV_NLIMB; ++i) S.s.ik_q[i] = qik[i];
+    }
+#endif
+    RV_LANES_BEGIN
+      if (lane == 0) control_update_b(S, K);
+    RV_LANES_END
   }
 }
 // ControllableBody.is_ready(limb joints) (controllable_body.py:565-595)
@@ -1207,9 +1342,7 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
 RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, const int count_step) {
   const rv_config* c = K.cfg;
   const rv_arm* arm = K.arm;
-  RV_LANES_BEGIN
-    if (lane == 0) control_update(S, K);
-  RV_LANES_END
+  control_update_phases(S, K);
   // joint motors of the kinematic arm, (a) per joint: the raw
   // commanded velocity and the factor that would bring it within its limit
   RV_LANES_BEGIN
@@ -1689,9 +1822,11 @@ template <int N> RV_DEV float row_ror_add(float x) {
 RV_DEV int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 RV_DEV float unif(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
 #endif
-// returns the number of substeps taken; *tick_pending (why it stopped): 0 ControllableBody.update has
-// work to do, 1 the clearance is used up, 2 at a tick the phase machine must see
-RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, int* tick_pending) {
+// returns the number of substeps taken; *tick_pending (why it stopped): 1 the clearance is used up,
+// 2 at a tick the phase machine must see, 3 max_n substeps taken.  steps_check == 0: no phase
+// machine (plain stepping, wait_until_stable with every body asleep)
+RV_DEV void arm_refresh_kinematics(Shared& S, const Consts& K);
+RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const int max_n, int* tick_pending) {
   const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
   *tick_pending = 0;
   if (K.stop_after != 0 || !S.e.arm_enabled) return 0;
@@ -1710,10 +1845,16 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, int* t
   }
   RV_LANES_BEGIN
     if (fresh && lane < RV_NCOL) coast_measure_clearances(S, K, lane);
-    if (lane == 63) S.s.clr_valid = 1;
+    if (lane == 63) { S.s.clr_valid = 1; S.s.fused_n = 0; }
     if (lane >= 32 && lane < 32 + RV_NJ) S.s.jtravel[lane - 32] = 0.0f;
   RV_LANES_END
+  RV_PROF(21)
+  // segments: between two of them ControllableBody.update does real work (a new IK solution,
+  // the next pose of a path, ...) on lane 0; the clearances and path lengths carry over
+  int skip_st = -1;            // the update of this step has been executed already
+  for (;;) {
   const int st0 = S.e.sim_steps;
+  int pending = 0;             // 0 update due, 1 clearance used up, 2 tick
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
   CoastCtl C = coast_ctl_load(S, K);
   C.lt_on = uni(C.lt_on); C.jt_on = uni(C.jt_on); C.applied = uni(C.applied); C.from_ik = uni(C.from_ik);
@@ -1724,9 +1865,10 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, int* t
   const int lane = (int)threadIdx.x;
   const int j = lane < RV_NJ ? lane : RV_NJ - 1;
   const bool mine = lane < RV_NJ;
+  const bool limb = j < RV_NLIMB;
   const float dt = C.dt;
   float q = e.q[j], qd = e.qd[j];
-  const int on = e.motor_on[j];
+  const bool on = e.motor_on[j] != 0;
   const float kp = e.motor_kp[j], mq = e.motor_q[j], vmax = e.vmax_cmd[j];
   const float amax_dt = arm->a_max[j] * dt, lo = arm->q_lo[j], hi = arm->q_hi[j];
   // lanes 16 .. 16 + RV_NCOL - 1 watch one collider box each
@@ -1744,31 +1886,52 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, int* t
   }
   const float pos_thr = unif(e.jt.pos_thr), vel_thr = unif(e.jt.vel_thr);
   const int has_vel = uni(e.jt.has_vel);
-  float trav = 0.0f;
-  RV_PROF(21)
-  int st = uni(st0), pending = 0;    // pending: 0 update due, 1 clearance used up, 2 tick
+  float trav = S.s.jtravel[j];
+  int st = uni(st0);
+  // the control schedule as counters (st % 10, st % 100, st % steps_check)
+  int k10 = st % RV_STEPS_TO_UPDATE_IK, k100 = st % RV_STEPS_TO_CHECK_DONE, kchk = steps_check > 0 ? st % steps_check : 0;
+  int left = max_n - uni(S.s.fused_n);
+  const bool any_tgt = C.lt_on || C.jt_on, quiet_ok = C.jt_on && C.applied;
+  const int skip = uni(skip_st);
   for (;;) {
-    if (ctl_update_due(C, st)) {
+    if (any_tgt && (!quiet_ok || k100 == 0 || (C.lt_on && k10 == 0)) && st != skip) {
       int reached = 1;
       if (C.jt_on) {
         const bool ok = fabsr(tpos - q) < pos_thr && (!has_vel || fabsr(0.0f - qd) < vel_thr);
         reached = __builtin_amdgcn_ballot_w64(tgt && !ok) == 0;
       }
-      if (!ctl_update_noop(C, st, reached)) break;
+      if (!ctl_update_noop(C, st, reached)) {
+        // the update runs between two segments -- provided this substep can be taken whatever the
+        // update commands (|velocity step| <= a_max dt), so that it is not run twice
+        const float travub = trav + (fabsr(qd) + amax_dt) * dt;
+        float T = 0.0f;
+#pragma unroll
+        for (int k = 0; k < RV_NJ; ++k) T = __builtin_fmaf(cf[k], rdlane(travub, k), T);
+        const float D = T * 1.02f + 1e-4f;
+        if (__builtin_amdgcn_ballot_w64(iscol && !(clt > D && clb > 2.0f * D)) != 0) pending = 1;
+        break;
+      }
     }
-    float vd = 0.0f, ratio = 1.0f;
-    if (on) {
-      vd = kp * (mq - q) / dt;
-      float raw = fabsr(vd);
-      if (j < RV_NLIMB && raw > vmax) ratio = vmax / raw;
+    float vd = 0.0f;
+    if (on) vd = kp * (mq - q) / dt;
+    const float raw = fabsr(vd);
+    const bool sat = on && limb && mine && raw > vmax;
+    float sync = 1.0f;
+    if (__builtin_amdgcn_ballot_w64(sat) != 0) {       // some limb joint is over its speed limit: common scale
+      float ratio = 1.0f;
+      if (sat) ratio = vmax / raw;
+      // ratios are positive floats: their order is the order of their bit patterns
+      int r = __builtin_bit_cast(int, fminr(1.0f, ratio));
+      r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x128, 0xf, 0xf, false));
+      r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x124, 0xf, 0xf, false));
+      r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x122, 0xf, 0xf, false));
+      r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x121, 0xf, 0xf, false));
+      sync = __builtin_bit_cast(float, r);
     }
-    if (!mine) ratio = 1.0f;
-    float sync = fminr(1.0f, ratio);
-    sync = row_ror_min<8>(sync); sync = row_ror_min<4>(sync); sync = row_ror_min<2>(sync); sync = row_ror_min<1>(sync);
     float vdd = 0.0f;
     if (on) {
       vdd = vd;
-      if (j < RV_NLIMB) vdd = vdd * sync;
+      if (limb) vdd = vdd * sync;
       vdd = fclampr(vdd, -vmax, vmax);
     }
     float dv = fclampr(vdd - qd, -amax_dt, amax_dt);
@@ -1780,11 +1943,15 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, int* t
     // the boxes after this substep: still out of reach of everything?
     float T = 0.0f;
 #pragma unroll
-    for (int k = 0; k < RV_NJ; ++k) T = T + cf[k] * rdlane(travn, k);
+    for (int k = 0; k < RV_NJ; ++k) T = __builtin_fmaf(cf[k], rdlane(travn, k), T);
     const float D = T * 1.02f + 1e-4f;
     if (__builtin_amdgcn_ballot_w64(iscol && !(clt > D && clb > 2.0f * D)) != 0) { pending = 1; break; }   // no: this substep is not taken
     q = qn; qd = qdn; trav = travn; ++st;
-    if (st % steps_check == 0) {
+    if (++k10 == RV_STEPS_TO_UPDATE_IK) k10 = 0;
+    if (++k100 == RV_STEPS_TO_CHECK_DONE) k100 = 0;
+    if (--left == 0) { pending = 3; break; }
+    if (++kchk == steps_check) {
+      kchk = 0;
       int reached = 1;
       if (C.jt_on) {
         const bool ok = fabsr(tpos - q) < pos_thr && (!has_vel || fabsr(0.0f - qd) < vel_thr);
@@ -1796,21 +1963,29 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, int* t
   const int n = st - uni(st0);
   if (n > 0) {
     if (mine) { e.q[j] = q; e.qd[j] = qd; S.s.jtravel[j] = trav; }
-    if (lane == 0) { e.sim_steps += n; e.substeps_last += n; }
+    if (lane == 0) { e.sim_steps += n; e.substeps_last += n; S.s.fused_n += n; }
   }
-  if (lane == 0) { S.s.fused_n = n; S.s.fused_pending = pending; }
+  if (lane == 0) S.s.fused_pending = pending;
   __syncthreads();
-  RV_PROF(22)
 #else
   {
     DevEnv& e = S.e;
-    const CoastCtl C = coast_ctl_load(S, K);
+    CoastCtl C = coast_ctl_load(S, K);
     const float dt = c->dt;
     float trav[RV_NJ];
-    for (int j = 0; j < RV_NJ; ++j) trav[j] = 0.0f;
-    int st = st0, pending = 0;
+    for (int j = 0; j < RV_NJ; ++j) trav[j] = S.s.jtravel[j];
+    int st = st0;
     for (;;) {
-      if (ctl_update_due(C, st) && !ctl_update_noop(C, st, check_joints_reached(e))) { RV_CNT(4, 1) break; }
+      if (st != skip_st && ctl_update_due(C, st) && !ctl_update_noop(C, st, check_joints_reached(e))) {
+        RV_CNT(4, 1)
+        for (int col = 0; col < RV_NCOL; ++col) {
+          float Tc = 0.0f;
+          for (int j = 0; j < RV_NJ; ++j) Tc = Tc + S.s.ccoef[col][j] * (trav[j] + (fabsr(e.qd[j]) + arm->a_max[j] * dt) * dt);
+          const float D = Tc * 1.02f + 1e-4f;
+          if (!(S.s.clr_t[col] > D && S.s.clr_b[col] > 2.0f * D)) pending = 1;
+        }
+        break;
+      }
       float vdr[RV_NJ], sync = 1.0f, qn_[RV_NJ], qdn_[RV_NJ], tn_[RV_NJ];
       for (int j = 0; j < RV_NJ; ++j) {
         float vd = 0.0f, ratio = 1.0f;
@@ -1841,37 +2016,27 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, int* t
         float Tc = 0.0f;
         for (int j = 0; j < RV_NJ; ++j) Tc = Tc + S.s.ccoef[col][j] * tn_[j];
         const float D = Tc * 1.02f + 1e-4f;
-        if (!(S.s.clr_t[col] > D && S.s.clr_b[col] > 2.0f * D)) {
-          out_of_reach = 0;
-#ifdef RV_EMU_COUNT
-          if (getenv("RV_EMU_TRACE")) fprintf(stderr, "  violator col %d frame %d: clr_t %.4f clr_b %.4f D %.4f\n", col, arm->col_frame[col], S.s.clr_t[col], S.s.clr_b[col], D);
-#endif
-        }
+        if (!(S.s.clr_t[col] > D && S.s.clr_b[col] > 2.0f * D)) out_of_reach = 0;
       }
       if (!out_of_reach) { RV_CNT(5, 1) pending = 1; break; }
       for (int j = 0; j < RV_NJ; ++j) { e.q[j] = qn_[j]; e.qd[j] = qdn_[j]; trav[j] = tn_[j]; }
       ++st;
-      if (st % steps_check == 0 && !ctl_tick_noop(C, st, check_joints_reached(e))) { pending = 2; break; }
+      if (S.s.fused_n + (st - st0) >= max_n) { pending = 3; break; }
+      if (steps_check > 0 && st % steps_check == 0 && !ctl_tick_noop(C, st, check_joints_reached(e))) { pending = 2; break; }
     }
     const int n = st - st0;
     for (int j = 0; j < RV_NJ; ++j) S.s.jtravel[j] = trav[j];
     e.sim_steps += n; e.substeps_last += n;
-    S.s.fused_n = n; S.s.fused_pending = pending;
-    RV_CNT(2, 1) RV_CNT(3, n) RV_CNT(6, pending == 2) RV_CNT(7, n == 0)
-#ifdef RV_EMU_COUNT
-    if (fresh && getenv("RV_EMU_TRACE")) {
-      int wc = 0; float w = 1e30f; int wt = 0;
-      for (int col = 0; col < RV_NCOL; ++col) {
-        float a = S.s.clr_t[col], b2 = 0.5f * S.s.clr_b[col];
-        if (a < w) { w = a; wc = col; wt = 0; } if (b2 < w) { w = b2; wc = col; wt = 1; }
-      }
-      float T = 0; for (int j = 0; j < RV_NJ; ++j) T += S.s.ccoef[wc][j] * trav[j];
-      fprintf(stderr, "fused fresh phase %d n %d why %d (col %d %s %.4f) T %.4f  qd %.2f %.2f %.2f %.2f %.2f %.2f %.2f\n", e.phase, n, pending, wc, wt ? "body" : "table", w, T,
-              e.qd[0], e.qd[1], e.qd[2], e.qd[3], e.qd[4], e.qd[5], e.qd[6]);
-    }
-#endif
+    S.s.fused_n += n; S.s.fused_pending = pending;
+    RV_CNT(2, 1) RV_CNT(3, n) RV_CNT(6, pending == 2)
   }
 #endif
+  if (S.s.fused_pending != 0) break;
+  // ControllableBody.update of this step for real, then on with its motors
+  skip_st = S.e.sim_steps;
+  control_update_phases(S, K);
+  }
+  RV_PROF(22)
   const int n_taken = S.s.fused_n;
   *tick_pending = S.s.fused_pending;
   if (n_taken == 0) return 0;
@@ -1887,6 +2052,21 @@ RV_DEV void arm_refresh_kinematics(Shared& S, const Consts& K) {
   arm_lq_phase(S, K);
   arm_fk_phases(S, K);
   arm_collider_phases(S, K, 1);
+}
+// up to `want` coasted substeps with the fused loop; the kinematics are measured again whenever the
+// clearance is used up (fresh clearances that buy nothing: close to something -> the caller steps)
+RV_DEV int coast_run(Shared& S, const Consts& K, const int steps_check, const int want, int* why_out) {
+  int why = 0, n = 0;
+  for (;;) {
+    n += coast_fused(S, K, steps_check, want - n, &why);
+    RV_PROF(11)
+    if (why != 1 || S.s.kin_fresh) break;
+    arm_refresh_kinematics(S, K);
+    RV_PROF(10)
+    RV_CNT(12, 1)
+  }
+  *why_out = why;
+  return n;
 }
 
 RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
@@ -2514,20 +2694,18 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
     RV_PROF(7)
     if (phase_mode && !grasp_mode && coast_wait == 0) {
       // free-space motion: as many substeps (and ticks that change nothing) as provably possible
-      int why = 0, n = 0;
-      for (;;) {
-        n += coast_fused(S, K, K.cfg->steps_check, &why);
-        RV_PROF(11)
-        if (why != 1 || S.s.kin_fresh) break;     // (fresh clearances that buy nothing: close to something)
-        arm_refresh_kinematics(S, K);             // clearance used up: measure again, go on
-        RV_PROF(10)
-        RV_CNT(12, 1)
-      }
-      RV_PROF(11)
+      int why = 0;
+      const int n = coast_run(S, K, K.cfg->steps_check, 1 << 30, &why);
       if (n > 0) {
         if (why == 2) break;               // the phase machine has something to do at this tick
         n_fixed = K.cfg->steps_check - (S.e.sim_steps % K.cfg->steps_check); taken = 0;
       }
+    }
+    if (!phase_mode && n_fixed > 0 && coast_wait == 0) {
+      int why = 0;
+      const int n = coast_run(S, K, 0, n_fixed - taken, &why);
+      taken += n;
+      if (taken >= n_fixed) break;
     }
     if (n_fixed > 0 && coast_wait == 0) {
       int kidx = 0;
@@ -2551,25 +2729,48 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
       int T = 0;
       {
         int st = S.s.wus_steps, sb = S.s.wus_stable, fin = 0;
-        while (T < 16 && !fin) {
+        while (T < 256 && !fin) {
           ++T; ++st;
           if (st >= check_after) { if (st_ok) ++sb; if (sb >= min_stable || st >= max_steps) fin = 1; }
         }
       }
-      int kidx = 0;
-      int m = coast_budget(S, K, T, &kidx);
-      if (m < 0) { arm_refresh_kinematics(S, K); m = coast_budget(S, K, T, &kidx); }
-      if (m >= 2) {
-        coast_substeps(S, K, m, kidx);
+      int m = 0;
+      {
+        int any_on = 0;
+#pragma unroll
+        for (int b = 0; b < RV_MAXB; ++b) any_on |= body_on(S.e, b);
+        if (!S.e.arm_enabled && !any_on && K.stop_after == 0) {
+          // no arm, nothing awake: these substeps only count
+          m = T;
+          RV_LANES_BEGIN
+            DevEnv& e = S.e;
+            if (lane == 0) { e.flag_arm_table = 0; e.sim_steps += m; e.substeps_last += m; }
+            if (lane >= 1 && lane <= RV_MAXB) e.flag_arm_body[lane - 1] = 0;
+          RV_LANES_END
+        } else {
+          int why = 0;
+          m = coast_run(S, K, 0, T, &why);
+        }
+      }
+      if (m == 0) {
+        const int T16 = T < 16 ? T : 16;
+        int kidx = 0;
+        m = coast_budget(S, K, T16, &kidx);
+        if (m < 0) { arm_refresh_kinematics(S, K); m = coast_budget(S, K, T16, &kidx); }
+        if (m >= 2) coast_substeps(S, K, m, kidx); else m = 0;
+      }
+      if (m > 0) {
         RV_LANES_BEGIN
           if (lane == 0) {
+            int ws = S.s.wus_steps, wb = S.s.wus_stable, lb = 0;
             for (int i = 0; i < m; ++i) {
-              S.s.wus_steps++;
-              if (S.s.wus_steps >= check_after) {
-                if (st_ok) S.s.wus_stable++;
-                if (S.s.wus_stable >= min_stable || S.s.wus_steps >= max_steps) S.s.loop_break = 1;
+              ws++;
+              if (ws >= check_after) {
+                if (st_ok) wb++;
+                if (wb >= min_stable || ws >= max_steps) lb = 1;
               }
             }
+            S.s.wus_steps = ws; S.s.wus_stable = wb; if (lb) S.s.loop_break = 1;
           }
         RV_LANES_END
         RV_PROF(0)
