@@ -336,7 +336,9 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
   v3 v = guess;
   if (!(dot(v, v) > 1e-12f)) v = mk(1.0f, 0.0f, 0.0f);
   int have_v = 0, penetrating = 0;
+  RV_CNT(18, 1)
   for (int it = 0; it < RV_GJK_MAX_ITERS; ++it) {
+    RV_CNT(19, 1)
     float pja, pjb;
     v3 va = support_v(A, nA, scale(v, -1.0f), &pja), vb = support_v(B, nB, v, &pjb);
     v3 w = sub(va, vb);
@@ -362,6 +364,7 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
   }
   if (penetrating == 1) {
     v3 nf; float depth;
+    RV_CNT(20, 1)
     epa(A, nA, B, nB, s, &nf, &depth, pa, pb);
     if (depth < 1e29f) {
       *n = scale(nf, -1.0f);

@@ -61,12 +61,6 @@ __device__ __forceinline__ void g_shared_profg(int g, int i, unsigned long long 
 #define RV_STREAM_RESET  1u
 #define RV_STREAM_RANDOM 2u
 #define RV_STREAM_HEUR   3u
-#ifdef RV_EMU_COUNT
-static long rv_emu_cnt[32];      // ad-hoc event counters of the host emulation (tools only)
-#define RV_CNT(i, n) rv_emu_cnt[i] += (n);
-#else
-#define RV_CNT(i, n)
-#endif
 #define RV_STEPS_TO_CHECK_DONE 100   // controllable_body.py:21
 #define RV_STEPS_TO_UPDATE_IK  10    // controllable_body.py:24
 
@@ -1185,6 +1179,7 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
       PY.l = mk(-t.x, -t.y, -t.z); PY.a = mk(-ab.x, -ab.y, -ab.z);
     }
   }
+  RV_PROF(7)
   // this lane's row of the Delassus matrix
   float A[60];
 #pragma unroll
@@ -1201,8 +1196,13 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
 #pragma unroll
   for (int s = 0; s < 60; ++s) if ((s < 24 || Y >= 0) && isl_row_on(s, ntx, nax, nty, nay, nxy)) g = g + A[s] * rdlane(lam, s);
   const int iters = c->solver_iters; const float tol = c->solver_tol;
+  RV_PROF(8)
+  // (v_max / v_med3 give what the ternaries of the host version give for every finite input; the
+  // residual |d| is tracked on the scalar unit through its bit pattern, whose integer order is the
+  // order of the magnitudes)
+  const int toli = __builtin_bit_cast(int, tol);
   for (int it = 0; it < iters; ++it) {
-    float res = 0.0f;
+    int resi = 0;
 #pragma unroll
     for (int pp = 0; pp < 20; ++pp) {
       if (!((pp < 8 || Y >= 0) && isl_row_on(3 * pp, ntx, nax, nty, nay, nxy))) continue;
@@ -1211,23 +1211,27 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
       for (int kk = 0; kk < 3; ++kk) {
         const int s = 3 * pp + kk;
         float nl;
-        if (kk == 0) nl = fmaxr(lam + (bias - g) * invk, 0.0f);
-        else nl = fclampr(lam + (-g * invk), -lim, lim);
+        if (kk == 0) nl = __builtin_fmaxf(lam + (bias - g) * invk, 0.0f);
+        else nl = __builtin_amdgcn_fmed3f(lam + (-g * invk), -lim, lim);
         const float d = nl - lam;
         if (lane == s) lam = nl;
-        const float sd = rdlane(d, s);
+        const int sdi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), s);
+        const float sd = __builtin_bit_cast(float, sdi);
         if (kk == 0) lim = rdlane(mu * nl, s);   // friction bound of the point: mu x its normal impulse
-        res = fmaxr(res, fabsr(sd));
+        const int mag = sdi & 0x7fffffff;
+        resi = resi > mag ? resi : mag;
         g = g + A[s] * sd;
       }
     }
-    if (res < tol) break;
+    if (tol > 0.0f ? resi < toli : false) break;
   }
+  RV_PROF(9)
   // impulses back to the manifolds; what every row adds to X and Y goes through LDS (the hull-vertex
   // scratch is dead here), one lane per velocity component sums it in row order
   float* cb = &S.s.u.r.wv[0][0][0][0];
-  if (act) {
-    if (k == 0) mm.ln[slot] = lam; else if (k == 1) mm.lt1[slot] = lam; else mm.lt2[slot] = lam;
+  if (act) { if (k == 0) mm.ln[slot] = lam; else if (k == 1) mm.lt1[slot] = lam; else mm.lt2[slot] = lam; }
+  if (lane < 60) {
+    // (rows that are off hold lam = 0 and zero P: they write zeros, which the sums below may add)
     float* o = cb + 12 * lane;
     o[0] = PX.l.x * lam; o[1] = PX.l.y * lam; o[2] = PX.l.z * lam; o[3] = PX.a.x * lam; o[4] = PX.a.y * lam; o[5] = PX.a.z * lam;
     o[6] = PY.l.x * lam; o[7] = PY.l.y * lam; o[8] = PY.l.z * lam; o[9] = PY.a.x * lam; o[10] = PY.a.y * lam; o[11] = PY.a.z * lam;
@@ -1235,10 +1239,20 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
   __syncthreads();
   if (lane < 12 && (lane < 6 || Y >= 0)) {
     const int isy = lane >= 6, cc = lane - 6 * isy, bd = isy ? Yc : X;
+    const float* src = cb + 6 * isy + cc;
     float acc = e.body[bd][7 + cc];
-    for (int s = isy ? 24 : 0; s < 60; ++s) {
-      if (!isy && s == 24) s = 48;                       // X: its own rows, then the pair rows
-      if (isl_row_on(s, ntx, nax, nty, nay, nxy)) acc = acc + cb[12 * s + 6 * isy + cc];
+    // its own 24 rows, then (two bodies) the 12 pair rows: loads first, sums in row order
+    float t[24];
+    const int base = isy ? 24 : 0;
+#pragma unroll
+    for (int s = 0; s < 24; ++s) t[s] = src[12 * (base + s)];
+#pragma unroll
+    for (int s = 0; s < 24; ++s) acc = acc + t[s];
+    if (Y >= 0) {
+#pragma unroll
+      for (int s = 0; s < 12; ++s) t[s] = src[12 * (48 + s)];
+#pragma unroll
+      for (int s = 0; s < 12; ++s) acc = acc + t[s];
     }
     e.body[bd][7 + cc] = acc;
   }
@@ -1286,7 +1300,9 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
   for (int s = 0; s < n_rows; ++s) for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s] * lam[s];
   int isl_rows = 0, done = 0;
   for (int s = 0; s < n_rows; ++s) isl_rows |= 1 << RV_ROW_ISL(S.s.rowmap[s]);
+  RV_CNT(21, 1) RV_CNT(23, n_rows)
   for (int it = 0; it < c->solver_iters; ++it) {
+    RV_CNT(22, 1)
     float res[RV_MAXB] = {0.0f, 0.0f, 0.0f, 0.0f}, lim = 0.0f;
     for (int s = 0; s < n_rows; ++s) {
       const int q = S.s.rowmap[s];
@@ -2466,19 +2482,28 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     RV_LANES_END
   }
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
+  {
+    // the partner / pair of every two-body island, then ONE instance of the island solver in
+    // the instruction stream, entered once per island of one or two bodies
+    int isl_y[RV_MAXB], isl_k[RV_MAXB];
 #pragma unroll
-  for (int b = 0; b < RV_MAXB; ++b) {
-    const int m_ = with_fingers ? 0 : __builtin_amdgcn_readfirstlane(mem_[b]);
-    if (m_ == 1) solve_island2(S, K, b, -1, 0);
-    else if (m_ == 2) {
+    for (int b = 0; b < RV_MAXB; ++b) {
       int y_ = -1;
 #pragma unroll
       for (int x = RV_MAXB - 1; x > 0; --x) if (x > b && on_[x] && label[x] == b) y_ = x;
-      y_ = __builtin_amdgcn_readfirstlane(y_);
       int kxy = 0;
 #pragma unroll
       for (int kk = 0; kk < RV_NBB; ++kk) if (bb_a(kk) == b && bb_b(kk) == y_) kxy = kk;
-      solve_island2(S, K, b, y_, __builtin_amdgcn_readfirstlane(kxy));
+      isl_y[b] = mem_[b] == 2 ? y_ : -1; isl_k[b] = mem_[b] == 2 ? kxy : 0;
+    }
+#pragma nounroll
+    for (int b = 0; b < RV_MAXB; ++b) {
+      int m_ = 0, y_ = -1, kxy = 0;
+#pragma unroll
+      for (int x = 0; x < RV_MAXB; ++x) if (x == b) { m_ = mem_[x]; y_ = isl_y[x]; kxy = isl_k[x]; }
+      m_ = with_fingers ? 0 : __builtin_amdgcn_readfirstlane(m_);
+      if (m_ == 1 || m_ == 2)
+        solve_island2(S, K, b, __builtin_amdgcn_readfirstlane(y_), __builtin_amdgcn_readfirstlane(kxy));
     }
   }
 #else
@@ -2487,15 +2512,22 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   RV_LANES_END
   if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows);
 #endif
-  // islands of three or four bodies: velocity-space Gauss-Seidel, one lane per island
-  RV_LANES_BEGIN
-    if (!with_fingers && lane < RV_MAXB && big_[lane]) {
-      const int root = lane; DevEnv& e = S.e;
-      {
-        for (int it = -1; it < c->solver_iters; ++it) {   // it == -1: warm start
+  // an island of three or four bodies (there can be only one): velocity-space Gauss-Seidel in the
+  // order  bodies (their table and arm points), then the three rounds of body pairs.  Bodies do
+  // not share anything in the first stage and the two pairs of a round touch disjoint bodies, so
+  // one lane per body / per pair of the round runs them side by side: same arithmetic, same order.
+  int big_root = -1;
+#pragma unroll
+  for (int b = RV_MAXB - 1; b >= 0; --b) if (big_[b]) big_root = b;
+  if (!with_fingers && big_root >= 0) {
+    const int root = big_root;
+    for (int it = -1; it < c->solver_iters; ++it) {   // it == -1: warm start
+      RV_LANES_BEGIN
+        DevEnv& e = S.e;
+        if (lane < RV_MAXB) {
+          const int b = lane;
           float res = 0.0f;
-          for (int b = root; b < RV_MAXB; ++b) {
-            if (!(body_on(e, b) && label[b] == root)) continue;
+          if (body_on(e, b) && label[b] == root) {
             BV A = ld_bv(e, b); const float ima = e.inv_mass[b];
             for (int kind = 0; kind < 2; ++kind) {
               DevMan& m = e.man[kind == 0 ? RV_TIDX(b) : RV_AIDX(b)];
@@ -2509,13 +2541,19 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
             }
             st_bv(e, b, A);
           }
-          for (int rd = 0; rd < 3; ++rd)
-            for (int x = 0; x < 2; ++x) {
-              const int k = bb_round_pair(rd, x);
-              const int a_ = bb_a(k), b_ = bb_b(k);
-              if (!(body_on(e, a_) && body_on(e, b_)) || label[a_] != root) continue;
+          S.s.res[b] = res;
+        }
+      RV_LANES_END
+      for (int rd = 0; rd < 3; ++rd) {
+        RV_LANES_BEGIN
+          DevEnv& e = S.e;
+          if (lane < 2) {
+            const int x = lane;
+            float res = 0.0f;
+            const int k = bb_round_pair(rd, x);
+            const int a_ = bb_a(k), b_ = bb_b(k);
+            if (body_on(e, a_) && body_on(e, b_) && label[a_] == root && e.man[RV_BBIDX(k)].n != 0) {
               DevMan& m = e.man[RV_BBIDX(k)];
-              if (m.n == 0) continue;
               BV A = ld_bv(e, a_), B = ld_bv(e, b_);
               const float ima = e.inv_mass[a_], imb = e.inv_mass[b_];
               for (int i = 0; i < m.n; ++i) {
@@ -2526,11 +2564,16 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
               }
               st_bv(e, a_, A); st_bv(e, b_, B);
             }
-          if (it >= 0 && res < c->solver_tol) break;
-        }
+            S.s.res[4 + 2 * rd + x] = res;
+          }
+        RV_LANES_END
       }
+      float res = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 10; ++t) res = fmaxr(res, S.s.res[t]);
+      if (it >= 0 && res < c->solver_tol) break;
     }
-  RV_LANES_END
+  }
 
   RV_STOP(5)
   RV_PROF(5)

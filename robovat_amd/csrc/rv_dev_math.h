@@ -20,6 +20,13 @@
 
 namespace rv {
 
+#ifdef RV_EMU_COUNT
+static long rv_emu_cnt[48];      // ad-hoc event counters of the host emulation (tools only)
+#define RV_CNT(i, n) rv_emu_cnt[i] += (n);
+#else
+#define RV_CNT(i, n)
+#endif
+
 #define RV_PI 3.14159265358979323846f
 
 RV_DEV float fminr(float a, float b) { return a < b ? a : b; }

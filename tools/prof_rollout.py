@@ -52,8 +52,8 @@ ms = w.last_kernel_ms()
 p = prof() - p0
 st = w.stats()
 names_ = ['quiet substeps (light part only)', 'light part of non-quiet substeps', 'heavy: twists + hull vertices',
-          'heavy: narrow phase', 'heavy: row setup', 'heavy: solver', 'heavy: integrate + return', 'between substeps',
-          'end of a STEPS_CHECK chunk', 'phase_tick', 'coast: budget (+refresh)', 'coast: control + motors']
+          'heavy: narrow phase', 'heavy: row setup', 'heavy: solver (epilogue + fallback)', 'heavy: integrate + return', 'solver: islands + row loads (+ between substeps)',
+          'solver: Delassus rows + warm start', 'solver: sweeps', 'coast: budget (+refresh)', 'coast: control + motors']
 names_.append('heavy: narrow phase prep (refresh, gate, list)')
 tot = p[:, :7].sum(axis=1) + p[:, 18]
 slow = int(np.argmax(tot))
