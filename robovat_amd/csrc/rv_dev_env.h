@@ -190,6 +190,7 @@ struct Scratch {
   float rf_dist[RV_NMAN * 4]; int rf_rm[RV_NMAN * 4];
   int cn[RV_MAXB][RV_NCOL];
   int ow_run[RV_NMAN + RV_NCOL], olist[RV_NMAN + RV_NCOL], n_olist;
+  int wvneed[RV_MAXB];                   // body has hulls in a convex query of this substep
 #if !defined(__HIPCC__) || defined(RV_EMULATE)
   int rowmap[120], n_rows;   // host emulation of the impulse-space solver: rows in visiting order
 #endif
@@ -564,6 +565,14 @@ RV_DEV void arm_ik_wave(Shared& S, const Consts& K) {
 #endif
 // ControllableBody.update for the env: every lane calls it
 RV_DEV void control_update_phases(Shared& S, const Consts& K) {
+  {
+    // most substeps nothing is due (control_update_a's own first test, taken by every lane)
+    const DevEnv& e = S.e;
+    const int lt_on = e.lt.active, jt_on = e.jt.active, steps = e.sim_steps, applied = S.s.jt_applied;
+    if (!lt_on && !jt_on) return;
+    if (steps % RV_STEPS_TO_CHECK_DONE != 0 && jt_on && applied &&
+        (!lt_on || steps % RV_STEPS_TO_UPDATE_IK != 0)) return;
+  }
   RV_LANES_BEGIN
     if (lane == 0) control_update_a(S, K);
   RV_LANES_END
@@ -1361,6 +1370,27 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
   control_update_phases(S, K);
   // joint motors of the kinematic arm, (a) per joint: the raw
   // commanded velocity and the factor that would bring it within its limit
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+  {
+    // (a) + (b) in one phase: the common scale is a 16-lane DPP min over the limb lanes (the
+    // factors are positive floats, ordered like their bit patterns)
+    const int lane = (int)threadIdx.x;
+    const DevEnv& e0 = S.e; const int j0 = lane < RV_NJ ? lane : RV_NJ - 1;
+    float vd0 = 0.0f, ratio0 = 1.0f;
+    if (e0.motor_on[j0]) {
+      vd0 = e0.motor_kp[j0] * (e0.motor_q[j0] - e0.q[j0]) / c->dt;
+      float raw = fabsr(vd0);
+      if (j0 < RV_NLIMB && raw > e0.vmax_cmd[j0]) ratio0 = e0.vmax_cmd[j0] / raw;
+    }
+    if (lane >= RV_NLIMB) ratio0 = 1.0f;
+    int r = __builtin_bit_cast(int, fminr(1.0f, ratio0));
+    r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x128, 0xf, 0xf, false));
+    r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x124, 0xf, 0xf, false));
+    r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x122, 0xf, 0xf, false));
+    r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x121, 0xf, 0xf, false));
+    if (lane < RV_NJ) { S.s.vdraw[lane] = vd0; S.s.ratio[lane] = __builtin_bit_cast(float, r); }
+  }
+#else
   RV_LANES_BEGIN
     if (lane < RV_NJ) {
       const DevEnv& e = S.e; int j = lane;
@@ -1373,6 +1403,7 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
       S.s.vdraw[j] = vd; S.s.ratio[j] = ratio;
     }
   RV_LANES_END
+#endif
   // (b) limb joints move synchronised: one common scale (the smallest factor)
   // keeps every commanded velocity within its limit, so the path is a straight
   // line in joint space.
@@ -1380,8 +1411,12 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
     if (lane < RV_NJ) {
       DevEnv& e = S.e; int j = lane; float dt = c->dt;
       float sync = 1.0f;
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+      sync = S.s.ratio[j];      // (its own store: the common scale)
+#else
 #pragma unroll
       for (int k = 0; k < RV_NLIMB; ++k) sync = fminr(sync, S.s.ratio[k]);
+#endif
       float vd = 0.0f;
       if (e.motor_on[j]) {
         vd = S.s.vdraw[j];
@@ -2280,15 +2315,8 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
 #else
     if (lane == 63) S.e.awake_last += S.s.any_on;
 #endif
-    for (int item = lane; item < RV_MAXB * RV_MAXH * RV_MAXV; item += 64) {
-      int b = item / (RV_MAXH * RV_MAXV), h = (item / RV_MAXV) % RV_MAXH, i = item % RV_MAXV;
-      if (!body_on(S.e, b)) continue;
-      if (h >= S.n_hulls[b] || i >= S.n_verts[b][h]) continue;
-      const rv_shape* s = &K.scene->shapes[S.e.shape[b]];
-      float sc = S.e.scale[b];
-      v3 l = mk(s->verts[h][i][0] * sc, s->verts[h][i][1] * sc, s->verts[h][i][2] * sc);
-      st3(S.s.u.r.wv[b][h][i], add(ld3(S.e.body[b]), mulv(S.s.rot[b], l)));
-    }
+    // (the hull vertices go to the world frame after the narrow-phase work list is known, and only
+    // for the bodies whose owners run convex queries in this substep)
   RV_LANES_END
   RV_STOP(2)
   RV_PROF(2)
@@ -2318,9 +2346,11 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       if (live && i < e.man[mi].n) refresh_point(S, K, kind, a, b, e.man[mi], i, &d, &rm);
       S.s.rf_dist[lane] = d; S.s.rf_rm[lane] = rm;
     }
+    if (lane >= 60) S.s.wvneed[lane - 60] = 0;
   RV_LANES_END
   RV_LANES_BEGIN
     DevEnv& e = S.e;
+    int runs = 0;
     if (lane < RV_NMAN + RV_NCOL) {
       const int owner = lane;
       OwnerInfo o;
@@ -2345,6 +2375,8 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         m.acc = acc;
       }
       S.s.ow_run[owner] = n_pairs > 0;
+      runs = n_pairs > 0;
+      if (n_pairs > 0 && o.role >= 0 && o.role <= 2) { S.s.wvneed[o.a] = 1; if (o.b >= 0) S.s.wvneed[o.b] = 1; }
     }
     if (lane >= RV_NMAN + RV_NCOL && lane < RV_NMAN + RV_NCOL + RV_MAXB * RV_NCOL / 2) {
       // (body, box) proximity for the arm-body owners, two pairs per lane
@@ -2358,7 +2390,18 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         S.s.cn[b][col] = near;
       }
     }
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+    {
+      // the compact list of owners that run, in owner order
+      const unsigned long long mk = __builtin_amdgcn_ballot_w64(runs != 0);
+      if (runs) S.s.olist[__builtin_popcountll(mk & ((1ull << lane) - 1ull))] = lane;
+      if (lane == 0) S.s.n_olist = __builtin_popcountll(mk);
+    }
+#else
+    (void)runs;
+#endif
   RV_LANES_END
+#if !defined(__HIPCC__) || defined(RV_EMULATE)
   RV_LANES_BEGIN
     if (lane == 0) {
       int n = 0;
@@ -2366,6 +2409,29 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       S.s.n_olist = n;
     }
   RV_LANES_END
+#endif
+  // world hull vertices of the bodies that take part in a convex query
+  {
+    int any = 0;
+#pragma unroll
+    for (int b = 0; b < RV_MAXB; ++b) any |= S.s.wvneed[b];
+    if (any) {
+      RV_LANES_BEGIN
+        for (int b = 0; b < RV_MAXB; ++b) {
+          if (!S.s.wvneed[b]) continue;
+          const rv_shape* s = &K.scene->shapes[S.e.shape[b]];
+          const float sc = S.e.scale[b];
+          const int n_items = S.n_hulls[b] * RV_MAXV;
+          for (int item = lane; item < n_items; item += 64) {
+            const int h = item / RV_MAXV, i = item % RV_MAXV;
+            if (i >= S.n_verts[b][h]) continue;
+            v3 l = mk(s->verts[h][i][0] * sc, s->verts[h][i][1] * sc, s->verts[h][i][2] * sc);
+            st3(S.s.u.r.wv[b][h][i], add(ld3(S.e.body[b]), mulv(S.s.rot[b], l)));
+          }
+        }
+      RV_LANES_END
+    }
+  }
   RV_PROF(18)
   RV_LANES_BEGIN
     DevEnv& e = S.e;
