@@ -2541,6 +2541,16 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     rv_emu_cnt[13] += n1; rv_emu_cnt[16] += n2; rv_emu_cnt[17] += n3;
     rv_emu_cnt[14] += (n3 > 0); rv_emu_cnt[15] += (n1 + n2 >= 2); }
 #endif
+#ifdef RV_EMU_COUNT
+  { int arm_pts = 0, tab_pts = 0, slow = 1, near = 0;
+    for (int b = 0; b < RV_MAXB; ++b) if (on_[b]) {
+      arm_pts += S.e.man[RV_AIDX(b)].n; tab_pts += S.e.man[RV_TIDX(b)].n;
+      if (len(ld3(S.e.body[b] + 7)) > 0.02f || len(ld3(S.e.body[b] + 10)) > 0.5f) slow = 0;
+      for (int col = 0; col < RV_NCOL; ++col) near |= S.s.cn[b][col];
+    }
+    rv_emu_cnt[24] += arm_pts > 0; rv_emu_cnt[25] += (arm_pts == 0 && near); rv_emu_cnt[26] += (arm_pts == 0 && !near && S.s.arm_moving);
+    rv_emu_cnt[27] += (arm_pts == 0 && !near && !S.s.arm_moving); rv_emu_cnt[28] += slow; rv_emu_cnt[29] += (slow && arm_pts == 0); }
+#endif
   const int with_fingers = c->finger_dynamics && arm_on;
   if (with_fingers) {
     RV_LANES_BEGIN
