@@ -233,6 +233,16 @@ typedef struct rv_config {
    * Body.set_dynamics passes spinning = rolling, body.py:229): a resisting angular impulse of at
    * most rolling_friction x (normal impulse of the body - table manifold) per substep */
   float    rolling_friction;
+  /* a sleeping body is woken by the moving arm when a collider box comes within wake_gap of its
+   * hulls (contact imminent); min(breaking, wake_gap) is used.  Contact points of an AWAKE body
+   * are still created at the contact-breaking distance; at larger gaps they carry no impulse, so
+   * waking later changes the work, not the motion */
+  float    wake_gap;
+  /* Bullet's own deactivation rule (btRigidBody::updateDeactivation, gDeactivationTime): a body
+   * slower than deact_lin / deact_ang for deact_steps substeps in a row that touches nothing awake
+   * but the table goes to sleep as well (0 steps: rule off) */
+  float    deact_lin, deact_ang;
+  int32_t  deact_steps;
 } rv_config;
 
 /* Per-launch statistics of rv_step_macro / rv_reset (device-side reductions of

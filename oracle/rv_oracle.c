@@ -40,7 +40,7 @@
 typedef struct { real p[3], q[4], v[3], w[3]; } orc_body;
 typedef struct {
   int active, frozen, shape;
-  int asleep, sleep_count;
+  int asleep, sleep_count, deact_count;
   int still_count; real still_ref[7];   /* pose window of the in-place oscillation test */
   int undisturbed;                      /* woken, but has not left the pose window it was sleeping in */
   real aabb[6];                         /* world box (lo, hi) of the hulls + margin, taken when the body fell asleep */
@@ -132,6 +132,23 @@ static const int BB_B[RV_NBB] = {1, 2, 3, 2, 3, 3};
 static const int BB_ROUND[3][2] = {{0, 5}, {1, 4}, {2, 3}};
 
 static int body_on(const orc_env* e, int b) { return e->bp[b].active && !e->bp[b].frozen && !e->bp[b].asleep; }
+/* Contact-breaking threshold of a manifold = rv_config.breaking x the smaller "angular motion disc" of the
+ * two shapes (btCollisionShape::getContactBreakingThreshold, btPersistentManifold): a movable's disc is
+ * its bounding radius about the body origin, a collider box's its half diagonal; the table's and the
+ * ground's are larger than any of them. */
+static real brk_body(const orc_env* e, const rv_config* c, int b) { return (real)c->breaking * (e->bp[b].radius - (real)c->margin); }
+static real brk_col(const orc_world* w, int col) {
+  const float* h = w->scene.arm.col_half[col];
+  return (real)w->cfg.breaking * rsqrt_((real)h[0] * (real)h[0] + (real)h[1] * (real)h[1] + (real)h[2] * (real)h[2]);
+}
+static real brk_bb(const orc_env* e, const rv_config* c, int a, int b) { real x = brk_body(e, c, a), y = brk_body(e, c, b); return x < y ? x : y; }
+static real brk_ab(const orc_world* w, const orc_env* e, int a, int col) { real x = brk_body(e, &w->cfg, a), y = brk_col(w, col); return x < y ? x : y; }
+/* kind: 0 body-table, 1 body-body, 2 arm-body (col = the collider box) */
+static real brk_of(const orc_world* w, const orc_env* e, int kind, int a, int b, int col) {
+  return kind == 0 ? brk_body(e, &w->cfg, a) : (kind == 1 ? brk_bb(e, &w->cfg, a, b) : brk_ab(w, e, a, col));
+}
+/* how close a moving collider box must come to the hulls of a sleeping body to wake it (rv_config.wake_gap) */
+static real wake_range(const orc_world* w, const orc_env* e, int b, int col) { real x = brk_ab(w, e, b, col), y = (real)w->cfg.wake_gap; return x < y ? x : y; }
 static real sim_time(const orc_world* w, const orc_env* e) { return (real)w->cfg.dt * (real)e->sim_steps; }
 
 /* a body entirely below the table slab can only touch the ground: its "table" manifold then
@@ -562,10 +579,10 @@ static void manifold_world_points(const orc_world* w, const orc_env* e, int kind
 }
 
 static int manifold_refresh(const orc_world* w, orc_env* e, int kind, int a, int b, orc_manifold* m) {
-  real brk = (real)w->cfg.breaking;
   int n0 = m->n;
   for (int i = m->n - 1; i >= 0; --i) {
     real wa[3], wb[3], d[3];
+    const real brk = brk_of(w, e, kind, a, b, m->col[i]);
     manifold_world_points(w, e, kind, a, b, m, i, wa, wb);
     v3sub(d, wa, wb);
     real dist = v3dot(d, m->nrm[i]);
@@ -587,13 +604,13 @@ static int manifold_refresh(const orc_world* w, orc_env* e, int kind, int a, int
 #define FEATURE_PERIOD 4
 
 static void manifold_add_world(const orc_world* w, orc_env* e, int kind, int a, int b, int col, orc_manifold* m,
-                               const real* wa, const real* wb, const real* n, real d) {
+                               const real* wa, const real* wb, const real* n, real d, real brk) {
   real la[3], lb[3];
   to_local_body(e, a, wa, la);
   if (kind == 0) v3cpy(lb, wb);
   else if (kind == 1) to_local_body(e, b, wb, lb);
   else to_local_frame(e, w->scene.arm.col_frame[col], wb, lb);
-  orc_man_add(m, la, lb, n, d, col, (real)w->cfg.breaking);
+  orc_man_add(m, la, lb, n, d, col, brk);
 }
 
 /* narrow phase of one convex pair: GJK/EPA witness point plus the feature
@@ -601,8 +618,8 @@ static void manifold_add_world(const orc_world* w, orc_env* e, int kind, int a, 
  * the other hull's support plane. */
 static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, int col,
                         const real (*A)[3], int nA, const real (*B)[3], int nB,
-                        const real* guess, orc_manifold* m, real* out_dist) {
-  real mg = (real)w->cfg.margin, brk = (real)w->cfg.breaking;
+                        const real* guess, orc_manifold* m, real* out_dist, const real brk) {
+  real mg = (real)w->cfg.margin;
   real n[3], dist, pa[3], pb[3];
   e->pairs_last++;
   if (!orc_gjk_epa(A, nA, B, nB, guess, brk + R(2.0) * mg, n, &dist, pa, pb)) return 0;
@@ -616,7 +633,7 @@ static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, 
 #endif
   real wa[3], wb[3];
   v3madd(wa, pa, n, -mg); v3madd(wb, pb, n, mg);
-  manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, d);
+  manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, d, brk);
   /* feature stage: only while the manifold is incomplete, or every
    * FEATURE_PERIOD-th full pass (cached points are refreshed every substep) */
   if (m->n >= 4 && m->age < FEATURE_PERIOD - 1) { m->age++; return 1; }
@@ -656,7 +673,7 @@ static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, 
       for (int j = 0; j < 8; ++j) if (v3dot(pt, dir[j]) > extB[j]) ok = 0;
       if (ok) {
         v3madd(wa, va, n, -mg); v3madd(wb, pt, n, mg);
-        manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, gap);
+        manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, gap, brk);
       }
     }
     /* vertex of B's contact feature, projected on A's support plane */
@@ -671,7 +688,7 @@ static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, 
       for (int j = 0; j < 8; ++j) if (v3dot(pt, dir[j]) > extA[j]) ok = 0;
       if (ok) {
         v3madd(wa, pt, n, -mg); v3madd(wb, vb, n, mg);
-        manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, gap);
+        manifold_add_world(w, e, kind, a, b, col, m, wa, wb, n, gap, brk);
       }
     }
   }
@@ -710,7 +727,7 @@ static real sphere_box_dist2(const real* p, const real* c, const real* h) {
 
 static void collide_all(const orc_world* w, orc_env* e) {
   const rv_config* c = &w->cfg;
-  real brk = (real)c->breaking, qd = (real)c->contact_query_dist;
+  real qd = (real)c->contact_query_dist;
   real tc[3] = {(real)c->table_center[0], (real)c->table_center[1], e->table_z - R(0.5) * (real)c->table_thickness};
   real th[3] = {(real)c->table_half[0], (real)c->table_half[1], R(0.5) * (real)c->table_thickness};
   int run[RV_NMAN];
@@ -723,7 +740,8 @@ static void collide_all(const orc_world* w, orc_env* e) {
       orc_manifold* m = &e->man[TIDX(b)];
       int lost = manifold_refresh(w, e, 0, b, -1, m);
       m->acc += e->mot[b];
-      run[TIDX(b)] = (c->np_max_age <= 0) || m->n == 0 || lost > 0 || m->acc > (real)c->np_gate || (e->sim_steps % c->np_max_age) == 0;
+      /* (a body on fewer than three support points is rocking or tipping: its support is looked at every substep) */
+      run[TIDX(b)] = (c->np_max_age <= 0) || m->n < 3 || lost > 0 || m->acc > (real)c->np_gate || (e->sim_steps % c->np_max_age) == 0;
     }
     if (e->arm_enabled) {
       /* arm - body pairs are gated the same way, on the body's plus the arm's travel */
@@ -750,7 +768,7 @@ static void collide_all(const orc_world* w, orc_env* e) {
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!body_on(e, b) || !run[TIDX(b)]) continue;
     e->man[TIDX(b)].acc = R(0.0);
-    real r = e->bp[b].radius + brk;
+    real r = e->bp[b].radius + brk_body(e, c, b);
     const int below = body_below_table(w, e, b);
     real guess[3] = {R(0.0), R(0.0), R(1.0)};
     if (below) {
@@ -762,7 +780,7 @@ static void collide_all(const orc_world* w, orc_env* e) {
     const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
     for (int h = 0; h < s->n_hulls; ++h) {
       real d;
-      collide_pair(w, e, 0, b, -1, -1, (const real(*)[3])e->wv[b][h], s->n_verts[h], (const real(*)[3])(below ? e->groundv : e->tablev), 8, guess, &e->man[TIDX(b)], &d);
+      collide_pair(w, e, 0, b, -1, -1, (const real(*)[3])e->wv[b][h], s->n_verts[h], (const real(*)[3])(below ? e->groundv : e->tablev), 8, guess, &e->man[TIDX(b)], &d, brk_body(e, c, b));
     }
   }
   /* body - body */
@@ -771,14 +789,14 @@ static void collide_all(const orc_world* w, orc_env* e) {
     if (!(body_on(e, a) && body_on(e, b)) || !run[BBIDX(k)]) continue;
     e->man[BBIDX(k)].acc = R(0.0);
     real d[3]; v3sub(d, e->body[a].p, e->body[b].p);
-    real r = e->bp[a].radius + e->bp[b].radius + brk;
+    real r = e->bp[a].radius + e->bp[b].radius + brk_bb(e, c, a, b);
     if (v3dot(d, d) >= r * r) continue;
     const rv_shape* sa = &w->scene.shapes[e->bp[a].shape];
     const rv_shape* sb = &w->scene.shapes[e->bp[b].shape];
     for (int ha = 0; ha < sa->n_hulls; ++ha)
       for (int hb = 0; hb < sb->n_hulls; ++hb) {
         real dd;
-        collide_pair(w, e, 1, a, b, -1, (const real(*)[3])e->wv[a][ha], sa->n_verts[ha], (const real(*)[3])e->wv[b][hb], sb->n_verts[hb], d, &e->man[BBIDX(k)], &dd);
+        collide_pair(w, e, 1, a, b, -1, (const real(*)[3])e->wv[a][ha], sa->n_verts[ha], (const real(*)[3])e->wv[b][hb], sb->n_verts[hb], d, &e->man[BBIDX(k)], &dd, brk_bb(e, c, a, b));
       }
   }
   /* arm */
@@ -789,23 +807,23 @@ static void collide_all(const orc_world* w, orc_env* e) {
       for (int b = 0; b < RV_MAXB; ++b) {
         if (!body_on(e, b) || !run[AIDX(b)]) continue;
         real d[3]; v3sub(d, e->body[b].p, e->colc[col]);
-        real r = e->bp[b].radius + brk;
+        real r = e->bp[b].radius + brk_ab(w, e, b, col);
         if (sphere_aabb_dist2(e->body[b].p, e->colmin[col], e->colmax[col]) >= r * r) continue;
         const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
         for (int h = 0; h < s->n_hulls; ++h) {
           real dd;
-          collide_pair(w, e, 2, b, -1, col, (const real(*)[3])e->wv[b][h], s->n_verts[h], (const real(*)[3])e->colv[col], 8, d, &e->man[AIDX(b)], &dd);
+          collide_pair(w, e, 2, b, -1, col, (const real(*)[3])e->wv[b][h], s->n_verts[h], (const real(*)[3])e->colv[col], 8, d, &e->man[AIDX(b)], &dd, brk_ab(w, e, b, col));
         }
       }
       /* arm - table: detection only (push_env.py:839-855) */
-      real r = e->colr[col] + brk;
+      real r = e->colr[col] + brk_col(w, col);
       real minz = e->colv[col][0][2];
       for (int k = 1; k < 8; ++k) minz = rmin(minz, e->colv[col][k][2]);
       /* exact rejection: the flag needs dist < query_dist and dist >= minz - table_z - margin */
       if (minz - e->table_z - (real)c->margin >= qd) continue;
       if (sphere_box_dist2(e->colc[col], tc, th) < r * r) {
         real guess[3] = {R(0.0), R(0.0), R(1.0)}, dd;
-        if (collide_pair(w, e, 0, 0, -1, col, (const real(*)[3])e->colv[col], 8, (const real(*)[3])e->tablev, 8, guess, NULL, &dd))
+        if (collide_pair(w, e, 0, 0, -1, col, (const real(*)[3])e->colv[col], 8, (const real(*)[3])e->tablev, 8, guess, NULL, &dd, brk_col(w, col)))
           if (dd < qd) e->flag_arm_table = 1;
       }
     }
@@ -1215,7 +1233,7 @@ static void sim_substep(const orc_world* w, orc_env* e) {
         /* ... and moving means: left its 1 mm pose window within the last 50 substeps */
         if (a == b || !body_on(e, a) || e->bp[a].sleep_count > 0 || e->bp[a].still_count >= 50) continue;
         real d[3]; v3sub(d, e->body[a].p, e->body[b].p);
-        real r = e->bp[a].radius + e->bp[b].radius + (real)c->breaking;
+        real r = e->bp[a].radius + e->bp[b].radius + brk_bb(e, c, a, b);
         if (v3dot(d, d) < r * r) wake[b] = 1;
       }
       if (e->arm_enabled && e->arm_moving) {
@@ -1224,7 +1242,7 @@ static void sim_substep(const orc_world* w, orc_env* e) {
          * created); boxes whose AABB is farther than that from the body's are skipped */
         int nearf[RV_NCOL], near = 0;
         for (int col = 0; col < RV_NCOL; ++col) {
-          real r = (real)c->breaking;
+          real r = wake_range(w, e, b, col) + R(2.0) * (real)c->margin;
           nearf[col] = aabb_aabb_dist2(e->bp[b].aabb, e->bp[b].aabb + 3, e->colmin[col], e->colmax[col]) < r * r;
           near |= nearf[col];
         }
@@ -1237,9 +1255,10 @@ static void sim_substep(const orc_world* w, orc_env* e) {
               real l[3] = {(real)s->verts[h][i][0] * e->bp[b].scale, (real)s->verts[h][i][1] * e->bp[b].scale, (real)s->verts[h][i][2] * e->bp[b].scale};
               real t[3]; m3mulv(t, m, l); v3add(wv[h][i], e->body[b].p, t);
             }
-          real mg = (real)c->margin, brk = (real)c->breaking;
+          real mg = (real)c->margin;
           for (int col = 0; col < RV_NCOL && !wake[b]; ++col) {
             if (!nearf[col]) continue;
+            const real brk = wake_range(w, e, b, col);
             real d[3]; v3sub(d, e->body[b].p, e->colc[col]);
             for (int h = 0; h < s->n_hulls && !wake[b]; ++h) {
               real n[3], dist, pa[3], pb[3];
@@ -1252,7 +1271,7 @@ static void sim_substep(const orc_world* w, orc_env* e) {
     }
     for (int b = 0; b < RV_MAXB; ++b) if (wake[b]) {
       orc_bparam* P = &e->bp[b];
-      P->asleep = 0; P->sleep_count = 0;
+      P->asleep = 0; P->sleep_count = 0; P->deact_count = 0;
       /* open the pose window at the pose it was resting in */
       P->still_count = 1; P->undisturbed = 1;
       v3cpy(P->still_ref, e->body[b].p);
@@ -1276,7 +1295,7 @@ static void sim_substep(const orc_world* w, orc_env* e) {
       real tc[3] = {(real)c->table_center[0], (real)c->table_center[1], e->table_z - R(0.5) * (real)c->table_thickness};
       real th[3] = {(real)c->table_half[0], (real)c->table_half[1], R(0.5) * (real)c->table_thickness};
       for (int col = 0; col < RV_NCOL; ++col) {
-        real r = e->colr[col] + (real)c->breaking;
+        real r = e->colr[col] + brk_col(w, col);
         if (!(e->colmin[col][2] - e->table_z - (real)c->margin >= (real)c->contact_query_dist) &&
             sphere_box_dist2(e->colc[col], tc, th) < r * r) at = 1;
       }
@@ -1294,6 +1313,8 @@ static void sim_substep(const orc_world* w, orc_env* e) {
   bodies_prepare(w, e);
   collide_all(w, e);
   solve_contacts(w, e);
+  int on_at_solve[RV_MAXB];      /* who is awake in this substep (the flags change in the loop below) */
+  for (int b = 0; b < RV_MAXB; ++b) on_at_solve[b] = body_on(e, b);
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!body_on(e, b)) continue;
     orc_body* B = &e->body[b];
@@ -1351,7 +1372,19 @@ static void sim_substep(const orc_world* w, orc_env* e) {
       int quick = e->bp[b].undisturbed && 4 * e->bp[b].still_count >= c->sleep_steps && 4 * e->bp[b].sleep_count >= c->sleep_steps;
       /* a body the force-limited gripper holds stays active (its island contains the moving fingers) */
       int held = c->finger_dynamics && e->man[AIDX(b)].n > 0;
-      if (!held && (e->bp[b].sleep_count >= c->sleep_steps || e->bp[b].still_count >= c->sleep_steps || quick)) {
+      /* Bullet's own rule (0.8 m/s, 1 rad/s, 2 s) for a body whose island is the body alone */
+      int deact = 0;
+      if (c->deact_steps > 0) {
+        int free_ = e->man[AIDX(b)].n == 0;
+        for (int k = 0; k < RV_NBB; ++k) {
+          int a_ = BB_A[k], b_ = BB_B[k];
+          if ((a_ == b || b_ == b) && e->man[BBIDX(k)].n != 0 && on_at_solve[a_ == b ? b_ : a_]) free_ = 0;
+        }
+        if (free_ && vv < (real)c->deact_lin * (real)c->deact_lin && ww < (real)c->deact_ang * (real)c->deact_ang) e->bp[b].deact_count++;
+        else e->bp[b].deact_count = 0;
+        deact = e->bp[b].deact_count >= c->deact_steps;
+      }
+      if (!held && (e->bp[b].sleep_count >= c->sleep_steps || e->bp[b].still_count >= c->sleep_steps || quick || deact)) {
         e->bp[b].asleep = 1;
         v3set(B->v, R(0.0), R(0.0), R(0.0)); v3set(B->w, R(0.0), R(0.0), R(0.0));
         /* world box of the resting hulls: what the arm has to come near to wake the body */
@@ -1790,7 +1823,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   if (c->env_type == RV_ENV_GRASP) {
     /* Grasp4DofEnv._reset_scene (grasp_4dof_env.py:166-198) */
     real poses[RV_MAXB][7];
-    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; }
+    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].deact_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; }
     e->n_bodies = 1;
     sample_poses(w, e, &g, 1, poses);
     int shape = c->movable_shapes[rng_randint(&g, c->n_movable_shapes)];
@@ -1805,7 +1838,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   } else
   for (;;) {
     real poses[RV_MAXB][7];
-    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; }
+    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].deact_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; }
     for (int i = 0; i < RV_NMAN; ++i) e->man[i].n = 0;
     sample_poses(w, e, &g, nb, poses);
     for (int i = 0; i < nb; ++i) {
@@ -1814,7 +1847,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
                              : c->movable_shapes[rng_randint(&g, c->n_movable_shapes)];
       real scale = rng_uniform(&g, (real)c->scale_range[0], (real)c->scale_range[1]);
       orc_bparam* p = &e->bp[i];
-      p->active = 1; p->frozen = 0; p->asleep = 0; p->sleep_count = 0; p->still_count = 0; p->undisturbed = 0; p->undisturbed = 0; p->shape = shape; p->scale = scale; p->friction = (real)c->drop_friction;
+      p->active = 1; p->frozen = 0; p->asleep = 0; p->sleep_count = 0; p->deact_count = 0; p->still_count = 0; p->undisturbed = 0; p->undisturbed = 0; p->shape = shape; p->scale = scale; p->friction = (real)c->drop_friction;
       body_set_mass(w, e, i, (real)c->drop_mass);
       v3cpy(e->body[i].p, poses[i]); memcpy(e->body[i].q, poses[i] + 3, sizeof(real) * 4);
       v3set(e->body[i].v, R(0.0), R(0.0), R(0.0)); v3set(e->body[i].w, R(0.0), R(0.0), R(0.0));
@@ -2041,7 +2074,7 @@ void orc_set_body_state(orc_world* w, const double* in) {
       for (int k = 0; k < 3; ++k) { B->p[k] = (real)o[k]; B->v[k] = (real)o[7 + k]; B->w[k] = (real)o[10 + k]; }
       for (int k = 0; k < 4; ++k) B->q[k] = (real)o[3 + k];
       w->env[i].man[TIDX(b)].n = 0; w->env[i].man[AIDX(b)].n = 0;
-      w->env[i].bp[b].asleep = 0; w->env[i].bp[b].sleep_count = 0; w->env[i].bp[b].still_count = 0; w->env[i].bp[b].undisturbed = 0;
+      w->env[i].bp[b].asleep = 0; w->env[i].bp[b].sleep_count = 0; w->env[i].bp[b].deact_count = 0; w->env[i].bp[b].still_count = 0; w->env[i].bp[b].undisturbed = 0;
     }
   for (int i = 0; i < w->n; ++i) for (int k = 0; k < RV_NBB; ++k) w->env[i].man[BBIDX(k)].n = 0;
 }
@@ -2059,7 +2092,7 @@ void orc_set_body_params(orc_world* w, const double* in) {
     for (int b = 0; b < RV_MAXB; ++b) {
       const double* o = in + ((size_t)i * RV_MAXB + b) * 8;
       orc_bparam* p = &e->bp[b];
-      p->active = (int)o[0]; p->shape = (int)o[1]; p->scale = (real)o[2]; p->friction = (real)o[4]; p->frozen = (int)o[5]; p->asleep = 0; p->sleep_count = 0; p->still_count = 0; p->undisturbed = 0;
+      p->active = (int)o[0]; p->shape = (int)o[1]; p->scale = (real)o[2]; p->friction = (real)o[4]; p->frozen = (int)o[5]; p->asleep = 0; p->sleep_count = 0; p->deact_count = 0; p->still_count = 0; p->undisturbed = 0;
       if (b == 0) { e->table_z = (real)o[6]; table_prepare(w, e); }
       if (p->active) body_set_mass(w, e, b, (real)o[3]);
     }

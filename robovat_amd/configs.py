@@ -115,16 +115,20 @@ PUSH_ENV_CONFIG = {
                               INTRINSICS_NOISE=None, TRANSLATION_NOISE=None, ROTATION_NOISE=None)},
     'PHYSICS': {
         'TIME_STEP': 1e-3, 'GRAVITY_Z': -9.8,
-        'SOLVER_ITERS': 8, 'ERP': 0.2, 'SLOP': 0.0005, 'MARGIN': 0.001,
+        'SOLVER_ITERS': 50, 'ERP': 0.2, 'SLOP': 0.0005, 'MARGIN': 0.001,
         'BREAKING': 0.02, 'WARMSTART': 0.85, 'MAX_PUSHOUT': 0.5,    # BREAKING = Bullet's gContactBreakingThreshold
         'LINEAR_DAMPING': 0.04, 'ANGULAR_DAMPING': 0.04,
         'CONTACT_QUERY_DIST': 0.001, 'ARM_FRICTION': 0.8,
-        'SOLVER_TOL': 1e-5,
+        'SOLVER_TOL': 1e-5,      # sweeps stop early on this residual (Bullet: 50 iterations, no early exit)
         'SLEEP_LINEAR': 0.02, 'SLEEP_ANGULAR': 0.5, 'SLEEP_STEPS': 200,
         'SLEEP_POSITION_WINDOW': 1e-3, 'SLEEP_ROTATION_WINDOW': 0.01,
         'NARROWPHASE_GATE': 1e-3, 'NARROWPHASE_MAX_AGE': 8,
         # rolling = spinning friction of the movables (tools/templates/urdf_template.xml:11-16; body.py:229)
         'ROLLING_FRICTION': 0.001,
+        # the moving arm wakes a sleeping body when a collider box is this close to its hulls
+        'WAKE_GAP': 0.003,
+        # Bullet's deactivation rule as well: below 0.8 m/s and 1 rad/s for 2 s, touching nothing awake but the table
+        'DEACTIVATION_LINEAR': 0.8, 'DEACTIVATION_ANGULAR': 1.0, 'DEACTIVATION_STEPS': 2000,
     },
 }
 
@@ -248,6 +252,9 @@ def make_rv_config(env_cfg=None, robot_cfg=None, shape_names=None, n_envs=1,
     c.ground_z = tb.POSE[0][2] + env_cfg.SIM.GROUND.Z
     c.ground_friction = env_cfg.SIM.GROUND.FRICTION
     c.rolling_friction = float(ph.get('ROLLING_FRICTION', 0.0))
+    c.wake_gap = float(ph.get('WAKE_GAP', 1.0))
+    c.deact_lin, c.deact_ang = float(ph.get('DEACTIVATION_LINEAR', 0.8)), float(ph.get('DEACTIVATION_ANGULAR', 1.0))
+    c.deact_steps = int(ph.get('DEACTIVATION_STEPS', 0))
     c.n_bodies_min = env_cfg.MIN_MOVABLE_BODIES
     c.n_bodies_max = env_cfg.MAX_MOVABLE_BODIES
     assert 1 <= c.n_bodies_min <= c.n_bodies_max <= abi.RV_MAXB

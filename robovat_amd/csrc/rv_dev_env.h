@@ -88,7 +88,7 @@ struct LTarget {
 struct DevEnv {
   float body[RV_MAXB][RV_BODY_STRIDE];
   int active[RV_MAXB], frozen[RV_MAXB], shape[RV_MAXB];
-  int asleep[RV_MAXB], sleep_count[RV_MAXB];
+  int asleep[RV_MAXB], sleep_count[RV_MAXB], deact_count[RV_MAXB];
   int still_count[RV_MAXB]; float still_ref[RV_MAXB][7];   // pose window of the in-place oscillation test
   int undisturbed[RV_MAXB];   // woken, but has not left the pose window it was sleeping in
   float baabb[RV_MAXB][6];   // world box (lo, hi) of the hulls + margin, taken when the body fell asleep
@@ -221,6 +221,23 @@ RV_DEV int bb_b(int k) { return k == 0 ? 1 : (k == 1 ? 2 : (k == 2 ? 3 : (k == 3
 // round-robin colouring: round r solves pairs {r, 5-r}, which touch disjoint bodies
 RV_DEV int bb_round_pair(int r, int x) { return x == 0 ? r : 5 - r; }
 
+// Contact-breaking threshold of a manifold = rv_config.breaking x the smaller "angular motion disc" of
+// the two shapes (btCollisionShape::getContactBreakingThreshold, btPersistentManifold): the disc of a
+// movable is its bounding radius about the body origin, that of a collider box its half diagonal;
+// the table's and the ground's are larger than any of them.
+RV_DEV float brk_body(const DevEnv& e, const rv_config* c, int b) { return c->breaking * (e.radius[b] - c->margin); }
+RV_DEV float brk_col(const rv_arm* arm, const rv_config* c, int col) {
+  const float* h = arm->col_half[col];
+  return c->breaking * fsqrtr(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+}
+RV_DEV float brk_bb(const DevEnv& e, const rv_config* c, int a, int b) { return fminr(brk_body(e, c, a), brk_body(e, c, b)); }
+RV_DEV float brk_ab(const DevEnv& e, const rv_arm* arm, const rv_config* c, int a, int col) { return fminr(brk_body(e, c, a), brk_col(arm, c, col)); }
+// kind: 0 body-table, 1 body-body, 2 arm-body (col = the collider box)
+RV_DEV float brk_of(const DevEnv& e, const rv_arm* arm, const rv_config* c, int kind, int a, int b, int col) {
+  return kind == 0 ? brk_body(e, c, a) : (kind == 1 ? brk_bb(e, c, a, b) : brk_ab(e, arm, c, a, col));
+}
+// how close a moving collider box must come to the hulls of a sleeping body to wake it
+RV_DEV float wake_range(const DevEnv& e, const rv_arm* arm, const rv_config* c, int b, int col) { return fminr(brk_ab(e, arm, c, b, col), c->wake_gap); }
 RV_DEV float sim_time(const Shared& S, const Consts& K) { return K.cfg->dt * (float)S.e.sim_steps; }
 RV_DEV int body_present(const DevEnv& e, int b) { return e.active[b] && !e.frozen[b]; }
 RV_DEV int body_on(const DevEnv& e, int b) { return e.active[b] && !e.frozen[b] && !e.asleep[b]; }
@@ -690,9 +707,9 @@ RV_DEV void point_world(const Shared& S, const Consts& K, int kind, int a, int b
 // refresh of ONE cached point: its current distance, and whether it broke (too far apart
 // along the normal, or the two anchors drifted apart tangentially)
 RV_DEV void refresh_point(const Shared& S, const Consts& K, int kind, int a, int b, const DevMan& m, int i, float* dist, int* rm) {
-  const float brk = K.cfg->breaking;
   ManPoint p;
   p.la = ld3(m.la[i]); p.lb = ld3(m.lb[i]); p.nrm = ld3(m.nrm[i]); p.col = m.col[i];
+  const float brk = brk_of(S.e, K.arm, K.cfg, kind, a, b, p.col);
   v3 wa, wb;
   point_world(S, K, kind, a, b, p, &wa, &wb);
   float d = dot(sub(wa, wb), p.nrm);
@@ -714,12 +731,12 @@ RV_DEV int refresh_apply(DevMan& m, const float* dist, const int* rm) {
   for (int i = 3; i >= 0; --i) if (i < n0 && rm[i]) man_remove(m, i);
   return n0 - m.n;
 }
-RV_DEV void manifold_add_world(const Shared& S, const Consts& K, int kind, int a, int b, int col, DevMan& m, v3 wa, v3 wb, v3 n, float d) {
+RV_DEV void manifold_add_world(const Shared& S, const Consts& K, int kind, int a, int b, int col, DevMan& m, v3 wa, v3 wb, v3 n, float d, float brk) {
   v3 la = to_local_body(S, a, wa), lb;
   if (kind == 0) lb = wb;
   else if (kind == 1) lb = to_local_body(S, b, wb);
   else lb = to_local_frame(S, K.arm->col_frame[col], wb);
-  man_add(m, la, lb, n, d, col, K.cfg->breaking);
+  man_add(m, la, lb, n, d, col, brk);
 }
 
 #define RV_MAN_C 0.932327f
@@ -729,8 +746,8 @@ RV_DEV void manifold_add_world(const Shared& S, const Consts& K, int kind, int a
 
 // narrow phase of one convex pair; m == nullptr: distance only
 RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b, int col,
-                        const float* A, int nA, const float* B, int nB, v3 guess, DevMan* m, float* out_dist) {
-  float mg = K.cfg->margin, brk = K.cfg->breaking;
+                        const float* A, int nA, const float* B, int nB, v3 guess, DevMan* m, float* out_dist, const float brk) {
+  float mg = K.cfg->margin;
   v3 n, pa, pb; float dist;
   RV_PROFG(0)
   const int hit_ = gjk_epa(A, nA, B, nB, guess, brk + 2.0f * mg, &n, &dist, &pa, &pb);
@@ -741,7 +758,7 @@ RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b
   if (!(dot(n, n) > 0.5f)) return 0;   // safety net: never accept a non-unit normal
   *out_dist = d;
   if (!m) return 1;
-  manifold_add_world(S, K, kind, a, b, col, *m, madd(pa, n, -mg), madd(pb, n, mg), n, d);
+  manifold_add_world(S, K, kind, a, b, col, *m, madd(pa, n, -mg), madd(pb, n, mg), n, d, brk);
   RV_PROFG(2)
   // feature stage: only while the manifold is incomplete, or every
   // RV_FEATURE_PERIOD-th full pass (cached points are refreshed every substep)
@@ -780,7 +797,7 @@ RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b
       int ok = 1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) if (dot(pt, dir[j]) > extB[j]) ok = 0;
-      if (ok) manifold_add_world(S, K, kind, a, b, col, *m, madd(va, n, -mg), madd(pt, n, mg), n, gap);
+      if (ok) manifold_add_world(S, K, kind, a, b, col, *m, madd(va, n, -mg), madd(pt, n, mg), n, gap, brk);
     }
     sd = madd(dir[k], n, 1.0f / RV_MAN_TAU);
     v3 vb = support_v(B, nB, sd, &pj);
@@ -791,7 +808,7 @@ RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b
       int ok = 1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) if (dot(pt, dir[j]) > extA[j]) ok = 0;
-      if (ok) manifold_add_world(S, K, kind, a, b, col, *m, madd(pt, n, -mg), madd(vb, n, mg), n, gap);
+      if (ok) manifold_add_world(S, K, kind, a, b, col, *m, madd(pt, n, -mg), madd(vb, n, mg), n, gap, brk);
     }
   }
   RV_PROFG(3)
@@ -838,7 +855,6 @@ struct OwnerInfo {
 };
 RV_DEV void owner_decode(const Shared& S, const Consts& K, int owner, int arm_on, OwnerInfo& o) {
   const rv_config* c = K.cfg; const DevEnv& e = S.e;
-  const float brk = c->breaking;
   v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
   v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
   o.role = -1; o.kind = 0; o.a = 0; o.b = -1; o.mi = 0; o.clear = 0; o.live = 0; o.n_outer = 0; o.n_inner = 0;
@@ -848,7 +864,7 @@ RV_DEV void owner_decode(const Shared& S, const Consts& K, int owner, int arm_on
     if (!body_present(e, a)) o.clear = 1;
     else if (!e.asleep[a]) {
       o.live = 1;
-      float r = e.radius[a] + brk;
+      float r = e.radius[a] + brk_body(e, c, a);
       if (body_below_table(e, c, a)) {
         if (!(e.body[a][2] - c->ground_z >= r)) { o.role = 0; o.n_outer = 1; o.n_inner = S.n_hulls[a]; }
       } else if (!(sphere_box_dist2(ld3(e.body[a]), tc, th) >= r * r)) {
@@ -863,7 +879,7 @@ RV_DEV void owner_decode(const Shared& S, const Consts& K, int owner, int arm_on
     else if (!e.asleep[a] && !e.asleep[b]) {
       o.live = 1;
       v3 d = sub(ld3(e.body[a]), ld3(e.body[b]));
-      float r = e.radius[a] + e.radius[b] + brk;
+      float r = e.radius[a] + e.radius[b] + brk_bb(e, c, a, b);
       if (!(dot(d, d) >= r * r)) { o.role = 1; o.n_outer = S.n_hulls[a]; o.n_inner = S.n_hulls[b]; o.guess0 = d; }
     }
   } else if (owner < RV_NMAN) {
@@ -878,7 +894,7 @@ RV_DEV void owner_decode(const Shared& S, const Consts& K, int owner, int arm_on
     const int col = owner - RV_NMAN;
     o.a = col;
     if (arm_on) {
-      float r = S.s.colr[col] + brk;
+      float r = S.s.colr[col] + brk_col(K.arm, c, col);
       float minz = S.s.colv[col][0][2];
       for (int k = 1; k < 8; ++k) minz = fminr(minz, S.s.colv[col][k][2]);
       // exact rejection: the flag needs dist < query_dist and dist >= minz - table_z - margin
@@ -1545,7 +1561,7 @@ RV_DEV void arm_collider_phases(Shared& S, const Consts& K, const int arm_on) {
       }
       v3 tc = mk(c->table_center[0], c->table_center[1], S.e.table_z - 0.5f * c->table_thickness);
       v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
-      float r = S.s.colr[col] + c->breaking;
+      float r = S.s.colr[col] + brk_col(arm, c, col);
       S.s.atflag[col] = (!(lo3[2] - S.e.table_z - c->margin >= c->contact_query_dist) &&
                          sphere_box_dist2(ld3(S.s.colc[col]), tc, th) < r * r) ? 1 : 0;
       // how far a vertex of this box can have moved in this substep (joint travel x reach)
@@ -1581,12 +1597,12 @@ RV_DEV void coast_measure_clearances(Shared& S, const Consts& K, const int col) 
   v3 tc = mk(c->table_center[0], c->table_center[1], e.table_z - 0.5f * c->table_thickness);
   v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
   const float zc = S.s.colmin[col][2] - e.table_z - c->margin - c->contact_query_dist;
-  const float sc = fsqrtr(sphere_box_dist2(ld3(S.s.colc[col]), tc, th)) - (S.s.colr[col] + c->breaking);
+  const float sc = fsqrtr(sphere_box_dist2(ld3(S.s.colc[col]), tc, th)) - (S.s.colr[col] + brk_col(K.arm, c, col));
   const float tclear = zc > sc ? zc : sc;                 // either test rejecting is enough
   float bclear = 1e30f;
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!body_present(e, b)) continue;
-    float d = fsqrtr(aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col])) - c->breaking;
+    float d = fsqrtr(aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col])) - (wake_range(e, K.arm, c, b, col) + 2.0f * c->margin);
     d = fmaxr(d, S.s.sep[b][col]);   // the distance bound left by the last wake query, if better
     bclear = fminr(bclear, d);
   }
@@ -2167,7 +2183,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
       // is positive the query cannot hit and is skipped.  Exact: only the work changes.
       float sep = S.s.sep[b][col] - S.s.coltravel[col];
       if (arm_on && S.s.arm_moving && body_present(e, b) && e.asleep[b]) {
-        float r = c->breaking;
+        float r = wake_range(e, K.arm, c, b, col) + 2.0f * c->margin;
         nr = aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col]) < r * r;
         if (nr && sep > 0.0f) nr = 0;
       }
@@ -2182,7 +2198,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
       // ... and moving means: left its 1 mm pose window within the last 50 substeps
       if (body_present(e, b) && e.asleep[b] && body_on(e, a) && !(e.sleep_count[a] > 0) && !(e.still_count[a] >= 50)) {
         v3 d = sub(ld3(e.body[a]), ld3(e.body[b]));
-        float r = e.radius[a] + e.radius[b] + c->breaking;
+        float r = e.radius[a] + e.radius[b] + brk_bb(e, c, a, b);
         if (dot(d, d) < r * r) S.s.wake[b] = 1;
       }
     }
@@ -2209,10 +2225,11 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
       if ((lane & 15) != 0) continue;   // host emulation: one lane per group does the work
 #endif
       if (S.s.bnear[b] && !S.s.wake[b]) {
-        const float mg = c->margin, brk = c->breaking;
+        const float mg = c->margin;
         int hit = 0;
         for (int col = 0; col < RV_NCOL && !hit; ++col) {
           if (!S.s.nearf[b][col]) continue;
+          const float brk = wake_range(e, K.arm, c, b, col);
           v3 d = sub(ld3(e.body[b]), ld3(S.s.colc[col]));
           float lbmin = 1e30f;
           for (int h = 0; h < S.n_hulls[b] && !hit; ++h) {
@@ -2234,7 +2251,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
     if (lane < RV_MAXB) {
       int b = lane; DevEnv& e = S.e;
       if (S.s.wake[b]) {
-        e.asleep[b] = 0; e.sleep_count[b] = 0;
+        e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0;
         // open the pose window at the pose it was resting in
         e.still_count[b] = 1; e.undisturbed[b] = 1;
         st3(e.still_ref[b], ld3(e.body[b])); stq(e.still_ref[b] + 3, ldq(e.body[b] + 3));
@@ -2370,7 +2387,8 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         }
         if (o.b >= 0) mo = mo + S.s.mot[o.b];
         float acc = m.acc + mo;
-        const int run = (c->np_max_age <= 0) || m.n == 0 || lost > 0 || acc > c->np_gate || (e.sim_steps % c->np_max_age) == 0;
+        // (a body on fewer than three support points is rocking or tipping: its support is looked at every substep)
+        const int run = (c->np_max_age <= 0) || m.n == 0 || (owner < RV_MAXB && m.n < 3) || lost > 0 || acc > c->np_gate || (e.sim_steps % c->np_max_age) == 0;
         if (run) acc = 0.0f; else n_pairs = 0;
         m.acc = acc;
       }
@@ -2384,7 +2402,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         const int b = t / RV_NCOL, col = t - b * RV_NCOL;
         int near = 0;
         if (arm_on && body_on(e, b)) {
-          const float r = e.radius[b] + c->breaking;
+          const float r = e.radius[b] + brk_ab(e, arm, c, b, col);
           near = !(sphere_aabb_dist2(ld3(e.body[b]), S.s.colmin[col], S.s.colmax[col]) >= r * r);
         }
         S.s.cn[b][col] = near;
@@ -2462,7 +2480,8 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         } else { col = a; A = &S.s.colv[col][0][0]; nA = 8; B = &S.s.tablev[0][0]; nB = 8; ckind = 0; }
         float dd;
         my_pairs++;
-        int hit = collide_pair(S, K, ckind, role == 3 ? 0 : a, b, col, A, nA, B, nB, guess, role == 3 ? nullptr : &e.man[mi], &dd);
+        const float brk = role == 3 ? brk_col(arm, c, col) : brk_of(e, arm, c, ckind, a, b, col);
+        int hit = collide_pair(S, K, ckind, role == 3 ? 0 : a, b, col, A, nA, B, nB, guess, role == 3 ? nullptr : &e.man[mi], &dd, brk);
         if (role == 3 && hit && dd < c->contact_query_dist) S.s.colflag[col] = 1;
       }
     }
@@ -2515,6 +2534,9 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   int label[RV_MAXB], on_[RV_MAXB], act_[RV_NBB];
 #pragma unroll
   for (int b = 0; b < RV_MAXB; ++b) { label[b] = b; on_[b] = body_on(S.e, b); }
+  int on_mask = 0;
+#pragma unroll
+  for (int b = 0; b < RV_MAXB; ++b) on_mask |= on_[b] ? (1 << b) : 0;
 #pragma unroll
   for (int k = 0; k < RV_NBB; ++k) act_[k] = on_[bb_a(k)] && on_[bb_b(k)] && S.e.man[RV_BBIDX(k)].n != 0;
 #pragma unroll
@@ -2691,7 +2713,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         }
         if (c->sleep_steps > 0) {   // deactivation counter
           if (dot(v, v) < c->sleep_lin * c->sleep_lin && dot(w, w) < c->sleep_ang * c->sleep_ang) e.sleep_count[b]++;
-          else e.sleep_count[b] = 0;
+          else { e.sleep_count[b] = 0; }
           // in-place oscillation: the pose has not left a small window around where
           // it was when the window opened
           if (c->sleep_pos_win > 0.0f) {
@@ -2710,7 +2732,21 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
           const int quick = e.undisturbed[b] && 4 * e.still_count[b] >= c->sleep_steps && 4 * e.sleep_count[b] >= c->sleep_steps;
           // a body the force-limited gripper holds stays active (its island contains the moving fingers)
           const int held = c->finger_dynamics && e.man[RV_AIDX(b)].n > 0;
-          if (!held && (e.sleep_count[b] >= c->sleep_steps || e.still_count[b] >= c->sleep_steps || quick)) {
+          // Bullet's own rule (0.8 m/s, 1 rad/s, 2 s) for a body whose island is the body alone:
+          // no arm contact points, no contact points with another awake body
+          int deact = 0;
+          if (c->deact_steps > 0) {
+            int free_ = e.man[RV_AIDX(b)].n == 0;
+#pragma unroll
+            for (int k = 0; k < RV_NBB; ++k) {
+              const int a_ = bb_a(k), b_ = bb_b(k);
+              if ((a_ == b || b_ == b) && e.man[RV_BBIDX(k)].n != 0 && ((on_mask >> (a_ == b ? b_ : a_)) & 1)) free_ = 0;
+            }
+            if (free_ && dot(v, v) < c->deact_lin * c->deact_lin && dot(w, w) < c->deact_ang * c->deact_ang) e.deact_count[b]++;
+            else e.deact_count[b] = 0;
+            deact = e.deact_count[b] >= c->deact_steps;
+          }
+          if (!held && (e.sleep_count[b] >= c->sleep_steps || e.still_count[b] >= c->sleep_steps || quick || deact)) {
             e.asleep[b] = 1;
             st3(e.body[b] + 7, mk(0, 0, 0)); st3(e.body[b] + 10, mk(0, 0, 0));
             // world box of the resting hulls: what the arm has to come near to wake the body
@@ -3402,7 +3438,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
       DevEnv& e = S.e;
       if (lane == 0) {
         Rng& g = S.s.rng;
-        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; }
+        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; }
         e.n_bodies = 1;
         sample_poses(S, K, 1);
         int shape = c->movable_shapes[rng_randint(g, c->n_movable_shapes)];
@@ -3423,7 +3459,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
     RV_LANES_BEGIN
       DevEnv& e = S.e;
       if (lane == 0) {
-        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; }
+        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; }
         sample_poses(S, K, e.n_bodies);
       }
       if (lane >= 1 && lane <= RV_NMAN) e.man[lane - 1].n = 0;
@@ -3437,7 +3473,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
           int shape = use_target ? c->target_shapes[rng_randint(g, c->n_target_shapes)]
                                  : c->movable_shapes[rng_randint(g, c->n_movable_shapes)];
           float sc = rng_uniform(g, c->scale_range[0], c->scale_range[1]);
-          e.active[i] = 1; e.frozen[i] = 0; e.asleep[i] = 0; e.sleep_count[i] = 0; e.still_count[i] = 0; e.undisturbed[i] = 0; e.shape[i] = shape; e.scale[i] = sc; e.friction[i] = c->drop_friction;
+          e.active[i] = 1; e.frozen[i] = 0; e.asleep[i] = 0; e.sleep_count[i] = 0; e.deact_count[i] = 0; e.still_count[i] = 0; e.undisturbed[i] = 0; e.shape[i] = shape; e.scale[i] = sc; e.friction[i] = c->drop_friction;
           body_set_mass(e, K, i, c->drop_mass);
           cache_shape_meta(S, K, i);
           for (int k = 0; k < 3; ++k) e.body[i][k] = S.s.poses[i][k];

@@ -119,7 +119,7 @@ __global__ void k_set_body_state(DevEnv* envs, int n, const float* in) {
   ENV_THREAD();
   for (int b = 0; b < RV_MAXB; ++b) for (int k = 0; k < 13; ++k) e.body[b][k] = in[((size_t)i * RV_MAXB + b) * 13 + k];
   for (int m = 0; m < RV_NMAN; ++m) e.man[m].n = 0;
-  for (int b = 0; b < RV_MAXB; ++b) { e.asleep[b] = 0; e.sleep_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; }
+  for (int b = 0; b < RV_MAXB; ++b) { e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; }
 }
 __global__ void k_get_body_params(const DevEnv* envs, int n, float* out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
@@ -136,7 +136,7 @@ __global__ void k_set_body_params(DevEnv* envs, int n, const float* in, const rv
   int nb = 0;
   for (int b = 0; b < RV_MAXB; ++b) {
     const float* o = in + ((size_t)i * RV_MAXB + b) * 8;
-    e.active[b] = (int)o[0]; e.shape[b] = (int)o[1]; e.scale[b] = o[2]; e.friction[b] = o[4]; e.frozen[b] = (int)o[5]; e.asleep[b] = 0; e.sleep_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0;
+    e.active[b] = (int)o[0]; e.shape[b] = (int)o[1]; e.scale[b] = o[2]; e.friction[b] = o[4]; e.frozen[b] = (int)o[5]; e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0;
     if (b == 0) e.table_z = o[6];
     if (e.active[b]) { body_set_mass(e, K, b, o[3]); nb++; }
   }

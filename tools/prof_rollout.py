@@ -44,10 +44,15 @@ def prof():
     return out.cpu().numpy().astype(np.float64)
 
 
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # launches of `steps` steps before the measured one (bench.py: 5)
 w.reset(); w.synchronize()
-w.rollout(1, first_macro_index=0, auto_reset=True, record=False); w.synchronize()
+first = 0
+if warm == 0:
+    w.rollout(1, first_macro_index=0, auto_reset=True, record=False); w.synchronize(); first = 1
+for _ in range(warm):
+    w.rollout(steps, first_macro_index=first, auto_reset=True, record=False); w.synchronize(); first += steps
 p0 = prof()
-w.rollout(steps, first_macro_index=1, auto_reset=True, record=False); w.synchronize()
+w.rollout(steps, first_macro_index=first, auto_reset=True, record=False); w.synchronize()
 ms = w.last_kernel_ms()
 p = prof() - p0
 st = w.stats()
