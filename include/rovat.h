@@ -234,7 +234,7 @@ typedef struct rv_config {
    * most rolling_friction x (normal impulse of the body - table manifold) per substep */
   float    rolling_friction;
   /* a sleeping body is woken by the moving arm when a collider box comes within wake_gap of its
-   * hulls (contact imminent); min(breaking, wake_gap) is used.  Contact points of an AWAKE body
+   * hulls (contact imminent); min(breaking threshold of the pair, wake_gap) is used.  Contact points of an AWAKE body
    * are still created at the contact-breaking distance; at larger gaps they carry no impulse, so
    * waking later changes the work, not the motion */
   float    wake_gap;

@@ -35,7 +35,6 @@ VARIANTS = [
     ('no deactivation at all', {'PHYSICS.SLEEP_STEPS': 0}),
     ('contact breaking factor 0.04 (Bullet: 0.02 x the smaller shape\'s disc = shipped)', {'PHYSICS.BREAKING': 0.04}),
     ('narrow phase every substep (no gating)', {'PHYSICS.NARROWPHASE_MAX_AGE': 0}),
-    ('arm wakes a sleeper 3 cm away (not at the contact-breaking distance)', {'PHYSICS.WAKE_GAP': 1.0, 'PHYSICS.WAKE_FAR': 0.03}),
     ('all Bullet defaults (solver + sleep, no gating)',
      {'PHYSICS.SOLVER_ITERS': 50, 'PHYSICS.SOLVER_TOL': 0.0, 'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0,
       'PHYSICS.SLEEP_STEPS': 2000, 'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.NARROWPHASE_MAX_AGE': 0, 'PHYSICS.WAKE_GAP': 1.0, 'PHYSICS.DEACTIVATION_STEPS': 0}),
