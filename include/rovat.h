@@ -125,7 +125,9 @@ typedef struct rv_config {
   uint32_t seed_lo, seed_hi;
   float    dt;                   /* simulator.py:26                            */
   float    gravity_z;            /* simulator.py:27                            */
-  /* contact solver */
+  /* contact solver.  breaking: Bullet's gContactBreakingThreshold, a FACTOR -- the threshold of a
+   * manifold is breaking x the smaller angular-motion disc of its two shapes (bounding radius of
+   * a movable, half diagonal of a collider box; btCollisionShape::getContactBreakingThreshold) */
   int32_t  solver_iters;
   float    erp, slop, margin, breaking, warmstart, max_pushout;
   float    lin_damp, ang_damp;   /* per-substep velocity multipliers           */
