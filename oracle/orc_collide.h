@@ -30,7 +30,12 @@ typedef struct {
   real w[4][3], a[4][3], b[4][3];
   real lam[4];
   int n;
+  int ia[4], ib[4];   /* vertex indices of a[], b[] (for the simplex cache) */
 } orc_simplex;
+
+/* the closest feature found by the last query of a pair: the next query of the SAME pair starts from it
+ * (Bullet keeps a cached separating axis per pair for the same reason: temporal coherence) */
+typedef struct { int n, pair; int ia[3], ib[3]; } orc_gjk_cache;
 
 static inline int orc_support(const real (*verts)[3], int n, const real* d) {
   int best = 0;
@@ -141,7 +146,7 @@ static inline int orc_simplex_solve(orc_simplex* s, real* v) {
   int m = 0;
   for (int i = 0; i < s->n; ++i) {
     if (l[i] > R(0.0)) {
-      if (m != i) { v3cpy(s->w[m], s->w[i]); v3cpy(s->a[m], s->a[i]); v3cpy(s->b[m], s->b[i]); }
+      if (m != i) { v3cpy(s->w[m], s->w[i]); v3cpy(s->a[m], s->a[i]); v3cpy(s->b[m], s->b[i]); s->ia[m] = s->ia[i]; s->ib[m] = s->ib[i]; }
       s->lam[m] = l[i];
       ++m;
     }
@@ -240,14 +245,36 @@ static inline void orc_epa(const real (*A)[3], int nA, const real (*B)[3], int n
  * overlap.  Returns 0 if the sets are farther apart than max_dist, else 1 and
  * n (unit, from B towards A), signed core distance (negative = overlap) and
  * witness points on the two cores.  guess = initial search direction. */
-static inline int orc_gjk_epa(const real (*A)[3], int nA, const real (*B)[3], int nB,
-                              const real* guess, real max_dist,
-                              real* n, real* dist, real* pa, real* pb) {
+static long orc_gjk_calls = 0, orc_gjk_iters = 0;
+static inline int orc_gjk_epa_c(const real (*A)[3], int nA, const real (*B)[3], int nB,
+                                const real* guess, real max_dist,
+                                real* n, real* dist, real* pa, real* pb, orc_gjk_cache* gc, int pair) {
   orc_simplex s; s.n = 0;
   real v[3]; v3cpy(v, guess);
   if (!(v3dot(v, v) > R(1e-12))) v3set(v, R(1.0), R(0.0), R(0.0));
   int have_v = 0, penetrating = 0;
+  if (gc && gc->n > 0 && gc->pair == pair) {
+    int ok = 1;
+    for (int i = 0; i < gc->n; ++i) if (gc->ia[i] >= nA || gc->ib[i] >= nB) ok = 0;
+    if (ok) {
+      real v0[3];
+      for (int i = 0; i < gc->n; ++i) {
+        v3cpy(s.a[i], A[gc->ia[i]]); v3cpy(s.b[i], B[gc->ib[i]]); v3sub(s.w[i], s.a[i], s.b[i]);
+        s.ia[i] = gc->ia[i]; s.ib[i] = gc->ib[i];
+      }
+      s.n = gc->n;
+      if (!orc_simplex_solve(&s, v0) && v3dot(v0, v0) > R(1e-14)) { v3cpy(v, v0); have_v = 1; }
+      else s.n = 0;
+    }
+  }
+  if (gc) gc->n = 0;
+#ifdef ORC_COUNT_GJK
+  orc_gjk_calls++;
+#endif
   for (int it = 0; it < GJK_MAX_ITERS; ++it) {
+#ifdef ORC_COUNT_GJK
+    orc_gjk_iters++;
+#endif
     real nv[3]; v3scale(nv, v, R(-1.0));
     int ia = orc_support(A, nA, nv);
     int ib = orc_support(B, nB, v);
@@ -259,7 +286,7 @@ static inline int orc_gjk_epa(const real (*A)[3], int nA, const real (*B)[3], in
       if (s.w[k][0] == w[0] && s.w[k][1] == w[1] && s.w[k][2] == w[2]) dup = 1;
     if (dup) break;
     if (have_v && vv - vw <= GJK_REL_TOL * vv) break;
-    v3cpy(s.w[s.n], w); v3cpy(s.a[s.n], A[ia]); v3cpy(s.b[s.n], B[ib]); s.n++;
+    v3cpy(s.w[s.n], w); v3cpy(s.a[s.n], A[ia]); v3cpy(s.b[s.n], B[ib]); s.ia[s.n] = ia; s.ib[s.n] = ib; s.n++;
     if (orc_simplex_solve(&s, v)) { penetrating = 1; break; }
     real vn = v3dot(v, v);
     if (!(vn > R(1e-14))) { penetrating = 2; break; }
@@ -322,7 +349,16 @@ touching:
     }
   }
   *dist = d;
+  if (gc && s.n <= 3) {
+    gc->n = s.n; gc->pair = pair;
+    for (int i = 0; i < s.n; ++i) { gc->ia[i] = s.ia[i]; gc->ib[i] = s.ib[i]; }
+  }
   return 1;
+}
+static inline int orc_gjk_epa(const real (*A)[3], int nA, const real (*B)[3], int nB,
+                              const real* guess, real max_dist,
+                              real* n, real* dist, real* pa, real* pb) {
+  return orc_gjk_epa_c(A, nA, B, nB, guess, max_dist, n, dist, pa, pb, (orc_gjk_cache*)0, 0);
 }
 
 /* ---------------- persistent manifold ---------------- */
@@ -336,6 +372,7 @@ typedef struct {
   int  col[4];     /* arm collider id for arm-body manifolds, else -1   */
   real acc;        /* relative motion since the last full narrow phase  */
   int  age;        /* full passes since the last feature stage          */
+  orc_gjk_cache gc; /* closest feature of the last convex query of this manifold */
 } orc_manifold;
 
 static inline void orc_man_remove(orc_manifold* m, int i) {

@@ -618,11 +618,12 @@ static void manifold_add_world(const orc_world* w, orc_env* e, int kind, int a, 
  * the other hull's support plane. */
 static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, int col,
                         const real (*A)[3], int nA, const real (*B)[3], int nB,
-                        const real* guess, orc_manifold* m, real* out_dist, const real brk) {
+                        const real* guess, orc_manifold* m, real* out_dist, const real brk, const int pair) {
   real mg = (real)w->cfg.margin;
   real n[3], dist, pa[3], pb[3];
   e->pairs_last++;
-  if (!orc_gjk_epa(A, nA, B, nB, guess, brk + R(2.0) * mg, n, &dist, pa, pb)) return 0;
+  if (!orc_gjk_epa_c(A, nA, B, nB, guess, brk + R(2.0) * mg, n, &dist, pa, pb,
+                     m ? &m->gc : (orc_gjk_cache*)0, pair)) return 0;
   real d = dist - R(2.0) * mg;
   if (d > brk) return 0;
   if (!(v3dot(n, n) > R(0.5))) return 0;   /* safety net: never accept a non-unit normal */
@@ -780,7 +781,7 @@ static void collide_all(const orc_world* w, orc_env* e) {
     const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
     for (int h = 0; h < s->n_hulls; ++h) {
       real d;
-      collide_pair(w, e, 0, b, -1, -1, (const real(*)[3])e->wv[b][h], s->n_verts[h], (const real(*)[3])(below ? e->groundv : e->tablev), 8, guess, &e->man[TIDX(b)], &d, brk_body(e, c, b));
+      collide_pair(w, e, 0, b, -1, -1, (const real(*)[3])e->wv[b][h], s->n_verts[h], (const real(*)[3])(below ? e->groundv : e->tablev), 8, guess, &e->man[TIDX(b)], &d, brk_body(e, c, b), h + (below ? 64 : 0));
     }
   }
   /* body - body */
@@ -796,7 +797,7 @@ static void collide_all(const orc_world* w, orc_env* e) {
     for (int ha = 0; ha < sa->n_hulls; ++ha)
       for (int hb = 0; hb < sb->n_hulls; ++hb) {
         real dd;
-        collide_pair(w, e, 1, a, b, -1, (const real(*)[3])e->wv[a][ha], sa->n_verts[ha], (const real(*)[3])e->wv[b][hb], sb->n_verts[hb], d, &e->man[BBIDX(k)], &dd, brk_bb(e, c, a, b));
+        collide_pair(w, e, 1, a, b, -1, (const real(*)[3])e->wv[a][ha], sa->n_verts[ha], (const real(*)[3])e->wv[b][hb], sb->n_verts[hb], d, &e->man[BBIDX(k)], &dd, brk_bb(e, c, a, b), ha * 8 + hb);
       }
   }
   /* arm */
@@ -812,7 +813,7 @@ static void collide_all(const orc_world* w, orc_env* e) {
         const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
         for (int h = 0; h < s->n_hulls; ++h) {
           real dd;
-          collide_pair(w, e, 2, b, -1, col, (const real(*)[3])e->wv[b][h], s->n_verts[h], (const real(*)[3])e->colv[col], 8, d, &e->man[AIDX(b)], &dd, brk_ab(w, e, b, col));
+          collide_pair(w, e, 2, b, -1, col, (const real(*)[3])e->wv[b][h], s->n_verts[h], (const real(*)[3])e->colv[col], 8, d, &e->man[AIDX(b)], &dd, brk_ab(w, e, b, col), col * 8 + h);
         }
       }
       /* arm - table: detection only (push_env.py:839-855) */
@@ -823,7 +824,7 @@ static void collide_all(const orc_world* w, orc_env* e) {
       if (minz - e->table_z - (real)c->margin >= qd) continue;
       if (sphere_box_dist2(e->colc[col], tc, th) < r * r) {
         real guess[3] = {R(0.0), R(0.0), R(1.0)}, dd;
-        if (collide_pair(w, e, 0, 0, -1, col, (const real(*)[3])e->colv[col], 8, (const real(*)[3])e->tablev, 8, guess, NULL, &dd, brk_col(w, col)))
+        if (collide_pair(w, e, 0, 0, -1, col, (const real(*)[3])e->colv[col], 8, (const real(*)[3])e->tablev, 8, guess, NULL, &dd, brk_col(w, col), 0))
           if (dd < qd) e->flag_arm_table = 1;
       }
     }
@@ -2479,3 +2480,6 @@ int orc_eval_gjk(const double* A, int nA, const double* B, int nB, double max_di
   if (hit) { for (int k = 0; k < 3; ++k) { out[k] = n[k]; out[4 + k] = pa[k]; out[7 + k] = pb[k]; } out[3] = dist; }
   return hit;
 }
+
+/* debugging aid: GJK calls / iterations since the library was loaded (-DORC_COUNT_GJK builds) */
+void orc_debug_gjk_counts(long* out) { out[0] = orc_gjk_calls; out[1] = orc_gjk_iters; }

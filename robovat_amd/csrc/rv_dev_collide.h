@@ -26,7 +26,11 @@ struct Simplex {
   v3 w[4], a[4], b[4];
   float lam[4];
   int n;
+  int ia[4], ib[4];   // vertex indices of a[], b[] (for the simplex cache)
 };
+// the closest feature found by the last convex query of a manifold: the next query of the SAME pair of
+// hulls starts from it (temporal coherence; Bullet keeps a cached separating axis per pair)
+struct GjkCache { int n, pair; int ia[3], ib[3]; };
 
 // EPA polytope workspace (per-lane private memory)
 struct EpaWork {
@@ -46,6 +50,7 @@ struct DevMan {
   float dist[4], ln[4], lt1[4], lt2[4];
   float acc;   // relative motion since the last full narrow phase
   int age;     // full passes since the last feature stage
+  GjkCache gc;
 };
 
 // Support vertex (by value) of a hull stored as n <= 16 packed xyz triples.
@@ -72,7 +77,7 @@ template <int N> RV_DEV int row_ror_imin(int x) {
   int o = row_ror_i<N>(x);
   return o < x ? o : x;
 }
-RV_DEV v3 support_v(const float* verts, int n, v3 d, float* proj) {
+RV_DEV v3 support_v(const float* verts, int n, v3 d, float* proj, int* idx_out = nullptr) {
   const int sl = (int)threadIdx.x & 15;
   const int j = sl < n ? sl : n - 1;
   const float val = dot(mk(verts[3 * j], verts[3 * j + 1], verts[3 * j + 2]), d);
@@ -81,6 +86,7 @@ RV_DEV v3 support_v(const float* verts, int n, v3 d, float* proj) {
   int idx = (val == m) ? j : 16;
   idx = row_ror_imin<8>(idx); idx = row_ror_imin<4>(idx); idx = row_ror_imin<2>(idx); idx = row_ror_imin<1>(idx);
   *proj = m;
+  if (idx_out) *idx_out = idx;
   return mk(verts[3 * idx], verts[3 * idx + 1], verts[3 * idx + 2]);
 }
 // largest projection only (no witness vertex)
@@ -100,15 +106,17 @@ RV_DEV float support_proj(const float* verts, int n, v3 d) {
   }
   return bd;
 }
-RV_DEV v3 support_v(const float* verts, int n, v3 d, float* proj) {
+RV_DEV v3 support_v(const float* verts, int n, v3 d, float* proj, int* idx_out = nullptr) {
   v3 best = ld3(verts);
   float bd = dot(best, d);
+  int bi = 0;
   for (int i = 1; i < n; ++i) {
     v3 p = ld3(verts + 3 * i);
     float x = dot(p, d);
-    if (x > bd) { bd = x; best = p; }
+    if (x > bd) { bd = x; best = p; bi = i; }
   }
   *proj = bd;
+  if (idx_out) *idx_out = bi;
   return best;
 }
 #endif
@@ -227,7 +235,7 @@ RV_DEV int simplex_solve(Simplex& s, v3* vout) {
     if (i < s.n && l[i] > 0.0f) {
 #pragma unroll
       for (int j = 0; j <= i; ++j) {
-        if (j == m) { s.w[j] = s.w[i]; s.a[j] = s.a[i]; s.b[j] = s.b[i]; s.lam[j] = l[i]; }
+        if (j == m) { s.w[j] = s.w[i]; s.a[j] = s.a[i]; s.b[j] = s.b[i]; s.ia[j] = s.ia[i]; s.ib[j] = s.ib[i]; s.lam[j] = l[i]; }
       }
       ++m;
     }
@@ -328,19 +336,45 @@ RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const S
 // lb_out (optional): a rigorous lower bound of the distance between the two hulls
 // (the largest separating-plane bound seen), valid also when the query misses.
 RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, float max_dist,
-                   v3* n, float* dist, v3* pa, v3* pb, float* lb_out = nullptr) {
+                   v3* n, float* dist, v3* pa, v3* pb, float* lb_out = nullptr, GjkCache* gc = nullptr, int pair = 0) {
   float lb = 0.0f;
   Simplex s; s.n = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { s.w[i] = mk(0, 0, 0); s.a[i] = mk(0, 0, 0); s.b[i] = mk(0, 0, 0); s.lam[i] = 0.0f; }
+  for (int i = 0; i < 4; ++i) { s.w[i] = mk(0, 0, 0); s.a[i] = mk(0, 0, 0); s.b[i] = mk(0, 0, 0); s.lam[i] = 0.0f; s.ia[i] = 0; s.ib[i] = 0; }
   v3 v = guess;
   if (!(dot(v, v) > 1e-12f)) v = mk(1.0f, 0.0f, 0.0f);
   int have_v = 0, penetrating = 0;
+  if (gc) {
+    // start from the closest feature of the last query of this pair, if there is one
+    const int cn = gc->n, cp = gc->pair;
+    int cia[3], cib[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { cia[i] = gc->ia[i]; cib[i] = gc->ib[i]; }
+    if (cn > 0 && cp == pair) {
+      int ok = 1;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) if (i < cn && (cia[i] >= nA || cib[i] >= nB)) ok = 0;
+      if (ok) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (i < cn) {
+          s.a[i] = mk(A[3 * cia[i]], A[3 * cia[i] + 1], A[3 * cia[i] + 2]);
+          s.b[i] = mk(B[3 * cib[i]], B[3 * cib[i] + 1], B[3 * cib[i] + 2]);
+          s.w[i] = sub(s.a[i], s.b[i]); s.ia[i] = cia[i]; s.ib[i] = cib[i];
+        }
+        s.n = cn;
+        v3 v0;
+        if (!simplex_solve(s, &v0) && dot(v0, v0) > 1e-14f) { v = v0; have_v = 1; }
+        else s.n = 0;
+      }
+    }
+    gc->n = 0;
+  }
   RV_CNT(18, 1)
   for (int it = 0; it < RV_GJK_MAX_ITERS; ++it) {
     RV_CNT(19, 1)
     float pja, pjb;
-    v3 va = support_v(A, nA, scale(v, -1.0f), &pja), vb = support_v(B, nB, v, &pjb);
+    int ia_ = 0, ib_ = 0;
+    v3 va = support_v(A, nA, scale(v, -1.0f), &pja, &ia_), vb = support_v(B, nB, v, &pjb, &ib_);
     v3 w = sub(va, vb);
     float vv = dot(v, v), vw = dot(v, w);
     if (lb_out && vw > 0.0f) { float l = vw / fsqrtr(vv); if (l > lb) lb = l; *lb_out = lb; }
@@ -352,7 +386,7 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
     if (dup) break;
     if (have_v && vv - vw <= RV_GJK_REL_TOL * vv) break;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (k == s.n) { s.w[k] = w; s.a[k] = va; s.b[k] = vb; }
+    for (int k = 0; k < 4; ++k) if (k == s.n) { s.w[k] = w; s.a[k] = va; s.b[k] = vb; s.ia[k] = ia_; s.ib[k] = ib_; }
     s.n++;
     if (simplex_solve(s, &v)) { penetrating = 1; break; }
     float vn = dot(v, v);
@@ -414,6 +448,11 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
   }
   *n = nn;
   *dist = d;
+  if (gc && s.n <= 3) {
+    gc->n = s.n; gc->pair = pair;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if (i < s.n) { gc->ia[i] = s.ia[i]; gc->ib[i] = s.ib[i]; }
+  }
   return 1;
 }
 

@@ -746,11 +746,11 @@ RV_DEV void manifold_add_world(const Shared& S, const Consts& K, int kind, int a
 
 // narrow phase of one convex pair; m == nullptr: distance only
 RV_DEV int collide_pair(const Shared& S, const Consts& K, int kind, int a, int b, int col,
-                        const float* A, int nA, const float* B, int nB, v3 guess, DevMan* m, float* out_dist, const float brk) {
+                        const float* A, int nA, const float* B, int nB, v3 guess, DevMan* m, float* out_dist, const float brk, const int pair) {
   float mg = K.cfg->margin;
   v3 n, pa, pb; float dist;
   RV_PROFG(0)
-  const int hit_ = gjk_epa(A, nA, B, nB, guess, brk + 2.0f * mg, &n, &dist, &pa, &pb);
+  const int hit_ = gjk_epa(A, nA, B, nB, guess, brk + 2.0f * mg, &n, &dist, &pa, &pb, nullptr, m ? &m->gc : nullptr, pair);
   RV_PROFG(1)
   if (!hit_) return 0;
   float d = dist - 2.0f * mg;
@@ -2481,7 +2481,9 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         float dd;
         my_pairs++;
         const float brk = role == 3 ? brk_col(arm, c, col) : brk_of(e, arm, c, ckind, a, b, col);
-        int hit = collide_pair(S, K, ckind, role == 3 ? 0 : a, b, col, A, nA, B, nB, guess, role == 3 ? nullptr : &e.man[mi], &dd, brk);
+        // which pair of hulls of the manifold (the key of its simplex cache)
+        const int pair = role == 0 ? ii + (body_below_table(e, c, a) ? 64 : 0) : (role == 1 ? io * 8 + ii : (role == 2 ? col * 8 + ii : 0));
+        int hit = collide_pair(S, K, ckind, role == 3 ? 0 : a, b, col, A, nA, B, nB, guess, role == 3 ? nullptr : &e.man[mi], &dd, brk, pair);
         if (role == 3 && hit && dd < c->contact_query_dist) S.s.colflag[col] = 1;
       }
     }

@@ -31,7 +31,8 @@ from robovat_amd import configs, scenes, lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 scene, names = scenes.make_scene()
-cfg = configs.make_rv_config(n_envs=n, seed=1234, shape_names=names)
+seed = int(sys.argv[4]) if len(sys.argv) > 4 else 1234
+cfg = configs.make_rv_config(n_envs=n, seed=seed, shape_names=names)
 w = lib.World(cfg, scene, 0)
 L = lib.load()
 
