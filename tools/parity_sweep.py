@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""HIP kernel vs float oracle, bit for bit, over many seeds / configs (MI355X; a wider net than the test-suite):
+    python tools/parity_sweep.py [n_seeds=8] [n_envs=128] [steps=8]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from robovat_amd import configs, scenes, lib  # noqa: E402
+from oracle import orc  # noqa: E402
+
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+CASES = [('config 2', {}), ('crossing / concave', dict(TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)),
+         ('crowded: 4 bodies in a 20 cm square', {'MOVABLE.CONVEX.POSE.X': [0.5, 0.7], 'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07})]
+bad = 0
+for name, over in CASES:
+    scene, names = scenes.make_scene()
+    for seed in range(n_seeds):
+        cfg = configs.make_rv_config(env_cfg=configs.push_env_config(**over), n_envs=n, seed=1000 + seed, shape_names=names)
+        w = lib.World(cfg, scene, device=0); o = orc.OracleWorld(cfg, scene, double=False)
+        w.reset(); o.reset()
+        w.rollout(steps, first_macro_index=0, auto_reset=True, record=False); w.synchronize()
+        o.rollout(steps, 0, True)
+        eq_b = np.array_equal(w.body_state().cpu().numpy(), o.body_state().astype(np.float32))
+        eq_j = np.array_equal(w.joint_state().cpu().numpy(), o.joint_state().astype(np.float32))
+        eq_c = np.array_equal(w.env_counters().cpu().numpy()[:, :8], o.env_counters()[:, :8])
+        st = w.stats()
+        print('%-38s seed %d: bodies %s joints %s counters %s | awake %.3f' % (name, 1000 + seed, eq_b, eq_j, eq_c, st['awake_substeps'] / st['substeps']), flush=True)
+        bad += not (eq_b and eq_j)
+        w.close()
+print('MISMATCHES: %d' % bad)
+sys.exit(1 if bad else 0)
