@@ -32,5 +32,20 @@ for name, over in CASES:
         print('%-38s seed %d: bodies %s joints %s counters %s | awake %.3f' % (name, 1000 + seed, eq_b, eq_j, eq_c, st['awake_substeps'] / st['substeps']), flush=True)
         bad += not (eq_b and eq_j)
         w.close()
+# Grasp4DofEnv (force-limited gripper in the solver, phase machine ticking every substep)
+genv = configs.grasp_env_config()
+gscene, gnames = scenes.make_scene(env_cfg=genv)
+for seed in range(max(n_seeds // 2, 1)):
+    cfg = configs.make_rv_config(env_cfg=genv, n_envs=n, seed=2000 + seed, shape_names=gnames)
+    w = lib.World(cfg, gscene, device=0); o = orc.OracleWorld(cfg, gscene, double=False)
+    w.reset(); o.reset()
+    w.rollout(min(steps, 4), first_macro_index=0, auto_reset=True, record=False); w.synchronize()
+    o.rollout(min(steps, 4), 0, True)
+    eq_b = np.array_equal(w.body_state().cpu().numpy(), o.body_state().astype(np.float32))
+    eq_j = np.array_equal(w.joint_state().cpu().numpy(), o.joint_state().astype(np.float32))
+    st = w.stats()
+    print('%-38s seed %d: bodies %s joints %s | successes %d / %d' % ('Grasp4DofEnv', 2000 + seed, eq_b, eq_j, st['successes'], st['env_steps']), flush=True)
+    bad += not (eq_b and eq_j)
+    w.close()
 print('MISMATCHES: %d' % bad)
 sys.exit(1 if bad else 0)
