@@ -69,9 +69,10 @@ template <int N> RV_DEV int row_ror_i(int x) { return __builtin_amdgcn_update_dp
 // two-stage reduction: the largest projection (4 DPP max steps), then the lowest lane
 // index that attains it (4 DPP min steps) -- exactly the serial first-maximum -- and one
 // broadcast LDS read of the winning vertex
+// (v_max_f32 on the rotated value: equal to the ternary for every finite input up to the sign of a zero,
+// which neither the index search `val == m` nor the uses of the projection can see)
 template <int N> RV_DEV float row_ror_fmax(float x) {
-  float o = row_ror_f<N>(x);
-  return o > x ? o : x;
+  return __builtin_fmaxf(row_ror_f<N>(x), x);
 }
 template <int N> RV_DEV int row_ror_imin(int x) {
   int o = row_ror_i<N>(x);
