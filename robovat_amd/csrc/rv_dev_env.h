@@ -2847,6 +2847,7 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
   }
   int taken = 0;
   int coast_wait = 0;     // regular substeps to take before coasting is considered again
+  int coast_fail = 0;     // attempts in a row that bought nothing: the wait doubles (1, 2, 4, 8)
   for (;;) {
     RV_PROF(7)
     if (phase_mode && !grasp_mode && coast_wait == 0) {
@@ -2854,17 +2855,21 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
       int why = 0;
       const int n = coast_run(S, K, K.cfg->steps_check, 1 << 30, &why);
       if (n > 0) {
+        coast_fail = 0;
         if (why == 2) break;               // the phase machine has something to do at this tick
         n_fixed = K.cfg->steps_check - (S.e.sim_steps % K.cfg->steps_check); taken = 0;
       }
-    }
-    if (!phase_mode && n_fixed > 0 && coast_wait == 0) {
+      // the substep the loop stopped at is a regular one; after attempts that bought nothing
+      // (awake bodies / close to something) step normally for a while
+      if (n == 0) { coast_wait = 1 << (coast_fail < 3 ? coast_fail : 3); ++coast_fail; }
+    } else if (!phase_mode && n_fixed > 0 && coast_wait == 0) {
       int why = 0;
       const int n = coast_run(S, K, 0, n_fixed - taken, &why);
       taken += n;
       if (taken >= n_fixed) break;
-    }
-    if (n_fixed > 0 && coast_wait == 0) {
+      if (n > 0) coast_fail = 0; else { coast_wait = 1 << (coast_fail < 3 ? coast_fail : 3); ++coast_fail; }
+    } else if (n_fixed > 0 && coast_wait == 0) {
+      // (Grasp4DofEnv ticks its phase machine every substep: chunks of one do not coast)
       int kidx = 0;
       int m = coast_budget(S, K, n_fixed - taken, &kidx);
       if (m < 0) { arm_refresh_kinematics(S, K); m = coast_budget(S, K, n_fixed - taken, &kidx); }
@@ -2876,7 +2881,7 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
         if (taken >= n_fixed) break;
         continue;
       }
-      coast_wait = 8;     // awake bodies / close to something: step normally for a while
+      coast_wait = 8;
     }
     if (n_fixed == 0 && coast_wait == 0) {
       // wait_until_stable with every body asleep: the stability verdict cannot change
@@ -2931,10 +2936,11 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
           }
         RV_LANES_END
         RV_PROF(0)
+        coast_fail = 0;
         if (S.s.loop_break) break;
         continue;
       }
-      coast_wait = 8;
+      coast_wait = 1 << (coast_fail < 3 ? coast_fail : 3); ++coast_fail;
     }
     if (coast_wait > 0) --coast_wait;
     RV_CNT(9, 1)
