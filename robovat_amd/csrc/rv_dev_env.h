@@ -1344,6 +1344,7 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
     }
     for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < c->solver_tol) done |= 1 << x;
     if ((done & isl_rows) == isl_rows) break;
+    if (it == c->solver_iters - 1) { RV_CNT(30, 1) }
   }
   for (int s = 0; s < n_rows; ++s) {
     const int q = S.s.rowmap[s];

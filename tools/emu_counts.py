@@ -41,5 +41,6 @@ for name, k in rows:
 print('islands: 1 body %d, 2 bodies %d, 3+ %d' % (c[13], c[16], c[17]))
 print('GJK: %d calls, %.2f iterations per call, EPA %d' % (c[18], c[19] / max(c[18], 1), c[20]))
 print('solver (host row list): %d solves, %.2f iterations, %.1f rows per solve' % (c[21], c[22] / max(c[21], 1), c[23] / max(c[21], 1)))
+print('solves that ran into the iteration cap: %d' % c[30])
 print('heavy substeps: arm contact points %d | arm near %d | arm far, moving %d | arm far, static %d ; bodies below the sleep speeds %d'
       % (c[24], c[25], c[26], c[27], c[28]))
