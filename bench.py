@@ -131,7 +131,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--envs-per-gpu', type=int, default=1024)
+    ap.add_argument('--envs-per-gpu', type=int, default=None,
+                    help='default: 1024 at --gpus 1 (BASELINE configs[1]), 8192 at --gpus N > 1 (BASELINE configs[4])')
     ap.add_argument('--seed', type=int, default=1234)
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip every CPU-oracle leg')
     ap.add_argument('--no-extra-legs', action='store_true',
@@ -140,6 +141,12 @@ def main():
     ap.add_argument('--quick', action='store_true', help='shorter CPU legs')
     ap.add_argument('--mode', choices=['rollout', 'lockstep'], default='rollout')
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON: libraries that print to the C-level stdout (RCCL's
+    # version banner, flushed at exit) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     from robovat_amd import configs, scenes, lib
@@ -159,7 +166,12 @@ def main():
     assert world_size == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     scene, names = scenes.make_scene()
+    if args.envs_per_gpu is None:
+        args.envs_per_gpu = 1024 if args.gpus == 1 else 8192
     n = args.envs_per_gpu
+    workload = ('PushEnv 4 rigid convex bodies, %d vectorised envs/GPU, random policy (BASELINE.json configs[1])' % n if n != 8192 else
+                'PushEnv 4 rigid convex bodies, 8192 envs/GPU sharded across %d GPU(s), random policy, RCCL return-gather '
+                '(BASELINE.json configs[4])' % args.gpus)
     cfg_kwargs = dict(seed=args.seed)
 
     def barrier():
@@ -230,6 +242,48 @@ def main():
         el = all_max(time.perf_counter() - t0)
         return el, tot, kern_ms, k_steps
 
+    def deactivation_legs(make_world, n_envs, k_steps, quick=False):
+        import numpy as np
+        variants = [
+            ('shipped', {}),
+            ('bullet_rule_alone', {'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0, 'PHYSICS.SLEEP_STEPS': 2000,
+                                   'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.DEACTIVATION_STEPS': 0}),
+            ('no_deactivation', {'PHYSICS.SLEEP_STEPS': 0}),
+        ]
+        if not quick:
+            variants.append(('no_deactivation_50_sweeps', {'PHYSICS.SLEEP_STEPS': 0, 'PHYSICS.SOLVER_TOL': 0.0}))
+        out = {'note': 'same workload / seed / actions, one rv_rollout_record launch of %d steps without auto-reset; displacement = '
+                       'sum over the bodies of an env of the xy distance moved by one env.step(), mm.  bullet_physics.py:173-181 '
+                       'passes no URDF_ENABLE_SLEEPING: no_deactivation is the closest to the reference; no_deactivation_50_sweeps '
+                       'also drops the residual early exit of the solver (whose 1e-5 N s tolerance lets resting bodies creep at '
+                       '~4e-5 m/s when nothing ever puts them to sleep)' % k_steps}
+        for name, over in variants:
+            w, _ = make_world(n_envs, **over)
+            w.reset()
+            pos0 = w.observe()['position']
+            barrier(); t0 = time.perf_counter()
+            obs, r, d = w.rollout_record(k_steps, first_macro_index=0, auto_reset=False, point_cloud=False)
+            st = w.stats()
+            barrier(); el = all_max(time.perf_counter() - t0)
+            pos = torch.cat([pos0[None], obs['position']], 0).cpu().numpy()
+            moved = np.linalg.norm(pos[1:, ..., :2] - pos[:-1, ..., :2], axis=-1).sum(-1)
+            es = max(st['env_steps'], 1)
+            out[name] = {'value': all_sum(st['env_steps'])[0] / el, 'unit': 'env_steps/s',
+                         'useful': st['useful'] / es, 'unsafe': st['unsafe'] / es, 'ineffective': st['ineffective'] / es,
+                         'disp_mean_mm': 1e3 * float(moved.mean()), 'disp_p50_mm': 1e3 * float(np.percentile(moved, 50)),
+                         'disp_p90_mm': 1e3 * float(np.percentile(moved, 90)), 'disp_p99_mm': 1e3 * float(np.percentile(moved, 99)),
+                         'awake_substep_fraction': st['awake_substeps'] / max(st['substeps'], 1),
+                         'substeps_per_env_step': st['substeps'] / es}
+            w.close()
+        ref = out['no_deactivation_50_sweeps' if 'no_deactivation_50_sweeps' in out else 'no_deactivation']
+        sh = out['shipped']
+        out['shipped_vs_reference_semantics'] = {
+            'reference_leg': 'no_deactivation_50_sweeps' if 'no_deactivation_50_sweeps' in out else 'no_deactivation',
+            'disp_mean_ratio': sh['disp_mean_mm'] / max(ref['disp_mean_mm'], 1e-9),
+            'useful_diff': sh['useful'] - ref['useful'], 'unsafe_diff': sh['unsafe'] - ref['unsafe'],
+            'ineffective_diff': sh['ineffective'] - ref['ineffective']}
+        return out
+
     def leg_summary(el, st, k_steps, n_envs):
         es, ss = all_sum(st['env_steps'], st['substeps'])
         return {'value': es / el, 'unit': 'env_steps/s', 'sim_steps_per_s': ss / el, 'ms_per_step': 1e3 * el / k_steps,
@@ -266,6 +320,12 @@ def main():
                 'note': 'rv_rollout_async: K*N env.step() calls shared by the N envs of each GPU (work-conserving, no '
                         'observations recorded); per-env step counts vary'})
         world.close()
+        # Deactivation semantics.  The reference loads its movables with
+        # flags=URDF_USE_SELF_COLLISION_EXCLUDE_PARENT only (bullet_physics.py:173-181): no
+        # URDF_ENABLE_SLEEPING, so PyBullet most likely never deactivates them.  Same workload,
+        # same seed, same actions with (a) the shipped rule, (b) Bullet's own rule alone, (c) no
+        # deactivation at all [+ Bullet's fixed 50 solver sweeps]: outcome statistics and rate.
+        extra['deactivation'] = deactivation_legs(make_world, n, min(args.steps, 20), quick=args.quick)
         # BASELINE configs[2]: 'crossing' layout, V-HACD concave movables, 4096 envs
         w3, _ = make_world(4096, TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)
         w3.reset()
@@ -306,6 +366,26 @@ def main():
             'grasp_success_rate': st4['successes'] / max(st4['env_steps'], 1),
             'roofline_frac_nominal': 1912 * st4['substeps'] / (1e-3 * w4.last_kernel_ms()) / 1e9 / HBM_PEAK_GBS})
         w4.close()
+        # the path's only collective, alone: one RCCL all-gather of returns f32[8192] + all-reduce of 4
+        # int64 counters on a 1-rank group (the 8-rank curve is the driver's to measure)
+        if dist is None:
+            try:
+                import torch.distributed as d1
+                from robovat_amd import parallel
+                d1.init_process_group(backend='nccl', init_method='tcp://127.0.0.1:29621', rank=0, world_size=1,
+                                      device_id=torch.device('cuda', 0))
+                ret = torch.zeros(8192, dtype=torch.float32, device='cuda'); cnt4 = torch.zeros(4, dtype=torch.int64, device='cuda')
+                for _ in range(5):
+                    parallel.gather_returns(ret, cnt4)
+                torch.cuda.synchronize(); tg = time.perf_counter()
+                for _ in range(100):
+                    parallel.gather_returns(ret, cnt4)
+                torch.cuda.synchronize()
+                extra['gather_returns_alone'] = {'us_per_call': 1e4 * (time.perf_counter() - tg), 'ranks': 1, 'backend': 'nccl (RCCL)',
+                                                 'payload': 'all-gather f32[8192] + all-reduce int64[4]'}
+                d1.destroy_process_group()
+            except Exception as ex:  # noqa: BLE001 -- a report field, not the product path
+                extra['gather_returns_alone'] = {'error': repr(ex)[:200]}
     else:
         world.close()
 
@@ -332,8 +412,7 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'PushEnv 4 rigid convex bodies, %d vectorised envs/GPU, random policy '
-                                   '(BASELINE.json configs[1])' % n,
+            'config': {'workload': workload,
                        'envs_per_gpu': n, 'bodies': 4, 'dt': 1e-3, 'solver_iters': int(cfg.solver_iters),
                        'parallelism': 'env-shards x%d' % world_size,
                        'mode': 'single-launch rollout: K env.step() per env in one rv_rollout_record launch, observation (incl. '
@@ -361,7 +440,7 @@ def main():
         out.update(extra)
         if not args.no_cpu_baseline and world_size == 1:
             out.update(cpu_legs(cfg_kwargs, scene, names, quick=args.quick))
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -245,6 +245,9 @@ typedef struct rv_config {
    * but the table goes to sleep as well (0 steps: rule off) */
   float    deact_lin, deact_ang;
   int32_t  deact_steps;
+  /* horizontal components of the gravity vector (simulator.py:27 takes a 3-vector;
+   * bullet_physics.py:129-137 set_gravity); gravity_z above is the third */
+  float    gravity_xy[2];
 } rv_config;
 
 /* Per-launch statistics of rv_step_macro / rv_reset (device-side reductions of
@@ -346,6 +349,9 @@ int  rv_set_link_target(rv_world* w, const float* d_pose /* [N][7] pos+xyzw */, 
 int  rv_set_motor_targets(rv_world* w, const float* d_q /* [N][RV_NJ] */, const uint8_t* d_mask /* [N][RV_NJ] or NULL */);
 /* ---- SawyerSim.grip (sawyer_sim.py:362-392): value in [0, 1], 0 = open. */
 int  rv_grip(rv_world* w, float value);
+/* BulletPhysics.set_gravity (bullet_physics.py:129-137): the gravity vector of every env of
+ * the world from now on (host float[3]) */
+int  rv_set_gravity(rv_world* w, const float* gravity);
 /* ---- ControllableBody.reset_targets (controllable_body.py:347-350): drop the
  *      link / joint targets; the motors keep their last commanded positions. */
 int  rv_reset_targets(rv_world* w);

@@ -1282,6 +1282,7 @@ static void sim_substep(const orc_world* w, orc_env* e) {
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!body_on(e, b)) continue;
     orc_body* B = &e->body[b];
+    B->v[0] += (real)c->gravity_xy[0] * dt; B->v[1] += (real)c->gravity_xy[1] * dt;
     B->v[2] += (real)c->gravity_z * dt;
     v3scale(B->v, B->v, (real)c->lin_damp);
     v3scale(B->w, B->w, (real)c->ang_damp);

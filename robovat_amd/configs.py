@@ -230,6 +230,8 @@ def make_rv_config(env_cfg=None, robot_cfg=None, shape_names=None, n_envs=1,
     ph = env_cfg.PHYSICS
     c.dt = ph.TIME_STEP
     c.gravity_z = ph.GRAVITY_Z
+    gxy = ph.get('GRAVITY_XY', (0.0, 0.0))
+    c.gravity_xy[0], c.gravity_xy[1] = float(gxy[0]), float(gxy[1])
     c.solver_iters = ph.SOLVER_ITERS
     c.erp, c.slop, c.margin = ph.ERP, ph.SLOP, ph.MARGIN
     c.breaking, c.warmstart, c.max_pushout = ph.BREAKING, ph.WARMSTART, ph.MAX_PUSHOUT

@@ -121,7 +121,7 @@ struct DevEnv {
   float mu_finger, mu_table;
   int num_action_steps;       // Grasp4DofEnv: substeps spent in the 'start' phase
 #ifdef RV_PROFILE
-  unsigned long long prof[24], prof_t, prof_t2[4];   // tools/prof_rollout.py: shader-clock time per substep part
+  unsigned long long prof[32], prof_t, prof_t2[4];   // tools/prof_rollout.py: shader-clock time per substep part
 #endif
 };
 static_assert(sizeof(DevEnv) % 4 == 0, "DevEnv is copied word-wise");
@@ -1204,7 +1204,7 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
       PY.l = mk(-t.x, -t.y, -t.z); PY.a = mk(-ab.x, -ab.y, -ab.z);
     }
   }
-  RV_PROF(7)
+  RV_PROF(25)
   // this lane's row of the Delassus matrix
   float A[60];
 #pragma unroll
@@ -1221,7 +1221,7 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
 #pragma unroll
   for (int s = 0; s < 60; ++s) if ((s < 24 || Y >= 0) && isl_row_on(s, ntx, nax, nty, nay, nxy)) g = g + A[s] * rdlane(lam, s);
   const int iters = c->solver_iters; const float tol = c->solver_tol;
-  RV_PROF(8)
+  RV_PROF(26)
   // (v_max / v_med3 give what the ternaries of the host version give for every finite input; the
   // residual |d| is tracked on the scalar unit through its bit pattern, whose integer order is the
   // order of the magnitudes)
@@ -1250,7 +1250,7 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
     }
     if (tol > 0.0f ? resi < toli : false) break;
   }
-  RV_PROF(9)
+  RV_PROF(27)
   // impulses back to the manifolds; what every row adds to X and Y goes through LDS (the hull-vertex
   // scratch is dead here), one lane per velocity component sums it in row order
   float* cb = &S.s.u.r.wv[0][0][0][0];
@@ -2259,6 +2259,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
       }
       if (body_on(e, b)) {
         float dt = c->dt;
+        e.body[b][7] += c->gravity_xy[0] * dt; e.body[b][8] += c->gravity_xy[1] * dt;
         e.body[b][9] += c->gravity_z * dt;
         v3 v = scale(ld3(e.body[b] + 7), c->lin_damp);
         v3 w = scale(ld3(e.body[b] + 10), c->ang_damp);
@@ -2620,6 +2621,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   int big_root = -1;
 #pragma unroll
   for (int b = RV_MAXB - 1; b >= 0; --b) if (big_[b]) big_root = b;
+  RV_PROF(24)
   if (!with_fingers && big_root >= 0) {
     const int root = big_root;
     for (int it = -1; it < c->solver_iters; ++it) {   // it == -1: warm start
@@ -3219,10 +3221,10 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
       }
     }
   RV_LANES_END
-  RV_PROF(21)
+  RV_PROF(29)
   // phase loop + closing wait_until_stable, in one out-of-line call
   sim_run_call(K.scene, K.stop_after, -1, 0u, 0.005f, 0.005f, 100, 100, 2000);
-  RV_PROF(9)
+  RV_PROF(30)
   RV_LANES_BEGIN
     if (lane == 0) {
       DevEnv& e = S.e; Scratch& s = S.s;
@@ -3256,7 +3258,7 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
       }
     }
   RV_LANES_END
-  RV_PROF(22)
+  RV_PROF(31)
 }
 
 // ------------------------------------------------------------- Grasp4DofEnv --
@@ -3490,7 +3492,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
           for (int k = 7; k < 13; ++k) e.body[i][k] = 0.0f;
         }
       RV_LANES_END
-      RV_PROF(19)
+      RV_PROF(28)
       wait_until_stable(S, K, 1u << i, 0.1f, 0.1f, 100, 100, 500);
       RV_LANES_BEGIN
         if (lane == 0) {
@@ -3509,7 +3511,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
       }
     RV_LANES_END
   }
-  RV_PROF(19)
+  RV_PROF(28)
   wait_until_stable(S, K, 0u, 0.005f, 0.005f, 100, 100, 2000);
   // ArmEnv._reset_robot (arm_env.py:101-107) -> SawyerSim.reboot (sawyer_sim.py:86-171)
   RV_LANES_BEGIN
@@ -3592,7 +3594,7 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
     if (S.e.done) {
       if (!auto_reset) break;
       env_reset(S, K, gid, 0);
-      RV_PROF(19)
+      RV_PROF(28)
     }
     RV_LANES_BEGIN
       if (lane == 0) random_action(c, gid, first_index + k, &S.e.action[0][0]);

@@ -65,6 +65,10 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
     for (int i = lane; i < W; i += 64) dst[i] = src[i];
   }
   __syncthreads();
+#ifdef RV_PROFILE
+  if (lane == 0) { S.e.prof_t = __builtin_amdgcn_s_memtime(); for (int g2 = 0; g2 < 4; ++g2) S.e.prof_t2[g2] = S.e.prof_t; }
+  __syncthreads();
+#endif
   if (MODE == MODE_MACRO) skip = (S.e.done != 0);
   if (MODE == MODE_ROLLOUT) skip = (S.e.done != 0) && !args.auto_reset;
   if (skip) {
@@ -178,7 +182,7 @@ __global__ void k_get_link_poses(const DevEnv* envs, int n, float* out) {
 #ifdef RV_PROFILE
 __global__ void k_debug_profile(const DevEnv* envs, int n, unsigned long long* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) for (int k = 0; k < 24; ++k) out[(size_t)i * 24 + k] = envs[i].prof[k];
+  if (i < n) for (int k = 0; k < 32; ++k) out[(size_t)i * 32 + k] = envs[i].prof[k];
 }
 #endif
 __global__ void k_get_env_counters(const DevEnv* envs, int n, int32_t* out) {
@@ -675,6 +679,13 @@ int rv_set_link_target(rv_world* w, const float* d, float timeout, float thresho
 int rv_set_motor_targets(rv_world* w, const float* d_q, const uint8_t* d_mask) {
   WCHK(w); NEED(d_q, "rv_set_motor_targets");
   SIMPLE_LAUNCH(k_set_motor_targets, w->d_envs, w->n, d_q, d_mask, w->d_cfg); return RV_OK;
+}
+int rv_set_gravity(rv_world* w, const float* g) {
+  WCHK(w); NEED(g, "rv_set_gravity");
+  w->cfg.gravity_xy[0] = g[0]; w->cfg.gravity_xy[1] = g[1]; w->cfg.gravity_z = g[2];
+  HIPCHK(hipMemcpyAsync(w->d_cfg, &w->cfg, sizeof(rv_config), hipMemcpyHostToDevice, w->stream));
+  HIPCHK(hipStreamSynchronize(w->stream));
+  return RV_OK;
 }
 int rv_grip(rv_world* w, float value) { WCHK(w); SIMPLE_LAUNCH(k_grip, w->d_envs, w->n, value, w->d_cfg, w->d_scene); return RV_OK; }
 int rv_reset_targets(rv_world* w) { WCHK(w); SIMPLE_LAUNCH(k_reset_targets, w->d_envs, w->n); return RV_OK; }

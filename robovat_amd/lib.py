@@ -30,7 +30,7 @@ SYMBOLS = [
     'rv_compute_ik', 'rv_query_contacts', 'rv_get_manifold_counts', 'rv_observe',
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
-    'rv_rollout_record', 'rv_render',
+    'rv_rollout_record', 'rv_render', 'rv_set_gravity',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -116,6 +116,7 @@ def load():
     lib.rv_render.argtypes = [vp, vp, vp]
     lib.rv_set_motor_targets.argtypes = [vp, vp, vp]
     lib.rv_grip.argtypes = [vp, f32]
+    lib.rv_set_gravity.argtypes = [vp, C.POINTER(C.c_float)]
     lib.rv_get_state_ptrs.argtypes = [vp, C.POINTER(abi.rv_state_view)]
     lib.rv_set_joint_targets.argtypes = [vp, vp, f32, f32]
     lib.rv_set_link_target.argtypes = [vp, vp, f32, f32]
@@ -319,6 +320,10 @@ class World(object):
 
     def grip(self, value):
         check(self.lib.rv_grip(self.h, float(value)))
+
+    def set_gravity(self, gravity):
+        g = (C.c_float * 3)(float(gravity[0]), float(gravity[1]), float(gravity[2]))
+        check(self.lib.rv_set_gravity(self.h, g))
 
     def state_view(self):
         """Zero-copy READ-ONLY torch views of the resident env blocks (rv_get_state_ptrs)."""

@@ -72,11 +72,10 @@ class HipPhysics(Physics):
         return self._time_step * self._num_steps
 
     def set_gravity(self, gravity):
-        if abs(gravity[0]) > 0 or abs(gravity[1]) > 0:
-            raise NotImplementedError('only gravity along z is supported')
-        if self._world is not None and abs(gravity[2] - self._cfg.gravity_z) > 1e-5:
-            raise NotImplementedError('gravity is fixed at world creation (PHYSICS.GRAVITY_Z)')
+        # bullet_physics.py:129-137
         self._gravity = list(gravity)
+        if self._world is not None:
+            self._world.set_gravity(gravity)
 
     # ---- helpers
     def _np(self, t):

@@ -1,12 +1,16 @@
 """Where does the time of the bench workload go?  (profiling build, -DRV_PROFILE)
 
-    RV_LIB=robovat_amd/librovat_hip_prof.so python tools/prof_rollout.py [n_envs] [steps]
+    python tools/prof_rollout.py --build            # here, without a GPU
+    python tools/prof_rollout.py [--envs 1024] [--steps 20] [--warm 1] [--seed 1234] [--over KEY=VALUE ...]
 
-Lane 0 of every env accumulates shader-clock time per substep part; this prints
-the split over all envs and for the slowest env (which sets the launch time).
-Build the profiling library first (here, without a GPU):
-    python tools/prof_rollout.py --build
+Lane 0 of every env adds the shader-clock time since its last mark to one of 32 slots
+(RV_PROF(i) in rv_dev_env.h; every slot has ONE meaning).  The table gives each slot as
+a share of the env's TOTAL marked time (the columns sum to 100 %), for the mean env and
+for the slowest env (which sets the launch time), and the busy ratio mean / slowest.
+The profiling library is a separate binary (librovat_hip_prof.so); the product library
+has no marks.
 """
+import argparse
 import ctypes as C
 import os
 import subprocess
@@ -18,72 +22,98 @@ PROF_LIB = os.path.join(ROOT, 'robovat_amd', 'librovat_hip_prof.so')
 
 if '--build' in sys.argv:
     from robovat_amd import lib
-    cmd = ['/opt/rocm/bin/hipcc'] + lib.HIPCC_FLAGS + ['-DRV_PROFILE', os.path.join(lib.CSRC, 'rv_kernels.hip'), '-o', PROF_LIB]
+    cmd = (['/opt/rocm/bin/hipcc'] + lib.HIPCC_FLAGS +
+           ['-DRV_PROFILE', '-DRV_SOURCE_HASH="%s"' % lib.source_hash(), os.path.join(lib.CSRC, 'rv_kernels.hip'), '-o', PROF_LIB])
     subprocess.run(cmd, check=True)
     print('built', PROF_LIB)
     sys.exit(0)
 
-os.environ['RV_LIB'] = PROF_LIB
-import numpy as np
-import torch
-from robovat_amd import configs, scenes, lib
+ap = argparse.ArgumentParser()
+ap.add_argument('--envs', type=int, default=1024)
+ap.add_argument('--steps', type=int, default=20)
+ap.add_argument('--warm', type=int, default=1, help='launches of `steps` steps before the measured one')
+ap.add_argument('--seed', type=int, default=1234)
+ap.add_argument('--over', nargs='*', default=[], help='config overrides, e.g. PHYSICS.SLEEP_STEPS=0')
+ap.add_argument('--top', type=int, default=6)
+args = ap.parse_args()
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+os.environ['RV_LIB'] = PROF_LIB
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+from robovat_amd import configs, scenes, lib   # noqa: E402
+
+NS = 32
+SLOTS = {
+    0: 'quiet substep (light part only)', 1: 'light part of a non-quiet substep', 2: 'heavy: link twists',
+    18: 'heavy: narrow-phase prep (refresh, gate, work list, hull vertices)', 3: 'heavy: narrow-phase queries (GJK/EPA, features)',
+    4: 'heavy: solver row setup + flags', 25: 'solver: island entry + row loads', 26: 'solver: Delassus rows + warm start',
+    27: 'solver: sweeps', 24: 'solver: island glue + epilogues', 5: 'solver: island of 3-4 bodies (velocity space)',
+    6: 'heavy: integrate, sleep tests, return', 7: 'substep loop top', 21: 'coast: entry (clearances, loads)',
+    22: 'coast: fused substep loop', 19: 'coast: finish', 11: 'coast: after a fused run', 10: 'coast: kinematics re-measured',
+    8: 'tick: kinematics refresh', 9: 'tick: phase machine', 29: 'env.step prologue', 30: 'env.step: after the run call',
+    31: 'env.step epilogue (effectiveness, obs, reward)', 28: 'reset (drop and settle)', 20: 'random_action', 23: 'rollout_record',
+}
+GROUP = ['other (culling, loop, idle rounds)', 'GJK/EPA', 'first manifold point', 'feature stage', 'manifold refresh', '-']
+
+over = {}
+for kv in args.over:
+    k, v = kv.split('=')
+    over[k] = float(v) if ('.' in v or 'e' in v) else int(v)
 scene, names = scenes.make_scene()
-seed = int(sys.argv[4]) if len(sys.argv) > 4 else 1234
-cfg = configs.make_rv_config(n_envs=n, seed=seed, shape_names=names)
+env_cfg = configs.push_env_config(**over)
+cfg = configs.make_rv_config(env_cfg=env_cfg, n_envs=args.envs, seed=args.seed, shape_names=names)
 w = lib.World(cfg, scene, 0)
 L = lib.load()
+n = args.envs
 
 
 def prof():
-    out = torch.zeros((n, 24), dtype=torch.int64, device=w.device)
+    out = torch.zeros((n, NS), dtype=torch.int64, device=w.device)
     rc = L.rv_debug_profile(w.h, C.c_void_p(out.data_ptr()))
     assert rc == 0
     w.synchronize()
     return out.cpu().numpy().astype(np.float64)
 
 
-warm = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # launches of `steps` steps before the measured one (bench.py: 5)
 w.reset(); w.synchronize()
 first = 0
-if warm == 0:
-    w.rollout(1, first_macro_index=0, auto_reset=True, record=False); w.synchronize(); first = 1
-for _ in range(warm):
-    w.rollout(steps, first_macro_index=first, auto_reset=True, record=False); w.synchronize(); first += steps
+for _ in range(args.warm):
+    w.rollout(args.steps, first_macro_index=first, auto_reset=True, record=False); w.synchronize(); first += args.steps
 p0 = prof()
-w.rollout(steps, first_macro_index=first, auto_reset=True, record=False); w.synchronize()
+w.rollout(args.steps, first_macro_index=first, auto_reset=True, record=False); w.synchronize()
 ms = w.last_kernel_ms()
 p = prof() - p0
 st = w.stats()
-names_ = ['quiet substeps (light part only)', 'light part of non-quiet substeps', 'heavy: twists + hull vertices',
-          'heavy: narrow phase', 'heavy: row setup', 'heavy: solver (epilogue + fallback)', 'heavy: integrate + return', 'solver: islands + row loads (+ between substeps)',
-          'solver: Delassus rows + warm start', 'solver: sweeps', 'coast: budget (+refresh)', 'coast: control + motors']
-names_.append('heavy: narrow phase prep (refresh, gate, list)')
-tot = p[:, :7].sum(axis=1) + p[:, 18]
+main = [k for k in range(NS) if not (12 <= k < 18)]
+tot = p[:, main].sum(axis=1)
 slow = int(np.argmax(tot))
 clk = tot.max() / (ms * 1e-3)
-print('rollout of %d steps x %d envs: %.1f ms; slowest env = %.3g clocks => counter at %.1f MHz' % (steps, n, ms, tot.max(), clk / 1e6))
-print('substeps %d, awake fraction %.3f' % (st['substeps'], st['awake_substeps'] / max(st['substeps'], 1)))
-print('%-36s %10s %10s' % ('part', 'mean env', 'slowest'))
-for k in list(range(12)) + [18]:
-    print('%-46s %9.1f%% %9.1f%%' % (names_[k if k < 12 else 12], 100 * p[:, k].mean() / tot.mean(), 100 * p[slow, k] / tot[slow]))
-xn = {19: 'fused: finish', 20: 'random_action', 21: 'fused: entry (clearances, loads)', 22: 'fused: substep loop', 23: 'rollout_record'}
-for k in sorted(xn):
-    print('%-46s %9.1f%% %9.1f%%' % (xn[k], 100 * p[:, k].mean() / tot.mean(), 100 * p[slow, k] / tot[slow]))
-allt = p[:, :12].sum(axis=1) + p[:, 18:24].sum(axis=1)
-print('all slots / (slots 0-6,18): mean %.3f slowest %.3f' % (allt.mean() / tot.mean(), allt[slow] / tot[slow]))
+print('# tools/prof_rollout.py --envs %d --steps %d --warm %d --seed %d %s' % (n, args.steps, args.warm, args.seed, ' '.join(args.over)))
+print('rollout of %d steps x %d envs: %.1f ms kernel; slowest env marks %.3g clocks => counter at %.1f MHz' % (args.steps, n, ms, tot.max(), clk / 1e6))
+print('substeps %d, awake fraction %.4f, env-steps/s (kernel only) %.0f' % (st['substeps'], st['awake_substeps'] / max(st['substeps'], 1), st['env_steps'] / (ms * 1e-3)))
 print('mean env busy time / slowest env = %.3f' % (tot.mean() / tot.max()))
-gn = ['other (culling, loop, idle rounds)', 'GJK/EPA', 'first manifold point', 'feature stage', 'manifold refresh', '-']
-for g, gname in ((0, 'group 0 of the query stage'),):
-    gt = p[:, 12 + 6 * g: 18 + 6 * g]
-    print(gname + ': share of the narrow-phase slot, mean env / slowest env')
-    for k in range(5):
-        print('   %-36s %6.1f%% %6.1f%%' % (gn[k], 100 * gt[:, k].mean() / p[:, 3].mean(), 100 * gt[slow, k] / p[slow, 3]))
+print('%-72s %9s %9s %12s' % ('part (share of the env\'s own total)', 'mean env', 'slowest', 'slowest ms'))
+s_mean = s_slow = 0.0
+for k in SLOTS:
+    a, b = 100 * p[:, k].mean() / tot.mean(), 100 * p[slow, k] / tot[slow]
+    s_mean += a; s_slow += b
+    print('%-72s %8.1f%% %8.1f%% %12.2f' % (SLOTS[k], a, b, p[slow, k] / clk * 1e3))
+rest = [k for k in main if k not in SLOTS]
+a, b = 100 * p[:, rest].sum(1).mean() / tot.mean(), 100 * p[slow, rest].sum() / tot[slow]
+print('%-72s %8.1f%% %8.1f%%' % ('(unnamed slots)', a, b))
+print('%-72s %8.1f%% %8.1f%%' % ('sum', s_mean + a, s_slow + b))
+gt = p[:, 12:18]
+print('group 0 of the query stage: share of the narrow-phase query slot, mean env / slowest env')
+for k in range(5):
+    print('   %-40s %6.1f%% %6.1f%%' % (GROUP[k], 100 * gt[:, k].mean() / max(p[:, 3].mean(), 1), 100 * gt[slow, k] / max(p[slow, 3], 1)))
 cnt = w.env_counters().cpu().numpy()
-order = np.argsort(-tot)[:6]
-print('slowest envs: id, ms, substeps, awake, pairs')
+order = np.argsort(-tot)[:args.top]
+heavy = [1, 2, 18, 3, 4, 25, 26, 27, 24, 5, 6]
+print('slowest envs: id, ms, substeps, awake substeps, convex pairs | % of own time: light, twists, np prep, np queries, rows, isl entry, Delassus, sweeps, glue, big island, integrate | coast+ticks')
 for i in order:
-    print('  %4d %7.1f %7d %6d %6d   parts%% %s' % (i, tot[i] / clk * 1e3, cnt[i, 7], cnt[i, 8], cnt[i, 9],
-          np.round(100 * np.append(p[i, :7], p[i, 18]) / tot[i], 1)))
+    sh = 100 * p[i, heavy] / tot[i]
+    print('  %4d %7.1f %7d %6d %6d | %s | %.1f' % (i, tot[i] / clk * 1e3, cnt[i, 7], cnt[i, 8], cnt[i, 9], ' '.join('%4.1f' % x for x in sh),
+                                                   100 - sh.sum()))
+q = np.percentile(tot / clk * 1e3, [50, 90, 99, 100])
+print('env busy time ms: p50 %.1f  p90 %.1f  p99 %.1f  max %.1f' % tuple(q))
+w.close()
