@@ -105,8 +105,9 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
         got = world.body_state().cpu().numpy().astype(np.float64); want = f64.body_state()
         perr = np.linalg.norm(got[..., :3] - want[..., :3], axis=-1)
         ang = rotations.quaternion_angle(got[..., 3:7], want[..., 3:7])
-        pe[tag] = {'max_pos_m': float(perr.max()), 'median_pos_m': float(np.median(perr)),
-                   'max_angle_rad': float(ang.max()), 'median_angle_rad': float(np.median(ang))}
+        pe[tag] = {'max_pos_m': float(perr.max()), 'p99_pos_m': float(np.percentile(perr, 99)), 'median_pos_m': float(np.median(perr)),
+                   'max_angle_rad': float(ang.max()), 'p99_angle_rad': float(np.percentile(ang, 99)),
+                   'median_angle_rad': float(np.median(ang))}
     for horizon in (1, 10, 100):
         world.step_sub(horizon - done); f64.step_sub(horizon - done); done = horizon
         err('substeps_%d' % horizon)

@@ -52,6 +52,7 @@ def _lib(double):
         lib.orc_is_gripper_ready.restype = C.c_int
         lib.orc_time.restype = C.c_double
         lib.orc_eval_gjk.restype = C.c_int
+        lib.orc_get_manifold.restype = C.c_int
         lib.orc_eval_wait_until_stable.restype = C.c_int
         _LIBS[key] = lib
     return _LIBS[key]
@@ -205,6 +206,12 @@ class OracleWorld(object):
 
     def query_contacts(self):
         return self._get('orc_query_contacts', (self.n, 2 + abi.RV_MAXB), np.uint8)
+
+    def manifold(self, env, mi):
+        """(n, [4, 13]) points of one manifold: la, lb, nrm, dist, ln, lt1, lt2 (diagnostics)."""
+        out = np.zeros((4, 13))
+        n = self.lib.orc_get_manifold(self.h, C.c_int(env), C.c_int(mi), _p(out))
+        return n, out
 
     def manifold_counts(self):
         return self._get('orc_get_manifold_counts', (self.n, abi.RV_NMAN), np.int32)

@@ -107,10 +107,11 @@ static inline void orc_closest_triangle(const real* a, const real* b, const real
   l[0] = R(1.0) - v - w; l[1] = v; l[2] = w;
 }
 
-/* Reduce the simplex to the feature closest to the origin; writes v (closest
- * point) and lam.  Returns 1 when the origin is enclosed by a tetrahedron. */
-static inline int orc_simplex_solve(orc_simplex* s, real* v) {
-  real l[4] = {R(0.0), R(0.0), R(0.0), R(0.0)};
+/* Barycentric weights l[4] of the point of the simplex closest to the origin (zero for the
+ * vertices that do not support it).  Returns 1 when the origin is enclosed by a tetrahedron.
+ * The simplex is not modified. */
+static inline int orc_simplex_weights(const orc_simplex* s, real* l) {
+  l[0] = l[1] = l[2] = l[3] = R(0.0);
   if (s->n == 1) {
     l[0] = R(1.0);
   } else if (s->n == 2) {
@@ -142,7 +143,15 @@ static inline int orc_simplex_solve(orc_simplex* s, real* v) {
     }
     if (!any_outside) return 1;
   }
-  /* compact: keep vertices with positive weight, preserve order */
+  return 0;
+}
+/* the closest point those weights give: sum of l_i w_i over the supporting vertices, in order */
+static inline void orc_simplex_point(const orc_simplex* s, const real* l, real* v) {
+  v[0] = v[1] = v[2] = R(0.0);
+  for (int i = 0; i < s->n; ++i) if (l[i] > R(0.0)) v3madd(v, v, s->w[i], l[i]);
+}
+/* reduce the simplex to the vertices with positive weight (order preserved), store the weights */
+static inline void orc_simplex_commit(orc_simplex* s, const real* l) {
   int m = 0;
   for (int i = 0; i < s->n; ++i) {
     if (l[i] > R(0.0)) {
@@ -152,8 +161,14 @@ static inline int orc_simplex_solve(orc_simplex* s, real* v) {
     }
   }
   s->n = m;
-  v[0] = v[1] = v[2] = R(0.0);
-  for (int i = 0; i < m; ++i) v3madd(v, v, s->w[i], s->lam[i]);
+}
+/* Reduce the simplex to the feature closest to the origin; writes v (closest
+ * point) and lam.  Returns 1 when the origin is enclosed by a tetrahedron. */
+static inline int orc_simplex_solve(orc_simplex* s, real* v) {
+  real l[4];
+  if (orc_simplex_weights(s, l)) return 1;
+  orc_simplex_point(s, l, v);
+  orc_simplex_commit(s, l);
   return 0;
 }
 
@@ -246,6 +261,12 @@ static inline void orc_epa(const real (*A)[3], int nA, const real (*B)[3], int n
  * n (unit, from B towards A), signed core distance (negative = overlap) and
  * witness points on the two cores.  guess = initial search direction. */
 static long orc_gjk_calls = 0, orc_gjk_iters = 0;
+#ifdef ORC_DEBUG_GJK
+static __thread int orc_dbg_reason, orc_dbg_iters, orc_dbg_cache_n, orc_dbg_start_n, orc_dbg_end_n;
+#define ORC_DBG(x) x
+#else
+#define ORC_DBG(x)
+#endif
 static inline int orc_gjk_epa_c(const real (*A)[3], int nA, const real (*B)[3], int nB,
                                 const real* guess, real max_dist,
                                 real* n, real* dist, real* pa, real* pb, orc_gjk_cache* gc, int pair) {
@@ -253,6 +274,7 @@ static inline int orc_gjk_epa_c(const real (*A)[3], int nA, const real (*B)[3], 
   real v[3]; v3cpy(v, guess);
   if (!(v3dot(v, v) > R(1e-12))) v3set(v, R(1.0), R(0.0), R(0.0));
   int have_v = 0, penetrating = 0;
+  ORC_DBG(orc_dbg_reason = 0; orc_dbg_iters = 0; orc_dbg_cache_n = (gc && gc->pair == pair) ? gc->n : 0; orc_dbg_start_n = 0;)
   if (gc && gc->n > 0 && gc->pair == pair) {
     int ok = 1;
     for (int i = 0; i < gc->n; ++i) if (gc->ia[i] >= nA || gc->ib[i] >= nB) ok = 0;
@@ -265,6 +287,7 @@ static inline int orc_gjk_epa_c(const real (*A)[3], int nA, const real (*B)[3], 
       s.n = gc->n;
       if (!orc_simplex_solve(&s, v0) && v3dot(v0, v0) > R(1e-14)) { v3cpy(v, v0); have_v = 1; }
       else s.n = 0;
+      ORC_DBG(orc_dbg_start_n = s.n;)
     }
   }
   if (gc) gc->n = 0;
@@ -284,17 +307,25 @@ static inline int orc_gjk_epa_c(const real (*A)[3], int nA, const real (*B)[3], 
     int dup = 0;
     for (int k = 0; k < s.n; ++k)
       if (s.w[k][0] == w[0] && s.w[k][1] == w[1] && s.w[k][2] == w[2]) dup = 1;
-    if (dup) break;
-    if (have_v && vv - vw <= GJK_REL_TOL * vv) break;
+    ORC_DBG(orc_dbg_iters = it + 1;)
+    if (dup) { ORC_DBG(orc_dbg_reason = 1;) break; }
+    if (have_v && vv - vw <= GJK_REL_TOL * vv) { ORC_DBG(orc_dbg_reason = 2;) break; }
     v3cpy(s.w[s.n], w); v3cpy(s.a[s.n], A[ia]); v3cpy(s.b[s.n], B[ib]); s.ia[s.n] = ia; s.ib[s.n] = ib; s.n++;
-    if (orc_simplex_solve(&s, v)) { penetrating = 1; break; }
-    real vn = v3dot(v, v);
-    if (!(vn > R(1e-14))) { penetrating = 2; break; }
-    /* no progress: the closest point stopped getting closer (face-face contacts
-     * would otherwise cycle through the vertices of the touching faces) */
-    if (have_v && vv - vn <= GJK_PROGRESS_TOL * vv) break;
+    real l[4], vc[3];
+    if (orc_simplex_weights(&s, l)) { penetrating = 1; break; }
+    orc_simplex_point(&s, l, vc);
+    real vn = v3dot(vc, vc);
+    if (!(vn > R(1e-14))) { orc_simplex_commit(&s, l); v3cpy(v, vc); penetrating = 2; break; }
+    /* no progress: the new support point does not bring the closest point closer (face-face
+     * contacts would otherwise cycle through the vertices of the touching faces).  The new point
+     * is DROPPED and the query ends on the simplex it had: with four nearly coplanar points (a
+     * cached face feature plus one more vertex of the same face) the sub-simplex chosen in FP32
+     * can be farther from the origin than the one before, with a normal tilted by 20 degrees */
+    if (have_v && vv - vn <= GJK_PROGRESS_TOL * vv) { s.n--; ORC_DBG(orc_dbg_reason = 3;) break; }
+    orc_simplex_commit(&s, l); v3cpy(v, vc);
     have_v = 1;
   }
+  ORC_DBG(orc_dbg_end_n = s.n; if (penetrating) orc_dbg_reason = 10 + penetrating;)
   if (penetrating == 1) {
     real nf[3], depth;
     orc_epa(A, nA, B, nB, &s, nf, &depth, pa, pb);

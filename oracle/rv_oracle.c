@@ -629,6 +629,12 @@ static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, 
   if (!(v3dot(n, n) > R(0.5))) return 0;   /* safety net: never accept a non-unit normal */
   *out_dist = d;
   if (!m) return 1;
+#ifdef ORC_DEBUG_GJK
+  if (kind == 0 && n[2] < R(0.99) && !body_below_table(w, e, a))
+    fprintf(stderr, "TILTED table normal: step %d body %d n (%.4f %.4f %.4f) d %.6g reason %d iters %d cache_n %d start_n %d end_n %d pa (%.5f %.5f %.5f) pb (%.5f %.5f %.5f)\n",
+            e->sim_steps, a, (double)n[0], (double)n[1], (double)n[2], (double)d, orc_dbg_reason, orc_dbg_iters, orc_dbg_cache_n, orc_dbg_start_n, orc_dbg_end_n,
+            (double)pa[0], (double)pa[1], (double)pa[2], (double)pb[0], (double)pb[1], (double)pb[2]);
+#endif
 #ifdef ORC_DEBUG_NP
   fprintf(stderr, "pair kind %d a %d: n (%.6f %.6f %.6f) dist %.6g pa (%.5f %.5f %.5f) pb (%.5f %.5f %.5f)\n", kind, a, (double)n[0], (double)n[1], (double)n[2], (double)d, (double)pa[0], (double)pa[1], (double)pa[2], (double)pb[0], (double)pb[1], (double)pb[2]);
 #endif
@@ -2209,6 +2215,16 @@ void orc_query_contacts(orc_world* w, uint8_t* out) {
     o[0] = (uint8_t)e->flag_arm_table; o[1] = (uint8_t)arm_touches_movables(e);
     for (int b = 0; b < RV_MAXB; ++b) o[2 + b] = (uint8_t)(e->bp[b].active && e->flag_arm_body[b]);
   }
+}
+/* diagnostic: the points of one manifold, out[4][13] = la, lb, nrm, dist, ln, lt1, lt2; returns n */
+int orc_get_manifold(orc_world* w, int env, int mi, double* out) {
+  const orc_manifold* m = &w->env[env].man[mi];
+  for (int i = 0; i < 4; ++i) {
+    double* o = out + 13 * i;
+    for (int k = 0; k < 3; ++k) { o[k] = m->la[i][k]; o[3 + k] = m->lb[i][k]; o[6 + k] = m->nrm[i][k]; }
+    o[9] = m->dist[i]; o[10] = m->ln[i]; o[11] = m->lt1[i]; o[12] = m->lt2[i];
+  }
+  return m->n;
 }
 void orc_get_manifold_counts(orc_world* w, int32_t* out) {
   for (int i = 0; i < w->n; ++i) for (int m = 0; m < RV_NMAN; ++m) out[(size_t)i * RV_NMAN + m] = w->env[i].man[m].n;

@@ -196,9 +196,10 @@ RV_DEV void closest_triangle(v3 a, v3 b, v3 c, float* l0, float* l1, float* l2) 
   *l0 = 1.0f - v - w; *l1 = v; *l2 = w;
 }
 
-// returns 1 when a tetrahedron encloses the origin
-RV_DEV int simplex_solve(Simplex& s, v3* vout) {
-  float l[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+// barycentric weights of the point of the simplex closest to the origin (zero for the vertices
+// that do not support it); returns 1 when a tetrahedron encloses the origin.  s is not modified.
+RV_DEV int simplex_weights(const Simplex& s, float* l) {
+  l[0] = l[1] = l[2] = l[3] = 0.0f;
   if (s.n == 1) {
     l[0] = 1.0f;
   } else if (s.n == 2) {
@@ -230,6 +231,17 @@ RV_DEV int simplex_solve(Simplex& s, v3* vout) {
     }
     if (!any_outside) return 1;
   }
+  return 0;
+}
+// the closest point those weights give: sum of l_i w_i over the supporting vertices, in order
+RV_DEV v3 simplex_point(const Simplex& s, const float* l) {
+  v3 v = mk(0.0f, 0.0f, 0.0f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (i < s.n && l[i] > 0.0f) v = madd(v, s.w[i], l[i]);
+  return v;
+}
+// reduce the simplex to the vertices with positive weight (order preserved), store the weights
+RV_DEV void simplex_commit(Simplex& s, const float* l) {
   int m = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -242,10 +254,13 @@ RV_DEV int simplex_solve(Simplex& s, v3* vout) {
     }
   }
   s.n = m;
-  v3 v = mk(0.0f, 0.0f, 0.0f);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) if (i < m) v = madd(v, s.w[i], s.lam[i]);
-  *vout = v;
+}
+// returns 1 when a tetrahedron encloses the origin
+RV_DEV int simplex_solve(Simplex& s, v3* vout) {
+  float l[4];
+  if (simplex_weights(s, l)) return 1;
+  *vout = simplex_point(s, l);
+  simplex_commit(s, l);
   return 0;
 }
 
@@ -389,12 +404,18 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
 #pragma unroll
     for (int k = 0; k < 4; ++k) if (k == s.n) { s.w[k] = w; s.a[k] = va; s.b[k] = vb; s.ia[k] = ia_; s.ib[k] = ib_; }
     s.n++;
-    if (simplex_solve(s, &v)) { penetrating = 1; break; }
-    float vn = dot(v, v);
-    if (!(vn > 1e-14f)) { penetrating = 2; break; }
-    // no progress: the closest point stopped getting closer (face-face contacts
-    // would otherwise cycle through the vertices of the touching faces)
-    if (have_v && vv - vn <= RV_GJK_PROGRESS_TOL * vv) break;
+    float l[4];
+    if (simplex_weights(s, l)) { penetrating = 1; break; }
+    const v3 vc = simplex_point(s, l);
+    float vn = dot(vc, vc);
+    if (!(vn > 1e-14f)) { simplex_commit(s, l); v = vc; penetrating = 2; break; }
+    // no progress: the new support point does not bring the closest point closer (face-face
+    // contacts would otherwise cycle through the vertices of the touching faces).  The new point
+    // is DROPPED and the query ends on the simplex it had: with four nearly coplanar points (a
+    // cached face feature plus one more vertex of the same face) the sub-simplex chosen in FP32
+    // can be farther from the origin than the one before, with a normal tilted by 20 degrees
+    if (have_v && vv - vn <= RV_GJK_PROGRESS_TOL * vv) { s.n--; break; }
+    simplex_commit(s, l); v = vc;
     have_v = 1;
   }
   if (penetrating == 1) {

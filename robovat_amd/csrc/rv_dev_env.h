@@ -1342,6 +1342,19 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
       res[isl] = fmaxr(res[isl], fabsr(d));
       for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s] * d;
     }
+#ifdef RV_EMU_COUNT
+    for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && !((done >> x) & 1) && (res[x] < c->solver_tol || it == c->solver_iters - 1)) {
+      int nr = 0, arm_rows = 0;
+      for (int s = 0; s < n_rows; ++s) if (RV_ROW_ISL(S.s.rowmap[s]) == x) { ++nr; arm_rows += RV_ROW_MI(S.s.rowmap[s]) >= RV_MAXB + RV_NBB; }
+      const int cap = !(res[x] < c->solver_tol);
+      rv_emu_cnt[35] += 1; rv_emu_cnt[33] += (long)nr * (it + 1);
+      if (cap && arm_rows && e.phase >= 0 && e.phase < 8) rv_emu_cnt[38 + e.phase] += 1;
+      if (cap && arm_rows) { float nn = 0.0f; for (int s = 0; s < n_rows; ++s) if (RV_ROW_ISL(S.s.rowmap[s]) == x && RV_ROW_K(S.s.rowmap[s]) == 0 && RV_ROW_MI(S.s.rowmap[s]) >= RV_MAXB + RV_NBB) nn += lam[s];
+        if (nn / c->dt > 100.0f) rv_emu_cnt[46] += 1; if (nn / c->dt > 1000.0f) rv_emu_cnt[47] += 1; }
+      if (cap) { rv_emu_cnt[arm_rows ? 31 : 32] += 1; rv_emu_cnt[34] += (long)nr * (it + 1); if (res[x] > 10.0f * c->solver_tol) rv_emu_cnt[37] += 1; }
+      else rv_emu_cnt[36] += it + 1;
+    }
+#endif
     for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < c->solver_tol) done |= 1 << x;
     if ((done & isl_rows) == isl_rows) break;
     if (it == c->solver_iters - 1) { RV_CNT(30, 1) }

@@ -168,14 +168,21 @@ def test_observe_matches_oracle_all_modalities():
     world.close()
 
 
-def test_pose_error_vs_double_oracle_recorded():
-    """max / median body position error HIP(FP32) vs the FP64 oracle after 1, 10, 100
-    substeps of sliding contact and after a whole push, written to
-    gpurun_out/pose_err.json (bench.py reports the same numbers).  The bounds are 4x the
-    values measured on the MI355X in round 2 (profiles/r02_pose_err.json)."""
+@pytest.mark.parametrize('seed', [9, 11])
+def test_pose_error_vs_double_oracle_recorded(seed):
+    """max / p99 / p90 / median body position error HIP(FP32) vs the FP64 oracle after 1, 10, 100
+    substeps of sliding contact, written to gpurun_out/pose_err.json (bench.py reports the same
+    numbers).  Round 3: the worst body of round 2 (4.5 mm at 100 substeps, seed 9: env 34 body 2)
+    was a BUG, not rounding -- GJK started from the cached face feature, added a fourth nearly
+    coplanar vertex, and on "no progress" kept the NEW sub-simplex, which in FP32 was farther from
+    the origin than the old one and had a normal tilted by 23 degrees: the body was kicked at
+    0.16 m/s (rv_dev_collide.h gjk_epa: the new point is now dropped).  Measured since, float oracle
+    (= HIP bit for bit) vs double oracle over seeds 9..12 (1024 bodies): worst body 0.5-1.4e-6 /
+    3-9e-5 / 3.1-8.1e-4 m, p99 3-6e-7 / 1.6-2.5e-5 / 2.8-4.0e-4 m, median 2e-8 / 8e-8 / 1.5e-6 m
+    at 1 / 10 / 100 substeps.  Bounds: (max, p99, p90, median), about 3x the worst seed."""
     n = 64
-    world, ref = _world(n, seed=9), _oracle(n, seed=9, double=True)
-    f32 = _oracle(n, seed=9)
+    world, ref = _world(n, seed=seed), _oracle(n, seed=seed, double=True)
+    f32 = _oracle(n, seed=seed)
     f32.reset()
     state, params, joints = f32.body_state(), f32.body_params(), f32.joint_state()
     ref.set_body_params(params); ref.set_joint_state(joints)
@@ -183,32 +190,25 @@ def test_pose_error_vs_double_oracle_recorded():
     state[:, :, 7] += 0.2                      # shove every body at 0.2 m/s
     ref.set_body_state(state); world.set_body_state(state)
     out, done = {}, 0
-    # measured on the MI355X (profiles/r02_pose_err.json): worst body 2.1e-6 / 5.8e-5 / 6.5e-4 m, median
-    # 2.1e-8 / 1.3e-7 / 2.0e-6 m, 90th percentile 2.6e-7 / 4.4e-6 / 2.5e-5 m at 1 / 10 / 100 substeps
-    # (round 1: worst 7e-6 / 5e-4 / 1e-2 m -- the contact normal is now taken from the closest FEATURE,
-    # DESIGN.md section 3.3).  With the simplex cache (GJK starts from the last closest feature) the worst
-    # body of the 256 is 1.4e-6 / 7.5e-5 / 4.5e-3 m (one body leaves the common contact sequence between
-    # substeps 10 and 100), median 2.0e-8 / 1.1e-7 / 1.6e-6 m, p90 6.9e-8 / 1.7e-6 / 1.9e-5 m.
-    # Bounds = 4 x measured: (max, median, p90)
-    bounds = {1: (1e-5, 1e-7, 1e-6), 10: (3e-4, 6e-7, 2e-5), 100: (1.8e-2, 8e-6, 1e-4)}
+    bounds = {1: (5e-6, 2e-6, 3e-7, 8e-8), 10: (3e-4, 8e-5, 1e-5, 4e-7), 100: (2.6e-3, 1.2e-3, 1e-4, 6e-6)}
+    from robovat_amd.math import rotations
     for horizon in (1, 10, 100):
         world.step_sub(horizon - done); ref.step_sub(horizon - done); done = horizon
         got = world.body_state().cpu().numpy().astype(np.float64); want = ref.body_state()
         perr = np.linalg.norm(got[..., :3] - want[..., :3], axis=-1)
-        from robovat_amd.math import rotations
         ang = rotations.quaternion_angle(got[..., 3:7], want[..., 3:7])
-        out['substeps_%d' % horizon] = {'max_pos_m': float(perr.max()), 'median_pos_m': float(np.median(perr)),
-                                        'p90_pos_m': float(np.percentile(perr, 90)),
-                                        'max_angle_rad': float(ang.max()), 'median_angle_rad': float(np.median(ang))}
+        out['substeps_%d' % horizon] = {'max_pos_m': float(perr.max()), 'p99_pos_m': float(np.percentile(perr, 99)),
+                                        'median_pos_m': float(np.median(perr)), 'p90_pos_m': float(np.percentile(perr, 90)),
+                                        'max_angle_rad': float(ang.max()), 'p99_angle_rad': float(np.percentile(ang, 99)),
+                                        'median_angle_rad': float(np.median(ang))}
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-    with open(os.path.join(ROOT, 'gpurun_out', 'pose_err.json'), 'w') as f:
+    with open(os.path.join(ROOT, 'gpurun_out', 'pose_err_seed%d.json' % seed), 'w') as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
     for horizon in (1, 10, 100):
         o = out['substeps_%d' % horizon]
-        assert o['max_pos_m'] <= bounds[horizon][0], (horizon, o)
-        assert o['median_pos_m'] <= bounds[horizon][1], (horizon, o)
-        assert o['p90_pos_m'] <= bounds[horizon][2], (horizon, o)
+        for key, bnd in zip(('max_pos_m', 'p99_pos_m', 'p90_pos_m', 'median_pos_m'), bounds[horizon]):
+            assert o[key] <= bnd, (horizon, key, o)
     world.close()
 
 

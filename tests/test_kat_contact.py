@@ -1,0 +1,165 @@
+"""Analytic known-answer tests of the contact physics, on the CPU oracle (both
+precisions) AND on the HIP library: PyBullet is absent, so these closed-form cases are the
+external anchors of a1 (stepSimulation):
+
+  * friction cone on an incline: a box stays iff tan(theta) < mu, and beyond that slides with
+    a = g (sin theta - mu cos theta)            (gravity vector tilted: bullet_physics.py:129-137)
+  * tipping threshold: a box overhanging the table edge tips iff its centre of mass is beyond it
+  * two-box stack: stays, the upper box neither sinks nor drifts
+  * pushed box: in steady state it moves with the velocity of the pusher (the kinematic arm)
+"""
+import numpy as np
+import pytest
+
+from robovat_amd import abi, configs, scenes
+
+G = 9.8
+BOX_H = (0.035, 0.03, 0.03)      # scenes.default_shape_hulls: shape 0
+EDGE_X = 0.6 + 0.38              # +x edge of the table (layouts.py:30)
+
+
+class _Np(object):
+    """lib.World with numpy in / numpy out, so that one test body drives both backends."""
+
+    def __init__(self, w):
+        self.w = w
+
+    def __getattr__(self, name):
+        f = getattr(self.w, name)
+
+        def call(*a, **k):
+            r = f(*a, **k)
+            return r.cpu().numpy().astype(np.float64) if hasattr(r, 'cpu') else r
+        return call
+
+
+BACKENDS = ['oracle64', 'oracle32', pytest.param('hip', marks=pytest.mark.gpu)]
+
+
+def _world(backend, n=1, **over):
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(env_cfg=configs.push_env_config(**over), n_envs=n, seed=1, shape_names=names)
+    if backend == 'hip':
+        from robovat_amd import lib
+        return _Np(lib.World(cfg, scene, device=0)), cfg
+    from oracle import orc
+    return orc.OracleWorld(cfg, scene, double=(backend == 'oracle64')), cfg
+
+
+def _bodies(w, rows, n=1):
+    """rows: list of (shape, mass, friction, xyz, quat xyzw, vel3)."""
+    p = np.zeros((n, abi.RV_MAXB, 8)); s = np.zeros((n, abi.RV_MAXB, 13)); s[..., 6] = 1
+    for b, (shape, mass, mu, xyz, quat, vel) in enumerate(rows):
+        p[:, b] = [1, shape, 1.0, mass, mu, 0, 0.0, 0]
+        s[:, b, :3] = xyz; s[:, b, 3:7] = quat; s[:, b, 7:10] = vel
+    w.set_body_params(p); w.set_body_state(s)
+
+
+Q0 = (0, 0, 0, 1)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_incline_friction_cone(backend):
+    """mu = 0.5 (body 0.5 x table 1.0): critical angle atan(0.5) = 26.57 deg.  The tangent rows of a
+    contact with normal +z run along x and y (plane_space), so the pyramid is exact along x."""
+    mu = 0.5
+    for deg, slides in ((24.0, False), (25.5, False), (27.5, True), (30.0, True)):
+        th = np.radians(deg)
+        w, cfg = _world(backend, **{'PHYSICS.GRAVITY_Z': -G * np.cos(th), 'PHYSICS.GRAVITY_XY': (G * np.sin(th), 0.0)})
+        _bodies(w, [(0, 0.2, mu, (0.45, 0.0, 0.031), Q0, (0, 0, 0))])
+        T = 400
+        w.step_sub(T)
+        st = w.body_state()[0, 0]
+        dx = st[0] - 0.45
+        if not slides:
+            assert abs(dx) < 2e-4 and np.abs(st[7:10]).max() < 2e-3, (deg, dx, st[7:10])
+        else:
+            # semi-implicit Euler with Bullet's 0.04 damping: v <- (v + a dt) * damp each substep
+            a, v, x, damp = G * (np.sin(th) - mu * np.cos(th)), 0.0, 0.0, float(cfg.lin_damp)
+            for _ in range(T):
+                v = (v + a * float(cfg.dt)) * damp; x += v * float(cfg.dt)
+            assert abs(dx - x) < 0.08 * x + 2e-4, (deg, dx, x)
+            assert abs(st[7] - v) < 0.08 * v + 1e-3, (deg, st[7], v)
+        if hasattr(w, 'w'):
+            w.close()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_tipping_threshold_at_the_table_edge(backend):
+    """A box whose centre of mass is 4 mm inside the table edge stays; 4 mm outside it tips over
+    the edge and falls to the ground (torque balance about the edge)."""
+    for off, tips in ((-0.004, False), (0.004, True)):
+        w, cfg = _world(backend)
+        _bodies(w, [(0, 0.2, 0.5, (EDGE_X + off, 0.0, 0.031), Q0, (0, 0, 0))])
+        w.step_sub(1500)
+        st = w.body_state()[0, 0]
+        if tips:
+            assert st[2] < -0.2 and st[0] > EDGE_X, (off, st[:3])                 # left the table
+        else:
+            assert abs(st[2] - 0.031) < 1e-3 and abs(st[0] - (EDGE_X + off)) < 3e-3, (off, st[:3])
+            assert np.abs(st[7:13]).max() < 5e-3
+        if hasattr(w, 'w'):
+            w.close()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_two_box_stack_rests(backend):
+    w, cfg = _world(backend)
+    z0, z1 = 0.031, 0.031 + 0.06 + 0.002
+    _bodies(w, [(0, 0.3, 0.5, (0.6, 0.0, z0), Q0, (0, 0, 0)), (0, 0.2, 0.5, (0.605, 0.003, z1), Q0, (0, 0, 0))])
+    w.step_sub(1500)
+    st = w.body_state()[0]
+    assert abs(st[0, 2] - z0) < 1.2e-3 and abs(st[1, 2] - z1) < 2.4e-3, st[:2, 2]      # no sinking (slop 0.5 mm per contact)
+    assert np.abs(st[0, :2] - [0.6, 0.0]).max() < 1e-4 and np.abs(st[1, :2] - [0.605, 0.003]).max() < 1e-4
+    assert np.abs(st[:2, 7:13]).max() < 2e-3
+    mc = w.manifold_counts()[0]
+    assert mc[0] == 4 and mc[abi.RV_MAXB + 0] >= 3, mc         # box-table, box-box (pair 0 = bodies 0, 1)
+    assert mc[1] == 0                                           # the upper box does not touch the table
+    if hasattr(w, 'w'):
+        w.close()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_pushed_box_moves_with_the_pusher(backend):
+    """The (kinematic) gripper pushes a box across the table: while they are in contact the box
+    moves with the velocity of the finger it touches."""
+    w, cfg = _world(backend)
+    w.reset()
+    z_push = float(cfg.finger_tip_offset) + 0.5 * (float(cfg.cspace_high[2]) + float(cfg.cspace_low[2]))
+    tz = float(w.body_params()[0, 0, 6])
+    quat = np.array([1.0, 0.0, 0.0, 0.0])                         # euler [pi, 0, 0]: top-down gripper
+    start = np.concatenate([[0.50, 0.0, tz + z_push], quat]).astype(np.float32)
+    end = np.concatenate([[0.75, 0.0, tz + z_push], quat]).astype(np.float32)
+    js = w.joint_state()
+    for _ in range(8):                                            # joint state at the start pose (IK from the last state)
+        q = w.compute_ik(start[None])[0]
+        js[0, :7, 0] = q; js[0, :7, 1] = 0.0
+        w.set_joint_state(js)
+    p = np.zeros((1, abi.RV_MAXB, 8)); p[0, 0] = [1, 0, 1.0, 0.2, 0.5, 0, tz, 0]
+    s = np.zeros((1, abi.RV_MAXB, 13)); s[..., 6] = 1; s[0, 0, :3] = [0.62, 0.0, tz + 0.031]
+    w.set_body_params(p); w.set_body_state(s)
+    w.set_link_target(end[None])
+    hist = []
+    prev = w.link_poses()[0, 8:10, 0].copy()                      # the two finger frames
+    for _ in range(160):
+        w.step_sub(10)
+        cur = w.link_poses()[0, 8:10, 0].copy()
+        vf = (cur - prev).mean() / (10 * float(cfg.dt)); prev = cur
+        st = w.body_state()[0, 0]
+        touching = w.manifold_counts()[0, abi.RV_MAXB + abi.RV_NBB] > 0
+        hist.append((vf, st[7], touching, st[0], st[12]))
+    hist = np.array(hist)
+    # steady straight pushing: in contact, the pusher above 60 % of its top speed (when it brakes at
+    # the end of the stroke the box slides on ahead of it) and the box not yet yawing (its centre
+    # then moves differently from the contact point)
+    first = int(np.argmax(hist[:, 2] > 0)) + 3                    # after the impact transient
+    yawing = np.nonzero(np.abs(hist[first:, 4]) >= 0.02)[0]
+    last = first + (int(yawing[0]) if len(yawing) else len(hist) - first)
+    push = hist[first:last]
+    push = push[(push[:, 2] > 0) & (push[:, 0] > 0.6 * hist[:, 0].max())]
+    assert len(push) >= 20, len(push)                             # >= 0.2 s
+    rel = np.abs(push[:, 1] - push[:, 0]) / push[:, 0]
+    assert np.median(rel) < 0.01 and rel.max() < 0.03, (np.median(rel), rel.max())
+    assert hist[-1, 3] - 0.62 > 0.05                              # the box was carried along
+    if hasattr(w, 'w'):
+        w.close()

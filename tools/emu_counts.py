@@ -44,3 +44,7 @@ print('solver (host row list): %d solves, %.2f iterations, %.1f rows per solve' 
 print('solves that ran into the iteration cap: %d' % c[30])
 print('heavy substeps: arm contact points %d | arm near %d | arm far, moving %d | arm far, static %d ; bodies below the sleep speeds %d'
       % (c[24], c[25], c[26], c[27], c[28]))
+print('islands solved (1-2 bodies): %d; ran into the cap: %d with arm rows, %d without (%d of them with a residual > 10 x tol); mean sweeps of the others %.2f'
+      % (c[35], c[31], c[32], c[37], c[36] / max(c[35] - c[31] - c[32], 1)))
+print('solver work (rows x sweeps): %d, of which in islands that ran into the cap: %d (%.1f %%)' % (c[33], c[34], 100.0 * c[34] / max(c[33], 1)))
+print('cap hits with arm rows by phase (initial, pre, start, motion, post, offstage, done): %s; arm normal force > 100 N: %d, > 1000 N: %d' % (c[38:45], c[46], c[47]))

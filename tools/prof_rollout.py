@@ -32,6 +32,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--envs', type=int, default=1024)
 ap.add_argument('--steps', type=int, default=20)
 ap.add_argument('--warm', type=int, default=1, help='launches of `steps` steps before the measured one')
+ap.add_argument('--warm-steps', type=int, default=None, help='steps per warm launch (default: --steps); bench.py = --warm 1 --warm-steps 5')
 ap.add_argument('--seed', type=int, default=1234)
 ap.add_argument('--over', nargs='*', default=[], help='config overrides, e.g. PHYSICS.SLEEP_STEPS=0')
 ap.add_argument('--top', type=int, default=6)
@@ -77,8 +78,9 @@ def prof():
 
 w.reset(); w.synchronize()
 first = 0
+ws = args.steps if args.warm_steps is None else args.warm_steps
 for _ in range(args.warm):
-    w.rollout(args.steps, first_macro_index=first, auto_reset=True, record=False); w.synchronize(); first += args.steps
+    w.rollout(ws, first_macro_index=first, auto_reset=True, record=False); w.synchronize(); first += ws
 p0 = prof()
 w.rollout(args.steps, first_macro_index=first, auto_reset=True, record=False); w.synchronize()
 ms = w.last_kernel_ms()
