@@ -107,6 +107,12 @@ typedef struct rv_arm {
   int32_t col_frame[RV_NCOL];    /* which link frame each collider box rides on */
   float col_center[RV_NCOL][3];
   float col_half[RV_NCOL][3];
+  /* 1 / (URDF effort limit) of every joint (1 / N m; fingers 1 / N), 0 = unlimited.  PyBullet's
+   * POSITION_CONTROL motors are limited to the joint effort (bullet_physics.py:1061-1104: default
+   * max force); with the kinematic limb the limit acts on what the arm can push with: the normal
+   * impulse of an arm - body contact row is capped at dt x min_j tau_j / |J_j . n| over the joints
+   * upstream of the collider (rv_config.arm_effort_limit) */
+  float inv_tau_max[RV_NJ];
 } rv_arm;
 
 typedef struct rv_scene {
@@ -248,6 +254,8 @@ typedef struct rv_config {
   /* horizontal components of the gravity vector (simulator.py:27 takes a 3-vector;
    * bullet_physics.py:129-137 set_gravity); gravity_z above is the third */
   float    gravity_xy[2];
+  /* 1: arm - body contact forces are limited by the joint efforts (rv_arm.inv_tau_max) */
+  int32_t  arm_effort_limit;
 } rv_config;
 
 /* Per-launch statistics of rv_step_macro / rv_reset (device-side reductions of

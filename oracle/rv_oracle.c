@@ -850,6 +850,7 @@ typedef struct {
   real vbc[3];        /* dir . (kinematic surface velocity) */
   real target, mu;
   real jf[3]; int fidx;   /* dynamic finger (rv_config.finger_dynamics): Jacobian on finger joint 7 + fidx; -1: none */
+  real cap;           /* largest normal impulse the row may carry (arm effort limit); 1e30: none */
 } orc_row;
 
 static void row_setup(const orc_world* w, orc_env* e, int kind, int a, int b, const orc_manifold* m, int i, orc_row* r) {
@@ -891,6 +892,24 @@ static void row_setup(const orc_world* w, orc_env* e, int kind, int a, int b, co
     r->jf[k] = jf;
   }
   r->fidx = fing ? m->col[i] - 8 : -1;
+  /* what the arm can push with along the normal: min over the joints upstream of the collider of
+   * tau_j / |J_j . n| (J_j = axis_j x (p - p_j); a finger pad also slides along the hand's y) */
+  r->cap = R(1e30);
+  if (kind == 2 && c->arm_effort_limit) {
+    const rv_arm* arm = &w->scene.arm;
+    const int f = arm->col_frame[m->col[i]];
+    const int fl = f < RV_NLIMB ? f : RV_NLIMB - 1;
+    real worst = R(0.0);
+    for (int j = 0; j < RV_NLIMB; ++j) {
+      if (j > fl) continue;
+      real d[3], lever[3];
+      v3sub(d, wb, e->fpos[j]); v3cross(lever, e->axis[j], d);
+      worst = rmax(worst, rabs(v3dot(lever, r->dir[0])) * (real)arm->inv_tau_max[j]);
+    }
+    if (f >= 8 && !c->finger_dynamics) worst = rmax(worst, rabs(v3dot(fy, r->dir[0])) * (real)arm->inv_tau_max[f - 1]);
+    /* (the budget is shared equally by the points of the manifold) */
+    if (worst > R(0.0)) r->cap = dt / (worst * (real)m->n);
+  }
   real dist = m->dist[i];
   if (dist > R(0.0)) r->target = -dist / dt;
   else r->target = rmin((real)c->erp * rmax(-dist - (real)c->slop, R(0.0)) / dt, (real)c->max_pushout);
@@ -917,7 +936,7 @@ static real point_solve(orc_env* e, int kind, int a, int b, orc_manifold* m, int
   real res;
   real jv = row_jv(e, kind, a, b, r, 0);
   real dl = (r->target - jv) * r->invk[0];
-  real ln = rmax(m->ln[i] + dl, R(0.0));
+  real ln = rclamp(m->ln[i] + dl, R(0.0), r->cap);
   dl = ln - m->ln[i]; m->ln[i] = ln;
   res = rabs(dl);
   row_apply(e, kind, a, b, r, 0, dl);
@@ -950,7 +969,7 @@ static real point_solve_g(orc_env* e, int a, orc_manifold* m, int i, const orc_r
   real jv = row_jv(e, 0, a, -1, r, 0);
   if (fi >= 0) jv += r->jf[0] * qf[fi];
   real dl = (r->target - jv) * r->invk[0];
-  real ln = rmax(m->ln[i] + dl, R(0.0));
+  real ln = rclamp(m->ln[i] + dl, R(0.0), r->cap);
   dl = ln - m->ln[i]; m->ln[i] = ln;
   real res = rabs(dl);
   row_apply(e, 0, a, -1, r, 0, dl);
@@ -1043,13 +1062,13 @@ static real dotj(const orc_j6* j, const real* pl, const real* pa) { return v3dot
 static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const orc_rowid* id, int n_rows, const int* use, const int* big, const int* label) {
   const rv_config* c = &w->cfg;
   static __thread real A[SOLVE_ROWS][SOLVE_ROWS];
-  real g[SOLVE_ROWS], lam[SOLVE_ROWS], invk[SOLVE_ROWS], bias[SOLVE_ROWS], mu[SOLVE_ROWS];
+  real g[SOLVE_ROWS], lam[SOLVE_ROWS], invk[SOLVE_ROWS], bias[SOLVE_ROWS], mu[SOLVE_ROWS], cap[SOLVE_ROWS];
   orc_j6 jx[SOLVE_ROWS][RV_MAXB];
   for (int r = 0; r < n_rows; ++r) {
     const orc_row* rw = &rows[id[r].mi][id[r].i]; const orc_manifold* mm = &e->man[id[r].mi];
     const int k = id[r].k, ra = id[r].a, rb = id[r].b, pi = id[r].i;
     memset(jx[r], 0, sizeof(jx[r]));
-    invk[r] = rw->invk[k]; mu[r] = rw->mu; bias[r] = k == 0 ? rw->target : R(0.0);
+    invk[r] = rw->invk[k]; mu[r] = rw->mu; bias[r] = k == 0 ? rw->target : R(0.0); cap[r] = rw->cap;
     lam[r] = k == 0 ? mm->ln[pi] : (k == 1 ? mm->lt1[pi] : mm->lt2[pi]);
     real gg = v3dot(rw->dir[k], e->body[ra].v) + v3dot(rw->rxa[k], e->body[ra].w);
     v3cpy(jx[r][ra].l, rw->dir[k]); v3cpy(jx[r][ra].a, rw->rxa[k]);
@@ -1081,7 +1100,7 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
       const int isl = id[s2].isl;
       if ((done >> isl) & 1) continue;
       real nl;
-      if (id[s2].k == 0) nl = rmax(lam[s2] + (bias[s2] - g[s2]) * invk[s2], R(0.0));
+      if (id[s2].k == 0) nl = rclamp(lam[s2] + (bias[s2] - g[s2]) * invk[s2], R(0.0), cap[s2]);
       else nl = rclamp(lam[s2] + (-g[s2] * invk[s2]), -lim, lim);
       const real d = nl - lam[s2];
       lam[s2] = nl;

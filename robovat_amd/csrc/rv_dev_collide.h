@@ -265,7 +265,10 @@ RV_DEV int simplex_solve(Simplex& s, v3* vout) {
 }
 
 // EPA on an origin-enclosing tetrahedron; polytope in the private workspace E.
-RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const Simplex& s,
+// (the four seed vertices come in a struct of their own: passing the GJK simplex by reference to
+// this out-of-line function would pin it in private memory for the whole query)
+struct EpaSeed { v3 w[4], a[4], b[4]; };
+RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const EpaSeed& s,
                          v3* out_nf, float* out_depth, v3* pa, v3* pb) {
   EpaWork E;  // private (scratch) memory: deep penetration is rare, LDS is not spent on it
   int nv = 4, nf = 0;
@@ -421,7 +424,10 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
   if (penetrating == 1) {
     v3 nf; float depth;
     RV_CNT(20, 1)
-    epa(A, nA, B, nB, s, &nf, &depth, pa, pb);
+    EpaSeed seed;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { seed.w[i] = s.w[i]; seed.a[i] = s.a[i]; seed.b[i] = s.b[i]; }
+    epa(A, nA, B, nB, seed, &nf, &depth, pa, pb);
     if (depth < 1e29f) {
       *n = scale(nf, -1.0f);
       *dist = -depth;

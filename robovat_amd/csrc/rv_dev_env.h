@@ -134,6 +134,7 @@ struct Row {
   // dynamic finger (rv_config.finger_dynamics): the row also acts on finger joint 7 + fidx with
   // Jacobian jf = -(dir . slide axis); fidx = -1: no finger involved
   float jf[3]; int fidx;
+  float cap;   // largest normal impulse the row may carry (arm effort limit); 1e30: none
 };
 
 struct Scratch {
@@ -905,7 +906,7 @@ RV_DEV void owner_decode(const Shared& S, const Consts& K, int owner, int arm_on
 }
 
 // ------------------------------------------------------------------ PGS --
-RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, const ManPoint& p, Row& r) {
+RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, const ManPoint& p, Row& r, const int n_pts) {
   const rv_config* c = K.cfg; const DevEnv& e = S.e;
   float dt = c->dt;
   v3 wa, wb;
@@ -947,6 +948,24 @@ RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, 
     r.jf[k] = jf;
   }
   r.fidx = fing ? p.col - 8 : -1;
+  // what the arm can push with along the normal: min over the joints upstream of the collider of
+  // tau_j / |J_j . n| (J_j = axis_j x (p - p_j); a finger pad also slides along the hand's y)
+  r.cap = 1e30f;
+  if (kind == 2 && c->arm_effort_limit) {
+    const rv_arm* arm = K.arm;
+    const int f = arm->col_frame[p.col];
+    const int fl = f < RV_NLIMB ? f : RV_NLIMB - 1;
+    float worst = 0.0f;
+#pragma unroll
+    for (int j = 0; j < RV_NLIMB; ++j) {
+      if (j > fl) continue;
+      const v3 lever = cross(ld3(S.s.axis[j]), sub(wb, ld3(e.fpos[j])));
+      worst = fmaxr(worst, fabsr(dot(lever, d0)) * arm->inv_tau_max[j]);
+    }
+    if (f >= 8 && !c->finger_dynamics) worst = fmaxr(worst, fabsr(dot(fy, d0)) * arm->inv_tau_max[f - 1]);
+    // (the budget is shared equally by the points of the manifold)
+    if (worst > 0.0f) r.cap = dt / (worst * (float)n_pts);
+  }
   float dist = p.dist;
   if (dist > 0.0f) r.target = -dist / dt;
   else r.target = fminr(c->erp * fmaxr(-dist - c->slop, 0.0f) / dt, c->max_pushout);
@@ -977,7 +996,7 @@ struct Lam { float n, t1, t2; };
 RV_DEV float point_solve(BV& A, BV* B, float ima, float imb, Lam& l, const Row& r) {
   float jv = row_jv(A, B, r, 0);
   float dl = (r.target - jv) * r.invk[0];
-  float ln = fmaxr(l.n + dl, 0.0f);
+  float ln = fclampr(l.n + dl, 0.0f, r.cap);
   dl = ln - l.n; l.n = ln;
   float res = fabsr(dl);
   row_apply(A, B, ima, imb, r, 0, dl);
@@ -1013,7 +1032,7 @@ RV_DEV float point_solve_g(BV& A, float ima, Lam& l, const Row& r, float* qf, fl
   float jv = row_jv(A, nullptr, r, 0);
   if (fi >= 0) jv += r.jf[0] * qf[fi];
   float dl = (r.target - jv) * r.invk[0];
-  float ln = fmaxr(l.n + dl, 0.0f);
+  float ln = fclampr(l.n + dl, 0.0f, r.cap);
   dl = ln - l.n; l.n = ln;
   float res = fabsr(dl);
   row_apply(A, nullptr, ima, 0.0f, r, 0, dl);
@@ -1185,10 +1204,10 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
   DevMan& mm = e.man[mi];
   J6 JX, JY, PX, PY;
   JX.l = JX.a = JY.l = JY.a = PX.l = PX.a = PY.l = PY.a = mk(0, 0, 0);
-  float invk = 0.0f, bias = 0.0f, mu = 0.0f, lam = 0.0f, g = 0.0f;
+  float invk = 0.0f, bias = 0.0f, mu = 0.0f, lam = 0.0f, g = 0.0f, cap = 1e30f;
   if (act) {
     const v3 dir = ld3(R.dir[k]), rxa = ld3(R.rxa[k]);
-    invk = R.invk[k]; mu = R.mu; bias = k == 0 ? R.target : 0.0f;
+    invk = R.invk[k]; mu = R.mu; bias = k == 0 ? R.target : 0.0f; cap = R.cap;
     lam = k == 0 ? mm.ln[slot] : (k == 1 ? mm.lt1[slot] : mm.lt2[slot]);
     const int ba = blk == 1 ? Yc : X;          // body a of the row's manifold
     g = dot(dir, ld3(e.body[ba] + 7)) + dot(rxa, ld3(e.body[ba] + 10));
@@ -1236,7 +1255,7 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
       for (int kk = 0; kk < 3; ++kk) {
         const int s = 3 * pp + kk;
         float nl;
-        if (kk == 0) nl = __builtin_fmaxf(lam + (bias - g) * invk, 0.0f);
+        if (kk == 0) nl = __builtin_amdgcn_fmed3f(lam + (bias - g) * invk, 0.0f, cap);
         else nl = __builtin_amdgcn_fmed3f(lam + (-g * invk), -lim, lim);
         const float d = nl - lam;
         if (lane == s) lam = nl;
@@ -1287,7 +1306,7 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
 RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
   DevEnv& e = S.e; const rv_config* c = K.cfg;
   static thread_local float A[RV_SOLVE_ROWS][RV_SOLVE_ROWS];
-  float g[RV_SOLVE_ROWS], lam[RV_SOLVE_ROWS], invk[RV_SOLVE_ROWS], bias[RV_SOLVE_ROWS], mu[RV_SOLVE_ROWS];
+  float g[RV_SOLVE_ROWS], lam[RV_SOLVE_ROWS], invk[RV_SOLVE_ROWS], bias[RV_SOLVE_ROWS], mu[RV_SOLVE_ROWS], cap[RV_SOLVE_ROWS];
   J6 jx[RV_SOLVE_ROWS][RV_MAXB];
   for (int r = 0; r < n_rows; ++r) {
     const int rm = S.s.rowmap[r];
@@ -1296,7 +1315,7 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
     const DevMan& mm = e.man[mi];
     for (int x = 0; x < RV_MAXB; ++x) { jx[r][x].l = mk(0, 0, 0); jx[r][x].a = mk(0, 0, 0); }
     const v3 dir = ld3(R.dir[k]), rxa = ld3(R.rxa[k]);
-    invk[r] = R.invk[k]; mu[r] = R.mu; bias[r] = k == 0 ? R.target : 0.0f;
+    invk[r] = R.invk[k]; mu[r] = R.mu; bias[r] = k == 0 ? R.target : 0.0f; cap[r] = R.cap;
     lam[r] = k == 0 ? mm.ln[pi] : (k == 1 ? mm.lt1[pi] : mm.lt2[pi]);
     float gg = dot(dir, ld3(e.body[ra] + 7)) + dot(rxa, ld3(e.body[ra] + 10));
     v3 nd = mk(0, 0, 0), nrxb = mk(0, 0, 0);
@@ -1334,12 +1353,18 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
       const int isl = RV_ROW_ISL(q);
       if ((done >> isl) & 1) continue;
       float nl;
-      if (RV_ROW_K(q) == 0) nl = fmaxr(lam[s] + (bias[s] - g[s]) * invk[s], 0.0f);
+      if (RV_ROW_K(q) == 0) nl = fclampr(lam[s] + (bias[s] - g[s]) * invk[s], 0.0f, cap[s]);
       else nl = fclampr(lam[s] + (-g[s] * invk[s]), -lim, lim);
       const float d = nl - lam[s];
       lam[s] = nl;
       if (RV_ROW_K(q) == 0) lim = mu[s] * nl;
       res[isl] = fmaxr(res[isl], fabsr(d));
+#ifdef RV_EMU_COUNT
+      if (it == c->solver_iters - 1 && fabsr(d) >= c->solver_tol) {
+        const int mi_ = RV_ROW_MI(q), cls = (mi_ < RV_MAXB ? 0 : (mi_ < RV_MAXB + RV_NBB ? 1 : 2)) * 2 + (RV_ROW_K(q) != 0);
+        rv_emu_dbg[cls] += 1; if (RV_ROW_K(q) == 0 && nl >= cap[s]) rv_emu_dbg[6] += 1; if (RV_ROW_K(q) != 0 && (nl >= lim || nl <= -lim)) rv_emu_dbg[7] += 1;
+      }
+#endif
       for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s] * d;
     }
 #ifdef RV_EMU_COUNT
@@ -2523,7 +2548,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         p.la = ld3(m.la[i]); p.lb = ld3(m.lb[i]); p.nrm = ld3(m.nrm[i]); p.dist = m.dist[i]; p.col = m.col[i];
         p.ln = m.ln[i]; p.lt1 = m.lt1[i]; p.lt2 = m.lt2[i];
         Row r;
-        row_setup(S, K, kind, a, b, p, r);
+        row_setup(S, K, kind, a, b, p, r, m.n);
         S.s.u.r.rows[mi][i] = r;
         m.ln[i] = p.ln * c->warmstart; m.lt1[i] = p.lt1 * c->warmstart; m.lt2[i] = p.lt2 * c->warmstart;
       }

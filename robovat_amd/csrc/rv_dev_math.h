@@ -22,6 +22,7 @@ namespace rv {
 
 #ifdef RV_EMU_COUNT
 static long rv_emu_cnt[48];      // ad-hoc event counters of the host emulation (tools only)
+static long rv_emu_dbg[16];
 #define RV_CNT(i, n) rv_emu_cnt[i] += (n);
 #else
 #define RV_CNT(i, n)

@@ -211,6 +211,8 @@ SAWYER_LIMITS = [(-3.0503, 3.0503), (-3.8095, 2.2736), (-3.0426, 3.0426),
                  (-4.7124, 4.7124)]
 SAWYER_MAX_VELOCITY = [1.74, 1.328, 1.957, 1.957, 3.485, 3.485, 4.545]
 SAWYER_MAX_ACCEL = [8.0, 8.0, 10.0, 10.0, 15.0, 15.0, 20.0]
+SAWYER_EFFORT = [80.0, 80.0, 40.0, 40.0, 9.0, 9.0, 9.0]     # N m
+FINGER_EFFORT = 20.0                                         # N
 LIMB_JOINT_NAMES = ['right_j%d' % i for i in range(7)]
 FINGER_JOINT_NAMES = ['right_gripper_l_finger_joint',
                       'right_gripper_r_finger_joint']
@@ -239,11 +241,13 @@ def make_arm(base_pos=(0.0, 0.0, 0.0), base_rpy=(0.0, 0.0, 0.0), finger_accel=2.
         arm.q_lo[j], arm.q_hi[j] = SAWYER_LIMITS[j]
         arm.v_max[j] = SAWYER_MAX_VELOCITY[j]
         arm.a_max[j] = SAWYER_MAX_ACCEL[j]
+        arm.inv_tau_max[j] = 1.0 / SAWYER_EFFORT[j]
     # electric parallel gripper: left finger 0..+stroke, right -stroke..0
     arm.q_lo[7], arm.q_hi[7] = 0.0, FINGER_STROKE
     arm.q_lo[8], arm.q_hi[8] = -FINGER_STROKE, 0.0
     arm.v_max[7] = arm.v_max[8] = 0.1
     arm.a_max[7] = arm.a_max[8] = float(finger_accel)
+    arm.inv_tau_max[7] = arm.inv_tau_max[8] = 1.0 / FINGER_EFFORT
     # open gap (2 x (0.004 + stroke) - pad thickness) ~ 3.8 cm: narrower than the smallest movable, so a
     # push cannot straddle a body
     arm.finger_y0[0], arm.finger_y0[1] = 0.004, -0.004

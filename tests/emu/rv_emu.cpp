@@ -35,6 +35,7 @@ static void run_env(EmuWorld* w, int i, int mode, int n_sub, float lin, float an
 extern "C" {
 #ifdef RV_EMU_COUNT
 void emu_get_counts(long* out) { for (int i = 0; i < 48; ++i) out[i] = rv_emu_cnt[i]; }
+void emu_get_dbg(long* out) { for (int i = 0; i < 16; ++i) out[i] = rv_emu_dbg[i]; }
 #endif
 EmuWorld* emu_create(const rv_config* cfg, const rv_scene* scene) {
   EmuWorld* w = (EmuWorld*)calloc(1, sizeof(EmuWorld));

@@ -154,3 +154,18 @@ def test_wide_rollout_matches_oracle_bit_for_bit():
     ws, rs = world.stats(), ref.stats()
     for k in ('env_steps', 'substeps', 'awake_substeps', 'max_substeps'):
         assert ws[k] == rs[k], k
+
+
+@pytest.mark.parametrize('over', [{'PHYSICS.ARM_EFFORT_LIMIT': 1}, {'PHYSICS.GRAVITY_XY': (0.3, -0.2)},
+                                  {'PHYSICS.SLEEP_STEPS': 0}])
+def test_optional_physics_match_oracle_bit_for_bit(over):
+    """The optional pieces -- joint-effort limit on the arm's contact forces, a tilted gravity
+    vector (set_gravity), no deactivation at all -- through a rollout with resets."""
+    world, ref, cfg = _worlds(48, seed=5, MAX_STEPS=3, **over)
+    world.reset(); ref.reset()
+    world.rollout(4, first_macro_index=0, auto_reset=True, record=False)
+    ref.rollout(4, 0, True)
+    assert _cmp(world, ref, 0.0) == 0.0
+    ws, rs = world.stats(), ref.stats()
+    for k in ('env_steps', 'substeps', 'awake_substeps'):
+        assert ws[k] == rs[k], k

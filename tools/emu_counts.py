@@ -48,3 +48,5 @@ print('islands solved (1-2 bodies): %d; ran into the cap: %d with arm rows, %d w
       % (c[35], c[31], c[32], c[37], c[36] / max(c[35] - c[31] - c[32], 1)))
 print('solver work (rows x sweeps): %d, of which in islands that ran into the cap: %d (%.1f %%)' % (c[33], c[34], 100.0 * c[34] / max(c[33], 1)))
 print('cap hits with arm rows by phase (initial, pre, start, motion, post, offstage, done): %s; arm normal force > 100 N: %d, > 1000 N: %d' % (c[38:45], c[46], c[47]))
+dbg = (C.c_long * 16)(); lib.emu_get_dbg(dbg)
+print('rows still changing by >= tol in the last sweep of a capped solve: table n %d t %d | pair n %d t %d | arm n %d t %d ; normal rows at their effort cap %d, friction rows at the cone %d' % tuple(list(dbg)[:8]))
