@@ -1095,16 +1095,18 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
   int isl_rows = 0, done = 0;
   for (int s2 = 0; s2 < n_rows; ++s2) isl_rows |= 1 << id[s2].isl;
   for (int it = 0; it < c->solver_iters; ++it) {
-    real res[RV_MAXB] = {R(0.0), R(0.0), R(0.0), R(0.0)}, lim = R(0.0);
+    real res[RV_MAXB] = {R(0.0), R(0.0), R(0.0), R(0.0)};
+    real limtab[RV_NMAN][4];   /* friction bound of every point: mu x its normal impulse (the rows of a point need not be neighbours in the list) */
     for (int s2 = 0; s2 < n_rows; ++s2) {
       const int isl = id[s2].isl;
       if ((done >> isl) & 1) continue;
       real nl;
+      const real lim = id[s2].k == 0 ? R(0.0) : limtab[id[s2].mi][id[s2].i];
       if (id[s2].k == 0) nl = rclamp(lam[s2] + (bias[s2] - g[s2]) * invk[s2], R(0.0), cap[s2]);
       else nl = rclamp(lam[s2] + (-g[s2] * invk[s2]), -lim, lim);
       const real d = nl - lam[s2];
       lam[s2] = nl;
-      if (id[s2].k == 0) lim = mu[s2] * nl;
+      if (id[s2].k == 0) limtab[id[s2].mi][id[s2].i] = mu[s2] * nl;
       res[isl] = rmax(res[isl], rabs(d));
       for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s2] * d;
     }
@@ -1174,9 +1176,27 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
       for (int i = 0; i < m->n; ++i) {
         row_setup(w, e, kind, b, -1, m, i, &rows[mi][i]);
         m->ln[i] *= (real)c->warmstart; m->lt1[i] *= (real)c->warmstart; m->lt2[i] *= (real)c->warmstart;
-        if (!big[label[b]]) for (int k3 = 0; k3 < 3; ++k3) { orc_rowid x = {mi, i, k3, b, -1, label[b]}; id[n_rows++] = x; }
       }
     }
+  /* visiting order of the rows of a body's own manifolds: bodies ascending, per body the table points
+   * then the arm points, per point n, t1, t2 -- and the two members X < Y of a two-body island are
+   * visited TOGETHER, slot by slot (X's row of slot t, then Y's row of slot t; slot = 3 * (4 * [arm] +
+   * point) + row): their own rows do not couple with each other (only through the X-Y manifold, which
+   * comes later), so the device solves the two blocks side by side */
+  for (int b = 0; b < RV_MAXB; ++b) {
+    if (!use[TIDX(b)] || big[label[b]]) continue;
+    int partner = -1;
+    for (int x = 0; x < RV_MAXB; ++x) if (x != b && use[TIDX(x)] && label[x] == label[b]) partner = x;
+    if (partner >= 0 && partner < b) continue;       /* visited with the first member */
+    for (int t = 0; t < 24; ++t)
+      for (int side = 0; side < 2; ++side) {
+        const int body = side == 0 ? b : partner;
+        if (body < 0) continue;
+        const int p = t / 3, k3 = t % 3, mi = p < 4 ? TIDX(body) : AIDX(body), i = p & 3;
+        if (!use[mi] || i >= e->man[mi].n) continue;
+        orc_rowid x = {mi, i, k3, body, -1, label[body]}; id[n_rows++] = x;
+      }
+  }
   for (int rd = 0; rd < 3; ++rd)
     for (int x = 0; x < 2; ++x) {
       int k = BB_ROUND[rd][x]; int mi = BBIDX(k);

@@ -1146,14 +1146,22 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K) {
 RV_DEV int solver_row_list(Shared& S, const int* label, const int* on_, const int* act_, const int* big_) {
   DevEnv& e = S.e;
   int n = 0;
+  // a body's own rows: bodies ascending; the two members X < Y of a two-body island are visited
+  // together, slot by slot (X's row of slot t, then Y's; slot = 3 * (4 * [arm] + point) + row)
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!on_[b] || big_[label[b]]) continue;
-    for (int kind = 0; kind < 2; ++kind) {
-      const int mi = kind == 0 ? RV_TIDX(b) : RV_AIDX(b);
-      const int np_ = e.man[mi].n;
-      if (n + 3 * np_ > RV_SOLVE_ROWS) return -1;
-      for (int i = 0; i < np_; ++i) for (int k = 0; k < 3; ++k) S.s.rowmap[n++] = RV_ROW_PACK(mi, i, k, b, -1, label[b]);
-    }
+    int partner = -1;
+    for (int x = 0; x < RV_MAXB; ++x) if (x != b && on_[x] && label[x] == label[b]) partner = x;
+    if (partner >= 0 && partner < b) continue;
+    for (int t = 0; t < 24; ++t)
+      for (int side = 0; side < 2; ++side) {
+        const int body = side == 0 ? b : partner;
+        if (body < 0) continue;
+        const int p = t / 3, k = t % 3, mi = p < 4 ? RV_TIDX(body) : RV_AIDX(body), i = p & 3;
+        if (i >= e.man[mi].n) continue;
+        if (n + 1 > RV_SOLVE_ROWS) return -1;
+        S.s.rowmap[n++] = RV_ROW_PACK(mi, i, k, body, -1, label[body]);
+      }
   }
   for (int rd = 0; rd < 3; ++rd)
     for (int x = 0; x < 2; ++x) {
@@ -1236,35 +1244,90 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
     }
     A[s] = a_;
   }
-  // warm start: the impulses kept from the last substep act first
+  // warm start: the impulses kept from the last substep act first, in visiting order (X and Y slot
+  // by slot, then the pair manifold)
 #pragma unroll
-  for (int s = 0; s < 60; ++s) if ((s < 24 || Y >= 0) && isl_row_on(s, ntx, nax, nty, nay, nxy)) g = g + A[s] * rdlane(lam, s);
+  for (int t = 0; t < 24; ++t) {
+    if (isl_row_on(t, ntx, nax, nty, nay, nxy)) g = g + A[t] * rdlane(lam, t);
+    if (Y >= 0 && isl_row_on(24 + t, ntx, nax, nty, nay, nxy)) g = g + A[24 + t] * rdlane(lam, 24 + t);
+  }
+#pragma unroll
+  for (int s = 48; s < 60; ++s) if (Y >= 0 && isl_row_on(s, ntx, nax, nty, nay, nxy)) g = g + A[s] * rdlane(lam, s);
   const int iters = c->solver_iters; const float tol = c->solver_tol;
   RV_PROF(26)
-  // (v_max / v_med3 give what the ternaries of the host version give for every finite input; the
+  // (v_med3 gives what the ternaries of the host version give for every finite input; the
   // residual |d| is tracked on the scalar unit through its bit pattern, whose integer order is the
   // order of the magnitudes)
   const int toli = __builtin_bit_cast(int, tol);
+  const bool in_y = lane >= 24 && lane < 48;
   for (int it = 0; it < iters; ++it) {
     int resi = 0;
+    if (Y < 0) {
+      // one body: its points one after the other
 #pragma unroll
-    for (int pp = 0; pp < 20; ++pp) {
-      if (!((pp < 8 || Y >= 0) && isl_row_on(3 * pp, ntx, nax, nty, nay, nxy))) continue;
-      float lim = 0.0f;
+      for (int pp = 0; pp < 8; ++pp) {
+        if (!isl_row_on(3 * pp, ntx, nax, nty, nay, nxy)) continue;
+        float lim = 0.0f;
 #pragma unroll
-      for (int kk = 0; kk < 3; ++kk) {
-        const int s = 3 * pp + kk;
-        float nl;
-        if (kk == 0) nl = __builtin_amdgcn_fmed3f(lam + (bias - g) * invk, 0.0f, cap);
-        else nl = __builtin_amdgcn_fmed3f(lam + (-g * invk), -lim, lim);
-        const float d = nl - lam;
-        if (lane == s) lam = nl;
-        const int sdi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), s);
-        const float sd = __builtin_bit_cast(float, sdi);
-        if (kk == 0) lim = rdlane(mu * nl, s);   // friction bound of the point: mu x its normal impulse
-        const int mag = sdi & 0x7fffffff;
-        resi = resi > mag ? resi : mag;
-        g = g + A[s] * sd;
+        for (int kk = 0; kk < 3; ++kk) {
+          const int s = 3 * pp + kk;
+          float nl;
+          if (kk == 0) nl = __builtin_amdgcn_fmed3f(lam + (bias - g) * invk, 0.0f, cap);
+          else nl = __builtin_amdgcn_fmed3f(lam + (-g * invk), -lim, lim);
+          const float d = nl - lam;
+          if (lane == s) lam = nl;
+          const int sdi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), s);
+          const float sd = __builtin_bit_cast(float, sdi);
+          if (kk == 0) lim = rdlane(mu * nl, s);   // friction bound of the point: mu x its normal impulse
+          const int mag = sdi & 0x7fffffff;
+          resi = resi > mag ? resi : mag;
+          g = g + A[s] * sd;
+        }
+      }
+    } else {
+      // two bodies: the own rows of X and of Y do not couple (A[x][y] = 0), so slot t of X (lane t)
+      // and slot t of Y (lane 24 + t) are solved in the same step; the rows of the pair manifold,
+      // which see both, add X's change first, then Y's -- the visiting order of the row list
+#pragma unroll
+      for (int pp = 0; pp < 8; ++pp) {
+        if (!(isl_row_on(3 * pp, ntx, nax, nty, nay, nxy) || isl_row_on(24 + 3 * pp, ntx, nax, nty, nay, nxy))) continue;
+        float lim = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          const int s = 3 * pp + kk;
+          float nl;
+          if (kk == 0) nl = __builtin_amdgcn_fmed3f(lam + (bias - g) * invk, 0.0f, cap);
+          else nl = __builtin_amdgcn_fmed3f(lam + (-g * invk), -lim, lim);
+          const float d = nl - lam;
+          if (lane == s || lane == s + 24) lam = nl;
+          const int sdx = __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), s);
+          const int sdy = __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), s + 24);
+          if (kk == 0) { const float ml = mu * nl; const float lx = rdlane(ml, s), ly = rdlane(ml, s + 24); lim = in_y ? ly : lx; }
+          const int mx = sdx & 0x7fffffff, my = sdy & 0x7fffffff;
+          resi = resi > mx ? resi : mx; resi = resi > my ? resi : my;
+          g = g + A[s] * __builtin_bit_cast(float, sdx);
+          g = g + A[s + 24] * __builtin_bit_cast(float, sdy);
+        }
+      }
+#pragma unroll
+      for (int pp = 16; pp < 20; ++pp) {
+        if (!isl_row_on(3 * pp, ntx, nax, nty, nay, nxy)) continue;
+        float lim = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          const int s = 3 * pp + kk;
+          float nl;
+          if (kk == 0) nl = __builtin_amdgcn_fmed3f(lam + (bias - g) * invk, 0.0f, cap);
+          else nl = __builtin_amdgcn_fmed3f(lam + (-g * invk), -lim, lim);
+          const float d = nl - lam;
+          if (lane == s) lam = nl;
+          const int sdi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), s);
+          const float sd = __builtin_bit_cast(float, sdi);
+          if (kk == 0) lim = rdlane(mu * nl, s);
+          const int mag = sdi & 0x7fffffff;
+          resi = resi > mag ? resi : mag;
+          g = g + A[s] * sd;
+        }
       }
     }
     if (tol > 0.0f ? resi < toli : false) break;
@@ -1347,17 +1410,19 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
   RV_CNT(21, 1) RV_CNT(23, n_rows)
   for (int it = 0; it < c->solver_iters; ++it) {
     RV_CNT(22, 1)
-    float res[RV_MAXB] = {0.0f, 0.0f, 0.0f, 0.0f}, lim = 0.0f;
+    float res[RV_MAXB] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float limtab[RV_NMAN][4];    // friction bound of every point: mu x its normal impulse (the rows of a point need not be neighbours in the list)
     for (int s = 0; s < n_rows; ++s) {
       const int q = S.s.rowmap[s];
       const int isl = RV_ROW_ISL(q);
       if ((done >> isl) & 1) continue;
       float nl;
+      const float lim = RV_ROW_K(q) == 0 ? 0.0f : limtab[RV_ROW_MI(q)][RV_ROW_I(q)];
       if (RV_ROW_K(q) == 0) nl = fclampr(lam[s] + (bias[s] - g[s]) * invk[s], 0.0f, cap[s]);
       else nl = fclampr(lam[s] + (-g[s] * invk[s]), -lim, lim);
       const float d = nl - lam[s];
       lam[s] = nl;
-      if (RV_ROW_K(q) == 0) lim = mu[s] * nl;
+      if (RV_ROW_K(q) == 0) limtab[RV_ROW_MI(q)][RV_ROW_I(q)] = mu[s] * nl;
       res[isl] = fmaxr(res[isl], fabsr(d));
 #ifdef RV_EMU_COUNT
       if (it == c->solver_iters - 1 && fabsr(d) >= c->solver_tol) {
@@ -1995,10 +2060,29 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
   float trav = S.s.jtravel[j];
   int st = uni(st0);
   // the control schedule as counters (st % 10, st % 100, st % steps_check)
-  int k10 = st % RV_STEPS_TO_UPDATE_IK, k100 = st % RV_STEPS_TO_CHECK_DONE, kchk = steps_check > 0 ? st % steps_check : 0;
-  int left = max_n - uni(S.s.fused_n);
+  // (function arguments are not provably wave-uniform: without the readfirstlane the loop control
+  // below is compiled as divergent code, exec-mask updates and all)
+  const int sc = uni(steps_check);
+  int k10 = st % RV_STEPS_TO_UPDATE_IK, k100 = st % RV_STEPS_TO_CHECK_DONE, kchk = sc > 0 ? st % sc : 0;
+  int left = uni(max_n) - uni(S.s.fused_n);
   const bool any_tgt = C.lt_on || C.jt_on, quiet_ok = C.jt_on && C.applied;
   const int skip = uni(skip_st);
+  // The out-of-reach test need not run every substep: within a segment |qd_j| never exceeds
+  // vb_j = max(|qd_j| now, commanded limit) (the motor law moves qd towards a target inside the
+  // limit), so a box travels at most Bc = sum_j lever_j vb_j dt per substep.  After a test that
+  // passed with travel bound T, the next n substeps pass it as well when
+  // 1.05 (T + (n + 1) Bc) + 2e-4 <= slack (3 % and 1e-4 more than the test itself asks for: far
+  // above the rounding of the sums) -- they are taken unchecked, then the test runs again on the
+  // exact path lengths.  Same substeps taken, same state: only the number of tests changes.
+  float Bc = 0.0f;
+  {
+    const float vb = on ? fmaxr(fabsr(qd), vmax) : fabsr(qd);
+#pragma unroll
+    for (int k = 0; k < RV_NJ; ++k) Bc = __builtin_fmaf(cf[k], rdlane(vb, k), Bc);
+    Bc = Bc * dt;
+  }
+  const float slack = fminr(clt, 0.5f * clb);
+  int free_left = 0;
   for (;;) {
     if (any_tgt && (!quiet_ok || k100 == 0 || (C.lt_on && k10 == 0)) && st != skip) {
       int reached = 1;
@@ -2047,16 +2131,25 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
     if (qn > hi) { qn = hi; qdn = 0.0f; }
     const float travn = trav + fabsr(qdn) * dt;
     // the boxes after this substep: still out of reach of everything?
-    float T = 0.0f;
+    if (free_left > 0) --free_left;
+    else {
+      float T = 0.0f;
 #pragma unroll
-    for (int k = 0; k < RV_NJ; ++k) T = __builtin_fmaf(cf[k], rdlane(travn, k), T);
-    const float D = T * 1.02f + 1e-4f;
-    if (__builtin_amdgcn_ballot_w64(iscol && !(clt > D && clb > 2.0f * D)) != 0) { pending = 1; break; }   // no: this substep is not taken
+      for (int k = 0; k < RV_NJ; ++k) T = __builtin_fmaf(cf[k], rdlane(travn, k), T);
+      const float D = T * 1.02f + 1e-4f;
+      if (__builtin_amdgcn_ballot_w64(iscol && !(clt > D && clb > 2.0f * D)) != 0) { pending = 1; break; }   // no: this substep is not taken
+      // how many of the next substeps need no test (smallest count over the box lanes 16 .. 25)
+      float nf = 1e6f;
+      if (iscol && Bc > 0.0f) nf = fminr(((slack - 2e-4f) * (1.0f / 1.05f) - T) / Bc - 1.0f, 1e6f);
+      nf = row_ror_min<8>(nf); nf = row_ror_min<4>(nf); nf = row_ror_min<2>(nf); nf = row_ror_min<1>(nf);
+      const float nmin = rdlane(nf, 16);
+      free_left = nmin >= 1.0f ? (int)nmin : 0;
+    }
     q = qn; qd = qdn; trav = travn; ++st;
     if (++k10 == RV_STEPS_TO_UPDATE_IK) k10 = 0;
     if (++k100 == RV_STEPS_TO_CHECK_DONE) k100 = 0;
     if (--left == 0) { pending = 3; break; }
-    if (++kchk == steps_check) {
+    if (++kchk == sc) {
       kchk = 0;
       int reached = 1;
       if (C.jt_on) {
@@ -2122,7 +2215,14 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
         float Tc = 0.0f;
         for (int j = 0; j < RV_NJ; ++j) Tc = Tc + S.s.ccoef[col][j] * tn_[j];
         const float D = Tc * 1.02f + 1e-4f;
-        if (!(S.s.clr_t[col] > D && S.s.clr_b[col] > 2.0f * D)) out_of_reach = 0;
+        if (!(S.s.clr_t[col] > D && S.s.clr_b[col] > 2.0f * D)) {
+          out_of_reach = 0;
+#ifdef RV_EMU_COUNT
+          rv_emu_dbg2[col * 2 + !(S.s.clr_t[col] > D)] += 1;
+          rv_emu_dbg2[20 + col] += (long)(1e6f * (!(S.s.clr_t[col] > D) ? S.s.clr_t[col] : 0.5f * S.s.clr_b[col]));
+          rv_emu_dbg2[30 + col] += st - st0;
+#endif
+        }
       }
       if (!out_of_reach) { RV_CNT(5, 1) pending = 1; break; }
       for (int j = 0; j < RV_NJ; ++j) { e.q[j] = qn_[j]; e.qd[j] = qdn_[j]; trav[j] = tn_[j]; }

@@ -22,7 +22,7 @@ namespace rv {
 
 #ifdef RV_EMU_COUNT
 static long rv_emu_cnt[48];      // ad-hoc event counters of the host emulation (tools only)
-static long rv_emu_dbg[16];
+static long rv_emu_dbg[16], rv_emu_dbg2[48];
 #define RV_CNT(i, n) rv_emu_cnt[i] += (n);
 #else
 #define RV_CNT(i, n)

@@ -36,6 +36,7 @@ extern "C" {
 #ifdef RV_EMU_COUNT
 void emu_get_counts(long* out) { for (int i = 0; i < 48; ++i) out[i] = rv_emu_cnt[i]; }
 void emu_get_dbg(long* out) { for (int i = 0; i < 16; ++i) out[i] = rv_emu_dbg[i]; }
+void emu_get_dbg2(long* out) { for (int i = 0; i < 48; ++i) out[i] = rv_emu_dbg2[i]; }
 #endif
 EmuWorld* emu_create(const rv_config* cfg, const rv_scene* scene) {
   EmuWorld* w = (EmuWorld*)calloc(1, sizeof(EmuWorld));

@@ -50,3 +50,7 @@ print('solver work (rows x sweeps): %d, of which in islands that ran into the ca
 print('cap hits with arm rows by phase (initial, pre, start, motion, post, offstage, done): %s; arm normal force > 100 N: %d, > 1000 N: %d' % (c[38:45], c[46], c[47]))
 dbg = (C.c_long * 16)(); lib.emu_get_dbg(dbg)
 print('rows still changing by >= tol in the last sweep of a capped solve: table n %d t %d | pair n %d t %d | arm n %d t %d ; normal rows at their effort cap %d, friction rows at the cone %d' % tuple(list(dbg)[:8]))
+d2 = (C.c_long * 48)(); lib.emu_get_dbg2(d2); d2 = list(d2)
+print('fused runs ended by the clearance of box: (body-limited, table-limited) x 10 boxes:', [(d2[2 * i], d2[2 * i + 1]) for i in range(10)])
+print('  mean clearance (mm) the limiting box had at the start of the run:', ['%.1f' % (1e-3 * d2[20 + i] / max(d2[2 * i] + d2[2 * i + 1], 1)) for i in range(10)])
+print('  mean substeps of those runs:', ['%.1f' % (d2[30 + i] / max(d2[2 * i] + d2[2 * i + 1], 1)) for i in range(10)])
