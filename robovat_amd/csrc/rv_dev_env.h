@@ -57,6 +57,13 @@ __device__ __forceinline__ void g_shared_profg(int g, int i, unsigned long long 
 #define RV_PROF(i)
 #define RV_PROFG(i)
 #endif
+// RV_PROFILE build only: event counts in slots 32..39
+#if defined(RV_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void g_shared_cnt(int i, int n);
+#define RV_PCNT(i, n) { if (threadIdx.x == 0) g_shared_cnt((i), (n)); }
+#else
+#define RV_PCNT(i, n)
+#endif
 
 #define RV_STREAM_RESET  1u
 #define RV_STREAM_RANDOM 2u
@@ -121,7 +128,7 @@ struct DevEnv {
   float mu_finger, mu_table;
   int num_action_steps;       // Grasp4DofEnv: substeps spent in the 'start' phase
 #ifdef RV_PROFILE
-  unsigned long long prof[32], prof_t, prof_t2[4];   // tools/prof_rollout.py: shader-clock time per substep part
+  unsigned long long prof[40], prof_t, prof_t2[4];   // tools/prof_rollout.py: shader-clock time per substep part
 #endif
 };
 static_assert(sizeof(DevEnv) % 4 == 0, "DevEnv is copied word-wise");
@@ -180,6 +187,7 @@ struct Scratch {
   float clr_t[RV_NCOL], clr_b[RV_NCOL]; int clr_valid;      // coasting: clearances left (table, bodies)
   float jtravel[RV_NJ];                                     // coasting: joint path lengths of the chunk
   float ccoef[RV_NCOL][RV_NJ];                              // coasting: lever of joint j on collider box col (col_travelled's weights)
+  float crun[RV_NCOL][RV_NJ];                               // ... as measured on the last fresh kinematics (coast_measure_clearances)
   int fused_n, fused_pending;
   int coast_unsafe[3];
   float jlen[RV_NLIMB + 1], colext[RV_NCOL];   // |jpos_i|; collider extent from its frame origin
@@ -1711,6 +1719,23 @@ RV_DEV void coast_measure_clearances(Shared& S, const Consts& K, const int col) 
     bclear = fminr(bclear, d);
   }
   S.s.clr_t[col] = tclear; S.s.clr_b[col] = bclear;
+  // Levers for the travel bound of the fused loop.  ccoef (the length of the chain from the joint
+  // to the box, valid in any configuration) is what a folded arm never reaches: the distance R_j
+  // from joint j's origin to the farthest point of the box, measured now, changes only through the
+  // joints between j and the box, i.e. by no more than the box itself travels -- and the loop never
+  // lets that exceed the clearance measured here.  So R_j + clearance bounds the lever for as long
+  // as these clearances are in use.
+  {
+    const rv_arm* arm = K.arm;
+    const int f = arm->col_frame[col]; const int fl = f < RV_NLIMB ? f : RV_NLIMB - 1;
+    const float slack = fmaxr(fminr(tclear, 0.5f * bclear), 0.0f);
+    const v3 cc = ld3(S.s.colc[col]);
+    for (int j = 0; j < RV_NJ; ++j) {
+      float L = S.s.ccoef[col][j];
+      if (j <= fl && j < RV_NLIMB) L = fminr(L, (len(sub(cc, ld3(e.fpos[j]))) + S.s.colr[col] + slack) * 1.001f);
+      S.s.crun[col][j] = L;
+    }
+  }
 }
 RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining, int* kidx) {
   const rv_config* c = K.cfg;
@@ -2047,7 +2072,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
   const int col = iscol ? lane - 16 : 0;
   float cf[RV_NJ];
 #pragma unroll
-  for (int k = 0; k < RV_NJ; ++k) cf[k] = S.s.ccoef[col][k];
+  for (int k = 0; k < RV_NJ; ++k) cf[k] = S.s.crun[col][k];
   const float clt = S.s.clr_t[col], clb = S.s.clr_b[col];
   // this lane's joint in the joint target
   int tgt = 0; float tpos = 0.0f;
@@ -2074,16 +2099,72 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
   // 1.05 (T + (n + 1) Bc) + 2e-4 <= slack (3 % and 1e-4 more than the test itself asks for: far
   // above the rounding of the sums) -- they are taken unchecked, then the test runs again on the
   // exact path lengths.  Same substeps taken, same state: only the number of tests changes.
-  float Bc = 0.0f;
+  // (a second bound of the same kind: a joint gains at most a_max dt of speed per substep, so the
+  // next n substeps move a box by at most n B1 + n (n + 1) / 2 B2 with B1 = sum_j lever_j |qd_j| dt
+  // now and B2 = sum_j lever_j a_j dt^2 -- much less than n Bc while the joints are slow; the
+  // larger of the two counts is used)
+  float Bc = 0.0f, B2 = 0.0f;
   {
     const float vb = on ? fmaxr(fabsr(qd), vmax) : fabsr(qd);
 #pragma unroll
-    for (int k = 0; k < RV_NJ; ++k) Bc = __builtin_fmaf(cf[k], rdlane(vb, k), Bc);
-    Bc = Bc * dt;
+    for (int k = 0; k < RV_NJ; ++k) { Bc = __builtin_fmaf(cf[k], rdlane(vb, k), Bc); B2 = __builtin_fmaf(cf[k], rdlane(amax_dt, k), B2); }
+    Bc = Bc * dt; B2 = B2 * dt;
   }
   const float slack = fminr(clt, 0.5f * clb);
+  RV_PCNT(35, 1)
   int free_left = 0;
   for (;;) {
+    {
+      // Substeps at which nothing has to look at anything: no ControllableBody.update due at their
+      // top (the counters say when the next one is), no out-of-reach test (free_left), not the last
+      // one allowed, no tick of the phase machine after them.  Those m substeps are the joint
+      // motors alone -- a loop without a single scalar decision in it.
+      int m = free_left < left - 1 ? free_left : left - 1;
+      if (sc > 0) m = m < sc - 1 - kchk ? m : sc - 1 - kchk;
+      if (any_tgt) {
+        if (!quiet_ok) m = 0;
+        else {
+          const int u100 = k100 == 0 ? 0 : RV_STEPS_TO_CHECK_DONE - k100;
+          m = m < u100 ? m : u100;
+          if (C.lt_on) { const int u10 = k10 == 0 ? 0 : RV_STEPS_TO_UPDATE_IK - k10; m = m < u10 ? m : u10; }
+        }
+      }
+      if (m > 0) {
+        for (int i = 0; i < m; ++i) {
+          float vd = 0.0f;
+          if (on) vd = kp * (mq - q) / dt;
+          const float raw = fabsr(vd);
+          const bool sat = on && limb && mine && raw > vmax;
+          float sync = 1.0f;
+          if (__builtin_amdgcn_ballot_w64(sat) != 0) {
+            float ratio = 1.0f;
+            if (sat) ratio = vmax / raw;
+            int r = __builtin_bit_cast(int, fminr(1.0f, ratio));
+            r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x128, 0xf, 0xf, false));
+            r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x124, 0xf, 0xf, false));
+            r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x122, 0xf, 0xf, false));
+            r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x121, 0xf, 0xf, false));
+            sync = __builtin_bit_cast(float, r);
+          }
+          float vdd = 0.0f;
+          if (on) {
+            vdd = vd;
+            if (limb) vdd = vdd * sync;
+            vdd = fclampr(vdd, -vmax, vmax);
+          }
+          const float dv = fclampr(vdd - qd, -amax_dt, amax_dt);
+          float qdn = qd + dv;
+          float qn = q + qdn * dt;
+          if (qn < lo) { qn = lo; qdn = 0.0f; }
+          if (qn > hi) { qn = hi; qdn = 0.0f; }
+          trav = trav + fabsr(qdn) * dt;
+          q = qn; qd = qdn;
+        }
+        RV_PCNT(32, m)
+        st += m; left -= m; free_left -= m; kchk += m; k100 += m;
+        k10 += m; if (k10 >= RV_STEPS_TO_UPDATE_IK) k10 -= RV_STEPS_TO_UPDATE_IK * (k10 / RV_STEPS_TO_UPDATE_IK);
+      }
+    }
     if (any_tgt && (!quiet_ok || k100 == 0 || (C.lt_on && k10 == 0)) && st != skip) {
       int reached = 1;
       if (C.jt_on) {
@@ -2131,8 +2212,10 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
     if (qn > hi) { qn = hi; qdn = 0.0f; }
     const float travn = trav + fabsr(qdn) * dt;
     // the boxes after this substep: still out of reach of everything?
+    RV_PCNT(33, 1)
     if (free_left > 0) --free_left;
     else {
+      RV_PCNT(34, 1)
       float T = 0.0f;
 #pragma unroll
       for (int k = 0; k < RV_NJ; ++k) T = __builtin_fmaf(cf[k], rdlane(travn, k), T);
@@ -2140,7 +2223,20 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
       if (__builtin_amdgcn_ballot_w64(iscol && !(clt > D && clb > 2.0f * D)) != 0) { pending = 1; break; }   // no: this substep is not taken
       // how many of the next substeps need no test (smallest count over the box lanes 16 .. 25)
       float nf = 1e6f;
-      if (iscol && Bc > 0.0f) nf = fminr(((slack - 2e-4f) * (1.0f / 1.05f) - T) / Bc - 1.0f, 1e6f);
+      if (iscol && Bc > 0.0f) {
+        const float room = (slack - 2e-4f) * (1.0f / 1.05f) - T;
+        nf = room / Bc - 1.0f;
+        if (B2 > 0.0f && room > 0.0f) {
+          float B1 = 0.0f;
+          const float sp = fabsr(qdn);
+#pragma unroll
+          for (int k = 0; k < RV_NJ; ++k) B1 = __builtin_fmaf(cf[k], rdlane(sp, k), B1);
+          const float hb = B1 * dt + 0.5f * B2;          // n hb + n^2 B2 / 2 <= room
+          const float nq = 0.98f * (fsqrtr(hb * hb + 2.0f * B2 * room) - hb) / B2 - 1.0f;
+          nf = fmaxr(nf, nq);
+        }
+        nf = fminr(nf, 1e6f);
+      }
       nf = row_ror_min<8>(nf); nf = row_ror_min<4>(nf); nf = row_ror_min<2>(nf); nf = row_ror_min<1>(nf);
       const float nmin = rdlane(nf, 16);
       free_left = nmin >= 1.0f ? (int)nmin : 0;
@@ -2179,7 +2275,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
         RV_CNT(4, 1)
         for (int col = 0; col < RV_NCOL; ++col) {
           float Tc = 0.0f;
-          for (int j = 0; j < RV_NJ; ++j) Tc = Tc + S.s.ccoef[col][j] * (trav[j] + (fabsr(e.qd[j]) + arm->a_max[j] * dt) * dt);
+          for (int j = 0; j < RV_NJ; ++j) Tc = Tc + S.s.crun[col][j] * (trav[j] + (fabsr(e.qd[j]) + arm->a_max[j] * dt) * dt);
           const float D = Tc * 1.02f + 1e-4f;
           if (!(S.s.clr_t[col] > D && S.s.clr_b[col] > 2.0f * D)) pending = 1;
         }
@@ -2213,7 +2309,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
       int out_of_reach = 1;
       for (int col = 0; col < RV_NCOL; ++col) {
         float Tc = 0.0f;
-        for (int j = 0; j < RV_NJ; ++j) Tc = Tc + S.s.ccoef[col][j] * tn_[j];
+        for (int j = 0; j < RV_NJ; ++j) Tc = Tc + S.s.crun[col][j] * tn_[j];
         const float D = Tc * 1.02f + 1e-4f;
         if (!(S.s.clr_t[col] > D && S.s.clr_b[col] > 2.0f * D)) {
           out_of_reach = 0;
@@ -2926,6 +3022,7 @@ static thread_local Shared g_shared;
 __device__ __forceinline__ void g_shared_prof(int i, unsigned long long t) {
   g_shared.e.prof[i] += t - g_shared.e.prof_t; g_shared.e.prof_t = t;
 }
+__device__ __forceinline__ void g_shared_cnt(int i, int n) { g_shared.e.prof[i] += (unsigned long long)n; }
 __device__ __forceinline__ void g_shared_profg(int g, int i, unsigned long long t) {
   g_shared.e.prof[12 + g * 6 + i] += t - g_shared.e.prof_t2[g]; g_shared.e.prof_t2[g] = t;
 }

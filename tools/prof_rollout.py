@@ -43,7 +43,7 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 from robovat_amd import configs, scenes, lib   # noqa: E402
 
-NS = 32
+NS = 40
 SLOTS = {
     0: 'quiet substep (light part only)', 1: 'light part of a non-quiet substep', 2: 'heavy: link twists',
     18: 'heavy: narrow-phase prep (refresh, gate, work list, hull vertices)', 3: 'heavy: narrow-phase queries (GJK/EPA, features)',
@@ -86,7 +86,7 @@ w.rollout(args.steps, first_macro_index=first, auto_reset=True, record=False); w
 ms = w.last_kernel_ms()
 p = prof() - p0
 st = w.stats()
-main = [k for k in range(NS) if not (12 <= k < 18)]
+main = [k for k in range(32) if not (12 <= k < 18)]
 tot = p[:, main].sum(axis=1)
 slow = int(np.argmax(tot))
 clk = tot.max() / (ms * 1e-3)
@@ -116,6 +116,8 @@ for i in order:
     sh = 100 * p[i, heavy] / tot[i]
     print('  %4d %7.1f %7d %6d %6d | %s | %.1f' % (i, tot[i] / clk * 1e3, cnt[i, 7], cnt[i, 8], cnt[i, 9], ' '.join('%4.1f' % x for x in sh),
                                                    100 - sh.sum()))
+print('coast loop counts, mean env / slowest env: substeps in the check-free path %.0f / %.0f, full iterations %.0f / %.0f, out-of-reach tests %.0f / %.0f, segments %.0f / %.0f'
+      % (p[:, 32].mean(), p[slow, 32], p[:, 33].mean(), p[slow, 33], p[:, 34].mean(), p[slow, 34], p[:, 35].mean(), p[slow, 35]))
 q = np.percentile(tot / clk * 1e3, [50, 90, 99, 100])
 print('env busy time ms: p50 %.1f  p90 %.1f  p99 %.1f  max %.1f' % tuple(q))
 w.close()
