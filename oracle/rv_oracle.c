@@ -1315,6 +1315,24 @@ static void sim_substep(const orc_world* w, orc_env* e) {
         }
       }
     }
+    /* a contact island is awake or asleep as a whole (Bullet deactivates islands, not bodies): a
+     * sleeper that shares a manifold holding points with a body that is awake, or is being woken,
+     * wakes as well -- otherwise that manifold would not be solved and the awake body would lose
+     * its support */
+    int any_wake = 0;      /* (islands sleep as a whole, so only a wake-up can leave a sleeper next to an awake body) */
+    for (int b = 0; b < RV_MAXB; ++b) any_wake |= wake[b];
+    if (any_wake) {
+      int aw[RV_MAXB];
+      for (int b = 0; b < RV_MAXB; ++b) aw[b] = body_on(e, b) || wake[b];
+      for (int pass = 0; pass < 3; ++pass)
+        for (int k = 0; k < RV_NBB; ++k) {
+          const int a_ = BB_A[k], b_ = BB_B[k];
+          if (!(e->bp[a_].active && !e->bp[a_].frozen && e->bp[b_].active && !e->bp[b_].frozen) || e->man[BBIDX(k)].n == 0) continue;
+          if (aw[a_] && !aw[b_]) aw[b_] = 1;
+          else if (aw[b_] && !aw[a_]) aw[a_] = 1;
+        }
+      for (int b = 0; b < RV_MAXB; ++b) if (aw[b] && e->bp[b].active && !e->bp[b].frozen && e->bp[b].asleep) wake[b] = 1;
+    }
     for (int b = 0; b < RV_MAXB; ++b) if (wake[b]) {
       orc_bparam* P = &e->bp[b];
       P->asleep = 0; P->sleep_count = 0; P->deact_count = 0;
@@ -1362,6 +1380,7 @@ static void sim_substep(const orc_world* w, orc_env* e) {
   solve_contacts(w, e);
   int on_at_solve[RV_MAXB];      /* who is awake in this substep (the flags change in the loop below) */
   for (int b = 0; b < RV_MAXB; ++b) on_at_solve[b] = body_on(e, b);
+  int ready[RV_MAXB] = {0, 0, 0, 0};   /* the body's own deactivation tests say it may sleep */
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!body_on(e, b)) continue;
     orc_body* B = &e->body[b];
@@ -1431,7 +1450,28 @@ static void sim_substep(const orc_world* w, orc_env* e) {
         else e->bp[b].deact_count = 0;
         deact = e->bp[b].deact_count >= c->deact_steps;
       }
-      if (!held && (e->bp[b].sleep_count >= c->sleep_steps || e->bp[b].still_count >= c->sleep_steps || quick || deact)) {
+      ready[b] = e->bp[b].frozen || (!held && (e->bp[b].sleep_count >= c->sleep_steps || e->bp[b].still_count >= c->sleep_steps || quick || deact));
+    }
+  }
+  /* islands go to sleep as a whole: a body sleeps when every awake body it is coupled to
+   * (transitively) by manifolds that hold points is ready as well */
+  {
+    int label[RV_MAXB];
+    for (int b = 0; b < RV_MAXB; ++b) label[b] = b;
+    for (int pass = 0; pass < RV_MAXB; ++pass)
+      for (int k = 0; k < RV_NBB; ++k) {
+        const int a_ = BB_A[k], b_ = BB_B[k];
+        if (!(on_at_solve[a_] && on_at_solve[b_] && e->man[BBIDX(k)].n != 0)) continue;
+        const int lo = label[a_] < label[b_] ? label[a_] : label[b_];
+        label[a_] = lo; label[b_] = lo;
+      }
+    for (int b = 0; b < RV_MAXB; ++b) {
+      if (!on_at_solve[b] || !ready[b] || e->bp[b].frozen) continue;
+      int all = 1;
+      for (int x = 0; x < RV_MAXB; ++x) if (on_at_solve[x] && label[x] == label[b] && !ready[x]) all = 0;
+      if (!all) continue;
+      orc_body* B = &e->body[b];
+      {
         e->bp[b].asleep = 1;
         v3set(B->v, R(0.0), R(0.0), R(0.0)); v3set(B->w, R(0.0), R(0.0), R(0.0));
         /* world box of the resting hulls: what the arm has to come near to wake the body */

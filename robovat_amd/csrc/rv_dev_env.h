@@ -168,6 +168,7 @@ struct Scratch {
   int num_waypoints, interrupt, has_budget, max_phase_steps;
   int loop_break, wus_steps, wus_stable, valid;
   int wake[RV_MAXB];
+  int ready[RV_MAXB];                    // the body's own deactivation tests say it may sleep (islands sleep as a whole)
   float res[16];
   float mot[RV_MAXB];
   float sync;
@@ -2482,10 +2483,53 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   RV_STOPL(17)
 
   // body velocity update + rotations
+  // A contact island is awake or asleep as a whole (Bullet deactivates islands, not bodies): a
+  // sleeper that shares a manifold holding points with a body that is awake, or is being woken,
+  // wakes as well -- otherwise that manifold would not be solved and the awake body would lose its
+  // support.  Every body lane works the closure out for itself.
+  int wake_me = 0;
   RV_LANES_BEGIN
     if (lane < RV_MAXB) {
+      const DevEnv& e = S.e;
+      // (islands sleep as a whole, so only a wake-up can leave a sleeper next to an awake body)
+      int any_wake = 0;
+#pragma unroll
+      for (int x = 0; x < RV_MAXB; ++x) any_wake |= S.s.wake[x];
+      int me = 0;
+      if (any_wake) {
+        int aw[RV_MAXB], pr[RV_MAXB], np[RV_NBB];
+#pragma unroll
+        for (int x = 0; x < RV_MAXB; ++x) { pr[x] = body_present(e, x); aw[x] = (pr[x] && !e.asleep[x]) || S.s.wake[x]; }
+#pragma unroll
+        for (int k = 0; k < RV_NBB; ++k) np[k] = e.man[RV_BBIDX(k)].n;
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+          for (int k = 0; k < RV_NBB; ++k) {
+            const int a_ = bb_a(k), b_ = bb_b(k);
+            if (!(pr[a_] && pr[b_]) || np[k] == 0) continue;
+            if (aw[a_] && !aw[b_]) aw[b_] = 1;
+            else if (aw[b_] && !aw[a_]) aw[a_] = 1;
+          }
+#pragma unroll
+        for (int x = 0; x < RV_MAXB; ++x) if (x == lane) me = aw[x] && pr[x] && e.asleep[x];
+      }
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+      wake_me = me;
+#else
+      S.s.ready[lane] = me;      // (host emulation: lane-local values do not survive the phase)
+#endif
+    }
+#if !defined(__HIPCC__) || defined(RV_EMULATE)
+  RV_LANES_END
+  RV_LANES_BEGIN
+#endif
+    if (lane < RV_MAXB) {
       int b = lane; DevEnv& e = S.e;
-      if (S.s.wake[b]) {
+#if !defined(__HIPCC__) || defined(RV_EMULATE)
+      wake_me = S.s.ready[lane];
+#endif
+      if (S.s.wake[b] || wake_me) {
         e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0;
         // open the pose window at the pose it was resting in
         e.still_count[b] = 1; e.undisturbed[b] = 1;
@@ -2985,7 +3029,55 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
             else e.deact_count[b] = 0;
             deact = e.deact_count[b] >= c->deact_steps;
           }
-          if (!held && (e.sleep_count[b] >= c->sleep_steps || e.still_count[b] >= c->sleep_steps || quick || deact)) {
+          S.s.ready[b] = e.frozen[b] || (!held && (e.sleep_count[b] >= c->sleep_steps || e.still_count[b] >= c->sleep_steps || quick || deact));
+        }
+      }
+    }
+    if (lane == 32) { e.sim_steps++; e.substeps_last++; }
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+  }
+  // islands go to sleep as a whole: a body sleeps when every awake body it is coupled to
+  // (transitively) by manifolds that hold points is ready as well (the ready flags of the four
+  // body lanes travel in a ballot: no LDS round trip)
+  if (c->sleep_steps > 0) {
+    const int lane = (int)threadIdx.x;
+    DevEnv& e = S.e;
+    const int rb = lane < RV_MAXB ? lane : 0;
+    const int my_ready = lane < RV_MAXB && S.s.ready[rb];   // (its own store; lanes of bodies that were not awake hold stale flags nobody looks at)
+    const unsigned rmask = (unsigned)__builtin_amdgcn_ballot_w64(my_ready != 0);
+    if (lane < RV_MAXB) {
+      int b = lane;
+      int mine = 0, all = 1;
+#pragma unroll
+      for (int x = 0; x < RV_MAXB; ++x) if (x == b) mine = on_[x] && label[x] >= 0;
+      int lb = 0;
+#pragma unroll
+      for (int x = 0; x < RV_MAXB; ++x) if (x == b) lb = label[x];
+#pragma unroll
+      for (int x = 0; x < RV_MAXB; ++x) if (on_[x] && label[x] == lb && !((rmask >> x) & 1u)) all = 0;
+      if (mine && ((rmask >> b) & 1u) && !e.frozen[b] && all) {
+#else
+  RV_LANES_END
+  // islands go to sleep as a whole: a body sleeps when every awake body it is coupled to
+  // (transitively) by manifolds that hold points is ready as well
+  if (c->sleep_steps > 0) {
+  RV_LANES_BEGIN
+    DevEnv& e = S.e;
+    if (lane < RV_MAXB) {
+      int b = lane;
+      int mine = 0, all = 1;
+#pragma unroll
+      for (int x = 0; x < RV_MAXB; ++x) if (x == b) mine = on_[x] && label[x] >= 0;
+      int lb = 0;
+#pragma unroll
+      for (int x = 0; x < RV_MAXB; ++x) if (x == b) lb = label[x];
+#pragma unroll
+      for (int x = 0; x < RV_MAXB; ++x) if (on_[x] && label[x] == lb && !S.s.ready[x]) all = 0;
+      if (mine && S.s.ready[b] && !e.frozen[b] && all) {
+#endif
+        {
+          {
+            const v3 p = ld3(e.body[b]); const q4 q = ldq(e.body[b] + 3);
             e.asleep[b] = 1;
             st3(e.body[b] + 7, mk(0, 0, 0)); st3(e.body[b] + 10, mk(0, 0, 0));
             // world box of the resting hulls: what the arm has to come near to wake the body
@@ -3006,8 +3098,13 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         }
       }
     }
-    if (lane == 32) { e.sim_steps++; e.substeps_last++; }
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+  }
+  __syncthreads();
+#else
   RV_LANES_END
+  }
+#endif
 }
 
 // The env block lives in ONE statically addressed LDS object so that the

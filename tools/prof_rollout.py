@@ -59,7 +59,13 @@ GROUP = ['other (culling, loop, idle rounds)', 'GJK/EPA', 'first manifold point'
 over = {}
 for kv in args.over:
     k, v = kv.split('=')
-    over[k] = float(v) if ('.' in v or 'e' in v) else int(v)
+    try:
+        over[k] = int(v)
+    except ValueError:
+        try:
+            over[k] = float(v)
+        except ValueError:
+            over[k] = v
 scene, names = scenes.make_scene()
 env_cfg = configs.push_env_config(**over)
 cfg = configs.make_rv_config(env_cfg=env_cfg, n_envs=args.envs, seed=args.seed, shape_names=names)
