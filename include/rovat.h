@@ -392,6 +392,21 @@ typedef struct rv_obs_buffers {
 } rv_obs_buffers;
 int  rv_observe(rv_world* w, const rv_obs_buffers* obs);
 
+/* ---- the complete record of a rollout: what generate_episode writes per transition
+ *      (episode_generation.py:47-67: state, ACTION, reward, info, where the state of an episode's
+ *      first transition is the observation env.reset() returned).  Beyond rv_rollout_record: the
+ *      action every env.step() executed, and for every step that an auto-reset preceded, the
+ *      observation of the freshly reset state (rows of the other steps are zero).  With them the
+ *      [n_steps][N] buffers split into the reference's episodes without losing a transition. */
+typedef struct rv_rollout_extra {
+  float*   d_actions;        /* [n_steps][N][G][4]  (G = max(num_goal_steps, 1)); NULL: skipped */
+  uint8_t* d_reset;          /* [n_steps][N]  1 = the env was reset right before this step      */
+  rv_obs_buffers reset_obs;  /* [n_steps][N]...  observation env.reset() returned; NULL members skipped */
+} rv_rollout_extra;
+int  rv_rollout_record_full(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t auto_reset,
+                            float* d_rewards, uint8_t* d_dones, const rv_obs_buffers* step_obs,
+                            const rv_rollout_extra* extra);
+
 /* ---- CameraObs 'depth' / 'segmask' (camera_obs.py:33-88; BulletCamera._frames,
  *      bullet_camera.py:188-235) of the simulated depth camera: eye-space depth (0 where
  *      nothing is hit) and segmentation (body index, RV_MAXB = table, 255 = nothing).

@@ -158,6 +158,10 @@ class rv_obs_buffers(C.Structure):
     ]
 
 
+class rv_rollout_extra(C.Structure):
+    _fields_ = [('d_actions', C.c_void_p), ('d_reset', C.c_void_p), ('reset_obs', rv_obs_buffers)]
+
+
 class rv_state_view(C.Structure):
     _fields_ = [
         ('d_envs', C.c_void_p), ('env_stride_bytes', i64),

@@ -114,6 +114,8 @@ struct DevEnv {
   int flag_arm_table, flag_arm_body[RV_MAXB];
   int sim_steps, num_steps, num_episodes, done, phase, is_safe, is_effective, reset_count, substeps_last, awake_last, pairs_last;
   int stepped;      // this env executed an env.step() in the last macro launch
+  int reward_valid; // last_reward is the reward of the env.step() the last rv_step_macro / rollout gave this env
+                    // (set by the step, cleared when a macro launch skips the env or the env is reset; other launches leave it)
   float episode_reward, last_reward;
   float action[RV_MAXG][4];
   float obs_pos[RV_MAXB][3], prev_obs_pos[RV_MAXB][3];
@@ -3376,6 +3378,10 @@ struct RolloutRec {
   float* rewards; uint8_t* dones;
   rv_obs_buffers obs; int has_obs;
   ObsSnap* snaps;
+  // rv_rollout_record_full: the action of every step, the observation after every auto-reset
+  float* actions; uint8_t* resets;
+  rv_obs_buffers robs; int has_robs;
+  ObsSnap* rsnaps;
 };
 RV_DEV void rollout_record(const RolloutRec& r, const DevEnv* e, size_t row, const rv_config* cfg) {
   if (r.rewards) r.rewards[row] = e ? e->last_reward : 0.0f;
@@ -3540,7 +3546,7 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
     if (lane == 0) {
       DevEnv& e = S.e; Scratch& s = S.s;
       if (zero_counters) { e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; }
-      e.stepped += 1;
+      e.stepped += 1; e.reward_valid = 1;
       e.obs_num_steps = e.num_steps; e.obs_num_episodes = e.num_episodes;
       int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
       for (int g = 0; g < G; ++g) compute_waypoints(c, e.action[g], s.wp[g][0], s.wp[g][1]);
@@ -3668,7 +3674,7 @@ RV_DEV void genv_step(Shared& S, const Consts& K, int zero_counters = 1) {
     if (lane == 0) {
       DevEnv& e = S.e; Scratch& s = S.s;
       if (zero_counters) { e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; }
-      e.stepped += 1;
+      e.stepped += 1; e.reward_valid = 1;
       e.obs_num_steps = e.num_steps; e.obs_num_episodes = e.num_episodes;
       // start = Pose([[x, y, z + FINGER_TIP_OFFSET], [0, pi, angle]])
       s.gstart[0] = e.action[0][0]; s.gstart[1] = e.action[0][1]; s.gstart[2] = e.action[0][2] + c->finger_tip_offset;
@@ -3758,6 +3764,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
       S.s.rng = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RESET, (uint32_t)e.reset_count);
       e.reset_count++;
       if (zero_counters) launch_counters_zero(e);
+      e.reward_valid = 0;
       e.sim_steps = 0; e.num_steps = 0; e.obs_num_steps = 0; e.obs_num_episodes = e.num_episodes; e.episode_reward = 0.0f; e.last_reward = 0.0f;
       e.done = 0; e.phase = RV_PHASE_INITIAL; e.is_safe = 1; e.is_effective = 1;
       e.arm_enabled = 0;
@@ -3923,13 +3930,29 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
       RV_LANES_END
       if (S.s.loop_break) break;
     }
+    int was_reset = 0;
     if (S.e.done) {
       if (!auto_reset) break;
       env_reset(S, K, gid, 0);
+      was_reset = 1;
       RV_PROF(28)
     }
     RV_LANES_BEGIN
-      if (lane == 0) random_action(c, gid, first_index + k, &S.e.action[0][0]);
+      if (lane == 0) {
+        random_action(c, gid, first_index + k, &S.e.action[0][0]);
+        if (budget == nullptr) {
+          const size_t row = (size_t)k * n_envs + env;
+          if (rec.actions) {
+            const int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
+            for (int x = 0; x < G * 4; ++x) rec.actions[row * (size_t)(G * 4) + x] = (&S.e.action[0][0])[x];
+          }
+          if (rec.resets) rec.resets[row] = (uint8_t)was_reset;
+          if (was_reset) {      // what env.reset() returned (robot_env.py:204-237)
+            if (rec.has_robs) obs_write_row(&S.e, rec.robs, row, c);
+            if (rec.rsnaps) obs_snap_fill(S.e, rec.rsnaps[row]);
+          }
+        }
+      }
     RV_LANES_END
     RV_PROF(20)
     if (c->env_type == RV_ENV_GRASP) genv_step(S, K, 0); else env_step(S, K, 0);

@@ -72,7 +72,11 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   if (MODE == MODE_MACRO) skip = (S.e.done != 0);
   if (MODE == MODE_ROLLOUT) skip = (S.e.done != 0) && !args.auto_reset;
   if (skip) {
+    // (the counters are per launch: an env the launch skips contributes nothing to rv_get_stats; an
+    // env that a macro launch does not step -- its episode is over -- has no step result any more,
+    // while a reset that masks it out, rv_step_sub or rv_wait_until_stable leave its reward alone)
     if (lane == 0) launch_counters_zero(*g);
+    if (lane == 0 && (MODE == MODE_MACRO || MODE == MODE_ROLLOUT)) g->reward_valid = 0;
     if (MODE == MODE_ROLLOUT && args.budget == nullptr)   // steps not taken: reward 0, done, zero rows
       for (int k = lane; k < args.n_substeps; k += 64) rollout_record(args.rec, nullptr, (size_t)k * args.n_envs + env, &S.cfg);
     return;
@@ -391,7 +395,7 @@ __global__ void k_reward(const DevEnv* envs, int n, float* reward, uint8_t* done
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
   // an env whose episode is over is not stepped by rv_step_macro (the reference raises
   // "Forget to reset?", robot_env.py:244-245): it reports reward 0, done
-  if (reward) reward[i] = envs[i].stepped ? envs[i].last_reward : 0.0f;
+  if (reward) reward[i] = envs[i].reward_valid ? envs[i].last_reward : 0.0f;
   if (done) done[i] = (uint8_t)envs[i].done;
 }
 __global__ void k_returns(const DevEnv* envs, int n, float* r) {
@@ -623,6 +627,40 @@ int rv_rollout_record(rv_world* w, int32_t n_steps, int32_t first_macro_index, i
   if (rc != RV_OK) return rc;
   // the segmented point clouds of all n_steps x N observations, rendered together
   if (d_pc) return launch_point_cloud(w, rows, d_pc);
+  return RV_OK;
+}
+int rv_rollout_record_full(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t auto_reset,
+                           float* d_rewards, uint8_t* d_dones, const rv_obs_buffers* step_obs, const rv_rollout_extra* extra) {
+  WCHK(w);
+  if (n_steps <= 0) return fail(RV_ERR_VALUE, "rv_rollout_record_full: n_steps must be positive");
+  RolloutRec rec; memset(&rec, 0, sizeof(rec));
+  rec.rewards = d_rewards; rec.dones = d_dones;
+  float *d_pc = nullptr, *d_rpc = nullptr;
+  if (step_obs) { rec.obs = *step_obs; rec.has_obs = 1; d_pc = step_obs->d_point_cloud; rec.obs.d_point_cloud = nullptr; }
+  if (extra) {
+    rec.actions = extra->d_actions; rec.resets = extra->d_reset;
+    rec.robs = extra->reset_obs; rec.has_robs = 1; d_rpc = extra->reset_obs.d_point_cloud; rec.robs.d_point_cloud = nullptr;
+  }
+  const size_t rows = (size_t)n_steps * (size_t)w->n;
+  if (d_pc || d_rpc) {
+    if (w->cfg.num_points <= 0 || w->cfg.num_points > RV_PC_MAXPIX) return fail(RV_ERR_VALUE, "rv_rollout_record_full: num_points outside [1, RV_PC_MAXPIX]");
+    int rc = ensure_snaps(w, 2 * rows); if (rc != RV_OK) return rc;
+    if (d_pc) rec.snaps = w->d_snaps;
+    if (d_rpc) {
+      rec.rsnaps = w->d_snaps + rows;
+      // rows without a reset keep shape = -1 for every body (all bits set): empty clouds
+      HIPCHK(hipMemsetAsync(rec.rsnaps, 0xFF, sizeof(ObsSnap) * rows, w->stream));
+    }
+  }
+  if (extra && extra->d_reset) HIPCHK(hipMemsetAsync(extra->d_reset, 0, rows, w->stream));
+  int rc = launch_env<MODE_ROLLOUT>(w, nullptr, n_steps, 0, 0, 0, 0, 0, first_macro_index, auto_reset, &rec);
+  if (rc != RV_OK) return rc;
+  if (d_pc) { rc = launch_point_cloud(w, rows, d_pc); if (rc != RV_OK) return rc; }
+  if (d_rpc) {
+    hipLaunchKernelGGL(k_point_cloud, dim3((unsigned)(rows * RV_MAXB)), dim3(64), 0, w->stream,
+                       w->d_snaps + rows, (int)rows, w->n, d_rpc, w->d_cfg, w->d_scene);
+    HIPCHK(hipGetLastError());
+  }
   return RV_OK;
 }
 int rv_rollout_async(rv_world* w, int32_t total_env_steps, int32_t first_macro_index, int32_t* d_steps_taken) {

@@ -61,7 +61,10 @@ def convex_hull_reduced(points, max_verts=abi.RV_MAXV):
     span = np.ptp(pts, axis=0)
     if span.min() <= 1e-9 * max(span.max(), 1e-12):
         raise ValueError('degenerate (flat) collision part')
-    v = pts[ConvexHull(pts).vertices]
+    try:
+        v = pts[ConvexHull(pts).vertices]
+    except Exception as ex:       # scipy's QhullError: a flat part that is not axis-aligned
+        raise ValueError('degenerate (flat) collision part: %s' % str(ex).splitlines()[0])
     while len(v) > max_verts:
         if len(v) > 4 * max_verts:
             # far too many: coarse pre-thinning by farthest-point sampling
@@ -86,9 +89,19 @@ def convex_hull_reduced(points, max_verts=abi.RV_MAXV):
     return v
 
 
-def merge_hulls(hulls, max_hulls=abi.RV_MAXH, max_verts=abi.RV_MAXV):
-    """At most ``max_hulls`` hulls: the pair whose union hull adds the least volume is merged first."""
+def merge_hulls(hulls, max_hulls=abi.RV_MAXH, max_verts=abi.RV_MAXV, max_added_fraction=0.25):
+    """At most ``max_hulls`` hulls: the pair whose union hull adds the least volume is merged first.
+
+    Merging FILLS the concavity between two parts (the template then collides where the mesh does
+    not), unlike the vertex thinning of ``convex_hull_reduced``, which only ever shrinks a hull.  The
+    volume added by all merges is therefore measured: above ``max_added_fraction`` of the volume of
+    the parts a ``ValueError`` asks for fewer / coarser V-HACD parts (or a larger RV_MAXH), below it
+    a ``UserWarning`` reports the figure."""
+    import warnings
     hulls = [np.asarray(h, dtype=np.float64) for h in hulls]
+    parts_volume = sum(_hull_volume(h) for h in hulls)
+    added = 0.0
+    n_in = len(hulls)
     while len(hulls) > max_hulls:
         best = None
         vol = [_hull_volume(h) for h in hulls]
@@ -98,9 +111,17 @@ def merge_hulls(hulls, max_hulls=abi.RV_MAXH, max_verts=abi.RV_MAXV):
                 extra = u - vol[i] - vol[j]
                 if best is None or extra < best[0]:
                     best = (extra, i, j)
-        _, i, j = best
+        extra, i, j = best
+        added += max(extra, 0.0)
         merged = convex_hull_reduced(np.concatenate([hulls[i], hulls[j]]), max_verts)
         hulls = [h for k, h in enumerate(hulls) if k not in (i, j)] + [merged]
+    if n_in > max_hulls:
+        frac = added / max(parts_volume, 1e-30)
+        msg = ('%d collision parts merged into %d hulls: the merges fill %.1f %% of the parts\' volume '
+               '(concavities the mesh has and the template does not)' % (n_in, max_hulls, 100.0 * frac))
+        if frac > max_added_fraction:
+            raise ValueError(msg + '; above the %.0f %% limit -- decompose into at most %d parts' % (100.0 * max_added_fraction, max_hulls))
+        warnings.warn(msg)
     return hulls
 
 

@@ -9,9 +9,11 @@ returns an ``h5py.File`` when h5py is importable and otherwise an ``NpzStore`` -
 groups kept in one ``.npz`` file whose keys are the HDF5 paths -- so that the layout can be written,
 read back and tested here; files written with h5py are readable by the reference's own reader.
 
-``episodes_from_rollout`` turns the ``[K, N, ...]`` buffers of ``World.rollout_record`` into the
-episode dictionaries ``generate_episode`` produces (``episode_generation.py:36-67``), one per env and
-episode, without stepping the envs again.
+``episodes_from_rollout`` turns the ``[K, N, ...]`` buffers of ``World.rollout_record_full`` (per-step
+observations, actions, rewards, dones, and the observation ``env.reset()`` returned before every step
+that an auto-reset preceded) into the episode dictionaries ``generate_episode`` produces
+(``episode_generation.py:36-67``), one per env and episode, without stepping the envs again and
+without losing a transition.
 """
 import socket
 import time
@@ -115,7 +117,7 @@ class NpzStore(_NpzGroup):
 
     def __init__(self, filename, mode='a'):
         import os
-        self.filename = filename
+        self.filename, self.mode = filename, mode
         store = {}
         if mode in ('a', 'r') and os.path.exists(filename):
             with np.load(filename, allow_pickle=False) as z:
@@ -127,9 +129,14 @@ class NpzStore(_NpzGroup):
         _NpzGroup.__init__(self, store, '')
 
     def close(self):
+        if self.mode == 'r':
+            return                                  # nothing to write back
+        import os
         out = {k: v for k, v in self._store.items() if k != '__groups__'}
         out['__groups__'] = np.array(sorted(self._store.get('__groups__', ())), dtype=str)
-        np.savez_compressed(self.filename, **out)
+        tmp = self.filename + '.tmp.npz'            # (a crash while saving must not corrupt the episodes already on disk)
+        np.savez_compressed(tmp, **out)
+        os.replace(tmp, self.filename)
 
     def __enter__(self):
         return self
@@ -154,34 +161,48 @@ def append_episode(store, episode):
     return name
 
 
-def episodes_from_rollout(first_obs, obs, actions, rewards, dones):
-    """Episode dictionaries from ``World.rollout_record`` buffers.
+def episodes_from_rollout(first_obs, obs, actions, rewards, dones, reset=None, reset_obs=None):
+    """Episode dictionaries from ``World.rollout_record_full`` buffers.
 
     first_obs: observation dict of the state before the first step ([N, ...]); obs: dict of
-    [K, N, ...] per-step observations; actions [K, N, ...]; rewards [K, N]; dones [K, N].
-    An env contributes one episode per ``done`` (its tail without a done is a last, open episode).
-    After a done the rollout auto-resets: the next episode's first state is not recorded (only
-    observations after steps are), so it starts from the observation of its first step's result
-    being paired with the PREVIOUS recorded state where there is one, and is dropped otherwise.
+    [K, N, ...] per-step observations; actions [K, N, ...]; rewards [K, N]; dones [K, N];
+    reset [K, N] (1 = an auto-reset preceded step k) and reset_obs (dict of [K, N, ...]: what
+    ``env.reset()`` returned then), as ``rollout_record_full`` gives them.  An env contributes one
+    episode per ``done`` (its tail without a done is a last, open episode); every transition is
+    (state before the step, action, reward, info) as in ``generate_episode``
+    (episode_generation.py:47-67), the first state of an episode being the reset observation.
+    Without ``reset_obs`` (plain ``rollout_record``) the first transition of every episode after
+    an auto-reset has no recorded state and is dropped -- the number dropped is returned in the
+    ``dropped_transitions`` attribute of the list.
     """
     to_np = lambda x: x.cpu().numpy() if hasattr(x, 'cpu') else np.asarray(x)
     first_obs = {k: to_np(v) for k, v in first_obs.items()}
     obs = {k: to_np(v) for k, v in obs.items()}
     actions, rewards, dones = to_np(actions), to_np(rewards), to_np(dones)
+    if reset_obs is not None:
+        reset_obs = {k: to_np(v) for k, v in reset_obs.items()}
+        reset = to_np(reset)
     K, N = rewards.shape
     host, stamp = socket.gethostname(), time.strftime('%Y-%m-%d-%H-%M-%S')
-    episodes = []
+
+    class _Episodes(list):
+        dropped_transitions = 0
+    episodes = _Episodes()
     for i in range(N):
         state = {k: v[i] for k, v in first_obs.items()}
         transitions = []
         for k in range(K):
+            if reset_obs is not None and reset[k, i]:
+                state = {key: v[k, i] for key, v in reset_obs.items()}      # what env.reset() returned
             if state is not None:
                 transitions.append({'state': state, 'action': actions[k, i], 'reward': float(rewards[k, i]), 'info': None})
+            else:
+                episodes.dropped_transitions += 1
             state = {key: v[k, i] for key, v in obs.items()}
             if dones[k, i]:
                 if transitions:
                     episodes.append({'hostname': host, 'timestamp': stamp, 'transitions': transitions, 'env': i})
-                transitions, state = [], None       # auto-reset: the new episode's first state was not observed
+                transitions, state = [], None       # the next step starts a new episode from a reset
         if transitions:
             episodes.append({'hostname': host, 'timestamp': stamp, 'transitions': transitions, 'env': i})
     return episodes

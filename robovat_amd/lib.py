@@ -30,7 +30,7 @@ SYMBOLS = [
     'rv_compute_ik', 'rv_query_contacts', 'rv_get_manifold_counts', 'rv_observe',
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
-    'rv_rollout_record', 'rv_render', 'rv_set_gravity',
+    'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -104,6 +104,7 @@ def load():
     lib.rv_rollout.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.rv_rollout_async.argtypes = [vp, i32, i32, vp]
     lib.rv_rollout_record.argtypes = [vp, i32, i32, i32, vp, vp, C.POINTER(abi.rv_obs_buffers)]
+    lib.rv_rollout_record_full.argtypes = [vp, i32, i32, i32, vp, vp, C.POINTER(abi.rv_obs_buffers), C.POINTER(abi.rv_rollout_extra)]
     lib.rv_wait_until_stable.argtypes = [vp, f32, f32, i32, i32, i32]
     lib.rv_policy_random.argtypes = [vp, i32, vp]
     lib.rv_policy_heuristic.argtypes = [vp, i32, vp]
@@ -246,6 +247,24 @@ class World(object):
         check(self.lib.rv_rollout_record(self.h, k, int(first_macro_index), int(bool(auto_reset)),
                                          self._ptr(r), self._ptr(d), C.byref(b)))
         return obs, r, d
+
+    def rollout_record_full(self, n_steps, first_macro_index=0, auto_reset=True, point_cloud=True, pose_modes=False):
+        """rollout_record plus what a complete episode record needs (rv_rollout_record_full): returns
+        (obs, rewards, dones, extra) with extra = {'actions' [K, N, G, 4], 'reset' [K, N] uint8,
+        'reset_obs' dict of [K, N, ...] observations env.reset() returned before the steps that
+        an auto-reset preceded (zero rows elsewhere)}; feed io.hdf5_utils.episodes_from_rollout."""
+        k = int(n_steps)
+        obs, b = self._obs_buffers((k, self.n), point_cloud, pose_modes)
+        robs, rb = self._obs_buffers((k, self.n), point_cloud, pose_modes)
+        r = self.torch.zeros((k, self.n), dtype=self.torch.float32, device=self.device)
+        d = self.torch.ones((k, self.n), dtype=self.torch.uint8, device=self.device)
+        acts = self.torch.zeros((k, self.n, self.G, 4), dtype=self.torch.float32, device=self.device)
+        rst = self.torch.zeros((k, self.n), dtype=self.torch.uint8, device=self.device)
+        ex = abi.rv_rollout_extra()
+        ex.d_actions = acts.data_ptr(); ex.d_reset = rst.data_ptr(); ex.reset_obs = rb
+        check(self.lib.rv_rollout_record_full(self.h, k, int(first_macro_index), int(bool(auto_reset)),
+                                              self._ptr(r), self._ptr(d), C.byref(b), C.byref(ex)))
+        return obs, r, d, {'actions': acts, 'reset': rst, 'reset_obs': robs}
 
     def rollout_async(self, total_env_steps, first_macro_index=0):
         """total_env_steps x (RandomPolicy action -> env.step) shared by all envs: every env

@@ -181,3 +181,23 @@ def test_ingested_movables_run_through_reset_and_pushes(tmp_path):
     assert np.isfinite(w.body_state()).all()
     moved = np.linalg.norm(w.body_state()[:, :3, :2] - st[:, :3, :2], axis=-1)
     assert moved.max() > 1e-3                                    # random pushes moved something
+
+
+def test_merging_parts_reports_the_volume_it_fills():
+    """More than RV_MAXH parts are merged pairwise; a merge fills the concavity between two parts, so
+    the volume added is measured: a warning below the limit, a ValueError above it; a flat part that
+    is not axis-aligned is a ValueError too (not a raw QhullError)."""
+    import warnings
+    from robovat_amd.io import asset_ingest as A
+    box = scenes.box_hull(0.01, 0.01, 0.01)
+    row = [box + [0.02 * i, 0, 0] for i in range(6)]              # six touching cubes in a row: merges add nothing
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter('always')
+        out = A.merge_hulls(row)
+    assert len(out) == abi.RV_MAXH and len(wlist) == 1 and 'merged into' in str(wlist[0].message)
+    ring = [box + [0.1 * np.cos(a), 0.1 * np.sin(a), 0] for a in np.arange(6) * np.pi / 3]    # far apart: merging fills a lot
+    with pytest.raises(ValueError, match='limit'):
+        A.merge_hulls(ring)
+    flat = np.array([[0, 0, 0], [1, 0, 1], [0, 1, 0], [1, 1, 1], [0.5, 0.5, 0.5]], dtype=float)   # a tilted plane
+    with pytest.raises(ValueError, match='flat'):
+        A.convex_hull_reduced(flat)

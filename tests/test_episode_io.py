@@ -58,6 +58,19 @@ def test_write_calls_follow_the_reference_rules():
     assert ('group', '/d') in calls and ('group', '/l[]') in calls and ('group', '/l[]/0') in calls and ('group', '/l[]/1') in calls
 
 
+def test_writer_reproduces_the_reference_call_for_call():
+    """tests/golden/hdf5_golden.json: the reference's write_data_to_hdf5, imported, recorded on a
+    generate_episode-shaped episode (gen_hdf5_golden.py); the build's writer makes the same calls."""
+    import json, os, sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    sys.path.insert(0, here)
+    import gen_hdf5_golden as G
+    with open(os.path.join(here, 'hdf5_golden.json')) as f:
+        want = json.load(f)['calls']
+    got = json.loads(json.dumps(G.record(H.write_data_to_hdf5)))
+    assert got == want
+
+
 def test_episodes_from_rollout_buffers():
     K, N = 4, 3
     rng = np.random.RandomState(1)
@@ -65,11 +78,22 @@ def test_episodes_from_rollout_buffers():
     obs = {'position': rng.rand(K, N, 4, 3)}
     actions, rewards = rng.rand(K, N, 4), rng.rand(K, N)
     dones = np.zeros((K, N), np.uint8); dones[1, 0] = 1; dones[3, 1] = 1
+    # plain rollout_record: the state after an auto-reset is unknown -> that transition is dropped, and counted
     eps = H.episodes_from_rollout(first, obs, actions, rewards, dones)
     by_env = {}
     for e in eps:
         by_env.setdefault(e['env'], []).append(e)
-    assert [len(e['transitions']) for e in by_env[0]] == [2, 1]       # done after 2 steps; step 2 unobserved start -> step 3 only
+    assert [len(e['transitions']) for e in by_env[0]] == [2, 1] and eps.dropped_transitions == 1
     assert [len(e['transitions']) for e in by_env[1]] == [4] and [len(e['transitions']) for e in by_env[2]] == [4]
     t = by_env[2][0]['transitions']
     assert np.array_equal(t[0]['state']['position'], first['position'][2]) and np.array_equal(t[1]['state']['position'], obs['position'][0, 2])
+    # rollout_record_full: the reset observation is the first state of the next episode, nothing is lost
+    reset = np.zeros((K, N), np.uint8); reset[2, 0] = 1
+    robs = {'position': rng.rand(K, N, 4, 3)}
+    eps = H.episodes_from_rollout(first, obs, actions, rewards, dones, reset=reset, reset_obs=robs)
+    assert eps.dropped_transitions == 0 and sum(len(e['transitions']) for e in eps) == K * N
+    e0 = [e for e in eps if e['env'] == 0]
+    assert [len(e['transitions']) for e in e0] == [2, 2]
+    assert np.array_equal(e0[1]['transitions'][0]['state']['position'], robs['position'][2, 0])
+    assert np.array_equal(e0[1]['transitions'][1]['state']['position'], obs['position'][2, 0])
+    assert np.array_equal(e0[1]['transitions'][0]['action'], actions[2, 0])

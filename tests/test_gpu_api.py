@@ -81,3 +81,29 @@ def test_rollout_async_argument_errors_and_accounting():
     st = w.stats()
     assert taken.sum() == 24 == st['env_steps'] and (taken >= 1).all()
     w.close()
+
+
+def test_reward_survives_launches_that_are_not_steps():
+    """rv_reward is the reward of the last env.step(): a masked reset that skips the env,
+    rv_step_sub or rv_wait_until_stable in between must not turn it into 0 (round-2 advice)."""
+    import numpy as np
+    import torch
+    from robovat_amd import configs, scenes, lib
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(env_cfg=configs.push_env_config(MAX_STEPS=1), n_envs=6, seed=3, shape_names=names)
+    w = lib.World(cfg, scene, device=0)
+    w.reset(); w.set_actions(w.policy_random(0)); w.step_macro()
+    r0, d0 = w.reward()
+    r0, d0 = r0.cpu().numpy().copy(), d0.cpu().numpy().copy()
+    assert d0.all() and (r0 == 1.0).all()                     # TASK_NAME=None: dummy reward 1 (push_reward.py:34-47)
+    mask = torch.tensor([1, 0, 1, 0, 0, 0], dtype=torch.uint8, device='cuda')
+    w.reset(mask); w.step_sub(3); w.wait_until_stable(max_steps=50)
+    r1, d1 = w.reward()
+    r1, d1 = r1.cpu().numpy(), d1.cpu().numpy()
+    assert np.array_equal(r1[[1, 3, 4, 5]], r0[[1, 3, 4, 5]]) and (r1[[0, 2]] == 0).all()   # reset envs start a new episode
+    assert np.array_equal(d1, [0, 1, 0, 1, 1, 1])
+    w.set_actions(w.policy_random(1)); w.step_macro()        # steps envs 0, 2 only; the others' episodes are over
+    r2, _ = w.reward()
+    r2 = r2.cpu().numpy()
+    assert (r2[[0, 2]] == 1.0).all() and (r2[[1, 3, 4, 5]] == 0).all()
+    w.close()

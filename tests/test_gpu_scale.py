@@ -331,3 +331,39 @@ def test_ingested_urdf_movables_match_oracle_bit_for_bit(tmp_path):
     assert np.array_equal(w.body_state().cpu().numpy(), o.body_state().astype(np.float32))
     assert np.array_equal(w.joint_state().cpu().numpy(), o.joint_state().astype(np.float32))
     w.close()
+
+
+def test_rollout_record_full_gives_complete_episodes(tmp_path):
+    """rv_rollout_record_full: actions + the observation after every auto-reset.  The [K][N]
+    buffers split into generate_episode-shaped episodes without losing a transition, survive a
+    write / read through the episode store, and agree with the oracle's rollout."""
+    from robovat_amd.io import hdf5_utils as H
+    n, K = 24, 6
+    world, ref = _world(n, seed=21, MAX_STEPS=2), _oracle(n, seed=21, MAX_STEPS=2)
+    world.reset(); ref.reset()
+    first = {k: v.clone() for k, v in world.observe(point_cloud=True).items()}
+    obs, r, d, ex = world.rollout_record_full(K, first_macro_index=0, auto_reset=True, point_cloud=True)
+    ref.rollout(K, 0, True)
+    assert np.abs(world.body_state().cpu().numpy() - ref.body_state().astype(np.float32)).max() == 0.0
+    acts, rst = ex['actions'].cpu().numpy(), ex['reset'].cpu().numpy()
+    for k in range(K):                                   # the recorded actions are the policy's draws
+        assert np.array_equal(acts[k], world.policy_random(k).cpu().numpy())
+    dn = d.cpu().numpy()
+    assert np.array_equal(rst[1:], dn[:-1]) and not rst[0].any()     # a reset follows every done (MAX_STEPS = 2: every other step)
+    robs = ex['reset_obs']
+    pc = robs['point_cloud'].cpu().numpy(); pos = robs['position'].cpu().numpy(); ns = robs['num_steps'].cpu().numpy()
+    assert (ns[rst == 1] == 0).all() and (np.abs(pos[rst == 1]).sum(axis=(1, 2)) > 0).all()
+    assert (np.abs(pc[rst == 1]).sum(axis=(1, 2, 3)) > 0).all() and not pc[rst == 0].any() and not pos[rst == 0].any()
+    eps = H.episodes_from_rollout(first, obs, ex['actions'], r, d, reset=ex['reset'], reset_obs=robs)
+    assert eps.dropped_transitions == 0 and sum(len(e['transitions']) for e in eps) == K * n
+    assert all(len(e['transitions']) == 2 for e in eps)              # MAX_STEPS = 2
+    path = str(tmp_path / 'episodes.hdf5')
+    with H.open_store(path, 'w') as f:
+        names = [H.append_episode(f, {k: v for k, v in e.items() if k != 'env'}) for e in eps[:5]]
+    with H.open_store(path, 'r') as f:
+        top = dict(f.items())
+        back = H.read_data_from_hdf5(top[names[3]])
+    t0 = eps[3]['transitions'][0]
+    assert np.array_equal(back['transitions'][0]['state']['point_cloud'], t0['state']['point_cloud'])
+    assert np.array_equal(back['transitions'][0]['action'], t0['action']) and back['transitions'][1]['info'] is None
+    world.close()

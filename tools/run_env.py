@@ -38,17 +38,21 @@ def main():
         policy = getattr(policies, args.policy)(env)
         t0 = time.time()
         from robovat_amd.io import hdf5_utils
-        in_file, path = 0, None
+        in_file, fout = 0, None            # one store stays open per output file (run_env.py:229-247)
         for i, episode in generate_episodes(env, policy, args.num_steps, args.num_episodes):
             r = sum(t['reward'] for t in episode['transitions'])
             print('episode %d: %d steps, return %.3f, %.2f s' % (i, len(episode['transitions']), r, time.time() - t0))
             if args.output_dir:
                 if in_file == 0:
                     os.makedirs(args.output_dir, exist_ok=True)
-                    path = os.path.join(args.output_dir, 'episodes_%s.hdf5' % time.strftime('%Y-%m-%d-%H-%M-%S'))
-                with hdf5_utils.open_store(path) as fout:
-                    hdf5_utils.append_episode(fout, episode)
+                    path = os.path.join(args.output_dir, 'episodes_%s_%06d.hdf5' % (time.strftime('%Y-%m-%d-%H-%M-%S'), i))
+                    fout = hdf5_utils.open_store(path, 'w')
+                hdf5_utils.append_episode(fout, episode)
                 in_file = (in_file + 1) % args.num_episodes_per_file
+                if in_file == 0:
+                    fout.close(); fout = None
+        if fout is not None:
+            fout.close()
     else:
         env = envs.VecPushEnv(args.num_envs, config=cfg, seed=args.seed)
         env.reset()
