@@ -309,6 +309,44 @@ def main():
         extra[name]['note'] = ('host loop: K x (policy -> rv_set_actions -> rv_step_macro -> rv_observe incl. point cloud -> rv_reward); '
                                'every step waits for the slowest env of the batch' if args.mode == 'rollout' else
                                'one rv_rollout_record launch, observations of every step recorded')
+        # host-driven, but without the lock step: rv_step_begin / rv_step_poll (EnvPool style).  Every
+        # poll runs the stepping envs for ~poll_usec of GPU time and hands back observation (incl. point
+        # cloud), reward and done of the envs whose env.step() completed; the host draws their next
+        # action and starts them again.  K * N env.step() calls in all, no env waits for another.
+        barrier()
+        poll_usec = 1500
+        A = torch.stack([world.policy_random(next_index + k) for k in range(4 * args.steps)])     # [4K, N, G, 4]
+        out_buf = world.poll_buffers(point_cloud=True)
+        cnt = torch.zeros(n, dtype=torch.long, device='cuda'); ar = torch.arange(n, device='cuda')
+        tp = time.perf_counter()
+        world.step_begin(A[0])
+        done_steps, polls, sub_p = 0, 0, 0
+        idle = 0
+        while done_steps < args.steps * n and idle < 50:
+            fin = world.step_poll(max_usec=poll_usec, out=out_buf).bool()
+            polls += 1
+            nf = int(fin.sum())                       # (synchronises: the host looks at what came back)
+            sub_p += world.stats()['substeps']
+            idle = idle + 1 if nf == 0 else 0
+            if nf == 0:
+                continue
+            done_steps += nf
+            cnt[fin] += 1
+            live = fin & ~out_buf['done'].bool()      # an env whose episode ended stops, as in the lock-step leg (which has no reset either)
+            if not bool(live.any()) and not bool((cnt == 0).any()) and int(fin.sum()) == 0:
+                break
+            world.step_begin(A[cnt.clamp(max=A.shape[0] - 1), ar], mask=live.to(torch.uint8))
+        barrier()
+        ep = all_max(time.perf_counter() - tp)
+        next_index += 4 * args.steps
+        extra['lockstep_partial'] = {'value': all_sum(done_steps)[0] / ep, 'unit': 'env_steps/s', 'sim_steps_per_s': all_sum(sub_p)[0] / ep,
+                                     'polls': polls, 'poll_usec': poll_usec, 'envs_per_gpu': n,
+                                     'steps_per_env_min_max': [int(cnt.min()), int(cnt.max())],
+                                     'note': 'host loop over rv_step_begin / rv_step_poll: K*N env.step() calls, each poll returns the '
+                                             'observation (incl. point cloud), reward and done of the envs that finished; per-env '
+                                             'trajectories are those of rv_step_macro (tests/test_gpu_parity.py)'}
+        # drain the steps still in flight so that the next legs start from whole steps
+        world.step_poll()                             # (no budget: every pending step runs to its end)
         if not args.no_async:
             barrier()
             ta = time.perf_counter()

@@ -299,12 +299,27 @@ int  rv_step_macro(rv_world* w);
  *      step, otherwise it stops.  d_rewards / d_dones: optional [n_steps][N]. */
 int  rv_rollout(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t auto_reset,
                 float* d_rewards, uint8_t* d_dones);
+/* Partial batches (EnvPool style), for policies that run on the host and must not wait for the
+ * slowest env of every batched env.step() (robot_env.py:239-275; the reference's worker
+ * processes are just as independent, tools/parallel_run.py:54-90).  rv_step_begin gives the envs
+ * flagged in d_mask (NULL: all) their next action ([N][G][4]); rv_step_poll advances every env
+ * that is in the middle of a step by at most max_substeps Simulator.step() calls and / or about
+ * max_usec microseconds of GPU time (0 = no limit) and sets d_finished[i] = 1 for the envs whose
+ * env.step() completed in this launch; for those envs -- and only those -- row i of the optional
+ * obs / d_reward / d_done ([N] rows, as rv_observe / rv_reward lay them out) receives what
+ * env.step() returned (rows of the other envs are unspecified; their point-cloud rows are
+ * zeroed).  An env.step() may take several polls; WHAT an env computes does not depend
+ * on how its step is cut into launches: its trajectory is rv_step_macro's, bit for bit.  A step
+ * begun on an env whose episode is over is reported finished at once (reward 0, done). */
+int  rv_step_begin(rv_world* w, const float* d_actions /* [N][G][4] */, const uint8_t* d_mask /* [N] or NULL */);
+struct rv_obs_buffers;
+int  rv_step_poll(rv_world* w, int32_t max_substeps, int32_t max_usec, uint8_t* d_finished /* [N] */,
+                  const struct rv_obs_buffers* obs /* or NULL */, float* d_reward /* [N] or NULL */, uint8_t* d_done /* [N] or NULL */);
 /* The same rollout returning what every env.step() of the loop returns
  * (robot_env.py:275: observation, reward, done): per-step observation rows
  * [n_steps][N]... in the layouts of rv_obs_buffers (NULL members are skipped;
  * steps not taken are zero rows).  The segmented point clouds of all steps are
  * rendered from per-step pose snapshots right after the stepping kernel. */
-struct rv_obs_buffers;
 int  rv_rollout_record(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t auto_reset,
                        float* d_rewards, uint8_t* d_dones, const struct rv_obs_buffers* step_obs /* host struct of device pointers */);
 /* ---- the same loop run the way the reference runs it at scale: every env is an

@@ -114,6 +114,14 @@ struct DevEnv {
   int flag_arm_table, flag_arm_body[RV_MAXB];
   int sim_steps, num_steps, num_episodes, done, phase, is_safe, is_effective, reset_count, substeps_last, awake_last, pairs_last;
   int stepped;      // this env executed an env.step() in the last macro launch
+  // rv_step_begin / rv_step_poll (partial batches): an env.step() that is spread over several
+  // launches.  in_step: 0 no step pending, 1 stepping, 2 a step was begun on a finished episode
+  // (reported as finished with reward 0, like rv_step_macro skips it); step_stage: -1 not started,
+  // 0 in the phase loop, 1 in the closing wait_until_stable; ms_*: the locals of _execute_action
+  // that have to survive the launch boundary
+  int in_step, step_stage;
+  int ms_num_waypoints, ms_interrupt, ms_has_budget, ms_max_phase_steps, ms_wus_steps, ms_wus_stable;
+  float ms_wp[RV_MAXG][2][7], ms_start_pos[RV_MAXB][3], ms_start_yaw[RV_MAXB];
   int reward_valid; // last_reward is the reward of the env.step() the last rv_step_macro / rollout gave this env
                     // (set by the step, cleared when a macro launch skips the env or the env is reset; other launches leave it)
   float episode_reward, last_reward;
@@ -170,6 +178,10 @@ struct Scratch {
   int num_waypoints, interrupt, has_budget, max_phase_steps;
   int loop_break, wus_steps, wus_stable, valid;
   int wake[RV_MAXB];
+  // budget of the running sim_run_call (rv_step_poll): at most bud_sub substeps / bud_clk shader
+  // clocks from bud_t0 in this launch (0 = no limit); suspended: the call returned on the budget
+  int bud_sub, bud_sub0, suspended, wus_resume;
+  unsigned long long bud_clk, bud_t0;
   int ready[RV_MAXB];                    // the body's own deactivation tests say it may sleep (islands sleep as a whole)
   float res[16];
   float mot[RV_MAXB];
@@ -2247,7 +2259,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
     q = qn; qd = qdn; trav = travn; ++st;
     if (++k10 == RV_STEPS_TO_UPDATE_IK) k10 = 0;
     if (++k100 == RV_STEPS_TO_CHECK_DONE) k100 = 0;
-    if (--left == 0) { pending = 3; break; }
+    --left;
     if (++kchk == sc) {
       kchk = 0;
       int reached = 1;
@@ -2257,6 +2269,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
       }
       if (!ctl_tick_noop(C, st, reached)) { pending = 2; break; }
     }
+    if (left == 0) { pending = 3; break; }      // (after the tick test: a tick that is due is never skipped)
   }
   const int n = st - uni(st0);
   if (n > 0) {
@@ -2326,8 +2339,8 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
       if (!out_of_reach) { RV_CNT(5, 1) pending = 1; break; }
       for (int j = 0; j < RV_NJ; ++j) { e.q[j] = qn_[j]; e.qd[j] = qdn_[j]; trav[j] = tn_[j]; }
       ++st;
-      if (S.s.fused_n + (st - st0) >= max_n) { pending = 3; break; }
       if (steps_check > 0 && st % steps_check == 0 && !ctl_tick_noop(C, st, check_joints_reached(e))) { pending = 2; break; }
+      if (S.s.fused_n + (st - st0) >= max_n) { pending = 3; break; }
     }
     const int n = st - st0;
     for (int j = 0; j < RV_NJ; ++j) S.s.jtravel[j] = trav[j];
@@ -2366,6 +2379,9 @@ RV_DEV int coast_run(Shared& S, const Consts& K, const int steps_check, const in
     n += coast_fused(S, K, steps_check, want - n, &why);
     RV_PROF(11)
     if (why != 1 || S.s.kin_fresh) break;
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+    if (S.s.bud_clk != 0 && __builtin_amdgcn_s_memtime() - S.s.bud_t0 > S.s.bud_clk) break;   // rv_step_poll: out of time
+#endif
     arm_refresh_kinematics(S, K);
     RV_PROF(10)
     RV_CNT(12, 1)
@@ -3169,6 +3185,17 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
   Shared& S = g_shared;
   int phase_mode = n_arg < 0;
   const int grasp_mode = n_arg == -2;     // Grasp4DofEnv: its phase machine looks at the world after EVERY substep
+  // rv_step_poll: a budget of substeps and / or shader clocks for this launch; the call may return
+  // between any two substeps (S.s.suspended) and is entered again by the next launch -- the
+  // substep sequence, and so every result, is the one of an uninterrupted call
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+  const int bud_sub = __builtin_amdgcn_readfirstlane(S.s.bud_sub);
+  const unsigned long long bud_clk = S.s.bud_clk;
+#else
+  const int bud_sub = S.s.bud_sub; const unsigned long long bud_clk = 0;
+#endif
+  const int bud_any = bud_sub > 0 || bud_clk != 0;
+  int suspended = 0;
   for (;;) {                  // one pass, except in phase mode
   int n_fixed = n_arg;
   if (phase_mode) {
@@ -3179,7 +3206,12 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
   }
   if (n_fixed == 0) {
     RV_LANES_BEGIN
-      if (lane == 0) { S.s.wus_steps = 0; S.s.wus_stable = 0; S.s.loop_break = 0; }
+      if (lane == 0) {
+        if (S.s.wus_resume) { S.s.wus_steps = S.e.ms_wus_steps; S.s.wus_stable = S.e.ms_wus_stable; S.s.wus_resume = 0; }
+        else { S.s.wus_steps = 0; S.s.wus_stable = 0; }
+        S.s.loop_break = 0;
+        if (n_arg == -1) S.e.step_stage = 1;      // the closing wait_until_stable of env.step()
+      }
     RV_LANES_END
   }
   int taken = 0;
@@ -3187,10 +3219,19 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
   int coast_fail = 0;     // attempts in a row that bought nothing: the wait doubles (1, 2, 4, 8)
   for (;;) {
     RV_PROF(7)
+    int bud_left = 1 << 30;
+    if (bud_any) {
+      int stop = 0;
+      if (bud_sub > 0) { bud_left = bud_sub - (S.e.substeps_last - S.s.bud_sub0); if (bud_left <= 0) stop = 1; }
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+      if (bud_clk != 0) { if (__builtin_amdgcn_s_memtime() - S.s.bud_t0 > bud_clk) stop = 1; if (bud_left > 128) bud_left = 128; }
+#endif
+      if (stop) { suspended = 1; break; }
+    }
     if (phase_mode && !grasp_mode && coast_wait == 0) {
       // free-space motion: as many substeps (and ticks that change nothing) as provably possible
       int why = 0;
-      const int n = coast_run(S, K, K.cfg->steps_check, 1 << 30, &why);
+      const int n = coast_run(S, K, K.cfg->steps_check, bud_left, &why);
       if (n > 0) {
         coast_fail = 0;
         if (why == 2) break;               // the phase machine has something to do at this tick
@@ -3228,7 +3269,8 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
       int T = 0;
       {
         int st = S.s.wus_steps, sb = S.s.wus_stable, fin = 0;
-        while (T < 256 && !fin) {
+        const int tmax = bud_left < 256 ? bud_left : 256;
+        while (T < tmax && !fin) {
           ++T; ++st;
           if (st >= check_after) { if (st_ok) ++sb; if (sb >= min_stable || st >= max_steps) fin = 1; }
         }
@@ -3305,6 +3347,7 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
     RV_LANES_END
     if (S.s.loop_break) break;
   }
+  if (suspended) break;
   if (!phase_mode) break;
   // the phase machine looks at the world every STEPS_CHECK substeps (push_env.py:652-661);
   // it reads the end-effector frame only in these situations
@@ -3317,6 +3360,11 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
   RV_PROF(9)
   }
   if (!S.s.kin_fresh && S.e.arm_enabled) arm_refresh_kinematics(S, K);   // leave with frames that match the joints
+  if (bud_any) {
+    RV_LANES_BEGIN
+      if (lane == 0) S.s.suspended = suspended;
+    RV_LANES_END
+  }
 }
 RV_DEV void sim_steps_call(const Consts& K, int n) {
   if (n > 0) sim_run_call(K.scene, K.stop_after, n, 0u, 0.0f, 0.0f, 0, 0, 0);
@@ -3540,13 +3588,14 @@ RV_DEV void phase_tick(Shared& S, const Consts& K) {
 
 // RobotEnv.step (robot_env.py:239-275) + PushEnv._execute_action
 // (push_env.py:631-733) + PushEnv.step bookkeeping (push_env.py:599-629)
-RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
+RV_DEV void env_step_prologue(Shared& S, const Consts& K, int zero_counters, int count_step) {
   const rv_config* c = K.cfg;
   RV_LANES_BEGIN
     if (lane == 0) {
       DevEnv& e = S.e; Scratch& s = S.s;
       if (zero_counters) { e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; }
-      e.stepped += 1; e.reward_valid = 1;
+      if (count_step) { e.stepped += 1; e.reward_valid = 1; }
+      e.step_stage = 0;
       e.obs_num_steps = e.num_steps; e.obs_num_episodes = e.num_episodes;
       int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
       for (int g = 0; g < G; ++g) compute_waypoints(c, e.action[g], s.wp[g][0], s.wp[g][1]);
@@ -3560,12 +3609,13 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
     }
   RV_LANES_END
   RV_PROF(29)
-  // phase loop + closing wait_until_stable, in one out-of-line call
-  sim_run_call(K.scene, K.stop_after, -1, 0u, 0.005f, 0.005f, 100, 100, 2000);
-  RV_PROF(30)
+}
+RV_DEV void env_step_epilogue(Shared& S, const Consts& K) {
+  const rv_config* c = K.cfg;
   RV_LANES_BEGIN
     if (lane == 0) {
       DevEnv& e = S.e; Scratch& s = S.s;
+      e.step_stage = -1;
       // _check_effectiveness (push_env.py:900-923)
       float dpos = 0.0f, dang = 0.0f;
       for (int b = 0; b < RV_MAXB; ++b) {
@@ -3597,6 +3647,47 @@ RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
     }
   RV_LANES_END
   RV_PROF(31)
+}
+RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
+  env_step_prologue(S, K, zero_counters, 1);
+  // phase loop + closing wait_until_stable, in one out-of-line call
+  sim_run_call(K.scene, K.stop_after, -1, 0u, 0.005f, 0.005f, 100, 100, 2000);
+  RV_PROF(30)
+  env_step_epilogue(S, K);
+}
+// rv_step_poll: the env.step() this env is in the middle of (S.e.in_step == 1), continued within
+// the budget set in S.s.bud_*; returns 1 when the step completed in this launch
+RV_DEV int env_step_partial(Shared& S, const Consts& K) {
+  if (S.e.step_stage < 0) env_step_prologue(S, K, 0, 0);
+  else {
+    RV_LANES_BEGIN
+      if (lane == 0) {
+        DevEnv& e = S.e; Scratch& s = S.s;
+        for (int g = 0; g < RV_MAXG; ++g) for (int x = 0; x < 2; ++x) for (int k = 0; k < 7; ++k) s.wp[g][x][k] = e.ms_wp[g][x][k];
+        for (int b = 0; b < RV_MAXB; ++b) { for (int k = 0; k < 3; ++k) s.start_pos[b][k] = e.ms_start_pos[b][k]; s.start_yaw[b] = e.ms_start_yaw[b]; }
+        s.num_waypoints = e.ms_num_waypoints; s.interrupt = e.ms_interrupt; s.has_budget = e.ms_has_budget; s.max_phase_steps = e.ms_max_phase_steps;
+        s.wus_resume = e.step_stage == 1;
+      }
+    RV_LANES_END
+  }
+  sim_run_call(K.scene, K.stop_after, -1, 0u, 0.005f, 0.005f, 100, 100, 2000);
+  if (S.s.suspended) {
+    RV_LANES_BEGIN
+      if (lane == 0) {
+        DevEnv& e = S.e; const Scratch& s = S.s;
+        for (int g = 0; g < RV_MAXG; ++g) for (int x = 0; x < 2; ++x) for (int k = 0; k < 7; ++k) e.ms_wp[g][x][k] = s.wp[g][x][k];
+        for (int b = 0; b < RV_MAXB; ++b) { for (int k = 0; k < 3; ++k) e.ms_start_pos[b][k] = s.start_pos[b][k]; e.ms_start_yaw[b] = s.start_yaw[b]; }
+        e.ms_num_waypoints = s.num_waypoints; e.ms_interrupt = s.interrupt; e.ms_has_budget = s.has_budget; e.ms_max_phase_steps = s.max_phase_steps;
+        e.ms_wus_steps = s.wus_steps; e.ms_wus_stable = s.wus_stable;
+      }
+    RV_LANES_END
+    return 0;
+  }
+  env_step_epilogue(S, K);
+  RV_LANES_BEGIN
+    if (lane == 0) { S.e.in_step = 0; S.e.stepped += 1; S.e.reward_valid = 1; }
+  RV_LANES_END
+  return 1;
 }
 
 // ------------------------------------------------------------- Grasp4DofEnv --
@@ -3760,7 +3851,8 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
     DevEnv& e = S.e;
     if (lane == 0) {
       // per-launch scratch state that a reset kernel does not get from env_enter
-      S.s.jt_applied = 0; S.s.kin_fresh = 0; S.s.clr_valid = 0;
+      S.s.jt_applied = 0; S.s.kin_fresh = 0; S.s.clr_valid = 0; S.s.bud_sub = 0; S.s.bud_clk = 0; S.s.suspended = 0; S.s.wus_resume = 0;
+      e.in_step = 0; e.step_stage = -1;
       S.s.rng = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RESET, (uint32_t)e.reset_count);
       e.reset_count++;
       if (zero_counters) launch_counters_zero(e);
@@ -3973,7 +4065,7 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
 // rebuild the per-launch caches that are not part of the persistent block
 RV_DEV void env_enter(Shared& S, const Consts& K) {
   RV_LANES_BEGIN
-    if (lane == 63) { S.s.jt_applied = 0; S.s.kin_fresh = 0; S.s.clr_valid = 0; }
+    if (lane == 63) { S.s.jt_applied = 0; S.s.kin_fresh = 0; S.s.clr_valid = 0; S.s.bud_sub = 0; S.s.bud_clk = 0; S.s.suspended = 0; S.s.wus_resume = 0; }
     if (lane < RV_MAXB * RV_NCOL) S.s.sep[lane / RV_NCOL][lane % RV_NCOL] = 0.0f;
     if (lane < 8) table_prepare(S, K, lane);
     if (lane >= 48 && lane < 48 + RV_NLIMB + 1) { int i = lane - 48; S.s.jlen[i] = len(ld3(K.arm->jpos[i])); }

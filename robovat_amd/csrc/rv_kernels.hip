@@ -21,7 +21,7 @@
 using namespace rv;
 
 // ------------------------------------------------------------------ kernels
-enum { MODE_RESET = 0, MODE_MACRO = 1, MODE_SUB = 2, MODE_WAIT = 3, MODE_ROLLOUT = 4 };
+enum { MODE_RESET = 0, MODE_MACRO = 1, MODE_SUB = 2, MODE_WAIT = 3, MODE_ROLLOUT = 4, MODE_PARTIAL = 5 };
 
 struct EnvKernelArgs {
   const rv_config* cfg;
@@ -37,6 +37,8 @@ struct EnvKernelArgs {
   RolloutRec rec;                // MODE_ROLLOUT: what every env.step() returns
   int* budget;                   // MODE_ROLLOUT, asynchronous: shared pool of env.step() calls
   int32_t* steps_taken;          // optional [N]
+  unsigned long long budget_clk; // MODE_PARTIAL: shader clocks this launch may spend per env (0: no limit)
+  uint8_t* finished;             // MODE_PARTIAL: [N] 1 = the env.step() of this env completed in this launch
 };
 
 template <int MODE>
@@ -70,6 +72,16 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   __syncthreads();
 #endif
   if (MODE == MODE_MACRO) skip = (S.e.done != 0);
+  if (MODE == MODE_PARTIAL) {
+    skip = (S.e.in_step != 1);
+    if (skip && lane == 0) {
+      // no step pending; a step that was begun on a finished episode is reported once, with
+      // reward 0 and done (rv_step_macro skips such an env the same way)
+      const int fin = S.e.in_step == 2;
+      if (args.finished) args.finished[env] = (uint8_t)fin;
+      if (fin) { g->in_step = 0; g->reward_valid = 0; rollout_record(args.rec, nullptr, (size_t)env, &S.cfg); }   // reward 0, done, zero rows
+    }
+  }
   if (MODE == MODE_ROLLOUT) skip = (S.e.done != 0) && !args.auto_reset;
   if (skip) {
     // (the counters are per launch: an env the launch skips contributes nothing to rv_get_stats; an
@@ -91,6 +103,17 @@ __global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
   } else if (MODE == MODE_ROLLOUT) {
     env_rollout(S, K, K.cfg->env_id_offset + env, args.n_substeps, args.first_index, args.auto_reset, args.rec, env, args.n_envs, args.budget);
     if (lane == 0 && args.steps_taken) args.steps_taken[env] = S.e.stepped;
+  } else if (MODE == MODE_PARTIAL) {
+    if (lane == 0) {
+      launch_counters_zero(S.e);
+      S.s.bud_sub = args.n_substeps; S.s.bud_sub0 = 0; S.s.bud_clk = args.budget_clk; S.s.bud_t0 = __builtin_amdgcn_s_memtime();
+    }
+    __syncthreads();
+    const int fin = env_step_partial(S, K);
+    if (lane == 0) {
+      if (args.finished) args.finished[env] = (uint8_t)fin;
+      if (fin) rollout_record(args.rec, &S.e, (size_t)env, &S.cfg);     // what env.step() returns, for the envs that finished
+    }
   } else if (MODE == MODE_SUB) {
     if (lane == 0) launch_counters_zero(S.e);
     __syncthreads();
@@ -198,6 +221,15 @@ __global__ void k_get_env_counters(const DevEnv* envs, int n, int32_t* out) {
 __global__ void k_set_actions(DevEnv* envs, int n, const float* a, int G) {
   ENV_THREAD();
   for (int g = 0; g < G; ++g) for (int k = 0; k < 4; ++k) e.action[g][k] = a[((size_t)i * G + g) * 4 + k];
+}
+// rv_step_begin: the next action of the flagged envs; they are stepping from now on
+__global__ void k_step_begin(DevEnv* envs, int n, const float* actions, const uint8_t* mask, int G) {
+  ENV_THREAD();
+  if (mask && !mask[i]) return;
+  if (e.in_step == 1) return;                     // (still in the middle of its step: the action is ignored)
+  for (int g2 = 0; g2 < G; ++g2) for (int k = 0; k < 4; ++k) e.action[g2][k] = actions[((size_t)i * G + g2) * 4 + k];
+  e.in_step = e.done ? 2 : 1;
+  e.step_stage = -1;
 }
 __global__ void k_reset_targets(DevEnv* envs, int n) {
   ENV_THREAD();
@@ -513,7 +545,7 @@ static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, fl
                       int first_index = 0, int auto_reset = 0, const RolloutRec* rec = nullptr,
                       int* budget = nullptr, int32_t* steps_taken = nullptr) {
   EnvKernelArgs a;
-  a.budget = budget; a.steps_taken = steps_taken;
+  a.budget = budget; a.steps_taken = steps_taken; a.budget_clk = 0; a.finished = nullptr;
   a.first_index = first_index; a.auto_reset = auto_reset;
   memset(&a.rec, 0, sizeof(a.rec));
   if (rec) a.rec = *rec;
@@ -669,6 +701,52 @@ int rv_rollout_async(rv_world* w, int32_t total_env_steps, int32_t first_macro_i
   hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, w->stream, w->d_budget, (int)total_env_steps);
   HIPCHK(hipGetLastError());
   return launch_env<MODE_ROLLOUT>(w, nullptr, 0, 0, 0, 0, 0, 0, first_macro_index, 1, nullptr, w->d_budget, d_steps_taken);
+}
+int rv_step_begin(rv_world* w, const float* d_actions, const uint8_t* d_mask) {
+  WCHK(w);
+  if (!d_actions) return fail(RV_ERR_VALUE, "rv_step_begin: null buffer");
+  if (w->cfg.env_type != RV_ENV_PUSH) return fail(RV_ERR_NOTIMPL, "rv_step_begin: PushEnv only");
+  const int G = w->cfg.num_goal_steps > 0 ? w->cfg.num_goal_steps : 1;
+  hipLaunchKernelGGL(k_step_begin, grid1(w->n), dim3(TPB), 0, w->stream, w->d_envs, w->n, d_actions, d_mask, G);
+  HIPCHK(hipGetLastError());
+  return RV_OK;
+}
+int rv_step_poll(rv_world* w, int32_t max_substeps, int32_t max_usec, uint8_t* d_finished,
+                 const rv_obs_buffers* obs, float* d_reward, uint8_t* d_done) {
+  WCHK(w);
+  if (!d_finished) return fail(RV_ERR_VALUE, "rv_step_poll: null buffer");
+  if (max_substeps < 0 || max_usec < 0) return fail(RV_ERR_VALUE, "rv_step_poll: negative budget");
+  if (w->cfg.env_type != RV_ENV_PUSH) return fail(RV_ERR_NOTIMPL, "rv_step_poll: PushEnv only");
+  EnvKernelArgs a;
+  memset(&a, 0, sizeof(a));
+  a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.n_envs = w->n;
+  a.n_substeps = max_substeps; a.finished = d_finished;
+  a.rec.rewards = d_reward; a.rec.dones = d_done;
+  float* d_pc = nullptr;
+  if (obs) {
+    a.rec.obs = *obs; a.rec.has_obs = 1; d_pc = obs->d_point_cloud; a.rec.obs.d_point_cloud = nullptr;
+    if (d_pc) {
+      if (w->cfg.num_points <= 0 || w->cfg.num_points > RV_PC_MAXPIX) return fail(RV_ERR_VALUE, "rv_step_poll: num_points outside [1, RV_PC_MAXPIX]");
+      int rc = ensure_snaps(w, (size_t)w->n); if (rc != RV_OK) return rc;
+      a.rec.snaps = w->d_snaps;
+      HIPCHK(hipMemsetAsync(w->d_snaps, 0xFF, sizeof(ObsSnap) * (size_t)w->n, w->stream));   // shape = -1: no cloud for envs that do not finish
+    }
+  }
+  if (max_usec > 0) {
+    int khz = 0;
+    HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, w->device));   // s_memtime ticks at the shader clock on gfx950
+    a.budget_clk = (unsigned long long)max_usec * (unsigned long long)(khz > 0 ? khz : 2400000) / 1000ull;
+  }
+  HIPCHK(hipMemsetAsync(w->d_stats, 0, sizeof(rv_macro_stats), w->stream));
+  HIPCHK(hipEventRecord(w->ev0, w->stream));
+  hipLaunchKernelGGL(k_env<MODE_PARTIAL>, dim3((unsigned)w->n), dim3(64), 0, w->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(w->ev1, w->stream));
+  w->timed = true;
+  hipLaunchKernelGGL(k_stats, grid1(w->n), dim3(TPB), 0, w->stream, w->d_envs, w->n, w->d_stats, w->cfg.success_thresh);
+  HIPCHK(hipGetLastError());
+  if (d_pc) return launch_point_cloud(w, (size_t)w->n, d_pc);
+  return RV_OK;
 }
 int rv_step_sub(rv_world* w, int32_t n) {
   WCHK(w);

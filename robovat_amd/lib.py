@@ -30,7 +30,7 @@ SYMBOLS = [
     'rv_compute_ik', 'rv_query_contacts', 'rv_get_manifold_counts', 'rv_observe',
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
-    'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full',
+    'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -101,6 +101,8 @@ def load():
     lib.rv_reset.argtypes = [vp, vp]
     lib.rv_step_macro.argtypes = [vp]
     lib.rv_step_sub.argtypes = [vp, i32]
+    lib.rv_step_begin.argtypes = [vp, vp, vp]
+    lib.rv_step_poll.argtypes = [vp, i32, i32, vp, C.POINTER(abi.rv_obs_buffers), vp, vp]
     lib.rv_rollout.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.rv_rollout_async.argtypes = [vp, i32, i32, vp]
     lib.rv_rollout_record.argtypes = [vp, i32, i32, i32, vp, vp, C.POINTER(abi.rv_obs_buffers)]
@@ -199,6 +201,30 @@ class World(object):
 
     def step_macro(self):
         check(self.lib.rv_step_macro(self.h))
+
+    def step_begin(self, actions, mask=None):
+        """rv_step_begin: the next action of the envs flagged in ``mask`` (uint8 [N], None = all)."""
+        a = self._in(actions, (self.n, self.G, 4), self.torch.float32)
+        m = None if mask is None else self._in(mask, (self.n,), self.torch.uint8)
+        check(self.lib.rv_step_begin(self.h, self._ptr(a), None if m is None else self._ptr(m)))
+
+    def step_poll(self, max_substeps=0, max_usec=0, out=None):
+        """rv_step_poll: advance the stepping envs within the budget; returns uint8 [N], 1 = this
+        env's env.step() completed in this launch.  ``out`` (from ``poll_buffers``): the observation,
+        reward and done of the envs that finished are written to their rows."""
+        f = self._new((self.n,), self.torch.uint8)
+        if out is None:
+            check(self.lib.rv_step_poll(self.h, int(max_substeps), int(max_usec), self._ptr(f), None, None, None))
+        else:
+            check(self.lib.rv_step_poll(self.h, int(max_substeps), int(max_usec), self._ptr(f), C.byref(out['_buffers']),
+                                        self._ptr(out['reward']), self._ptr(out['done'])))
+        return f
+
+    def poll_buffers(self, point_cloud=True, pose_modes=False):
+        """Persistent [N]-row buffers for ``step_poll(out=...)``: {'obs': dict, 'reward', 'done'}."""
+        obs, b = self._obs_buffers((self.n,), point_cloud, pose_modes)
+        return {'obs': obs, '_buffers': b, 'reward': self.torch.zeros((self.n,), dtype=self.torch.float32, device=self.device),
+                'done': self.torch.zeros((self.n,), dtype=self.torch.uint8, device=self.device)}
 
     def rollout(self, n_steps, first_macro_index=0, auto_reset=True, record=False):
         """n_steps x (RandomPolicy action -> env.step) per env in one launch."""

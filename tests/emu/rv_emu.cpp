@@ -71,6 +71,34 @@ void emu_rollout(EmuWorld* w, int n_steps, int first_index, int auto_reset) {
     run_env(w, i, 4, n_steps, 0, 0, first_index, auto_reset, 0);
   }
 }
+// rv_step_begin / rv_step_poll with a substep budget (the time budget needs the shader clock)
+void emu_step_begin(EmuWorld* w, const float* a, const uint8_t* mask) {
+  int G = w->cfg.num_goal_steps > 0 ? w->cfg.num_goal_steps : 1;
+  for (int i = 0; i < w->n; ++i) {
+    DevEnv& e = w->envs[i];
+    if ((mask && !mask[i]) || e.in_step == 1) continue;
+    for (int g = 0; g < G; ++g) for (int k = 0; k < 4; ++k) e.action[g][k] = a[((size_t)i * G + g) * 4 + k];
+    e.in_step = e.done ? 2 : 1; e.step_stage = -1;
+  }
+}
+void emu_step_poll(EmuWorld* w, int max_substeps, uint8_t* finished) {
+#pragma omp parallel for schedule(dynamic)
+  for (int i = 0; i < w->n; ++i) {
+    DevEnv& g = w->envs[i];
+    g.substeps_last = 0; g.awake_last = 0; g.pairs_last = 0; g.stepped = 0;
+    g.l_unsafe = 0; g.l_ineffective = 0; g.l_useful = 0; g.l_episodes = 0; g.l_successes = 0;
+    if (g.in_step != 1) { finished[i] = g.in_step == 2; if (g.in_step == 2) { g.in_step = 0; g.reward_valid = 0; } continue; }
+    Shared& S = g_shared;
+    memset(&S.s, 0xFF, sizeof(S.s));
+    S.cfg = w->cfg; S.arm = w->scene.arm;
+    Consts K = lds_consts(&w->scene, 0);
+    memcpy(&S.e, &g, sizeof(DevEnv));
+    env_enter(S, K);
+    S.s.bud_sub = max_substeps; S.s.bud_sub0 = 0; S.s.bud_clk = 0; S.s.bud_t0 = 0;
+    finished[i] = (uint8_t)env_step_partial(S, K);
+    memcpy(&g, &S.e, sizeof(DevEnv));
+  }
+}
 void emu_step_sub(EmuWorld* w, int n) {
 #pragma omp parallel for schedule(dynamic)
   for (int i = 0; i < w->n; ++i) run_env(w, i, 2, n, 0, 0, 0, 0, 0);

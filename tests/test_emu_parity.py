@@ -154,3 +154,37 @@ def test_grasp_env_is_bit_exact_vs_float_oracle(emu):
     assert 0 < r.sum() < 8                       # some grasps hold, some miss
     ref.rollout(2, 1, True); emu.emu_rollout(e.h, 2, 1, 1)
     _check(e, ref)
+
+
+@pytest.mark.parametrize('budget', [37, 500, 2500])
+def test_partial_steps_equal_whole_steps(emu, budget):
+    """rv_step_begin / rv_step_poll (lane emulator, substep budget): an env.step() cut into launches
+    of at most `budget` substeps gives the states, counters and rewards of rv_step_macro, bit for
+    bit, whatever the budget (37 cuts inside phase segments, coasting runs and the closing settle)."""
+    from oracle import orc
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(env_cfg=configs.push_env_config(MAX_STEPS=3), n_envs=5, seed=23, shape_names=names)
+    ref = orc.OracleWorld(cfg, scene, double=False)
+    e = Emu(emu, cfg, scene)
+    ref.reset(); emu.emu_reset(e.h, None)
+    for k in range(2):
+        a = ref.policy_random(k)
+        ref.set_actions(a); ref.step_macro()
+        emu.emu_step_begin(e.h, a.ctypes.data_as(C.c_void_p), None)
+        done_mask = np.zeros(5, np.uint8); polls = 0
+        while not done_mask.all():
+            fin = np.zeros(5, np.uint8)
+            emu.emu_step_poll(e.h, budget, fin.ctypes.data_as(C.c_void_p))
+            assert not (fin & done_mask).any()                  # an env finishes once
+            done_mask |= fin; polls += 1
+            assert polls < 2000
+        assert polls > 1 or budget > 2000
+        assert np.array_equal(e.body_state(), ref.body_state().astype(np.float32))
+        assert np.array_equal(e.joint_state(), ref.joint_state().astype(np.float32))
+        cr, ce = ref.env_counters(), e.counters()
+        assert np.array_equal(ce[:, :7], cr[:, :7])              # sim_steps, num_steps, episodes, phase, done, safe, effective
+        assert np.array_equal(e.manifolds(), ref.manifold_counts())
+        r = np.zeros(5, np.float32); d = np.zeros(5, np.uint8)
+        emu.emu_reward(e.h, r.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p))
+        rr, rd = ref.reward()
+        assert np.array_equal(d, rd)

@@ -169,3 +169,60 @@ def test_optional_physics_match_oracle_bit_for_bit(over):
     ws, rs = world.stats(), ref.stats()
     for k in ('env_steps', 'substeps', 'awake_substeps'):
         assert ws[k] == rs[k], k
+
+
+def test_partial_batch_trajectories_equal_step_macro():
+    """rv_step_begin / rv_step_poll: (a) used in lock step with a substep budget and (b) as a
+    work-conserving loop with a time budget, where every env runs at its own pace -- after its
+    k-th env.step() each env is in the state the float oracle reaches with step_macro, bit for
+    bit, and the observation / reward the poll hands back are those of that step."""
+    import torch
+    n, K = 48, 3
+    world, ref, cfg = _worlds(n, seed=41)
+    world.reset(); ref.reset()
+    acts = [ref.policy_random(k) for k in range(K)]
+    states, rewards = [], []
+    for k in range(K):
+        ref.set_actions(acts[k]); ref.step_macro()
+        states.append(ref.body_state().astype(np.float32)); rewards.append(ref.reward()[0].astype(np.float32))
+    # (a) lock step, 700 substeps per launch
+    for k in range(K):
+        world.step_begin(acts[k])
+        left = np.ones(n, bool); polls = 0
+        while left.any():
+            fin = world.step_poll(max_substeps=700).cpu().numpy().astype(bool)
+            assert not (fin & ~left).any()
+            left &= ~fin; polls += 1
+        assert polls > 3
+        assert np.array_equal(world.body_state().cpu().numpy(), states[k])
+    # (b) every env at its own pace, 200 us of GPU time per launch, results through the poll buffers
+    world2 = _worlds(n, seed=41)[0]
+    world2.reset()
+    out = world2.poll_buffers(point_cloud=True)
+    A = torch.as_tensor(np.stack(acts), device='cuda')                       # [K, N, G, 4]
+    cnt = torch.zeros(n, dtype=torch.long, device='cuda')
+    world2.step_begin(A[0])
+    ar = torch.arange(n, device='cuda')
+    seen = np.zeros((K, n), bool); polls = 0
+    while int(cnt.min()) < K:
+        fin = world2.step_poll(max_usec=200, out=out).bool()
+        polls += 1
+        assert polls < 20000
+        if not bool(fin.any()):
+            continue
+        idx = fin.nonzero().flatten()
+        k_done = cnt[idx]
+        got_pos = out['obs']['position'][idx].cpu().numpy(); got_r = out['reward'][idx].cpu().numpy()
+        st = world2.body_state()[idx].cpu().numpy()
+        for j, (i, kk) in enumerate(zip(idx.cpu().numpy(), k_done.cpu().numpy())):
+            assert np.array_equal(st[j], states[kk][i])                         # the state right after its kk-th step
+            assert np.array_equal(got_pos[j], states[kk][i][:, :3]) and got_r[j] == rewards[kk][i]
+            seen[kk, i] = True
+        cnt[idx] += 1
+        nxt = fin & (cnt < K)
+        if bool(nxt.any()):
+            world2.step_begin(A[cnt.clamp(max=K - 1), ar], mask=nxt.to(torch.uint8))
+    assert seen.all() and polls > K
+    pc = out['obs']['point_cloud'].cpu().numpy()
+    assert np.isfinite(pc).all()
+    world.close(); world2.close()
