@@ -1059,10 +1059,23 @@ static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4]
 typedef struct { int mi, i, k, a, b, isl; } orc_rowid;
 typedef struct { real l[3], a[3]; } orc_j6;
 static real dotj(const orc_j6* j, const real* pl, const real* pa) { return v3dot(j->l, pl) + v3dot(j->a, pa); }
-static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const orc_rowid* id, int n_rows, const int* use, const int* big, const int* label) {
+/* fing != 0 (rv_config.finger_dynamics, at most one awake body): the two finger joints are DOFs of the
+ * system as well.  A contact row on a finger pad has the Jacobian entry jf on its finger's velocity (an
+ * impulse dl changes that velocity by jf dl / finger_mass), and each finger has a POSITION_CONTROL motor
+ * row (bullet_physics.py:1061-1104) after the contact rows: J = 1 on the finger, target = the commanded
+ * velocity, impulse within +-finger_max_force dt minus what the joint motors of the light part already
+ * spent on the free motion.  The Delassus matrix gets the finger terms, nothing else changes; the fingers
+ * then move with the solved velocity. */
+static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const orc_rowid* id, int n_rows, const int* use, const int* big, const int* label, const int fing) {
   const rv_config* c = &w->cfg;
-  static __thread real A[SOLVE_ROWS][SOLVE_ROWS];
-  real g[SOLVE_ROWS], lam[SOLVE_ROWS], invk[SOLVE_ROWS], bias[SOLVE_ROWS], mu[SOLVE_ROWS], cap[SOLVE_ROWS];
+  const rv_arm* arm = &w->scene.arm;
+  static __thread real A[SOLVE_ROWS + 2][SOLVE_ROWS + 2];
+  real g[SOLVE_ROWS + 2], lam[SOLVE_ROWS + 2], invk[SOLVE_ROWS + 2], bias[SOLVE_ROWS + 2], mu[SOLVE_ROWS + 2], cap[SOLVE_ROWS + 2];
+  real jf[SOLVE_ROWS + 2], pf[SOLVE_ROWS + 2], mlo[2] = {R(0.0), R(0.0)}, mhi[2] = {R(0.0), R(0.0)}; int fi[SOLVE_ROWS + 2];
+  const real mf = (real)c->finger_mass, imf = fing ? R(1.0) / (real)c->finger_mass : R(0.0), fdt = (real)c->finger_max_force * (real)c->dt;
+  const real qf0[2] = {e->qd[RV_NLIMB], e->qd[RV_NLIMB + 1]};
+  const int n_all = n_rows + (fing ? 2 : 0);
+  int fisl = 0;      /* the island the motor rows belong to: the awake body's (there is at most one) */
   orc_j6 jx[SOLVE_ROWS][RV_MAXB];
   for (int r = 0; r < n_rows; ++r) {
     const orc_row* rw = &rows[id[r].mi][id[r].i]; const orc_manifold* mm = &e->man[id[r].mi];
@@ -1076,7 +1089,19 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
       gg -= v3dot(rw->dir[k], e->body[rb].v) + v3dot(rw->rxb[k], e->body[rb].w);
       for (int x = 0; x < 3; ++x) { jx[r][rb].l[x] = -rw->dir[k][x]; jx[r][rb].a[x] = -rw->rxb[k][x]; }
     } else gg -= rw->vbc[k];
+    jf[r] = R(0.0); pf[r] = R(0.0); fi[r] = -1;
+    if (fing) {
+      fi[r] = rw->fidx; fisl = id[r].isl;
+      if (fi[r] >= 0) { jf[r] = rw->jf[k]; pf[r] = jf[r] * imf; gg += jf[r] * qf0[fi[r]]; }
+    }
     g[r] = gg;
+  }
+  for (int m = 0; fing && m < 2; ++m) {       /* motor rows */
+    const int r = n_rows + m;
+    const real i0 = mf * e->fing_dv[m];
+    g[r] = qf0[m] - e->fing_vt[m]; lam[r] = R(0.0); invk[r] = mf; bias[r] = R(0.0); mu[r] = R(0.0); cap[r] = R(0.0);
+    jf[r] = R(1.0); pf[r] = imf; fi[r] = m;
+    mlo[m] = -fdt - i0; mhi[m] = fdt - i0;
   }
   for (int r = 0; r < n_rows; ++r)
     for (int s2 = 0; s2 < n_rows; ++s2) {
@@ -1089,11 +1114,18 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
         real nl_[3] = {-t[0], -t[1], -t[2]}, na_[3] = {-q->ab[ks][0], -q->ab[ks][1], -q->ab[ks][2]};
         a_ = a_ + dotj(&jx[r][bs], nl_, na_);
       }
+      if (fing && fi[r] >= 0 && fi[r] == fi[s2]) a_ = a_ + jf[r] * pf[s2];
       A[r][s2] = a_;
     }
-  for (int s2 = 0; s2 < n_rows; ++s2) for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s2] * lam[s2];
+  for (int m = 0; fing && m < 2; ++m) {
+    const int q = n_rows + m;
+    for (int r = 0; r < n_rows; ++r) { A[r][q] = fi[r] == m ? jf[r] * pf[q] : R(0.0); A[q][r] = fi[r] == m ? pf[r] : R(0.0); }
+    for (int m2 = 0; m2 < 2; ++m2) A[q][n_rows + m2] = m == m2 ? pf[q] : R(0.0);
+  }
+  for (int s2 = 0; s2 < n_rows; ++s2) for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s2] * lam[s2];
   int isl_rows = 0, done = 0;
   for (int s2 = 0; s2 < n_rows; ++s2) isl_rows |= 1 << id[s2].isl;
+  if (fing) isl_rows |= 1 << fisl;
   for (int it = 0; it < c->solver_iters; ++it) {
     real res[RV_MAXB] = {R(0.0), R(0.0), R(0.0), R(0.0)};
     real limtab[RV_NMAN][4];   /* friction bound of every point: mu x its normal impulse (the rows of a point need not be neighbours in the list) */
@@ -1108,7 +1140,15 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
       lam[s2] = nl;
       if (id[s2].k == 0) limtab[id[s2].mi][id[s2].i] = mu[s2] * nl;
       res[isl] = rmax(res[isl], rabs(d));
-      for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s2] * d;
+      for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s2] * d;
+    }
+    for (int m = 0; fing && m < 2; ++m) {
+      const int q = n_rows + m;
+      const real nl = rclamp(lam[q] + (-g[q] * invk[q]), mlo[m], mhi[m]);
+      const real d = nl - lam[q];
+      lam[q] = nl;
+      res[fisl] = rmax(res[fisl], rabs(d));
+      for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][q] * d;
     }
     for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < (real)c->solver_tol) done |= 1 << x;
 #ifdef ORC_DEBUG_SOLVE
@@ -1137,6 +1177,16 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
       }
       if (cc < 3) e->body[X].v[cc] = acc; else e->body[X].w[cc - 3] = acc;
     }
+  }
+  for (int m = 0; fing && m < 2; ++m) {        /* the fingers move with the solved velocity */
+    real qd = qf0[m];
+    for (int s2 = 0; s2 < n_rows; ++s2) if (fi[s2] == m) qd = qd + pf[s2] * lam[s2];
+    qd = qd + pf[n_rows + m] * lam[n_rows + m];
+    const int j = RV_NLIMB + m;
+    real qn = e->q[j] + (qd - e->fing_qd0[m]) * (real)c->dt;
+    if (qn < (real)arm->q_lo[j]) { qn = (real)arm->q_lo[j]; qd = R(0.0); }
+    if (qn > (real)arm->q_hi[j]) { qn = (real)arm->q_hi[j]; qd = R(0.0); }
+    e->q[j] = qn; e->qd[j] = qd;
   }
 }
 
@@ -1208,8 +1258,16 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
         if (!big[label[BB_A[k]]]) for (int k3 = 0; k3 < 3; ++k3) { orc_rowid y = {mi, i, k3, BB_A[k], BB_B[k], label[BB_A[k]]}; id[n_rows++] = y; }
       }
     }
-  if (c->finger_dynamics && e->arm_enabled) { solve_with_fingers(w, e, rows, use); return; }
-  if (n_rows > 0) solve_rows(w, e, rows, id, n_rows, use, big, label);
+  if (c->finger_dynamics && e->arm_enabled) {
+    /* at most one awake body (a grasp scene): impulse space, fingers included; else the
+     * velocity-space system solver */
+    int n_on = 0;
+    for (int b = 0; b < RV_MAXB; ++b) n_on += use[TIDX(b)];
+    if (n_on <= 1) solve_rows(w, e, rows, id, n_rows, use, big, label, 1);
+    else solve_with_fingers(w, e, rows, use);
+    return;
+  }
+  if (n_rows > 0) solve_rows(w, e, rows, id, n_rows, use, big, label, 0);
   /* big islands: warm start first */
   for (int b = 0; b < RV_MAXB; ++b)
     for (int kind = 0; kind <= 2; kind += 2) {

@@ -1388,11 +1388,153 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
   }
   __syncthreads();
 }
+// The force-limited gripper in impulse space (rv_config.finger_dynamics; at most one awake body X, or
+// none: X < 0).  Layout: lanes 0..23 the rows of X (table points 0..3, arm points 0..3, x 3 rows), lanes
+// 24 / 25 the POSITION_CONTROL motor rows of the two finger joints (bullet_physics.py:1061-1104).  The
+// finger joints are DOFs of mass finger_mass: a contact row on a finger pad has the Jacobian entry jf on
+// its finger's velocity, so A_rs gains jf_r jf_s / m for two rows on the same finger, a motor row couples
+// with the rows of its finger through jf / m, and with itself through 1 / m.  Visiting order: the contact
+// rows, then the two motor rows; the motor impulse stays within +-finger_max_force dt minus what the
+// joint motors of the light part already spent on the free motion.  Same arithmetic as solve_rows(fing).
+RV_DEV void solve_island_fingers(Shared& S, const Consts& K, const int X) {
+  DevEnv& e = S.e; const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
+  const int lane = (int)threadIdx.x;
+  const int Xc = X >= 0 ? X : 0;
+  const int ntx = X >= 0 ? __builtin_amdgcn_readfirstlane(e.man[RV_TIDX(Xc)].n) : 0;
+  const int nax = X >= 0 ? __builtin_amdgcn_readfirstlane(e.man[RV_AIDX(Xc)].n) : 0;
+  const float mf = c->finger_mass, imf = 1.0f / c->finger_mass, fdt = c->finger_max_force * c->dt;
+  const int L = lane < 24 ? lane : 23;
+  const int p = L / 3, k = L - 3 * p, slot = p & 3;
+  const int mi = p < 4 ? RV_TIDX(Xc) : RV_AIDX(Xc);
+  const bool act = lane < 24 && (p < 4 ? p < ntx : p - 4 < nax);
+  const bool motor = lane == 24 || lane == 25;
+  const int mid = lane == 25 ? 1 : 0;
+  const Row& R = S.s.u.r.rows[mi][slot];
+  DevMan& mm = e.man[mi];
+  J6 JX, PX;
+  JX.l = JX.a = PX.l = PX.a = mk(0, 0, 0);
+  float invk = 0.0f, bias = 0.0f, mu = 0.0f, lam = 0.0f, g = 0.0f, cap = 1e30f, jf = 0.0f, pf = 0.0f, lo = 0.0f, hi = 0.0f;
+  int fi = -1;
+  const float qf0a = e.qd[RV_NLIMB], qf0b = e.qd[RV_NLIMB + 1];
+  if (act) {
+    const v3 dir = ld3(R.dir[k]), rxa = ld3(R.rxa[k]);
+    invk = R.invk[k]; mu = R.mu; bias = k == 0 ? R.target : 0.0f; cap = R.cap;
+    lam = k == 0 ? mm.ln[slot] : (k == 1 ? mm.lt1[slot] : mm.lt2[slot]);
+    g = dot(dir, ld3(e.body[Xc] + 7)) + dot(rxa, ld3(e.body[Xc] + 10));
+    JX.l = dir; JX.a = rxa; PX.l = scale(dir, e.inv_mass[Xc]); PX.a = ld3(R.aa[k]);
+    g -= R.vbc[k];
+    fi = R.fidx;
+    if (fi >= 0) { jf = R.jf[k]; pf = jf * imf; g += jf * (fi == 0 ? qf0a : qf0b); }
+  }
+  if (motor) {
+    const float i0 = mf * S.s.fing_dv[mid];
+    g = (mid == 0 ? qf0a : qf0b) - S.s.fing_vt[mid]; invk = mf; jf = 1.0f; pf = imf; fi = mid;
+    lo = -fdt - i0; hi = fdt - i0;
+  }
+  // this lane's row of the Delassus matrix: columns 0..23 the contact rows, 24 / 25 the motor rows
+  float A[26];
+#pragma unroll
+  for (int s = 0; s < 24; ++s) {
+    float a_ = 0.0f;
+    const int ps = s / 3;
+    if (ps < 4 ? ps < ntx : ps - 4 < nax) {
+      a_ = dotj(JX, rdlane3(PX.l, s), rdlane3(PX.a, s));
+      const int fs = __builtin_amdgcn_readlane(fi, s);
+      const float pfs = rdlane(pf, s);
+      if (motor) a_ = fs == fi ? pfs : 0.0f;                    // a motor row sees the rows of its finger through jf_s / m
+      else if (fi >= 0 && fs == fi) a_ = a_ + jf * pfs;
+    }
+    A[s] = a_;
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) A[24 + m] = (fi == m) ? jf * imf : 0.0f;   // (motor row m on itself: 1 x 1 / m)
+  // warm start: the contact impulses kept from the last substep (the motor rows start from zero)
+#pragma unroll
+  for (int s = 0; s < 24; ++s) { const int ps = s / 3; if (ps < 4 ? ps < ntx : ps - 4 < nax) g = g + A[s] * rdlane(lam, s); }
+  const int iters = c->solver_iters; const float tol = c->solver_tol;
+  const int toli = __builtin_bit_cast(int, tol);
+  for (int it = 0; it < iters; ++it) {
+    int resi = 0;
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {
+      if (!(pp < 4 ? pp < ntx : pp - 4 < nax)) continue;
+      float lim = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const int s = 3 * pp + kk;
+        float nl;
+        if (kk == 0) nl = __builtin_amdgcn_fmed3f(lam + (bias - g) * invk, 0.0f, cap);
+        else nl = __builtin_amdgcn_fmed3f(lam + (-g * invk), -lim, lim);
+        const float d = nl - lam;
+        if (lane == s) lam = nl;
+        const int sdi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), s);
+        const float sd = __builtin_bit_cast(float, sdi);
+        if (kk == 0) lim = rdlane(mu * nl, s);
+        const int mag = sdi & 0x7fffffff;
+        resi = resi > mag ? resi : mag;
+        g = g + A[s] * sd;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int s = 24 + m;
+      const float nl = __builtin_amdgcn_fmed3f(lam + (-g * invk), lo, hi);
+      const float d = nl - lam;
+      if (lane == s) lam = nl;
+      const int sdi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), s);
+      const int mag = sdi & 0x7fffffff;
+      resi = resi > mag ? resi : mag;
+      g = g + A[s] * __builtin_bit_cast(float, sdi);
+    }
+    if (tol > 0.0f ? resi < toli : false) break;
+  }
+  // impulses back to the manifolds; body and finger velocities rebuilt in row order through LDS
+  float* cb = &S.s.u.r.wv[0][0][0][0];
+  if (act) { if (k == 0) mm.ln[slot] = lam; else if (k == 1) mm.lt1[slot] = lam; else mm.lt2[slot] = lam; }
+  if (lane < 26) {
+    float* o = cb + 8 * lane;
+    o[0] = PX.l.x * lam; o[1] = PX.l.y * lam; o[2] = PX.l.z * lam; o[3] = PX.a.x * lam; o[4] = PX.a.y * lam; o[5] = PX.a.z * lam;
+    o[6] = pf * lam; o[7] = __builtin_bit_cast(float, fi);
+  }
+  __syncthreads();
+  if (lane < 6 && X >= 0) {
+    float acc = e.body[Xc][7 + lane];
+    float t[24];
+#pragma unroll
+    for (int s = 0; s < 24; ++s) t[s] = cb[8 * s + lane];
+#pragma unroll
+    for (int s = 0; s < 24; ++s) acc = acc + t[s];
+    e.body[Xc][7 + lane] = acc;
+  } else if (lane == 8 || lane == 9) {
+    const int m = lane - 8;
+    float qd = m == 0 ? qf0a : qf0b;
+    for (int s = 0; s < 24; ++s) {
+      const int ps = s / 3;
+      if (!(ps < 4 ? ps < ntx : ps - 4 < nax)) continue;
+      if (__builtin_bit_cast(int, cb[8 * s + 7]) == m) qd = qd + cb[8 * s + 6];
+    }
+    qd = qd + cb[8 * (24 + m) + 6];
+    const int j = RV_NLIMB + m;
+    float qn = e.q[j] + (qd - S.s.fing_qd0[m]) * c->dt;
+    if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
+    if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
+    e.q[j] = qn; e.qd[j] = qd;
+  }
+  __syncthreads();
+}
 #else
-RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
-  DevEnv& e = S.e; const rv_config* c = K.cfg;
-  static thread_local float A[RV_SOLVE_ROWS][RV_SOLVE_ROWS];
-  float g[RV_SOLVE_ROWS], lam[RV_SOLVE_ROWS], invk[RV_SOLVE_ROWS], bias[RV_SOLVE_ROWS], mu[RV_SOLVE_ROWS], cap[RV_SOLVE_ROWS];
+// fing != 0 (rv_config.finger_dynamics, at most one awake body): the two finger joints are DOFs of
+// the system as well -- contact rows on a finger pad carry jf on their finger's velocity, each finger
+// has a motor row after the contact rows (see solve_island_fingers, the device version)
+RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int fing) {
+  DevEnv& e = S.e; const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
+  static thread_local float A[RV_SOLVE_ROWS + 2][RV_SOLVE_ROWS + 2];
+  float g[RV_SOLVE_ROWS + 2], lam[RV_SOLVE_ROWS + 2], invk[RV_SOLVE_ROWS + 2], bias[RV_SOLVE_ROWS + 2], mu[RV_SOLVE_ROWS + 2], cap[RV_SOLVE_ROWS + 2];
+  float jf[RV_SOLVE_ROWS + 2], pf[RV_SOLVE_ROWS + 2], mlo[2] = {0.0f, 0.0f}, mhi[2] = {0.0f, 0.0f}; int fi[RV_SOLVE_ROWS + 2];
+  const float mf = c->finger_mass, imf = fing ? 1.0f / c->finger_mass : 0.0f, fdt = c->finger_max_force * c->dt;
+  const float qf0[2] = {e.qd[RV_NLIMB], e.qd[RV_NLIMB + 1]};
+  const int n_all = n_rows + (fing ? 2 : 0);
+  int fisl = 0;
   J6 jx[RV_SOLVE_ROWS][RV_MAXB];
   for (int r = 0; r < n_rows; ++r) {
     const int rm = S.s.rowmap[r];
@@ -1410,9 +1552,21 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
       gg -= dot(dir, ld3(e.body[rb] + 7)) + dot(rxb, ld3(e.body[rb] + 10));
       nd = mk(-dir.x, -dir.y, -dir.z); nrxb = mk(-rxb.x, -rxb.y, -rxb.z);
     } else gg -= R.vbc[k];
+    jf[r] = 0.0f; pf[r] = 0.0f; fi[r] = -1;
+    if (fing) {
+      fi[r] = R.fidx; fisl = RV_ROW_ISL(rm);
+      if (fi[r] >= 0) { jf[r] = R.jf[k]; pf[r] = jf[r] * imf; gg += jf[r] * qf0[fi[r]]; }
+    }
     g[r] = gg;
     jx[r][ra].l = dir; jx[r][ra].a = rxa;
     if (rb >= 0) { jx[r][rb].l = nd; jx[r][rb].a = nrxb; }
+  }
+  for (int m = 0; fing && m < 2; ++m) {       // motor rows
+    const int r = n_rows + m;
+    const float i0 = mf * S.s.fing_dv[m];
+    g[r] = qf0[m] - S.s.fing_vt[m]; lam[r] = 0.0f; invk[r] = mf; bias[r] = 0.0f; mu[r] = 0.0f; cap[r] = 0.0f;
+    jf[r] = 1.0f; pf[r] = imf; fi[r] = m;
+    mlo[m] = -fdt - i0; mhi[m] = fdt - i0;
   }
   for (int r = 0; r < n_rows; ++r)
     for (int s = 0; s < n_rows; ++s) {
@@ -1425,11 +1579,18 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
         const v3 t = scale(ds, e.inv_mass[bs]), ab = ld3(Q.ab[ks]);
         a_ = a_ + dotj(jx[r][bs], mk(-t.x, -t.y, -t.z), mk(-ab.x, -ab.y, -ab.z));
       }
+      if (fing && fi[r] >= 0 && fi[r] == fi[s]) a_ = a_ + jf[r] * pf[s];
       A[r][s] = a_;
     }
-  for (int s = 0; s < n_rows; ++s) for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s] * lam[s];
+  for (int m = 0; fing && m < 2; ++m) {
+    const int q = n_rows + m;
+    for (int r = 0; r < n_rows; ++r) { A[r][q] = fi[r] == m ? jf[r] * pf[q] : 0.0f; A[q][r] = fi[r] == m ? pf[r] : 0.0f; }
+    for (int m2 = 0; m2 < 2; ++m2) A[q][n_rows + m2] = m == m2 ? pf[q] : 0.0f;
+  }
+  for (int s = 0; s < n_rows; ++s) for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s] * lam[s];
   int isl_rows = 0, done = 0;
   for (int s = 0; s < n_rows; ++s) isl_rows |= 1 << RV_ROW_ISL(S.s.rowmap[s]);
+  if (fing) isl_rows |= 1 << fisl;
   RV_CNT(21, 1) RV_CNT(23, n_rows)
   for (int it = 0; it < c->solver_iters; ++it) {
     RV_CNT(22, 1)
@@ -1453,7 +1614,15 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
         rv_emu_dbg[cls] += 1; if (RV_ROW_K(q) == 0 && nl >= cap[s]) rv_emu_dbg[6] += 1; if (RV_ROW_K(q) != 0 && (nl >= lim || nl <= -lim)) rv_emu_dbg[7] += 1;
       }
 #endif
-      for (int r = 0; r < n_rows; ++r) g[r] = g[r] + A[r][s] * d;
+      for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s] * d;
+    }
+    for (int m = 0; fing && m < 2; ++m) {
+      const int q = n_rows + m;
+      const float nl = fclampr(lam[q] + (-g[q] * invk[q]), mlo[m], mhi[m]);
+      const float d = nl - lam[q];
+      lam[q] = nl;
+      res[fisl] = fmaxr(res[fisl], fabsr(d));
+      for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][q] * d;
     }
 #ifdef RV_EMU_COUNT
     for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && !((done >> x) & 1) && (res[x] < c->solver_tol || it == c->solver_iters - 1)) {
@@ -1494,6 +1663,16 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows) {
       }
       e.body[X][7 + cc] = acc;
     }
+  }
+  for (int m = 0; fing && m < 2; ++m) {        // the fingers move with the solved velocity
+    float qd = qf0[m];
+    for (int s = 0; s < n_rows; ++s) if (fi[s] == m) qd = qd + pf[s] * lam[s];
+    qd = qd + pf[n_rows + m] * lam[n_rows + m];
+    const int j = RV_NLIMB + m;
+    float qn = e.q[j] + (qd - S.s.fing_qd0[m]) * c->dt;
+    if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
+    if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
+    e.q[j] = qn; e.qd[j] = qd;
   }
 }
 #endif
@@ -1972,6 +2151,9 @@ struct CoastCtl {
   int lt_on, jt_on, applied, from_ik, lt_has_stop, lt_more, jt_has_stop, jt_limb;
   float lt_stop, jt_stop, dt;
   int interrupt, has_budget, max_phase_steps;
+  // Grasp4DofEnv (its phase machine ticks after every substep): phase, substeps spent in 'start'
+  int grasp, g_phase, g_action_steps, g_max_action;
+  float g_ready_time;
 };
 RV_DEV int ctl_link_done(const CoastCtl& C, int st) {        // check_link_target_done at step st
   if (!C.lt_has_stop) return 1;
@@ -2023,7 +2205,19 @@ RV_DEV CoastCtl coast_ctl_load(const Shared& S, const Consts& K) {
   for (int i = 0; i < e.jt.n_idx; ++i) if (e.jt.idx[i] < RV_NLIMB) C.jt_limb = 1;
   C.lt_stop = e.lt.stop_t; C.jt_stop = e.jt.stop_t; C.dt = K.cfg->dt;
   C.interrupt = S.s.interrupt; C.has_budget = S.s.has_budget; C.max_phase_steps = S.s.max_phase_steps;
+  C.grasp = K.cfg->env_type == RV_ENV_GRASP; C.g_phase = e.phase; C.g_action_steps = e.num_action_steps;
+  C.g_max_action = K.cfg->max_action_steps; C.g_ready_time = e.gripper_ready_time;
   return C;
+}
+// gphase_tick() at step st (Grasp4DofEnv, after EVERY substep): nothing but the count of 'start'
+// substeps changes.  start_ticks: ticks since C was loaded, this one included.  (The arm - table
+// flag is clear while coasting.)
+RV_DEV int ctl_gtick_noop(const CoastCtl& C, int st, int reached, int start_ticks) {
+  if (C.g_phase == RV_GPHASE_START && C.g_action_steps + start_ticks >= C.g_max_action) return 0;   // the grasping motion is stuck
+  if (C.lt_on && ctl_link_done(C, st)) return 0;
+  if (C.jt_on && ctl_joint_done(C, st, reached)) return 0;
+  if (C.lt_on || (C.jt_on && C.jt_limb)) return 1;                // limb not ready
+  return C.dt * (float)st < C.g_ready_time;                       // limb ready: the gripper is not
 }
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
 template <int N> RV_DEV float row_ror_add(float x) {
@@ -2072,6 +2266,8 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
   C.lt_has_stop = uni(C.lt_has_stop); C.lt_more = uni(C.lt_more); C.jt_has_stop = uni(C.jt_has_stop); C.jt_limb = uni(C.jt_limb);
   C.lt_stop = unif(C.lt_stop); C.jt_stop = unif(C.jt_stop); C.dt = unif(C.dt);
   C.interrupt = uni(C.interrupt); C.has_budget = uni(C.has_budget); C.max_phase_steps = uni(C.max_phase_steps);
+  C.grasp = uni(C.grasp); C.g_phase = uni(C.g_phase); C.g_action_steps = uni(C.g_action_steps); C.g_max_action = uni(C.g_max_action);
+  C.g_ready_time = unif(C.g_ready_time);
   DevEnv& e = S.e;
   const int lane = (int)threadIdx.x;
   const int j = lane < RV_NJ ? lane : RV_NJ - 1;
@@ -2267,14 +2463,19 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
         const bool ok = fabsr(tpos - q) < pos_thr && (!has_vel || fabsr(0.0f - qd) < vel_thr);
         reached = __builtin_amdgcn_ballot_w64(tgt && !ok) == 0;
       }
-      if (!ctl_tick_noop(C, st, reached)) { pending = 2; break; }
+      if (!(C.grasp ? ctl_gtick_noop(C, st, reached, st - uni(st0)) : ctl_tick_noop(C, st, reached))) { pending = 2; break; }
     }
     if (left == 0) { pending = 3; break; }      // (after the tick test: a tick that is due is never skipped)
   }
   const int n = st - uni(st0);
   if (n > 0) {
     if (mine) { e.q[j] = q; e.qd[j] = qd; S.s.jtravel[j] = trav; }
-    if (lane == 0) { e.sim_steps += n; e.substeps_last += n; S.s.fused_n += n; }
+    if (lane == 0) {
+      e.sim_steps += n; e.substeps_last += n; S.s.fused_n += n;
+      // Grasp4DofEnv: the ticks this segment passed over counted their 'start' substeps (the tick
+      // that ended it, if any, is executed -- and counted -- by the caller)
+      if (C.grasp && C.g_phase == RV_GPHASE_START) e.num_action_steps += n - (pending == 2 ? 1 : 0);
+    }
   }
   if (lane == 0) S.s.fused_pending = pending;
   __syncthreads();
@@ -2339,11 +2540,13 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
       if (!out_of_reach) { RV_CNT(5, 1) pending = 1; break; }
       for (int j = 0; j < RV_NJ; ++j) { e.q[j] = qn_[j]; e.qd[j] = qdn_[j]; trav[j] = tn_[j]; }
       ++st;
-      if (steps_check > 0 && st % steps_check == 0 && !ctl_tick_noop(C, st, check_joints_reached(e))) { pending = 2; break; }
+      if (steps_check > 0 && st % steps_check == 0 &&
+          !(C.grasp ? ctl_gtick_noop(C, st, check_joints_reached(e), st - st0) : ctl_tick_noop(C, st, check_joints_reached(e)))) { pending = 2; break; }
       if (S.s.fused_n + (st - st0) >= max_n) { pending = 3; break; }
     }
     const int n = st - st0;
     for (int j = 0; j < RV_NJ; ++j) S.s.jtravel[j] = trav[j];
+    if (C.grasp && C.g_phase == RV_GPHASE_START) e.num_action_steps += n - (pending == 2 ? 1 : 0);
     e.sim_steps += n; e.substeps_last += n;
     S.s.fused_n += n; S.s.fused_pending = pending;
     RV_CNT(2, 1) RV_CNT(3, n) RV_CNT(6, pending == 2)
@@ -2874,11 +3077,20 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     rv_emu_cnt[27] += (arm_pts == 0 && !near && !S.s.arm_moving); rv_emu_cnt[28] += slow; rv_emu_cnt[29] += (slow && arm_pts == 0); }
 #endif
   const int with_fingers = c->finger_dynamics && arm_on;
-  if (with_fingers) {
+  // force-limited gripper: at most one awake body (a grasp scene) -> impulse space with the two
+  // finger DOFs and their motor rows, one lane per row; else the velocity-space system solver
+  int n_on = 0, the_body = -1;
+#pragma unroll
+  for (int b = RV_MAXB - 1; b >= 0; --b) if (on_[b]) { ++n_on; the_body = b; }
+  const int fing_fast = with_fingers && n_on <= 1;
+  if (with_fingers && !fing_fast) {
     RV_LANES_BEGIN
       if (lane == 0) solve_with_fingers(S, K);
     RV_LANES_END
   }
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+  if (fing_fast) solve_island_fingers(S, K, __builtin_amdgcn_readfirstlane(the_body));
+#endif
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
   {
     // the partner / pair of every two-body island, then ONE instance of the island solver in
@@ -2906,9 +3118,10 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   }
 #else
   RV_LANES_BEGIN
-    if (lane == 0) S.s.n_rows = with_fingers ? 0 : solver_row_list(S, label, on_, act_, big_);
+    if (lane == 0) S.s.n_rows = (with_fingers && !fing_fast) ? 0 : solver_row_list(S, label, on_, act_, big_);
   RV_LANES_END
-  if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows);
+  if (fing_fast) solve_rows(S, K, S.s.n_rows < 0 ? 0 : S.s.n_rows, 1);
+  else if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows, 0);
 #endif
   // an island of three or four bodies (there can be only one): velocity-space Gauss-Seidel in the
   // order  bodies (their table and arm points), then the three rounds of body pairs.  Bodies do
@@ -3228,14 +3441,15 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
 #endif
       if (stop) { suspended = 1; break; }
     }
-    if (phase_mode && !grasp_mode && coast_wait == 0) {
+    if (phase_mode && coast_wait == 0) {
       // free-space motion: as many substeps (and ticks that change nothing) as provably possible
+      // (Grasp4DofEnv: a tick after every substep)
       int why = 0;
-      const int n = coast_run(S, K, K.cfg->steps_check, bud_left, &why);
+      const int n = coast_run(S, K, grasp_mode ? 1 : K.cfg->steps_check, bud_left, &why);
       if (n > 0) {
         coast_fail = 0;
         if (why == 2) break;               // the phase machine has something to do at this tick
-        n_fixed = K.cfg->steps_check - (S.e.sim_steps % K.cfg->steps_check); taken = 0;
+        n_fixed = grasp_mode ? 1 : K.cfg->steps_check - (S.e.sim_steps % K.cfg->steps_check); taken = 0;
       }
       // the substep the loop stopped at is a regular one; after attempts that bought nothing
       // (awake bodies / close to something) step normally for a while
@@ -3352,7 +3566,7 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
   // the phase machine looks at the world every STEPS_CHECK substeps (push_env.py:652-661);
   // it reads the end-effector frame only in these situations
   if (!S.s.kin_fresh && S.e.arm_enabled &&
-      (S.e.phase == RV_PHASE_START || S.e.phase == RV_PHASE_MOTION || S.s.interrupt)) arm_refresh_kinematics(S, K);
+      (grasp_mode || S.e.phase == RV_PHASE_START || S.e.phase == RV_PHASE_MOTION || S.s.interrupt)) arm_refresh_kinematics(S, K);
   RV_PROF(8)
   RV_LANES_BEGIN
     if (lane == 0) { if (grasp_mode) gphase_tick(S, K); else phase_tick(S, K); }

@@ -188,3 +188,23 @@ def test_partial_steps_equal_whole_steps(emu, budget):
         emu.emu_reward(e.h, r.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p))
         rr, rd = ref.reward()
         assert np.array_equal(d, rd)
+
+
+def test_emulated_grasp_env_is_bit_exact_vs_float_oracle(emu):
+    """Grasp4DofEnv (force-limited gripper: impulse-space solver with the two finger DOFs and their motor
+    rows; phase machine ticking after every substep, fused coasting included) on the lane emulator."""
+    from oracle import orc
+    genv = configs.grasp_env_config()
+    scene, names = scenes.make_scene(env_cfg=genv)
+    cfg = configs.make_rv_config(env_cfg=genv, n_envs=6, seed=5, shape_names=names)
+    ref = orc.OracleWorld(cfg, scene, double=False)
+    e = Emu(emu, cfg, scene)
+    ref.reset(); emu.emu_reset(e.h, None)
+    _check(e, ref)
+    for k in range(2):
+        a = ref.policy_random(k)
+        ref.set_actions(a); emu.emu_set_actions(e.h, a.ctypes.data_as(C.c_void_p))
+        ref.step_macro(); emu.emu_step_macro(e.h)
+        _check(e, ref)
+        ref.reset(); emu.emu_reset(e.h, None)          # every grasp is a whole episode
+        _check(e, ref)

@@ -36,6 +36,7 @@ ap.add_argument('--warm-steps', type=int, default=None, help='steps per warm lau
 ap.add_argument('--seed', type=int, default=1234)
 ap.add_argument('--over', nargs='*', default=[], help='config overrides, e.g. PHYSICS.SLEEP_STEPS=0')
 ap.add_argument('--top', type=int, default=6)
+ap.add_argument('--grasp', action='store_true', help='BASELINE config 4: Grasp4DofEnv (random CUBOID grasps)')
 args = ap.parse_args()
 
 os.environ['RV_LIB'] = PROF_LIB
@@ -66,8 +67,12 @@ for kv in args.over:
             over[k] = float(v)
         except ValueError:
             over[k] = v
-scene, names = scenes.make_scene()
-env_cfg = configs.push_env_config(**over)
+if args.grasp:
+    env_cfg = configs.grasp_env_config(**over)
+    scene, names = scenes.make_scene(env_cfg=env_cfg)
+else:
+    scene, names = scenes.make_scene()
+    env_cfg = configs.push_env_config(**over)
 cfg = configs.make_rv_config(env_cfg=env_cfg, n_envs=args.envs, seed=args.seed, shape_names=names)
 w = lib.World(cfg, scene, 0)
 L = lib.load()
