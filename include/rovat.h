@@ -372,6 +372,15 @@ int  rv_set_link_target(rv_world* w, const float* d_pose /* [N][7] pos+xyzw */, 
 int  rv_set_motor_targets(rv_world* w, const float* d_q /* [N][RV_NJ] */, const uint8_t* d_mask /* [N][RV_NJ] or NULL */);
 /* ---- SawyerSim.grip (sawyer_sim.py:362-392): value in [0, 1], 0 = open. */
 int  rv_grip(rv_world* w, float value);
+/* Simulator.add_constraint / Constraint.pose, max_force setters / remove_constraint
+ * (simulator.py:166-224; bullet_physics.py:748-957 createConstraint / changeConstraint /
+ * removeConstraint), for the constraint ControllableConstraint servoes
+ * (controllable_constraint.py:21-170): a FIXED joint between the frame frame7 (host float[7]:
+ * position + xyzw quaternion in the body frame; NULL = the body frame itself) of movable body
+ * `body` and the world frame target7, applying at most max_force newtons per row.  Every env of
+ * the world gets it; calling again moves the world frame (the servo does that every substep);
+ * max_force < 0 removes the constraint.  Other joint types / a movable child raise in the mirror. */
+int  rv_set_constraint(rv_world* w, int32_t body, const float* frame7, const float* target7, float max_force);
 /* BulletPhysics.set_gravity (bullet_physics.py:129-137): the gravity vector of every env of
  * the world from now on (host float[3]) */
 int  rv_set_gravity(rv_world* w, const float* gravity);

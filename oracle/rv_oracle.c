@@ -45,6 +45,10 @@ typedef struct {
   int undisturbed;                      /* woken, but has not left the pose window it was sleeping in */
   real aabb[6];                         /* world box (lo, hi) of the hulls + margin, taken when the body fell asleep */
   real scale, mass, inv_mass, inv_inertia[3], friction, radius;
+  /* user constraint (Simulator.add_constraint, simulator.py:166-224; bullet_physics.py:748-957):
+   * a fixed joint between the frame (con_lpos, con_lquat) of this body and a frame of the world
+   * (con_tpos, con_tquat), which can apply at most con_fmax N per row */
+  int con_on; real con_lpos[3], con_lquat[4], con_tpos[3], con_tquat[4], con_fmax;
 } orc_bparam;
 
 /* JointTarget (controllable_body.py:28-129) */
@@ -993,10 +997,50 @@ static real point_solve_g(orc_env* e, int a, orc_manifold* m, int i, const orc_r
   if (fi >= 0) qf[fi] += r->jf[2] * dl * imf;
   return res;
 }
+/* The six rows of a user constraint on body b (a fixed joint to a frame of the world: the mocap-style
+ * constraint ControllableConstraint servoes, controllable_constraint.py:21-170): three linear rows at
+ * the pivot, three angular rows, Baumgarte-stabilised with rv_config.erp, accumulated impulse within
+ * +- con_fmax dt per row (pybullet changeConstraint maxForce).  lam[6]: accumulated impulses. */
+static real constraint_solve(const orc_world* w, orc_env* e, int b, real* lam) {
+  const rv_config* c = &w->cfg; const orc_bparam* P = &e->bp[b]; orc_body* B = &e->body[b];
+  const real dt = (real)c->dt, lim = P->con_fmax * dt;
+  real rot[9], r[3], wp[3], res = R(0.0);
+  qmat(rot, B->q); m3mulv(r, rot, P->con_lpos); v3add(wp, B->p, r);
+  real qw[4], qc[4], qe[4];
+  qmul(qw, B->q, P->con_lquat);                                  /* the joint frame of the body, in the world */
+  qc[0] = -qw[0]; qc[1] = -qw[1]; qc[2] = -qw[2]; qc[3] = qw[3];
+  qmul(qe, P->con_tquat, qc);                                    /* rotation that takes it to the target frame */
+  const real sg = qe[3] < R(0.0) ? R(-2.0) : R(2.0);
+  const real th[3] = {qe[0] * sg, qe[1] * sg, qe[2] * sg};
+  for (int k = 0; k < 6; ++k) {
+    real jl[3] = {R(0.0), R(0.0), R(0.0)}, ja[3] = {R(0.0), R(0.0), R(0.0)}, ia[3], bias;
+    if (k < 3) {
+      jl[k] = R(1.0);
+      real ek[3] = {R(0.0), R(0.0), R(0.0)}; ek[k] = R(1.0);
+      v3cross(ja, r, ek);
+      bias = (real)c->erp * (P->con_tpos[k] - wp[k]) / dt;
+    } else {
+      ja[k - 3] = R(1.0);
+      bias = (real)c->erp * th[k - 3] / dt;
+    }
+    m3mulv(ia, e->iinv[b], ja);
+    const real kk = (k < 3 ? P->inv_mass : R(0.0)) + v3dot(ja, ia);
+    const real jv = v3dot(jl, B->v) + v3dot(ja, B->w);
+    real dl = (bias - jv) / kk;
+    const real ln = rclamp(lam[k] + dl, -lim, lim);
+    dl = ln - lam[k]; lam[k] = ln;
+    res = rmax(res, rabs(dl));
+    v3madd(B->v, B->v, jl, dl * P->inv_mass);
+    v3madd(B->w, B->w, ia, dl);
+  }
+  return res;
+}
 static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4], const int* use) {
   const rv_config* c = &w->cfg; const rv_arm* arm = &w->scene.arm;
+  const int fd = c->finger_dynamics && e->arm_enabled;           /* the finger joints are DOFs of the system */
   const real mf = (real)c->finger_mass, imf = R(1.0) / (real)c->finger_mass, fdt = (real)c->finger_max_force * (real)c->dt;
   real qf[2] = {e->qd[RV_NLIMB], e->qd[RV_NLIMB + 1]}, lam_m[2] = {R(0.0), R(0.0)};
+  real lam_c[RV_MAXB][6]; memset(lam_c, 0, sizeof(lam_c));
   for (int it = -1; it < c->solver_iters; ++it) {
     real res = R(0.0);
     for (int b = 0; b < RV_MAXB; ++b) {
@@ -1026,7 +1070,8 @@ static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4]
         }
       }
     if (it < 0) continue;
-    for (int f = 0; f < 2; ++f) {
+    for (int b = 0; b < RV_MAXB; ++b) if (use[TIDX(b)] && e->bp[b].con_on) res = rmax(res, constraint_solve(w, e, b, lam_c[b]));
+    for (int f = 0; fd && f < 2; ++f) {
       const real i0 = mf * e->fing_dv[f];
       real dl = (e->fing_vt[f] - qf[f]) * mf;
       const real ln = rclamp(lam_m[f] + dl, -fdt - i0, fdt - i0);
@@ -1036,7 +1081,7 @@ static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4]
     }
     if (res < (real)c->solver_tol) break;
   }
-  for (int f = 0; f < 2; ++f) {
+  for (int f = 0; fd && f < 2; ++f) {
     const int j = RV_NLIMB + f;
     real qd = qf[f];
     real qn = e->q[j] + (qd - e->fing_qd0[f]) * (real)c->dt;
@@ -1258,6 +1303,12 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
         if (!big[label[BB_A[k]]]) for (int k3 = 0; k3 < 3; ++k3) { orc_rowid y = {mi, i, k3, BB_A[k], BB_B[k], label[BB_A[k]]}; id[n_rows++] = y; }
       }
     }
+  {
+    /* an awake body with a user constraint: everything goes through the velocity-space system solver */
+    int any_con = 0;
+    for (int b = 0; b < RV_MAXB; ++b) any_con |= use[TIDX(b)] && e->bp[b].con_on;
+    if (any_con) { solve_with_fingers(w, e, rows, use); return; }
+  }
   if (c->finger_dynamics && e->arm_enabled) {
     /* at most one awake body (a grasp scene): impulse space, fingers included; else the
      * velocity-space system solver */
@@ -1968,7 +2019,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   if (c->env_type == RV_ENV_GRASP) {
     /* Grasp4DofEnv._reset_scene (grasp_4dof_env.py:166-198) */
     real poses[RV_MAXB][7];
-    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].deact_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; }
+    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].deact_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; e->bp[b].con_on = 0; }
     e->n_bodies = 1;
     sample_poses(w, e, &g, 1, poses);
     int shape = c->movable_shapes[rng_randint(&g, c->n_movable_shapes)];
@@ -1983,7 +2034,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
   } else
   for (;;) {
     real poses[RV_MAXB][7];
-    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].deact_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; }
+    for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].deact_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; e->bp[b].con_on = 0; }
     for (int i = 0; i < RV_NMAN; ++i) e->man[i].n = 0;
     sample_poses(w, e, &g, nb, poses);
     for (int i = 0; i < nb; ++i) {
@@ -2340,6 +2391,21 @@ void orc_set_friction(orc_world* w, double mu_finger, double mu_table) {
 /* move_to_gripper_pose(..., timeout=t): LinkTarget.set stop_time = start_time + timeout */
 void orc_set_link_timeout(orc_world* w, double timeout) {
   for (int i = 0; i < w->n; ++i) w->env[i].lt.stop_t = w->env[i].lt.start_t + (real)timeout;
+}
+/* Simulator.add_constraint / Constraint.pose setter (bullet_physics.py:748-957) for body `body` of every env:
+ * frame7 = joint frame in the body frame (NULL: identity), target7 = the world frame it is tied to,
+ * max_force < 0: the constraint is removed */
+void orc_set_constraint(orc_world* w, int body, const double* frame7, const double* target7, double max_force) {
+  for (int i = 0; i < w->n; ++i) {
+    orc_bparam* P = &w->env[i].bp[body];
+    if (max_force < 0.0) P->con_on = 0;
+    else {
+      P->con_on = 1; P->con_fmax = (real)max_force;
+      for (int k = 0; k < 3; ++k) { P->con_lpos[k] = frame7 ? (real)frame7[k] : R(0.0); P->con_tpos[k] = (real)target7[k]; }
+      for (int k = 0; k < 4; ++k) { P->con_lquat[k] = frame7 ? (real)frame7[3 + k] : (k == 3 ? R(1.0) : R(0.0)); P->con_tquat[k] = (real)target7[3 + k]; }
+    }
+    P->asleep = 0; P->sleep_count = 0; P->deact_count = 0; P->still_count = 0; P->undisturbed = 0;
+  }
 }
 void orc_grip(orc_world* w, float value) { for (int i = 0; i < w->n; ++i) robot_grip(w, &w->env[i], (real)value); }
 int orc_is_limb_ready(orc_world* w, int env) { return arm_is_ready_limb(w, &w->env[env]); }

@@ -100,6 +100,10 @@ struct DevEnv {
   int undisturbed[RV_MAXB];   // woken, but has not left the pose window it was sleeping in
   float baabb[RV_MAXB][6];   // world box (lo, hi) of the hulls + margin, taken when the body fell asleep
   float scale[RV_MAXB], mass[RV_MAXB], inv_mass[RV_MAXB], inv_inertia[RV_MAXB][3], friction[RV_MAXB], radius[RV_MAXB];
+  // user constraint (Simulator.add_constraint, simulator.py:166-224; bullet_physics.py:748-957): a fixed
+  // joint between the frame (con_lpos, con_lquat) of the body and a frame of the world (con_tpos,
+  // con_tquat), which can apply at most con_fmax N per row
+  int con_on[RV_MAXB]; float con_lpos[RV_MAXB][3], con_lquat[RV_MAXB][4], con_tpos[RV_MAXB][3], con_tquat[RV_MAXB][4], con_fmax[RV_MAXB];
   float table_z;
   int n_bodies;
   int arm_enabled;
@@ -1079,10 +1083,51 @@ RV_DEV float point_solve_g(BV& A, float ima, Lam& l, const Row& r, float* qf, fl
   if (fi >= 0) qf[fi] += r.jf[2] * dl * imf;
   return res;
 }
+// The six rows of a user constraint on body b (a fixed joint to a frame of the world: the mocap-style
+// constraint ControllableConstraint servoes, controllable_constraint.py:21-170): three linear rows at the
+// pivot, three angular rows, Baumgarte-stabilised with rv_config.erp, accumulated impulse within
+// +- con_fmax dt per row (pybullet changeConstraint maxForce).  lam[6]: accumulated impulses.
+RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
+  DevEnv& e = S.e; const rv_config* c = K.cfg;
+  const float dt = c->dt, lim = e.con_fmax[b] * dt, ima = e.inv_mass[b];
+  const m3 rot = qmat(ldq(e.body[b] + 3));
+  const v3 r = mulv(rot, ld3(e.con_lpos[b])), wp = add(ld3(e.body[b]), r);
+  const q4 qw = qmul(ldq(e.body[b] + 3), ldq(e.con_lquat[b]));
+  q4 qc; qc.x = -qw.x; qc.y = -qw.y; qc.z = -qw.z; qc.w = qw.w;
+  const q4 qe = qmul(ldq(e.con_tquat[b]), qc);
+  const float sg = qe.w < 0.0f ? -2.0f : 2.0f;
+  const float th[3] = {qe.x * sg, qe.y * sg, qe.z * sg};
+  const float tp[3] = {e.con_tpos[b][0], e.con_tpos[b][1], e.con_tpos[b][2]}, wpa[3] = {wp.x, wp.y, wp.z};
+  float res = 0.0f;
+  for (int k = 0; k < 6; ++k) {
+    v3 jl = mk(0, 0, 0), ja = mk(0, 0, 0); float bias;
+    if (k < 3) {
+      const v3 ek = mk(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f);
+      jl = ek; ja = cross(r, ek);
+      bias = c->erp * (tp[k] - wpa[k]) / dt;
+    } else {
+      ja = mk(k == 3 ? 1.0f : 0.0f, k == 4 ? 1.0f : 0.0f, k == 5 ? 1.0f : 0.0f);
+      bias = c->erp * th[k - 3] / dt;
+    }
+    const v3 ia = mulv(ldm(S.s.iinv[b]), ja);
+    const float kk = (k < 3 ? ima : 0.0f) + dot(ja, ia);
+    const float jv = dot(jl, ld3(e.body[b] + 7)) + dot(ja, ld3(e.body[b] + 10));
+    float dl = (bias - jv) / kk;
+    const float ln = fclampr(lam[k] + dl, -lim, lim);
+    dl = ln - lam[k]; lam[k] = ln;
+    res = fmaxr(res, fabsr(dl));
+    st3(e.body[b] + 7, madd(ld3(e.body[b] + 7), jl, dl * ima));
+    st3(e.body[b] + 10, madd(ld3(e.body[b] + 10), ia, dl));
+  }
+  return res;
+}
 RV_DEV void solve_with_fingers(Shared& S, const Consts& K) {
   DevEnv& e = S.e; const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
+  const int fd = c->finger_dynamics && e.arm_enabled;            // the finger joints are DOFs of the system
   const float mf = c->finger_mass, imf = 1.0f / c->finger_mass, fdt = c->finger_max_force * c->dt;
   float qf[2] = {e.qd[RV_NLIMB], e.qd[RV_NLIMB + 1]}, lam_m[2] = {0.0f, 0.0f};
+  float lam_c[RV_MAXB][6];
+  for (int b = 0; b < RV_MAXB; ++b) for (int k = 0; k < 6; ++k) lam_c[b][k] = 0.0f;
   for (int it = -1; it < c->solver_iters; ++it) {   // it == -1: warm start
     float res = 0.0f;
     for (int b = 0; b < RV_MAXB; ++b) {
@@ -1120,7 +1165,8 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K) {
         st_bv(e, a_, A); st_bv(e, b_, B);
       }
     if (it < 0) continue;
-    for (int f = 0; f < 2; ++f) {      // motor rows
+    for (int b = 0; b < RV_MAXB; ++b) if (body_on(e, b) && e.con_on[b]) res = fmaxr(res, constraint_solve(S, K, b, lam_c[b]));
+    for (int f = 0; fd && f < 2; ++f) {      // motor rows
       const float i0 = mf * S.s.fing_dv[f];
       float dl = (S.s.fing_vt[f] - qf[f]) * mf;
       const float ln = fclampr(lam_m[f] + dl, -fdt - i0, fdt - i0);
@@ -1130,7 +1176,7 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K) {
     }
     if (res < c->solver_tol) break;
   }
-  for (int f = 0; f < 2; ++f) {        // the fingers move with the solved velocity
+  for (int f = 0; fd && f < 2; ++f) {        // the fingers move with the solved velocity
     const int j = RV_NLIMB + f;
     float qd = qf[f];
     float qn = e.q[j] + (qd - S.s.fing_qd0[f]) * c->dt;
@@ -3082,8 +3128,12 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   int n_on = 0, the_body = -1;
 #pragma unroll
   for (int b = RV_MAXB - 1; b >= 0; --b) if (on_[b]) { ++n_on; the_body = b; }
-  const int fing_fast = with_fingers && n_on <= 1;
-  if (with_fingers && !fing_fast) {
+  // an awake body with a user constraint: everything goes through the velocity-space system solver
+  int any_con = 0;
+#pragma unroll
+  for (int b = 0; b < RV_MAXB; ++b) any_con |= on_[b] && S.e.con_on[b];
+  const int fing_fast = with_fingers && n_on <= 1 && !any_con;
+  if ((with_fingers && !fing_fast) || any_con) {
     RV_LANES_BEGIN
       if (lane == 0) solve_with_fingers(S, K);
     RV_LANES_END
@@ -3111,14 +3161,14 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       int m_ = 0, y_ = -1, kxy = 0;
 #pragma unroll
       for (int x = 0; x < RV_MAXB; ++x) if (x == b) { m_ = mem_[x]; y_ = isl_y[x]; kxy = isl_k[x]; }
-      m_ = with_fingers ? 0 : __builtin_amdgcn_readfirstlane(m_);
+      m_ = (with_fingers || any_con) ? 0 : __builtin_amdgcn_readfirstlane(m_);
       if (m_ == 1 || m_ == 2)
         solve_island2(S, K, b, __builtin_amdgcn_readfirstlane(y_), __builtin_amdgcn_readfirstlane(kxy));
     }
   }
 #else
   RV_LANES_BEGIN
-    if (lane == 0) S.s.n_rows = (with_fingers && !fing_fast) ? 0 : solver_row_list(S, label, on_, act_, big_);
+    if (lane == 0) S.s.n_rows = ((with_fingers && !fing_fast) || any_con) ? 0 : solver_row_list(S, label, on_, act_, big_);
   RV_LANES_END
   if (fing_fast) solve_rows(S, K, S.s.n_rows < 0 ? 0 : S.s.n_rows, 1);
   else if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows, 0);
@@ -3131,7 +3181,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
 #pragma unroll
   for (int b = RV_MAXB - 1; b >= 0; --b) if (big_[b]) big_root = b;
   RV_PROF(24)
-  if (!with_fingers && big_root >= 0) {
+  if (!with_fingers && !any_con && big_root >= 0) {
     const int root = big_root;
     for (int it = -1; it < c->solver_iters; ++it) {   // it == -1: warm start
       RV_LANES_BEGIN
@@ -4094,7 +4144,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
       DevEnv& e = S.e;
       if (lane == 0) {
         Rng& g = S.s.rng;
-        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; }
+        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; e.con_on[b] = 0; }
         e.n_bodies = 1;
         sample_poses(S, K, 1);
         int shape = c->movable_shapes[rng_randint(g, c->n_movable_shapes)];
@@ -4115,7 +4165,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
     RV_LANES_BEGIN
       DevEnv& e = S.e;
       if (lane == 0) {
-        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; }
+        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; e.con_on[b] = 0; }
         sample_poses(S, K, e.n_bodies);
       }
       if (lane >= 1 && lane <= RV_NMAN) e.man[lane - 1].n = 0;

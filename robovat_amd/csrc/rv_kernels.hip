@@ -245,6 +245,19 @@ __global__ void k_set_motor_targets(DevEnv* envs, int n, const float* q, const u
     e.motor_on[j] = 1; e.motor_q[j] = q[(size_t)i * RV_NJ + j]; e.motor_kp[j] = cfg->kp; e.motor_kd[j] = cfg->kd;
   }
 }
+struct ConArgs { int body; float lp[3], lq[4], tp[3], tq[4], fmax; };
+__global__ void k_set_constraint(DevEnv* envs, int n, ConArgs a) {
+  ENV_THREAD();
+  const int b = a.body;
+  // (a body that went to sleep hanging from its constraint must notice that it changed or is gone)
+  if (a.fmax < 0.0f) e.con_on[b] = 0;
+  else {
+    e.con_on[b] = 1; e.con_fmax[b] = a.fmax;
+    for (int k = 0; k < 3; ++k) { e.con_lpos[b][k] = a.lp[k]; e.con_tpos[b][k] = a.tp[k]; }
+    for (int k = 0; k < 4; ++k) { e.con_lquat[b][k] = a.lq[k]; e.con_tquat[b][k] = a.tq[k]; }
+  }
+  e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0;
+}
 __global__ void k_grip(DevEnv* envs, int n, float value, const rv_config* cfg, const rv_scene* scene) {
   ENV_THREAD();
   grip_env(e, &scene->arm, cfg, value);
@@ -801,6 +814,20 @@ int rv_set_gravity(rv_world* w, const float* g) {
   w->cfg.gravity_xy[0] = g[0]; w->cfg.gravity_xy[1] = g[1]; w->cfg.gravity_z = g[2];
   HIPCHK(hipMemcpyAsync(w->d_cfg, &w->cfg, sizeof(rv_config), hipMemcpyHostToDevice, w->stream));
   HIPCHK(hipStreamSynchronize(w->stream));
+  return RV_OK;
+}
+int rv_set_constraint(rv_world* w, int32_t body, const float* frame7, const float* target7, float max_force) {
+  WCHK(w);
+  if (body < 0 || body >= RV_MAXB) return fail(RV_ERR_VALUE, "rv_set_constraint: not a movable body slot");
+  if (max_force >= 0.0f && !target7) return fail(RV_ERR_VALUE, "rv_set_constraint: null target");
+  ConArgs a; memset(&a, 0, sizeof(a));
+  a.body = body; a.fmax = max_force; a.lq[3] = 1.0f; a.tq[3] = 1.0f;
+  if (max_force >= 0.0f) {
+    if (frame7) { for (int k = 0; k < 3; ++k) a.lp[k] = frame7[k]; for (int k = 0; k < 4; ++k) a.lq[k] = frame7[3 + k]; }
+    for (int k = 0; k < 3; ++k) a.tp[k] = target7[k];
+    for (int k = 0; k < 4; ++k) a.tq[k] = target7[3 + k];
+  }
+  SIMPLE_LAUNCH(k_set_constraint, w->d_envs, w->n, a);
   return RV_OK;
 }
 int rv_grip(rv_world* w, float value) { WCHK(w); SIMPLE_LAUNCH(k_grip, w->d_envs, w->n, value, w->d_cfg, w->d_scene); return RV_OK; }

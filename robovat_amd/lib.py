@@ -30,7 +30,7 @@ SYMBOLS = [
     'rv_compute_ik', 'rv_query_contacts', 'rv_get_manifold_counts', 'rv_observe',
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
-    'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll',
+    'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll', 'rv_set_constraint',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -120,6 +120,7 @@ def load():
     lib.rv_set_motor_targets.argtypes = [vp, vp, vp]
     lib.rv_grip.argtypes = [vp, f32]
     lib.rv_set_gravity.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.rv_set_constraint.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), f32]
     lib.rv_get_state_ptrs.argtypes = [vp, C.POINTER(abi.rv_state_view)]
     lib.rv_set_joint_targets.argtypes = [vp, vp, f32, f32]
     lib.rv_set_link_target.argtypes = [vp, vp, f32, f32]
@@ -365,6 +366,16 @@ class World(object):
 
     def grip(self, value):
         check(self.lib.rv_grip(self.h, float(value)))
+
+    def set_constraint(self, body, target7, frame7=None, max_force=500.0):
+        """rv_set_constraint: tie frame7 (in the body frame; None = the body frame) of movable body
+        ``body`` to the world frame target7 with at most max_force N per row; max_force < 0 removes it."""
+        t = (C.c_float * 7)(*[float(x) for x in (target7 if target7 is not None else [0, 0, 0, 0, 0, 0, 1])])
+        f = None if frame7 is None else (C.c_float * 7)(*[float(x) for x in frame7])
+        check(self.lib.rv_set_constraint(self.h, int(body), f, t, float(max_force)))
+
+    def remove_constraint(self, body):
+        check(self.lib.rv_set_constraint(self.h, int(body), None, None, -1.0))
 
     def set_gravity(self, gravity):
         g = (C.c_float * 3)(float(gravity[0]), float(gravity[1]), float(gravity[2]))

@@ -37,6 +37,7 @@ class HipPhysics(Physics):
         self._world = None
         self._gravity = None
         self._static = {}
+        self._constraints = {}
         self.scene, self.shape_names = scenes.make_scene()
         self._num_steps = None
 
@@ -57,6 +58,7 @@ class HipPhysics(Physics):
         self._world = lib.World(cfg, self.scene, device=self._device)
         self._num_steps = None
         self._static = {}
+        self._constraints = {}
 
     def start(self):
         self._num_steps = 0
@@ -310,5 +312,68 @@ class HipPhysics(Physics):
         return [0.0] if hit else []
 
     # ---- not on the PushEnv / grasp paths ("implement last / stub")
-    def add_constraint(self, *args, **kwargs):
-        raise NotImplementedError('user constraints are a next-row item (SURVEY.md §8f rank 4)')
+    # ---- user constraints (bullet_physics.py:748-957: createConstraint / changeConstraint / removeConstraint)
+    def add_constraint(self, parent_uid, child_uid, joint_type='fixed', joint_axis=[0, 0, 0],
+                       parent_frame_pose=None, child_frame_pose=None):
+        """A FIXED joint between a frame of a movable body (the parent) and a frame of the world (child
+        None): the constraint ControllableConstraint servoes.  Returns the constraint uid."""
+        if joint_type != 'fixed':
+            raise NotImplementedError("only joint_type='fixed' is built (pose-servo constraints)")
+        if child_uid is not None:
+            raise NotImplementedError('the child of a constraint is the world (child=None)')
+        b = self._slot(parent_uid)
+        if b in self._constraints:
+            raise ValueError('body %d already has a constraint' % b)
+        frame = Pose(parent_frame_pose if parent_frame_pose is not None else [[0, 0, 0], [0, 0, 0]])
+        if child_frame_pose is None:        # where the joint frame of the body is now
+            child_frame_pose = self.get_body_pose(b).transform(frame)
+        child = Pose(child_frame_pose)
+        self._constraints[b] = {'frame': frame, 'pose': child, 'max_force': 500.0}     # pybullet's default maxForce
+        self._push_constraint(b)
+        return b
+
+    def _push_constraint(self, b):
+        c = self._constraints[b]
+        f = np.concatenate([np.asarray(c['frame'].position, np.float64), np.asarray(c['frame'].quaternion, np.float64)])
+        t = np.concatenate([np.asarray(c['pose'].position, np.float64), np.asarray(c['pose'].quaternion, np.float64)])
+        self._world.set_constraint(b, t, frame7=f, max_force=c['max_force'])
+
+    def _con(self, uid):
+        if uid not in self._constraints:
+            raise ValueError('no such constraint: %r' % (uid,))
+        return self._constraints[uid]
+
+    def remove_constraint(self, constraint_uid):
+        self._con(constraint_uid)
+        self._world.remove_constraint(constraint_uid)
+        del self._constraints[constraint_uid]
+
+    def get_constraint_pose(self, constraint_uid):
+        return self._con(constraint_uid)['pose']
+
+    def get_constraint_position(self, constraint_uid):
+        return self._con(constraint_uid)['pose'].position
+
+    def get_constraint_orientation(self, constraint_uid):
+        return self._con(constraint_uid)['pose'].orientation
+
+    def get_constraint_max_force(self, constraint_uid):
+        return self._con(constraint_uid)['max_force']
+
+    def set_constraint_pose(self, constraint_uid, pose):
+        self._con(constraint_uid)['pose'] = Pose(pose)
+        self._push_constraint(constraint_uid)
+
+    def set_constraint_position(self, constraint_uid, position):
+        c = self._con(constraint_uid)
+        c['pose'] = Pose([position, c['pose'].orientation])
+        self._push_constraint(constraint_uid)
+
+    def set_constraint_orientation(self, constraint_uid, orientation):
+        c = self._con(constraint_uid)
+        c['pose'] = Pose([c['pose'].position, orientation])
+        self._push_constraint(constraint_uid)
+
+    def set_constraint_max_force(self, constraint_uid, max_force):
+        self._con(constraint_uid)['max_force'] = float(max_force)
+        self._push_constraint(constraint_uid)

@@ -8,6 +8,7 @@ import numpy as np
 
 from robovat_amd.math import Pose
 from robovat_amd.simulation import physics
+from robovat_amd.simulation.constraint import Constraint, ControllableConstraint
 
 
 class Body(object):
@@ -103,6 +104,8 @@ class Simulator(object):
     def step(self):
         for body in self.bodies.values():
             body.update()
+        for constraint in self.constraints.values():       # simulator.py:94-103
+            constraint.update()
         self.physics.step()
         self._num_steps += 1
 
@@ -117,6 +120,25 @@ class Simulator(object):
     def remove_body(self, name):
         self.physics.remove_body(self._bodies[name].uid)
         del self._bodies[name]
+
+    def add_constraint(self, parent, child=None, joint_type='fixed', joint_axis=[0, 0, 0], parent_frame_pose=None,
+                       child_frame_pose=None, max_force=None, max_linear_velocity=None, max_angular_velocity=None,
+                       is_controllable=False, name=None):
+        """simulator.py:166-224."""
+        if is_controllable:
+            constraint = ControllableConstraint(parent, child, joint_type, joint_axis, parent_frame_pose, child_frame_pose,
+                                                max_force=max_force, max_linear_velocity=max_linear_velocity,
+                                                max_angular_velocity=max_angular_velocity, name=name)
+        else:
+            assert max_linear_velocity is None and max_angular_velocity is None
+            constraint = Constraint(parent, child, joint_type, joint_axis, parent_frame_pose, child_frame_pose,
+                                    max_force=max_force, name=name)
+        self._constraints[constraint.name] = constraint
+        return constraint
+
+    def remove_constraint(self, name):
+        self.physics.remove_constraint(self._constraints[name].uid)
+        del self._constraints[name]
 
     def receive_robot_commands(self, robot_command, component_type='body'):
         if component_type != 'body':

@@ -1,0 +1,111 @@
+"""User constraints (Simulator.add_constraint, simulator.py:166-224; ControllableConstraint,
+controllable_constraint.py:21-170): a fixed joint between a movable body and a frame of the world,
+limited to max_force.  Known answers on the oracle and on the HIP library, HIP == oracle, and the
+reference-shaped object API on the GPU."""
+import numpy as np
+import pytest
+
+from robovat_amd import abi, configs, scenes
+
+import test_kat_contact as T
+
+BACKENDS = ['oracle64', 'oracle32', pytest.param('hip', marks=pytest.mark.gpu)]
+Q0 = (0, 0, 0, 1)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_constraint_holds_a_body_against_gravity_within_its_force_limit(backend):
+    """0.2 kg box held 10 cm above the table: with 50 N per row it hangs at the target; with 1 N
+    (less than its weight, 1.96 N) it sinks to the table; removing the constraint drops it."""
+    w, cfg = T._world(backend)
+    T._bodies(w, [(0, 0.2, 0.5, (0.6, 0.0, 0.131), Q0, (0, 0, 0))])
+    w.set_constraint(0, [0.6, 0.0, 0.131, 0, 0, 0, 1], max_force=50.0)
+    w.step_sub(800)
+    st = w.body_state()[0, 0]
+    assert np.abs(st[:3] - [0.6, 0.0, 0.131]).max() < 1.5e-4 and np.abs(st[7:13]).max() < 1e-3, st[:3]
+    # move the world frame: the body follows (stiffness erp / dt: 1 mm per substep at most here)
+    w.set_constraint(0, [0.65, 0.02, 0.16, 0, 0, np.sin(0.3), np.cos(0.3)], max_force=50.0)
+    w.step_sub(1500)
+    st = w.body_state()[0, 0]
+    assert np.abs(st[:3] - [0.65, 0.02, 0.16]).max() < 3e-4
+    assert min(np.abs(st[3:7] - [0, 0, np.sin(0.3), np.cos(0.3)]).max(), np.abs(st[3:7] + [0, 0, np.sin(0.3), np.cos(0.3)]).max()) < 2e-3
+    # too weak to carry the weight: the body comes down onto the table
+    w.set_constraint(0, [0.65, 0.02, 0.16, 0, 0, np.sin(0.3), np.cos(0.3)], max_force=1.0)
+    w.step_sub(1500)
+    assert w.body_state()[0, 0, 2] < 0.04
+    w.remove_constraint(0)
+    w.step_sub(300)
+    assert abs(w.body_state()[0, 0, 2] - 0.031) < 2e-3
+    if hasattr(w, 'w'):
+        w.close()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_constraint_with_an_offset_frame_and_contacts(backend):
+    """The joint frame sits on top of the box; the constraint presses the box onto the table next to
+    a second, free box -- contacts and constraint rows in one system."""
+    w, cfg = T._world(backend)
+    T._bodies(w, [(0, 0.2, 0.5, (0.6, 0.0, 0.031), Q0, (0, 0, 0)), (0, 0.3, 0.5, (0.6, 0.2, 0.031), Q0, (0, 0, 0))])
+    w.set_constraint(0, [0.62, 0.01, 0.061, 0, 0, 0, 1], frame7=[0, 0, 0.03, 0, 0, 0, 1], max_force=20.0)
+    w.step_sub(1000)
+    st = w.body_state()[0]
+    assert np.abs(st[0, :2] - [0.62, 0.01]).max() < 5e-4 and abs(st[0, 2] - 0.031) < 1e-3      # dragged along the table
+    assert np.abs(st[1, :3] - [0.6, 0.2, 0.031]).max() < 1e-3                                  # the other box is untouched
+    if hasattr(w, 'w'):
+        w.close()
+
+
+@pytest.mark.gpu
+def test_hip_equals_oracle_with_constraints():
+    from robovat_amd import lib
+    from oracle import orc
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(n_envs=6, seed=8, shape_names=names)
+    w, ref = lib.World(cfg, scene, device=0), orc.OracleWorld(cfg, scene, double=False)
+    w.reset(); ref.reset()
+    st = ref.body_state()[0]
+    tgt = [float(st[1, 0]) + 0.03, float(st[1, 1]) - 0.02, float(st[1, 2]) + 0.05, 0, 0, np.sin(0.2), np.cos(0.2)]
+    for x in (w, ref):
+        x.set_constraint(1, tgt, frame7=[0.01, 0, 0.0, 0, 0, 0, 1], max_force=30.0)
+    w.step_sub(400); ref.step_sub(400)
+    assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
+    a = ref.policy_random(0)
+    w.set_actions(a); ref.set_actions(a); w.step_macro(); ref.step_macro()      # a push with the constraint in place
+    assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
+    for x in (w, ref):
+        x.remove_constraint(1)
+    w.step_sub(300); ref.step_sub(300)
+    assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
+    w.close()
+
+
+@pytest.mark.gpu
+def test_simulator_add_constraint_and_pose_servo():
+    """The reference-shaped API: Simulator.add_constraint(is_controllable=True) + set_target_pose; the
+    servo moves the world frame by max_linear_velocity * dt per Simulator.step()."""
+    from robovat_amd.simulation import Simulator
+    sim = Simulator(physics_backend='HipPhysics')
+    sim.reset()
+    sim.start()
+    body = sim.add_body('box', pose=[[0.6, 0.0, 0.1], [0, 0, 0]], name='box')
+    con = sim.add_constraint(body, None, joint_type='fixed', max_force=40.0, max_linear_velocity=0.1,
+                             max_angular_velocity=1.0, is_controllable=True, name='mocap')
+    assert 'mocap' in sim.constraints and con.max_force == 40.0 and con.is_ready()
+    p0 = np.asarray(body.position).copy()
+    for _ in range(200):
+        sim.step()
+    assert np.abs(np.asarray(body.position) - p0).max() < 5e-4            # held where it was created
+    con.set_target_pose([[p0[0] + 0.03, p0[1], p0[2] + 0.02], [0, 0, 0]], timeout=2.0)
+    assert not con.is_ready()
+    for _ in range(600):
+        sim.step()
+    assert con.is_ready()                                                 # reached (checked every 100 steps)
+    # (the servo stops within POSITION_THRESHOLD = 1 cm of the target, controllable_constraint.py:16,135-156)
+    assert np.abs(np.asarray(body.position) - [p0[0] + 0.03, p0[1], p0[2] + 0.02]).max() < 0.0105
+    assert np.abs(np.asarray(body.position) - p0).max() > 0.015
+    with pytest.raises(NotImplementedError):
+        sim.add_constraint(body, body, joint_type='fixed')
+    sim.remove_constraint('mocap')
+    for _ in range(400):
+        sim.step()
+    assert body.position[2] < p0[2] - 0.03                                # free again: it falls
