@@ -436,6 +436,11 @@ int  rv_rollout_record_full(rv_world* w, int32_t n_steps, int32_t first_macro_in
  *      nothing is hit) and segmentation (body index, RV_MAXB = table, 255 = nothing).
  *      The arm is not rendered.  Either pointer may be NULL. */
 int  rv_render(rv_world* w, float* d_depth /* [N][cam_height][cam_width] */, uint8_t* d_segmask /* same shape */);
+/* CameraObs 'rgb' (camera_obs.py:33-88; bullet_camera.py:188-235): the same ray cast, flat colours
+ * per body slot / table / background, Lambert-shaded with the normal of the face that is hit under
+ * one fixed directional light (BUILD-CHOSEN colours: the reference draws random rgba per body,
+ * push_env.py:436).  The arm is not rendered. */
+int  rv_render_rgb(rv_world* w, uint8_t* d_rgb /* [N][cam_height][cam_width][3] */);
 
 /* ---- PushReward.get_reward (push_reward.py:377-405, 272-374) of the last
  *      macro step, and RobotEnv done flag (robot_env.py:257-259). ---- */

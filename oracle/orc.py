@@ -46,7 +46,7 @@ def _lib(double):
                      'orc_get_episode_returns', 'orc_get_stats', 'orc_eval_reward',
                      'orc_eval_waypoints', 'orc_set_external_control', 'orc_motor_targets',
                      'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout', 'orc_set_pose_f32',
-                     'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction', 'orc_set_constraint'):
+                     'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction', 'orc_set_constraint', 'orc_render_rgb'):
             getattr(lib, name).restype = None
         lib.orc_is_limb_ready.restype = C.c_int
         lib.orc_is_gripper_ready.restype = C.c_int
@@ -244,6 +244,12 @@ class OracleWorld(object):
         depth = np.zeros((h, w), dtype=np.float32); seg = np.zeros((h, w), dtype=np.uint8)
         self.lib.orc_render(self.h, C.c_int(env), _p(depth), _p(seg))
         return depth, seg
+
+    def render_rgb(self, env=0):
+        h, w = int(self.cfg.cam_height), int(self.cfg.cam_width)
+        rgb = np.zeros((h, w, 3), dtype=np.uint8)
+        self.lib.orc_render_rgb(self.h, C.c_int(env), _p(rgb))
+        return rgb
 
     def point_cloud(self):
         out = np.zeros((self.n, abi.RV_MAXB, int(self.cfg.num_points), 3), dtype=np.float32)

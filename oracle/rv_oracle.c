@@ -2480,41 +2480,44 @@ static void pc_cam_position(const rv_config* c, real* o) {
   pc_cam_rot(c, Rm); m3tmulv(p, Rm, t);
   o[0] = -p[0]; o[1] = -p[1]; o[2] = -p[2];
 }
-static int pc_ray_hull(const float (*planes)[4], int n, real sc, real margin, const real* o, const real* d, real* t_hit) {
-  real t0 = R(0.0), t1 = R(1e30);
+static int pc_ray_hull(const float (*planes)[4], int n, real sc, real margin, const real* o, const real* d, real* t_hit, int* plane_hit) {
+  real t0 = R(0.0), t1 = R(1e30); int ip = -1;
   for (int i = 0; i < n; ++i) {
     real nn[3] = {(real)planes[i][0], (real)planes[i][1], (real)planes[i][2]};
     real off = (real)planes[i][3] * sc + margin;
     real den = v3dot(nn, d);
     real num = off - v3dot(nn, o);
-    if (den < R(0.0)) { real t = num / den; if (t > t0) t0 = t; }
+    if (den < R(0.0)) { real t = num / den; if (t > t0) { t0 = t; ip = i; } }
     else if (den > R(0.0)) { real t = num / den; if (t < t1) t1 = t; }
     else if (num < R(0.0)) return 0;
   }
   if (t0 > t1) return 0;
   *t_hit = t0;
+  if (plane_hit) *plane_hit = ip;
   return 1;
 }
-static int pc_ray_table(const rv_config* c, real table_z, const real* o, const real* d, real* t_hit) {
+static int pc_ray_table(const rv_config* c, real table_z, const real* o, const real* d, real* t_hit, int* axis_hit) {
   const real lo[3] = {(real)c->table_center[0] - (real)c->table_half[0], (real)c->table_center[1] - (real)c->table_half[1], table_z - (real)c->table_thickness};
   const real hi[3] = {(real)c->table_center[0] + (real)c->table_half[0], (real)c->table_center[1] + (real)c->table_half[1], table_z};
-  real t0 = R(0.0), t1 = R(1e30);
+  real t0 = R(0.0), t1 = R(1e30); int ax = -1;
   for (int k = 0; k < 3; ++k) {
     if (d[k] != R(0.0)) {
       real a = (lo[k] - o[k]) / d[k], b = (hi[k] - o[k]) / d[k];
       real tn = a < b ? a : b, tf = a < b ? b : a;
-      if (tn > t0) t0 = tn;
+      if (tn > t0) { t0 = tn; ax = a < b ? k : 3 + k; }
       if (tf < t1) t1 = tf;
     } else if (o[k] < lo[k] || o[k] > hi[k]) return 0;
   }
   if (t0 > t1) return 0;
   *t_hit = t0;
+  if (axis_hit) *axis_hit = ax;
   return 1;
 }
 /* nearest hit of a pixel ray: body index, RV_MAXB = table, -1 = nothing */
-static int pc_render_pixel(const orc_world* w, const orc_env* e, real rot[][9], const real* cam_o, const real* dw, real* depth) {
+static int pc_render_pixel_n(const orc_world* w, const orc_env* e, real rot[][9], const real* cam_o, const real* dw, real* depth, real* normal) {
   const rv_config* c = &w->cfg;
   real best = R(1e30); int who = -1;
+  real nb[3] = {R(0.0), R(0.0), R(0.0)};
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!e->bp[b].active) continue;
     const rv_shape* sh = &w->scene.shapes[e->bp[b].shape];
@@ -2526,14 +2529,24 @@ static int pc_render_pixel(const orc_world* w, const orc_env* e, real rot[][9], 
     real ol[3], dl[3];
     m3tmulv(ol, rot[b], rel); m3tmulv(dl, rot[b], dw);
     for (int h = 0; h < sh->n_hulls; ++h) {
-      real t;
-      if (pc_ray_hull(sh->planes[h], sh->n_planes[h], e->bp[b].scale, (real)c->margin, ol, dl, &t) && t < best) { best = t; who = b; }
+      real t; int ip = -1;
+      if (pc_ray_hull(sh->planes[h], sh->n_planes[h], e->bp[b].scale, (real)c->margin, ol, dl, &t, &ip) && t < best) {
+        best = t; who = b;
+        if (normal && ip >= 0) { real pn[3] = {(real)sh->planes[h][ip][0], (real)sh->planes[h][ip][1], (real)sh->planes[h][ip][2]}; m3mulv(nb, rot[b], pn); }
+      }
     }
   }
-  real tt;
-  if (pc_ray_table(c, e->table_z, cam_o, dw, &tt) && tt < best) { best = tt; who = RV_MAXB; }
+  real tt; int ax = -1;
+  if (pc_ray_table(c, e->table_z, cam_o, dw, &tt, &ax) && tt < best) {
+    best = tt; who = RV_MAXB;
+    if (normal && ax >= 0) { const real sg = ax < 3 ? R(-1.0) : R(1.0); const int k = ax % 3; nb[0] = k == 0 ? sg : R(0.0); nb[1] = k == 1 ? sg : R(0.0); nb[2] = k == 2 ? sg : R(0.0); }
+  }
   *depth = best;
+  if (normal) { normal[0] = nb[0]; normal[1] = nb[1]; normal[2] = nb[2]; }
   return who;
+}
+static int pc_render_pixel(const orc_world* w, const orc_env* e, real rot[][9], const real* cam_o, const real* dw, real* depth) {
+  return pc_render_pixel_n(w, e, rot, cam_o, dw, depth, (real*)0);
 }
 static void pc_deproject(const rv_config* c, const real* cam_o, real u, real v, real z, real* out) {
   real d[3], pc[3], Rm[9], pw[3];
@@ -2568,6 +2581,28 @@ void orc_render(orc_world* w, int env, float* depth, uint8_t* segmask) {
       if (who >= 0 && !(dep > (real)c->cam_near)) who = -1;
       depth[(size_t)v * c->cam_width + u] = who >= 0 ? (float)dep : 0.0f;
       segmask[(size_t)v * c->cam_width + u] = who >= 0 ? (uint8_t)who : (uint8_t)255;
+    }
+}
+/* CameraObs 'rgb' (camera_obs.py:33-88): flat colours per body slot / table / background,
+ * Lambert-shaded with the normal of the face hit, one fixed directional light; rgb: [H][W][3] */
+void orc_render_rgb(orc_world* w, int env, uint8_t* rgb) {
+  const rv_config* c = &w->cfg; const orc_env* e = &w->env[env];
+  static const real base[RV_MAXB + 2][3] = {{230, 60, 60}, {60, 170, 230}, {250, 200, 40}, {90, 200, 110}, {150, 120, 90}, {30, 30, 30}};
+  real rot[RV_MAXB][9], cam_o[3], Rm[9];
+  pc_body_rots(e, rot); pc_cam_position(c, cam_o); pc_cam_rot(c, Rm);
+  for (int v = 0; v < c->cam_height; ++v)
+    for (int u = 0; u < c->cam_width; ++u) {
+      real dc[3], dw[3], dep, n[3];
+      pc_pixel_dir_cam(c, (real)u, (real)v, dc); m3tmulv(dw, Rm, dc);
+      int who = pc_render_pixel_n(w, e, rot, cam_o, dw, &dep, n);
+      if (who >= 0 && !(dep > (real)c->cam_near)) who = -1;
+      const int idx = who < 0 ? RV_MAXB + 1 : who;
+      real sh = R(1.0);
+      if (who >= 0) {
+        const real lam = n[0] * R(0.30151134) + n[1] * R(-0.30151134) + n[2] * R(0.90453403);
+        sh = R(0.35) + R(0.65) * (lam > R(0.0) ? lam : R(0.0));
+      }
+      for (int k = 0; k < 3; ++k) rgb[((size_t)v * c->cam_width + u) * 3 + k] = (uint8_t)(int)(base[idx][k] * sh + R(0.5));
     }
 }
 static int cmp_u32(const void* a, const void* b) { uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? -1 : (x > y); }

@@ -52,44 +52,48 @@ RV_DEV v3 cam_position(const rv_config* c) {
 
 // entry depth of the ray into one convex hull given by planes n.x <= d*scale + margin, in the
 // body frame; returns 0 on a miss
-RV_DEV int ray_hull(const float (*planes)[4], int n, float sc, float margin, v3 o, v3 d, float* t_hit) {
-  float t0 = 0.0f, t1 = 1e30f;
+RV_DEV int ray_hull(const float (*planes)[4], int n, float sc, float margin, v3 o, v3 d, float* t_hit, int* plane_hit = nullptr) {
+  float t0 = 0.0f, t1 = 1e30f; int ip = -1;
   for (int i = 0; i < n; ++i) {
     v3 nn = mk(planes[i][0], planes[i][1], planes[i][2]);
     float off = planes[i][3] * sc + margin;
     float den = dot(nn, d);
     float num = off - dot(nn, o);
-    if (den < 0.0f) { float t = num / den; if (t > t0) t0 = t; }
+    if (den < 0.0f) { float t = num / den; if (t > t0) { t0 = t; ip = i; } }
     else if (den > 0.0f) { float t = num / den; if (t < t1) t1 = t; }
     else if (num < 0.0f) return 0;
   }
   if (t0 > t1) return 0;
   *t_hit = t0;
+  if (plane_hit) *plane_hit = ip;
   return 1;
 }
-// entry depth into the axis-aligned table slab
-RV_DEV int ray_table(const rv_config* c, float table_z, v3 o, v3 d, float* t_hit) {
+// entry depth into the axis-aligned table slab (axis_hit: 0..2 = the -x/-y/-z face, 3..5 = +x/+y/+z)
+RV_DEV int ray_table(const rv_config* c, float table_z, v3 o, v3 d, float* t_hit, int* axis_hit = nullptr) {
   const float lo[3] = {c->table_center[0] - c->table_half[0], c->table_center[1] - c->table_half[1], table_z - c->table_thickness};
   const float hi[3] = {c->table_center[0] + c->table_half[0], c->table_center[1] + c->table_half[1], table_z};
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-  float t0 = 0.0f, t1 = 1e30f;
+  float t0 = 0.0f, t1 = 1e30f; int ax = -1;
   for (int k = 0; k < 3; ++k) {
     if (dd[k] != 0.0f) {
       float a = (lo[k] - oo[k]) / dd[k], b = (hi[k] - oo[k]) / dd[k];
       float tn = a < b ? a : b, tf = a < b ? b : a;
-      if (tn > t0) t0 = tn;
+      if (tn > t0) { t0 = tn; ax = a < b ? k : 3 + k; }
       if (tf < t1) t1 = tf;
     } else if (oo[k] < lo[k] || oo[k] > hi[k]) return 0;
   }
   if (t0 > t1) return 0;
   *t_hit = t0;
+  if (axis_hit) *axis_hit = ax;
   return 1;
 }
 
 // nearest hit of the pixel ray: body index, RV_MAXB for the table, -1 for nothing
+// normal (optional): outward world normal of the surface that is hit
 RV_DEV int render_pixel(const rv_config* c, const rv_scene* scene, const ObsSnap& s, const float (*rot)[9],
-                        v3 cam_o, v3 dw, float* depth) {
+                        v3 cam_o, v3 dw, float* depth, v3* normal = nullptr) {
   float best = 1e30f; int who = -1;
+  v3 nb = mk(0.0f, 0.0f, 0.0f);
   for (int b = 0; b < RV_MAXB; ++b) {
     if (s.shape[b] < 0) continue;
     const rv_shape* sh = &scene->shapes[s.shape[b]];
@@ -101,16 +105,37 @@ RV_DEV int render_pixel(const rv_config* c, const rv_scene* scene, const ObsSnap
     if (perp2 > r * r) continue;
     v3 ol = tmulv(rot[b], rel), dl = tmulv(rot[b], dw);
     for (int h = 0; h < sh->n_hulls; ++h) {
-      float t;
-      if (ray_hull(sh->planes[h], sh->n_planes[h], s.scale[b], c->margin, ol, dl, &t) && t < best) { best = t; who = b; }
+      float t; int ip = -1;
+      if (ray_hull(sh->planes[h], sh->n_planes[h], s.scale[b], c->margin, ol, dl, &t, &ip) && t < best) {
+        best = t; who = b;
+        if (normal && ip >= 0) nb = mulv(rot[b], mk(sh->planes[h][ip][0], sh->planes[h][ip][1], sh->planes[h][ip][2]));
+      }
     }
   }
-  float tt;
-  if (ray_table(c, s.table_z, cam_o, dw, &tt) && tt < best) { best = tt; who = RV_MAXB; }
+  float tt; int ax = -1;
+  if (ray_table(c, s.table_z, cam_o, dw, &tt, &ax) && tt < best) {
+    best = tt; who = RV_MAXB;
+    if (normal && ax >= 0) { const float sg = ax < 3 ? -1.0f : 1.0f; const int k = ax % 3; nb = mk(k == 0 ? sg : 0.0f, k == 1 ? sg : 0.0f, k == 2 ? sg : 0.0f); }
+  }
   *depth = best;
+  if (normal) *normal = nb;
   return who;
 }
 
+// CameraObs 'rgb' (camera_obs.py:33-88; bullet_camera.py:188-235 renders with pybullet's default
+// light): flat colours per body slot, table and background, Lambert-shaded with the normal of the
+// face that is hit under one fixed directional light
+RV_DEV void shade_rgb(int who, v3 n, uint8_t* out) {
+  const float base[RV_MAXB + 2][3] = {{230.0f, 60.0f, 60.0f}, {60.0f, 170.0f, 230.0f}, {250.0f, 200.0f, 40.0f}, {90.0f, 200.0f, 110.0f},
+                                      {150.0f, 120.0f, 90.0f}, {30.0f, 30.0f, 30.0f}};
+  const int idx = who < 0 ? RV_MAXB + 1 : who;
+  float sh = 1.0f;
+  if (who >= 0) {
+    const float lam = n.x * 0.30151134f + n.y * -0.30151134f + n.z * 0.90453403f;
+    sh = 0.35f + 0.65f * (lam > 0.0f ? lam : 0.0f);
+  }
+  for (int k = 0; k < 3; ++k) out[k] = (uint8_t)(int)(base[idx][k] * sh + 0.5f);
+}
 // point of pixel (u, v) at eye depth z (Camera.deproject_pixel, camera.py:195-211)
 RV_DEV v3 deproject(const rv_config* c, v3 cam_o, float u, float v, float z) {
   v3 pc = scale(pixel_dir_cam(c, u, v), z);

@@ -529,6 +529,22 @@ __global__ void k_stats(const DevEnv* envs, int n, rv_macro_stats* st, float suc
   }
 }
 
+__global__ void k_render_rgb(const ObsSnap* snaps, int n, uint8_t* rgb, const rv_config* c, const rv_scene* scene) {
+  const int H = c->cam_height, W = c->cam_width;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * H * W) return;
+  const int i = (int)(t / ((size_t)H * W)); const int px = (int)(t % ((size_t)H * W));
+  const int v = px / W, u = px - v * W;
+  const ObsSnap& s = snaps[i];
+  float rot[RV_MAXB][9];
+  for (int b = 0; b < RV_MAXB; ++b) { m3 m = qmat(ldq(s.pose[b] + 3)); stm(rot[b], m); }
+  const v3 cam_o = cam_position(c);
+  float d; v3 nrm;
+  int who = render_pixel(c, scene, s, rot, cam_o, cam_to_world_dir(c, pixel_dir_cam(c, (float)u, (float)v)), &d, &nrm);
+  if (who >= 0 && !(d > c->cam_near)) who = -1;
+  shade_rgb(who, nrm, rgb + t * 3);
+}
+
 // ------------------------------------------------------------------ host ABI
 struct rv_world {
   rv_config cfg;
@@ -860,6 +876,15 @@ int rv_observe(rv_world* w, const rv_obs_buffers* obs) {
     SIMPLE_LAUNCH(k_obs_snap, w->d_envs, w->n, w->d_snaps);
     rc = launch_point_cloud(w, w->n, obs->d_point_cloud); if (rc != RV_OK) return rc;
   }
+  return RV_OK;
+}
+int rv_render_rgb(rv_world* w, uint8_t* d_rgb) {
+  WCHK(w); NEED(d_rgb, "rv_render_rgb");
+  int rc = ensure_snaps(w, (size_t)w->n); if (rc != RV_OK) return rc;
+  SIMPLE_LAUNCH(k_obs_snap, w->d_envs, w->n, w->d_snaps);
+  const size_t total = (size_t)w->n * (size_t)w->cfg.cam_height * (size_t)w->cfg.cam_width;
+  hipLaunchKernelGGL(k_render_rgb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, w->stream, w->d_snaps, w->n, d_rgb, w->d_cfg, w->d_scene);
+  HIPCHK(hipGetLastError());
   return RV_OK;
 }
 int rv_render(rv_world* w, float* d_depth, uint8_t* d_segmask) {

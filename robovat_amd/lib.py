@@ -30,7 +30,7 @@ SYMBOLS = [
     'rv_compute_ik', 'rv_query_contacts', 'rv_get_manifold_counts', 'rv_observe',
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
-    'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll', 'rv_set_constraint',
+    'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll', 'rv_set_constraint', 'rv_render_rgb',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -117,6 +117,7 @@ def load():
     lib.rv_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.rv_reset_targets.argtypes = [vp]
     lib.rv_render.argtypes = [vp, vp, vp]
+    lib.rv_render_rgb.argtypes = [vp, vp]
     lib.rv_set_motor_targets.argtypes = [vp, vp, vp]
     lib.rv_grip.argtypes = [vp, f32]
     lib.rv_set_gravity.argtypes = [vp, C.POINTER(C.c_float)]
@@ -432,6 +433,12 @@ class World(object):
         seg = self._new((self.n, h, w), self.torch.uint8) if segmask else None
         check(self.lib.rv_render(self.h, self._ptr(depth), self._ptr(seg) if segmask else None))
         return depth, seg
+
+    def render_rgb(self):
+        """rv_render_rgb: uint8 [N, H, W, 3]."""
+        rgb = self._new((self.n, int(self.cfg.cam_height), int(self.cfg.cam_width), 3), self.torch.uint8)
+        check(self.lib.rv_render_rgb(self.h, self._ptr(rgb)))
+        return rgb
 
     def reward(self):
         r = self._new((self.n,), self.torch.float32)

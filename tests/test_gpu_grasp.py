@@ -105,3 +105,38 @@ def test_grasp_env_python_api():
     obs, r, d, _ = venv.step(venv.sample_random_actions())
     assert r.shape == (32,) and bool(d.all()) and obs['depth'].shape == (32, 424, 512)
     env.close(); venv.close()
+
+
+def test_rgb_render_matches_oracle_and_camera_obs():
+    """rv_render_rgb == the oracle's shaded render, pixel for pixel; every body visible in the
+    segmentation mask shows its slot colour; CameraObs hands the three modalities out."""
+    import torch
+    from robovat_amd import configs, scenes, lib, observations
+    from oracle import orc
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(n_envs=3, seed=13, shape_names=names)
+    w, ref = lib.World(cfg, scene, device=0), orc.OracleWorld(cfg, scene, double=False)
+    w.reset(); ref.reset()
+    rgb = w.render_rgb().cpu().numpy()
+    depth, seg = w.render()
+    seg = seg.cpu().numpy()
+    for i in range(3):
+        want = ref.render_rgb(i)
+        assert np.array_equal(rgb[i], want)
+    assert rgb.shape == (3, int(cfg.cam_height), int(cfg.cam_width), 3) and rgb.dtype == np.uint8
+    for b in range(4):
+        px = rgb[0][seg[0] == b]
+        assert len(px) > 50
+        base = np.array([[230, 60, 60], [60, 170, 230], [250, 200, 40], [90, 200, 110]][b], float)
+        ratio = px / base                      # one shade factor per pixel, within [0.35, 1]
+        assert (np.abs(ratio - ratio[:, :1]) < 0.02).all() and ratio.min() > 0.33 and ratio.max() < 1.01
+    assert (rgb[0][seg[0] == 255] == 30).all()                                   # background
+
+    class _Env(object):
+        world = w
+    for mod, shape in (('rgb', (424, 512, 3)), ('depth', (424, 512, 1)), ('segmask', (424, 512, 1))):
+        o = observations.CameraObs(modality=mod, env_index=1)
+        o.initialize(_Env())
+        x = o.get_observation()
+        assert x.shape == shape == o.get_gym_space().shape and x.dtype == o.get_gym_space().dtype
+    w.close()
