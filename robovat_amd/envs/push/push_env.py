@@ -36,14 +36,23 @@ class VecPushEnv(object):
     """N PushEnv instances on one GPU (env shards [offset, offset + N))."""
 
     def __init__(self, num_envs, config=None, robot_config=None, device=0, seed=0,
-                 env_id_offset=0, use_point_cloud=False):
+                 env_id_offset=0, use_point_cloud=False, physics=None):
         from robovat_amd import lib
         self.config = config or configs.push_env_config()
         self.robot_config = robot_config or configs.sawyer_config()
-        self.scene, self.shape_names = scenes.make_scene()
-        self.rv_config = configs.make_rv_config(self.config, self.robot_config, self.shape_names,
-                                                n_envs=num_envs, env_id_offset=env_id_offset, seed=seed)
-        self.world = lib.World(self.rv_config, self.scene, device=device)
+        self._owns_world = physics is None
+        if physics is None:
+            self.scene, self.shape_names = scenes.make_scene()
+            self.rv_config = configs.make_rv_config(self.config, self.robot_config, self.shape_names,
+                                                    n_envs=num_envs, env_id_offset=env_id_offset, seed=seed)
+            self.world = lib.World(self.rv_config, self.scene, device=device)
+        else:
+            # the env runs on the world of a Simulator's physics backend (HipPhysics): what the env
+            # does is visible through the Simulator / Body API and the other way round
+            assert int(num_envs) == 1, 'a Simulator holds one env'
+            physics.configure(self.config, self.robot_config, seed=seed, worker_id=env_id_offset)
+            self.scene, self.shape_names = physics.scene, physics.shape_names
+            self.world, self.rv_config = physics.world, physics.rv_config
         self.num_envs = int(num_envs)
         self.max_movable_bodies = abi.RV_MAXB
         self.use_point_cloud = bool(use_point_cloud)
@@ -91,7 +100,8 @@ class VecPushEnv(object):
         return self.world.stats()
 
     def close(self):
-        self.world.close()
+        if self._owns_world:
+            self.world.close()
 
 
 class PushEnv(object):
@@ -101,9 +111,16 @@ class PushEnv(object):
                  worker_id=0):
         self._config = config or configs.push_env_config()
         self._debug = debug
+        # PushEnv(simulator, config) as in the reference (push_env.py:43-48): the env lives in the
+        # simulator's physics backend -- bodies, constraints and getters of that Simulator see it
         self._simulator = simulator
+        physics = None
+        if simulator is not None:
+            physics = simulator.physics
+            if not hasattr(physics, 'configure'):
+                raise ValueError('PushEnv needs a Simulator whose physics backend is HipPhysics')
         self._vec = VecPushEnv(1, self._config, robot_config, device=device, seed=seed, env_id_offset=worker_id,
-                               use_point_cloud=True)
+                               use_point_cloud=True, physics=physics)
         self.max_movable_bodies = abi.RV_MAXB
         self.task_name = self._config.TASK_NAME
         self.layout_id = self._config.LAYOUT_ID

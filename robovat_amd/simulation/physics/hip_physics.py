@@ -48,6 +48,24 @@ class HipPhysics(Physics):
     uid = property(lambda s: s._worker_id)
     world = property(lambda s: s._world)
 
+    rv_config = property(lambda s: s._cfg)
+
+    def configure(self, env_config, robot_config=None, seed=None, worker_id=None):
+        """(Re)create the world for an env's configuration: what an env handed this backend through
+        its Simulator calls first (envs/push/push_env.py)."""
+        self._env_config = env_config
+        if robot_config is not None:
+            self._robot_config = robot_config
+        self._env_config.PHYSICS.TIME_STEP = self._time_step
+        if seed is not None:
+            self._seed = seed
+        if worker_id is not None:
+            self._worker_id = worker_id
+        self.reset()
+        if self._gravity is not None:
+            self._world.set_gravity(self._gravity)
+        self._num_steps = 0
+
     def reset(self):
         from robovat_amd import lib
         if self._world is not None:

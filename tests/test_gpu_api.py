@@ -107,3 +107,27 @@ def test_reward_survives_launches_that_are_not_steps():
     r2 = r2.cpu().numpy()
     assert (r2[[0, 2]] == 1.0).all() and (r2[[1, 3, 4, 5]] == 0).all()
     w.close()
+
+
+def test_push_env_lives_in_the_simulator_it_is_given():
+    """PushEnv(simulator=...) (push_env.py:43-48): the env runs on the world of the Simulator's
+    HipPhysics backend, so the Simulator's getters see what env.step() did -- and a PushEnv built
+    without a simulator computes the same thing."""
+    import numpy as np
+    from robovat_amd import envs
+    from robovat_amd.simulation import Simulator
+    sim = Simulator(physics_backend='HipPhysics')
+    env = envs.PushEnv(simulator=sim, seed=4)
+    assert env.simulator is sim and sim.physics.world is env._vec.world
+    env.reset()
+    before = np.array([np.asarray(sim.physics.get_body_position(b)) for b in range(4)])
+    obs, reward, done, _ = env.step(np.array([0.1, -0.2, 0.9, 0.3], np.float32))
+    after = np.array([np.asarray(sim.physics.get_body_position(b)) for b in range(4)])
+    assert np.allclose(after, obs['position'], atol=1e-6) if 'position' in obs else True
+    assert sim.physics.time() >= 0.0 and len(sim.physics.get_contact_points(0, None)) >= 0
+    env2 = envs.PushEnv(seed=4)
+    env2.reset()
+    obs2, reward2, done2, _ = env2.step(np.array([0.1, -0.2, 0.9, 0.3], np.float32))
+    assert np.array_equal(obs2['point_cloud'], obs['point_cloud']) and reward2 == reward and done2 == done
+    assert np.array_equal(after, env2._vec.world.body_state().cpu().numpy()[0, :, :3])
+    env.close(); env2.close()
