@@ -277,7 +277,28 @@ def arm_chain_from_urdf(path, tip_link, base_link=None):
     if base_link is not None and link != base_link:
         raise ValueError('%s is not an ancestor of %s' % (base_link, tip_link))
     chain.reverse()
-    out = {'names': [], 'jpos': [], 'jquat': [], 'q_lo': [], 'q_hi': [], 'v_max': [], 'effort': [], 'kind': []}
+    out = {'names': [], 'jpos': [], 'jquat': [], 'q_lo': [], 'q_hi': [], 'v_max': [], 'effort': [], 'kind': [],
+           'colliders': []}                    # per moving joint: [n, 3] collision points of the links riding on it, kernel frame
+    links = {l.get('name'): l for l in root.findall('link')}
+    base_dir = os.path.dirname(os.path.abspath(path))
+
+    def link_points(name):
+        pts = []
+        for col in links[name].findall('collision') if name in links else []:
+            geom = col.find('geometry')
+            if geom is None:
+                continue
+            org = col.find('origin')
+            xyz = np.asarray(_floats(org.get('xyz') if org is not None else None, 3, [0.0, 0.0, 0.0]))
+            R = _rpy_matrix(*_floats(org.get('rpy') if org is not None else None, 3, [0.0, 0.0, 0.0]))
+            g = np.asarray(_geometry_points(geom, base_dir), dtype=np.float64)
+            sph, cyl = geom.find('sphere'), geom.find('cylinder')
+            if sph is not None:                 # (the box of a round shape: its axis extremes, not the polyhedron's)
+                r = float(sph.get('radius')); g = np.concatenate([g, r * np.concatenate([np.eye(3), -np.eye(3)])])
+            if cyl is not None:
+                r = float(cyl.get('radius')); g = np.concatenate([g, r * np.array([[1.0, 1, 0], [-1, -1, 0]])])
+            pts.append(g @ R.T + xyz)
+        return np.concatenate(pts) if pts else np.zeros((0, 3))
     T_R, T_p = np.eye(3), np.zeros(3)          # pending fixed transform, in the frame of the last moving joint
     A_prev = np.eye(3)                         # rotation URDF-joint-frame -> kernel-joint-frame of the previous moving joint
     for j in chain:
@@ -289,6 +310,11 @@ def arm_chain_from_urdf(path, tip_link, base_link=None):
         kind = j.get('type')
         if kind == 'fixed':
             T_R, T_p = R_new, p_new
+            # a link behind a fixed joint rides on the last moving joint: its collision points in that frame
+            if out['colliders']:
+                lp = link_points(j.find('child').get('link'))
+                if len(lp):
+                    out['colliders'][-1] = np.concatenate([out['colliders'][-1], (lp @ T_R.T + T_p) @ A_prev])
             continue
         if kind not in ('revolute', 'continuous', 'prismatic'):
             raise ValueError('unsupported joint type %s' % kind)
@@ -306,8 +332,40 @@ def arm_chain_from_urdf(path, tip_link, base_link=None):
         out['effort'].append(float(lim.get('effort', 0.0)) if lim is not None else 0.0)
         out['names'].append(j.get('name')); out['kind'].append(kind)
         T_R, T_p, A_prev = np.eye(3), np.zeros(3), Az
+        out['colliders'].append(link_points(j.find('child').get('link')) @ Az)     # (row vectors: p_kernel = Az^T p_urdf)
     out['tip'] = {'pos': (A_prev.T @ T_p).tolist(), 'quat': _quat_from_matrix(A_prev.T @ T_R).tolist()}
     return out
+
+
+def arm_from_urdf(path, tip_link, base_link=None, base_pos=(0.0, 0.0, 0.0), base_rpy=(0.0, 0.0, 0.0), max_accel=None,
+                  link_radius=0.05):
+    """An ``rv_arm`` from a robot URDF (sawyer_sim.py:101-117 loads ARM_URDF the same way): the seven
+    revolute joints of the chain base -> ``tip_link`` (origins, axes, limits, velocity and effort limits)
+    and one collider box per limb link -- the box of its ``<collision>`` geometry in the joint frame (links
+    behind fixed joints included); a link without collision geometry gets a box of ``link_radius`` around
+    the segment to the next joint.  The gripper (base box, two prismatic fingers and their pads) keeps the
+    geometry of ``scenes.make_arm``: RoboVat drives it through two joints off the hand link that are not
+    on the chain.  ``max_accel``: joint acceleration limits (URDF has none), default scenes.SAWYER_MAX_ACCEL."""
+    from robovat_amd import scenes
+    ch = arm_chain_from_urdf(path, tip_link, base_link)
+    if len(ch['names']) != abi.RV_NLIMB or any(k == 'prismatic' for k in ch['kind']):
+        raise ValueError('the limb must be a chain of %d revolute joints, got %s' % (abi.RV_NLIMB, ch['kind']))
+    arm = scenes.make_arm(base_pos=base_pos, base_rpy=base_rpy)           # gripper geometry, finger joints
+    acc = list(max_accel) if max_accel is not None else list(scenes.SAWYER_MAX_ACCEL)
+    for i in range(abi.RV_NLIMB):
+        abi.assign(arm.jpos[i], ch['jpos'][i]); abi.assign(arm.jquat[i], ch['jquat'][i])
+        arm.q_lo[i], arm.q_hi[i], arm.v_max[i], arm.a_max[i] = ch['q_lo'][i], ch['q_hi'][i], ch['v_max'][i], acc[i]
+        arm.inv_tau_max[i] = 1.0 / ch['effort'][i] if ch['effort'][i] > 0 else 0.0
+        pts = np.asarray(ch['colliders'][i])
+        nxt = np.asarray(ch['jpos'][i + 1] if i + 1 < abi.RV_NLIMB else ch['tip']['pos'])
+        if len(pts):
+            lo, hi = pts.min(axis=0), pts.max(axis=0)
+        else:
+            lo, hi = np.minimum(0.0, nxt) - link_radius, np.maximum(0.0, nxt) + link_radius
+        arm.col_frame[i] = i
+        abi.assign(arm.col_center[i], (0.5 * (lo + hi)).tolist()); abi.assign(arm.col_half[i], (0.5 * (hi - lo)).tolist())
+    abi.assign(arm.jpos[abi.RV_NLIMB], ch['tip']['pos']); abi.assign(arm.jquat[abi.RV_NLIMB], ch['tip']['quat'])
+    return arm
 
 
 def fk_chain(chain, q):

@@ -268,10 +268,11 @@ def make_arm(base_pos=(0.0, 0.0, 0.0), base_rpy=(0.0, 0.0, 0.0), finger_accel=2.
     return arm
 
 
-def make_scene(shape_hulls=None, env_cfg=None):
+def make_scene(shape_hulls=None, env_cfg=None, arm=None):
     """Build the ``rv_scene`` (shape templates + arm).  Returns
     (scene, names).  ``env_cfg``: the env config, for the settings that live in the scene
-    (the finger acceleration limit of the force-limited gripper)."""
+    (the finger acceleration limit of the force-limited gripper).  ``arm``: an ``rv_arm`` to use
+    instead of the built-in one, e.g. ``io.asset_ingest.arm_from_urdf(ARM_URDF, 'right_hand')``."""
     if shape_hulls is None:
         shape_hulls = default_shape_hulls()
     assert len(shape_hulls) <= abi.RV_MAX_SHAPES
@@ -284,5 +285,9 @@ def make_scene(shape_hulls=None, env_cfg=None):
     accel = 2.0
     if env_cfg is not None and env_cfg.PHYSICS.get('FINGER_DYNAMICS'):
         accel = env_cfg.PHYSICS.FINGER_MAX_FORCE / env_cfg.PHYSICS.FINGER_MASS
-    scene.arm = make_arm(finger_accel=accel)
+    if arm is None:
+        scene.arm = make_arm(finger_accel=accel)
+    else:
+        scene.arm = arm
+        scene.arm.a_max[7] = scene.arm.a_max[8] = float(accel)
     return scene, names

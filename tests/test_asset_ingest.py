@@ -201,3 +201,52 @@ def test_merging_parts_reports_the_volume_it_fills():
     flat = np.array([[0, 0, 0], [1, 0, 1], [0, 1, 0], [1, 1, 1], [0.5, 0.5, 0.5]], dtype=float)   # a tilted plane
     with pytest.raises(ValueError, match='flat'):
         A.convex_hull_reduced(flat)
+
+
+def _builtin_arm_urdf():
+    """A URDF of the build's Sawyer-like arm: the joint origins / limits of scenes.py and, per link, the
+    collider box scenes.make_arm authors, as <collision><box>."""
+    o, lim, vel, eff = scenes.SAWYER_JOINT_ORIGINS, scenes.SAWYER_LIMITS, scenes.SAWYER_MAX_VELOCITY, scenes.SAWYER_EFFORT
+    arm = scenes.make_arm()
+    out = ['<?xml version="1.0"?>', '<robot name="sawyer_like">', '<link name="base"/>']
+    for i in range(7):
+        c, h = list(arm.col_center[i]), list(arm.col_half[i])
+        out.append('<link name="right_l%d"><collision><origin xyz="%r %r %r" rpy="0 0 0"/><geometry><box size="%r %r %r"/></geometry></collision></link>'
+                   % (i, c[0], c[1], c[2], 2 * h[0], 2 * h[1], 2 * h[2]))
+        out.append('<joint name="right_j%d" type="revolute"><parent link="%s"/><child link="right_l%d"/>'
+                   '<origin xyz="%r %r %r" rpy="%r %r %r"/><axis xyz="0 0 1"/><limit lower="%r" upper="%r" velocity="%r" effort="%r"/></joint>'
+                   % (i, 'base' if i == 0 else 'right_l%d' % (i - 1), i, *o[i][0], *o[i][1], lim[i][0], lim[i][1], vel[i], eff[i]))
+    out.append('<link name="right_hand"/>')
+    out.append('<joint name="right_hand" type="fixed"><parent link="right_l6"/><child link="right_hand"/><origin xyz="%r %r %r" rpy="%r %r %r"/></joint>'
+               % (*o[7][0], *o[7][1]))
+    out.append('</robot>')
+    return '\n'.join(out)
+
+
+def test_arm_from_urdf_reproduces_the_built_in_arm(tmp_path):
+    """Robot URDF -> rv_arm (sawyer_sim.py:101-117): joints, limits, efforts and the link collider boxes
+    read from <collision> geometry equal what scenes.make_arm authors by hand; a link without collision
+    geometry gets the default box."""
+    p = os.path.join(str(tmp_path), 'sawyer_like.urdf')
+    with open(p, 'w') as f:
+        f.write(_builtin_arm_urdf())
+    got, want = ai.arm_from_urdf(p, 'right_hand'), scenes.make_arm()
+    for i in range(8):
+        assert np.allclose(list(got.jpos[i]), list(want.jpos[i]), atol=1e-7)
+        qa, qb = np.array(list(got.jquat[i])), np.array(list(want.jquat[i]))
+        assert min(np.abs(qa - qb).max(), np.abs(qa + qb).max()) < 1e-6
+    for name in ('q_lo', 'q_hi', 'v_max', 'a_max', 'inv_tau_max'):
+        assert np.allclose(list(getattr(got, name)), list(getattr(want, name)), rtol=1e-6), name
+    for i in range(abi.RV_NCOL):
+        assert got.col_frame[i] == want.col_frame[i]
+        assert np.allclose(list(got.col_center[i]), list(want.col_center[i]), atol=1e-7) and np.allclose(list(got.col_half[i]), list(want.col_half[i]), atol=1e-7)
+    # a round link and a link without geometry
+    txt = _builtin_arm_urdf().replace('<link name="right_l3">', '<link name="right_l3x">').replace('<link name="base"/>', '<link name="base"/><link name="right_l3"/>')
+    txt = txt.replace('<link name="right_l5">', '<link name="right_l5x">').replace(
+        '<link name="base"/>', '<link name="base"/><link name="right_l5"><collision><origin xyz="0 0 0.1" rpy="0 0 0"/><geometry><sphere radius="0.04"/></geometry></collision></link>')
+    with open(p, 'w') as f:
+        f.write(txt)
+    arm = ai.arm_from_urdf(p, 'right_hand', link_radius=0.05)
+    assert np.allclose(list(arm.col_center[5]), [0, 0, 0.1], atol=1e-9) and np.allclose(list(arm.col_half[5]), [0.04] * 3, atol=1e-9)
+    nxt = np.array(scenes.SAWYER_JOINT_ORIGINS[4][0])
+    assert np.allclose(list(arm.col_half[3]), 0.5 * np.abs(nxt) + 0.05, atol=1e-7)

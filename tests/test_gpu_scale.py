@@ -367,3 +367,31 @@ def test_rollout_record_full_gives_complete_episodes(tmp_path):
     assert np.array_equal(back['transitions'][0]['state']['point_cloud'], t0['state']['point_cloud'])
     assert np.array_equal(back['transitions'][0]['action'], t0['action']) and back['transitions'][1]['info'] is None
     world.close()
+
+
+def test_env_with_an_arm_ingested_from_a_robot_urdf(tmp_path):
+    """scenes.make_scene(arm=asset_ingest.arm_from_urdf(...)): the arm of the env comes from a robot URDF
+    (joints, limits, link collider boxes from <collision>); reset and pushes run HIP == oracle bit for bit,
+    and the bodies end where the built-in arm (the same numbers, authored by hand) puts them."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_asset_ingest as TA
+    from robovat_amd import lib
+    from robovat_amd.io import asset_ingest as ai
+    from oracle import orc
+    p = os.path.join(str(tmp_path), 'sawyer_like.urdf')
+    with open(p, 'w') as f:
+        f.write(TA._builtin_arm_urdf())
+    scene, names = scenes.make_scene(arm=ai.arm_from_urdf(p, 'right_hand'))
+    cfg = configs.make_rv_config(n_envs=16, seed=3, shape_names=names)
+    w, ref = lib.World(cfg, scene, device=0), orc.OracleWorld(cfg, scene, double=False)
+    w.reset(); ref.reset()
+    w.rollout(2, 0, True); ref.rollout(2, 0, True)
+    got = w.body_state().cpu().numpy()
+    assert np.array_equal(got, ref.body_state().astype(np.float32))
+    scene0, _ = scenes.make_scene()
+    w0 = lib.World(cfg, scene0, device=0)
+    w0.reset(); w0.rollout(2, 0, True)
+    assert np.abs(w0.body_state().cpu().numpy() - got).max() < 2e-2      # same arm up to the rounding of the ingest
+    assert np.abs(w0.body_state().cpu().numpy() - got)[..., :3].mean() < 1e-3
+    w.close(); w0.close()
