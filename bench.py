@@ -405,6 +405,33 @@ def main():
             'grasp_success_rate': st4['successes'] / max(st4['env_steps'], 1),
             'roofline_frac_nominal': 1912 * st4['substeps'] / (1e-3 * w4.last_kernel_ms()) / 1e9 / HBM_PEAK_GBS})
         w4.close()
+        # the same two workloads with the dynamic limb (PHYSICS.LIMB_DYNAMICS: joint-space inertia,
+        # contact Jacobians and effort-limited motor rows of the seven joints in the solve of every substep in
+        # which the arm touches an awake body) -- cost and outcome next to the kinematic limb
+        limb = {'note': 'LIMB_DYNAMICS=1 vs the shipped kinematic limb (the headline and config4_grasp_2048 above): same seeds and actions'}
+        wl, _ = make_world(n, **{'PHYSICS.LIMB_DYNAMICS': 1})
+        wl.reset()
+        barrier(); tl = time.perf_counter()
+        wl.rollout(args.steps, first_macro_index=args.warmup, auto_reset=True, record=True)
+        stl = wl.stats()
+        barrier(); ell = all_max(time.perf_counter() - tl)
+        limb['push_%d' % n] = leg_summary(ell, stl, args.steps, n)
+        limb['push_%d' % n].update({k: stl[k] / max(stl['env_steps'], 1) for k in ('useful', 'unsafe', 'ineffective')})
+        limb['push_%d' % n]['kinematic'] = {k: st[k] / max(st['env_steps'], 1) for k in ('useful', 'unsafe', 'ineffective')}
+        wl.close()
+        genv = configs.grasp_env_config(**{'PHYSICS.LIMB_DYNAMICS': 1})
+        gc = configs.make_rv_config(env_cfg=genv, n_envs=2048, env_id_offset=rank * 2048, shape_names=gnames, **cfg_kwargs)
+        wl = lib.World(gc, gscene, device=local_rank)
+        wl.reset()
+        barrier(); tl = time.perf_counter()
+        wl.rollout(k3, first_macro_index=0, auto_reset=True, record=True)
+        stl = wl.stats()
+        barrier(); ell = all_max(time.perf_counter() - tl)
+        limb['grasp_2048'] = leg_summary(ell, stl, k3, 2048)
+        limb['grasp_2048']['grasp_success_rate'] = stl['successes'] / max(stl['env_steps'], 1)
+        limb['grasp_2048']['kinematic_grasp_success_rate'] = extra['config4_grasp_2048']['grasp_success_rate']
+        wl.close()
+        extra['limb_dynamics'] = limb
         # the path's only collective, alone: one RCCL all-gather of returns f32[8192] + all-reduce of 4
         # int64 counters on a 1-rank group (the 8-rank curve is the driver's to measure)
         if dist is None:

@@ -113,6 +113,13 @@ typedef struct rv_arm {
    * impulse of an arm - body contact row is capped at dt x min_j tau_j / |J_j . n| over the joints
    * upstream of the collider (rv_config.arm_effort_limit) */
   float inv_tau_max[RV_NJ];
+  /* inertial parameters of the limb (URDF <inertial>; controllable_body.py:458-466 drives PyBullet's
+   * btMultiBody, which has them from the URDF): link i rides on frame i (i < 7), entry 7 = the hand
+   * with the gripper; mass, centre of mass in the frame, principal moments (taken diagonal in the
+   * frame).  Read by rv_config.limb_dynamics only */
+  float link_mass[RV_NLIMB + 1];
+  float link_com[RV_NLIMB + 1][3];
+  float link_inertia[RV_NLIMB + 1][3];
 } rv_arm;
 
 typedef struct rv_scene {
@@ -256,6 +263,15 @@ typedef struct rv_config {
   float    gravity_xy[2];
   /* 1: arm - body contact forces are limited by the joint efforts (rv_arm.inv_tau_max) */
   int32_t  arm_effort_limit;
+  /* 1: the seven limb joints are dynamic while the arm touches a body (SURVEY.md 8 f1;
+   * controllable_body.py:458-466, bullet_physics.py:1061-1104): the solver of such a substep has the
+   * joint velocities as unknowns next to the body velocities -- joint-space inertia M(q) of the chain
+   * (composite bodies, rv_arm.link_*), contact rows with their joint-space Jacobians, and one
+   * POSITION_CONTROL motor row per joint that pulls the joint back to the commanded velocity with at most
+   * the joint effort (1 / rv_arm.inv_tau_max) minus what the free motion and holding the arm against
+   * gravity already take.  A pad that lands on an object then stalls instead of crushing it.  0: the
+   * limb is a kinematic pusher (its trajectory does not depend on contacts) */
+  int32_t  limb_dynamics;
 } rv_config;
 
 /* Per-launch statistics of rv_step_macro / rv_reset (device-side reductions of

@@ -221,6 +221,14 @@ class OracleWorld(object):
         n = self.lib.orc_get_manifold(self.h, C.c_int(env), C.c_int(mi), _p(out))
         return n, out
 
+    def limb_debug(self, env=0):
+        """(M [7,7], M^-1 [7,7], lo [7], hi [7]) of rv_config.limb_dynamics at the current joint state;
+        the motor-row impulses of the last limb solve are left in ``last_motor_impulse``."""
+        M = np.zeros((7, 7)); Mi = np.zeros((7, 7)); lohi = np.zeros(21)
+        self.lib.orc_limb_debug(self.h, C.c_int(env), _p(M), _p(Mi), _p(lohi))
+        self.last_motor_impulse = lohi[14:]
+        return M, Mi, lohi[:7], lohi[7:14]
+
     def manifold_counts(self):
         return self._get('orc_get_manifold_counts', (self.n, abi.RV_NMAN), np.int32)
 

@@ -104,6 +104,8 @@ typedef struct {
   real mu_finger, mu_table;
   int num_action_steps;                  /* Grasp4DofEnv: substeps spent in the 'start' phase */
   real fing_dv[2], fing_vt[2], fing_qd0[2];   /* finger motors this substep: velocity step, commanded velocity, velocity after it */
+  real limb_lam[RV_NLIMB];   /* impulses of the limb motor rows of the last solve that had them (diagnostic) */
+  real limb_dv[RV_NLIMB], limb_vt[RV_NLIMB], limb_qd0[RV_NLIMB];   /* the same of the limb joints (rv_config.limb_dynamics) */
   int l_unsafe, l_ineffective, l_useful, l_episodes, l_successes;   /* per-launch sums (stats) */
   int done, phase, is_safe, is_effective;
   int reset_count;
@@ -494,6 +496,7 @@ static void arm_motor_step(const orc_world* w, orc_env* e) {
     if (qn < (real)a->q_lo[j]) { qn = (real)a->q_lo[j]; qd = R(0.0); }
     if (qn > (real)a->q_hi[j]) { qn = (real)a->q_hi[j]; qd = R(0.0); }
     if (j >= RV_NLIMB) { e->fing_dv[j - RV_NLIMB] = dv; e->fing_vt[j - RV_NLIMB] = vd; e->fing_qd0[j - RV_NLIMB] = qd; }
+    else { e->limb_dv[j] = dv; e->limb_vt[j] = vd; e->limb_qd0[j] = qd; }
     e->q[j] = qn; e->qd[j] = qd;
   }
 }
@@ -961,6 +964,126 @@ static real point_solve(orc_env* e, int kind, int a, int b, orc_manifold* m, int
   return res;
 }
 
+/* ---- limb dynamics (rv_config.limb_dynamics) --------------------------------------
+ * While the arm touches an awake body the seven limb joints are unknowns of the solver (PyBullet: the
+ * arm is a btMultiBody whose POSITION_CONTROL motors are constraint rows of the same PGS,
+ * controllable_body.py:458-466, bullet_physics.py:1061-1104).  The unknown is the DEVIATION dq of the
+ * joint velocities from the ones the motor law of this substep commanded (limb_qd0): the link twists the
+ * contact rows were set up with stay as they are, a contact row on a collider of frame f gets the
+ * joint-space Jacobian  Ja_j = -dir . (axis_j x (p - p_j)), j <= min(f, 6), an impulse dl on it changes
+ * dq by M^-1 Ja^T dl, and its effective mass gains Ja M^-1 Ja^T.  M(q) is the joint-space inertia of the
+ * chain of eight masses (links 0..6 and the hand):
+ *   M_jk = sum_{i >= max(j,k)} m_i (a_j x (c_i - p_j)) . (a_k x (c_i - p_k)) + (R_i^T a_j) . I_i (R_i^T a_k)
+ * (the composite-rigid-body sum written out for revolute joints; velocity-product terms are neglected: the
+ * limb moves at < 1 rad/s).  The solve starts from the joint velocities BEFORE the motor step of this
+ * substep (dq = -limb_dv: the acceleration limits of the kinematic motor law are no statement about
+ * torques).  Motor row j: J = e_j, target dq_j = commanded - current velocity, accumulated impulse within
+ * +- tau_j dt minus the torque that holds the chain against gravity.  After the solve the joints move
+ * with the solved velocity and the link frames are recomputed. */
+typedef struct {
+  real M[RV_NLIMB][RV_NLIMB], Mi[RV_NLIMB][RV_NLIMB];
+  real lo[RV_NLIMB], hi[RV_NLIMB], tgt[RV_NLIMB];
+  real Ja[RV_MAXB][4][3][RV_NLIMB], MiJ[RV_MAXB][4][3][RV_NLIMB], invk[RV_MAXB][4][3];
+} orc_limb;
+static void limb_prepare(const orc_world* w, orc_env* e, orc_row rows[][4], const int* use, orc_limb* L) {
+  const rv_config* c = &w->cfg; const rv_arm* arm = &w->scene.arm;
+  const real dt = (real)c->dt;
+  real com[RV_NLIMB + 1][3];
+  for (int i = 0; i <= RV_NLIMB; ++i) {
+    real lc[3] = {(real)arm->link_com[i][0], (real)arm->link_com[i][1], (real)arm->link_com[i][2]}, t[3];
+    m3mulv(t, e->frot[i], lc); v3add(com[i], e->fpos[i], t);
+  }
+  const real g[3] = {(real)c->gravity_xy[0], (real)c->gravity_xy[1], (real)c->gravity_z};
+  real A[RV_NLIMB][2 * RV_NLIMB], Gq[RV_NLIMB];
+  for (int j = 0; j < RV_NLIMB; ++j) {
+    for (int k = 0; k < RV_NLIMB; ++k) {
+      const int mx = j > k ? j : k;
+      real acc = R(0.0);
+      for (int i = mx; i <= RV_NLIMB; ++i) {
+        real dj[3], dk[3], lj[3], lk[3], aj[3], ak[3];
+        v3sub(dj, com[i], e->fpos[j]); v3cross(lj, e->axis[j], dj);
+        v3sub(dk, com[i], e->fpos[k]); v3cross(lk, e->axis[k], dk);
+        const real t = (real)arm->link_mass[i] * v3dot(lj, lk);
+        m3tmulv(aj, e->frot[i], e->axis[j]); m3tmulv(ak, e->frot[i], e->axis[k]);
+        const real r = (aj[0] * ak[0]) * (real)arm->link_inertia[i][0] + (aj[1] * ak[1]) * (real)arm->link_inertia[i][1]
+                     + (aj[2] * ak[2]) * (real)arm->link_inertia[i][2];
+        acc = acc + (t + r);
+      }
+      L->M[j][k] = acc; A[j][k] = acc; A[j][RV_NLIMB + k] = j == k ? R(1.0) : R(0.0);
+    }
+    real gq = R(0.0);
+    for (int i = j; i <= RV_NLIMB; ++i) {
+      real dj[3], lj[3];
+      v3sub(dj, com[i], e->fpos[j]); v3cross(lj, e->axis[j], dj);
+      gq = gq + (real)arm->link_mass[i] * v3dot(lj, g);
+    }
+    Gq[j] = gq;
+  }
+  /* M^-1 by Gauss-Jordan on [M | 1] without pivoting (M is symmetric positive definite); a column that has
+   * been the pivot column is not touched again (the device runs one lane per column) */
+  for (int p = 0; p < RV_NLIMB; ++p) {
+    const real piv = A[p][p];
+    for (int col = 0; col < 2 * RV_NLIMB; ++col) {
+      if (col <= p) continue;
+      const real ap = A[p][col] / piv;
+      for (int r = 0; r < RV_NLIMB; ++r) if (r != p) A[r][col] = A[r][col] - A[r][p] * ap;
+      A[p][col] = ap;
+    }
+  }
+  for (int j = 0; j < RV_NLIMB; ++j) for (int k = 0; k < RV_NLIMB; ++k) L->Mi[j][k] = A[j][RV_NLIMB + k];
+  for (int j = 0; j < RV_NLIMB; ++j) {
+    const real hold = -Gq[j] * dt;
+    const real tdt = arm->inv_tau_max[j] > 0.0f ? dt / (real)arm->inv_tau_max[j] : R(1e30);
+    L->lo[j] = rmin(R(0.0), -tdt - hold); L->hi[j] = rmax(R(0.0), tdt - hold);
+    L->tgt[j] = e->limb_vt[j] - e->limb_qd0[j];
+  }
+  for (int b = 0; b < RV_MAXB; ++b) {
+    const orc_manifold* m = &e->man[AIDX(b)];
+    if (!use[AIDX(b)]) continue;
+    for (int i = 0; i < m->n; ++i) {
+      real wa[3], wb[3];
+      manifold_world_points(w, e, 2, b, -1, m, i, wa, wb);
+      const int f = arm->col_frame[m->col[i]], fl = f < RV_NLIMB ? f : RV_NLIMB - 1;
+      for (int k = 0; k < 3; ++k) {
+        const orc_row* r = &rows[AIDX(b)][i];
+        real* Ja = L->Ja[b][i][k]; real* MiJ = L->MiJ[b][i][k];
+        for (int j = 0; j < RV_NLIMB; ++j) {
+          real d[3], lever[3];
+          v3sub(d, wb, e->fpos[j]); v3cross(lever, e->axis[j], d);
+          Ja[j] = j <= fl ? -v3dot(r->dir[k], lever) : R(0.0);
+        }
+        real kk = R(1.0) / r->invk[k];
+        for (int j = 0; j < RV_NLIMB; ++j) {
+          real a_ = R(0.0);
+          for (int x = 0; x < RV_NLIMB; ++x) a_ = a_ + L->Mi[j][x] * Ja[x];
+          MiJ[j] = a_;
+        }
+        for (int j = 0; j < RV_NLIMB; ++j) kk = kk + Ja[j] * MiJ[j];
+        L->invk[b][i][k] = R(1.0) / kk;
+      }
+    }
+  }
+}
+/* diagnostics for the tests: joint-space inertia (49), its inverse (49), the motor-row bounds lo/hi (7 + 7)
+ * of the CURRENT joint state of env i and the motor-row impulses of the last limb solve (7) */
+void orc_limb_debug(orc_world* w, int i, double* M, double* Mi, double* lohi) {
+  orc_env* e = &w->env[i];
+  orc_limb L; orc_row rows[RV_NMAN][4]; int use[RV_NMAN];
+  memset(use, 0, sizeof(use)); memset(rows, 0, sizeof(rows));
+  arm_update_kinematics(w, e);
+  limb_prepare(w, e, rows, use, &L);
+  for (int j = 0; j < RV_NLIMB; ++j) {
+    for (int k = 0; k < RV_NLIMB; ++k) { M[j * RV_NLIMB + k] = (double)L.M[j][k]; Mi[j * RV_NLIMB + k] = (double)L.Mi[j][k]; }
+    lohi[j] = (double)L.lo[j]; lohi[RV_NLIMB + j] = (double)L.hi[j]; lohi[2 * RV_NLIMB + j] = (double)e->limb_lam[j];
+  }
+}
+static real limb_jv(const real* Ja, const real* dq) {
+  real a_ = R(0.0);
+  for (int j = 0; j < RV_NLIMB; ++j) a_ = a_ + Ja[j] * dq[j];
+  return a_;
+}
+static void limb_apply(const real* MiJ, real* dq, real dl) { for (int j = 0; j < RV_NLIMB; ++j) dq[j] = dq[j] + MiJ[j] * dl; }
+
 /* PGS with the force-limited gripper (rv_config.finger_dynamics; Grasp4DofEnv).  The two finger
  * joints are dynamic 1-DoF bodies of mass finger_mass sliding along the hand's y axis: contact rows
  * on a finger pad (collider boxes 8 / 9) carry jf = -(dir . y) on the finger velocity, and each
@@ -968,33 +1091,42 @@ static real point_solve(orc_env* e, int kind, int a, int b, orc_manifold* m, int
  * the commanded one with at most finger_max_force (the joint motors have already spent m * fing_dv
  * of that budget on the free motion).  Velocity-space Gauss-Seidel over all awake bodies and both
  * fingers as one system. */
-static real point_solve_g(orc_env* e, int a, orc_manifold* m, int i, const orc_row* r, real* qf, real imf) {
+/* lj / lm / lk: the limb Jacobians Ja[3][7], M^-1 Ja^T [3][7] and effective masses [3] of an arm row in
+ * limb_dynamics mode (NULL otherwise), dq: the deviation of the joint velocities */
+static real point_solve_g(orc_env* e, int a, orc_manifold* m, int i, const orc_row* r, real* qf, real imf,
+                          const real (*lj)[RV_NLIMB], const real (*lm)[RV_NLIMB], const real* lk, real* dq) {
   const int fi = r->fidx;
   real jv = row_jv(e, 0, a, -1, r, 0);
   if (fi >= 0) jv += r->jf[0] * qf[fi];
-  real dl = (r->target - jv) * r->invk[0];
+  if (lj) jv += limb_jv(lj[0], dq);
+  real dl = (r->target - jv) * (lj ? lk[0] : r->invk[0]);
   real ln = rclamp(m->ln[i] + dl, R(0.0), r->cap);
   dl = ln - m->ln[i]; m->ln[i] = ln;
   real res = rabs(dl);
   row_apply(e, 0, a, -1, r, 0, dl);
   if (fi >= 0) qf[fi] += r->jf[0] * dl * imf;
+  if (lj) limb_apply(lm[0], dq, dl);
   real lim = r->mu * ln;
   jv = row_jv(e, 0, a, -1, r, 1);
   if (fi >= 0) jv += r->jf[1] * qf[fi];
-  dl = -jv * r->invk[1];
+  if (lj) jv += limb_jv(lj[1], dq);
+  dl = -jv * (lj ? lk[1] : r->invk[1]);
   real l1 = rclamp(m->lt1[i] + dl, -lim, lim);
   dl = l1 - m->lt1[i]; m->lt1[i] = l1;
   res = rmax(res, rabs(dl));
   row_apply(e, 0, a, -1, r, 1, dl);
   if (fi >= 0) qf[fi] += r->jf[1] * dl * imf;
+  if (lj) limb_apply(lm[1], dq, dl);
   jv = row_jv(e, 0, a, -1, r, 2);
   if (fi >= 0) jv += r->jf[2] * qf[fi];
-  dl = -jv * r->invk[2];
+  if (lj) jv += limb_jv(lj[2], dq);
+  dl = -jv * (lj ? lk[2] : r->invk[2]);
   real l2 = rclamp(m->lt2[i] + dl, -lim, lim);
   dl = l2 - m->lt2[i]; m->lt2[i] = l2;
   res = rmax(res, rabs(dl));
   row_apply(e, 0, a, -1, r, 2, dl);
   if (fi >= 0) qf[fi] += r->jf[2] * dl * imf;
+  if (lj) limb_apply(lm[2], dq, dl);
   return res;
 }
 /* The six rows of a user constraint on body b (a fixed joint to a frame of the world: the mocap-style
@@ -1035,8 +1167,10 @@ static real constraint_solve(const orc_world* w, orc_env* e, int b, real* lam) {
   }
   return res;
 }
-static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4], const int* use) {
+static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4], const int* use, const orc_limb* L) {
   const rv_config* c = &w->cfg; const rv_arm* arm = &w->scene.arm;
+  real dq[RV_NLIMB], lam_l[RV_NLIMB];
+  for (int j = 0; j < RV_NLIMB; ++j) { dq[j] = L ? -e->limb_dv[j] : R(0.0); lam_l[j] = R(0.0); }   /* (the solve starts from the velocity before the motor step) */
   const int fd = c->finger_dynamics && e->arm_enabled;           /* the finger joints are DOFs of the system */
   const real mf = (real)c->finger_mass, imf = R(1.0) / (real)c->finger_mass, fdt = (real)c->finger_max_force * (real)c->dt;
   real qf[2] = {e->qd[RV_NLIMB], e->qd[RV_NLIMB + 1]}, lam_m[2] = {R(0.0), R(0.0)};
@@ -1050,10 +1184,12 @@ static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4]
         orc_manifold* m = &e->man[mi];
         for (int i = 0; i < m->n; ++i) {
           const orc_row* r = &rows[mi][i];
+          const int la = L && kind == 2;
           if (it < 0) {
             row_apply(e, 0, b, -1, r, 0, m->ln[i]); row_apply(e, 0, b, -1, r, 1, m->lt1[i]); row_apply(e, 0, b, -1, r, 2, m->lt2[i]);
             if (r->fidx >= 0) { qf[r->fidx] += r->jf[0] * m->ln[i] * imf; qf[r->fidx] += r->jf[1] * m->lt1[i] * imf; qf[r->fidx] += r->jf[2] * m->lt2[i] * imf; }
-          } else res = rmax(res, point_solve_g(e, b, m, i, r, qf, imf));
+            if (la) { limb_apply(L->MiJ[b][i][0], dq, m->ln[i]); limb_apply(L->MiJ[b][i][1], dq, m->lt1[i]); limb_apply(L->MiJ[b][i][2], dq, m->lt2[i]); }
+          } else res = rmax(res, point_solve_g(e, b, m, i, r, qf, imf, la ? L->Ja[b][i] : NULL, la ? L->MiJ[b][i] : NULL, la ? L->invk[b][i] : NULL, dq));
         }
       }
     }
@@ -1079,7 +1215,22 @@ static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4]
       qf[f] += dl * imf;
       res = rmax(res, rabs(dl));
     }
+    for (int j = 0; L && j < RV_NLIMB; ++j) {     /* limb motor rows */
+      real dl = (L->tgt[j] - dq[j]) / L->Mi[j][j];
+      const real ln = rclamp(lam_l[j] + dl, L->lo[j], L->hi[j]);
+      dl = ln - lam_l[j]; lam_l[j] = ln;
+      for (int k = 0; k < RV_NLIMB; ++k) dq[k] = dq[k] + L->Mi[k][j] * dl;
+      res = rmax(res, rabs(dl));
+    }
     if (res < (real)c->solver_tol) break;
+  }
+  for (int j = 0; L && j < RV_NLIMB; ++j) {       /* the limb moves with the solved velocity */
+    real qd = e->limb_qd0[j] + dq[j];
+    real qn = e->q[j] + dq[j] * (real)c->dt;
+    if (qn < (real)arm->q_lo[j]) { qn = (real)arm->q_lo[j]; qd = R(0.0); }
+    if (qn > (real)arm->q_hi[j]) { qn = (real)arm->q_hi[j]; qd = R(0.0); }
+    e->q[j] = qn; e->qd[j] = qd;
+    e->limb_lam[j] = lam_l[j];
   }
   for (int f = 0; fd && f < 2; ++f) {
     const int j = RV_NLIMB + f;
@@ -1111,15 +1262,22 @@ static real dotj(const orc_j6* j, const real* pl, const real* pa) { return v3dot
  * velocity, impulse within +-finger_max_force dt minus what the joint motors of the light part already
  * spent on the free motion.  The Delassus matrix gets the finger terms, nothing else changes; the fingers
  * then move with the solved velocity. */
-static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const orc_rowid* id, int n_rows, const int* use, const int* big, const int* label, const int fing) {
+static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const orc_rowid* id, int n_rows, const int* use, const int* big, const int* label, const int fing, const orc_limb* L) {
   const rv_config* c = &w->cfg;
   const rv_arm* arm = &w->scene.arm;
-  static __thread real A[SOLVE_ROWS + 2][SOLVE_ROWS + 2];
-  real g[SOLVE_ROWS + 2], lam[SOLVE_ROWS + 2], invk[SOLVE_ROWS + 2], bias[SOLVE_ROWS + 2], mu[SOLVE_ROWS + 2], cap[SOLVE_ROWS + 2];
-  real jf[SOLVE_ROWS + 2], pf[SOLVE_ROWS + 2], mlo[2] = {R(0.0), R(0.0)}, mhi[2] = {R(0.0), R(0.0)}; int fi[SOLVE_ROWS + 2];
+  static __thread real A[SOLVE_ROWS + 9][SOLVE_ROWS + 9];
+  real g[SOLVE_ROWS + 9], lam[SOLVE_ROWS + 9], invk[SOLVE_ROWS + 9], bias[SOLVE_ROWS + 9], mu[SOLVE_ROWS + 9], cap[SOLVE_ROWS + 9];
+  real jf[SOLVE_ROWS + 9], pf[SOLVE_ROWS + 9], mlo[2] = {R(0.0), R(0.0)}, mhi[2] = {R(0.0), R(0.0)}; int fi[SOLVE_ROWS + 9];
   const real mf = (real)c->finger_mass, imf = fing ? R(1.0) / (real)c->finger_mass : R(0.0), fdt = (real)c->finger_max_force * (real)c->dt;
   const real qf0[2] = {e->qd[RV_NLIMB], e->qd[RV_NLIMB + 1]};
-  const int n_all = n_rows + (fing ? 2 : 0);
+  /* L != NULL (rv_config.limb_dynamics, at most one awake body): the seven limb joints are DOFs as well.  Rows
+   * of the arm manifold and the seven limb motor rows (after the finger motor rows) are 'limb rows': row r has
+   * the joint-space Jacobian ja[r] (a motor row: e_j) and the velocity change per unit impulse pj[r] = M^-1 ja^T
+   * (a motor row: column j of M^-1); A_rs gains ja[r] . pj[s] */
+  const int nfm = fing ? 2 : 0, nlm = L ? RV_NLIMB : 0;
+  const int n_all = n_rows + nfm + nlm;
+  int la[SOLVE_ROWS + 9]; real ja[SOLVE_ROWS + 9][RV_NLIMB], pj[SOLVE_ROWS + 9][RV_NLIMB], dq0[RV_NLIMB];
+  for (int x = 0; x < RV_NLIMB; ++x) dq0[x] = L ? -e->limb_dv[x] : R(0.0);     /* the solve starts from the velocity before the motor step */
   int fisl = 0;      /* the island the motor rows belong to: the awake body's (there is at most one) */
   orc_j6 jx[SOLVE_ROWS][RV_MAXB];
   for (int r = 0; r < n_rows; ++r) {
@@ -1139,6 +1297,17 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
       fi[r] = rw->fidx; fisl = id[r].isl;
       if (fi[r] >= 0) { jf[r] = rw->jf[k]; pf[r] = jf[r] * imf; gg += jf[r] * qf0[fi[r]]; }
     }
+    la[r] = 0;
+    if (L) {
+      fisl = id[r].isl;
+      if (id[r].mi >= AIDX(0)) {
+        const int b_ = id[r].mi - AIDX(0);
+        la[r] = 1; invk[r] = L->invk[b_][pi][k];
+        real t = R(0.0);
+        for (int x = 0; x < RV_NLIMB; ++x) { ja[r][x] = L->Ja[b_][pi][k][x]; pj[r][x] = L->MiJ[b_][pi][k][x]; t = t + ja[r][x] * dq0[x]; }
+        gg += t;
+      }
+    }
     g[r] = gg;
   }
   for (int m = 0; fing && m < 2; ++m) {       /* motor rows */
@@ -1147,6 +1316,13 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
     g[r] = qf0[m] - e->fing_vt[m]; lam[r] = R(0.0); invk[r] = mf; bias[r] = R(0.0); mu[r] = R(0.0); cap[r] = R(0.0);
     jf[r] = R(1.0); pf[r] = imf; fi[r] = m;
     mlo[m] = -fdt - i0; mhi[m] = fdt - i0;
+    la[r] = 0;
+  }
+  for (int j = 0; j < nlm; ++j) {             /* limb motor rows */
+    const int r = n_rows + nfm + j;
+    g[r] = dq0[j] - L->tgt[j]; lam[r] = R(0.0); invk[r] = R(1.0) / L->Mi[j][j]; bias[r] = R(0.0); mu[r] = R(0.0); cap[r] = R(0.0);
+    jf[r] = R(0.0); pf[r] = R(0.0); fi[r] = -1; la[r] = 1;
+    for (int x = 0; x < RV_NLIMB; ++x) { ja[r][x] = x == j ? R(1.0) : R(0.0); pj[r][x] = L->Mi[x][j]; }
   }
   for (int r = 0; r < n_rows; ++r)
     for (int s2 = 0; s2 < n_rows; ++s2) {
@@ -1167,10 +1343,21 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
     for (int r = 0; r < n_rows; ++r) { A[r][q] = fi[r] == m ? jf[r] * pf[q] : R(0.0); A[q][r] = fi[r] == m ? pf[r] : R(0.0); }
     for (int m2 = 0; m2 < 2; ++m2) A[q][n_rows + m2] = m == m2 ? pf[q] : R(0.0);
   }
+  for (int j = 0; j < nlm; ++j) {
+    const int q = n_rows + nfm + j;
+    for (int r = 0; r < n_all; ++r) { A[r][q] = R(0.0); A[q][r] = R(0.0); }
+  }
+  for (int r = 0; L && r < n_all; ++r)
+    for (int s2 = 0; s2 < n_all; ++s2) {
+      if (!(la[r] && la[s2])) continue;
+      real t = R(0.0);
+      for (int x = 0; x < RV_NLIMB; ++x) t = t + ja[r][x] * pj[s2][x];
+      A[r][s2] = A[r][s2] + t;
+    }
   for (int s2 = 0; s2 < n_rows; ++s2) for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s2] * lam[s2];
   int isl_rows = 0, done = 0;
   for (int s2 = 0; s2 < n_rows; ++s2) isl_rows |= 1 << id[s2].isl;
-  if (fing) isl_rows |= 1 << fisl;
+  if (fing || L) isl_rows |= 1 << fisl;
   for (int it = 0; it < c->solver_iters; ++it) {
     real res[RV_MAXB] = {R(0.0), R(0.0), R(0.0), R(0.0)};
     real limtab[RV_NMAN][4];   /* friction bound of every point: mu x its normal impulse (the rows of a point need not be neighbours in the list) */
@@ -1190,6 +1377,14 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
     for (int m = 0; fing && m < 2; ++m) {
       const int q = n_rows + m;
       const real nl = rclamp(lam[q] + (-g[q] * invk[q]), mlo[m], mhi[m]);
+      const real d = nl - lam[q];
+      lam[q] = nl;
+      res[fisl] = rmax(res[fisl], rabs(d));
+      for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][q] * d;
+    }
+    for (int j = 0; j < nlm; ++j) {
+      const int q = n_rows + nfm + j;
+      const real nl = rclamp(lam[q] + (-g[q] * invk[q]), L->lo[j], L->hi[j]);
       const real d = nl - lam[q];
       lam[q] = nl;
       res[fisl] = rmax(res[fisl], rabs(d));
@@ -1232,6 +1427,16 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
     if (qn < (real)arm->q_lo[j]) { qn = (real)arm->q_lo[j]; qd = R(0.0); }
     if (qn > (real)arm->q_hi[j]) { qn = (real)arm->q_hi[j]; qd = R(0.0); }
     e->q[j] = qn; e->qd[j] = qd;
+  }
+  for (int x = 0; x < nlm; ++x) {              /* the limb moves with the solved velocity */
+    real dq = dq0[x];
+    for (int s2 = 0; s2 < n_all; ++s2) if (la[s2]) dq = dq + pj[s2][x] * lam[s2];
+    real qd = e->limb_qd0[x] + dq;
+    real qn = e->q[x] + dq * (real)c->dt;
+    if (qn < (real)arm->q_lo[x]) { qn = (real)arm->q_lo[x]; qd = R(0.0); }
+    if (qn > (real)arm->q_hi[x]) { qn = (real)arm->q_hi[x]; qd = R(0.0); }
+    e->q[x] = qn; e->qd[x] = qd;
+    e->limb_lam[x] = lam[n_rows + nfm + x];
   }
 }
 
@@ -1305,20 +1510,33 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
     }
   {
     /* an awake body with a user constraint: everything goes through the velocity-space system solver */
-    int any_con = 0;
+    int any_con = 0, limb = 0;
     for (int b = 0; b < RV_MAXB; ++b) any_con |= use[TIDX(b)] && e->bp[b].con_on;
-    if (any_con) { solve_with_fingers(w, e, rows, use); return; }
+    /* limb dynamics: an awake body touches the arm -> the joint velocities are unknowns too */
+    if (c->limb_dynamics && e->arm_enabled) for (int b = 0; b < RV_MAXB; ++b) limb |= use[AIDX(b)] && e->man[AIDX(b)].n > 0;
+    if (limb) {
+      /* one awake body and no user constraint: impulse space with the limb (and finger) DOFs and motor rows;
+       * else the velocity-space system solver */
+      orc_limb L; limb_prepare(w, e, rows, use, &L);
+      int n_on = 0;
+      for (int b = 0; b < RV_MAXB; ++b) n_on += use[TIDX(b)];
+      if (n_on <= 1 && !any_con && !getenv("ORC_LIMB_SYS")) solve_rows(w, e, rows, id, n_rows, use, big, label, c->finger_dynamics && e->arm_enabled, &L);
+      else solve_with_fingers(w, e, rows, use, &L);
+      arm_update_kinematics(w, e);      /* the link frames follow the solved joint state */
+      return;
+    }
+    if (any_con) { solve_with_fingers(w, e, rows, use, NULL); return; }
   }
   if (c->finger_dynamics && e->arm_enabled) {
     /* at most one awake body (a grasp scene): impulse space, fingers included; else the
      * velocity-space system solver */
     int n_on = 0;
     for (int b = 0; b < RV_MAXB; ++b) n_on += use[TIDX(b)];
-    if (n_on <= 1) solve_rows(w, e, rows, id, n_rows, use, big, label, 1);
-    else solve_with_fingers(w, e, rows, use);
+    if (n_on <= 1) solve_rows(w, e, rows, id, n_rows, use, big, label, 1, NULL);
+    else solve_with_fingers(w, e, rows, use, NULL);
     return;
   }
-  if (n_rows > 0) solve_rows(w, e, rows, id, n_rows, use, big, label, 0);
+  if (n_rows > 0) solve_rows(w, e, rows, id, n_rows, use, big, label, 0, NULL);
   /* big islands: warm start first */
   for (int b = 0; b < RV_MAXB; ++b)
     for (int kind = 0; kind <= 2; kind += 2) {

@@ -60,6 +60,7 @@ class rv_arm(C.Structure):
         ('col_center', (f32 * 3) * RV_NCOL),
         ('col_half', (f32 * 3) * RV_NCOL),
         ('inv_tau_max', f32 * RV_NJ),
+        ('link_mass', f32 * (RV_NLIMB + 1)), ('link_com', (f32 * 3) * (RV_NLIMB + 1)), ('link_inertia', (f32 * 3) * (RV_NLIMB + 1)),
     ]
 
 
@@ -136,7 +137,7 @@ class rv_config(C.Structure):
         ('max_action_steps', i32), ('end_effector_step', f32),
         ('grasp_mu_descend', f32 * 2), ('grasp_mu_lift', f32 * 2),
         ('ground_z', f32), ('ground_friction', f32), ('rolling_friction', f32), ('wake_gap', f32), ('deact_lin', f32), ('deact_ang', f32), ('deact_steps', i32),
-        ('gravity_xy', f32 * 2), ('arm_effort_limit', i32),
+        ('gravity_xy', f32 * 2), ('arm_effort_limit', i32), ('limb_dynamics', i32),
     ]
 
 

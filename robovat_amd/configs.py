@@ -231,6 +231,7 @@ def make_rv_config(env_cfg=None, robot_cfg=None, shape_names=None, n_envs=1,
     c.dt = ph.TIME_STEP
     c.gravity_z = ph.GRAVITY_Z
     c.arm_effort_limit = int(ph.get('ARM_EFFORT_LIMIT', 0))
+    c.limb_dynamics = int(ph.get('LIMB_DYNAMICS', 0))
     gxy = ph.get('GRAVITY_XY', (0.0, 0.0))
     c.gravity_xy[0], c.gravity_xy[1] = float(gxy[0]), float(gxy[1])
     c.solver_iters = ph.SOLVER_ITERS

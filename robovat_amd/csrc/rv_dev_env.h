@@ -195,6 +195,14 @@ struct Scratch {
   float lq[RV_NLIMB][4];
   float vdraw[RV_NJ], ratio[RV_NJ];      // motor phase: raw commanded velocity, limit factor
   float fing_dv[2], fing_vt[2], fing_qd0[2];   // finger motors this substep: velocity step taken, commanded velocity, velocity after it
+  // limb dynamics (rv_config.limb_dynamics): the same of the limb joints; centres of mass, joint-space
+  // inertia, the Gauss-Jordan workspace [M | 1] -> [. | M^-1], generalised gravity force, motor-row bounds
+  // and targets; per arm contact row (12 x body + 3 x point + direction) the joint-space Jacobian,
+  // M^-1 Ja^T and the effective mass
+  float limb_dv[RV_NLIMB], limb_vt[RV_NLIMB], limb_qd0[RV_NLIMB];
+  float lcom[RV_NLIMB + 1][3], lA[RV_NLIMB][2 * RV_NLIMB], lGq[RV_NLIMB];
+  float llo[RV_NLIMB], lhi[RV_NLIMB], ltgt[RV_NLIMB];
+  float lJa[RV_MAXB * 12 + RV_NLIMB][RV_NLIMB], lMiJ[RV_MAXB * 12 + RV_NLIMB][RV_NLIMB], linvk[RV_MAXB * 12];   // (the last seven: the motor rows, e_j and column j of M^-1)
   int jmoving[RV_NJ], jchg[RV_NJ];
   float rvec[RV_NLIMB + 1][3];           // FK: link offsets rotated into the world
   int jt_applied;                        // the motor targets hold the current joint target (per launch)
@@ -1054,33 +1062,157 @@ RV_DEV void warm_apply(BV& A, BV* B, float ima, float imb, const Lam& l, const R
 // finger_max_force: the joint motors of the light part have already spent m * fing_dv of that
 // budget on the free motion, the row may add the rest.  Velocity-space Gauss-Seidel over ALL
 // awake bodies and both fingers as one system, one lane (a grasp scene has one body).
-RV_DEV float point_solve_g(BV& A, float ima, Lam& l, const Row& r, float* qf, float imf) {
+// ---- limb dynamics (rv_config.limb_dynamics) ----------------------------------
+// While the arm touches an awake body the seven limb joints are unknowns of the solver (PyBullet: the
+// arm is a btMultiBody whose POSITION_CONTROL motors are constraint rows of the same PGS,
+// controllable_body.py:458-466, bullet_physics.py:1061-1104).  The unknown is the DEVIATION dq of the
+// joint velocities from the ones the motor law of this substep commanded (limb_qd0): the link twists
+// the contact rows were set up with stay as they are, a contact row on a collider of frame f gets the
+// joint-space Jacobian  Ja_j = -dir . (axis_j x (p - p_j)), j <= min(f, 6), an impulse dl on it changes
+// dq by M^-1 Ja^T dl, and its effective mass gains Ja M^-1 Ja^T.  M(q) is the joint-space inertia of
+// the chain of eight masses (links 0..6 and the hand):
+//   M_jk = sum_{i >= max(j,k)} m_i (a_j x (c_i - p_j)) . (a_k x (c_i - p_k)) + (R_i^T a_j) . I_i (R_i^T a_k)
+// (the composite-rigid-body sum written out for revolute joints; velocity-product terms are neglected:
+// the limb moves at < 1 rad/s).  The solve starts from the joint velocities BEFORE the motor step of
+// this substep (dq = -limb_dv: the acceleration limits of the kinematic motor law are no statement about
+// torques).  Motor row j: J = e_j, target dq_j = commanded - current velocity, accumulated impulse within
+// +- tau_j dt minus the torque that holds the chain against gravity.  After the solve the joints move
+// with the solved velocity and the link frames are recomputed.
+// limb_prepare: wave-wide -- one lane per entry of M, per column of the Gauss-Jordan elimination of
+// [M | 1], per contact row; the Gauss-Seidel itself is the velocity-space system solver below.
+RV_DEV void limb_prepare(Shared& S, const Consts& K) {
+  const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
+  RV_LANES_BEGIN
+    if (lane <= RV_NLIMB) st3(S.s.lcom[lane], add(ld3(S.e.fpos[lane]), mulv(S.s.frot[lane], ld3(arm->link_com[lane]))));
+  RV_LANES_END
+  RV_LANES_BEGIN
+    const DevEnv& e = S.e;
+    if (lane < RV_NLIMB * RV_NLIMB) {
+      const int j = lane / RV_NLIMB, k = lane - j * RV_NLIMB, mx = j > k ? j : k;
+      const v3 aj = ld3(S.s.axis[j]), ak = ld3(S.s.axis[k]), pj = ld3(e.fpos[j]), pk = ld3(e.fpos[k]);
+      float acc = 0.0f;
+      for (int i = 0; i <= RV_NLIMB; ++i) {
+        if (i < mx) continue;
+        const v3 ci = ld3(S.s.lcom[i]);
+        const v3 lj = cross(aj, sub(ci, pj)), lk = cross(ak, sub(ci, pk));
+        const float t = arm->link_mass[i] * dot(lj, lk);
+        const v3 bj = tmulv(S.s.frot[i], aj), bk = tmulv(S.s.frot[i], ak);
+        const float r = (bj.x * bk.x) * arm->link_inertia[i][0] + (bj.y * bk.y) * arm->link_inertia[i][1]
+                      + (bj.z * bk.z) * arm->link_inertia[i][2];
+        acc = acc + (t + r);
+      }
+      S.s.lA[j][k] = acc; S.s.lA[j][RV_NLIMB + k] = j == k ? 1.0f : 0.0f;
+    } else if (lane >= 56 && lane < 56 + RV_NLIMB) {
+      const int j = lane - 56;
+      const v3 aj = ld3(S.s.axis[j]), pj = ld3(e.fpos[j]), g = mk(c->gravity_xy[0], c->gravity_xy[1], c->gravity_z);
+      float gq = 0.0f;
+      for (int i = 0; i <= RV_NLIMB; ++i) {
+        if (i < j) continue;
+        const v3 lj = cross(aj, sub(ld3(S.s.lcom[i]), pj));
+        gq = gq + arm->link_mass[i] * dot(lj, g);
+      }
+      S.s.lGq[j] = gq;
+    }
+  RV_LANES_END
+  // M^-1 by Gauss-Jordan on [M | 1] without pivoting (M is symmetric positive definite), one lane per
+  // column; a column that has been the pivot column is not touched again
+  for (int p = 0; p < RV_NLIMB; ++p) {
+    RV_LANES_BEGIN
+      if (lane < 2 * RV_NLIMB && lane > p) {
+        const int col = lane;
+        const float ap = S.s.lA[p][col] / S.s.lA[p][p];
+        for (int r = 0; r < RV_NLIMB; ++r) if (r != p) S.s.lA[r][col] = S.s.lA[r][col] - S.s.lA[r][p] * ap;
+        S.s.lA[p][col] = ap;
+      }
+    RV_LANES_END
+  }
+  RV_LANES_BEGIN
+    const DevEnv& e = S.e; const float dt = c->dt;
+    if (lane < RV_NLIMB) {
+      const int j = lane;
+      const float hold = -S.s.lGq[j] * dt;
+      const float tdt = arm->inv_tau_max[j] > 0.0f ? dt / arm->inv_tau_max[j] : 1e30f;
+      S.s.llo[j] = fminr(0.0f, -tdt - hold); S.s.lhi[j] = fmaxr(0.0f, tdt - hold);
+      S.s.ltgt[j] = S.s.limb_vt[j] - S.s.limb_qd0[j];
+#pragma unroll
+      for (int x = 0; x < RV_NLIMB; ++x) { S.s.lJa[RV_MAXB * 12 + j][x] = x == j ? 1.0f : 0.0f; S.s.lMiJ[RV_MAXB * 12 + j][x] = S.s.lA[x][RV_NLIMB + j]; }
+    } else if (lane >= 8 && lane < 8 + RV_MAXB * 12) {
+      const int row = lane - 8, b = row / 12, i = (row - b * 12) / 3, k = row - b * 12 - i * 3;
+      const DevMan& m = e.man[RV_AIDX(b)];
+      if (body_on(e, b) && i < m.n) {
+        const int f = arm->col_frame[m.col[i]], fl = f < RV_NLIMB ? f : RV_NLIMB - 1;
+        const v3 wb = to_world_frame(S, f, ld3(m.lb[i]));
+        const Row& r = S.s.u.r.rows[RV_AIDX(b)][i];
+        const v3 dk = ld3(r.dir[k]);
+        float ja[RV_NLIMB];
+#pragma unroll
+        for (int j = 0; j < RV_NLIMB; ++j) {
+          const v3 lever = cross(ld3(S.s.axis[j]), sub(wb, ld3(e.fpos[j])));
+          ja[j] = j <= fl ? -dot(dk, lever) : 0.0f;
+          S.s.lJa[row][j] = ja[j];
+        }
+        float kk = 1.0f / r.invk[k];
+        float mij[RV_NLIMB];
+#pragma unroll
+        for (int j = 0; j < RV_NLIMB; ++j) {
+          float a_ = 0.0f;
+#pragma unroll
+          for (int x = 0; x < RV_NLIMB; ++x) a_ = a_ + S.s.lA[j][RV_NLIMB + x] * ja[x];
+          mij[j] = a_; S.s.lMiJ[row][j] = a_;
+        }
+#pragma unroll
+        for (int j = 0; j < RV_NLIMB; ++j) kk = kk + ja[j] * mij[j];
+        S.s.linvk[row] = 1.0f / kk;
+      }
+    }
+  RV_LANES_END
+}
+RV_DEV float limb_jv(const float* Ja, const float* dq) {
+  float a_ = 0.0f;
+#pragma unroll
+  for (int j = 0; j < RV_NLIMB; ++j) a_ = a_ + Ja[j] * dq[j];
+  return a_;
+}
+RV_DEV void limb_apply(const float* MiJ, float* dq, float dl) {
+#pragma unroll
+  for (int j = 0; j < RV_NLIMB; ++j) dq[j] = dq[j] + MiJ[j] * dl;
+}
+// lj / lm / lk: the limb Jacobians Ja[3][7], M^-1 Ja^T [3][7] and effective masses [3] of an arm row in
+// limb_dynamics mode (null otherwise), dq: the deviation of the joint velocities
+RV_DEV float point_solve_g(BV& A, float ima, Lam& l, const Row& r, float* qf, float imf,
+                           const float (*lj)[RV_NLIMB], const float (*lm)[RV_NLIMB], const float* lk, float* dq) {
   const int fi = r.fidx;
   float jv = row_jv(A, nullptr, r, 0);
   if (fi >= 0) jv += r.jf[0] * qf[fi];
-  float dl = (r.target - jv) * r.invk[0];
+  if (lj) jv += limb_jv(lj[0], dq);
+  float dl = (r.target - jv) * (lj ? lk[0] : r.invk[0]);
   float ln = fclampr(l.n + dl, 0.0f, r.cap);
   dl = ln - l.n; l.n = ln;
   float res = fabsr(dl);
   row_apply(A, nullptr, ima, 0.0f, r, 0, dl);
   if (fi >= 0) qf[fi] += r.jf[0] * dl * imf;
+  if (lj) limb_apply(lm[0], dq, dl);
   float lim = r.mu * ln;
   jv = row_jv(A, nullptr, r, 1);
   if (fi >= 0) jv += r.jf[1] * qf[fi];
-  dl = -jv * r.invk[1];
+  if (lj) jv += limb_jv(lj[1], dq);
+  dl = -jv * (lj ? lk[1] : r.invk[1]);
   float l1 = fclampr(l.t1 + dl, -lim, lim);
   dl = l1 - l.t1; l.t1 = l1;
   res = fmaxr(res, fabsr(dl));
   row_apply(A, nullptr, ima, 0.0f, r, 1, dl);
   if (fi >= 0) qf[fi] += r.jf[1] * dl * imf;
+  if (lj) limb_apply(lm[1], dq, dl);
   jv = row_jv(A, nullptr, r, 2);
   if (fi >= 0) jv += r.jf[2] * qf[fi];
-  dl = -jv * r.invk[2];
+  if (lj) jv += limb_jv(lj[2], dq);
+  dl = -jv * (lj ? lk[2] : r.invk[2]);
   float l2 = fclampr(l.t2 + dl, -lim, lim);
   dl = l2 - l.t2; l.t2 = l2;
   res = fmaxr(res, fabsr(dl));
   row_apply(A, nullptr, ima, 0.0f, r, 2, dl);
   if (fi >= 0) qf[fi] += r.jf[2] * dl * imf;
+  if (lj) limb_apply(lm[2], dq, dl);
   return res;
 }
 // The six rows of a user constraint on body b (a fixed joint to a frame of the world: the mocap-style
@@ -1121,8 +1253,11 @@ RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
   }
   return res;
 }
-RV_DEV void solve_with_fingers(Shared& S, const Consts& K) {
+RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb) {
   DevEnv& e = S.e; const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
+  float dq[RV_NLIMB], lam_l[RV_NLIMB];
+#pragma unroll
+  for (int j = 0; j < RV_NLIMB; ++j) { dq[j] = limb ? -S.s.limb_dv[j] : 0.0f; lam_l[j] = 0.0f; }   // (the solve starts from the velocity before the motor step)
   const int fd = c->finger_dynamics && e.arm_enabled;            // the finger joints are DOFs of the system
   const float mf = c->finger_mass, imf = 1.0f / c->finger_mass, fdt = c->finger_max_force * c->dt;
   float qf[2] = {e.qd[RV_NLIMB], e.qd[RV_NLIMB + 1]}, lam_m[2] = {0.0f, 0.0f};
@@ -1139,10 +1274,15 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K) {
         for (int i = 0; i < m.n; ++i) {
           Row r = S.s.u.r.rows[mi][i];
           Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
+          const int la = limb && kind == 1, lrow = b * 12 + i * 3;
           if (it < 0) {
             warm_apply(A, nullptr, ima, 0.0f, l, r);
             if (r.fidx >= 0) { qf[r.fidx] += r.jf[0] * l.n * imf; qf[r.fidx] += r.jf[1] * l.t1 * imf; qf[r.fidx] += r.jf[2] * l.t2 * imf; }
-          } else { res = fmaxr(res, point_solve_g(A, ima, l, r, qf, imf)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
+            if (la) { limb_apply(S.s.lMiJ[lrow], dq, l.n); limb_apply(S.s.lMiJ[lrow + 1], dq, l.t1); limb_apply(S.s.lMiJ[lrow + 2], dq, l.t2); }
+          } else {
+            res = fmaxr(res, point_solve_g(A, ima, l, r, qf, imf, la ? &S.s.lJa[lrow] : nullptr, la ? &S.s.lMiJ[lrow] : nullptr, la ? &S.s.linvk[lrow] : nullptr, dq));
+            m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2;
+          }
         }
       }
       st_bv(e, b, A);
@@ -1174,8 +1314,24 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K) {
       qf[f] += dl * imf;
       res = fmaxr(res, fabsr(dl));
     }
+    for (int j = 0; limb && j < RV_NLIMB; ++j) {   // limb motor rows
+      float dl = (S.s.ltgt[j] - dq[j]) / S.s.lA[j][RV_NLIMB + j];
+      const float ln = fclampr(lam_l[j] + dl, S.s.llo[j], S.s.lhi[j]);
+      dl = ln - lam_l[j]; lam_l[j] = ln;
+#pragma unroll
+      for (int k = 0; k < RV_NLIMB; ++k) dq[k] = dq[k] + S.s.lA[k][RV_NLIMB + j] * dl;
+      res = fmaxr(res, fabsr(dl));
+    }
     if (res < c->solver_tol) break;
   }
+  for (int j = 0; limb && j < RV_NLIMB; ++j) {   // the limb moves with the solved velocity
+    float qd = S.s.limb_qd0[j] + dq[j];
+    float qn = e.q[j] + dq[j] * c->dt;
+    if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
+    if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
+    e.q[j] = qn; e.qd[j] = qd;
+  }
+  if (limb) S.s.kin_fresh = 0;                   // the frames no longer match the joints
   for (int f = 0; fd && f < 2; ++f) {        // the fingers move with the solved velocity
     const int j = RV_NLIMB + f;
     float qd = qf[f];
@@ -1442,7 +1598,12 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
 // with the rows of its finger through jf / m, and with itself through 1 / m.  Visiting order: the contact
 // rows, then the two motor rows; the motor impulse stays within +-finger_max_force dt minus what the
 // joint motors of the light part already spent on the free motion.  Same arithmetic as solve_rows(fing).
-RV_DEV void solve_island_fingers(Shared& S, const Consts& K, const int X) {
+// LIMB (rv_config.limb_dynamics): lanes 26..32 are the motor rows of the seven limb joints; the rows of the
+// arm manifold and these motor rows are 'limb rows' with a joint-space Jacobian ja (a motor row: e_j) and the
+// velocity change per unit impulse pj = M^-1 ja^T (a motor row: column j of M^-1), both prepared in LDS by
+// limb_prepare; the Delassus entry of two limb rows gains ja_r . pj_s.
+template <bool LIMB>
+RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, const int with_fingers) {
   DevEnv& e = S.e; const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
   const int lane = (int)threadIdx.x;
   const int Xc = X >= 0 ? X : 0;
@@ -1453,7 +1614,10 @@ RV_DEV void solve_island_fingers(Shared& S, const Consts& K, const int X) {
   const int p = L / 3, k = L - 3 * p, slot = p & 3;
   const int mi = p < 4 ? RV_TIDX(Xc) : RV_AIDX(Xc);
   const bool act = lane < 24 && (p < 4 ? p < ntx : p - 4 < nax);
-  const bool motor = lane == 24 || lane == 25;
+  const bool motor = with_fingers && (lane == 24 || lane == 25);
+  const bool lmotor = LIMB && lane >= 26 && lane < 26 + RV_NLIMB;
+  const int lj = lmotor ? lane - 26 : 0;
+  constexpr int NA = LIMB ? 26 + RV_NLIMB : 26, CS = LIMB ? 16 : 8;
   const int mid = lane == 25 ? 1 : 0;
   const Row& R = S.s.u.r.rows[mi][slot];
   DevMan& mm = e.man[mi];
@@ -1477,8 +1641,31 @@ RV_DEV void solve_island_fingers(Shared& S, const Consts& K, const int X) {
     g = (mid == 0 ? qf0a : qf0b) - S.s.fing_vt[mid]; invk = mf; jf = 1.0f; pf = imf; fi = mid;
     lo = -fdt - i0; hi = fdt - i0;
   }
+  // limb rows
+  const bool la = LIMB && ((act && p >= 4) || lmotor);
+  const int lrow = lmotor ? RV_MAXB * 12 + lj : Xc * 12 + slot * 3 + k;
+  float ja[RV_NLIMB], pj[RV_NLIMB];
+#pragma unroll
+  for (int x = 0; x < RV_NLIMB; ++x) { ja[x] = 0.0f; pj[x] = 0.0f; }
+  if (LIMB) {
+    if (la) {
+#pragma unroll
+      for (int x = 0; x < RV_NLIMB; ++x) { ja[x] = S.s.lJa[lrow][x]; pj[x] = S.s.lMiJ[lrow][x]; }
+    }
+    if (act && p >= 4) {
+      invk = S.s.linvk[lrow];
+      float t = 0.0f;
+#pragma unroll
+      for (int x = 0; x < RV_NLIMB; ++x) t = t + ja[x] * (-S.s.limb_dv[x]);     // (the solve starts from the velocity before the motor step)
+      g += t;
+    }
+    if (lmotor) {
+      g = (-S.s.limb_dv[lj]) - S.s.ltgt[lj]; invk = 1.0f / S.s.lA[lj][RV_NLIMB + lj];
+      lo = S.s.llo[lj]; hi = S.s.lhi[lj];
+    }
+  }
   // this lane's row of the Delassus matrix: columns 0..23 the contact rows, 24 / 25 the motor rows
-  float A[26];
+  float A[NA];
 #pragma unroll
   for (int s = 0; s < 24; ++s) {
     float a_ = 0.0f;
@@ -1489,11 +1676,31 @@ RV_DEV void solve_island_fingers(Shared& S, const Consts& K, const int X) {
       const float pfs = rdlane(pf, s);
       if (motor) a_ = fs == fi ? pfs : 0.0f;                    // a motor row sees the rows of its finger through jf_s / m
       else if (fi >= 0 && fs == fi) a_ = a_ + jf * pfs;
+      if (LIMB) {
+        if (lmotor) a_ = 0.0f;
+        if (ps >= 4) {
+          const float* pjs = S.s.lMiJ[Xc * 12 + (s - 12)];
+          float t = 0.0f;
+#pragma unroll
+          for (int x = 0; x < RV_NLIMB; ++x) t = t + ja[x] * pjs[x];
+          if (la) a_ = a_ + t;
+        }
+      }
     }
     A[s] = a_;
   }
 #pragma unroll
   for (int m = 0; m < 2; ++m) A[24 + m] = (fi == m) ? jf * imf : 0.0f;   // (motor row m on itself: 1 x 1 / m)
+  if (LIMB) {
+#pragma unroll
+    for (int j = 0; j < RV_NLIMB; ++j) {
+      const float* pjs = S.s.lMiJ[RV_MAXB * 12 + j];
+      float t = 0.0f;
+#pragma unroll
+      for (int x = 0; x < RV_NLIMB; ++x) t = t + ja[x] * pjs[x];
+      A[26 + j] = la ? 0.0f + t : 0.0f;
+    }
+  }
   // warm start: the contact impulses kept from the last substep (the motor rows start from zero)
 #pragma unroll
   for (int s = 0; s < 24; ++s) { const int ps = s / 3; if (ps < 4 ? ps < ntx : ps - 4 < nax) g = g + A[s] * rdlane(lam, s); }
@@ -1532,54 +1739,97 @@ RV_DEV void solve_island_fingers(Shared& S, const Consts& K, const int X) {
       resi = resi > mag ? resi : mag;
       g = g + A[s] * __builtin_bit_cast(float, sdi);
     }
+    if (LIMB) {
+#pragma unroll
+      for (int j = 0; j < RV_NLIMB; ++j) {
+        const int s = 26 + j;
+        const float nl = __builtin_amdgcn_fmed3f(lam + (-g * invk), lo, hi);
+        const float d = nl - lam;
+        if (lane == s) lam = nl;
+        const int sdi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), s);
+        const int mag = sdi & 0x7fffffff;
+        resi = resi > mag ? resi : mag;
+        g = g + A[s] * __builtin_bit_cast(float, sdi);
+      }
+    }
     if (tol > 0.0f ? resi < toli : false) break;
   }
-  // impulses back to the manifolds; body and finger velocities rebuilt in row order through LDS
+  // impulses back to the manifolds; body, finger and limb velocities rebuilt in row order through LDS
   float* cb = &S.s.u.r.wv[0][0][0][0];
   if (act) { if (k == 0) mm.ln[slot] = lam; else if (k == 1) mm.lt1[slot] = lam; else mm.lt2[slot] = lam; }
-  if (lane < 26) {
-    float* o = cb + 8 * lane;
+  if (lane < NA) {
+    float* o = cb + CS * lane;
     o[0] = PX.l.x * lam; o[1] = PX.l.y * lam; o[2] = PX.l.z * lam; o[3] = PX.a.x * lam; o[4] = PX.a.y * lam; o[5] = PX.a.z * lam;
     o[6] = pf * lam; o[7] = __builtin_bit_cast(float, fi);
+    if (LIMB) {
+#pragma unroll
+      for (int x = 0; x < RV_NLIMB; ++x) o[8 + x] = pj[x] * lam;
+    }
   }
   __syncthreads();
   if (lane < 6 && X >= 0) {
     float acc = e.body[Xc][7 + lane];
     float t[24];
 #pragma unroll
-    for (int s = 0; s < 24; ++s) t[s] = cb[8 * s + lane];
+    for (int s = 0; s < 24; ++s) t[s] = cb[CS * s + lane];
 #pragma unroll
     for (int s = 0; s < 24; ++s) acc = acc + t[s];
     e.body[Xc][7 + lane] = acc;
-  } else if (lane == 8 || lane == 9) {
+  } else if (with_fingers && (lane == 8 || lane == 9)) {
     const int m = lane - 8;
     float qd = m == 0 ? qf0a : qf0b;
     for (int s = 0; s < 24; ++s) {
       const int ps = s / 3;
       if (!(ps < 4 ? ps < ntx : ps - 4 < nax)) continue;
-      if (__builtin_bit_cast(int, cb[8 * s + 7]) == m) qd = qd + cb[8 * s + 6];
+      if (__builtin_bit_cast(int, cb[CS * s + 7]) == m) qd = qd + cb[CS * s + 6];
     }
-    qd = qd + cb[8 * (24 + m) + 6];
+    qd = qd + cb[CS * (24 + m) + 6];
     const int j = RV_NLIMB + m;
     float qn = e.q[j] + (qd - S.s.fing_qd0[m]) * c->dt;
     if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
     if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
     e.q[j] = qn; e.qd[j] = qd;
+  } else if (LIMB && lane >= 16 && lane < 16 + RV_NLIMB) {
+    // the limb moves with the solved velocity: dq = dq0 + sum over the limb rows, in row order
+    const int x = lane - 16;
+    float dq = -S.s.limb_dv[x];
+    for (int s = 12; s < 24; ++s) {
+      if (!((s / 3) - 4 < nax)) continue;
+      dq = dq + cb[CS * s + 8 + x];
+    }
+    for (int j = 0; j < RV_NLIMB; ++j) dq = dq + cb[CS * (26 + j) + 8 + x];
+    float qd = S.s.limb_qd0[x] + dq;
+    float qn = e.q[x] + dq * c->dt;
+    if (qn < arm->q_lo[x]) { qn = arm->q_lo[x]; qd = 0.0f; }
+    if (qn > arm->q_hi[x]) { qn = arm->q_hi[x]; qd = 0.0f; }
+    e.q[x] = qn; e.qd[x] = qd;
   }
+  if (LIMB && lane == 63) S.s.kin_fresh = 0;
   __syncthreads();
+}
+RV_DEV void solve_island_fingers(Shared& S, const Consts& K, const int X, const int with_fingers, const int limb) {
+  if (limb) solve_island_fingers_t<true>(S, K, X, with_fingers);
+  else solve_island_fingers_t<false>(S, K, X, with_fingers);
 }
 #else
 // fing != 0 (rv_config.finger_dynamics, at most one awake body): the two finger joints are DOFs of
 // the system as well -- contact rows on a finger pad carry jf on their finger's velocity, each finger
 // has a motor row after the contact rows (see solve_island_fingers, the device version)
-RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int fing) {
+RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int fing, const int limb) {
   DevEnv& e = S.e; const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
-  static thread_local float A[RV_SOLVE_ROWS + 2][RV_SOLVE_ROWS + 2];
-  float g[RV_SOLVE_ROWS + 2], lam[RV_SOLVE_ROWS + 2], invk[RV_SOLVE_ROWS + 2], bias[RV_SOLVE_ROWS + 2], mu[RV_SOLVE_ROWS + 2], cap[RV_SOLVE_ROWS + 2];
-  float jf[RV_SOLVE_ROWS + 2], pf[RV_SOLVE_ROWS + 2], mlo[2] = {0.0f, 0.0f}, mhi[2] = {0.0f, 0.0f}; int fi[RV_SOLVE_ROWS + 2];
+  static thread_local float A[RV_SOLVE_ROWS + 9][RV_SOLVE_ROWS + 9];
+  float g[RV_SOLVE_ROWS + 9], lam[RV_SOLVE_ROWS + 9], invk[RV_SOLVE_ROWS + 9], bias[RV_SOLVE_ROWS + 9], mu[RV_SOLVE_ROWS + 9], cap[RV_SOLVE_ROWS + 9];
+  float jf[RV_SOLVE_ROWS + 9], pf[RV_SOLVE_ROWS + 9], mlo[2] = {0.0f, 0.0f}, mhi[2] = {0.0f, 0.0f}; int fi[RV_SOLVE_ROWS + 9];
   const float mf = c->finger_mass, imf = fing ? 1.0f / c->finger_mass : 0.0f, fdt = c->finger_max_force * c->dt;
   const float qf0[2] = {e.qd[RV_NLIMB], e.qd[RV_NLIMB + 1]};
-  const int n_all = n_rows + (fing ? 2 : 0);
+  // limb != 0 (rv_config.limb_dynamics, at most one awake body): the seven limb joints are DOFs as well.
+  // Rows of the arm manifold and the seven limb motor rows (after the finger motor rows) are 'limb rows':
+  // row r has the joint-space Jacobian ja[r] (a motor row: e_j) and the velocity change per unit impulse
+  // pj[r] = M^-1 ja^T (a motor row: column j of M^-1); A_rs gains ja[r] . pj[s]
+  const int nfm = fing ? 2 : 0, nlm = limb ? RV_NLIMB : 0;
+  const int n_all = n_rows + nfm + nlm;
+  int la[RV_SOLVE_ROWS + 9]; float ja[RV_SOLVE_ROWS + 9][RV_NLIMB], pj[RV_SOLVE_ROWS + 9][RV_NLIMB], dq0[RV_NLIMB];
+  for (int x = 0; x < RV_NLIMB; ++x) dq0[x] = limb ? -S.s.limb_dv[x] : 0.0f;     // the solve starts from the velocity before the motor step
   int fisl = 0;
   J6 jx[RV_SOLVE_ROWS][RV_MAXB];
   for (int r = 0; r < n_rows; ++r) {
@@ -1603,6 +1853,17 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
       fi[r] = R.fidx; fisl = RV_ROW_ISL(rm);
       if (fi[r] >= 0) { jf[r] = R.jf[k]; pf[r] = jf[r] * imf; gg += jf[r] * qf0[fi[r]]; }
     }
+    la[r] = 0;
+    if (limb) {
+      fisl = RV_ROW_ISL(rm);
+      if (mi >= RV_AIDX(0)) {
+        const int lrow = (mi - RV_AIDX(0)) * 12 + pi * 3 + k;
+        la[r] = 1; invk[r] = S.s.linvk[lrow];
+        float t = 0.0f;
+        for (int x = 0; x < RV_NLIMB; ++x) { ja[r][x] = S.s.lJa[lrow][x]; pj[r][x] = S.s.lMiJ[lrow][x]; t = t + ja[r][x] * dq0[x]; }
+        gg += t;
+      }
+    }
     g[r] = gg;
     jx[r][ra].l = dir; jx[r][ra].a = rxa;
     if (rb >= 0) { jx[r][rb].l = nd; jx[r][rb].a = nrxb; }
@@ -1613,6 +1874,13 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
     g[r] = qf0[m] - S.s.fing_vt[m]; lam[r] = 0.0f; invk[r] = mf; bias[r] = 0.0f; mu[r] = 0.0f; cap[r] = 0.0f;
     jf[r] = 1.0f; pf[r] = imf; fi[r] = m;
     mlo[m] = -fdt - i0; mhi[m] = fdt - i0;
+    la[r] = 0;
+  }
+  for (int j = 0; j < nlm; ++j) {             // limb motor rows
+    const int r = n_rows + nfm + j, lrow = RV_MAXB * 12 + j;
+    g[r] = dq0[j] - S.s.ltgt[j]; lam[r] = 0.0f; invk[r] = 1.0f / S.s.lA[j][RV_NLIMB + j]; bias[r] = 0.0f; mu[r] = 0.0f; cap[r] = 0.0f;
+    jf[r] = 0.0f; pf[r] = 0.0f; fi[r] = -1; la[r] = 1;
+    for (int x = 0; x < RV_NLIMB; ++x) { ja[r][x] = S.s.lJa[lrow][x]; pj[r][x] = S.s.lMiJ[lrow][x]; }
   }
   for (int r = 0; r < n_rows; ++r)
     for (int s = 0; s < n_rows; ++s) {
@@ -1633,10 +1901,21 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
     for (int r = 0; r < n_rows; ++r) { A[r][q] = fi[r] == m ? jf[r] * pf[q] : 0.0f; A[q][r] = fi[r] == m ? pf[r] : 0.0f; }
     for (int m2 = 0; m2 < 2; ++m2) A[q][n_rows + m2] = m == m2 ? pf[q] : 0.0f;
   }
+  for (int j = 0; j < nlm; ++j) {
+    const int q = n_rows + nfm + j;
+    for (int r = 0; r < n_all; ++r) { A[r][q] = 0.0f; A[q][r] = 0.0f; }
+  }
+  for (int r = 0; limb && r < n_all; ++r)
+    for (int s = 0; s < n_all; ++s) {
+      if (!(la[r] && la[s])) continue;
+      float t = 0.0f;
+      for (int x = 0; x < RV_NLIMB; ++x) t = t + ja[r][x] * pj[s][x];
+      A[r][s] = A[r][s] + t;
+    }
   for (int s = 0; s < n_rows; ++s) for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s] * lam[s];
   int isl_rows = 0, done = 0;
   for (int s = 0; s < n_rows; ++s) isl_rows |= 1 << RV_ROW_ISL(S.s.rowmap[s]);
-  if (fing) isl_rows |= 1 << fisl;
+  if (fing || limb) isl_rows |= 1 << fisl;
   RV_CNT(21, 1) RV_CNT(23, n_rows)
   for (int it = 0; it < c->solver_iters; ++it) {
     RV_CNT(22, 1)
@@ -1665,6 +1944,14 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
     for (int m = 0; fing && m < 2; ++m) {
       const int q = n_rows + m;
       const float nl = fclampr(lam[q] + (-g[q] * invk[q]), mlo[m], mhi[m]);
+      const float d = nl - lam[q];
+      lam[q] = nl;
+      res[fisl] = fmaxr(res[fisl], fabsr(d));
+      for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][q] * d;
+    }
+    for (int j = 0; j < nlm; ++j) {
+      const int q = n_rows + nfm + j;
+      const float nl = fclampr(lam[q] + (-g[q] * invk[q]), S.s.llo[j], S.s.lhi[j]);
       const float d = nl - lam[q];
       lam[q] = nl;
       res[fisl] = fmaxr(res[fisl], fabsr(d));
@@ -1720,6 +2007,16 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
     if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
     e.q[j] = qn; e.qd[j] = qd;
   }
+  for (int x = 0; x < nlm; ++x) {              // the limb moves with the solved velocity
+    float dq = dq0[x];
+    for (int s = 0; s < n_all; ++s) if (la[s]) dq = dq + pj[s][x] * lam[s];
+    float qd = S.s.limb_qd0[x] + dq;
+    float qn = e.q[x] + dq * c->dt;
+    if (qn < arm->q_lo[x]) { qn = arm->q_lo[x]; qd = 0.0f; }
+    if (qn > arm->q_hi[x]) { qn = arm->q_hi[x]; qd = 0.0f; }
+    e.q[x] = qn; e.qd[x] = qd;
+  }
+  if (limb) S.s.kin_fresh = 0;
 }
 #endif
 
@@ -1797,6 +2094,7 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
       if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
       if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
       if (j >= RV_NLIMB) { S.s.fing_dv[j - RV_NLIMB] = dv; S.s.fing_vt[j - RV_NLIMB] = vd; S.s.fing_qd0[j - RV_NLIMB] = qd; }
+      else if (c->limb_dynamics) { S.s.limb_dv[j] = dv; S.s.limb_vt[j] = vd; S.s.limb_qd0[j] = qd; }
       if (with_lq) S.s.jchg[j] = (qn != e.q[j]) || (qd != 0.0f);   // did the joint state change at all?
       e.q[j] = qn; e.qd[j] = qd;
       if (with_lq) {
@@ -3132,14 +3430,24 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   int any_con = 0;
 #pragma unroll
   for (int b = 0; b < RV_MAXB; ++b) any_con |= on_[b] && S.e.con_on[b];
-  const int fing_fast = with_fingers && n_on <= 1 && !any_con;
-  if ((with_fingers && !fing_fast) || any_con) {
+  // limb dynamics: an awake body touches the arm -> the joint velocities are unknowns too (system solver)
+  int limb = 0;
+  if (c->limb_dynamics && arm_on) {
+#pragma unroll
+    for (int b = 0; b < RV_MAXB; ++b) limb |= on_[b] && S.e.man[RV_AIDX(b)].n > 0;
+  }
+  // one awake body at most and no user constraint: impulse space, one lane per row, with the finger / limb
+  // DOFs and their motor rows; else the velocity-space system solver
+  const int fing_fast = (with_fingers || limb) && n_on <= 1 && !any_con;
+  any_con |= limb;
+  if (limb) limb_prepare(S, K);
+  if (((with_fingers || limb) && !fing_fast) || (any_con && !limb)) {
     RV_LANES_BEGIN
-      if (lane == 0) solve_with_fingers(S, K);
+      if (lane == 0) solve_with_fingers(S, K, limb);
     RV_LANES_END
   }
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
-  if (fing_fast) solve_island_fingers(S, K, __builtin_amdgcn_readfirstlane(the_body));
+  if (fing_fast) solve_island_fingers(S, K, __builtin_amdgcn_readfirstlane(the_body), with_fingers, limb);
 #endif
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
   {
@@ -3168,11 +3476,12 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   }
 #else
   RV_LANES_BEGIN
-    if (lane == 0) S.s.n_rows = ((with_fingers && !fing_fast) || any_con) ? 0 : solver_row_list(S, label, on_, act_, big_);
+    if (lane == 0) S.s.n_rows = (!fing_fast && (with_fingers || any_con)) ? 0 : solver_row_list(S, label, on_, act_, big_);
   RV_LANES_END
-  if (fing_fast) solve_rows(S, K, S.s.n_rows < 0 ? 0 : S.s.n_rows, 1);
-  else if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows, 0);
+  if (fing_fast) solve_rows(S, K, S.s.n_rows < 0 ? 0 : S.s.n_rows, with_fingers, limb);
+  else if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows, 0, 0);
 #endif
+  if (limb) { arm_lq_phase(S, K); arm_fk_phases(S, K); }   // the link frames follow the solved joint state
   // an island of three or four bodies (there can be only one): velocity-space Gauss-Seidel in the
   // order  bodies (their table and arm points), then the three rounds of body pairs.  Bodies do
   // not share anything in the first stage and the two pairs of a round touch disjoint bodies, so

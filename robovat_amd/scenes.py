@@ -213,6 +213,19 @@ SAWYER_MAX_VELOCITY = [1.74, 1.328, 1.957, 1.957, 3.485, 3.485, 4.545]
 SAWYER_MAX_ACCEL = [8.0, 8.0, 10.0, 10.0, 15.0, 15.0, 20.0]
 SAWYER_EFFORT = [80.0, 80.0, 40.0, 40.0, 9.0, 9.0, 9.0]     # N m
 FINGER_EFFORT = 20.0                                         # N
+# <inertial> of right_l0 .. right_l6 (mass kg, centre of mass in the link frame m, principal moments kg m^2;
+# RECALLED from sawyer_description like the chain above), and the hand with the
+# electric gripper lumped on the hand frame.  Read by PHYSICS.LIMB_DYNAMICS only
+SAWYER_INERTIAL = [
+    (5.3213, (0.024366, 0.010969, 0.14363), (0.053314, 0.057902, 0.023659)),
+    (4.505, (-0.0030849, -0.026811, 0.092521), (0.022398, 0.014613, 0.017295)),
+    (1.745, (-0.00016044, -0.014967, 0.13582), (0.025506, 0.0253, 0.0034179)),
+    (2.5097, (-0.0048135, -0.0281, -0.084154), (0.01016, 0.0065685, 0.0069078)),
+    (1.1136, (-0.0018844, 0.0069001, 0.1341), (0.013557, 0.013555, 0.0013658)),
+    (1.5625, (0.0061133, -0.023697, 0.076416), (0.0047328, 0.0029676, 0.0031762)),
+    (0.3292, (-8.0726e-06, 0.0085838, -0.0049566), (0.00031105, 0.00021549, 0.00035976)),
+    (0.8, (0.0, 0.0, 0.06), (0.0012, 0.0012, 0.0006)),
+]
 LIMB_JOINT_NAMES = ['right_j%d' % i for i in range(7)]
 FINGER_JOINT_NAMES = ['right_gripper_l_finger_joint',
                       'right_gripper_r_finger_joint']
@@ -242,6 +255,10 @@ def make_arm(base_pos=(0.0, 0.0, 0.0), base_rpy=(0.0, 0.0, 0.0), finger_accel=2.
         arm.v_max[j] = SAWYER_MAX_VELOCITY[j]
         arm.a_max[j] = SAWYER_MAX_ACCEL[j]
         arm.inv_tau_max[j] = 1.0 / SAWYER_EFFORT[j]
+    for i, (m, com, inertia) in enumerate(SAWYER_INERTIAL):
+        arm.link_mass[i] = m
+        abi.assign(arm.link_com[i], com)
+        abi.assign(arm.link_inertia[i], inertia)
     # electric parallel gripper: left finger 0..+stroke, right -stroke..0
     arm.q_lo[7], arm.q_hi[7] = 0.0, FINGER_STROKE
     arm.q_lo[8], arm.q_hi[8] = -FINGER_STROKE, 0.0

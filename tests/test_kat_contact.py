@@ -119,11 +119,13 @@ def test_two_box_stack_rests(backend):
         w.close()
 
 
+@pytest.mark.parametrize('limb', [0, 1])
 @pytest.mark.parametrize('backend', BACKENDS)
-def test_pushed_box_moves_with_the_pusher(backend):
-    """The (kinematic) gripper pushes a box across the table: while they are in contact the box
-    moves with the velocity of the finger it touches."""
-    w, cfg = _world(backend)
+def test_pushed_box_moves_with_the_pusher(backend, limb):
+    """The gripper pushes a box across the table: while they are in contact the box moves with the
+    velocity of the finger it touches -- with the kinematic limb, and with the dynamic one
+    (PHYSICS.LIMB_DYNAMICS: 2 N of friction do not slow a Sawyer down)."""
+    w, cfg = _world(backend, **{'PHYSICS.LIMB_DYNAMICS': limb})
     w.reset()
     z_push = float(cfg.finger_tip_offset) + 0.5 * (float(cfg.cspace_high[2]) + float(cfg.cspace_low[2]))
     tz = float(w.body_params()[0, 0, 6])
