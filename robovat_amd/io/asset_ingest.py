@@ -278,7 +278,8 @@ def arm_chain_from_urdf(path, tip_link, base_link=None):
         raise ValueError('%s is not an ancestor of %s' % (base_link, tip_link))
     chain.reverse()
     out = {'names': [], 'jpos': [], 'jquat': [], 'q_lo': [], 'q_hi': [], 'v_max': [], 'effort': [], 'kind': [],
-           'colliders': []}                    # per moving joint: [n, 3] collision points of the links riding on it, kernel frame
+           'colliders': [],                    # per moving joint: [n, 3] collision points of the links riding on it, kernel frame
+           'inertials': []}                    # per moving joint: [(mass, com[3], inertia 3x3 about the com)] of those links, kernel frame
     links = {l.get('name'): l for l in root.findall('link')}
     base_dir = os.path.dirname(os.path.abspath(path))
 
@@ -299,6 +300,17 @@ def arm_chain_from_urdf(path, tip_link, base_link=None):
                 r = float(cyl.get('radius')); g = np.concatenate([g, r * np.array([[1.0, 1, 0], [-1, -1, 0]])])
             pts.append(g @ R.T + xyz)
         return np.concatenate(pts) if pts else np.zeros((0, 3))
+    def link_inertial(name):
+        ine = links[name].find('inertial') if name in links else None
+        if ine is None or ine.find('mass') is None:
+            return None
+        org = ine.find('origin')
+        xyz = np.asarray(_floats(org.get('xyz') if org is not None else None, 3, [0.0, 0.0, 0.0]))
+        R = _rpy_matrix(*_floats(org.get('rpy') if org is not None else None, 3, [0.0, 0.0, 0.0]))
+        it = ine.find('inertia')
+        g = (lambda k: float(it.get(k, 0.0))) if it is not None else (lambda k: 0.0)
+        I = np.array([[g('ixx'), g('ixy'), g('ixz')], [g('ixy'), g('iyy'), g('iyz')], [g('ixz'), g('iyz'), g('izz')]])
+        return float(ine.find('mass').get('value')), xyz, R @ I @ R.T
     T_R, T_p = np.eye(3), np.zeros(3)          # pending fixed transform, in the frame of the last moving joint
     A_prev = np.eye(3)                         # rotation URDF-joint-frame -> kernel-joint-frame of the previous moving joint
     for j in chain:
@@ -315,6 +327,10 @@ def arm_chain_from_urdf(path, tip_link, base_link=None):
                 lp = link_points(j.find('child').get('link'))
                 if len(lp):
                     out['colliders'][-1] = np.concatenate([out['colliders'][-1], (lp @ T_R.T + T_p) @ A_prev])
+                li = link_inertial(j.find('child').get('link'))
+                if li is not None:
+                    Rk = A_prev.T @ T_R
+                    out['inertials'][-1].append((li[0], A_prev.T @ (T_R @ li[1] + T_p), Rk @ li[2] @ Rk.T))
             continue
         if kind not in ('revolute', 'continuous', 'prismatic'):
             raise ValueError('unsupported joint type %s' % kind)
@@ -333,6 +349,8 @@ def arm_chain_from_urdf(path, tip_link, base_link=None):
         out['names'].append(j.get('name')); out['kind'].append(kind)
         T_R, T_p, A_prev = np.eye(3), np.zeros(3), Az
         out['colliders'].append(link_points(j.find('child').get('link')) @ Az)     # (row vectors: p_kernel = Az^T p_urdf)
+        li = link_inertial(j.find('child').get('link'))
+        out['inertials'].append([(li[0], Az.T @ li[1], Az.T @ li[2] @ Az)] if li is not None else [])
     out['tip'] = {'pos': (A_prev.T @ T_p).tolist(), 'quat': _quat_from_matrix(A_prev.T @ T_R).tolist()}
     return out
 
@@ -365,6 +383,30 @@ def arm_from_urdf(path, tip_link, base_link=None, base_pos=(0.0, 0.0, 0.0), base
         arm.col_frame[i] = i
         abi.assign(arm.col_center[i], (0.5 * (lo + hi)).tolist()); abi.assign(arm.col_half[i], (0.5 * (hi - lo)).tolist())
     abi.assign(arm.jpos[abi.RV_NLIMB], ch['tip']['pos']); abi.assign(arm.jquat[abi.RV_NLIMB], ch['tip']['quat'])
+    # inertial parameters (PHYSICS.LIMB_DYNAMICS): per limb link the composite of the <inertial> elements riding on
+    # its joint -- total mass, common centre of mass, and the DIAGONAL of the inertia tensor about it in the joint
+    # frame (rv_arm keeps principal moments along the frame axes).  Links behind the last joint (hand, gripper base)
+    # stay with the hand entry of scenes.make_arm unless the URDF has inertials for them.
+    for i in range(abi.RV_NLIMB):
+        parts = ch['inertials'][i]
+        if not parts:
+            continue
+        if i == abi.RV_NLIMB - 1 and len(parts) > 1:       # wrist link + what is bolted to it: the link itself, and the hand entry
+            groups = [(i, parts[:1]), (abi.RV_NLIMB, parts[1:])]
+        else:
+            groups = [(i, parts)]
+        for slot, ps in groups:
+            m = sum(p[0] for p in ps)
+            com = sum(p[0] * np.asarray(p[1]) for p in ps) / m
+            I = np.zeros((3, 3))
+            for pm, pc, pI in ps:
+                d = np.asarray(pc) - com
+                I += np.asarray(pI) + pm * (d @ d * np.eye(3) - np.outer(d, d))
+            if slot == abi.RV_NLIMB:                        # the hand frame: rotate / shift from the wrist joint frame
+                Rt = _quat_matrix(ch['tip']['quat'])
+                com = Rt.T @ (com - np.asarray(ch['tip']['pos'])); I = Rt.T @ I @ Rt
+            arm.link_mass[slot] = m
+            abi.assign(arm.link_com[slot], com.tolist()); abi.assign(arm.link_inertia[slot], np.diag(I).tolist())
     return arm
 
 

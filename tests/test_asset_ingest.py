@@ -211,12 +211,17 @@ def _builtin_arm_urdf():
     out = ['<?xml version="1.0"?>', '<robot name="sawyer_like">', '<link name="base"/>']
     for i in range(7):
         c, h = list(arm.col_center[i]), list(arm.col_half[i])
-        out.append('<link name="right_l%d"><collision><origin xyz="%r %r %r" rpy="0 0 0"/><geometry><box size="%r %r %r"/></geometry></collision></link>'
-                   % (i, c[0], c[1], c[2], 2 * h[0], 2 * h[1], 2 * h[2]))
+        m, com, ine = scenes.SAWYER_INERTIAL[i]
+        out.append('<link name="right_l%d"><inertial><origin xyz="%r %r %r" rpy="0 0 0"/><mass value="%r"/>'
+                   '<inertia ixx="%r" ixy="0" ixz="0" iyy="%r" iyz="0" izz="%r"/></inertial>'
+                   '<collision><origin xyz="%r %r %r" rpy="0 0 0"/><geometry><box size="%r %r %r"/></geometry></collision></link>'
+                   % (i, com[0], com[1], com[2], m, ine[0], ine[1], ine[2], c[0], c[1], c[2], 2 * h[0], 2 * h[1], 2 * h[2]))
         out.append('<joint name="right_j%d" type="revolute"><parent link="%s"/><child link="right_l%d"/>'
                    '<origin xyz="%r %r %r" rpy="%r %r %r"/><axis xyz="0 0 1"/><limit lower="%r" upper="%r" velocity="%r" effort="%r"/></joint>'
                    % (i, 'base' if i == 0 else 'right_l%d' % (i - 1), i, *o[i][0], *o[i][1], lim[i][0], lim[i][1], vel[i], eff[i]))
-    out.append('<link name="right_hand"/>')
+    m, com, ine = scenes.SAWYER_INERTIAL[7]
+    out.append('<link name="right_hand"><inertial><origin xyz="%r %r %r" rpy="0 0 0"/><mass value="%r"/>'
+               '<inertia ixx="%r" ixy="0" ixz="0" iyy="%r" iyz="0" izz="%r"/></inertial></link>' % (com[0], com[1], com[2], m, ine[0], ine[1], ine[2]))
     out.append('<joint name="right_hand" type="fixed"><parent link="right_l6"/><child link="right_hand"/><origin xyz="%r %r %r" rpy="%r %r %r"/></joint>'
                % (*o[7][0], *o[7][1]))
     out.append('</robot>')
@@ -237,6 +242,10 @@ def test_arm_from_urdf_reproduces_the_built_in_arm(tmp_path):
         assert min(np.abs(qa - qb).max(), np.abs(qa + qb).max()) < 1e-6
     for name in ('q_lo', 'q_hi', 'v_max', 'a_max', 'inv_tau_max'):
         assert np.allclose(list(getattr(got, name)), list(getattr(want, name)), rtol=1e-6), name
+    assert np.allclose(list(got.link_mass), list(want.link_mass), rtol=1e-6)
+    for i in range(8):                                    # <inertial>: mass, centre of mass, principal moments
+        assert np.allclose(list(got.link_com[i]), list(want.link_com[i]), atol=1e-7), i
+        assert np.allclose(list(got.link_inertia[i]), list(want.link_inertia[i]), rtol=1e-5), i
     for i in range(abi.RV_NCOL):
         assert got.col_frame[i] == want.col_frame[i]
         assert np.allclose(list(got.col_center[i]), list(want.col_center[i]), atol=1e-7) and np.allclose(list(got.col_half[i]), list(want.col_half[i]), atol=1e-7)
