@@ -141,6 +141,9 @@ def main():
     ap.add_argument('--no-async', action='store_true')
     ap.add_argument('--quick', action='store_true', help='shorter CPU legs')
     ap.add_argument('--mode', choices=['rollout', 'lockstep'], default='rollout')
+    ap.add_argument('--workload', choices=['config2', 'config3', 'config4', 'config5'], default='config2',
+                    help='the timed workload (BASELINE.json configs[1..4]); other than config2: for profiling one of the legs '
+                         'alone (tools/profile_bench.sh), implies --no-extra-legs')
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON: libraries that print to the C-level stdout (RCCL's
@@ -167,10 +170,22 @@ def main():
     assert world_size == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     scene, names = scenes.make_scene()
+    base_over, grasp_env = {}, None
+    if args.workload != 'config2':
+        args.no_extra_legs = True
+        args.envs_per_gpu = args.envs_per_gpu or {'config3': 4096, 'config4': 2048, 'config5': 8192}[args.workload]
+        if args.workload == 'config3':
+            base_over = dict(TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)
+        if args.workload == 'config4':
+            grasp_env = configs.grasp_env_config()
+            scene, names = scenes.make_scene(env_cfg=grasp_env)
     if args.envs_per_gpu is None:
         args.envs_per_gpu = 1024 if args.gpus == 1 else 8192
     n = args.envs_per_gpu
-    workload = ('PushEnv 4 rigid convex bodies, %d vectorised envs/GPU, random policy (BASELINE.json configs[1])' % n if n != 8192 else
+    workload = ("PushEnv 'crossing' layout 0, V-HACD concave movables, %d envs/GPU, random policy (BASELINE.json configs[2])" % n
+                if args.workload == 'config3' else
+                'Grasp4DofEnv, %d envs/GPU, random CUBOID grasps (BASELINE.json configs[3])' % n if args.workload == 'config4' else
+                'PushEnv 4 rigid convex bodies, %d vectorised envs/GPU, random policy (BASELINE.json configs[1])' % n if n != 8192 else
                 'PushEnv 4 rigid convex bodies, 8192 envs/GPU sharded across %d GPU(s), random policy, RCCL return-gather '
                 '(BASELINE.json configs[4])' % args.gpus)
     cfg_kwargs = dict(seed=args.seed)
@@ -182,7 +197,7 @@ def main():
         torch.cuda.synchronize()
 
     def make_world(n_envs, **over):
-        env_cfg = configs.push_env_config(**over)
+        env_cfg = grasp_env if (grasp_env is not None and not over) else configs.push_env_config(**over)
         c = configs.make_rv_config(env_cfg=env_cfg, n_envs=n_envs, env_id_offset=rank * n_envs, shape_names=names, **cfg_kwargs)
         return lib.World(c, scene, device=local_rank), c
 
@@ -290,11 +305,14 @@ def main():
         return {'value': es / el, 'unit': 'env_steps/s', 'sim_steps_per_s': ss / el, 'ms_per_step': 1e3 * el / k_steps,
                 'envs_per_gpu': n_envs, 'steps': k_steps}
 
-    world, cfg = make_world(n)
+    world, cfg = make_world(n, **base_over)
     world.reset()
     reset_stats = world.stats()
-    for k in range(args.warmup):
-        lockstep_step(world, k)
+    if args.workload == 'config2':
+        for k in range(args.warmup):
+            lockstep_step(world, k)
+    else:
+        world.rollout(args.warmup, first_macro_index=0, auto_reset=True, record=True)
     timer = time_rollout if args.mode == 'rollout' else time_lockstep
     elapsed, st, kern_ms, launches = timer(world, args.steps, args.warmup)
     env_steps_all, substeps_all = all_sum(st['env_steps'], st['substeps'])
@@ -456,7 +474,7 @@ def main():
         world.close()
 
     if rank == 0:
-        algo = ALGO_BYTES['config2']
+        algo = {'config3': ALGO_BYTES['config3'], 'config4': 1912}.get(args.workload, ALGO_BYTES['config2'])
         avg_kernel_s = 1e-3 * kern_ms / launches
         per_launch = st['substeps'] / launches
         achieved = algo * per_launch / avg_kernel_s / 1e9
@@ -466,7 +484,7 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if args.mode == 'rollout':
+            if args.mode == 'rollout' and args.workload == 'config2':
                 # measured offline with rocprofv3 PMC passes on this same command, scaled to this launch
                 traffic = tj['hbm_bytes_per_env_substep'] * per_launch
                 issue = tj.get('issue')

@@ -42,7 +42,12 @@ struct EnvKernelArgs {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k_env(EnvKernelArgs args) {
+#ifdef RV_WAVES_PER_EU      // experiment: cap the registers so that RV_WAVES_PER_EU waves fit a SIMD (tools/flag_variants.sh)
+#define RV_ENV_OCC __attribute__((amdgpu_waves_per_eu(RV_WAVES_PER_EU, RV_WAVES_PER_EU)))
+#else
+#define RV_ENV_OCC
+#endif
+__global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
   Shared& S = g_shared;
   const int env = (int)blockIdx.x;
   if (env >= args.n_envs) return;

@@ -1,8 +1,11 @@
 #!/bin/bash
-# usage (on the GPU box, via gpurun): bash tools/profile_bench.sh <tag>
+# usage (on the GPU box, via gpurun): bash tools/profile_bench.sh <tag> [bench.py arguments]
 # kernel-trace/stats pass + separate PMC passes (FETCH_SIZE, WRITE_SIZE, two SQ sets) of the headline bench command
 R=$GRAFT_REPO_ROOT; TAG=$1; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs"   # one k_env<MODE_ROLLOUT> launch is timed
+# optional further arguments go to bench.py (e.g. --workload config3 --steps 10)
+shift; EXTRA="$@"; [ -z "$EXTRA" ] && EXTRA="--steps 20 --warmup 5"
+CMD="python $R/bench.py $EXTRA --no-cpu-baseline --no-extra-legs"   # one k_env<MODE_ROLLOUT> launch is timed
+echo "$CMD" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- $CMD > $OUT/write.log 2>&1

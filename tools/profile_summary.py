@@ -41,7 +41,12 @@ def kernel_stats():
 
 bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
 ks = kernel_stats()
-lines = ['# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs',
+cmdfile = os.path.join(src, 'command.txt')
+command = open(cmdfile).read().strip().replace(ROOT + '/', '') if os.path.exists(cmdfile) else 'python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs'
+command = command.split('/')[-1] if command.startswith('python /') else command
+headline = '--workload' not in command
+algo_bytes = bench['roofline']['algorithmic_bytes_per_env_substep']
+lines = ['# rocprofv3 --kernel-trace --stats -- python ' + command.replace('python ', '', 1) + '      [' + bench['config']['workload'] + ']',
          '%-60s %8s %14s %14s %8s' % ('kernel', 'calls', 'total_us', 'avg_us', 'pct')]
 for r in ks[:12]:
     lines.append('%-60s %8d %14.0f %14.0f %8.3f' % (r['Name'][:60], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage']))
@@ -61,8 +66,8 @@ f_kb, w_kb = get('FETCH_SIZE'), get('WRITE_SIZE')
 hbm = (2 * f_kb + w_kb) * 1024
 out = ['# PMC passes (separate rocprofv3 runs) for %s' % kname,
        '# launch: %.4g env-substeps (bench.py of the same session)' % env_substeps,
-       'FETCH_SIZE_KB %.0f  WRITE_SIZE_KB %.0f  -> HBM bytes (reads doubled, gfx950 correction) %.3e = %.1f B per env-substep (algorithmic: 3056)'
-       % (f_kb, w_kb, hbm, hbm / env_substeps)]
+       'FETCH_SIZE_KB %.0f  WRITE_SIZE_KB %.0f  -> HBM bytes (reads doubled, gfx950 correction) %.3e = %.1f B per env-substep (algorithmic: %d)'
+       % (f_kb, w_kb, hbm, hbm / env_substeps, algo_bytes)]
 names = ['SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM', 'SQ_INSTS_FLAT',
          'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS', 'SQ_INSTS_BRANCH', 'SQ_IFETCH', 'SQ_INSTS_SMEM']
 for n in names:
@@ -87,5 +92,6 @@ if wc > 0:
                % (100 * get('SQ_WAIT_ANY') / wc, 100 * get('SQ_WAIT_INST_ANY') / wc, 100 * get('SQ_ACTIVE_INST_ANY') / wc))
 open(os.path.join(prof, tag + '_pmc.txt'), 'w').write('\n'.join(out) + '\n')
 print('\n'.join(out))
-with open(os.path.join(prof, 'traffic.json'), 'w') as fh:
+if headline:
+  with open(os.path.join(prof, 'traffic.json'), 'w') as fh:
     json.dump({'hbm_bytes_per_env_substep': hbm / env_substeps, 'source': tag + '_pmc.txt', 'issue': issue}, fh, indent=1)
