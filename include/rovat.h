@@ -33,7 +33,7 @@ extern "C" {
 #define RV_MAXH        4   /* convex hulls per shape (V-HACD parts)                */
 #define RV_MAXV       16   /* vertices per convex hull                             */
 #define RV_MAXP       28   /* faces per convex hull (2 V - 4 for V = 16)           */
-#define RV_PC_MAXPIX 4096  /* visible pixels of one body kept for point-cloud sampling */
+#define RV_PC_MAXPIX 2048  /* visible pixels of one body kept for point-cloud sampling (more: every stride-th one) */
 #define RV_MAX_SHAPES 16   /* shape templates per scene                            */
 #define RV_NJ          9   /* arm joints: 7 limb (right_j0..j6) + 2 finger         */
 #define RV_NLIMB       7

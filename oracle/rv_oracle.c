@@ -475,18 +475,19 @@ static int robot_is_gripper_ready(const orc_world* w, const orc_env* e) { return
 static void arm_motor_step(const orc_world* w, orc_env* e) {
   const rv_arm* a = &w->scene.arm;
   real dt = (real)w->cfg.dt;
+  const real inv_dt = R(1.0) / dt;      /* (the velocity error is scaled by 1 / dt: a multiplication per joint and substep) */
   /* limb joints move synchronised: one common scale keeps every commanded
    * velocity within its limit, so the path is a straight line in joint space */
   real sync = R(1.0);
   for (int j = 0; j < RV_NLIMB; ++j) {
     if (!e->motor_on[j]) continue;
-    real raw = rabs(e->motor_kp[j] * (e->motor_q[j] - e->q[j]) / dt);
+    real raw = rabs(e->motor_kp[j] * (e->motor_q[j] - e->q[j]) * inv_dt);
     if (raw > e->vmax_cmd[j]) sync = rmin(sync, e->vmax_cmd[j] / raw);
   }
   for (int j = 0; j < RV_NJ; ++j) {
     real vd = R(0.0);
     if (e->motor_on[j]) {
-      vd = e->motor_kp[j] * (e->motor_q[j] - e->q[j]) / dt;
+      vd = e->motor_kp[j] * (e->motor_q[j] - e->q[j]) * inv_dt;
       if (j < RV_NLIMB) vd = vd * sync;
       vd = rclamp(vd, -e->vmax_cmd[j], e->vmax_cmd[j]);
     }
@@ -2861,18 +2862,25 @@ void orc_point_cloud(orc_world* w, float* out) {
           const int v0 = (int)rclamp(R(floor)(mv) - R(1.0), R(0.0), H1), v1 = (int)rclamp(R(floor)(xv) + R(2.0), R(0.0), H1);
           const int ww = u1 - u0 + 1, hh = v1 - v0 + 1;
           const int total = (xu < R(0.0) || xv < R(0.0) || mu > W1 || mv > H1) ? 0 : ww * hh;
-          for (int idx = 0; idx < total; ++idx) {
-            const int u = u0 + idx % ww, v = v0 + idx / ww;
-            real dc[3], dw[3], d, pt[3];
-            pc_pixel_dir_cam(c, (real)u, (real)v, dc); m3tmulv(dw, Rm, dc);
-            int who = pc_render_pixel(w, e, rot, cam_o, dw, &d);
-            if (!(who == b && d > (real)c->cam_near)) continue;
-            pc_deproject(c, cam_o, (real)u, (real)v, d, pt);
-            if (!pc_crop_ok(c, pt)) continue;
-            if (n < RV_PC_MAXPIX) { pix[n] = ((uint32_t)v << 16) | (uint32_t)u; dep[n] = d; }
-            n++;
+          /* a body with more than RV_PC_MAXPIX visible pixels: every stride-th one (scan order) is kept */
+          int stride = 1;
+          for (int pass = 0; pass < 2; ++pass) {
+            n = 0;
+            for (int idx = 0; idx < total; ++idx) {
+              const int u = u0 + idx % ww, v = v0 + idx / ww;
+              real dc[3], dw[3], d, pt[3];
+              pc_pixel_dir_cam(c, (real)u, (real)v, dc); m3tmulv(dw, Rm, dc);
+              int who = pc_render_pixel(w, e, rot, cam_o, dw, &d);
+              if (!(who == b && d > (real)c->cam_near)) continue;
+              pc_deproject(c, cam_o, (real)u, (real)v, d, pt);
+              if (!pc_crop_ok(c, pt)) continue;
+              if (n % stride == 0 && n / stride < RV_PC_MAXPIX) { pix[n / stride] = ((uint32_t)v << 16) | (uint32_t)u; dep[n / stride] = d; }
+              n++;
+            }
+            if (n <= RV_PC_MAXPIX) break;
+            if (pass == 0) stride = (n + RV_PC_MAXPIX - 1) / RV_PC_MAXPIX;
           }
-          if (n > RV_PC_MAXPIX) n = RV_PC_MAXPIX;
+          n = (n + stride - 1) / stride;
         }
       }
       if (n == 0) { for (int j = 0; j < P * 3; ++j) o[j] = 0.0f; continue; }
@@ -2893,8 +2901,12 @@ void orc_point_cloud(orc_world* w, float* out) {
         int sel = key[k] < T;
         if (!sel && key[k] == T && need > 0) { sel = 1; need--; }
         if (!sel) continue;
+        /* np.random.choice(replace=False) returns the subset in random order: the points go out in the order of
+         * their keys (ties in scan order) */
+        int rank = 0;
+        for (int t = 0; t < n; ++t) rank += (key[t] < key[k] || (key[t] == key[k] && t < k)) ? 1 : 0;
         real pt[3]; pc_deproject(c, cam_o, (real)(pix[k] & 0xffffu), (real)(pix[k] >> 16), dep[k], pt);
-        o[3 * outn] = (float)pt[0]; o[3 * outn + 1] = (float)pt[1]; o[3 * outn + 2] = (float)pt[2];
+        o[3 * rank] = (float)pt[0]; o[3 * rank + 1] = (float)pt[1]; o[3 * rank + 2] = (float)pt[2];
         outn++;
       }
     }

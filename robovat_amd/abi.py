@@ -9,7 +9,7 @@ RV_MAXB = 4
 RV_MAXH = 4
 RV_MAXV = 16
 RV_MAXP = 28
-RV_PC_MAXPIX = 4096
+RV_PC_MAXPIX = 2048
 RV_MAX_SHAPES = 16
 RV_NJ = 9
 RV_NLIMB = 7

@@ -2043,7 +2043,7 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
     const DevEnv& e0 = S.e; const int j0 = lane < RV_NJ ? lane : RV_NJ - 1;
     float vd0 = 0.0f, ratio0 = 1.0f;
     if (e0.motor_on[j0]) {
-      vd0 = e0.motor_kp[j0] * (e0.motor_q[j0] - e0.q[j0]) / c->dt;
+      vd0 = e0.motor_kp[j0] * (e0.motor_q[j0] - e0.q[j0]) * (1.0f / c->dt);
       float raw = fabsr(vd0);
       if (j0 < RV_NLIMB && raw > e0.vmax_cmd[j0]) ratio0 = e0.vmax_cmd[j0] / raw;
     }
@@ -2061,7 +2061,7 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
       const DevEnv& e = S.e; int j = lane;
       float vd = 0.0f, ratio = 1.0f;
       if (e.motor_on[j]) {
-        vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) / c->dt;
+        vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) * (1.0f / c->dt);
         float raw = fabsr(vd);
         if (j < RV_NLIMB && raw > e.vmax_cmd[j]) ratio = e.vmax_cmd[j] / raw;
       }
@@ -2355,7 +2355,7 @@ RV_DEV void motors_only_substeps(Shared& S, const Consts& K, const int r) {
   for (int i = 0; i < r; ++i) {
     float vd = 0.0f, ratio = 1.0f;
     if (on) {
-      vd = kp * (mq - q) / dt;
+      vd = kp * (mq - q) * (1.0f / dt);
       float raw = fabsr(vd);
       if (j < RV_NLIMB && raw > vmax) ratio = vmax / raw;
     }
@@ -2390,7 +2390,7 @@ RV_DEV void motors_only_substeps(Shared& S, const Consts& K, const int r) {
     for (int j = 0; j < RV_NJ; ++j) {
       float vd = 0.0f, ratio = 1.0f;
       if (e.motor_on[j]) {
-        vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) / dt;
+        vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) * (1.0f / dt);
         float raw = fabsr(vd);
         if (j < RV_NLIMB && raw > e.vmax_cmd[j]) ratio = e.vmax_cmd[j] / raw;
       }
@@ -2687,7 +2687,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
       if (m > 0) {
         for (int i = 0; i < m; ++i) {
           float vd = 0.0f;
-          if (on) vd = kp * (mq - q) / dt;
+          if (on) vd = kp * (mq - q) * (1.0f / dt);
           const float raw = fabsr(vd);
           const bool sat = on && limb && mine && raw > vmax;
           float sync = 1.0f;
@@ -2739,7 +2739,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
       }
     }
     float vd = 0.0f;
-    if (on) vd = kp * (mq - q) / dt;
+    if (on) vd = kp * (mq - q) * (1.0f / dt);
     const float raw = fabsr(vd);
     const bool sat = on && limb && mine && raw > vmax;
     float sync = 1.0f;
@@ -2846,7 +2846,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
       for (int j = 0; j < RV_NJ; ++j) {
         float vd = 0.0f, ratio = 1.0f;
         if (e.motor_on[j]) {
-          vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) / dt;
+          vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) * (1.0f / dt);
           float raw = fabsr(vd);
           if (j < RV_NLIMB && raw > e.vmax_cmd[j]) ratio = e.vmax_cmd[j] / raw;
         }

@@ -13,7 +13,8 @@
 // screen rectangle against the convex hulls of every body (face planes of rv_shape) and
 // the table, keeps the pixels on which this body is the nearest hit (segmentation),
 // compacts them into LDS in scan order, and samples: a uniformly random num_points-subset
-// (the num_points smallest of per-pixel Philox keys, found by a 32-step radix select) or
+// (the num_points smallest of per-pixel Philox keys, found by a 32-step radix select, emitted in
+// key order; a body with more than RV_PC_MAXPIX visible pixels keeps every stride-th one) or
 // num_points draws with replacement.  The observation is a pure function of a small pose
 // snapshot (ObsSnap), so a rollout records one snapshot per env.step() and all clouds of
 // the launch are rendered together afterwards.

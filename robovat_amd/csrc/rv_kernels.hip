@@ -358,21 +358,30 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
       const int v0 = (int)fclampr(ffloorr(mv) - 1.0f, 0.0f, H1), v1 = (int)fclampr(ffloorr(xv) + 2.0f, 0.0f, H1);
       const int w = u1 - u0 + 1, hh = v1 - v0 + 1;
       const int total = (xu < 0.0f || xv < 0.0f || mu > W1 || mv > H1) ? 0 : w * hh;
-      for (int base = 0; base < total; base += 64) {
-        const int idx = base + lane;
-        bool vis = false; float dep = 0.0f; int u = 0, v = 0;
-        if (idx < total) {
-          u = u0 + idx % w; v = v0 + idx / w;
-          v3 dw = cam_to_world_dir(c, pixel_dir_cam(c, (float)u, (float)v));
-          int who = render_pixel(c, scene, s, s_rot, cam_o, dw, &dep);
-          vis = (who == b) && dep > c->cam_near && crop_ok(c, deproject(c, cam_o, (float)u, (float)v, dep));
+      // pass 0 keeps every visible pixel; a body with more than RV_PC_MAXPIX of them is cast again and every
+      // stride-th visible pixel (scan order) is kept, so that the sample covers the whole body
+      int stride = 1;
+      for (int pass = 0; pass < 2; ++pass) {
+        n = 0;
+        for (int base = 0; base < total; base += 64) {
+          const int idx = base + lane;
+          bool vis = false; float dep = 0.0f; int u = 0, v = 0;
+          if (idx < total) {
+            u = u0 + idx % w; v = v0 + idx / w;
+            v3 dw = cam_to_world_dir(c, pixel_dir_cam(c, (float)u, (float)v));
+            int who = render_pixel(c, scene, s, s_rot, cam_o, dw, &dep);
+            vis = (who == b) && dep > c->cam_near && crop_ok(c, deproject(c, cam_o, (float)u, (float)v, dep));
+          }
+          const unsigned long long bal = __ballot(vis);
+          const int rank = n + (int)__popcll(bal & ((1ull << lane) - 1ull));
+          const int pos = rank / stride;
+          if (vis && rank % stride == 0 && pos < RV_PC_MAXPIX) { s_pix[pos] = ((uint32_t)v << 16) | (uint32_t)u; s_dep[pos] = dep; }
+          n += (int)__popcll(bal);
         }
-        const unsigned long long bal = __ballot(vis);
-        const int pos = n + (int)__popcll(bal & ((1ull << lane) - 1ull));
-        if (vis && pos < RV_PC_MAXPIX) { s_pix[pos] = ((uint32_t)v << 16) | (uint32_t)u; s_dep[pos] = dep; }
-        n += (int)__popcll(bal);
+        if (n <= RV_PC_MAXPIX) break;
+        if (pass == 0) stride = (n + RV_PC_MAXPIX - 1) / RV_PC_MAXPIX;
       }
-      if (n > RV_PC_MAXPIX) n = RV_PC_MAXPIX;
+      n = (n + stride - 1) / stride;
     }
   }
   __syncthreads();
@@ -404,10 +413,14 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
     mask = m2;
   }
   const uint32_t T = prefix;       // k = how many keys equal to T are still needed (scan order)
+  // the selected pixels are compacted IN PLACE to the front of the three arrays (a lane writes at or below its own
+  // index, after every lane of the chunk has read its element) ...
   int outn = 0, ties = 0;
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
     const uint32_t key = i < n ? s_key[i] : 0xffffffffu;
+    const uint32_t px = i < n ? s_pix[i] : 0u;
+    const float dp = i < n ? s_dep[i] : 0.0f;
     const bool lt = i < n && key < T;
     const bool eq = i < n && key == T;
     const unsigned long long beq = __ballot(eq);
@@ -415,11 +428,30 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
     const bool sel = lt || (eq && tie_rank < k);
     const unsigned long long bs = __ballot(sel);
     const int pos = outn + (int)__popcll(bs & ((1ull << lane) - 1ull));
-    if (sel && pos < P) {
-      const uint32_t px = s_pix[i];
-      st3(o + 3 * pos, deproject(c, cam_o, (float)(px & 0xffffu), (float)(px >> 16), s_dep[i]));
-    }
+    if (sel && pos < P) { s_key[pos] = key; s_pix[pos] = px; s_dep[pos] = dp; }
     outn += (int)__popcll(bs); ties += (int)__popcll(beq);
+  }
+  __syncthreads();
+  // ... and go out in the order of their keys (ties in scan order): np.random.choice(replace=False) returns the
+  // subset in random order (point_cloud_utils.py:23-39).  Rank of an element = how many selected ones precede it;
+  // a lane ranks up to four elements per pass over the keys
+  for (int j0 = 0; j0 < P; j0 += 256) {
+    uint32_t kq[4]; int rq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int jj = j0 + lane + 64 * q; kq[q] = jj < P ? s_key[jj] : 0u; rq[q] = 0; }
+    for (int t = 0; t < P; ++t) {
+      const uint32_t kt = s_key[t];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rq[q] += (kt < kq[q] || (kt == kq[q] && t < j0 + lane + 64 * q)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int jj = j0 + lane + 64 * q;
+      if (jj < P) {
+        const uint32_t px = s_pix[jj];
+        st3(o + 3 * rq[q], deproject(c, cam_o, (float)(px & 0xffffu), (float)(px >> 16), s_dep[jj]));
+      }
+    }
   }
 }
 // CameraObs 'depth' / 'segmask' (camera_obs.py:33-88 over BulletCamera._frames,

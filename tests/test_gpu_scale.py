@@ -395,3 +395,33 @@ def test_env_with_an_arm_ingested_from_a_robot_urdf(tmp_path):
     assert np.abs(w0.body_state().cpu().numpy() - got).max() < 2e-2      # same arm up to the rounding of the ingest
     assert np.abs(w0.body_state().cpu().numpy() - got)[..., :3].mean() < 1e-3
     w.close(); w0.close()
+
+
+def test_point_cloud_of_a_body_with_more_pixels_than_the_buffer_holds():
+    """A body that covers more than RV_PC_MAXPIX pixels is cast a second time and every stride-th visible pixel is
+    kept, so the sample covers the whole body (not its top rows); the subset comes in key order, not in scan
+    order.  HIP == oracle bit for bit."""
+    world, ref = _world(4, seed=3), _oracle(4, seed=3)
+    world.reset(); ref.reset()
+    tz = float(ref.body_params()[0, 0, 6])
+    p = np.zeros((4, abi.RV_MAXB, 8)); s = np.zeros((4, abi.RV_MAXB, 13)); s[..., 6] = 1
+    p[:, 0] = [1, 0, 4.0, 0.3, 0.5, 0, tz, 0]                    # the box template at 4 x its size: 28 x 24 cm, 24 cm tall
+    s[:, 0, :3] = [0.6, 0.0, tz + 0.13]
+    for w in (world, ref):
+        w.set_body_params(p); w.set_body_state(s)
+    got = world.observe(point_cloud=True)['point_cloud'].cpu().numpy()
+    want = ref.point_cloud()
+    assert np.array_equal(got, want), np.abs(got - want).max()
+    depth, seg = ref.render(0)
+    vis = int((seg == 0).sum())
+    assert vis > 2 * abi.RV_PC_MAXPIX, vis                       # (else the test does not test the stride path)
+    cloud = got[0, 0]
+    rows = np.nonzero((seg == 0).any(axis=1))[0]
+    # the points spread over the whole visible body: along camera v (image rows) the sampled points reach both ends
+    from robovat_amd.perception import Camera
+    assert cloud[:, 2].max() - cloud[:, 2].min() > 0.15          # top face AND the sides down to the table
+    ext = cloud.max(axis=0) - cloud.min(axis=0)
+    assert ext[0] > 0.2 and ext[1] > 0.18, ext
+    first = cloud[:64]
+    assert (first.max(axis=0) - first.min(axis=0) > 0.6 * ext).all()      # no slice of the cloud is a spatial slice
+    world.close()
