@@ -336,29 +336,43 @@ def main():
         A = torch.stack([world.policy_random(next_index + k) for k in range(4 * args.steps)])     # [4K, N, G, 4]
         out_buf = world.poll_buffers(point_cloud=True)
         cnt = torch.zeros(n, dtype=torch.long, device='cuda'); ar = torch.arange(n, device='cuda')
+        # (the device ops of the loop once, untimed: on a fresh machine the first use of a torch kernel loads its code
+        # object -- ~0.2 s for the handful used here, which would be charged to the 0.4 s leg)
+        _live = torch.ones(n, dtype=torch.uint8, device='cuda') * (1 - out_buf['done'])
+        _ = A[(cnt + _live.to(torch.long)).clamp(max=A.shape[0] - 1), ar]
+        del _live, _
+        barrier()
         tp = time.perf_counter()
         world.step_begin(A[0])
         done_steps, polls, sub_p = 0, 0, 0
         idle = 0
+        t_poll = t_kern = 0.0
+        amax = A.shape[0] - 1
+        # the host looks at ONE number per poll (how many env.step() calls completed: rv_get_stats, which also
+        # paces the loop); the bookkeeping -- per-env step counts, who is restarted, which action each env gets --
+        # is a handful of asynchronous device ops, as the action selection of a policy network would be
         while done_steps < args.steps * n and idle < 50:
-            fin = world.step_poll(max_usec=poll_usec, out=out_buf).bool()
+            tq = time.perf_counter()
+            fin = world.step_poll(max_usec=poll_usec, out=out_buf)
             polls += 1
-            nf = int(fin.sum())                       # (synchronises: the host looks at what came back)
-            sub_p += world.stats()['substeps']
+            stp = world.stats()
+            nf = stp['env_steps']
+            t_poll += time.perf_counter() - tq; t_kern += world.last_kernel_ms()
+            sub_p += stp['substeps']
             idle = idle + 1 if nf == 0 else 0
             if nf == 0:
                 continue
             done_steps += nf
-            cnt[fin] += 1
-            live = fin & ~out_buf['done'].bool()      # an env whose episode ended stops, as in the lock-step leg (which has no reset either)
-            if not bool(live.any()) and not bool((cnt == 0).any()) and int(fin.sum()) == 0:
-                break
-            world.step_begin(A[cnt.clamp(max=A.shape[0] - 1), ar], mask=live.to(torch.uint8))
+            live = fin * (1 - out_buf['done'])        # an env whose episode ended stops, as in the lock-step leg (which has no reset either)
+            cnt += live.to(torch.long)
+            world.step_begin(A[cnt.clamp(max=amax), ar], mask=live)
         barrier()
         ep = all_max(time.perf_counter() - tp)
         next_index += 4 * args.steps
         extra['lockstep_partial'] = {'value': all_sum(done_steps)[0] / ep, 'unit': 'env_steps/s', 'sim_steps_per_s': all_sum(sub_p)[0] / ep,
                                      'polls': polls, 'poll_usec': poll_usec, 'envs_per_gpu': n,
+                                     'ms_per_poll_call': 1e3 * t_poll / max(polls, 1), 'kernel_ms_per_poll': t_kern / max(polls, 1),
+                                     'ms_per_poll_loop': 1e3 * ep / max(polls, 1),
                                      'steps_per_env_min_max': [int(cnt.min()), int(cnt.max())],
                                      'note': 'host loop over rv_step_begin / rv_step_poll: K*N env.step() calls, each poll returns the '
                                              'observation (incl. point cloud), reward and done of the envs that finished; per-env '

@@ -142,7 +142,7 @@ struct DevEnv {
   float mu_finger, mu_table;
   int num_action_steps;       // Grasp4DofEnv: substeps spent in the 'start' phase
 #ifdef RV_PROFILE
-  unsigned long long prof[40], prof_t, prof_t2[4];   // tools/prof_rollout.py: shader-clock time per substep part
+  unsigned long long prof[48], prof_t, prof_t2[4];   // tools/prof_rollout.py: shader-clock time per substep part
 #endif
 };
 static_assert(sizeof(DevEnv) % 4 == 0, "DevEnv is copied word-wise");
@@ -2947,6 +2947,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   int arm_static = 0;
   if (arm_on) {
     arm_motor_phases(S, K, 1, 0);
+    RV_PROF(40)
     RV_STOPL(12)
     if (S.s.kin_fresh && K.stop_after == 0) {
       arm_static = 1;
@@ -2955,6 +2956,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
     }
     if (!arm_static) arm_fk_phases(S, K);
   }
+  RV_PROF(41)
   RV_STOPL(1)
   if (arm_static) {
     RV_LANES_BEGIN
@@ -2967,6 +2969,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   } else {
     arm_collider_phases(S, K, arm_on);
   }
+  RV_PROF(42)
   RV_STOPL(16)
 
   // wake test.  A sleeping body is woken by a MOVING awake body nearby, or by the
@@ -3045,6 +3048,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
       }
     RV_LANES_END
   }
+  RV_PROF(43)
   RV_STOPL(17)
 
   // body velocity update + rotations

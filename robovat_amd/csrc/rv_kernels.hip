@@ -214,7 +214,7 @@ __global__ void k_get_link_poses(const DevEnv* envs, int n, float* out) {
 #ifdef RV_PROFILE
 __global__ void k_debug_profile(const DevEnv* envs, int n, unsigned long long* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) for (int k = 0; k < 40; ++k) out[(size_t)i * 40 + k] = envs[i].prof[k];
+  if (i < n) for (int k = 0; k < 48; ++k) out[(size_t)i * 48 + k] = envs[i].prof[k];
 }
 #endif
 __global__ void k_get_env_counters(const DevEnv* envs, int n, int32_t* out) {

@@ -44,9 +44,11 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 from robovat_amd import configs, scenes, lib   # noqa: E402
 
-NS = 40
+NS = 48
 SLOTS = {
-    0: 'quiet substep (light part only)', 1: 'light part of a non-quiet substep', 2: 'heavy: link twists',
+    0: 'quiet substep: rest of the light part', 1: 'non-quiet substep: rest of the light part (body velocities, quiet test)',
+    40: 'light: ControllableBody.update + joint motors', 41: 'light: forward kinematics', 42: 'light: collider boxes, AABBs, gates',
+    43: 'light: wake tests', 2: 'heavy: link twists',
     18: 'heavy: narrow-phase prep (refresh, gate, work list, hull vertices)', 3: 'heavy: narrow-phase queries (GJK/EPA, features)',
     4: 'heavy: solver row setup + flags', 25: 'solver: island entry + row loads', 26: 'solver: Delassus rows + warm start',
     27: 'solver: sweeps', 24: 'solver: island glue + epilogues', 5: 'solver: island of 3-4 bodies (velocity space)',
@@ -97,7 +99,7 @@ w.rollout(args.steps, first_macro_index=first, auto_reset=True, record=False); w
 ms = w.last_kernel_ms()
 p = prof() - p0
 st = w.stats()
-main = [k for k in range(32) if not (12 <= k < 18)]
+main = [k for k in range(32) if not (12 <= k < 18)] + [40, 41, 42, 43]
 tot = p[:, main].sum(axis=1)
 slow = int(np.argmax(tot))
 clk = tot.max() / (ms * 1e-3)
@@ -122,6 +124,7 @@ for k in range(5):
 cnt = w.env_counters().cpu().numpy()
 order = np.argsort(-tot)[:args.top]
 heavy = [1, 2, 18, 3, 4, 25, 26, 27, 24, 5, 6]
+light4 = [40, 41, 42, 43]
 print('slowest envs: id, ms, substeps, awake substeps, convex pairs | % of own time: light, twists, np prep, np queries, rows, isl entry, Delassus, sweeps, glue, big island, integrate | coast+ticks')
 for i in order:
     sh = 100 * p[i, heavy] / tot[i]
