@@ -144,7 +144,11 @@ def main():
     ap.add_argument('--workload', choices=['config2', 'config3', 'config4', 'config5'], default='config2',
                     help='the timed workload (BASELINE.json configs[1..4]); other than config2: for profiling one of the legs '
                          'alone (tools/profile_bench.sh), implies --no-extra-legs')
+    ap.add_argument('--extra-legs', action='store_true', help='run the extra legs at --gpus N > 1 as well (default: N = 1 only -- '
+                    'at 8192 envs per rank the no-deactivation legs alone take minutes)')
     args = ap.parse_args()
+    if args.gpus > 1 and not args.extra_legs:
+        args.no_extra_legs = True
 
     # stdout carries exactly ONE line, the JSON: libraries that print to the C-level stdout (RCCL's
     # version banner, flushed at exit) are sent to stderr for the whole run
@@ -321,9 +325,10 @@ def main():
     extra = {}
     if not args.no_extra_legs:
         other = time_lockstep if args.mode == 'rollout' else time_rollout
-        el2, st2, _, _ = other(world, args.steps, next_index); next_index += args.steps
+        el2, st2, km2, _ = other(world, args.steps, next_index); next_index += args.steps
         name = 'lockstep_env_step' if args.mode == 'rollout' else 'single_launch_rollout'
         extra[name] = leg_summary(el2, st2, args.steps, n)
+        extra[name]['kernel_ms_per_step'] = km2 / args.steps
         extra[name]['note'] = ('host loop: K x (policy -> rv_set_actions -> rv_step_macro -> rv_observe incl. point cloud -> rv_reward); '
                                'every step waits for the slowest env of the batch' if args.mode == 'rollout' else
                                'one rv_rollout_record launch, observations of every step recorded')

@@ -3334,6 +3334,10 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         const int pair = role == 0 ? ii + (body_below_table(e, c, a) ? 64 : 0) : (role == 1 ? io * 8 + ii : (role == 2 ? col * 8 + ii : 0));
         int hit = collide_pair(S, K, ckind, role == 3 ? 0 : a, b, col, A, nA, B, nB, guess, role == 3 ? nullptr : &e.man[mi], &dd, brk, pair);
         if (role == 3 && hit && dd < c->contact_query_dist) S.s.colflag[col] = 1;
+#ifdef RV_EMU_COUNT
+        // queries by role; of them: no contact found (separation beyond the breaking distance)
+        rv_emu_dbg2[40 + role] += 1; if (!hit) rv_emu_dbg2[44 + role] += 1;
+#endif
       }
     }
     if ((lane & 15) == 0) S.s.pairs[slot] = my_pairs;

@@ -54,3 +54,4 @@ d2 = (C.c_long * 48)(); lib.emu_get_dbg2(d2); d2 = list(d2)
 print('fused runs ended by the clearance of box: (body-limited, table-limited) x 10 boxes:', [(d2[2 * i], d2[2 * i + 1]) for i in range(10)])
 print('  mean clearance (mm) the limiting box had at the start of the run:', ['%.1f' % (1e-3 * d2[20 + i] / max(d2[2 * i] + d2[2 * i + 1], 1)) for i in range(10)])
 print('  mean substeps of those runs:', ['%.1f' % (d2[30 + i] / max(d2[2 * i] + d2[2 * i + 1], 1)) for i in range(10)])
+print('convex queries by owner role (table, body-body, arm-body, arm-table):', d2[40:44], ' of them without a contact:', d2[44:48])
