@@ -15,7 +15,9 @@ n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 CASES = [('config 2', {}), ('crossing / concave', dict(TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)),
-         ('crowded: 4 bodies in a 20 cm square', {'MOVABLE.CONVEX.POSE.X': [0.5, 0.7], 'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07})]
+         ('crowded: 4 bodies in a 20 cm square', {'MOVABLE.CONVEX.POSE.X': [0.5, 0.7], 'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07}),
+         ('dynamic limb, 1-4 bodies', {'PHYSICS.LIMB_DYNAMICS': 1, 'MIN_MOVABLE_BODIES': 1, 'MAX_MOVABLE_BODIES': 4}),
+         ('no deactivation', {'PHYSICS.SLEEP_STEPS': 0, 'MAX_STEPS': 2})]
 bad = 0
 for name, over in CASES:
     scene, names = scenes.make_scene()
@@ -32,10 +34,10 @@ for name, over in CASES:
         print('%-38s seed %d: bodies %s joints %s counters %s | awake %.3f' % (name, 1000 + seed, eq_b, eq_j, eq_c, st['awake_substeps'] / st['substeps']), flush=True)
         bad += not (eq_b and eq_j)
         w.close()
-# Grasp4DofEnv (force-limited gripper in the solver, phase machine ticking every substep)
-genv = configs.grasp_env_config()
-gscene, gnames = scenes.make_scene(env_cfg=genv)
-for seed in range(max(n_seeds // 2, 1)):
+# Grasp4DofEnv (force-limited gripper in the solver, phase machine ticking every substep), kinematic and dynamic limb
+for seed in range(max(n_seeds // 2, 1) * 2):
+    genv = configs.grasp_env_config(**({'PHYSICS.LIMB_DYNAMICS': 1} if seed % 2 else {}))
+    gscene, gnames = scenes.make_scene(env_cfg=genv)
     cfg = configs.make_rv_config(env_cfg=genv, n_envs=n, seed=2000 + seed, shape_names=gnames)
     w = lib.World(cfg, gscene, device=0); o = orc.OracleWorld(cfg, gscene, double=False)
     w.reset(); o.reset()
@@ -44,7 +46,7 @@ for seed in range(max(n_seeds // 2, 1)):
     eq_b = np.array_equal(w.body_state().cpu().numpy(), o.body_state().astype(np.float32))
     eq_j = np.array_equal(w.joint_state().cpu().numpy(), o.joint_state().astype(np.float32))
     st = w.stats()
-    print('%-38s seed %d: bodies %s joints %s | successes %d / %d' % ('Grasp4DofEnv', 2000 + seed, eq_b, eq_j, st['successes'], st['env_steps']), flush=True)
+    print('%-38s seed %d: bodies %s joints %s | successes %d / %d' % ('Grasp4DofEnv' + (', dynamic limb' if seed % 2 else ''), 2000 + seed, eq_b, eq_j, st['successes'], st['env_steps']), flush=True)
     bad += not (eq_b and eq_j)
     w.close()
 print('MISMATCHES: %d' % bad)
