@@ -271,7 +271,7 @@ def main():
             ('no_deactivation', {'PHYSICS.SLEEP_STEPS': 0}),
         ]
         if not quick:
-            variants.append(('no_deactivation_50_sweeps', {'PHYSICS.SLEEP_STEPS': 0, 'PHYSICS.SOLVER_TOL': 0.0}))
+            variants.append(('no_deactivation_50_sweeps', {'PHYSICS.SLEEP_STEPS': 0, 'PHYSICS.SOLVER_TOL': 0.0, 'PHYSICS.SOLVER_STALL': 0}))
         out = {'note': 'same workload / seed / actions, one rv_rollout_record launch of %d steps without auto-reset; displacement = '
                        'sum over the bodies of an env of the xy distance moved by one env.step(), mm.  bullet_physics.py:173-181 '
                        'passes no URDF_ENABLE_SLEEPING: no_deactivation is the closest to the reference; no_deactivation_50_sweeps '

@@ -272,6 +272,10 @@ typedef struct rv_config {
    * gravity already take.  A pad that lands on an object then stalls instead of crushing it.  0: the
    * limb is a kinematic pusher (its trajectory does not depend on contacts) */
   int32_t  limb_dynamics;
+  /* > 0: an island also stops when its residual has not fallen below the smallest one seen so far for this
+   * many sweeps in a row -- a Gauss-Seidel that cycles (friction rows dithering at the cone under a body the
+   * arm pins to the table) instead of converging; 0: only solver_tol / solver_iters end a solve */
+  int32_t  solver_stall;
 } rv_config;
 
 /* Per-launch statistics of rv_step_macro / rv_reset (device-side reductions of

@@ -1176,6 +1176,7 @@ static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4]
   const real mf = (real)c->finger_mass, imf = R(1.0) / (real)c->finger_mass, fdt = (real)c->finger_max_force * (real)c->dt;
   real qf[2] = {e->qd[RV_NLIMB], e->qd[RV_NLIMB + 1]}, lam_m[2] = {R(0.0), R(0.0)};
   real lam_c[RV_MAXB][6]; memset(lam_c, 0, sizeof(lam_c));
+  real best = R(1e30); int since = 0;               /* rv_config.solver_stall */
   for (int it = -1; it < c->solver_iters; ++it) {
     real res = R(0.0);
     for (int b = 0; b < RV_MAXB; ++b) {
@@ -1224,6 +1225,7 @@ static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4]
       res = rmax(res, rabs(dl));
     }
     if (res < (real)c->solver_tol) break;
+    if (c->solver_stall > 0) { if (res < best) { best = res; since = 0; } else if (++since >= c->solver_stall) break; }
   }
   for (int j = 0; L && j < RV_NLIMB; ++j) {       /* the limb moves with the solved velocity */
     real qd = e->limb_qd0[j] + dq[j];
@@ -1357,6 +1359,7 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
     }
   for (int s2 = 0; s2 < n_rows; ++s2) for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s2] * lam[s2];
   int isl_rows = 0, done = 0;
+  real best[RV_MAXB] = {R(1e30), R(1e30), R(1e30), R(1e30)}; int since[RV_MAXB] = {0, 0, 0, 0};
   for (int s2 = 0; s2 < n_rows; ++s2) isl_rows |= 1 << id[s2].isl;
   if (fing || L) isl_rows |= 1 << fisl;
   for (int it = 0; it < c->solver_iters; ++it) {
@@ -1392,6 +1395,12 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
       for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][q] * d;
     }
     for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < (real)c->solver_tol) done |= 1 << x;
+    /* stalled islands (rv_config.solver_stall): no new smallest residual for that many sweeps */
+    for (int x = 0; c->solver_stall > 0 && x < RV_MAXB; ++x) {
+      if (!((isl_rows >> x) & 1) || ((done >> x) & 1)) continue;
+      if (res[x] < best[x]) { best[x] = res[x]; since[x] = 0; }
+      else if (++since[x] >= c->solver_stall) done |= 1 << x;
+    }
 #ifdef ORC_DEBUG_SOLVE
     fprintf(stderr, "it %d res %g %g %g %g | lam", it, (double)res[0], (double)res[1], (double)res[2], (double)res[3]);
     for (int s2 = 0; s2 < n_rows; ++s2) fprintf(stderr, " %.4g", (double)lam[s2]);
@@ -1563,6 +1572,7 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
     }
   for (int root = 0; root < RV_MAXB; ++root) {
     if (!big[root]) continue;
+    real big_best = R(1e30); int big_since = 0;     /* rv_config.solver_stall */
     for (int it = 0; it < c->solver_iters; ++it) {
       real res = R(0.0);
       int rows_seen = 0;
@@ -1581,6 +1591,7 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
           for (int i = 0; i < m->n; ++i) { res = rmax(res, point_solve(e, 1, BB_A[k], BB_B[k], m, i, &rows[BBIDX(k)][i])); rows_seen++; }
         }
       if (rows_seen == 0 || res < (real)c->solver_tol) break;   /* residual-based early exit */
+      if (c->solver_stall > 0) { if (res < big_best) { big_best = res; big_since = 0; } else if (++big_since >= c->solver_stall) break; }
     }
   }
 }

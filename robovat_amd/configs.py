@@ -120,6 +120,7 @@ PUSH_ENV_CONFIG = {
         'LINEAR_DAMPING': 0.04, 'ANGULAR_DAMPING': 0.04,
         'CONTACT_QUERY_DIST': 0.001, 'ARM_FRICTION': 0.8,
         'SOLVER_TOL': 1e-5,      # sweeps stop early on this residual (Bullet: 50 iterations, no early exit)
+        'SOLVER_STALL': 12,      # ... and when no new smallest residual has been seen for this many sweeps (a cycling Gauss-Seidel)
         'SLEEP_LINEAR': 0.02, 'SLEEP_ANGULAR': 0.5, 'SLEEP_STEPS': 200,
         'SLEEP_POSITION_WINDOW': 1e-3, 'SLEEP_ROTATION_WINDOW': 0.01,
         'NARROWPHASE_GATE': 1e-3, 'NARROWPHASE_MAX_AGE': 8,
@@ -241,6 +242,7 @@ def make_rv_config(env_cfg=None, robot_cfg=None, shape_names=None, n_envs=1,
     c.ang_damp = float(np.float32((1.0 - ph.ANGULAR_DAMPING) ** ph.TIME_STEP))
     c.contact_query_dist = ph.CONTACT_QUERY_DIST
     c.solver_tol = ph.SOLVER_TOL
+    c.solver_stall = int(ph.get('SOLVER_STALL', 0))
     c.sleep_lin, c.sleep_ang, c.sleep_steps = ph.SLEEP_LINEAR, ph.SLEEP_ANGULAR, int(ph.SLEEP_STEPS)
     c.sleep_pos_win, c.sleep_rot_win = ph.SLEEP_POSITION_WINDOW, ph.SLEEP_ROTATION_WINDOW
     c.np_gate, c.np_max_age = ph.NARROWPHASE_GATE, int(ph.NARROWPHASE_MAX_AGE)

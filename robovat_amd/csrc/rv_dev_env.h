@@ -1263,6 +1263,7 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb) {
   float qf[2] = {e.qd[RV_NLIMB], e.qd[RV_NLIMB + 1]}, lam_m[2] = {0.0f, 0.0f};
   float lam_c[RV_MAXB][6];
   for (int b = 0; b < RV_MAXB; ++b) for (int k = 0; k < 6; ++k) lam_c[b][k] = 0.0f;
+  float best = 1e30f; int since = 0;              // rv_config.solver_stall
   for (int it = -1; it < c->solver_iters; ++it) {   // it == -1: warm start
     float res = 0.0f;
     for (int b = 0; b < RV_MAXB; ++b) {
@@ -1323,6 +1324,7 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb) {
       res = fmaxr(res, fabsr(dl));
     }
     if (res < c->solver_tol) break;
+    if (c->solver_stall > 0) { if (res < best) { best = res; since = 0; } else if (++since >= c->solver_stall) break; }
   }
   for (int j = 0; limb && j < RV_NLIMB; ++j) {   // the limb moves with the solved velocity
     float qd = S.s.limb_qd0[j] + dq[j];
@@ -1484,6 +1486,7 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
   // residual |d| is tracked on the scalar unit through its bit pattern, whose integer order is the
   // order of the magnitudes)
   const int toli = __builtin_bit_cast(int, tol);
+  const int stall = c->solver_stall; int besti = 0x7f800000, since = 0;
   const bool in_y = lane >= 24 && lane < 48;
   for (int it = 0; it < iters; ++it) {
     int resi = 0;
@@ -1556,6 +1559,8 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
       }
     }
     if (tol > 0.0f ? resi < toli : false) break;
+    // stalled (rv_config.solver_stall): no new smallest residual for that many sweeps
+    if (stall > 0) { if (resi < besti) { besti = resi; since = 0; } else if (++since >= stall) break; }
   }
   RV_PROF(27)
   // impulses back to the manifolds; what every row adds to X and Y goes through LDS (the hull-vertex
@@ -1706,6 +1711,7 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
   for (int s = 0; s < 24; ++s) { const int ps = s / 3; if (ps < 4 ? ps < ntx : ps - 4 < nax) g = g + A[s] * rdlane(lam, s); }
   const int iters = c->solver_iters; const float tol = c->solver_tol;
   const int toli = __builtin_bit_cast(int, tol);
+  const int stall = c->solver_stall; int besti = 0x7f800000, since = 0;
   for (int it = 0; it < iters; ++it) {
     int resi = 0;
 #pragma unroll
@@ -1753,6 +1759,8 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
       }
     }
     if (tol > 0.0f ? resi < toli : false) break;
+    // stalled (rv_config.solver_stall): no new smallest residual for that many sweeps
+    if (stall > 0) { if (resi < besti) { besti = resi; since = 0; } else if (++since >= stall) break; }
   }
   // impulses back to the manifolds; body, finger and limb velocities rebuilt in row order through LDS
   float* cb = &S.s.u.r.wv[0][0][0][0];
@@ -1914,6 +1922,7 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
     }
   for (int s = 0; s < n_rows; ++s) for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s] * lam[s];
   int isl_rows = 0, done = 0;
+  float best[RV_MAXB] = {1e30f, 1e30f, 1e30f, 1e30f}; int since[RV_MAXB] = {0, 0, 0, 0};
   for (int s = 0; s < n_rows; ++s) isl_rows |= 1 << RV_ROW_ISL(S.s.rowmap[s]);
   if (fing || limb) isl_rows |= 1 << fisl;
   RV_CNT(21, 1) RV_CNT(23, n_rows)
@@ -1971,6 +1980,12 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
     }
 #endif
     for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < c->solver_tol) done |= 1 << x;
+    // stalled islands (rv_config.solver_stall): no new smallest residual for that many sweeps
+    for (int x = 0; c->solver_stall > 0 && x < RV_MAXB; ++x) {
+      if (!((isl_rows >> x) & 1) || ((done >> x) & 1)) continue;
+      if (res[x] < best[x]) { best[x] = res[x]; since[x] = 0; }
+      else if (++since[x] >= c->solver_stall) { done |= 1 << x; RV_CNT(7, 1) }
+    }
     if ((done & isl_rows) == isl_rows) break;
     if (it == c->solver_iters - 1) { RV_CNT(30, 1) }
   }
@@ -3500,6 +3515,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   RV_PROF(24)
   if (!with_fingers && !any_con && big_root >= 0) {
     const int root = big_root;
+    float big_best = 1e30f; int big_since = 0;        // rv_config.solver_stall
     for (int it = -1; it < c->solver_iters; ++it) {   // it == -1: warm start
       RV_LANES_BEGIN
         DevEnv& e = S.e;
@@ -3551,6 +3567,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
 #pragma unroll
       for (int t = 0; t < 10; ++t) res = fmaxr(res, S.s.res[t]);
       if (it >= 0 && res < c->solver_tol) break;
+      if (it >= 0 && c->solver_stall > 0) { if (res < big_best) { big_best = res; big_since = 0; } else if (++big_since >= c->solver_stall) break; }
     }
   }
 

@@ -23,7 +23,11 @@ lib.emu_create.argtypes = [C.POINTER(abi.rv_config), C.POINTER(abi.rv_scene)]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 scene, names = scenes.make_scene()
-cfg = configs.make_rv_config(n_envs=n, seed=1234, shape_names=names)
+over = {}
+for kv in sys.argv[3:]:                      # config overrides, e.g. PHYSICS.SOLVER_STALL=8
+    k_, v_ = kv.split('=', 1)
+    over[k_] = eval(v_)
+cfg = configs.make_rv_config(env_cfg=configs.push_env_config(**over), n_envs=n, seed=1234, shape_names=names)
 h = C.c_void_p(lib.emu_create(C.byref(cfg), C.byref(scene)))
 lib.emu_reset(h, None)
 out = (C.c_long * 48)()

@@ -27,7 +27,7 @@ VARIANTS = [
     ('shipped', {}),
     ('rolling / spinning friction 0 (round-1 value; urdf_template: 0.001 = shipped)', {'PHYSICS.ROLLING_FRICTION': 0.0}),
     ('solver: at most 8 iterations (round-1 value; Bullet: 50 = shipped)', {'PHYSICS.SOLVER_ITERS': 8}),
-    ('solver: 50 iterations, no early exit (Bullet)', {'PHYSICS.SOLVER_TOL': 0.0}),
+    ('solver: 50 iterations, no early exit (Bullet)', {'PHYSICS.SOLVER_TOL': 0.0, 'PHYSICS.SOLVER_STALL': 0}),
     ('sleep: Bullet\'s rule alone (0.8 m/s, 1 rad/s, 2 s)',
      {'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0, 'PHYSICS.SLEEP_STEPS': 2000, 'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.DEACTIVATION_STEPS': 0}),
     ('sleep: without Bullet\'s rule (the strict thresholds and the pose window only)', {'PHYSICS.DEACTIVATION_STEPS': 0}),
@@ -36,7 +36,7 @@ VARIANTS = [
     ('contact breaking factor 0.04 (Bullet: 0.02 x the smaller shape\'s disc = shipped)', {'PHYSICS.BREAKING': 0.04}),
     ('narrow phase every substep (no gating)', {'PHYSICS.NARROWPHASE_MAX_AGE': 0}),
     ('all Bullet defaults (solver + sleep, no gating)',
-     {'PHYSICS.SOLVER_ITERS': 50, 'PHYSICS.SOLVER_TOL': 0.0, 'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0,
+     {'PHYSICS.SOLVER_ITERS': 50, 'PHYSICS.SOLVER_TOL': 0.0, 'PHYSICS.SOLVER_STALL': 0, 'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0,
       'PHYSICS.SLEEP_STEPS': 2000, 'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.NARROWPHASE_MAX_AGE': 0, 'PHYSICS.WAKE_GAP': 1.0, 'PHYSICS.DEACTIVATION_STEPS': 0}),
 ]
 
