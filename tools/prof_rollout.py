@@ -78,6 +78,8 @@ else:
 cfg = configs.make_rv_config(env_cfg=env_cfg, n_envs=args.envs, seed=args.seed, shape_names=names)
 w = lib.World(cfg, scene, 0)
 L = lib.load()
+if lib.built_source_hash() != lib.source_hash():
+    sys.exit('librovat_hip_prof.so was built from other sources: python tools/prof_rollout.py --build')
 n = args.envs
 
 
