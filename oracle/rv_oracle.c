@@ -1791,6 +1791,12 @@ static void sim_substep(const orc_world* w, orc_env* e) {
       }
       ready[b] = e->bp[b].frozen || (!held && (e->bp[b].sleep_count >= c->sleep_steps || e->bp[b].still_count >= c->sleep_steps || quick || deact));
     }
+#ifdef ORC_TRACE_AWAKE
+    /* diagnostic (tools): one line per awake body and substep of env ORC_TRACE_ENV */
+    { static int tenv = -2; if (tenv == -2) { const char* t_ = getenv("ORC_TRACE_ENV"); tenv = t_ ? atoi(t_) : -1; }
+      if (tenv == (int)(e - w->env)) fprintf(stderr, "T %d ph %d b %d v %.4f w %.3f sc %d st %d arm %d tab %d\n", e->sim_steps, e->phase, b,
+          (double)rsqrt_(vv), (double)rsqrt_(ww), e->bp[b].sleep_count, e->bp[b].still_count, e->man[AIDX(b)].n, e->man[TIDX(b)].n); }
+#endif
   }
   /* islands go to sleep as a whole: a body sleeps when every awake body it is coupled to
    * (transitively) by manifolds that hold points is ready as well */
