@@ -243,10 +243,10 @@ static void arm_update_kinematics(const orc_world* w, orc_env* e) {
       real l[3] = {cc[0] + ((k & 1) ? hh[0] : -hh[0]), cc[1] + ((k & 2) ? hh[1] : -hh[1]), cc[2] + ((k & 4) ? hh[2] : -hh[2])};
       m3mulv(t, e->frot[f], l); v3add(e->colv[c][k], e->fpos[f], t);
     }
+    /* world AABB of the oriented box: centre +- |R| half (no vertices needed) */
     for (int x = 0; x < 3; ++x) {
-      real lo = e->colv[c][0][x], hi = e->colv[c][0][x];
-      for (int k = 1; k < 8; ++k) { lo = rmin(lo, e->colv[c][k][x]); hi = rmax(hi, e->colv[c][k][x]); }
-      e->colmin[c][x] = lo; e->colmax[c][x] = hi;
+      const real ext = rabs(e->frot[f][3 * x]) * hh[0] + rabs(e->frot[f][3 * x + 1]) * hh[1] + rabs(e->frot[f][3 * x + 2]) * hh[2];
+      e->colmin[c][x] = e->colc[c][x] - ext; e->colmax[c][x] = e->colc[c][x] + ext;
     }
   }
   e->arm_moving = 0;
@@ -832,9 +832,8 @@ static void collide_all(const orc_world* w, orc_env* e) {
       }
       /* arm - table: detection only (push_env.py:839-855) */
       real r = e->colr[col] + brk_col(w, col);
-      real minz = e->colv[col][0][2];
-      for (int k = 1; k < 8; ++k) minz = rmin(minz, e->colv[col][k][2]);
-      /* exact rejection: the flag needs dist < query_dist and dist >= minz - table_z - margin */
+      const real minz = e->colmin[col][2];
+      /* rejection: the flag needs dist < query_dist and dist >= minz - table_z - margin */
       if (minz - e->table_z - (real)c->margin >= qd) continue;
       if (sphere_box_dist2(e->colc[col], tc, th) < r * r) {
         real guess[3] = {R(0.0), R(0.0), R(1.0)}, dd;

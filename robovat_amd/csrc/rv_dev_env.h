@@ -931,9 +931,8 @@ RV_DEV void owner_decode(const Shared& S, const Consts& K, int owner, int arm_on
     o.a = col;
     if (arm_on) {
       float r = S.s.colr[col] + brk_col(K.arm, c, col);
-      float minz = S.s.colv[col][0][2];
-      for (int k = 1; k < 8; ++k) minz = fminr(minz, S.s.colv[col][k][2]);
-      // exact rejection: the flag needs dist < query_dist and dist >= minz - table_z - margin
+      const float minz = S.s.colmin[col][2];
+      // rejection: the flag needs dist < query_dist and dist >= minz - table_z - margin
       if (!(minz - e.table_z - c->margin >= c->contact_query_dist) &&
           sphere_box_dist2(ld3(S.s.colc[col]), tc, th) < r * r) { o.role = 3; o.n_outer = 1; o.n_inner = 1; }
     }
@@ -2186,52 +2185,43 @@ RV_DEV void arm_fk_phases(Shared& S, const Consts& K) {
     }
   RV_LANES_END
 }
-// collider boxes in the world, their AABBs and the arm-table gate
+// collider boxes in the world: centres, AABBs (centre +- |R| half: no vertices needed) and the arm-table gate.
+// The eight vertices of a box are only the input of a convex query: arm_box_vertices() computes them for the
+// boxes that are about to take part in one (a wake query, an arm - body or an arm - table query).
 RV_DEV void arm_collider_phases(Shared& S, const Consts& K, const int arm_on) {
   const rv_config* c = K.cfg;
   const rv_arm* arm = K.arm;
   RV_LANES_BEGIN
-    if (lane < RV_MAXB) { S.s.wake[lane] = 0; S.s.bnear[lane] = 0; }
-    if (lane == 8) S.s.near_any = 0;
-    if (arm_on) {
-      for (int item = lane; item < RV_NCOL * 8; item += 64) {
-        int col = item >> 3, k = item & 7;
-        int f = arm->col_frame[col];
-        v3 cc = ld3(arm->col_center[col]), hh = ld3(arm->col_half[col]);
-        v3 l = mk(cc.x + ((k & 1) ? hh.x : -hh.x), cc.y + ((k & 2) ? hh.y : -hh.y), cc.z + ((k & 4) ? hh.z : -hh.z));
-        st3(S.s.colv[col][k], add(ld3(S.e.fpos[f]), mulv(S.s.frot[f], l)));
-      }
-      if (lane < RV_NCOL) {
-        int col = lane; int f = arm->col_frame[col];
-        v3 cc = ld3(arm->col_center[col]), hh = ld3(arm->col_half[col]);
-        st3(S.s.colc[col], add(ld3(S.e.fpos[f]), mulv(S.s.frot[f], cc)));
-        S.s.colr[col] = fsqrtr(hh.x * hh.x + hh.y * hh.y + hh.z * hh.z) + c->margin;
-        S.s.colflag[col] = 0;
-      }
-    }
-  RV_LANES_END
-  // world AABB of every collider box; can the box be within the contact-query
-  // distance of the table?  (the two rejection tests of the arm-table detector)
-  RV_LANES_BEGIN
+    if (lane >= 16 && lane < 16 + RV_MAXB) { S.s.wake[lane - 16] = 0; S.s.bnear[lane - 16] = 0; }
+    if (lane == 24) S.s.near_any = 0;
     if (arm_on && lane < RV_NCOL) {
-      int col = lane;
-      float lo3[3];
+      const int col = lane; const int f = arm->col_frame[col];
+      const v3 cc = ld3(arm->col_center[col]), hh = ld3(arm->col_half[col]);
+      const float* R = S.s.frot[f];
+      const v3 cw = add(ld3(S.e.fpos[f]), mulv(R, cc));
+      st3(S.s.colc[col], cw);
+      const float colr = fsqrtr(hh.x * hh.x + hh.y * hh.y + hh.z * hh.z) + c->margin;
+      S.s.colr[col] = colr;
+      S.s.colflag[col] = 0;
+      const float cwa[3] = {cw.x, cw.y, cw.z};
+      float lo_z = 0.0f;
 #pragma unroll
       for (int x = 0; x < 3; ++x) {
-        float lo = S.s.colv[col][0][x], hi = lo;
-#pragma unroll
-        for (int k = 1; k < 8; ++k) { float v = S.s.colv[col][k][x]; lo = fminr(lo, v); hi = fmaxr(hi, v); }
-        S.s.colmin[col][x] = lo; S.s.colmax[col][x] = hi;
-        lo3[x] = lo;
+        const float ext = fabsr(R[3 * x]) * hh.x + fabsr(R[3 * x + 1]) * hh.y + fabsr(R[3 * x + 2]) * hh.z;
+        const float lo = cwa[x] - ext;
+        S.s.colmin[col][x] = lo; S.s.colmax[col][x] = cwa[x] + ext;
+        if (x == 2) lo_z = lo;
       }
+      // can the box be within the contact-query distance of the table?  (the two rejection tests of the
+      // arm-table detector)
       v3 tc = mk(c->table_center[0], c->table_center[1], S.e.table_z - 0.5f * c->table_thickness);
       v3 th = mk(c->table_half[0], c->table_half[1], 0.5f * c->table_thickness);
-      float r = S.s.colr[col] + brk_col(arm, c, col);
-      S.s.atflag[col] = (!(lo3[2] - S.e.table_z - c->margin >= c->contact_query_dist) &&
-                         sphere_box_dist2(ld3(S.s.colc[col]), tc, th) < r * r) ? 1 : 0;
+      float r = colr + brk_col(arm, c, col);
+      S.s.atflag[col] = (!(lo_z - S.e.table_z - c->margin >= c->contact_query_dist) &&
+                         sphere_box_dist2(cw, tc, th) < r * r) ? 1 : 0;
       // how far a vertex of this box can have moved in this substep (joint travel x reach)
       {
-        const DevEnv& e = S.e; const int f = arm->col_frame[col]; const int fl = f < 7 ? f : 7;
+        const DevEnv& e = S.e; const int fl = f < 7 ? f : 7;
         float tr = 0.0f, reach = S.s.colext[col];
         for (int j = fl; j >= 0; --j) {
           if (j < RV_NLIMB) tr += reach * (fabsr(e.qd[j]) * c->dt);
@@ -2243,6 +2233,14 @@ RV_DEV void arm_collider_phases(Shared& S, const Consts& K, const int arm_on) {
     }
     if (lane == 63) { S.s.kin_fresh = arm_on; S.s.clr_valid = 0; }   // left-over clearances are for coasting chains only
   RV_LANES_END
+}
+// the eight world vertices of collider box col (lane k < 8 of the caller's choice)
+RV_DEV void arm_box_vertex(Shared& S, const Consts& K, const int col, const int k) {
+  const rv_arm* arm = K.arm;
+  const int f = arm->col_frame[col];
+  const v3 cc = ld3(arm->col_center[col]), hh = ld3(arm->col_half[col]);
+  const v3 l = mk(cc.x + ((k & 1) ? hh.x : -hh.x), cc.y + ((k & 2) ? hh.y : -hh.y), cc.z + ((k & 4) ? hh.z : -hh.z));
+  st3(S.s.colv[col][k], add(ld3(S.e.fpos[f]), mulv(S.s.frot[f], l)));
 }
 
 #ifdef RV_EMU_COUNT
@@ -3024,8 +3022,15 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   RV_LANES_END
   const int near_any = S.s.near_any;
   if (near_any) {
-    // stage 2a: world hull vertices of the flagged sleepers
+    // stage 2a: world hull vertices of the flagged sleepers, and the vertices of the boxes near them
     RV_LANES_BEGIN
+      for (int item = lane; item < RV_NCOL * 8; item += 64) {
+        const int col = item >> 3;
+        int nd = 0;
+#pragma unroll
+        for (int b = 0; b < RV_MAXB; ++b) nd |= S.s.nearf[b][col];
+        if (nd) arm_box_vertex(S, K, col, item & 7);
+      }
       for (int item = lane; item < RV_MAXB * RV_MAXH * RV_MAXV; item += 64) {
         int b = item / (RV_MAXH * RV_MAXV), h = (item / RV_MAXV) % RV_MAXH, i = item % RV_MAXV;
         if (!S.s.bnear[b]) continue;
@@ -3292,13 +3297,26 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     }
   RV_LANES_END
 #endif
-  // world hull vertices of the bodies that take part in a convex query
+  // world hull vertices of the bodies, and vertices of the collider boxes, that take part in a convex query
   {
     int any = 0;
 #pragma unroll
     for (int b = 0; b < RV_MAXB; ++b) any |= S.s.wvneed[b];
+    if (arm_on) {
+#pragma unroll
+      for (int col = 0; col < RV_NCOL; ++col) any |= S.s.atflag[col];
+    }
     if (any) {
       RV_LANES_BEGIN
+        if (arm_on) {
+          for (int item = lane; item < RV_NCOL * 8; item += 64) {
+            const int col = item >> 3;
+            int nd = S.s.atflag[col];
+#pragma unroll
+            for (int b = 0; b < RV_MAXB; ++b) nd |= S.s.cn[b][col];
+            if (nd) arm_box_vertex(S, K, col, item & 7);
+          }
+        }
         for (int b = 0; b < RV_MAXB; ++b) {
           if (!S.s.wvneed[b]) continue;
           const rv_shape* s = &K.scene->shapes[S.e.shape[b]];
