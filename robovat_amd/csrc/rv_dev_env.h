@@ -2950,6 +2950,28 @@ RV_DEV int coast_run(Shared& S, const Consts& K, const int steps_check, const in
   return n;
 }
 
+// link twist of frame f (used by the arm-body contact rows; base is static): w_f = sum_k axis_k qd_k,
+// v_f = sum_k (axis_k qd_k) x (p_f - p_k) over the joints upstream of f; the fingers add their slide along
+// the hand's y axis.  fmot: how far a collider vertex riding on the frame can travel in this substep.
+// Runs on idle lanes of the body-velocity phase of the light part (one phase less per heavy substep).
+RV_DEV void arm_twist_lane(Shared& S, const Consts& K, const int f) {
+  const rv_config* c = K.cfg;
+  const DevEnv& e = S.e;
+  const int kmax = f < RV_NLIMB ? f : RV_NLIMB - 1;
+  v3 pf = ld3(e.fpos[f]);
+  v3 fw = mk(0, 0, 0), fv = mk(0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < RV_NLIMB; ++k) if (k <= kmax) {
+    v3 u = scale(ld3(S.s.axis[k]), e.qd[k]);
+    fw = add(fw, u);
+    fv = add(fv, cross(u, sub(pf, ld3(e.fpos[k]))));
+  }
+  // the slide of a finger along the hand's y axis (a solver DOF of its own in finger_dynamics mode)
+  if (f >= 8 && !c->finger_dynamics) fv = madd(fv, mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]), e.qd[f - 1]);
+  st3(S.s.fv[f], fv); st3(S.s.fw[f], fw);
+  S.s.fmot[f] = (len(fv) + len(fw) * S.s.fext[f]) * c->dt;
+  if (f >= 8 && c->finger_dynamics) S.s.fmot[f] += fabsr(e.qd[f - 1]) * c->dt;
+}
 RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   const rv_config* c = K.cfg;
   const int arm_on = S.e.arm_enabled;
@@ -3113,6 +3135,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   RV_LANES_END
   RV_LANES_BEGIN
 #endif
+    if (arm_on && lane >= 16 && lane < 16 + RV_NFRAME) arm_twist_lane(S, K, lane - 16);
     if (lane < RV_MAXB) {
       int b = lane; DevEnv& e = S.e;
 #if !defined(__HIPCC__) || defined(RV_EMULATE)
@@ -3173,37 +3196,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   const rv_config* c = K.cfg;
   const rv_arm* arm = K.arm;
   const int arm_on = S.e.arm_enabled;
-  // link twists (used by the arm-body contact rows) and hull vertices to world frame
-  RV_LANES_BEGIN
-    if (lane < RV_NFRAME && arm_on) {
-      // twists (base is static), frame by frame: w_f = sum_k axis_k qd_k,
-      // v_f = sum_k (axis_k qd_k) x (p_f - p_k) over the joints upstream of f; the
-      // fingers add their slide along the hand's y axis.  fmot: how far a collider
-      // vertex riding on the frame can travel in this substep.
-      const DevEnv& e = S.e; const int f = lane;
-      const int kmax = f < RV_NLIMB ? f : RV_NLIMB - 1;
-      v3 pf = ld3(e.fpos[f]);
-      v3 fw = mk(0, 0, 0), fv = mk(0, 0, 0);
-#pragma unroll
-      for (int k = 0; k < RV_NLIMB; ++k) if (k <= kmax) {
-        v3 u = scale(ld3(S.s.axis[k]), e.qd[k]);
-        fw = add(fw, u);
-        fv = add(fv, cross(u, sub(pf, ld3(e.fpos[k]))));
-      }
-      // the slide of a finger along the hand's y axis (a solver DOF of its own in finger_dynamics mode)
-      if (f >= 8 && !c->finger_dynamics) fv = madd(fv, mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]), e.qd[f - 1]);
-      st3(S.s.fv[f], fv); st3(S.s.fw[f], fw);
-      S.s.fmot[f] = (len(fv) + len(fw) * S.s.fext[f]) * c->dt;
-      if (f >= 8 && c->finger_dynamics) S.s.fmot[f] += fabsr(e.qd[f - 1]) * c->dt;
-    }
-#ifdef RV_DIAG_AWAKE_BODIES   // diagnostic build (tools/diag_lockstep.py): count awake BODIES per substep
-    if (lane == 63) { int nb_ = 0; for (int b = 0; b < RV_MAXB; ++b) nb_ += body_on(S.e, b); S.e.awake_last += nb_ * 65536 + S.s.any_on; }
-#else
-    if (lane == 63) S.e.awake_last += S.s.any_on;
-#endif
-    // (the hull vertices go to the world frame after the narrow-phase work list is known, and only
-    // for the bodies whose owners run convex queries in this substep)
-  RV_LANES_END
+  // (the link twists are computed by idle lanes of the last light phase, arm_twist_lane)
   RV_STOP(2)
   RV_PROF(2)
   // manifold refresh + narrow phase.  24 manifold owners (4 body-table, 6 body-body, 4
@@ -3233,6 +3226,11 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       S.s.rf_dist[lane] = d; S.s.rf_rm[lane] = rm;
     }
     if (lane >= 60) S.s.wvneed[lane - 60] = 0;
+#ifdef RV_DIAG_AWAKE_BODIES   // diagnostic build (tools/diag_lockstep.py): count awake BODIES per substep
+    if (lane == 59) { int nb_ = 0; for (int b = 0; b < RV_MAXB; ++b) nb_ += body_on(S.e, b); S.e.awake_last += nb_ * 65536 + S.s.any_on; }
+#else
+    if (lane == 59) S.e.awake_last += S.s.any_on;
+#endif
   RV_LANES_END
   RV_LANES_BEGIN
     DevEnv& e = S.e;
