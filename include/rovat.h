@@ -453,7 +453,7 @@ int  rv_rollout_record_full(rv_world* w, int32_t n_steps, int32_t first_macro_in
 
 /* ---- CameraObs 'depth' / 'segmask' (camera_obs.py:33-88; BulletCamera._frames,
  *      bullet_camera.py:188-235) of the simulated depth camera: eye-space depth (0 where
- *      nothing is hit) and segmentation (body index, RV_MAXB = table, 255 = nothing).
+ *      nothing is hit) and segmentation (body index, RV_MAXB = table, RV_MAXB + 1 = the arm's link boxes, 255 = nothing).
  *      The arm is not rendered.  Either pointer may be NULL. */
 int  rv_render(rv_world* w, float* d_depth /* [N][cam_height][cam_width] */, uint8_t* d_segmask /* same shape */);
 /* CameraObs 'rgb' (camera_obs.py:33-88; bullet_camera.py:188-235): the same ray cast, flat colours

@@ -2748,7 +2748,22 @@ static int pc_ray_table(const rv_config* c, real table_z, const real* o, const r
   if (axis_hit) *axis_hit = ax;
   return 1;
 }
-/* nearest hit of a pixel ray: body index, RV_MAXB = table, -1 = nothing */
+/* entry depth into the box |x_k| <= h_k (ray in the box frame) */
+static int pc_ray_box(const real* h, const real* o, const real* d, real* t_hit, int* axis_hit) {
+  real t0 = R(0.0), t1 = R(1e30); int ax = -1;
+  for (int k = 0; k < 3; ++k) {
+    if (d[k] != R(0.0)) {
+      real a = (-h[k] - o[k]) / d[k], b = (h[k] - o[k]) / d[k];
+      real tn = a < b ? a : b, tf = a < b ? b : a;
+      if (tn > t0) { t0 = tn; ax = a < b ? k : 3 + k; }
+      if (tf < t1) t1 = tf;
+    } else if (o[k] < -h[k] || o[k] > h[k]) return 0;
+  }
+  if (t0 > t1) return 0;
+  *t_hit = t0; *axis_hit = ax;
+  return 1;
+}
+/* nearest hit of a pixel ray: body index, RV_MAXB = table, RV_MAXB + 1 = the arm (its link collider boxes), -1 = nothing */
 static int pc_render_pixel_n(const orc_world* w, const orc_env* e, real rot[][9], const real* cam_o, const real* dw, real* depth, real* normal) {
   const rv_config* c = &w->cfg;
   real best = R(1e30); int who = -1;
@@ -2768,6 +2783,29 @@ static int pc_render_pixel_n(const orc_world* w, const orc_env* e, real rot[][9]
       if (pc_ray_hull(sh->planes[h], sh->n_planes[h], e->bp[b].scale, (real)c->margin, ol, dl, &t, &ip) && t < best) {
         best = t; who = b;
         if (normal && ip >= 0) { real pn[3] = {(real)sh->planes[h][ip][0], (real)sh->planes[h][ip][1], (real)sh->planes[h][ip][2]}; m3mulv(nb, rot[b], pn); }
+      }
+    }
+  }
+  if (e->arm_enabled) {
+    const rv_arm* arm = &w->scene.arm;
+    for (int col = 0; col < RV_NCOL; ++col) {
+      const int f = arm->col_frame[col];
+      const real hh[3] = {(real)arm->col_half[col][0] + (real)c->margin, (real)arm->col_half[col][1] + (real)c->margin, (real)arm->col_half[col][2] + (real)c->margin};
+      real Rm[9], cc[3] = {(real)arm->col_center[col][0], (real)arm->col_center[col][1], (real)arm->col_center[col][2]}, t3[3], cw[3], rel[3];
+      qmat(Rm, e->fquat[f]);
+      m3mulv(t3, Rm, cc); v3add(cw, e->fpos[f], t3);
+      /* (the device keeps the box centre in a float snapshot) */
+      cw[0] = (real)(float)cw[0]; cw[1] = (real)(float)cw[1]; cw[2] = (real)(float)cw[2];
+      v3sub(rel, cam_o, cw);
+      const real r2 = hh[0] * hh[0] + hh[1] * hh[1] + hh[2] * hh[2];
+      const real dd = v3dot(dw, dw), rd = v3dot(rel, dw);
+      const real perp2 = v3dot(rel, rel) - rd * rd / dd;
+      if (perp2 > r2) continue;
+      real ol[3], dl[3], t; int ia = -1;
+      m3tmulv(ol, Rm, rel); m3tmulv(dl, Rm, dw);
+      if (pc_ray_box(hh, ol, dl, &t, &ia) && t < best) {
+        best = t; who = RV_MAXB + 1;
+        if (normal && ia >= 0) { const real sg = ia < 3 ? R(-1.0) : R(1.0); const int k = ia % 3; real an[3] = {k == 0 ? sg : R(0.0), k == 1 ? sg : R(0.0), k == 2 ? sg : R(0.0)}; m3mulv(nb, Rm, an); }
       }
     }
   }
@@ -2803,7 +2841,7 @@ static uint32_t pc_hash(const rv_config* c, uint32_t gid, uint32_t rng_arg, uint
 static void pc_body_rots(const orc_env* e, real rot[][9]) { for (int b = 0; b < RV_MAXB; ++b) qmat(rot[b], e->body[b].q); }
 /* the full depth / segmentation image of one env (tests: input of the reference-shaped
  * deproject -> convert_segment_ids -> group_by_labels pipeline).  segmask: body index,
- * RV_MAXB = table, 255 = nothing; depth 0 where nothing is hit */
+ * RV_MAXB = table, RV_MAXB + 1 = arm, 255 = nothing; depth 0 where nothing is hit */
 void orc_render(orc_world* w, int env, float* depth, uint8_t* segmask) {
   const rv_config* c = &w->cfg; const orc_env* e = &w->env[env];
   real rot[RV_MAXB][9], cam_o[3], Rm[9];
@@ -2822,7 +2860,7 @@ void orc_render(orc_world* w, int env, float* depth, uint8_t* segmask) {
  * Lambert-shaded with the normal of the face hit, one fixed directional light; rgb: [H][W][3] */
 void orc_render_rgb(orc_world* w, int env, uint8_t* rgb) {
   const rv_config* c = &w->cfg; const orc_env* e = &w->env[env];
-  static const real base[RV_MAXB + 2][3] = {{230, 60, 60}, {60, 170, 230}, {250, 200, 40}, {90, 200, 110}, {150, 120, 90}, {30, 30, 30}};
+  static const real base[RV_MAXB + 3][3] = {{230, 60, 60}, {60, 170, 230}, {250, 200, 40}, {90, 200, 110}, {150, 120, 90}, {185, 185, 195}, {30, 30, 30}};   /* bodies, table, arm, background */
   real rot[RV_MAXB][9], cam_o[3], Rm[9];
   pc_body_rots(e, rot); pc_cam_position(c, cam_o); pc_cam_rot(c, Rm);
   for (int v = 0; v < c->cam_height; ++v)
@@ -2831,7 +2869,7 @@ void orc_render_rgb(orc_world* w, int env, uint8_t* rgb) {
       pc_pixel_dir_cam(c, (real)u, (real)v, dc); m3tmulv(dw, Rm, dc);
       int who = pc_render_pixel_n(w, e, rot, cam_o, dw, &dep, n);
       if (who >= 0 && !(dep > (real)c->cam_near)) who = -1;
-      const int idx = who < 0 ? RV_MAXB + 1 : who;
+      const int idx = who < 0 ? RV_MAXB + 2 : who;
       real sh = R(1.0);
       if (who >= 0) {
         const real lam = n[0] * R(0.30151134) + n[1] * R(-0.30151134) + n[2] * R(0.90453403);

@@ -3998,7 +3998,8 @@ RV_DEV void compute_obs(DevEnv& e) {
     }
 }
 // pose snapshot for the point-cloud render (rv_dev_obs.h)
-RV_DEV void obs_snap_fill(const DevEnv& e, ObsSnap& s) {
+RV_DEV void obs_snap_arm(const DevEnv& e, const rv_arm* arm, ObsSnap& s);
+RV_DEV void obs_snap_fill(const DevEnv& e, const rv_arm* arm, ObsSnap& s) {
   for (int b = 0; b < RV_MAXB; ++b) {
     for (int k = 0; k < 7; ++k) s.pose[b][k] = e.body[b][k];
     s.scale[b] = e.scale[b];
@@ -4006,6 +4007,17 @@ RV_DEV void obs_snap_fill(const DevEnv& e, ObsSnap& s) {
   }
   s.table_z = e.table_z;
   s.rng_arg = (uint32_t)e.reset_count * 4096u + (uint32_t)e.num_steps;
+  s.arm_on = e.arm_enabled;
+  if (s.arm_on) obs_snap_arm(e, arm, s);
+}
+// ... and the arm's link boxes (world centre, frame quaternion) from the link frames
+RV_DEV void obs_snap_arm(const DevEnv& e, const rv_arm* arm, ObsSnap& s) {
+  for (int col = 0; col < RV_NCOL; ++col) {
+    const int f = arm->col_frame[col];
+    const q4 q = ldq(e.fquat[f]);
+    st3(s.arm_c[col], add(ld3(e.fpos[f]), mulv(qmat(q), ld3(arm->col_center[col]))));
+    stq(s.arm_q[col], q);
+  }
 }
 // one observation row: PoseObs in its four modalities (pose_obs.py:53-73), the attribute
 // observations (attribute_obs.py:16-115; env.attributes snapshot), body mask.  NULL members
@@ -4045,13 +4057,13 @@ struct RolloutRec {
   rv_obs_buffers robs; int has_robs;
   ObsSnap* rsnaps;
 };
-RV_DEV void rollout_record(const RolloutRec& r, const DevEnv* e, size_t row, const rv_config* cfg) {
+RV_DEV void rollout_record(const RolloutRec& r, const DevEnv* e, size_t row, const rv_config* cfg, const rv_arm* arm) {
   if (r.rewards) r.rewards[row] = e ? e->last_reward : 0.0f;
   if (r.dones) r.dones[row] = (uint8_t)(e ? e->done : 1);
   if (r.has_obs) obs_write_row(e, r.obs, row, cfg);
   if (r.snaps) {
-    if (e) obs_snap_fill(*e, r.snaps[row]);
-    else for (int b = 0; b < RV_MAXB; ++b) r.snaps[row].shape[b] = -1;
+    if (e) obs_snap_fill(*e, arm, r.snaps[row]);
+    else { for (int b = 0; b < RV_MAXB; ++b) r.snaps[row].shape[b] = -1; r.snaps[row].arm_on = 0; }
   }
 }
 
@@ -4655,7 +4667,7 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
           if (rec.resets) rec.resets[row] = (uint8_t)was_reset;
           if (was_reset) {      // what env.reset() returned (robot_env.py:204-237)
             if (rec.has_robs) obs_write_row(&S.e, rec.robs, row, c);
-            if (rec.rsnaps) obs_snap_fill(S.e, rec.rsnaps[row]);
+            if (rec.rsnaps) obs_snap_fill(S.e, K.arm, rec.rsnaps[row]);
           }
         }
       }
@@ -4663,7 +4675,7 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
     RV_PROF(20)
     if (c->env_type == RV_ENV_GRASP) genv_step(S, K, 0); else env_step(S, K, 0);
     RV_LANES_BEGIN
-      if (lane == 0 && budget == nullptr) rollout_record(rec, &S.e, (size_t)k * n_envs + env, c);
+      if (lane == 0 && budget == nullptr) rollout_record(rec, &S.e, (size_t)k * n_envs + env, c, K.arm);
     RV_LANES_END
     RV_PROF(23)
     k_end = k + 1;
@@ -4671,7 +4683,7 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
   // steps not taken (episode over, no auto-reset): reward 0, done
   if (budget == nullptr) {
     RV_LANES_BEGIN
-      for (int k = k_end + lane; k < n_steps; k += 64) rollout_record(rec, nullptr, (size_t)k * n_envs + env, c);
+      for (int k = k_end + lane; k < n_steps; k += 64) rollout_record(rec, nullptr, (size_t)k * n_envs + env, c, K.arm);
     RV_LANES_END
   }
 }

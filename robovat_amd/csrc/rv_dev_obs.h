@@ -33,6 +33,9 @@ struct ObsSnap {
   int shape[RV_MAXB];       // -1: body absent
   float table_z;
   uint32_t rng_arg;         // reset_count * 4096 + num_steps: one sampling stream per observation
+  // the arm as the camera sees it: the collider boxes of the links (world centre, frame quaternion); arm_on = 0: no arm
+  int arm_on;
+  float arm_c[RV_NCOL][3], arm_q[RV_NCOL][4];
 };
 
 struct CamRay { v3 o, d; };   // world ray; the parameter along d is the eye-space depth
@@ -89,10 +92,28 @@ RV_DEV int ray_table(const rv_config* c, float table_z, v3 o, v3 d, float* t_hit
   return 1;
 }
 
-// nearest hit of the pixel ray: body index, RV_MAXB for the table, -1 for nothing
+// entry depth into the box |x_k| <= h_k (ray in the box frame; axis_hit as in ray_table)
+RV_DEV int ray_box(const float* h, v3 o, v3 d, float* t_hit, int* axis_hit) {
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  float t0 = 0.0f, t1 = 1e30f; int ax = -1;
+  for (int k = 0; k < 3; ++k) {
+    if (dd[k] != 0.0f) {
+      float a = (-h[k] - oo[k]) / dd[k], b = (h[k] - oo[k]) / dd[k];
+      float tn = a < b ? a : b, tf = a < b ? b : a;
+      if (tn > t0) { t0 = tn; ax = a < b ? k : 3 + k; }
+      if (tf < t1) t1 = tf;
+    } else if (oo[k] < -h[k] || oo[k] > h[k]) return 0;
+  }
+  if (t0 > t1) return 0;
+  *t_hit = t0; *axis_hit = ax;
+  return 1;
+}
+
+// nearest hit of the pixel ray: body index, RV_MAXB for the table, RV_MAXB + 1 for the arm (its link collider
+// boxes; arm_mask: the boxes that can be hit at all, a conservative pre-selection of the caller), -1 for nothing
 // normal (optional): outward world normal of the surface that is hit
 RV_DEV int render_pixel(const rv_config* c, const rv_scene* scene, const ObsSnap& s, const float (*rot)[9],
-                        v3 cam_o, v3 dw, float* depth, v3* normal = nullptr) {
+                        v3 cam_o, v3 dw, float* depth, v3* normal = nullptr, unsigned arm_mask = 0xffffffffu) {
   float best = 1e30f; int who = -1;
   v3 nb = mk(0.0f, 0.0f, 0.0f);
   for (int b = 0; b < RV_MAXB; ++b) {
@@ -113,6 +134,25 @@ RV_DEV int render_pixel(const rv_config* c, const rv_scene* scene, const ObsSnap
       }
     }
   }
+  if (s.arm_on == 1 && arm_mask) {
+    const rv_arm* arm = &scene->arm;
+    for (int col = 0; col < RV_NCOL; ++col) {
+      if (!((arm_mask >> col) & 1u)) continue;
+      const float hx = arm->col_half[col][0] + c->margin, hy = arm->col_half[col][1] + c->margin, hz = arm->col_half[col][2] + c->margin;
+      v3 rel = sub(cam_o, ld3(s.arm_c[col]));
+      float r2 = hx * hx + hy * hy + hz * hz;
+      float dd = dot(dw, dw), rd = dot(rel, dw);
+      float perp2 = dot(rel, rel) - rd * rd / dd;
+      if (perp2 > r2) continue;
+      const m3 R = qmat(ldq(s.arm_q[col]));
+      const float hh[3] = {hx, hy, hz};
+      float t; int ia = -1;
+      if (ray_box(hh, tmulv(R, rel), tmulv(R, dw), &t, &ia) && t < best) {
+        best = t; who = RV_MAXB + 1;
+        if (normal && ia >= 0) { const float sg = ia < 3 ? -1.0f : 1.0f; const int k = ia % 3; nb = mulv(R, mk(k == 0 ? sg : 0.0f, k == 1 ? sg : 0.0f, k == 2 ? sg : 0.0f)); }
+      }
+    }
+  }
   float tt; int ax = -1;
   if (ray_table(c, s.table_z, cam_o, dw, &tt, &ax) && tt < best) {
     best = tt; who = RV_MAXB;
@@ -127,9 +167,9 @@ RV_DEV int render_pixel(const rv_config* c, const rv_scene* scene, const ObsSnap
 // light): flat colours per body slot, table and background, Lambert-shaded with the normal of the
 // face that is hit under one fixed directional light
 RV_DEV void shade_rgb(int who, v3 n, uint8_t* out) {
-  const float base[RV_MAXB + 2][3] = {{230.0f, 60.0f, 60.0f}, {60.0f, 170.0f, 230.0f}, {250.0f, 200.0f, 40.0f}, {90.0f, 200.0f, 110.0f},
-                                      {150.0f, 120.0f, 90.0f}, {30.0f, 30.0f, 30.0f}};
-  const int idx = who < 0 ? RV_MAXB + 1 : who;
+  const float base[RV_MAXB + 3][3] = {{230.0f, 60.0f, 60.0f}, {60.0f, 170.0f, 230.0f}, {250.0f, 200.0f, 40.0f}, {90.0f, 200.0f, 110.0f},
+                                      {150.0f, 120.0f, 90.0f}, {185.0f, 185.0f, 195.0f}, {30.0f, 30.0f, 30.0f}};   // bodies, table, arm, background
+  const int idx = who < 0 ? RV_MAXB + 2 : who;
   float sh = 1.0f;
   if (who >= 0) {
     const float lam = n.x * 0.30151134f + n.y * -0.30151134f + n.z * 0.90453403f;

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
       // reward 0 and done (rv_step_macro skips such an env the same way)
       const int fin = S.e.in_step == 2;
       if (args.finished) args.finished[env] = (uint8_t)fin;
-      if (fin) { g->in_step = 0; g->reward_valid = 0; rollout_record(args.rec, nullptr, (size_t)env, &S.cfg); }   // reward 0, done, zero rows
+      if (fin) { g->in_step = 0; g->reward_valid = 0; rollout_record(args.rec, nullptr, (size_t)env, &S.cfg, &S.arm); }   // reward 0, done, zero rows
     }
   }
   if (MODE == MODE_ROLLOUT) skip = (S.e.done != 0) && !args.auto_reset;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
     if (lane == 0) launch_counters_zero(*g);
     if (lane == 0 && (MODE == MODE_MACRO || MODE == MODE_ROLLOUT)) g->reward_valid = 0;
     if (MODE == MODE_ROLLOUT && args.budget == nullptr)   // steps not taken: reward 0, done, zero rows
-      for (int k = lane; k < args.n_substeps; k += 64) rollout_record(args.rec, nullptr, (size_t)k * args.n_envs + env, &S.cfg);
+      for (int k = lane; k < args.n_substeps; k += 64) rollout_record(args.rec, nullptr, (size_t)k * args.n_envs + env, &S.cfg, &S.arm);
     return;
   }
   if (MODE != MODE_RESET) env_enter(S, K);
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
     const int fin = env_step_partial(S, K);
     if (lane == 0) {
       if (args.finished) args.finished[env] = (uint8_t)fin;
-      if (fin) rollout_record(args.rec, &S.e, (size_t)env, &S.cfg);     // what env.step() returns, for the envs that finished
+      if (fin) rollout_record(args.rec, &S.e, (size_t)env, &S.cfg, &S.arm);     // what env.step() returns, for the envs that finished
     }
   } else if (MODE == MODE_SUB) {
     if (lane == 0) launch_counters_zero(S.e);
@@ -312,9 +312,9 @@ __global__ void k_observe(const DevEnv* envs, int n, rv_obs_buffers o, const rv_
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
   obs_write_row(&envs[i], o, (size_t)i, cfg);
 }
-__global__ void k_obs_snap(const DevEnv* envs, int n, ObsSnap* snaps) {
+__global__ void k_obs_snap(const DevEnv* envs, int n, ObsSnap* snaps, const rv_scene* scene) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
-  obs_snap_fill(envs[i], snaps[i]);
+  obs_snap_fill(envs[i], &scene->arm, snaps[i]);
 }
 RV_DEV float wave_min(float x) { for (int o = 32; o > 0; o >>= 1) { float y = __shfl_xor(x, o); x = y < x ? y : x; } return x; }
 RV_DEV float wave_max(float x) { for (int o = 32; o > 0; o >>= 1) { float y = __shfl_xor(x, o); x = y > x ? y : x; } return x; }
@@ -358,6 +358,27 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
       const int v0 = (int)fclampr(ffloorr(mv) - 1.0f, 0.0f, H1), v1 = (int)fclampr(ffloorr(xv) + 2.0f, 0.0f, H1);
       const int w = u1 - u0 + 1, hh = v1 - v0 + 1;
       const int total = (xu < 0.0f || xv < 0.0f || mu > W1 || mv > H1) ? 0 : w * hh;
+      // which link boxes of the arm can cover a pixel of this rectangle at all?  (bounding sphere of the box
+      // projected as a disc, generously; the arm is off-stage when the envs observe, so the answer is
+      // almost always "none" and the pixels pay nothing for it)
+      unsigned arm_mask = 0u;
+      if (s.arm_on == 1) {
+        bool may = false;
+        if (lane < RV_NCOL) {
+          const rv_arm* arm = &scene->arm;
+          const float hx = arm->col_half[lane][0] + c->margin, hy = arm->col_half[lane][1] + c->margin, hz = arm->col_half[lane][2] + c->margin;
+          const float r = fsqrtr(hx * hx + hy * hy + hz * hz) * 1.01f + 1e-4f;
+          float uc, vc, zc;
+          project_vertex(c, ld3(s.arm_c[lane]), &uc, &vc, &zc);
+          if (zc - r <= c->cam_near) may = zc + r > 0.0f;          // too close to bound its disc: keep it
+          else {
+            const float f = fmaxr(fabsr(c->cam_intrinsics[0]), fabsr(c->cam_intrinsics[1])) + fabsr(c->cam_intrinsics[4]);
+            const float rp = r * f / (zc - r) * 1.05f + 2.0f;
+            may = !(uc + rp < (float)u0 || uc - rp > (float)u1 || vc + rp < (float)v0 || vc - rp > (float)v1);
+          }
+        }
+        arm_mask = (unsigned)(__ballot(may) & 0x3ffull);
+      }
       // pass 0 keeps every visible pixel; a body with more than RV_PC_MAXPIX of them is cast again and every
       // stride-th visible pixel (scan order) is kept, so that the sample covers the whole body
       int stride = 1;
@@ -369,7 +390,7 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
           if (idx < total) {
             u = u0 + idx % w; v = v0 + idx / w;
             v3 dw = cam_to_world_dir(c, pixel_dir_cam(c, (float)u, (float)v));
-            int who = render_pixel(c, scene, s, s_rot, cam_o, dw, &dep);
+            int who = render_pixel(c, scene, s, s_rot, cam_o, dw, &dep, nullptr, arm_mask);
             vis = (who == b) && dep > c->cam_near && crop_ok(c, deproject(c, cam_o, (float)u, (float)v, dep));
           }
           const unsigned long long bal = __ballot(vis);
@@ -456,7 +477,7 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
 }
 // CameraObs 'depth' / 'segmask' (camera_obs.py:33-88 over BulletCamera._frames,
 // bullet_camera.py:188-235): the same ray cast as the point cloud, one thread per pixel.
-// depth: eye z, 0 where nothing is hit; segmask: body index, RV_MAXB = table, 255 = nothing
+// depth: eye z, 0 where nothing is hit; segmask: body index, RV_MAXB = table, RV_MAXB + 1 = arm, 255 = nothing
 __global__ void k_render(const ObsSnap* snaps, int n, float* depth, uint8_t* seg, const rv_config* c, const rv_scene* scene) {
   const int H = c->cam_height, W = c->cam_width;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -910,7 +931,7 @@ int rv_observe(rv_world* w, const rv_obs_buffers* obs) {
   if (obs->d_point_cloud) {
     if (w->cfg.num_points <= 0 || w->cfg.num_points > RV_PC_MAXPIX) return fail(RV_ERR_VALUE, "rv_observe: num_points outside [1, RV_PC_MAXPIX]");
     int rc = ensure_snaps(w, (size_t)w->n); if (rc != RV_OK) return rc;
-    SIMPLE_LAUNCH(k_obs_snap, w->d_envs, w->n, w->d_snaps);
+    SIMPLE_LAUNCH(k_obs_snap, w->d_envs, w->n, w->d_snaps, w->d_scene);
     rc = launch_point_cloud(w, w->n, obs->d_point_cloud); if (rc != RV_OK) return rc;
   }
   return RV_OK;
@@ -918,7 +939,7 @@ int rv_observe(rv_world* w, const rv_obs_buffers* obs) {
 int rv_render_rgb(rv_world* w, uint8_t* d_rgb) {
   WCHK(w); NEED(d_rgb, "rv_render_rgb");
   int rc = ensure_snaps(w, (size_t)w->n); if (rc != RV_OK) return rc;
-  SIMPLE_LAUNCH(k_obs_snap, w->d_envs, w->n, w->d_snaps);
+  SIMPLE_LAUNCH(k_obs_snap, w->d_envs, w->n, w->d_snaps, w->d_scene);
   const size_t total = (size_t)w->n * (size_t)w->cfg.cam_height * (size_t)w->cfg.cam_width;
   hipLaunchKernelGGL(k_render_rgb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, w->stream, w->d_snaps, w->n, d_rgb, w->d_cfg, w->d_scene);
   HIPCHK(hipGetLastError());
@@ -928,7 +949,7 @@ int rv_render(rv_world* w, float* d_depth, uint8_t* d_segmask) {
   WCHK(w);
   if (!d_depth && !d_segmask) return fail(RV_ERR_VALUE, "rv_render: no output buffer");
   int rc = ensure_snaps(w, (size_t)w->n); if (rc != RV_OK) return rc;
-  SIMPLE_LAUNCH(k_obs_snap, w->d_envs, w->n, w->d_snaps);
+  SIMPLE_LAUNCH(k_obs_snap, w->d_envs, w->n, w->d_snaps, w->d_scene);
   const size_t total = (size_t)w->n * (size_t)w->cfg.cam_height * (size_t)w->cfg.cam_width;
   hipLaunchKernelGGL(k_render, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, w->stream, w->d_snaps, w->n, d_depth, d_segmask, w->d_cfg, w->d_scene);
   HIPCHK(hipGetLastError());

@@ -36,7 +36,7 @@ class Observation(object):
 
 class CameraObs(Observation):
     """Image of the simulated Kinect2 (camera_obs.py:33-88): 'rgb' uint8 [H, W, 3], 'depth' float32
-    [H, W, 1] (metres, 0 where nothing is hit), 'segmask' uint8 [H, W, 1] (body index, RV_MAXB =
+    [H, W, 1] (metres, 0 where nothing is hit), 'segmask' uint8 [H, W, 1] (body index, RV_MAXB + 1 = arm, RV_MAXB =
     table, 255 = nothing).  ``env_index``: which env of a vectorised env (images are per env)."""
 
     def __init__(self, camera=None, modality='rgb', max_visible_distance_m=None, name=None, env_index=0):

@@ -425,3 +425,41 @@ def test_point_cloud_of_a_body_with_more_pixels_than_the_buffer_holds():
     first = cloud[:64]
     assert (first.max(axis=0) - first.min(axis=0) > 0.6 * ext).all()      # no slice of the cloud is a spatial slice
     world.close()
+
+
+def test_the_arm_is_drawn_and_occludes():
+    """The camera sees the arm (its link collider boxes; bullet_camera.py:188-235 renders the whole scene): with
+    the gripper above a body the segmentation mask has arm pixels (RV_MAXB + 1), the body's point cloud loses
+    the pixels the arm covers, and depth / segmask / rgb / point cloud equal the oracle's pixel for pixel."""
+    import torch
+    world, ref = _world(2, seed=7), _oracle(2, seed=7)
+    world.reset(); ref.reset()
+    tz = float(ref.body_params()[0, 0, 6])
+    p = np.zeros((2, abi.RV_MAXB, 8)); s = np.zeros((2, abi.RV_MAXB, 13)); s[..., 6] = 1
+    p[:, 0] = [1, 0, 1.0, 0.3, 0.5, 0, tz, 0]
+    s[:, 0, :3] = [0.6, 0.0, tz + 0.031]
+    for w in (world, ref):
+        w.set_body_params(p); w.set_body_state(s)
+    before = world.observe(point_cloud=True)['point_cloud'].cpu().numpy()
+    seg0 = world.render()[1].cpu().numpy()
+    n_body0 = int((seg0[0] == 0).sum())
+    # env 0: the gripper 3 cm above the body; env 1 keeps the arm where reset left it
+    quat = np.array([1.0, 0.0, 0.0, 0.0])
+    pose = np.concatenate([[0.6, 0.0, tz + 0.14 + 0.09], quat]).astype(np.float32)
+    js = ref.joint_state()
+    for _ in range(8):
+        q = ref.compute_ik(np.stack([pose, pose]))[0]
+        js[0, :7, 0] = q; js[0, :7, 1] = 0.0
+        ref.set_joint_state(js)
+    world.set_joint_state(torch.from_numpy(js.astype(np.float32)).cuda())
+    depth, seg = world.render()
+    rdepth, rseg = ref.render(0)
+    assert np.array_equal(seg[0].cpu().numpy(), rseg) and np.array_equal(depth[0].cpu().numpy(), rdepth.astype(np.float32))
+    seg = seg.cpu().numpy()
+    assert (seg[0] == abi.RV_MAXB + 1).sum() > 500                                   # the arm is in the picture
+    assert int((seg[0] == 0).sum()) < n_body0 - 10                                   # ... and in front of a part of the body
+    assert np.array_equal(world.render_rgb()[0].cpu().numpy(), ref.render_rgb(0))
+    got = world.observe(point_cloud=True)['point_cloud'].cpu().numpy()
+    assert np.array_equal(got, ref.point_cloud())
+    assert not np.array_equal(got[0, 0], before[0, 0])                               # the occluded pixels are gone
+    world.close()
