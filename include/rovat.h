@@ -404,6 +404,11 @@ int  rv_set_constraint(rv_world* w, int32_t body, const float* frame7, const flo
 /* BulletPhysics.set_gravity (bullet_physics.py:129-137): the gravity vector of every env of
  * the world from now on (host float[3]) */
 int  rv_set_gravity(rv_world* w, const float* gravity);
+/* BulletPhysics.set_link_dynamics / set_body_dynamics, lateral friction only (bullet_physics.py:560-600,
+ * 318-350; grasp_4dof_env.py:262-293 switches the finger-tip and table friction between the phases of a
+ * grasp): the lateral friction of the two finger-tip pads and of the table top of every env of the world;
+ * a negative value leaves that coefficient as it is */
+int  rv_set_friction(rv_world* w, float mu_finger, float mu_table);
 /* ---- ControllableBody.reset_targets (controllable_body.py:347-350): drop the
  *      link / joint targets; the motors keep their last commanded positions. */
 int  rv_reset_targets(rv_world* w);

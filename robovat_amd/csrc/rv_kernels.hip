@@ -263,6 +263,11 @@ __global__ void k_set_constraint(DevEnv* envs, int n, ConArgs a) {
   }
   e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0;
 }
+__global__ void k_set_friction(DevEnv* envs, int n, float mu_finger, float mu_table) {
+  ENV_THREAD();
+  if (mu_finger >= 0.0f) e.mu_finger = mu_finger;
+  if (mu_table >= 0.0f) e.mu_table = mu_table;
+}
 __global__ void k_grip(DevEnv* envs, int n, float value, const rv_config* cfg, const rv_scene* scene) {
   ENV_THREAD();
   grip_env(e, &scene->arm, cfg, value);
@@ -888,6 +893,11 @@ int rv_set_gravity(rv_world* w, const float* g) {
   w->cfg.gravity_xy[0] = g[0]; w->cfg.gravity_xy[1] = g[1]; w->cfg.gravity_z = g[2];
   HIPCHK(hipMemcpyAsync(w->d_cfg, &w->cfg, sizeof(rv_config), hipMemcpyHostToDevice, w->stream));
   HIPCHK(hipStreamSynchronize(w->stream));
+  return RV_OK;
+}
+int rv_set_friction(rv_world* w, float mu_finger, float mu_table) {
+  WCHK(w);
+  SIMPLE_LAUNCH(k_set_friction, w->d_envs, w->n, mu_finger, mu_table);
   return RV_OK;
 }
 int rv_set_constraint(rv_world* w, int32_t body, const float* frame7, const float* target7, float max_force) {

@@ -30,7 +30,7 @@ SYMBOLS = [
     'rv_compute_ik', 'rv_query_contacts', 'rv_get_manifold_counts', 'rv_observe',
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
-    'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll', 'rv_set_constraint', 'rv_render_rgb',
+    'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll', 'rv_set_constraint', 'rv_render_rgb', 'rv_set_friction',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -121,6 +121,7 @@ def load():
     lib.rv_set_motor_targets.argtypes = [vp, vp, vp]
     lib.rv_grip.argtypes = [vp, f32]
     lib.rv_set_gravity.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.rv_set_friction.argtypes = [vp, f32, f32]
     lib.rv_set_constraint.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), f32]
     lib.rv_get_state_ptrs.argtypes = [vp, C.POINTER(abi.rv_state_view)]
     lib.rv_set_joint_targets.argtypes = [vp, vp, f32, f32]
@@ -377,6 +378,10 @@ class World(object):
 
     def remove_constraint(self, body):
         check(self.lib.rv_set_constraint(self.h, int(body), None, None, -1.0))
+
+    def set_friction(self, mu_finger=-1.0, mu_table=-1.0):
+        """rv_set_friction: lateral friction of the finger-tip pads / the table top (negative: unchanged)."""
+        check(self.lib.rv_set_friction(self.h, float(mu_finger), float(mu_table)))
 
     def set_gravity(self, gravity):
         g = (C.c_float * 3)(float(gravity[0]), float(gravity[1]), float(gravity[2]))

@@ -218,6 +218,10 @@ class HipPhysics(Physics):
 
     def set_body_dynamics(self, body_uid, mass=None, lateral_friction=None, rolling_friction=None,
                           spinning_friction=None):
+        if body_uid == TABLE_UID:      # Body.set_dynamics on the table (grasp_4dof_env.py:262-293): its friction
+            if lateral_friction is not None:
+                self._world.set_friction(mu_table=lateral_friction)
+            return
         b = self._slot(body_uid)
         params = self._np(self._world.body_params())
         if mass is not None:
@@ -243,11 +247,21 @@ class HipPhysics(Physics):
         return self.get_link_pose(link_uid)
 
     def get_link_mass(self, link_uid):
-        raise NotImplementedError('This is not implemented in the HIP backend.')
+        """<inertial> mass of a limb link / the hand (rv_arm.link_mass); the finger links are massless pads."""
+        i = link_uid[1]
+        return float(self.scene.arm.link_mass[i]) if i <= abi.RV_NLIMB else 0.0
 
     def set_link_dynamics(self, link_uid, mass=None, lateral_friction=None, rolling_friction=None,
                           spinning_friction=None):
-        raise NotImplementedError('per-link friction is a world-creation constant (PHYSICS.ARM_FRICTION)')
+        """Link.set_dynamics (bullet_physics.py:560-600).  What the reference uses it for is the lateral friction
+        of the two finger tips (grasp_4dof_env.py:262-293): rv_set_friction.  The friction of the other links is
+        the world-creation constant PHYSICS.ARM_FRICTION, masses come from the URDF."""
+        if lateral_friction is None:
+            return
+        if link_uid[1] >= abi.RV_NLIMB + 1:         # the finger-tip links
+            self._world.set_friction(mu_finger=lateral_friction)
+        else:
+            raise NotImplementedError('per-link friction of the limb links is a world-creation constant (PHYSICS.ARM_FRICTION)')
 
     def get_joint_name(self, joint_uid):
         names = scenes.LIMB_JOINT_NAMES + scenes.FINGER_JOINT_NAMES
@@ -259,7 +273,8 @@ class HipPhysics(Physics):
     def get_joint_limit(self, joint_uid):
         j = joint_uid[1]
         a = self.scene.arm
-        return {'lower': a.q_lo[j], 'upper': a.q_hi[j], 'effort': a.a_max[j], 'velocity': a.v_max[j]}
+        effort = 1.0 / a.inv_tau_max[j] if a.inv_tau_max[j] > 0 else float('inf')
+        return {'lower': a.q_lo[j], 'upper': a.q_hi[j], 'effort': effort, 'velocity': a.v_max[j]}
 
     def get_joint_position(self, joint_uid):
         return float(self._np(self._world.joint_state())[0, joint_uid[1], 0])

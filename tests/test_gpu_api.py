@@ -131,3 +131,38 @@ def test_push_env_lives_in_the_simulator_it_is_given():
     assert np.array_equal(obs2['point_cloud'], obs['point_cloud']) and reward2 == reward and done2 == done
     assert np.array_equal(after, env2._vec.world.body_state().cpu().numpy()[0, :, :3])
     env.close(); env2.close()
+
+
+def test_set_friction_matches_the_oracle_and_the_physics_mirror_routes_to_it():
+    """rv_set_friction (Link.set_dynamics on the finger tips / Body.set_dynamics on the table,
+    grasp_4dof_env.py:262-293): a body sliding on the table stops sooner with a higher table friction, bit for
+    bit like the oracle; HipPhysics.set_link_dynamics / set_body_dynamics reach the same setter."""
+    from oracle import orc
+    from robovat_amd import abi, configs, lib, scenes
+    from robovat_amd.simulation.physics import hip_physics as hp
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(n_envs=2, seed=3, shape_names=names)
+    ends = []
+    for mu in (0.3, 1.0):
+        w, ref = lib.World(cfg, scene, device=0), orc.OracleWorld(cfg, scene, double=False)
+        w.reset(); ref.reset()
+        tz = float(ref.body_params()[0, 0, 6])
+        p = np.zeros((2, abi.RV_MAXB, 8)); s = np.zeros((2, abi.RV_MAXB, 13)); s[..., 6] = 1
+        p[:, 0] = [1, 0, 1.0, 0.3, 0.5, 0, tz, 0]
+        s[:, 0, :3] = [0.5, 0.0, tz + 0.031]; s[:, 0, 7] = 0.5
+        for x in (w, ref):
+            x.set_body_params(p); x.set_body_state(s); x.set_friction(mu_table=mu)
+        w.step_sub(600); ref.step_sub(600)
+        got = w.body_state().cpu().numpy()
+        assert np.array_equal(got, ref.body_state().astype(np.float32))
+        ends.append(float(got[0, 0, 0]))
+        w.close()
+    slide = [e - 0.5 for e in ends]                       # v^2 / (2 mu_body mu_table g)
+    assert slide[0] > 2.5 * slide[1] > 0.0, slide
+    assert abs(slide[1] - 0.25 / (2 * 0.5 * 1.0 * 9.8)) < 0.004, slide
+    ph = hp.HipPhysics()
+    ph.reset(); ph.start()
+    ph.set_body_dynamics(hp.TABLE_UID, lateral_friction=0.7)
+    ph.set_link_dynamics((hp.ARM_UID, 8), lateral_friction=1.5)
+    assert abs(ph.get_link_mass((hp.ARM_UID, 1)) - 4.505) < 1e-3
+    assert ph.get_joint_limit((hp.ARM_UID, 0))['effort'] == pytest.approx(80.0)
