@@ -11,7 +11,7 @@ group at a time and all together, and the table reports push outcomes, the
 distribution of the per-step body displacement, substeps per env.step() and
 env-steps/s.
 
-    python tools/sensitivity.py [--envs 1024] [--steps 20] > profiles/r02_sensitivity.txt
+    python tools/sensitivity.py [--envs 1024] [--steps 20] > profiles/r03_sensitivity.txt
 """
 import argparse
 import json
@@ -28,6 +28,9 @@ VARIANTS = [
     ('rolling / spinning friction 0 (round-1 value; urdf_template: 0.001 = shipped)', {'PHYSICS.ROLLING_FRICTION': 0.0}),
     ('solver: at most 8 iterations (round-1 value; Bullet: 50 = shipped)', {'PHYSICS.SOLVER_ITERS': 8}),
     ('solver: 50 iterations, no early exit (Bullet)', {'PHYSICS.SOLVER_TOL': 0.0, 'PHYSICS.SOLVER_STALL': 0}),
+    ('solver: residual exit only, no stall exit (round-2 behaviour)', {'PHYSICS.SOLVER_STALL': 0}),
+    ('solver: stall exit after 6 sweeps (shipped: 12)', {'PHYSICS.SOLVER_STALL': 6}),
+    ('limb dynamics (joint-space inertia + effort-limited motors while the arm touches a body)', {'PHYSICS.LIMB_DYNAMICS': 1}),
     ('sleep: Bullet\'s rule alone (0.8 m/s, 1 rad/s, 2 s)',
      {'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0, 'PHYSICS.SLEEP_STEPS': 2000, 'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.DEACTIVATION_STEPS': 0}),
     ('sleep: without Bullet\'s rule (the strict thresholds and the pose window only)', {'PHYSICS.DEACTIVATION_STEPS': 0}),
