@@ -131,6 +131,7 @@ struct DevEnv {
   float episode_reward, last_reward;
   float action[RV_MAXG][4];
   float obs_pos[RV_MAXB][3], prev_obs_pos[RV_MAXB][3];
+  float obs_quat[RV_MAXB][4];   // ... and the orientations at that moment (the observation of an env.step() is taken before get_reward, robot_env.py:246-248)
   int num_total_steps, num_unsafe, num_ineffective, num_useful, num_successes;
   // env.attributes (push_env.py:368-375, 637-644): the counters the attribute observations
   // and the heuristic policy see are captured at the START of _execute_action / _reset_scene
@@ -3996,12 +3997,16 @@ RV_DEV void compute_obs(DevEnv& e) {
       e.prev_obs_pos[b][k] = e.obs_pos[b][k];
       e.obs_pos[b][k] = e.active[b] ? e.body[b][k] : 0.0f;
     }
+  for (int b = 0; b < RV_MAXB; ++b)
+    for (int k = 0; k < 4; ++k) e.obs_quat[b][k] = e.body[b][3 + k];
 }
 // pose snapshot for the point-cloud render (rv_dev_obs.h)
 RV_DEV void obs_snap_arm(const DevEnv& e, const rv_arm* arm, ObsSnap& s);
-RV_DEV void obs_snap_fill(const DevEnv& e, const rv_arm* arm, ObsSnap& s) {
+// at_obs: the body poses as they were when the env took its observation (RobotEnv.step observes BEFORE get_reward,
+// robot_env.py:246-248 -- GraspReward then waits until the object is stable) instead of the current ones
+RV_DEV void obs_snap_fill(const DevEnv& e, const rv_arm* arm, ObsSnap& s, const int at_obs = 0) {
   for (int b = 0; b < RV_MAXB; ++b) {
-    for (int k = 0; k < 7; ++k) s.pose[b][k] = e.body[b][k];
+    for (int k = 0; k < 7; ++k) s.pose[b][k] = !at_obs ? e.body[b][k] : (k < 3 ? e.obs_pos[b][k] : e.obs_quat[b][k - 3]);
     s.scale[b] = e.scale[b];
     s.shape[b] = e.active[b] ? e.shape[b] : -1;
   }
@@ -4062,7 +4067,7 @@ RV_DEV void rollout_record(const RolloutRec& r, const DevEnv* e, size_t row, con
   if (r.dones) r.dones[row] = (uint8_t)(e ? e->done : 1);
   if (r.has_obs) obs_write_row(e, r.obs, row, cfg);
   if (r.snaps) {
-    if (e) obs_snap_fill(*e, arm, r.snaps[row]);
+    if (e) obs_snap_fill(*e, arm, r.snaps[row], 1);
     else { for (int b = 0; b < RV_MAXB; ++b) r.snaps[row].shape[b] = -1; r.snaps[row].arm_on = 0; }
   }
 }
@@ -4667,7 +4672,7 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
           if (rec.resets) rec.resets[row] = (uint8_t)was_reset;
           if (was_reset) {      // what env.reset() returned (robot_env.py:204-237)
             if (rec.has_robs) obs_write_row(&S.e, rec.robs, row, c);
-            if (rec.rsnaps) obs_snap_fill(S.e, K.arm, rec.rsnaps[row]);
+            if (rec.rsnaps) obs_snap_fill(S.e, K.arm, rec.rsnaps[row], 1);
           }
         }
       }

@@ -140,3 +140,25 @@ def test_rgb_render_matches_oracle_and_camera_obs():
         x = o.get_observation()
         assert x.shape == shape == o.get_gym_space().shape and x.dtype == o.get_gym_space().dtype
     w.close()
+
+
+def test_recorded_grasp_observation_is_taken_before_the_reward_waits():
+    """RobotEnv.step observes BEFORE get_reward (robot_env.py:246-248) and GraspReward then waits until the object is
+    stable (grasp_reward.py:49-58): the recorded point cloud of a step shows the object where the recorded
+    'position' row has it, also when it dropped out of the gripper afterwards."""
+    from robovat_amd import lib
+    cfg, scene = _cfg(256, seed=23)
+    world = lib.World(cfg, scene, device=0)
+    world.reset()
+    obs, r, d = world.rollout_record(2, first_macro_index=0, auto_reset=True, point_cloud=True)
+    pos = obs['position'].cpu().numpy()[:, :, 0]                 # [K, N, 3]: the graspable
+    pc = obs['point_cloud'].cpu().numpy()[:, :, 0]              # [K, N, P, 3]
+    seen = np.abs(pc).sum(axis=(2, 3)) > 0
+    assert seen.mean() > 0.5
+    cz = pc[..., 2].mean(axis=2)
+    # the visible surface is the top / the camera side of the object: within a few cm of its origin
+    assert np.abs(cz - pos[..., 2])[seen].max() < 0.05
+    # (how many objects moved while the reward waited depends on the grasps: a slipping object shows the difference)
+    final = world.body_state().cpu().numpy()[:, 0, :3]
+    print('objects that moved more than 1 mm after the observation:', int((np.linalg.norm(final - pos[-1], axis=1) > 1e-3).sum()))
+    world.close()
