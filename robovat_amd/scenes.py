@@ -307,4 +307,10 @@ def make_scene(shape_hulls=None, env_cfg=None, arm=None):
     else:
         scene.arm = arm
         scene.arm.a_max[7] = scene.arm.a_max[8] = float(accel)
+    # PHYSICS.ARM_ACCEL_SCALE (tools/sensitivity.py): the BUILD-CHOSEN acceleration limits of the limb joints scaled
+    # (PyBullet's POSITION_CONTROL motors have none: with their large default force they reach the commanded
+    # velocity within a step)
+    if env_cfg is not None and env_cfg.PHYSICS.get('ARM_ACCEL_SCALE') is not None:
+        for j in range(7):
+            scene.arm.a_max[j] = float(scene.arm.a_max[j]) * float(env_cfg.PHYSICS.ARM_ACCEL_SCALE)
     return scene, names

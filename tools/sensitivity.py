@@ -31,6 +31,8 @@ VARIANTS = [
     ('solver: residual exit only, no stall exit (round-2 behaviour)', {'PHYSICS.SOLVER_STALL': 0}),
     ('solver: stall exit after 6 sweeps (shipped: 12)', {'PHYSICS.SOLVER_STALL': 6}),
     ('limb dynamics (joint-space inertia + effort-limited motors while the arm touches a body)', {'PHYSICS.LIMB_DYNAMICS': 1}),
+    ('limb joints without an acceleration limit (PyBullet\'s motors: commanded velocity within a step; shipped: 8-20 rad/s^2)', {'PHYSICS.ARM_ACCEL_SCALE': 1000.0}),
+    ('limb acceleration limits x 4', {'PHYSICS.ARM_ACCEL_SCALE': 4.0}),
     ('sleep: Bullet\'s rule alone (0.8 m/s, 1 rad/s, 2 s)',
      {'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0, 'PHYSICS.SLEEP_STEPS': 2000, 'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.DEACTIVATION_STEPS': 0}),
     ('sleep: without Bullet\'s rule (the strict thresholds and the pose window only)', {'PHYSICS.DEACTIVATION_STEPS': 0}),
@@ -47,8 +49,8 @@ VARIANTS = [
 def run(over, n_envs, steps, seed):
     import torch
     from robovat_amd import configs, scenes, lib
-    scene, names = scenes.make_scene()
     env_cfg = configs.push_env_config(**over)
+    scene, names = scenes.make_scene(env_cfg=env_cfg)
     cfg = configs.make_rv_config(env_cfg=env_cfg, n_envs=n_envs, seed=seed, shape_names=names)
     w = lib.World(cfg, scene, device=0)
     w.reset()
