@@ -332,6 +332,12 @@ int  rv_rollout(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t
  * on how its step is cut into launches: its trajectory is rv_step_macro's, bit for bit.  A step
  * begun on an env whose episode is over is reported finished at once (reward 0, done). */
 int  rv_step_begin(rv_world* w, const float* d_actions /* [N][G][4] */, const uint8_t* d_mask /* [N] or NULL */);
+/* on != 0: a step begun on an env whose episode is over RESETS it instead (RobotEnv.reset, robot_env.py:204-237,
+ * as the loop of generate_episodes does between episodes, episode_generation.py:36-46): the next poll reports the
+ * env finished with what env.reset() returns -- its observation, reward 0, done 0 -- and the action is not taken.
+ * The reset is not cut by the poll's budget (a poll that resets envs lasts as long as their drop-and-settle).
+ * Default: off (the env is reported finished at once with reward 0, done). */
+int  rv_set_auto_reset(rv_world* w, int32_t on);
 struct rv_obs_buffers;
 int  rv_step_poll(rv_world* w, int32_t max_substeps, int32_t max_usec, uint8_t* d_finished /* [N] */,
                   const struct rv_obs_buffers* obs /* or NULL */, float* d_reward /* [N] or NULL */, uint8_t* d_done /* [N] or NULL */);

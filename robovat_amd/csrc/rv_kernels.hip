@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
 #endif
   if (MODE == MODE_MACRO) skip = (S.e.done != 0);
   if (MODE == MODE_PARTIAL) {
-    skip = (S.e.in_step != 1);
+    skip = (S.e.in_step != 1) && !(S.e.in_step == 2 && args.auto_reset);
     if (skip && lane == 0) {
       // no step pending; a step that was begun on a finished episode is reported once, with
       // reward 0 and done (rv_step_macro skips such an env the same way)
@@ -108,6 +108,15 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
   } else if (MODE == MODE_ROLLOUT) {
     env_rollout(S, K, K.cfg->env_id_offset + env, args.n_substeps, args.first_index, args.auto_reset, args.rec, env, args.n_envs, args.budget);
     if (lane == 0 && args.steps_taken) args.steps_taken[env] = S.e.stepped;
+  } else if (MODE == MODE_PARTIAL && S.e.in_step == 2) {
+    // rv_set_auto_reset: the step was begun on a finished episode -> env.reset(); the poll hands back what it returns
+    env_reset(S, K, K.cfg->env_id_offset + env);
+    __syncthreads();
+    if (lane == 0) {
+      S.e.in_step = 0; S.e.reward_valid = 0; S.e.last_reward = 0.0f;
+      if (args.finished) args.finished[env] = 1;
+      rollout_record(args.rec, &S.e, (size_t)env, &S.cfg, &S.arm);
+    }
   } else if (MODE == MODE_PARTIAL) {
     if (lane == 0) {
       launch_counters_zero(S.e);
@@ -622,6 +631,7 @@ struct rv_world {
   ObsSnap* d_snaps; size_t n_snaps_cap;   // pose snapshots for the point-cloud render
   hipEvent_t ev0, ev1;
   bool timed;
+  int auto_reset;                         // rv_set_auto_reset
 };
 
 static thread_local std::string g_err;
@@ -803,6 +813,7 @@ int rv_step_begin(rv_world* w, const float* d_actions, const uint8_t* d_mask) {
   HIPCHK(hipGetLastError());
   return RV_OK;
 }
+int rv_set_auto_reset(rv_world* w, int32_t on) { WCHK(w); w->auto_reset = on != 0; return RV_OK; }
 int rv_step_poll(rv_world* w, int32_t max_substeps, int32_t max_usec, uint8_t* d_finished,
                  const rv_obs_buffers* obs, float* d_reward, uint8_t* d_done) {
   WCHK(w);
@@ -812,7 +823,7 @@ int rv_step_poll(rv_world* w, int32_t max_substeps, int32_t max_usec, uint8_t* d
   EnvKernelArgs a;
   memset(&a, 0, sizeof(a));
   a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.n_envs = w->n;
-  a.n_substeps = max_substeps; a.finished = d_finished;
+  a.n_substeps = max_substeps; a.finished = d_finished; a.auto_reset = w->auto_reset;
   a.rec.rewards = d_reward; a.rec.dones = d_done;
   float* d_pc = nullptr;
   if (obs) {

@@ -30,7 +30,7 @@ SYMBOLS = [
     'rv_compute_ik', 'rv_query_contacts', 'rv_get_manifold_counts', 'rv_observe',
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
-    'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll', 'rv_set_constraint', 'rv_render_rgb', 'rv_set_friction',
+    'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll', 'rv_set_constraint', 'rv_render_rgb', 'rv_set_friction', 'rv_set_auto_reset',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -122,6 +122,7 @@ def load():
     lib.rv_grip.argtypes = [vp, f32]
     lib.rv_set_gravity.argtypes = [vp, C.POINTER(C.c_float)]
     lib.rv_set_friction.argtypes = [vp, f32, f32]
+    lib.rv_set_auto_reset.argtypes = [vp, i32]
     lib.rv_set_constraint.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), f32]
     lib.rv_get_state_ptrs.argtypes = [vp, C.POINTER(abi.rv_state_view)]
     lib.rv_set_joint_targets.argtypes = [vp, vp, f32, f32]
@@ -210,6 +211,10 @@ class World(object):
         a = self._in(actions, (self.n, self.G, 4), self.torch.float32)
         m = None if mask is None else self._in(mask, (self.n,), self.torch.uint8)
         check(self.lib.rv_step_begin(self.h, self._ptr(a), None if m is None else self._ptr(m)))
+
+    def set_auto_reset(self, on=True):
+        """rv_set_auto_reset: step_begin on a finished episode resets the env; the next poll returns the reset observation."""
+        check(self.lib.rv_set_auto_reset(self.h, int(bool(on))))
 
     def step_poll(self, max_substeps=0, max_usec=0, out=None):
         """rv_step_poll: advance the stepping envs within the budget; returns uint8 [N], 1 = this

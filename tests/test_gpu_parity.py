@@ -226,3 +226,51 @@ def test_partial_batch_trajectories_equal_step_macro():
     pc = out['obs']['point_cloud'].cpu().numpy()
     assert np.isfinite(pc).all()
     world.close(); world2.close()
+
+
+def test_partial_batches_with_auto_reset():
+    """rv_set_auto_reset: a step begun on an env whose episode is over resets it (what generate_episodes does between
+    episodes, episode_generation.py:36-46) and the poll hands back what env.reset() returns.  (a) Round by round with
+    unlimited polls the envs are where the float oracle is with step_macro (which skips finished envs) followed by
+    reset(mask = finished before the round); (b) with a 300-substep budget per poll, every env at its own pace, each
+    env ends in the same state after the same number of calls."""
+    import torch
+    n, R = 48, 6
+    world, ref, cfg = _worlds(n, seed=43, MAX_STEPS=2)
+    world.set_auto_reset(True)
+    world.reset(); ref.reset()
+    out = world.poll_buffers(point_cloud=False)
+    acts = [ref.policy_random(k) for k in range(R)]
+    resets = 0
+    for k in range(R):
+        done_before = ref.reward()[1].astype(bool) if k else np.zeros(n, bool)
+        ref.set_actions(acts[k]); ref.step_macro()
+        if done_before.any():
+            ref.reset(mask=done_before.astype(np.uint8)); resets += int(done_before.sum())
+        world.step_begin(acts[k])
+        fin = world.step_poll(out=out).cpu().numpy().astype(bool)
+        assert fin.all()
+        assert np.array_equal(world.body_state().cpu().numpy(), ref.body_state().astype(np.float32)), k
+        assert np.array_equal(world.joint_state().cpu().numpy(), ref.joint_state().astype(np.float32)), k
+        d = out['done'].cpu().numpy().astype(bool); r = out['reward'].cpu().numpy()
+        assert not d[done_before].any() and (r[done_before] == 0).all()        # env.reset(): reward 0, not done
+        pos = out['obs']['position'].cpu().numpy()
+        assert np.array_equal(pos[done_before], ref.observe()[0][done_before].astype(np.float32))
+    assert resets >= n                                                          # MAX_STEPS = 2: every env was reset at least once
+    final = world.body_state().cpu().numpy()
+    # (b) the same R calls per env, cut into 300-substep polls, envs restarted as they finish
+    w2 = _worlds(n, seed=43, MAX_STEPS=2)[0]
+    w2.set_auto_reset(True); w2.reset()
+    A = torch.as_tensor(np.stack(acts), device='cuda')
+    cnt = torch.zeros(n, dtype=torch.long, device='cuda'); ar = torch.arange(n, device='cuda')
+    w2.step_begin(A[0]); polls = 0
+    while int(cnt.min()) < R:
+        fin = w2.step_poll(max_substeps=300).bool()
+        polls += 1
+        assert polls < 5000
+        cnt += fin.long()
+        go = fin & (cnt < R)
+        if bool(go.any()):
+            w2.step_begin(A[cnt.clamp(max=R - 1), ar], mask=go.to(torch.uint8))
+    assert np.array_equal(w2.body_state().cpu().numpy(), final)
+    world.close(); w2.close()
