@@ -165,3 +165,59 @@ def test_pushed_box_moves_with_the_pusher(backend, limb):
     assert hist[-1, 3] - 0.62 > 0.05                              # the box was carried along
     if hasattr(w, 'w'):
         w.close()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_friction_pyramid_is_bullets_not_a_cone(backend):
+    """Bullet's default contact friction is a PYRAMID: two independent tangent rows, each bounded by mu x the normal
+    impulse (btSequentialImpulseConstraintSolver without SOLVER_USE_2_FRICTION_DIRECTIONS / cone friction).  A box
+    sliding along a tangent axis of the table contact (x or y: plane_space of +z) is braked with mu g; sliding along
+    the diagonal both rows saturate and it is braked with sqrt(2) mu g.  (A friction cone would give mu g in every
+    direction.)  Closed form with the substep recursion v <- (v - a dt) * damping."""
+    mu, v0 = 0.5, 0.4
+    out = {}
+    for name, d in (('x', (1.0, 0.0)), ('y', (0.0, 1.0)), ('diag', (np.sqrt(0.5), np.sqrt(0.5)))):
+        w, cfg = _world(backend)
+        _bodies(w, [(0, 0.2, mu, (0.5, -0.1, 0.031), Q0, (v0 * d[0], v0 * d[1], 0))])
+        w.step_sub(500)
+        st = w.body_state()[0, 0]
+        out[name] = float(np.hypot(st[0] - 0.5, st[1] + 0.1))
+        assert np.abs(st[7:10]).max() < 2e-3                          # it has stopped
+        a = mu * G * (np.sqrt(2.0) if name == 'diag' else 1.0)
+        v, x, damp, dt = v0, 0.0, float(cfg.lin_damp), float(cfg.dt)
+        while v > 0:
+            v = (v - a * dt) * damp
+            if v > 0:
+                x += v * dt
+        assert abs(out[name] - x) < 0.04 * x + 3e-4, (name, out[name], x)
+        if hasattr(w, 'w'):
+            w.close()
+    assert abs(out['x'] - out['y']) < 1e-3 and out['diag'] < 0.78 * out['x']
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_dropped_box_lands_without_a_bounce(backend):
+    """Restitution 0 (the URDF template sets none; Bullet's default): a box dropped flat from 5 cm falls with
+    g t^2 / 2, arrives at sqrt(2 g h) and stays down -- the only rebound is the Baumgarte push-out of the
+    first-substep penetration, under 1 mm -- and comes to rest on the table within the collision margins."""
+    w, cfg = _world(backend)
+    h0 = 0.05
+    _bodies(w, [(0, 0.3, 0.5, (0.5, 0.0, BOX_H[2] + 0.001 + h0), Q0, (0, 0, 0))])
+    dt = float(cfg.dt)
+    zs, vs = [], []
+    for _ in range(400):
+        w.step_sub(1)
+        st = w.body_state()[0, 0]
+        zs.append(st[2]); vs.append(st[9])
+    zs, vs = np.array(zs), np.array(vs)
+    t_fall = np.sqrt(2 * h0 / G)
+    k = int(0.8 * t_fall / dt)
+    assert abs((zs[0] + G * dt * dt - zs[k]) - 0.5 * G * (k * dt) ** 2) < 0.04 * h0            # free fall (damping 0.04 / s)
+    assert abs(vs.min() + np.sqrt(2 * G * h0)) < 0.05                                          # arrives at sqrt(2 g h)
+    first = int(np.argmin(vs))                                                                 # the substep before the impact
+    rest = zs[-1]
+    assert zs[first + 1:].max() - rest < 1e-3, zs[first + 1:].max() - rest                     # no bounce
+    assert vs[first + 1:].max() < 0.15
+    assert abs(rest - BOX_H[2]) < 2.5e-3 and np.abs(vs[-50:]).max() < 1e-3                     # at rest on the table
+    if hasattr(w, 'w'):
+        w.close()
