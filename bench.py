@@ -144,6 +144,8 @@ def main():
     ap.add_argument('--workload', choices=['config2', 'config3', 'config4', 'config5'], default='config2',
                     help='the timed workload (BASELINE.json configs[1..4]); other than config2: for profiling one of the legs '
                          'alone (tools/profile_bench.sh), implies --no-extra-legs')
+    ap.add_argument('--over', nargs='*', default=[], help='config overrides of the timed workload, KEY=VALUE (profiling aid: e.g. '
+                    'PHYSICS.SLEEP_STEPS=0 times the no-deactivation launch alone; implies --no-extra-legs)')
     ap.add_argument('--extra-legs', action='store_true', help='run the extra legs at --gpus N > 1 as well (default: N = 1 only -- '
                     'at 8192 envs per rank the no-deactivation legs alone take minutes)')
     args = ap.parse_args()
@@ -193,6 +195,19 @@ def main():
                 'PushEnv 4 rigid convex bodies, 8192 envs/GPU sharded across %d GPU(s), random policy, RCCL return-gather '
                 '(BASELINE.json configs[4])' % args.gpus)
     cfg_kwargs = dict(seed=args.seed)
+    for kv in args.over:
+        key, val = kv.split('=', 1)
+        try:
+            val = int(val)
+        except ValueError:
+            try:
+                val = float(val)
+            except ValueError:
+                pass
+        base_over[key] = val
+    if args.over:
+        args.no_extra_legs = True
+        workload += ' + overrides ' + ' '.join(args.over)
 
     def barrier():
         torch.cuda.synchronize()

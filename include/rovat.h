@@ -330,7 +330,11 @@ int  rv_rollout(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t
  * env.step() returned (rows of the other envs are unspecified; their point-cloud rows are
  * zeroed).  An env.step() may take several polls; WHAT an env computes does not depend
  * on how its step is cut into launches: its trajectory is rv_step_macro's, bit for bit.  A step
- * begun on an env whose episode is over is reported finished at once (reward 0, done). */
+ * begun on an env whose episode is over is reported finished at once (reward 0, done).
+ * Mixing with the lock-step entry points: rv_step_macro, rv_rollout*, rv_step_sub and
+ * rv_wait_until_stable CANCEL the pending partial step of every env they run on (the env is no
+ * longer "stepping": a later poll does not resume or repeat it; the physics the cancelled step
+ * already did stays done); rv_reset cancels it as well.  Begin a new step to continue. */
 int  rv_step_begin(rv_world* w, const float* d_actions /* [N][G][4] */, const uint8_t* d_mask /* [N] or NULL */);
 /* on != 0: a step begun on an env whose episode is over RESETS it instead (RobotEnv.reset, robot_env.py:204-237,
  * as the loop of generate_episodes does between episodes, episode_generation.py:36-46): the next poll reports the
@@ -430,7 +434,10 @@ int  rv_get_manifold_counts(rv_world* w, int32_t* d_out /* [N][RV_NMAN] */);
 
 /* ---- observations (push_env.py:169-236): PoseObs('position') pose_obs.py:53-73,
  *      attribute obs attribute_obs.py:16-115, SegmentedPointCloudObs
- *      camera_obs.py:182-238 (analytic surface sampling).  NULL pointers are skipped. */
+ *      camera_obs.py:182-238: ray-cast depth + segmentation, deprojection, P pixels per body
+ *      emitted in the order of their Philox keys -- a random permutation, so the row order within
+ *      a body's cloud carries no meaning; bodies with more than RV_PC_MAXPIX = 2048 visible pixels
+ *      are sampled with a stride).  NULL pointers are skipped. */
 typedef struct rv_obs_buffers {
   float*   d_position;     /* [N][RV_MAXB][3]                                   */
   float*   d_body_mask;    /* [N][RV_MAXB]                                      */
@@ -465,12 +472,12 @@ int  rv_rollout_record_full(rv_world* w, int32_t n_steps, int32_t first_macro_in
 /* ---- CameraObs 'depth' / 'segmask' (camera_obs.py:33-88; BulletCamera._frames,
  *      bullet_camera.py:188-235) of the simulated depth camera: eye-space depth (0 where
  *      nothing is hit) and segmentation (body index, RV_MAXB = table, RV_MAXB + 1 = the arm's link boxes, 255 = nothing).
- *      The arm is not rendered.  Either pointer may be NULL. */
+ *      The arm is drawn as its ten link collider boxes and occludes bodies.  Either pointer may be NULL. */
 int  rv_render(rv_world* w, float* d_depth /* [N][cam_height][cam_width] */, uint8_t* d_segmask /* same shape */);
 /* CameraObs 'rgb' (camera_obs.py:33-88; bullet_camera.py:188-235): the same ray cast, flat colours
  * per body slot / table / background, Lambert-shaded with the normal of the face that is hit under
  * one fixed directional light (BUILD-CHOSEN colours: the reference draws random rgba per body,
- * push_env.py:436).  The arm is not rendered. */
+ * push_env.py:436).  The arm's link boxes are drawn in a flat grey. */
 int  rv_render_rgb(rv_world* w, uint8_t* d_rgb /* [N][cam_height][cam_width][3] */);
 
 /* ---- PushReward.get_reward (push_reward.py:377-405, 272-374) of the last

@@ -252,6 +252,28 @@ static inline void orc_epa(const real (*A)[3], int nA, const real (*B)[3], int n
     pa[k] = VA[fi[bestf][0]][k] * l[0] + VA[fi[bestf][1]][k] * l[1] + VA[fi[bestf][2]][k] * l[2];
     pb[k] = VB[fi[bestf][0]][k] * l[0] + VB[fi[bestf][1]][k] * l[1] + VB[fi[bestf][2]][k] * l[2];
   }
+  /* c lies on the facet of the difference body that CONTAINS the best triangle, not necessarily inside the
+   * triangle itself (a small box 2 mm deep in the table slab: the facet is the whole table top, the polytope's
+   * triangle a sliver of it): the clamped barycentric point then gives witnesses with pa - pb != c, i.e. two
+   * anchors centimetres apart tangentially that the next refresh drops as a broken point.  The three a_i all
+   * lie on A's support face for this normal, the three b_i on B's: when one of the two features is a single
+   * vertex it is that body's witness and the other is its projection; otherwise the mismatch is split.
+   * (found by the closed-form pin tests/test_independent_pin.py) */
+  {
+    const int i0 = fi[bestf][0], i1 = fi[bestf][1], i2 = fi[bestf][2];
+    const int vtx_a = VA[i0][0] == VA[i1][0] && VA[i0][1] == VA[i1][1] && VA[i0][2] == VA[i1][2] &&
+                      VA[i0][0] == VA[i2][0] && VA[i0][1] == VA[i2][1] && VA[i0][2] == VA[i2][2];
+    const int vtx_b = VB[i0][0] == VB[i1][0] && VB[i0][1] == VB[i1][1] && VB[i0][2] == VB[i1][2] &&
+                      VB[i0][0] == VB[i2][0] && VB[i0][1] == VB[i2][1] && VB[i0][2] == VB[i2][2];
+    if (vtx_a) { for (int k = 0; k < 3; ++k) pb[k] = pa[k] - c[k]; }
+    else if (vtx_b) { for (int k = 0; k < 3; ++k) pa[k] = pb[k] + c[k]; }
+    else {
+      for (int k = 0; k < 3; ++k) {
+        const real dl = (pa[k] - pb[k]) - c[k];
+        pa[k] = pa[k] - R(0.5) * dl; pb[k] = pb[k] + R(0.5) * dl;
+      }
+    }
+  }
   v3cpy(out_nf, fn[bestf]);
   *out_depth = fd[bestf];
 }

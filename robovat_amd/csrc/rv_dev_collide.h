@@ -347,6 +347,26 @@ RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const E
   *pb = mk(E.VB[i0][0] * l0 + E.VB[i1][0] * l1 + E.VB[i2][0] * l2,
            E.VB[i0][1] * l0 + E.VB[i1][1] * l1 + E.VB[i2][1] * l2,
            E.VB[i0][2] * l0 + E.VB[i1][2] * l1 + E.VB[i2][2] * l2);
+  // c lies on the facet of the difference body that CONTAINS the best triangle, not necessarily inside the
+  // triangle: the clamped barycentric point then gives witnesses with pa - pb != c (anchors centimetres apart
+  // tangentially, dropped as a broken point by the next refresh).  The a_i all lie on A's support face for
+  // this normal, the b_i on B's: a feature that is a single vertex is that body's witness and the other is
+  // its projection; otherwise the mismatch is split (oracle: orc_epa, same arithmetic)
+  {
+    const bool vtx_a = E.VA[i0][0] == E.VA[i1][0] && E.VA[i0][1] == E.VA[i1][1] && E.VA[i0][2] == E.VA[i1][2] &&
+                       E.VA[i0][0] == E.VA[i2][0] && E.VA[i0][1] == E.VA[i2][1] && E.VA[i0][2] == E.VA[i2][2];
+    const bool vtx_b = E.VB[i0][0] == E.VB[i1][0] && E.VB[i0][1] == E.VB[i1][1] && E.VB[i0][2] == E.VB[i1][2] &&
+                       E.VB[i0][0] == E.VB[i2][0] && E.VB[i0][1] == E.VB[i2][1] && E.VB[i0][2] == E.VB[i2][2];
+    v3 qa = *pa, qb = *pb;
+    if (vtx_a) qb = sub(qa, c);
+    else if (vtx_b) qa = add(qb, c);
+    else {
+      const v3 dl = sub(sub(qa, qb), c);
+      qa = mk(qa.x - 0.5f * dl.x, qa.y - 0.5f * dl.y, qa.z - 0.5f * dl.z);
+      qb = mk(qb.x + 0.5f * dl.x, qb.y + 0.5f * dl.y, qb.z + 0.5f * dl.z);
+    }
+    *pa = qa; *pb = qb;
+  }
   *out_nf = fnb;
   *out_depth = E.fd[bestf];
 }

@@ -77,6 +77,17 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
   __syncthreads();
 #endif
   if (MODE == MODE_MACRO) skip = (S.e.done != 0);
+  if (MODE == MODE_MACRO || MODE == MODE_ROLLOUT || MODE == MODE_SUB || MODE == MODE_WAIT) {
+    // A lock-step entry point on an env that rv_step_poll left in the middle of an env.step() CANCELS that
+    // step (include/rovat.h, rv_step_begin): its phase machine is not resumed by a later poll -- without
+    // this the next poll would run a second env.step() with the stale action.
+    if (S.e.in_step != 0) {
+      if (lane == 0) { g->in_step = 0; g->step_stage = -1; }
+      __syncthreads();
+      if (lane == 0) { S.e.in_step = 0; S.e.step_stage = -1; }
+      __syncthreads();
+    }
+  }
   if (MODE == MODE_PARTIAL) {
     skip = (S.e.in_step != 1) && !(S.e.in_step == 2 && args.auto_reset);
     if (skip && lane == 0) {

@@ -41,6 +41,7 @@ class VecPushEnv(object):
         self.config = config or configs.push_env_config()
         self.robot_config = robot_config or configs.sawyer_config()
         self._owns_world = physics is None
+        self._physics = physics
         if physics is None:
             self.scene, self.shape_names = scenes.make_scene()
             self.rv_config = configs.make_rv_config(self.config, self.robot_config, self.shape_names,
@@ -50,6 +51,7 @@ class VecPushEnv(object):
             # the env runs on the world of a Simulator's physics backend (HipPhysics): what the env
             # does is visible through the Simulator / Body API and the other way round
             assert int(num_envs) == 1, 'a Simulator holds one env'
+            self._physics = physics
             physics.configure(self.config, self.robot_config, seed=seed, worker_id=env_id_offset)
             self.scene, self.shape_names = physics.scene, physics.shape_names
             self.world, self.rv_config = physics.world, physics.rv_config
@@ -71,6 +73,8 @@ class VecPushEnv(object):
     def reset(self, mask=None):
         """RobotEnv.reset for every env (or the masked ones)."""
         self.world.reset(mask)
+        if self._physics is not None:
+            self._physics.on_env_reset()
         return self.get_observation()
 
     def step(self, actions):
@@ -93,6 +97,8 @@ class VecPushEnv(object):
 
     def rollout(self, n_steps, auto_reset=True, record=True):
         out = self.world.rollout(n_steps, self._macro_index, auto_reset, record)
+        if auto_reset and self._physics is not None:
+            self._physics.on_env_reset()
         self._macro_index += int(n_steps)
         return out
 
@@ -119,6 +125,10 @@ class PushEnv(object):
             physics = simulator.physics
             if not hasattr(physics, 'configure'):
                 raise ValueError('PushEnv needs a Simulator whose physics backend is HipPhysics')
+            if simulator.bodies or simulator.constraints:
+                # configure() recreates the world: bodies / constraints added before would silently vanish
+                raise ValueError('PushEnv(simulator): the Simulator already holds %d bodies / %d constraints; give the env '
+                                 'an empty Simulator' % (len(simulator.bodies), len(simulator.constraints)))
         self._vec = VecPushEnv(1, self._config, robot_config, device=device, seed=seed, env_id_offset=worker_id,
                                use_point_cloud=True, physics=physics)
         self.max_movable_bodies = abi.RV_MAXB
@@ -162,6 +172,9 @@ class PushEnv(object):
 
     def reset(self):
         self._prev_obs_data = None
+        if self._simulator is not None:
+            # RobotEnv.reset -> simulator.reset() (robot_env.py:204-237): the episode's Body / Constraint wrappers go
+            self._simulator._bodies.clear(); self._simulator._constraints.clear()
         self._obs_data = self._convert(self._vec.reset())
         self._done = False
         self._episode_reward = 0.0

@@ -161,7 +161,7 @@ def append_episode(store, episode):
     return name
 
 
-def episodes_from_rollout(first_obs, obs, actions, rewards, dones, reset=None, reset_obs=None):
+def episodes_from_rollout(first_obs, obs, actions, rewards, dones, reset=None, reset_obs=None, auto_reset=True):
     """Episode dictionaries from ``World.rollout_record_full`` buffers.
 
     first_obs: observation dict of the state before the first step ([N, ...]); obs: dict of
@@ -173,12 +173,18 @@ def episodes_from_rollout(first_obs, obs, actions, rewards, dones, reset=None, r
     (episode_generation.py:47-67), the first state of an episode being the reset observation.
     Without ``reset_obs`` (plain ``rollout_record``) the first transition of every episode after
     an auto-reset has no recorded state and is dropped -- the number dropped is returned in the
-    ``dropped_transitions`` attribute of the list.
+    ``dropped_transitions`` attribute of the list.  ``reset`` and ``reset_obs`` come together
+    (ValueError otherwise).  ``auto_reset=False`` says the rollout ran without auto-reset: the rows
+    after an env's ``done`` are steps that were never taken (reward 0, done) and are neither
+    transitions nor drops; with ``reset`` given the same is read off the flags (no reset flag
+    after a done = the env stopped).
     """
     to_np = lambda x: x.cpu().numpy() if hasattr(x, 'cpu') else np.asarray(x)
     first_obs = {k: to_np(v) for k, v in first_obs.items()}
     obs = {k: to_np(v) for k, v in obs.items()}
     actions, rewards, dones = to_np(actions), to_np(rewards), to_np(dones)
+    if (reset is None) != (reset_obs is None):
+        raise ValueError('episodes_from_rollout: reset and reset_obs are given together or not at all')
     if reset_obs is not None:
         reset_obs = {k: to_np(v) for k, v in reset_obs.items()}
         reset = to_np(reset)
@@ -194,6 +200,8 @@ def episodes_from_rollout(first_obs, obs, actions, rewards, dones, reset=None, r
         for k in range(K):
             if reset_obs is not None and reset[k, i]:
                 state = {key: v[k, i] for key, v in reset_obs.items()}      # what env.reset() returned
+            if state is None and (not auto_reset or reset_obs is not None):
+                break               # episode over and no reset: the remaining rows are steps that were never taken
             if state is not None:
                 transitions.append({'state': state, 'action': actions[k, i], 'reward': float(rewards[k, i]), 'info': None})
             else:

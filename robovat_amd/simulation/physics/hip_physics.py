@@ -53,6 +53,9 @@ class HipPhysics(Physics):
     def configure(self, env_config, robot_config=None, seed=None, worker_id=None):
         """(Re)create the world for an env's configuration: what an env handed this backend through
         its Simulator calls first (envs/push/push_env.py)."""
+        if self._constraints:
+            raise ValueError('HipPhysics.configure: the world would be recreated under %d user constraint(s) -- hand the '
+                             'Simulator to the env before adding bodies or constraints' % len(self._constraints))
         self._env_config = env_config
         if robot_config is not None:
             self._robot_config = robot_config
@@ -76,6 +79,13 @@ class HipPhysics(Physics):
         self._world = lib.World(cfg, self.scene, device=self._device)
         self._num_steps = None
         self._static = {}
+        self._constraints = {}
+
+    def on_env_reset(self):
+        """The env that runs on this world was reset (RobotEnv.reset -> simulator.reset() in the reference,
+        robot_env.py:204-237): the device dropped every user constraint with the old episode's bodies, so
+        the host mirror is dropped too -- a stale entry would re-attach the old constraint to whatever body
+        takes that slot in the new episode."""
         self._constraints = {}
 
     def start(self):

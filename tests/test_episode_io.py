@@ -97,3 +97,29 @@ def test_episodes_from_rollout_buffers():
     assert np.array_equal(e0[1]['transitions'][0]['state']['position'], robs['position'][2, 0])
     assert np.array_equal(e0[1]['transitions'][1]['state']['position'], obs['position'][2, 0])
     assert np.array_equal(e0[1]['transitions'][0]['action'], actions[2, 0])
+
+
+def test_episodes_from_rollout_without_auto_reset_and_argument_checks():
+    K, N = 4, 2
+    rng = np.random.RandomState(2)
+    first = {'position': rng.rand(N, 4, 3)}
+    obs = {'position': rng.rand(K, N, 4, 3)}
+    actions, rewards = rng.rand(K, N, 4), rng.rand(K, N)
+    # env 0 ends after its second step; without auto-reset the rows after it are steps never taken (done = 1)
+    dones = np.zeros((K, N), np.uint8); dones[1:, 0] = 1
+    eps = H.episodes_from_rollout(first, obs, actions, rewards, dones, auto_reset=False)
+    assert eps.dropped_transitions == 0
+    assert [len(e['transitions']) for e in eps if e['env'] == 0] == [2]
+    assert [len(e['transitions']) for e in eps if e['env'] == 1] == [4]
+    # the same read off the reset flags of rollout_record_full (no flag after the done = the env stopped)
+    reset = np.zeros((K, N), np.uint8)
+    robs = {'position': np.zeros((K, N, 4, 3))}
+    eps = H.episodes_from_rollout(first, obs, actions, rewards, dones, reset=reset, reset_obs=robs)
+    assert eps.dropped_transitions == 0 and [len(e['transitions']) for e in eps if e['env'] == 0] == [2]
+    # reset and reset_obs come together
+    for kw in ({'reset': reset}, {'reset_obs': robs}):
+        try:
+            H.episodes_from_rollout(first, obs, actions, rewards, dones, **kw)
+        except ValueError:
+            continue
+        raise AssertionError('expected ValueError for %s alone' % list(kw))

@@ -166,3 +166,58 @@ def test_set_friction_matches_the_oracle_and_the_physics_mirror_routes_to_it():
     ph.set_link_dynamics((hp.ARM_UID, 8), lateral_friction=1.5)
     assert abs(ph.get_link_mass((hp.ARM_UID, 1)) - 4.505) < 1e-3
     assert ph.get_joint_limit((hp.ARM_UID, 0))['effort'] == pytest.approx(80.0)
+
+
+def test_lockstep_entry_points_cancel_a_pending_partial_step():
+    """A poll leaves an env.step() half done (in_step == 1).  rv_step_macro / rv_rollout / rv_step_sub /
+    rv_wait_until_stable on that env CANCEL the pending step (include/rovat.h, rv_step_begin): the next poll
+    must not run a second env.step() with the stale action (round-3 advice)."""
+    import numpy as np
+    from robovat_amd import configs, scenes, lib
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(n_envs=6, seed=8, shape_names=names)
+    for entry in ('macro', 'sub', 'wait', 'rollout'):
+        w = lib.World(cfg, scene, device=0)
+        w.reset()
+        w.step_begin(w.policy_random(0))
+        fin = w.step_poll(max_substeps=300)                      # nobody finishes an env.step() in 300 substeps
+        assert int(fin.sum()) == 0
+        n0 = w.env_counters().cpu().numpy()[:, 1].copy()          # num_steps
+        if entry == 'macro':
+            w.set_actions(w.policy_random(1)); w.step_macro()
+            expect = n0 + 1
+        elif entry == 'sub':
+            w.step_sub(5); expect = n0
+        elif entry == 'wait':
+            w.wait_until_stable(max_steps=20); expect = n0
+        else:
+            w.rollout(1, first_macro_index=1, auto_reset=False, record=False); expect = n0 + 1
+        assert np.array_equal(w.env_counters().cpu().numpy()[:, 1], expect)
+        fin = w.step_poll()                                      # nothing is pending any more: no step runs
+        assert int(fin.sum()) == 0 and w.stats()['env_steps'] == 0
+        assert np.array_equal(w.env_counters().cpu().numpy()[:, 1], expect)
+        w.close()
+
+
+def test_env_reset_invalidates_the_constraint_mirror_and_configure_refuses_a_populated_simulator():
+    """round-3 advice: the device drops user constraints on env_reset, so the host mirror and the Simulator's
+    wrappers must go too; PushEnv(simulator) must not silently recreate the world under existing bodies."""
+    import numpy as np
+    from robovat_amd import envs
+    from robovat_amd.simulation import Simulator
+    sim = Simulator(physics_backend='HipPhysics')
+    env = envs.PushEnv(simulator=sim, seed=4)
+    env.reset()
+    uid = sim.physics.add_constraint(0, None, joint_type='fixed')
+    assert uid in sim.physics._constraints
+    env.reset()                                                  # new episode: the device cleared con_on[]
+    assert sim.physics._constraints == {} and not sim.constraints and not sim.bodies
+    uid2 = sim.physics.add_constraint(0, None, joint_type='fixed')      # does not raise 'already has a constraint'
+    assert uid2 == 0
+    with pytest.raises(ValueError):
+        envs.PushEnv(simulator=sim, seed=4)                      # configure() would recreate the world under the constraint
+    sim2 = Simulator(physics_backend='HipPhysics')
+    sim2.reset(); sim2.start(); sim2.add_body('box.urdf', [[0.6, 0.0, 0.05], [0, 0, 0]], name='b0')
+    with pytest.raises(ValueError):
+        envs.PushEnv(simulator=sim2, seed=4)
+    env.close()

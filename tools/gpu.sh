@@ -1,0 +1,58 @@
+#!/bin/bash
+# One parameterised GPU-box script (replaces the per-experiment tools/gpu_r03_*.sh of round 3).
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu.sh <tag> <stage> [<stage> ...]'
+# Everything a stage writes goes to gpurun_out/<tag>/ (merged back into the build container).
+# Stages:
+#   tests          pytest -m gpu (whole suite) + smoke()
+#   tests:<expr>   pytest -m gpu -k <expr>
+#   bench          the driver's command: python bench.py --steps 20 --warmup 5
+#   headline       bench.py headline only (no CPU legs, no extra legs)
+#   k50            bench.py --steps 50 headline only
+#   profile        rocprofv3 kernel stats + PMC passes of the headline (tools/profile_bench.sh)
+#   profile_nd     the same for the reference-semantics (no deactivation) launch
+#   parts          per-part shader-clock table of the bench launch (RV_PROFILE build)
+#   parts_nd       per-part table with PHYSICS.SLEEP_STEPS=0, 2 steps
+#   parts_c3 / parts_c4 / parts_c5   per-part tables of configs 3 / 4 / 5
+#   lanes          SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU lane-utilisation pass (headline and no-deactivation)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; TAG=$1; shift
+O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+export TMPDIR=/tmp
+for STAGE in "$@"; do
+  T0=$(date +%s)
+  case $STAGE in
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "tests rc=$?" >> $O/time.txt
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/time.txt
+      tail -3 $O/tests.log; tail -1 $O/smoke.log ;;
+    tests:*)
+      timeout 1500 python -m pytest tests -m gpu -x -q -k "${STAGE#tests:}" > $O/tests_k.log 2>&1; echo "tests -k rc=$?" >> $O/time.txt
+      tail -5 $O/tests_k.log ;;
+    bench)
+      timeout 1700 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/time.txt
+      python tools/bench_digest.py $O/bench.json ;;
+    headline)
+      timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs > $O/headline.json 2> $O/headline.err
+      cut -c1-400 $O/headline.json ;;
+    k50)
+      timeout 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-legs > $O/k50.json 2> $O/k50.err
+      cut -c1-300 $O/k50.json ;;
+    profile)    bash tools/profile_bench.sh $TAG/profile > $O/profile.log 2>&1; tail -2 $O/profile.log ;;
+    profile_nd) bash tools/profile_bench.sh $TAG/profile_nd --steps 2 --warmup 1 --over PHYSICS.SLEEP_STEPS=0 > $O/profile_nd.log 2>&1; tail -2 $O/profile_nd.log ;;
+    parts)      timeout 400 python tools/prof_rollout.py --warm 1 --warm-steps 5 --top 10 > $O/parts.txt 2>&1; head -40 $O/parts.txt ;;
+    parts_nd)   timeout 600 python tools/prof_rollout.py --warm 0 --steps 2 --top 4 --over PHYSICS.SLEEP_STEPS=0 > $O/parts_nd.txt 2>&1; head -48 $O/parts_nd.txt ;;
+    parts_c3)   timeout 600 python tools/prof_rollout.py --warm 0 --envs 4096 --steps 10 --top 6 --over TASK_NAME=crossing LAYOUT_ID=0 MOVABLE_NAME=CONCAVE MAX_STEPS=10 > $O/parts_c3.txt 2>&1; head -40 $O/parts_c3.txt ;;
+    parts_c4)   timeout 600 python tools/prof_rollout.py --warm 0 --envs 2048 --steps 10 --top 6 --grasp > $O/parts_c4.txt 2>&1; head -40 $O/parts_c4.txt ;;
+    parts_c5)   timeout 400 python tools/prof_rollout.py --warm 1 --envs 8192 --steps 10 --top 6 > $O/parts_c5.txt 2>&1; head -40 $O/parts_c5.txt ;;
+    lanes)
+      cd /tmp
+      for V in head nd; do
+        if [ $V = head ]; then A="--steps 20 --warmup 5"; else A="--steps 2 --warmup 1 --over PHYSICS.SLEEP_STEPS=0"; fi
+        CMD="python $R/bench.py $A --no-cpu-baseline --no-extra-legs"
+        rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/lanes_$V -o l --output-format csv -- $CMD > $O/lanes_$V.log 2>&1
+      done
+      cd $R; python tools/pmc_summary.py $O/lanes_head $O/lanes_nd > $O/lanes.txt 2>&1; cat $O/lanes.txt ;;
+    *) echo "unknown stage $STAGE" ;;
+  esac
+  echo "$STAGE: $(( $(date +%s) - T0 )) s" >> $O/time.txt
+done
+cat $O/time.txt
