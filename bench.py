@@ -43,7 +43,7 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
     HeuristicPushPolicy, 20 episodes; one thread and one worker per core as
     tools/parallel_run.py would start them) and the FP32-vs-FP64 pose error."""
     import numpy as np
-    from robovat_amd import configs, lib
+    from robovat_amd import configs, lib, scenes
     from oracle import orc
     cores = os.cpu_count() or 1
     out = {}
@@ -52,17 +52,48 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
     cfg = configs.make_rv_config(n_envs=n, shape_names=names, **cfg_kwargs)
     w = orc.OracleWorld(cfg, scene, double=False)
     w.reset()
-    t_all, steps, sub, k = 0.0, 0, 0, 0
+    t_all, steps, sub, awake, k = 0.0, 0, 0, 0, 0
     while t_all < 5.0 and k < 4:
         w.set_actions(w.policy_random(k))
         t0 = time.perf_counter(); w.step_macro(); t_all += time.perf_counter() - t0
-        st = w.stats(); steps += st['env_steps']; sub += st['substeps']; k += 1
+        st = w.stats(); steps += st['env_steps']; sub += st['substeps']; awake += st['awake_substeps']; k += 1
     out['cpu_baseline'] = {
         'value': steps / t_all, 'unit': 'env_steps/s', 'cores': cores, 'kind': 'port',
         'sim_steps_per_s': sub / t_all,
         'sample': '%d envs x %d macro steps of the same workload, float C oracle, OpenMP over envs '
                   '(pybullet not importable -> reference loop skipped)' % (n, k),
     }
+    out['cpu_baseline']['awake_sim_steps_per_s'] = awake / t_all     # (the oracle never coasts: the other substeps still run its light part)
+    # (i') the reference's most likely semantics on the host cores (same legs as reference_semantics.gpu): every
+    # substep is an awake one, so sim_steps_per_s compares like for like with the MI355X legs
+    def semantics_cpu(over):
+        env_cfg = configs.push_env_config(**over)
+        sc, nm = (scenes.make_scene(env_cfg=env_cfg) if 'PHYSICS.ARM_ACCEL_SCALE' in over else (scene, names))
+        c = configs.make_rv_config(env_cfg=env_cfg, n_envs=n, shape_names=nm, **cfg_kwargs)
+        wc = orc.OracleWorld(c, sc, double=False)
+        wc.reset()
+        p0, _ = wc.observe()
+        wc.set_actions(wc.policy_random(0))
+        t0 = time.perf_counter(); wc.step_macro(); el = time.perf_counter() - t0
+        stc = wc.stats(); p1, _ = wc.observe()
+        moved = np.linalg.norm(p1[..., :2] - p0[..., :2], axis=-1).sum(-1)
+        es = max(stc['env_steps'], 1)
+        return {'value': stc['env_steps'] / el, 'unit': 'env_steps/s', 'sim_steps_per_s': stc['substeps'] / el, 'cores': cores,
+                'envs': n, 'steps': 1, 'useful': stc['useful'] / es, 'unsafe': stc['unsafe'] / es, 'ineffective': stc['ineffective'] / es,
+                'disp_mean_mm': 1e3 * float(moved.mean()), 'substeps_per_env_step': stc['substeps'] / es}
+    nd = {'PHYSICS.SLEEP_STEPS': 0}
+    bs = {'PHYSICS.SOLVER_TOL': 0.0, 'PHYSICS.SOLVER_STALL': 0}
+    out['reference_semantics_cpu'] = {'early_exit_effort_limited_motor': semantics_cpu(nd)}
+    # ... and what ONE host thread needs per awake env-substep (1 env = 1 OpenMP thread), the unit the MI355X's
+    # one-wave-per-env figure (envs / sim_steps_per_s) compares with
+    c1 = configs.make_rv_config(env_cfg=configs.push_env_config(**nd), n_envs=1, shape_names=names, **cfg_kwargs)
+    w1 = orc.OracleWorld(c1, scene, double=False)
+    w1.reset(); w1.set_actions(w1.policy_random(0))
+    t0 = time.perf_counter(); w1.step_macro(); e1 = time.perf_counter() - t0
+    out['reference_semantics_cpu']['early_exit_effort_limited_motor']['one_thread_us_per_substep'] = 1e6 * e1 / max(w1.stats()['substeps'], 1)
+    if not quick:
+        out['reference_semantics_cpu']['effort_limited_motor'] = semantics_cpu(dict(nd, **bs))
+        out['reference_semantics_cpu']['unlimited_motor'] = semantics_cpu(dict(nd, **bs, **{'PHYSICS.ARM_ACCEL_SCALE': 1000.0}))
     # (ii) BASELINE config 1: run_env.py --env PushEnv --policy HeuristicPushPolicy, 20 episodes
     max_steps, episodes = 5, 20
 
@@ -164,15 +195,28 @@ def main():
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    if world_size > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-    else:
-        torch.cuda.set_device(0)
+    # The RCCL group is created at EVERY world size -- also 1 -- so that the N = 1 point of a scaling run
+    # executes exactly the code path N = 8 does (barriers, max-over-ranks timing and the return gather
+    # inside the timed region).  Under torch.distributed.run the rendezvous comes from the environment;
+    # a bare `python bench.py` makes its own one-rank group on a free local port.
+    import torch.distributed as dist
+    dist_note = None
+    if world_size == 1:
         local_rank = 0
+    torch.cuda.set_device(local_rank)
+    try:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world_size, device_id=torch.device('cuda', local_rank))
+    except Exception as ex:  # noqa: BLE001 -- only a one-rank run may go on without its group
+        if world_size > 1:
+            raise
+        dist_note = 'RCCL group not created: %r' % (ex,)
+        dist = None
     assert world_size == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     scene, names = scenes.make_scene()
@@ -277,47 +321,61 @@ def main():
         el = all_max(time.perf_counter() - t0)
         return el, tot, kern_ms, k_steps
 
-    def deactivation_legs(make_world, n_envs, k_steps, quick=False):
+    # ---- semantics legs: the same workload / seed / actions under other physics settings -------------------
+    # What the reference most likely runs (RECALLED PyBullet behaviour, DESIGN.md section 3, table of recalled
+    # defaults): bullet_physics.py:173-181 loads every body WITHOUT URDF_ENABLE_SLEEPING (no deactivation),
+    # Bullet sweeps 50 times without an early exit, and controllable_body.py:458-466 -> bullet_physics.py:1061-1104
+    # passes no `forces=` to setJointMotorControlArray, whose default maximum motor force is either the URDF joint
+    # effort (the shipped acceleration limits) or a large constant (the motors then reach
+    # the commanded velocity within a step: ARM_ACCEL_SCALE = 1000).  Both motor variants are first-class legs.
+    NO_DEACT = {'PHYSICS.SLEEP_STEPS': 0}
+    BULLET_SWEEPS = {'PHYSICS.SOLVER_TOL': 0.0, 'PHYSICS.SOLVER_STALL': 0}
+    SEMANTICS = [
+        ('shipped', {}),
+        ('bullet_rule_alone', {'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0, 'PHYSICS.SLEEP_STEPS': 2000,
+                               'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.DEACTIVATION_STEPS': 0}),
+        ('no_deactivation', dict(NO_DEACT)),
+        ('no_deactivation_50_sweeps', dict(NO_DEACT, **BULLET_SWEEPS)),
+        ('no_deactivation_50_sweeps_unlimited_motor', dict(NO_DEACT, **BULLET_SWEEPS, **{'PHYSICS.ARM_ACCEL_SCALE': 1000.0})),
+    ]
+
+    def outcome_stats(st, pos):
         import numpy as np
-        variants = [
-            ('shipped', {}),
-            ('bullet_rule_alone', {'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0, 'PHYSICS.SLEEP_STEPS': 2000,
-                                   'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.DEACTIVATION_STEPS': 0}),
-            ('no_deactivation', {'PHYSICS.SLEEP_STEPS': 0}),
-        ]
-        if not quick:
-            variants.append(('no_deactivation_50_sweeps', {'PHYSICS.SLEEP_STEPS': 0, 'PHYSICS.SOLVER_TOL': 0.0, 'PHYSICS.SOLVER_STALL': 0}))
-        out = {'note': 'same workload / seed / actions, one rv_rollout_record launch of %d steps without auto-reset; displacement = '
-                       'sum over the bodies of an env of the xy distance moved by one env.step(), mm.  bullet_physics.py:173-181 '
-                       'passes no URDF_ENABLE_SLEEPING: no_deactivation is the closest to the reference; no_deactivation_50_sweeps '
-                       'also drops the residual early exit of the solver (whose 1e-5 N s tolerance lets resting bodies creep at '
-                       '~4e-5 m/s when nothing ever puts them to sleep)' % k_steps}
-        for name, over in variants:
-            w, _ = make_world(n_envs, **over)
-            w.reset()
-            pos0 = w.observe()['position']
-            barrier(); t0 = time.perf_counter()
-            obs, r, d = w.rollout_record(k_steps, first_macro_index=0, auto_reset=False, point_cloud=False)
-            st = w.stats()
-            barrier(); el = all_max(time.perf_counter() - t0)
-            pos = torch.cat([pos0[None], obs['position']], 0).cpu().numpy()
-            moved = np.linalg.norm(pos[1:, ..., :2] - pos[:-1, ..., :2], axis=-1).sum(-1)
-            es = max(st['env_steps'], 1)
-            out[name] = {'value': all_sum(st['env_steps'])[0] / el, 'unit': 'env_steps/s',
-                         'useful': st['useful'] / es, 'unsafe': st['unsafe'] / es, 'ineffective': st['ineffective'] / es,
-                         'disp_mean_mm': 1e3 * float(moved.mean()), 'disp_p50_mm': 1e3 * float(np.percentile(moved, 50)),
-                         'disp_p90_mm': 1e3 * float(np.percentile(moved, 90)), 'disp_p99_mm': 1e3 * float(np.percentile(moved, 99)),
-                         'awake_substep_fraction': st['awake_substeps'] / max(st['substeps'], 1),
-                         'substeps_per_env_step': st['substeps'] / es}
-            w.close()
-        ref = out['no_deactivation_50_sweeps' if 'no_deactivation_50_sweeps' in out else 'no_deactivation']
-        sh = out['shipped']
-        out['shipped_vs_reference_semantics'] = {
-            'reference_leg': 'no_deactivation_50_sweeps' if 'no_deactivation_50_sweeps' in out else 'no_deactivation',
-            'disp_mean_ratio': sh['disp_mean_mm'] / max(ref['disp_mean_mm'], 1e-9),
-            'useful_diff': sh['useful'] - ref['useful'], 'unsafe_diff': sh['unsafe'] - ref['unsafe'],
-            'ineffective_diff': sh['ineffective'] - ref['ineffective']}
+        moved = np.linalg.norm(pos[1:, ..., :2] - pos[:-1, ..., :2], axis=-1).sum(-1)
+        es = max(st['env_steps'], 1)
+        return {'useful': st['useful'] / es, 'unsafe': st['unsafe'] / es, 'ineffective': st['ineffective'] / es,
+                'disp_mean_mm': 1e3 * float(moved.mean()), 'disp_p50_mm': 1e3 * float(np.percentile(moved, 50)),
+                'disp_p90_mm': 1e3 * float(np.percentile(moved, 90)), 'disp_p99_mm': 1e3 * float(np.percentile(moved, 99)),
+                'awake_substep_fraction': st['awake_substeps'] / max(st['substeps'], 1),
+                'substeps_per_env_step': st['substeps'] / es}
+
+    def gpu_semantics_leg(over, n_envs, k_steps):
+        env_cfg = configs.push_env_config(**over)
+        sc, nm = (scenes.make_scene(env_cfg=env_cfg) if 'PHYSICS.ARM_ACCEL_SCALE' in over else (scene, names))
+        c = configs.make_rv_config(env_cfg=env_cfg, n_envs=n_envs, env_id_offset=rank * n_envs, shape_names=nm, **cfg_kwargs)
+        w = lib.World(c, sc, device=local_rank)
+        w.reset()
+        pos0 = w.observe()['position']
+        barrier(); t0 = time.perf_counter()
+        obs, r, d = w.rollout_record(k_steps, first_macro_index=0, auto_reset=False, point_cloud=False)
+        st = w.stats()
+        barrier(); el = all_max(time.perf_counter() - t0)
+        pos = torch.cat([pos0[None], obs['position']], 0).cpu().numpy()
+        out = {'value': all_sum(st['env_steps'])[0] / el, 'unit': 'env_steps/s', 'sim_steps_per_s': all_sum(st['substeps'])[0] / el,
+               'awake_sim_steps_per_s': all_sum(st['awake_substeps'])[0] / el, 'envs': n_envs, 'steps': k_steps,
+               'kernel_ms': w.last_kernel_ms()}
+        out.update(outcome_stats(st, pos))
+        w.close()
         return out
+
+    def semantics_legs(n_envs, k_steps, quick=False):
+        legs = {}
+        for name, over in SEMANTICS:
+            if quick and '50_sweeps' in name:
+                continue
+            # (the 50-sweep legs run ~50 x slower than the headline: half the steps keep the default run short)
+            legs[name] = gpu_semantics_leg(over, n_envs, max(2, k_steps // 2) if '50_sweeps' in name else k_steps)
+        return legs
 
     def leg_summary(el, st, k_steps, n_envs):
         es, ss = all_sum(st['env_steps'], st['substeps'])
@@ -338,7 +396,13 @@ def main():
     next_index = args.warmup + args.steps
 
     extra = {}
+    if dist_note:
+        extra['dist_note'] = dist_note
     if not args.no_extra_legs:
+        # BASELINE.md's config 2 names 50 macro-steps per env: the same single-launch rollout with K = 50
+        el50, st50, km50, _ = time_rollout(world, 50, next_index); next_index += 50
+        extra['config2_k50'] = leg_summary(el50, st50, 50, n)
+        extra['config2_k50'].update({'kernel_ms': km50, 'roofline_frac_nominal': ALGO_BYTES['config2'] * st50['substeps'] / (1e-3 * km50) / 1e9 / HBM_PEAK_GBS})
         other = time_lockstep if args.mode == 'rollout' else time_rollout
         el2, st2, km2, _ = other(world, args.steps, next_index); next_index += args.steps
         name = 'lockstep_env_step' if args.mode == 'rollout' else 'single_launch_rollout'
@@ -416,7 +480,35 @@ def main():
         # URDF_ENABLE_SLEEPING, so PyBullet most likely never deactivates them.  Same workload,
         # same seed, same actions with (a) the shipped rule, (b) Bullet's own rule alone, (c) no
         # deactivation at all [+ Bullet's fixed 50 solver sweeps]: outcome statistics and rate.
-        extra['deactivation'] = deactivation_legs(make_world, n, min(args.steps, 20), quick=args.quick)
+        legs = semantics_legs(n, min(args.steps, 20), quick=args.quick)
+        deact = {'note': 'same workload / seed / actions, one rv_rollout_record launch without auto-reset; displacement = sum over the '
+                         'bodies of an env of the xy distance moved by one env.step(), mm.  bullet_physics.py:173-181 passes no '
+                         'URDF_ENABLE_SLEEPING: the no_deactivation legs are the closest to the reference (see reference_semantics)'}
+        for k in ('shipped', 'bullet_rule_alone', 'no_deactivation', 'no_deactivation_50_sweeps'):
+            if k in legs:
+                deact[k] = legs[k]
+        ref_name = 'no_deactivation_50_sweeps' if 'no_deactivation_50_sweeps' in legs else 'no_deactivation'
+        sh, ref = legs['shipped'], legs[ref_name]
+        deact['shipped_vs_reference_semantics'] = {
+            'reference_leg': ref_name, 'disp_mean_ratio': sh['disp_mean_mm'] / max(ref['disp_mean_mm'], 1e-9),
+            'useful_diff': sh['useful'] - ref['useful'], 'unsafe_diff': sh['unsafe'] - ref['unsafe'],
+            'ineffective_diff': sh['ineffective'] - ref['ineffective']}
+        nd, nd50 = legs['no_deactivation'], legs.get('no_deactivation_50_sweeps')
+        if nd50 is not None:
+            deact['early_exit_vs_50_sweeps_without_deactivation'] = {
+                'disp_mean_ratio': nd['disp_mean_mm'] / max(nd50['disp_mean_mm'], 1e-9),
+                'useful_diff': nd['useful'] - nd50['useful'], 'ineffective_diff': nd['ineffective'] - nd50['ineffective']}
+        extra['deactivation'] = deact
+        # the reference's most likely semantics as first-class legs, MI355X and (below, cpu_legs) host cores
+        extra['reference_semantics'] = {
+            'note': 'no deactivation, 50 solver sweeps without early exit (RECALLED Bullet defaults; DESIGN.md section 3) with both '
+                    'readings of the POSITION_CONTROL default maximum force: effort_limited_motor = the URDF joint efforts (shipped '
+                    'acceleration limits), unlimited_motor = commanded velocity reached within a step.  Every substep is an awake one: '
+                    'sim_steps_per_s is the like-for-like rate against the cpu legs of the same name',
+            'gpu': {'effort_limited_motor': legs.get('no_deactivation_50_sweeps'),
+                    'unlimited_motor': legs.get('no_deactivation_50_sweeps_unlimited_motor'),
+                    'early_exit_effort_limited_motor': legs['no_deactivation']},
+            'headline_semantics': {k: sh[k] for k in ('value', 'useful', 'unsafe', 'ineffective', 'disp_mean_mm', 'awake_substep_fraction')}}
         # BASELINE configs[2]: 'crossing' layout, V-HACD concave movables, 4096 envs
         w3, _ = make_world(4096, TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)
         w3.reset()
@@ -485,25 +577,18 @@ def main():
         wl.close()
         extra['limb_dynamics'] = limb
         # the path's only collective, alone: one RCCL all-gather of returns f32[8192] + all-reduce of 4
-        # int64 counters on a 1-rank group (the 8-rank curve is the driver's to measure)
-        if dist is None:
-            try:
-                import torch.distributed as d1
-                from robovat_amd import parallel
-                d1.init_process_group(backend='nccl', init_method='tcp://127.0.0.1:29621', rank=0, world_size=1,
-                                      device_id=torch.device('cuda', 0))
-                ret = torch.zeros(8192, dtype=torch.float32, device='cuda'); cnt4 = torch.zeros(4, dtype=torch.int64, device='cuda')
-                for _ in range(5):
-                    parallel.gather_returns(ret, cnt4)
-                torch.cuda.synchronize(); tg = time.perf_counter()
-                for _ in range(100):
-                    parallel.gather_returns(ret, cnt4)
-                torch.cuda.synchronize()
-                extra['gather_returns_alone'] = {'us_per_call': 1e4 * (time.perf_counter() - tg), 'ranks': 1, 'backend': 'nccl (RCCL)',
-                                                 'payload': 'all-gather f32[8192] + all-reduce int64[4]'}
-                d1.destroy_process_group()
-            except Exception as ex:  # noqa: BLE001 -- a report field, not the product path
-                extra['gather_returns_alone'] = {'error': repr(ex)[:200]}
+        # int64 counters on this run's group (the 8-rank curve is the driver's to measure)
+        if dist is not None:
+            from robovat_amd import parallel
+            ret = torch.zeros(8192, dtype=torch.float32, device='cuda'); cnt4 = torch.zeros(4, dtype=torch.int64, device='cuda')
+            for _ in range(5):
+                parallel.gather_returns(ret, cnt4)
+            torch.cuda.synchronize(); tg = time.perf_counter()
+            for _ in range(100):
+                parallel.gather_returns(ret, cnt4)
+            torch.cuda.synchronize()
+            extra['gather_returns_alone'] = {'us_per_call': 1e4 * (time.perf_counter() - tg), 'ranks': world_size, 'backend': 'nccl (RCCL)',
+                                             'payload': 'all-gather f32[8192] + all-reduce int64[4]'}
     else:
         world.close()
 
@@ -557,7 +642,18 @@ def main():
         }
         out.update(extra)
         if not args.no_cpu_baseline and world_size == 1:
-            out.update(cpu_legs(cfg_kwargs, scene, names, quick=args.quick))
+            cl = cpu_legs(cfg_kwargs, scene, names, quick=args.quick)
+            ref_cpu = cl.pop('reference_semantics_cpu', None)
+            out.update(cl)
+            if ref_cpu is not None:
+                rs = out.setdefault('reference_semantics', {})
+                rs['cpu'] = ref_cpu
+                g, c_ = rs.get('gpu', {}), ref_cpu
+                for k, v in g.items():
+                    if v:
+                        v['one_wave_us_per_substep'] = 1e6 * v['envs'] / v['sim_steps_per_s']
+                rs['gpu_over_cpu_sim_steps'] = {k: g[k]['sim_steps_per_s'] / c_[k]['sim_steps_per_s']
+                                                for k in c_ if g.get(k) and c_[k]['sim_steps_per_s'] > 0}
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.barrier()

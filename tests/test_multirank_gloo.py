@@ -63,6 +63,44 @@ def test_two_rank_gather_matches_single_process():
     assert np.array_equal(state0, single.body_state()[:N_PER_RANK])
 
 
+def test_eight_rank_shards_match_single_process():
+    """BASELINE config 5's layout in small: 8 ranks x 2 envs, keyed by global env id -- the gathered returns and
+    summed counters are those of one process that owns all 16 envs (no 8-GPU box is needed for that statement)."""
+    n_ranks, per = 8, 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, n_ranks, per, port, q)) for r in range(n_ranks)]
+    for p in procs:
+        p.start()
+    allr, allc = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single = _run_shard(0, n_ranks * per, 0)
+    assert allr.shape == (n_ranks, per)
+    assert np.array_equal(allr.reshape(-1), single.episode_returns().astype(np.float32))
+    cnt = single.env_counters()
+    assert list(allc) == [cnt[:, 2].sum(), cnt[:, 5].sum(), cnt[:, 6].sum(), cnt[:, 1].sum()]
+
+
+def _worker8(rank, world_size, per, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['OMP_NUM_THREADS'] = '2'
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    w = _run_shard(rank, per, parallel.env_id_offset(rank, per))
+    returns = torch.tensor(w.episode_returns(), dtype=torch.float32)
+    cnt = w.env_counters()
+    counters = torch.tensor([cnt[:, 2].sum(), cnt[:, 5].sum(), cnt[:, 6].sum(), cnt[:, 1].sum()], dtype=torch.int64)
+    allr, allc = parallel.gather_returns(returns, counters)
+    if rank == 0:
+        q.put((allr.numpy(), allc.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def test_gather_without_process_group_is_identity():
     r = torch.arange(4, dtype=torch.float32)
     out, c = parallel.gather_returns(r, torch.ones(4, dtype=torch.int64))

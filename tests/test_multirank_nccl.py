@@ -79,3 +79,57 @@ def test_one_rank_nccl_group_gathers():
         assert out.shape == (1, 8) and torch.equal(out[0], r) and torch.equal(cc, c)
     finally:
         dist.destroy_process_group()
+
+
+def test_two_worlds_on_two_streams_in_one_process_are_reentrant():
+    """SURVEY.md 8b "re-entrancy across worlds" (one process driving several GPUs holds several rv_world):
+    two worlds -- the two env shards of a 2-rank run -- live in ONE process on ONE device, each on its own
+    HIP stream, and are stepped concurrently (launches interleaved, no synchronisation in between).  Each
+    must compute what it computes alone, and together what a single world owning all envs computes."""
+    from robovat_amd import lib
+    scene, names = scenes.make_scene()
+
+    def cfg(n, offset):
+        return configs.make_rv_config(env_cfg=configs.push_env_config(TASK_NAME='insertion', LAYOUT_ID=0, MAX_STEPS=3),
+                                      n_envs=n, env_id_offset=offset, seed=77, shape_names=names)
+    n = 96
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    worlds = []
+    for r in range(2):
+        with torch.cuda.stream(streams[r]):
+            w = lib.World(cfg(n, r * n), scene, device=0)      # (binds the world to the stream that is current now)
+            worlds.append(w)
+    # interleaved launches on the two streams; nothing waits until the end
+    for r in range(2):
+        with torch.cuda.stream(streams[r]):
+            worlds[r].reset()
+    for k in range(STEPS):
+        for r in (1, 0):
+            with torch.cuda.stream(streams[r]):
+                worlds[r].rollout(1, k, True)
+    for s in streams:
+        s.synchronize()
+    both = lib.World(cfg(2 * n, 0), scene, device=0)
+    both.reset(); both.rollout(STEPS, 0, True)
+    torch.cuda.synchronize()
+    want_state, want_ret = both.body_state().cpu().numpy(), both.episode_returns().cpu().numpy()
+    for r in range(2):
+        with torch.cuda.stream(streams[r]):
+            got_state, got_ret = worlds[r].body_state().cpu().numpy(), worlds[r].episode_returns().cpu().numpy()
+        assert np.array_equal(got_state, want_state[r * n:(r + 1) * n])
+        assert np.array_equal(got_ret, want_ret[r * n:(r + 1) * n])
+    # ... and the path's collective on this process's own one-rank RCCL group
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        made = True
+    else:
+        made = False
+    allr, _ = parallel.gather_returns(worlds[0].episode_returns())
+    assert allr.shape == (1, n) and np.array_equal(allr[0].cpu().numpy(), want_ret[:n])
+    if made:
+        dist.destroy_process_group()
+    for w in worlds + [both]:
+        w.close()
