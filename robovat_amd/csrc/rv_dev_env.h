@@ -1595,6 +1595,153 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
   }
   __syncthreads();
 }
+// ALL islands that are one body on the table (or the ground) and nothing else -- no arm points, no point
+// with another awake body, no finger / limb / constraint rows -- solved TOGETHER: 16 lanes per body, lane
+// 16 b + 3 p + k = row k of table point p of body b.  The islands do not couple, so each keeps its own
+// iterates, residual and exit (bit for bit what solve_island2 computes for it alone); what is shared is
+// the instruction stream: one Delassus build with 12 columns (a lane's row only sees its own body) instead
+// of one 60-column build per island, one sweep loop whose row step serves four bodies.  Without
+// deactivation (the reference's most likely semantics) all four bodies of the scene are such islands in
+// most substeps.  The rows are set up by the solver lanes themselves (row_setup()'s arithmetic for a
+// body - table point, one row per lane): no Row records go through LDS for them.
+// lane S of the caller's own 16-lane group, to every lane of the group: ds_swizzle in bit mode (source lane =
+// (lane & 0x10) | S within each half of the wave) -- the LDS crossbar, no LDS memory, no trip through SGPRs
+template <int S_> RV_DEV float grp_bcast(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x10 | (S_ << 5)));
+}
+RV_DEV void solve_singles(Shared& S, const Consts& K, const int smask) {
+  DevEnv& e = S.e; const rv_config* c = K.cfg;
+  const int lane = (int)threadIdx.x;
+  const int b = lane >> 4, r = lane & 15;
+  const int rr = r < 12 ? r : 11;
+  const int p = rr / 3, k = rr - 3 * p;
+  DevMan& mm = e.man[RV_TIDX(b)];
+  const bool mine = ((smask >> b) & 1) != 0;
+  const int nt = mine ? mm.n : 0;                 // (uniform within the 16-lane group)
+  const bool act = r < 12 && p < nt;
+  // ---- this lane's row: row_setup() for a body - table point, row k only
+  J6 JX, PX;
+  JX.l = JX.a = PX.l = PX.a = mk(0, 0, 0);
+  float invk = 0.0f, bias = 0.0f, mu = 0.0f, lam = 0.0f, g = 0.0f;
+  const float cap = 1e30f;
+  if (act) {
+    const float dt = c->dt;
+    const v3 la = ld3(mm.la[p]), d0 = ld3(mm.nrm[p]);
+    const v3 wa = to_world_body(S, b, la);
+    const v3 ra = sub(wa, ld3(e.body[b]));
+    v3 d1, d2;
+    plane_space(d0, &d1, &d2);
+    const v3 vb_pt = mk(0.0f, 0.0f, 0.0f);
+    const m3 iia = ldm(S.s.iinv[b]);
+    const float ima = e.inv_mass[b];
+    const v3 dk = k == 0 ? d0 : (k == 1 ? d1 : d2);
+    const v3 rxa = cross(ra, dk);
+    const v3 aa = mulv(iia, rxa);
+    const float kk = ima + dot(rxa, aa);
+    invk = 1.0f / kk;
+    const float vbc = dot(dk, vb_pt);
+    const float dist = mm.dist[p];
+    float target;
+    if (dist > 0.0f) target = -dist / dt;
+    else target = fminr(c->erp * fmaxr(-dist - c->slop, 0.0f) / dt, c->max_pushout);
+    const float mub = body_below_table(e, c, b) ? c->ground_friction : e.mu_table;
+    mu = e.friction[b] * mub;
+    bias = k == 0 ? target : 0.0f;
+    // (the impulses kept from the last substep, scaled as the row-setup phase scales them)
+    lam = (k == 0 ? mm.ln[p] : (k == 1 ? mm.lt1[p] : mm.lt2[p])) * c->warmstart;
+    g = dot(dk, ld3(e.body[b] + 7)) + dot(rxa, ld3(e.body[b] + 10));
+    JX.l = dk; JX.a = rxa; PX.l = scale(dk, ima); PX.a = aa;
+    g -= vbc;
+  }
+  RV_PROF(25)
+  // ---- Delassus rows: what a unit impulse on row s of the SAME body does to this lane's row.  The P
+  // vectors go through LDS (the hull-vertex scratch is dead here): a lane reads the 12 of its group
+  float* cb = &S.s.u.r.wv[0][0][0][0];
+  {
+    float* o = cb + 8 * lane;
+    o[0] = PX.l.x; o[1] = PX.l.y; o[2] = PX.l.z; o[3] = PX.a.x; o[4] = PX.a.y; o[5] = PX.a.z;
+  }
+  __syncthreads();
+  float A[12];
+#pragma unroll
+  for (int s = 0; s < 12; ++s) {
+    const float* q = cb + 8 * (16 * b + s);
+    A[s] = dotj(JX, mk(q[0], q[1], q[2]), mk(q[3], q[4], q[5]));
+  }
+  __syncthreads();          // (cb is written again by the epilogue)
+  // warm start, in visiting order; lam of the rows of this lane's body through per-group broadcasts
+  const int n0 = __builtin_amdgcn_readlane(nt, 0), n1 = __builtin_amdgcn_readlane(nt, 16),
+            n2 = __builtin_amdgcn_readlane(nt, 32), n3 = __builtin_amdgcn_readlane(nt, 48);
+  int nmax = n0 > n1 ? n0 : n1; nmax = nmax > n2 ? nmax : n2; nmax = nmax > n3 ? nmax : n3;
+  {
+    float ls[12];
+#define RV_WS(s_) ls[s_] = grp_bcast<s_>(lam);
+    RV_WS(0) RV_WS(1) RV_WS(2) RV_WS(3) RV_WS(4) RV_WS(5) RV_WS(6) RV_WS(7) RV_WS(8) RV_WS(9) RV_WS(10) RV_WS(11)
+#undef RV_WS
+#pragma unroll
+    for (int s = 0; s < 12; ++s) if (s / 3 < nt) g = g + A[s] * ls[s];
+  }
+  RV_PROF(26)
+  const int iters = c->solver_iters; const float tol = c->solver_tol;
+  const int toli = __builtin_bit_cast(int, tol);
+  const int stall = c->solver_stall;
+  int best0 = 0x7f800000, best1 = 0x7f800000, best2 = 0x7f800000, best3 = 0x7f800000;
+  int since0 = 0, since1 = 0, since2 = 0, since3 = 0;
+  // done: bit g = island g has stopped (or has no rows at all)
+  int done = (n0 == 0 ? 1 : 0) | (n1 == 0 ? 2 : 0) | (n2 == 0 ? 4 : 0) | (n3 == 0 ? 8 : 0);
+  for (int it = 0; it < iters && done != 15; ++it) {
+    // (the rows of an island that has stopped are made inert: with a zero effective mass a row step returns
+    // the impulse it holds, d = 0)
+    const bool alive = act && !((done >> b) & 1);
+    const float invk_e = alive ? invk : 0.0f;
+    int resv = 0;              // largest |d| of this lane's island in this sweep (bit pattern)
+#define RV_ROW_STEP(pp_, kk_) { \
+      constexpr int s_ = 3 * pp_ + kk_; \
+      float nl; \
+      if (kk_ == 0) nl = __builtin_amdgcn_fmed3f(lam + (bias - g) * invk_e, 0.0f, cap); \
+      else nl = __builtin_amdgcn_fmed3f(lam + (-g * invk_e), -lim, lim); \
+      const float d = nl - lam; \
+      if (r == s_ && alive) lam = nl; \
+      const float sd = grp_bcast<s_>(d); \
+      if (kk_ == 0) lim = grp_bcast<s_>(mu * nl); \
+      const int mag = __builtin_bit_cast(int, sd) & 0x7fffffff; \
+      resv = resv > mag ? resv : mag; \
+      if (pp_ < nt) g = g + A[s_] * sd; }
+#define RV_POINT(pp_) if (pp_ < nmax) { float lim = 0.0f; RV_ROW_STEP(pp_, 0) RV_ROW_STEP(pp_, 1) RV_ROW_STEP(pp_, 2) }
+    RV_POINT(0) RV_POINT(1) RV_POINT(2) RV_POINT(3)
+#undef RV_POINT
+#undef RV_ROW_STEP
+    const int res0 = __builtin_amdgcn_readlane(resv, 0), res1 = __builtin_amdgcn_readlane(resv, 16),
+              res2 = __builtin_amdgcn_readlane(resv, 32), res3 = __builtin_amdgcn_readlane(resv, 48);
+    // every island stops on its own residual / stall count
+    if (tol > 0.0f) done |= (res0 < toli ? 1 : 0) | (res1 < toli ? 2 : 0) | (res2 < toli ? 4 : 0) | (res3 < toli ? 8 : 0);
+    if (stall > 0) {
+      if (!(done & 1)) { if (res0 < best0) { best0 = res0; since0 = 0; } else if (++since0 >= stall) done |= 1; }
+      if (!(done & 2)) { if (res1 < best1) { best1 = res1; since1 = 0; } else if (++since1 >= stall) done |= 2; }
+      if (!(done & 4)) { if (res2 < best2) { best2 = res2; since2 = 0; } else if (++since2 >= stall) done |= 4; }
+      if (!(done & 8)) { if (res3 < best3) { best3 = res3; since3 = 0; } else if (++since3 >= stall) done |= 8; }
+    }
+  }
+  RV_PROF(27)
+  // impulses back to the manifolds; the body velocities are rebuilt in row order through LDS
+  if (act) { if (k == 0) mm.ln[p] = lam; else if (k == 1) mm.lt1[p] = lam; else mm.lt2[p] = lam; }
+  {
+    float* o = cb + 8 * lane;
+    o[0] = PX.l.x * lam; o[1] = PX.l.y * lam; o[2] = PX.l.z * lam; o[3] = PX.a.x * lam; o[4] = PX.a.y * lam; o[5] = PX.a.z * lam;
+  }
+  __syncthreads();
+  if (r < 6 && nt > 0) {
+    float acc = e.body[b][7 + r];
+    float t[12];
+#pragma unroll
+    for (int s = 0; s < 12; ++s) t[s] = cb[8 * (16 * b + s) + r];
+#pragma unroll
+    for (int s = 0; s < 12; ++s) acc = acc + t[s];
+    acc = acc + 0.0f;        // (solve_island2 also adds the twelve -- empty -- arm rows: +0.0 each)
+    e.body[b][7 + r] = acc;
+  }
+  __syncthreads();
+}
 // The force-limited gripper in impulse space (rv_config.finger_dynamics; at most one awake body X, or
 // none: X < 0).  Layout: lanes 0..23 the rows of X (table points 0..3, arm points 0..3, x 3 rows), lanes
 // 24 / 25 the POSITION_CONTROL motor rows of the two finger joints (bullet_physics.py:1061-1104).  The
@@ -3377,44 +3524,6 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
 
   RV_STOP(3)
   RV_PROF(3)
-  // solver row setup (one lane per contact point) + contact flags
-  RV_LANES_BEGIN
-    DevEnv& e = S.e;
-    if (lane < RV_NMAN * 4) {
-      int mi = lane >> 2, i = lane & 3;
-      DevMan& m = e.man[mi];
-      int kind, a, b = -1;
-      if (mi < RV_MAXB) { kind = 0; a = mi; }
-      else if (mi < RV_MAXB + RV_NBB) { kind = 1; a = bb_a(mi - RV_MAXB); b = bb_b(mi - RV_MAXB); }
-      else { kind = 2; a = mi - RV_MAXB - RV_NBB; }
-      int use = body_on(e, a) && (kind != 1 || body_on(e, b));
-      if (use && i < m.n) {
-        ManPoint p;
-        p.la = ld3(m.la[i]); p.lb = ld3(m.lb[i]); p.nrm = ld3(m.nrm[i]); p.dist = m.dist[i]; p.col = m.col[i];
-        p.ln = m.ln[i]; p.lt1 = m.lt1[i]; p.lt2 = m.lt2[i];
-        Row r;
-        row_setup(S, K, kind, a, b, p, r, m.n);
-        S.s.u.r.rows[mi][i] = r;
-        m.ln[i] = p.ln * c->warmstart; m.lt1[i] = p.lt1 * c->warmstart; m.lt2[i] = p.lt2 * c->warmstart;
-      }
-    } else if (lane == 61) {
-      e.pairs_last += S.s.pairs[0] + S.s.pairs[1] + S.s.pairs[2] + S.s.pairs[3];
-    } else if (lane == 56) {
-      int f = 0;
-      if (arm_on) for (int col = 0; col < RV_NCOL; ++col) f |= S.s.colflag[col];
-      e.flag_arm_table = f;
-    } else if (lane >= 57 && lane < 57 + RV_MAXB) {
-      int b = lane - 57; int f = 0;
-      if (arm_on) {
-        const DevMan& m = e.man[RV_AIDX(b)];
-        for (int i = 0; i < m.n; ++i) if (m.dist[i] < c->contact_query_dist) f = 1;
-      }
-      e.flag_arm_body[b] = f;
-    }
-  RV_LANES_END
-
-  RV_STOP(4)
-  RV_PROF(4)
   // PGS over islands: awake bodies coupled (transitively) by body-body manifolds
   // that hold points.  Every island stops on its own residual.  All rows of the env are
   // solved by the whole wave in impulse space, one lane per row (solve_rows above).
@@ -3479,6 +3588,55 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   // one awake body at most and no user constraint: impulse space, one lane per row, with the finger / limb
   // DOFs and their motor rows; else the velocity-space system solver
   const int fing_fast = (with_fingers || limb) && n_on <= 1 && !any_con;
+  // islands that are one body on the table and nothing else are set up and solved together by
+  // solve_singles(): their rows never go through the Row records
+  int smask = 0;
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+  if (!with_fingers && !any_con && !limb) {
+#pragma unroll
+    for (int b = 0; b < RV_MAXB; ++b) if (on_[b] && mem_[b] == 1 && S.e.man[RV_AIDX(b)].n == 0) smask |= 1 << b;
+    smask = __builtin_amdgcn_readfirstlane(smask);
+  }
+#endif
+  // solver row setup (one lane per contact point) + contact flags
+  RV_LANES_BEGIN
+    DevEnv& e = S.e;
+    if (lane < RV_NMAN * 4) {
+      int mi = lane >> 2, i = lane & 3;
+      DevMan& m = e.man[mi];
+      int kind, a, b = -1;
+      if (mi < RV_MAXB) { kind = 0; a = mi; }
+      else if (mi < RV_MAXB + RV_NBB) { kind = 1; a = bb_a(mi - RV_MAXB); b = bb_b(mi - RV_MAXB); }
+      else { kind = 2; a = mi - RV_MAXB - RV_NBB; }
+      int use = body_on(e, a) && (kind != 1 || body_on(e, b));
+      if (mi < RV_MAXB && ((smask >> mi) & 1)) use = 0;      // (set up by its solver lanes)
+      if (use && i < m.n) {
+        ManPoint p;
+        p.la = ld3(m.la[i]); p.lb = ld3(m.lb[i]); p.nrm = ld3(m.nrm[i]); p.dist = m.dist[i]; p.col = m.col[i];
+        p.ln = m.ln[i]; p.lt1 = m.lt1[i]; p.lt2 = m.lt2[i];
+        Row r;
+        row_setup(S, K, kind, a, b, p, r, m.n);
+        S.s.u.r.rows[mi][i] = r;
+        m.ln[i] = p.ln * c->warmstart; m.lt1[i] = p.lt1 * c->warmstart; m.lt2[i] = p.lt2 * c->warmstart;
+      }
+    } else if (lane == 61) {
+      e.pairs_last += S.s.pairs[0] + S.s.pairs[1] + S.s.pairs[2] + S.s.pairs[3];
+    } else if (lane == 56) {
+      int f = 0;
+      if (arm_on) for (int col = 0; col < RV_NCOL; ++col) f |= S.s.colflag[col];
+      e.flag_arm_table = f;
+    } else if (lane >= 57 && lane < 57 + RV_MAXB) {
+      int b = lane - 57; int f = 0;
+      if (arm_on) {
+        const DevMan& m = e.man[RV_AIDX(b)];
+        for (int i = 0; i < m.n; ++i) if (m.dist[i] < c->contact_query_dist) f = 1;
+      }
+      e.flag_arm_body[b] = f;
+    }
+  RV_LANES_END
+
+  RV_STOP(4)
+  RV_PROF(4)
   any_con |= limb;
   if (limb) limb_prepare(S, K);
   if (((with_fingers || limb) && !fing_fast) || (any_con && !limb)) {
@@ -3504,8 +3662,10 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       for (int kk = 0; kk < RV_NBB; ++kk) if (bb_a(kk) == b && bb_b(kk) == y_) kxy = kk;
       isl_y[b] = mem_[b] == 2 ? y_ : -1; isl_k[b] = mem_[b] == 2 ? kxy : 0;
     }
+    if (smask) solve_singles(S, K, smask);
 #pragma nounroll
     for (int b = 0; b < RV_MAXB; ++b) {
+      if ((smask >> b) & 1) continue;
       int m_ = 0, y_ = -1, kxy = 0;
 #pragma unroll
       for (int x = 0; x < RV_MAXB; ++x) if (x == b) { m_ = mem_[x]; y_ = isl_y[x]; kxy = isl_k[x]; }
