@@ -171,7 +171,9 @@ struct Scratch {
   // scratch for the velocity update)
   struct {
     struct {
-      Row rows[RV_NMAN][4];
+#if !defined(__HIPCC__) || defined(RV_EMULATE)
+      Row rows[RV_NMAN][4];      // host emulation only: on the device every solver sets its rows up in registers
+#endif
       float wv[RV_MAXB][RV_MAXH][RV_MAXV][3];
     } r;
   } u;
@@ -941,7 +943,10 @@ RV_DEV void owner_decode(const Shared& S, const Consts& K, int owner, int arm_on
 }
 
 // ------------------------------------------------------------------ PGS --
-RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, const ManPoint& p, Row& r, const int n_pts) {
+// ONE solver row of a contact point (k = 0 the normal row, 1 / 2 the friction rows): everything the solvers
+// need of it.  row_setup() below is three calls of this; the lane-per-row solvers call it for their own row.
+struct RowK { v3 dir, rxa, rxb, aa, ab; float invk, vbc, target, mu, jf, cap; int fidx; };
+RV_DEV void row_setup_k(const Shared& S, const Consts& K, int kind, int a, int b, const ManPoint& p, const int k, const int n_pts, RowK& o) {
   const rv_config* c = K.cfg; const DevEnv& e = S.e;
   float dt = c->dt;
   v3 wa, wb;
@@ -963,8 +968,7 @@ RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, 
   const int fing = c->finger_dynamics && kind == 2 && p.col >= 8;
   const v3 fy = mk(S.s.frot[7][1], S.s.frot[7][4], S.s.frot[7][7]);   // slide axis = hand y
   float ima = e.inv_mass[a];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  {
     v3 dk = k == 0 ? d0 : (k == 1 ? d1 : d2);
     v3 rxa = cross(ra, dk);
     v3 aa = mulv(iia, rxa);
@@ -977,15 +981,15 @@ RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, 
     }
     float jf = 0.0f;
     if (fing) { jf = -dot(dk, fy); kk += jf * jf / c->finger_mass; }
-    st3(r.dir[k], dk); st3(r.rxa[k], rxa); st3(r.aa[k], aa); st3(r.rxb[k], rxb); st3(r.ab[k], ab);
-    r.invk[k] = 1.0f / kk;
-    r.vbc[k] = dot(dk, vb_pt);
-    r.jf[k] = jf;
+    o.dir = dk; o.rxa = rxa; o.aa = aa; o.rxb = rxb; o.ab = ab;
+    o.invk = 1.0f / kk;
+    o.vbc = dot(dk, vb_pt);
+    o.jf = jf;
   }
-  r.fidx = fing ? p.col - 8 : -1;
+  o.fidx = fing ? p.col - 8 : -1;
   // what the arm can push with along the normal: min over the joints upstream of the collider of
   // tau_j / |J_j . n| (J_j = axis_j x (p - p_j); a finger pad also slides along the hand's y)
-  r.cap = 1e30f;
+  o.cap = 1e30f;
   if (kind == 2 && c->arm_effort_limit) {
     const rv_arm* arm = K.arm;
     const int f = arm->col_frame[p.col];
@@ -999,13 +1003,49 @@ RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, 
     }
     if (f >= 8 && !c->finger_dynamics) worst = fmaxr(worst, fabsr(dot(fy, d0)) * arm->inv_tau_max[f - 1]);
     // (the budget is shared equally by the points of the manifold)
-    if (worst > 0.0f) r.cap = dt / (worst * (float)n_pts);
+    if (worst > 0.0f) o.cap = dt / (worst * (float)n_pts);
   }
   float dist = p.dist;
-  if (dist > 0.0f) r.target = -dist / dt;
-  else r.target = fminr(c->erp * fmaxr(-dist - c->slop, 0.0f) / dt, c->max_pushout);
+  if (dist > 0.0f) o.target = -dist / dt;
+  else o.target = fminr(c->erp * fmaxr(-dist - c->slop, 0.0f) / dt, c->max_pushout);
   float mub = (kind == 0) ? (body_below_table(e, c, a) ? c->ground_friction : e.mu_table) : (kind == 1 ? e.friction[b] : (p.col >= 8 ? e.mu_finger : c->arm_friction));
-  r.mu = e.friction[a] * mub;
+  o.mu = e.friction[a] * mub;
+}
+RV_DEV void row_setup(const Shared& S, const Consts& K, int kind, int a, int b, const ManPoint& p, Row& r, const int n_pts) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    RowK o;
+    row_setup_k(S, K, kind, a, b, p, k, n_pts, o);
+    st3(r.dir[k], o.dir); st3(r.rxa[k], o.rxa); st3(r.aa[k], o.aa); st3(r.rxb[k], o.rxb); st3(r.ab[k], o.ab);
+    r.invk[k] = o.invk; r.vbc[k] = o.vbc; r.jf[k] = o.jf;
+    r.fidx = o.fidx; r.cap = o.cap; r.target = o.target; r.mu = o.mu;
+  }
+}
+
+// kind / bodies of manifold slot mi
+RV_DEV void man_owner(int mi, int* kind, int* a, int* b) {
+  if (mi < RV_MAXB) { *kind = 0; *a = mi; *b = -1; }
+  else if (mi < RV_MAXB + RV_NBB) { *kind = 1; *a = bb_a(mi - RV_MAXB); *b = bb_b(mi - RV_MAXB); }
+  else { *kind = 2; *a = mi - RV_MAXB - RV_NBB; *b = -1; }
+}
+// The Row of manifold point (mi, i) for the one-lane system solver.  Host emulation: the record the
+// row-setup phase left in LDS.  Device: no Row records exist (they were 13 KB of the env's LDS block, and
+// every lane-per-row solver sets its rows up in registers): the rare serial path recomputes the row --
+// row_setup() of the same inputs, so the same values -- each time it visits the point.
+RV_DEV Row fetch_row(const Shared& S, const Consts& K, int mi, int i) {
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+  int kind, a, b;
+  man_owner(mi, &kind, &a, &b);
+  const DevMan& m = S.e.man[mi];
+  ManPoint pt;
+  pt.la = ld3(m.la[i]); pt.lb = ld3(m.lb[i]); pt.nrm = ld3(m.nrm[i]); pt.dist = m.dist[i]; pt.col = m.col[i];
+  Row r;
+  row_setup(S, K, kind, a, b, pt, r, m.n);
+  return r;
+#else
+  (void)K;
+  return S.s.u.r.rows[mi][i];
+#endif
 }
 
 // body velocity pair held in registers by the solving lane
@@ -1142,8 +1182,11 @@ RV_DEV void limb_prepare(Shared& S, const Consts& K) {
       if (body_on(e, b) && i < m.n) {
         const int f = arm->col_frame[m.col[i]], fl = f < RV_NLIMB ? f : RV_NLIMB - 1;
         const v3 wb = to_world_frame(S, f, ld3(m.lb[i]));
-        const Row& r = S.s.u.r.rows[RV_AIDX(b)][i];
-        const v3 dk = ld3(r.dir[k]);
+        ManPoint pt;
+        pt.la = ld3(m.la[i]); pt.lb = ld3(m.lb[i]); pt.nrm = ld3(m.nrm[i]); pt.dist = m.dist[i]; pt.col = m.col[i];
+        RowK r;
+        row_setup_k(S, K, 2, b, -1, pt, k, m.n, r);       // (the row as the solver sets it up)
+        const v3 dk = r.dir;
         float ja[RV_NLIMB];
 #pragma unroll
         for (int j = 0; j < RV_NLIMB; ++j) {
@@ -1151,7 +1194,7 @@ RV_DEV void limb_prepare(Shared& S, const Consts& K) {
           ja[j] = j <= fl ? -dot(dk, lever) : 0.0f;
           S.s.lJa[row][j] = ja[j];
         }
-        float kk = 1.0f / r.invk[k];
+        float kk = 1.0f / r.invk;
         float mij[RV_NLIMB];
 #pragma unroll
         for (int j = 0; j < RV_NLIMB; ++j) {
@@ -1273,7 +1316,7 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb) {
         const int mi = kind == 0 ? RV_TIDX(b) : RV_AIDX(b);
         DevMan& m = e.man[mi];
         for (int i = 0; i < m.n; ++i) {
-          Row r = S.s.u.r.rows[mi][i];
+          Row r = fetch_row(S, K, mi, i);
           Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
           const int la = limb && kind == 1, lrow = b * 12 + i * 3;
           if (it < 0) {
@@ -1298,7 +1341,7 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb) {
         BV A = ld_bv(e, a_), B = ld_bv(e, b_);
         const float ima = e.inv_mass[a_], imb = e.inv_mass[b_];
         for (int i = 0; i < m.n; ++i) {
-          Row r = S.s.u.r.rows[RV_BBIDX(k)][i];
+          Row r = fetch_row(S, K, RV_BBIDX(k), i);
           Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
           if (it < 0) warm_apply(A, &B, ima, imb, l, r);
           else { res = fmaxr(res, point_solve(A, &B, ima, imb, l, r)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
@@ -1435,42 +1478,59 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
   const int Yc = Y >= 0 ? Y : X;
   const int mi = blk == 0 ? (p < 4 ? RV_TIDX(X) : RV_AIDX(X)) : (blk == 1 ? (p < 4 ? RV_TIDX(Yc) : RV_AIDX(Yc)) : RV_BBIDX(kxy));
   const bool act = lane < 60 && isl_row_on(L, ntx, nax, nty, nay, nxy);
-  const Row& R = S.s.u.r.rows[mi][slot];
   DevMan& mm = e.man[mi];
   J6 JX, JY, PX, PY;
   JX.l = JX.a = JY.l = JY.a = PX.l = PX.a = PY.l = PY.a = mk(0, 0, 0);
   float invk = 0.0f, bias = 0.0f, mu = 0.0f, lam = 0.0f, g = 0.0f, cap = 1e30f;
   if (act) {
-    const v3 dir = ld3(R.dir[k]), rxa = ld3(R.rxa[k]);
-    invk = R.invk[k]; mu = R.mu; bias = k == 0 ? R.target : 0.0f; cap = R.cap;
-    lam = k == 0 ? mm.ln[slot] : (k == 1 ? mm.lt1[slot] : mm.lt2[slot]);
+    // this lane's row, set up by the lane itself (row_setup_k: the arithmetic of the row-setup phase)
+    const int kind = blk == 2 ? 1 : (p < 4 ? 0 : 2);
     const int ba = blk == 1 ? Yc : X;          // body a of the row's manifold
+    ManPoint pt;
+    pt.la = ld3(mm.la[slot]); pt.lb = ld3(mm.lb[slot]); pt.nrm = ld3(mm.nrm[slot]); pt.dist = mm.dist[slot]; pt.col = mm.col[slot];
+    RowK o;
+    row_setup_k(S, K, kind, ba, blk == 2 ? Yc : -1, pt, k, mm.n, o);
+    const v3 dir = o.dir, rxa = o.rxa;
+    invk = o.invk; mu = o.mu; bias = k == 0 ? o.target : 0.0f; cap = o.cap;
+    // (the impulses kept from the last substep, scaled as the row-setup phase scales them)
+    lam = (k == 0 ? mm.ln[slot] : (k == 1 ? mm.lt1[slot] : mm.lt2[slot])) * c->warmstart;
     g = dot(dir, ld3(e.body[ba] + 7)) + dot(rxa, ld3(e.body[ba] + 10));
-    const v3 pl = scale(dir, e.inv_mass[ba]), pa = ld3(R.aa[k]);
-    if (blk == 0) { JX.l = dir; JX.a = rxa; PX.l = pl; PX.a = pa; g -= R.vbc[k]; }
-    else if (blk == 1) { JY.l = dir; JY.a = rxa; PY.l = pl; PY.a = pa; g -= R.vbc[k]; }
+    const v3 pl = scale(dir, e.inv_mass[ba]), pa = o.aa;
+    if (blk == 0) { JX.l = dir; JX.a = rxa; PX.l = pl; PX.a = pa; g -= o.vbc; }
+    else if (blk == 1) { JY.l = dir; JY.a = rxa; PY.l = pl; PY.a = pa; g -= o.vbc; }
     else {
-      const v3 rxb = ld3(R.rxb[k]);
+      const v3 rxb = o.rxb;
       g -= dot(dir, ld3(e.body[Yc] + 7)) + dot(rxb, ld3(e.body[Yc] + 10));
       JX.l = dir; JX.a = rxa; PX.l = pl; PX.a = pa;
       JY.l = mk(-dir.x, -dir.y, -dir.z); JY.a = mk(-rxb.x, -rxb.y, -rxb.z);
-      const v3 t = scale(dir, e.inv_mass[Yc]), ab = ld3(R.ab[k]);
+      const v3 t = scale(dir, e.inv_mass[Yc]), ab = o.ab;
       PY.l = mk(-t.x, -t.y, -t.z); PY.a = mk(-ab.x, -ab.y, -ab.z);
     }
   }
   RV_PROF(25)
-  // this lane's row of the Delassus matrix
+  // this lane's row of the Delassus matrix.  The P vectors of all rows go through LDS (the hull-vertex
+  // scratch is dead here): every lane reads the same address -- a broadcast -- instead of six v_readlane
+  // trips through the scalar unit per column
+  float* cb = &S.s.u.r.wv[0][0][0][0];
+  if (lane < 60) {
+    float* o = cb + 12 * lane;
+    o[0] = PX.l.x; o[1] = PX.l.y; o[2] = PX.l.z; o[3] = PX.a.x; o[4] = PX.a.y; o[5] = PX.a.z;
+    o[6] = PY.l.x; o[7] = PY.l.y; o[8] = PY.l.z; o[9] = PY.a.x; o[10] = PY.a.y; o[11] = PY.a.z;
+  }
+  __syncthreads();
   float A[60];
 #pragma unroll
   for (int s = 0; s < 60; ++s) {
     float a_ = 0.0f;
     if ((s < 24 || Y >= 0) && isl_row_on(s, ntx, nax, nty, nay, nxy)) {
-      if (s < 24) a_ = dotj(JX, rdlane3(PX.l, s), rdlane3(PX.a, s));
-      else if (s < 48) a_ = dotj(JY, rdlane3(PY.l, s), rdlane3(PY.a, s));
-      else a_ = dotj(JX, rdlane3(PX.l, s), rdlane3(PX.a, s)) + dotj(JY, rdlane3(PY.l, s), rdlane3(PY.a, s));
+      const float* q = cb + 12 * s;
+      if (s < 24) a_ = dotj(JX, mk(q[0], q[1], q[2]), mk(q[3], q[4], q[5]));
+      else if (s < 48) a_ = dotj(JY, mk(q[6], q[7], q[8]), mk(q[9], q[10], q[11]));
+      else a_ = dotj(JX, mk(q[0], q[1], q[2]), mk(q[3], q[4], q[5])) + dotj(JY, mk(q[6], q[7], q[8]), mk(q[9], q[10], q[11]));
     }
     A[s] = a_;
   }
+  __syncthreads();          // (cb is written again by the epilogue)
   // warm start: the impulses kept from the last substep act first, in visiting order (X and Y slot
   // by slot, then the pair manifold)
 #pragma unroll
@@ -1565,7 +1625,6 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
   RV_PROF(27)
   // impulses back to the manifolds; what every row adds to X and Y goes through LDS (the hull-vertex
   // scratch is dead here), one lane per velocity component sums it in row order
-  float* cb = &S.s.u.r.wv[0][0][0][0];
   if (act) { if (k == 0) mm.ln[slot] = lam; else if (k == 1) mm.lt1[slot] = lam; else mm.lt2[slot] = lam; }
   if (lane < 60) {
     // (rows that are off hold lam = 0 and zero P: they write zeros, which the sums below may add)
@@ -1695,21 +1754,32 @@ RV_DEV void solve_singles(Shared& S, const Consts& K, const int smask) {
     const bool alive = act && !((done >> b) & 1);
     const float invk_e = alive ? invk : 0.0f;
     int resv = 0;              // largest |d| of this lane's island in this sweep (bit pattern)
-#define RV_ROW_STEP(pp_, kk_) { \
+    // One island left (a single body sliding on: the usual case with deactivation): its rows are broadcast
+    // with v_readlane at a wave-uniform lane index -- half the latency of the LDS crossbar.  (The lanes of the
+    // other groups see its values too; their rows are inert and their g is dead.)
+    const int alive_mask = (~done) & 15;
+    const bool one = (alive_mask & (alive_mask - 1)) == 0;
+    const int base = alive_mask == 1 ? 0 : (alive_mask == 2 ? 16 : (alive_mask == 4 ? 32 : 48));
+#define RV_ROW_STEP(pp_, kk_, BC_) { \
       constexpr int s_ = 3 * pp_ + kk_; \
       float nl; \
       if (kk_ == 0) nl = __builtin_amdgcn_fmed3f(lam + (bias - g) * invk_e, 0.0f, cap); \
       else nl = __builtin_amdgcn_fmed3f(lam + (-g * invk_e), -lim, lim); \
       const float d = nl - lam; \
       if (r == s_ && alive) lam = nl; \
-      const float sd = grp_bcast<s_>(d); \
-      if (kk_ == 0) lim = grp_bcast<s_>(mu * nl); \
+      const float sd = BC_(d, s_); \
+      if (kk_ == 0) lim = BC_(mu * nl, s_); \
       const int mag = __builtin_bit_cast(int, sd) & 0x7fffffff; \
       resv = resv > mag ? resv : mag; \
-      if (pp_ < nt) g = g + A[s_] * sd; }
-#define RV_POINT(pp_) if (pp_ < nmax) { float lim = 0.0f; RV_ROW_STEP(pp_, 0) RV_ROW_STEP(pp_, 1) RV_ROW_STEP(pp_, 2) }
-    RV_POINT(0) RV_POINT(1) RV_POINT(2) RV_POINT(3)
+      if (pp_ < nt && alive) g = g + A[s_] * sd; }
+#define RV_BC_SWZ(x_, s_) grp_bcast<s_>(x_)
+#define RV_BC_RDL(x_, s_) rdlane(x_, base + s_)
+#define RV_POINT(pp_, BC_) if (pp_ < nmax) { float lim = 0.0f; RV_ROW_STEP(pp_, 0, BC_) RV_ROW_STEP(pp_, 1, BC_) RV_ROW_STEP(pp_, 2, BC_) }
+    if (one) { RV_POINT(0, RV_BC_RDL) RV_POINT(1, RV_BC_RDL) RV_POINT(2, RV_BC_RDL) RV_POINT(3, RV_BC_RDL) }
+    else { RV_POINT(0, RV_BC_SWZ) RV_POINT(1, RV_BC_SWZ) RV_POINT(2, RV_BC_SWZ) RV_POINT(3, RV_BC_SWZ) }
 #undef RV_POINT
+#undef RV_BC_SWZ
+#undef RV_BC_RDL
 #undef RV_ROW_STEP
     const int res0 = __builtin_amdgcn_readlane(resv, 0), res1 = __builtin_amdgcn_readlane(resv, 16),
               res2 = __builtin_amdgcn_readlane(resv, 32), res3 = __builtin_amdgcn_readlane(resv, 48);
@@ -1771,23 +1841,31 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
   const int lj = lmotor ? lane - 26 : 0;
   constexpr int NA = LIMB ? 26 + RV_NLIMB : 26, CS = LIMB ? 16 : 8;
   const int mid = lane == 25 ? 1 : 0;
-  const Row& R = S.s.u.r.rows[mi][slot];
   DevMan& mm = e.man[mi];
   J6 JX, PX;
   JX.l = JX.a = PX.l = PX.a = mk(0, 0, 0);
   float invk = 0.0f, bias = 0.0f, mu = 0.0f, lam = 0.0f, g = 0.0f, cap = 1e30f, jf = 0.0f, pf = 0.0f, lo = 0.0f, hi = 0.0f;
   int fi = -1;
   const float qf0a = e.qd[RV_NLIMB], qf0b = e.qd[RV_NLIMB + 1];
+  float row_invk = 0.0f;   // (1 / effective mass of the row before the limb terms: limb_prepare's input)
+  v3 row_dir = mk(0, 0, 0);
   if (act) {
-    const v3 dir = ld3(R.dir[k]), rxa = ld3(R.rxa[k]);
-    invk = R.invk[k]; mu = R.mu; bias = k == 0 ? R.target : 0.0f; cap = R.cap;
-    lam = k == 0 ? mm.ln[slot] : (k == 1 ? mm.lt1[slot] : mm.lt2[slot]);
+    // this lane's row, set up by the lane itself (row_setup_k: the arithmetic of the row-setup phase)
+    ManPoint pt;
+    pt.la = ld3(mm.la[slot]); pt.lb = ld3(mm.lb[slot]); pt.nrm = ld3(mm.nrm[slot]); pt.dist = mm.dist[slot]; pt.col = mm.col[slot];
+    RowK o;
+    row_setup_k(S, K, p < 4 ? 0 : 2, Xc, -1, pt, k, mm.n, o);
+    const v3 dir = o.dir, rxa = o.rxa;
+    invk = o.invk; mu = o.mu; bias = k == 0 ? o.target : 0.0f; cap = o.cap;
+    row_invk = o.invk; row_dir = dir;
+    lam = (k == 0 ? mm.ln[slot] : (k == 1 ? mm.lt1[slot] : mm.lt2[slot])) * c->warmstart;
     g = dot(dir, ld3(e.body[Xc] + 7)) + dot(rxa, ld3(e.body[Xc] + 10));
-    JX.l = dir; JX.a = rxa; PX.l = scale(dir, e.inv_mass[Xc]); PX.a = ld3(R.aa[k]);
-    g -= R.vbc[k];
-    fi = R.fidx;
-    if (fi >= 0) { jf = R.jf[k]; pf = jf * imf; g += jf * (fi == 0 ? qf0a : qf0b); }
+    JX.l = dir; JX.a = rxa; PX.l = scale(dir, e.inv_mass[Xc]); PX.a = o.aa;
+    g -= o.vbc;
+    fi = o.fidx;
+    if (fi >= 0) { jf = o.jf; pf = jf * imf; g += jf * (fi == 0 ? qf0a : qf0b); }
   }
+  (void)row_invk; (void)row_dir;
   if (motor) {
     const float i0 = mf * S.s.fing_dv[mid];
     g = (mid == 0 ? qf0a : qf0b) - S.s.fing_vt[mid]; invk = mf; jf = 1.0f; pf = imf; fi = mid;
@@ -3591,6 +3669,8 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   // islands that are one body on the table and nothing else are set up and solved together by
   // solve_singles(): their rows never go through the Row records
   int smask = 0;
+  const int rows_all = ((with_fingers || limb) && !fing_fast) || (any_con && !limb);
+  (void)rows_all;
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
   if (!with_fingers && !any_con && !limb) {
 #pragma unroll
@@ -3609,14 +3689,27 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       else if (mi < RV_MAXB + RV_NBB) { kind = 1; a = bb_a(mi - RV_MAXB); b = bb_b(mi - RV_MAXB); }
       else { kind = 2; a = mi - RV_MAXB - RV_NBB; }
       int use = body_on(e, a) && (kind != 1 || body_on(e, b));
-      if (mi < RV_MAXB && ((smask >> mi) & 1)) use = 0;      // (set up by its solver lanes)
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+      // the lane-per-row solvers (solve_singles, solve_island2) set their rows up themselves; Row records are
+      // for the velocity-space paths only: an island of three or four bodies, the one-lane system solver
+      // (and, for now, the finger / limb solver)
+      {
+        int big_a = 0;
+#pragma unroll
+        for (int x = 0; x < RV_MAXB; ++x) if (x == a) big_a = big_[label[x]];
+        (void)big_a;
+        if (!rows_all) use = 0;
+      }
+#endif
       if (use && i < m.n) {
         ManPoint p;
         p.la = ld3(m.la[i]); p.lb = ld3(m.lb[i]); p.nrm = ld3(m.nrm[i]); p.dist = m.dist[i]; p.col = m.col[i];
         p.ln = m.ln[i]; p.lt1 = m.lt1[i]; p.lt2 = m.lt2[i];
+#if !defined(__HIPCC__) || defined(RV_EMULATE)
         Row r;
         row_setup(S, K, kind, a, b, p, r, m.n);
         S.s.u.r.rows[mi][i] = r;
+#endif
         m.ln[i] = p.ln * c->warmstart; m.lt1[i] = p.lt1 * c->warmstart; m.lt2[i] = p.lt2 * c->warmstart;
       }
     } else if (lane == 61) {
@@ -3690,6 +3783,117 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
 #pragma unroll
   for (int b = RV_MAXB - 1; b >= 0; --b) if (big_[b]) big_root = b;
   RV_PROF(24)
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+  if (!with_fingers && !any_con && __builtin_amdgcn_readfirstlane(big_root) >= 0) {
+    // Device: no Row records in LDS.  Lane 4 mi + i sets up the row set of point i of manifold mi in its
+    // REGISTERS (row_setup(): what the row-setup phase computes) and scales the impulses kept from the last
+    // substep; the body / pair lanes of the sweep below pull the row sets they visit out of those lanes with
+    // ds_bpermute (the LDS crossbar: one instruction per word, any lane to any lane).
+    const int root = __builtin_amdgcn_readfirstlane(big_root);
+    const int lane = (int)threadIdx.x;
+    DevEnv& e = S.e;
+    Row my;
+    {
+      const int L = lane < RV_NMAN * 4 ? lane : RV_NMAN * 4 - 1;
+      const int mi = L >> 2, i = L & 3;
+      int kind, a, b;
+      man_owner(mi, &kind, &a, &b);
+      DevMan& m = e.man[mi];
+      int in_big = 0;
+#pragma unroll
+      for (int x = 0; x < RV_MAXB; ++x) if (x == a) in_big = on_[x] && label[x] == root;
+      const int use = lane < RV_NMAN * 4 && in_big && (kind != 1 || body_on(e, b)) && i < m.n;
+      ManPoint pt;
+      pt.la = ld3(m.la[i]); pt.lb = ld3(m.lb[i]); pt.nrm = ld3(m.nrm[i]); pt.dist = m.dist[i]; pt.col = m.col[i];
+      row_setup(S, K, kind, a, b, pt, my, m.n);          // (lanes without a point compute a row nobody asks for)
+      if (use) { m.ln[i] = m.ln[i] * c->warmstart; m.lt1[i] = m.lt1[i] * c->warmstart; m.lt2[i] = m.lt2[i] * c->warmstart; }
+    }
+    __syncthreads();
+    auto pull = [&](float x, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, x))); };
+    auto pull_row = [&](int src, bool pair) {
+      Row r;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          r.dir[k][x] = pull(my.dir[k][x], src); r.rxa[k][x] = pull(my.rxa[k][x], src); r.aa[k][x] = pull(my.aa[k][x], src);
+          if (pair) { r.rxb[k][x] = pull(my.rxb[k][x], src); r.ab[k][x] = pull(my.ab[k][x], src); } else { r.rxb[k][x] = 0.0f; r.ab[k][x] = 0.0f; }
+        }
+        r.invk[k] = pull(my.invk[k], src); r.vbc[k] = pull(my.vbc[k], src); r.jf[k] = 0.0f;
+      }
+      r.target = pull(my.target, src); r.mu = pull(my.mu, src); r.cap = pull(my.cap, src); r.fidx = -1;
+      return r;
+    };
+    float big_best = 1e30f; int big_since = 0;        // rv_config.solver_stall
+    const int iters = c->solver_iters;
+    for (int it = -1; it < iters; ++it) {             // it == -1: warm start
+      {
+        const int b = lane < RV_MAXB ? lane : 0;
+        int mine = 0;
+#pragma unroll
+        for (int x = 0; x < RV_MAXB; ++x) if (x == b) mine = on_[x] && label[x] == root;
+        const bool active = lane < RV_MAXB && mine;
+        float res = 0.0f;
+        BV A = ld_bv(e, b); const float ima = e.inv_mass[b];
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) {
+          const int mi = kind == 0 ? RV_TIDX(b) : RV_AIDX(b);
+          DevMan& m = e.man[mi];
+          const int mn = m.n;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool need = active && i < mn;
+            if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
+            const Row r = pull_row(need ? mi * 4 + i : lane, false);
+            if (need) {
+              Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
+              if (it < 0) warm_apply(A, nullptr, ima, 0.0f, l, r);
+              else { res = fmaxr(res, point_solve(A, nullptr, ima, 0.0f, l, r)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
+            }
+          }
+        }
+        if (active) st_bv(e, b, A);
+        if (lane < RV_MAXB) S.s.res[lane] = res;
+      }
+      __syncthreads();
+      for (int rd = 0; rd < 3; ++rd) {
+        const int x = lane < 2 ? lane : 0;
+        const int k = bb_round_pair(rd, x);
+        const int a_ = bb_a(k), b_ = bb_b(k);
+        int la_ = 0;
+#pragma unroll
+        for (int y = 0; y < RV_MAXB; ++y) if (y == a_) la_ = label[y];
+        DevMan& m = e.man[RV_BBIDX(k)];
+        const int mn = m.n;
+        const bool active = lane < 2 && body_on(e, a_) && body_on(e, b_) && la_ == root && mn != 0;
+        float res = 0.0f;
+        BV A = ld_bv(e, a_), B = ld_bv(e, b_);
+        const float ima = e.inv_mass[a_], imb = e.inv_mass[b_];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool need = active && i < mn;
+          if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
+          const Row r = pull_row(need ? RV_BBIDX(k) * 4 + i : lane, true);
+          if (need) {
+            Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
+            if (it < 0) warm_apply(A, &B, ima, imb, l, r);
+            else { res = fmaxr(res, point_solve(A, &B, ima, imb, l, r)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
+          }
+        }
+        if (active) { st_bv(e, a_, A); st_bv(e, b_, B); }
+        if (lane < 2) S.s.res[4 + 2 * rd + lane] = res;
+        __syncthreads();
+      }
+      float res = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 10; ++t) res = fmaxr(res, S.s.res[t]);
+      res = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, res)));
+      if (it >= 0 && res < c->solver_tol) break;
+      if (it >= 0 && c->solver_stall > 0) { if (res < big_best) { big_best = res; big_since = 0; } else if (++big_since >= c->solver_stall) break; }
+      __syncthreads();          // (S.s.res is written again by the next sweep)
+    }
+  }
+#else
   if (!with_fingers && !any_con && big_root >= 0) {
     const int root = big_root;
     float big_best = 1e30f; int big_since = 0;        // rv_config.solver_stall
@@ -3748,6 +3952,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     }
   }
 
+#endif
   RV_STOP(5)
   RV_PROF(5)
   // integrate positions, freeze fallen bodies, counters
