@@ -205,7 +205,10 @@ struct Scratch {
   float limb_dv[RV_NLIMB], limb_vt[RV_NLIMB], limb_qd0[RV_NLIMB];
   float lcom[RV_NLIMB + 1][3], lA[RV_NLIMB][2 * RV_NLIMB], lGq[RV_NLIMB];
   float llo[RV_NLIMB], lhi[RV_NLIMB], ltgt[RV_NLIMB];
-  float lJa[RV_MAXB * 12 + RV_NLIMB][RV_NLIMB], lMiJ[RV_MAXB * 12 + RV_NLIMB][RV_NLIMB], linvk[RV_MAXB * 12];   // (the last seven: the motor rows, e_j and column j of M^-1)
+  // (rows 0..11: the arm rows of the ONE awake body the lane-per-row solver handles; the last seven: the motor rows,
+  // e_j and column j of M^-1.  The one-lane system solver, which takes the cases with several awake bodies, derives
+  // the rows of a point when it visits it: limb_point_row)
+  float lJa[12 + RV_NLIMB][RV_NLIMB], lMiJ[12 + RV_NLIMB][RV_NLIMB], linvk[12];
   int jmoving[RV_NJ], jchg[RV_NJ];
   float rvec[RV_NLIMB + 1][3];           // FK: link offsets rotated into the world
   int jt_applied;                        // the motor targets hold the current joint target (per launch)
@@ -1120,7 +1123,37 @@ RV_DEV void warm_apply(BV& A, BV* B, float ima, float imb, const Lam& l, const R
 // with the solved velocity and the link frames are recomputed.
 // limb_prepare: wave-wide -- one lane per entry of M, per column of the Gauss-Jordan elimination of
 // [M | 1], per contact row; the Gauss-Seidel itself is the velocity-space system solver below.
-RV_DEV void limb_prepare(Shared& S, const Consts& K) {
+// row k of arm point i of body b in limb_dynamics mode: joint-space Jacobian ja, M^-1 ja^T, 1 / effective mass
+// (needs M^-1 in S.s.lA: limb_prepare)
+RV_DEV void limb_point_row(const Shared& S, const Consts& K, int b, int i, int k, float* ja, float* mij, float* invk_out) {
+  const DevEnv& e = S.e; const rv_arm* arm = K.arm;
+  const DevMan& m = e.man[RV_AIDX(b)];
+  const int f = arm->col_frame[m.col[i]], fl = f < RV_NLIMB ? f : RV_NLIMB - 1;
+  const v3 wb = to_world_frame(S, f, ld3(m.lb[i]));
+  ManPoint pt;
+  pt.la = ld3(m.la[i]); pt.lb = ld3(m.lb[i]); pt.nrm = ld3(m.nrm[i]); pt.dist = m.dist[i]; pt.col = m.col[i];
+  RowK r;
+  row_setup_k(S, K, 2, b, -1, pt, k, m.n, r);       // (the row as the solver sets it up)
+  const v3 dk = r.dir;
+#pragma unroll
+  for (int j = 0; j < RV_NLIMB; ++j) {
+    const v3 lever = cross(ld3(S.s.axis[j]), sub(wb, ld3(e.fpos[j])));
+    ja[j] = j <= fl ? -dot(dk, lever) : 0.0f;
+  }
+  float kk = 1.0f / r.invk;
+#pragma unroll
+  for (int j = 0; j < RV_NLIMB; ++j) {
+    float a_ = 0.0f;
+#pragma unroll
+    for (int x = 0; x < RV_NLIMB; ++x) a_ = a_ + S.s.lA[j][RV_NLIMB + x] * ja[x];
+    mij[j] = a_;
+  }
+#pragma unroll
+  for (int j = 0; j < RV_NLIMB; ++j) kk = kk + ja[j] * mij[j];
+  *invk_out = 1.0f / kk;
+}
+// lbody: the one awake body whose arm rows the lane-per-row solver will want (-1: none)
+RV_DEV void limb_prepare(Shared& S, const Consts& K, const int lbody) {
   const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
   RV_LANES_BEGIN
     if (lane <= RV_NLIMB) st3(S.s.lcom[lane], add(ld3(S.e.fpos[lane]), mulv(S.s.frot[lane], ld3(arm->link_com[lane]))));
@@ -1175,37 +1208,16 @@ RV_DEV void limb_prepare(Shared& S, const Consts& K) {
       S.s.llo[j] = fminr(0.0f, -tdt - hold); S.s.lhi[j] = fmaxr(0.0f, tdt - hold);
       S.s.ltgt[j] = S.s.limb_vt[j] - S.s.limb_qd0[j];
 #pragma unroll
-      for (int x = 0; x < RV_NLIMB; ++x) { S.s.lJa[RV_MAXB * 12 + j][x] = x == j ? 1.0f : 0.0f; S.s.lMiJ[RV_MAXB * 12 + j][x] = S.s.lA[x][RV_NLIMB + j]; }
-    } else if (lane >= 8 && lane < 8 + RV_MAXB * 12) {
-      const int row = lane - 8, b = row / 12, i = (row - b * 12) / 3, k = row - b * 12 - i * 3;
+      for (int x = 0; x < RV_NLIMB; ++x) { S.s.lJa[12 + j][x] = x == j ? 1.0f : 0.0f; S.s.lMiJ[12 + j][x] = S.s.lA[x][RV_NLIMB + j]; }
+    } else if (lbody >= 0 && lane >= 8 && lane < 8 + 12) {
+      const int row = lane - 8, b = lbody, i = row / 3, k = row - i * 3;
       const DevMan& m = e.man[RV_AIDX(b)];
       if (body_on(e, b) && i < m.n) {
-        const int f = arm->col_frame[m.col[i]], fl = f < RV_NLIMB ? f : RV_NLIMB - 1;
-        const v3 wb = to_world_frame(S, f, ld3(m.lb[i]));
-        ManPoint pt;
-        pt.la = ld3(m.la[i]); pt.lb = ld3(m.lb[i]); pt.nrm = ld3(m.nrm[i]); pt.dist = m.dist[i]; pt.col = m.col[i];
-        RowK r;
-        row_setup_k(S, K, 2, b, -1, pt, k, m.n, r);       // (the row as the solver sets it up)
-        const v3 dk = r.dir;
-        float ja[RV_NLIMB];
+        float ja[RV_NLIMB], mij[RV_NLIMB], ik;
+        limb_point_row(S, K, b, i, k, ja, mij, &ik);
 #pragma unroll
-        for (int j = 0; j < RV_NLIMB; ++j) {
-          const v3 lever = cross(ld3(S.s.axis[j]), sub(wb, ld3(e.fpos[j])));
-          ja[j] = j <= fl ? -dot(dk, lever) : 0.0f;
-          S.s.lJa[row][j] = ja[j];
-        }
-        float kk = 1.0f / r.invk;
-        float mij[RV_NLIMB];
-#pragma unroll
-        for (int j = 0; j < RV_NLIMB; ++j) {
-          float a_ = 0.0f;
-#pragma unroll
-          for (int x = 0; x < RV_NLIMB; ++x) a_ = a_ + S.s.lA[j][RV_NLIMB + x] * ja[x];
-          mij[j] = a_; S.s.lMiJ[row][j] = a_;
-        }
-#pragma unroll
-        for (int j = 0; j < RV_NLIMB; ++j) kk = kk + ja[j] * mij[j];
-        S.s.linvk[row] = 1.0f / kk;
+        for (int j = 0; j < RV_NLIMB; ++j) { S.s.lJa[row][j] = ja[j]; S.s.lMiJ[row][j] = mij[j]; }
+        S.s.linvk[row] = ik;
       }
     }
   RV_LANES_END
@@ -1222,40 +1234,42 @@ RV_DEV void limb_apply(const float* MiJ, float* dq, float dl) {
 }
 // lj / lm / lk: the limb Jacobians Ja[3][7], M^-1 Ja^T [3][7] and effective masses [3] of an arm row in
 // limb_dynamics mode (null otherwise), dq: the deviation of the joint velocities
-RV_DEV float point_solve_g(BV& A, float ima, Lam& l, const Row& r, float* qf, float imf,
+// (lon says whether the limb arrays are there: a test of the POINTER would not do -- on the device the caller's
+// arrays live in private memory, where offset 0 is a valid address)
+RV_DEV float point_solve_g(BV& A, float ima, Lam& l, const Row& r, float* qf, float imf, const int lon,
                            const float (*lj)[RV_NLIMB], const float (*lm)[RV_NLIMB], const float* lk, float* dq) {
   const int fi = r.fidx;
   float jv = row_jv(A, nullptr, r, 0);
   if (fi >= 0) jv += r.jf[0] * qf[fi];
-  if (lj) jv += limb_jv(lj[0], dq);
-  float dl = (r.target - jv) * (lj ? lk[0] : r.invk[0]);
+  if (lon) jv += limb_jv(lj[0], dq);
+  float dl = (r.target - jv) * (lon ? lk[0] : r.invk[0]);
   float ln = fclampr(l.n + dl, 0.0f, r.cap);
   dl = ln - l.n; l.n = ln;
   float res = fabsr(dl);
   row_apply(A, nullptr, ima, 0.0f, r, 0, dl);
   if (fi >= 0) qf[fi] += r.jf[0] * dl * imf;
-  if (lj) limb_apply(lm[0], dq, dl);
+  if (lon) limb_apply(lm[0], dq, dl);
   float lim = r.mu * ln;
   jv = row_jv(A, nullptr, r, 1);
   if (fi >= 0) jv += r.jf[1] * qf[fi];
-  if (lj) jv += limb_jv(lj[1], dq);
-  dl = -jv * (lj ? lk[1] : r.invk[1]);
+  if (lon) jv += limb_jv(lj[1], dq);
+  dl = -jv * (lon ? lk[1] : r.invk[1]);
   float l1 = fclampr(l.t1 + dl, -lim, lim);
   dl = l1 - l.t1; l.t1 = l1;
   res = fmaxr(res, fabsr(dl));
   row_apply(A, nullptr, ima, 0.0f, r, 1, dl);
   if (fi >= 0) qf[fi] += r.jf[1] * dl * imf;
-  if (lj) limb_apply(lm[1], dq, dl);
+  if (lon) limb_apply(lm[1], dq, dl);
   jv = row_jv(A, nullptr, r, 2);
   if (fi >= 0) jv += r.jf[2] * qf[fi];
-  if (lj) jv += limb_jv(lj[2], dq);
-  dl = -jv * (lj ? lk[2] : r.invk[2]);
+  if (lon) jv += limb_jv(lj[2], dq);
+  dl = -jv * (lon ? lk[2] : r.invk[2]);
   float l2 = fclampr(l.t2 + dl, -lim, lim);
   dl = l2 - l.t2; l.t2 = l2;
   res = fmaxr(res, fabsr(dl));
   row_apply(A, nullptr, ima, 0.0f, r, 2, dl);
   if (fi >= 0) qf[fi] += r.jf[2] * dl * imf;
-  if (lj) limb_apply(lm[2], dq, dl);
+  if (lon) limb_apply(lm[2], dq, dl);
   return res;
 }
 // The six rows of a user constraint on body b (a fixed joint to a frame of the world: the mocap-style
@@ -1318,13 +1332,15 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb) {
         for (int i = 0; i < m.n; ++i) {
           Row r = fetch_row(S, K, mi, i);
           Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
-          const int la = limb && kind == 1, lrow = b * 12 + i * 3;
+          const int la = limb && kind == 1;
+          float pja[3][RV_NLIMB], pmi[3][RV_NLIMB], plk[3];
+          if (la) { for (int kk = 0; kk < 3; ++kk) limb_point_row(S, K, b, i, kk, pja[kk], pmi[kk], &plk[kk]); }
           if (it < 0) {
             warm_apply(A, nullptr, ima, 0.0f, l, r);
             if (r.fidx >= 0) { qf[r.fidx] += r.jf[0] * l.n * imf; qf[r.fidx] += r.jf[1] * l.t1 * imf; qf[r.fidx] += r.jf[2] * l.t2 * imf; }
-            if (la) { limb_apply(S.s.lMiJ[lrow], dq, l.n); limb_apply(S.s.lMiJ[lrow + 1], dq, l.t1); limb_apply(S.s.lMiJ[lrow + 2], dq, l.t2); }
+            if (la) { limb_apply(pmi[0], dq, l.n); limb_apply(pmi[1], dq, l.t1); limb_apply(pmi[2], dq, l.t2); }
           } else {
-            res = fmaxr(res, point_solve_g(A, ima, l, r, qf, imf, la ? &S.s.lJa[lrow] : nullptr, la ? &S.s.lMiJ[lrow] : nullptr, la ? &S.s.linvk[lrow] : nullptr, dq));
+            res = fmaxr(res, point_solve_g(A, ima, l, r, qf, imf, la, pja, pmi, plk, dq));
             m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2;
           }
         }
@@ -1873,7 +1889,7 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
   }
   // limb rows
   const bool la = LIMB && ((act && p >= 4) || lmotor);
-  const int lrow = lmotor ? RV_MAXB * 12 + lj : Xc * 12 + slot * 3 + k;
+  const int lrow = lmotor ? 12 + lj : slot * 3 + k;
   float ja[RV_NLIMB], pj[RV_NLIMB];
 #pragma unroll
   for (int x = 0; x < RV_NLIMB; ++x) { ja[x] = 0.0f; pj[x] = 0.0f; }
@@ -1909,7 +1925,7 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
       if (LIMB) {
         if (lmotor) a_ = 0.0f;
         if (ps >= 4) {
-          const float* pjs = S.s.lMiJ[Xc * 12 + (s - 12)];
+          const float* pjs = S.s.lMiJ[s - 12];
           float t = 0.0f;
 #pragma unroll
           for (int x = 0; x < RV_NLIMB; ++x) t = t + ja[x] * pjs[x];
@@ -1924,7 +1940,7 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
   if (LIMB) {
 #pragma unroll
     for (int j = 0; j < RV_NLIMB; ++j) {
-      const float* pjs = S.s.lMiJ[RV_MAXB * 12 + j];
+      const float* pjs = S.s.lMiJ[12 + j];
       float t = 0.0f;
 #pragma unroll
       for (int x = 0; x < RV_NLIMB; ++x) t = t + ja[x] * pjs[x];
@@ -2090,7 +2106,7 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
     if (limb) {
       fisl = RV_ROW_ISL(rm);
       if (mi >= RV_AIDX(0)) {
-        const int lrow = (mi - RV_AIDX(0)) * 12 + pi * 3 + k;
+        const int lrow = pi * 3 + k;
         la[r] = 1; invk[r] = S.s.linvk[lrow];
         float t = 0.0f;
         for (int x = 0; x < RV_NLIMB; ++x) { ja[r][x] = S.s.lJa[lrow][x]; pj[r][x] = S.s.lMiJ[lrow][x]; t = t + ja[r][x] * dq0[x]; }
@@ -2110,7 +2126,7 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
     la[r] = 0;
   }
   for (int j = 0; j < nlm; ++j) {             // limb motor rows
-    const int r = n_rows + nfm + j, lrow = RV_MAXB * 12 + j;
+    const int r = n_rows + nfm + j, lrow = 12 + j;
     g[r] = dq0[j] - S.s.ltgt[j]; lam[r] = 0.0f; invk[r] = 1.0f / S.s.lA[j][RV_NLIMB + j]; bias[r] = 0.0f; mu[r] = 0.0f; cap[r] = 0.0f;
     jf[r] = 0.0f; pf[r] = 0.0f; fi[r] = -1; la[r] = 1;
     for (int x = 0; x < RV_NLIMB; ++x) { ja[r][x] = S.s.lJa[lrow][x]; pj[r][x] = S.s.lMiJ[lrow][x]; }
@@ -3731,7 +3747,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   RV_STOP(4)
   RV_PROF(4)
   any_con |= limb;
-  if (limb) limb_prepare(S, K);
+  if (limb) limb_prepare(S, K, fing_fast ? the_body : -1);
   if (((with_fingers || limb) && !fing_fast) || (any_con && !limb)) {
     RV_LANES_BEGIN
       if (lane == 0) solve_with_fingers(S, K, limb);

@@ -13,6 +13,7 @@
 #   parts          per-part shader-clock table of the bench launch (RV_PROFILE build)
 #   parts_nd       per-part table with PHYSICS.SLEEP_STEPS=0, 2 steps
 #   parts_c3 / parts_c4 / parts_c5   per-part tables of configs 3 / 4 / 5
+#   variants       headline + configs 5 / 3 / 4 for the product library and every build/librovat_*.so
 #   lanes          SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU lane-utilisation pass (headline and no-deactivation)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
@@ -51,6 +52,14 @@ for STAGE in "$@"; do
         rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/lanes_$V -o l --output-format csv -- $CMD > $O/lanes_$V.log 2>&1
       done
       cd $R; python tools/pmc_summary.py $O/lanes_head $O/lanes_nd > $O/lanes.txt 2>&1; cat $O/lanes.txt ;;
+    variants)
+      # every library variant under build/ (and the product library): headline, config 5 / 3 / 4 single-launch rollouts
+      for SO in robovat_amd/librovat_hip.so build/librovat_*.so; do
+        for W in "--steps 20 --warmup 5" "--workload config5 --steps 10 --warmup 2" "--workload config3 --steps 10 --warmup 2" "--workload config4 --steps 10 --warmup 2"; do
+          V=$(RV_LIB=$R/$SO timeout 600 python bench.py $W --no-cpu-baseline --no-extra-legs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.0f env-steps/s  kernel %.1f ms' % (d['value'], d['roofline']['avg_kernel_ms']))")
+          echo "$SO [$W]: $V" | tee -a $O/variants.txt
+        done
+      done ;;
     *) echo "unknown stage $STAGE" ;;
   esac
   echo "$STAGE: $(( $(date +%s) - T0 )) s" >> $O/time.txt
