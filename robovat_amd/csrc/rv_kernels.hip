@@ -20,141 +20,7 @@
 
 using namespace rv;
 
-// ------------------------------------------------------------------ kernels
-enum { MODE_RESET = 0, MODE_MACRO = 1, MODE_SUB = 2, MODE_WAIT = 3, MODE_ROLLOUT = 4, MODE_PARTIAL = 5 };
-
-struct EnvKernelArgs {
-  const rv_config* cfg;
-  const rv_scene* scene;
-  DevEnv* envs;
-  const uint8_t* mask;
-  int n_envs;
-  int n_substeps;
-  float lin_thr, ang_thr;
-  int check_after, min_stable, max_steps;
-  int stop_after;   // profiling hook (env RV_DEBUG_STOP, MODE_SUB only)
-  int first_index, auto_reset;   // MODE_ROLLOUT
-  RolloutRec rec;                // MODE_ROLLOUT: what every env.step() returns
-  int* budget;                   // MODE_ROLLOUT, asynchronous: shared pool of env.step() calls
-  int32_t* steps_taken;          // optional [N]
-  unsigned long long budget_clk; // MODE_PARTIAL: shader clocks this launch may spend per env (0: no limit)
-  uint8_t* finished;             // MODE_PARTIAL: [N] 1 = the env.step() of this env completed in this launch
-};
-
-template <int MODE>
-#ifdef RV_WAVES_PER_EU      // experiment: cap the registers so that RV_WAVES_PER_EU waves fit a SIMD (tools/flag_variants.sh)
-#define RV_ENV_OCC __attribute__((amdgpu_waves_per_eu(RV_WAVES_PER_EU, RV_WAVES_PER_EU)))
-#else
-#define RV_ENV_OCC
-#endif
-__global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
-  Shared& S = g_shared;
-  const int env = (int)blockIdx.x;
-  if (env >= args.n_envs) return;
-  DevEnv* g = args.envs + env;
-  const int lane = (int)threadIdx.x;
-  {
-    // stage the launch constants in LDS
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(args.cfg);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&S.cfg);
-    for (int i = lane; i < (int)(sizeof(rv_config) / 4); i += 64) dst[i] = src[i];
-    src = reinterpret_cast<const uint32_t*>(&args.scene->arm);
-    dst = reinterpret_cast<uint32_t*>(&S.arm);
-    for (int i = lane; i < (int)(sizeof(rv_arm) / 4); i += 64) dst[i] = src[i];
-  }
-  Consts K = lds_consts(args.scene, (MODE == MODE_SUB) ? args.stop_after : 0);
-  constexpr int W = (int)(sizeof(DevEnv) / 4);
-  bool skip = false;
-  if (MODE == MODE_RESET) skip = (args.mask != nullptr) && (args.mask[env] == 0);
-  {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&S.e);
-    for (int i = lane; i < W; i += 64) dst[i] = src[i];
-  }
-  __syncthreads();
-#ifdef RV_PROFILE
-  if (lane == 0) { S.e.prof_t = __builtin_amdgcn_s_memtime(); for (int g2 = 0; g2 < 4; ++g2) S.e.prof_t2[g2] = S.e.prof_t; }
-  __syncthreads();
-#endif
-  if (MODE == MODE_MACRO) skip = (S.e.done != 0);
-  if (MODE == MODE_MACRO || MODE == MODE_ROLLOUT || MODE == MODE_SUB || MODE == MODE_WAIT) {
-    // A lock-step entry point on an env that rv_step_poll left in the middle of an env.step() CANCELS that
-    // step (include/rovat.h, rv_step_begin): its phase machine is not resumed by a later poll -- without
-    // this the next poll would run a second env.step() with the stale action.
-    if (S.e.in_step != 0) {
-      if (lane == 0) { g->in_step = 0; g->step_stage = -1; }
-      __syncthreads();
-      if (lane == 0) { S.e.in_step = 0; S.e.step_stage = -1; }
-      __syncthreads();
-    }
-  }
-  if (MODE == MODE_PARTIAL) {
-    skip = (S.e.in_step != 1) && !(S.e.in_step == 2 && args.auto_reset);
-    if (skip && lane == 0) {
-      // no step pending; a step that was begun on a finished episode is reported once, with
-      // reward 0 and done (rv_step_macro skips such an env the same way)
-      const int fin = S.e.in_step == 2;
-      if (args.finished) args.finished[env] = (uint8_t)fin;
-      if (fin) { g->in_step = 0; g->reward_valid = 0; rollout_record(args.rec, nullptr, (size_t)env, &S.cfg, &S.arm); }   // reward 0, done, zero rows
-    }
-  }
-  if (MODE == MODE_ROLLOUT) skip = (S.e.done != 0) && !args.auto_reset;
-  if (skip) {
-    // (the counters are per launch: an env the launch skips contributes nothing to rv_get_stats; an
-    // env that a macro launch does not step -- its episode is over -- has no step result any more,
-    // while a reset that masks it out, rv_step_sub or rv_wait_until_stable leave its reward alone)
-    if (lane == 0) launch_counters_zero(*g);
-    if (lane == 0 && (MODE == MODE_MACRO || MODE == MODE_ROLLOUT)) g->reward_valid = 0;
-    if (MODE == MODE_ROLLOUT && args.budget == nullptr)   // steps not taken: reward 0, done, zero rows
-      for (int k = lane; k < args.n_substeps; k += 64) rollout_record(args.rec, nullptr, (size_t)k * args.n_envs + env, &S.cfg, &S.arm);
-    return;
-  }
-  if (MODE != MODE_RESET) env_enter(S, K);
-  if (MODE == MODE_RESET) {
-    env_reset(S, K, K.cfg->env_id_offset + env);
-  } else if (MODE == MODE_MACRO) {
-    if (lane == 0) launch_counters_zero(S.e);
-    __syncthreads();
-    if (K.cfg->env_type == RV_ENV_GRASP) genv_step(S, K); else env_step(S, K);
-  } else if (MODE == MODE_ROLLOUT) {
-    env_rollout(S, K, K.cfg->env_id_offset + env, args.n_substeps, args.first_index, args.auto_reset, args.rec, env, args.n_envs, args.budget);
-    if (lane == 0 && args.steps_taken) args.steps_taken[env] = S.e.stepped;
-  } else if (MODE == MODE_PARTIAL && S.e.in_step == 2) {
-    // rv_set_auto_reset: the step was begun on a finished episode -> env.reset(); the poll hands back what it returns
-    env_reset(S, K, K.cfg->env_id_offset + env);
-    __syncthreads();
-    if (lane == 0) {
-      S.e.in_step = 0; S.e.reward_valid = 0; S.e.last_reward = 0.0f;
-      if (args.finished) args.finished[env] = 1;
-      rollout_record(args.rec, &S.e, (size_t)env, &S.cfg, &S.arm);
-    }
-  } else if (MODE == MODE_PARTIAL) {
-    if (lane == 0) {
-      launch_counters_zero(S.e);
-      S.s.bud_sub = args.n_substeps; S.s.bud_sub0 = 0; S.s.bud_clk = args.budget_clk; S.s.bud_t0 = __builtin_amdgcn_s_memtime();
-    }
-    __syncthreads();
-    const int fin = env_step_partial(S, K);
-    if (lane == 0) {
-      if (args.finished) args.finished[env] = (uint8_t)fin;
-      if (fin) rollout_record(args.rec, &S.e, (size_t)env, &S.cfg, &S.arm);     // what env.step() returns, for the envs that finished
-    }
-  } else if (MODE == MODE_SUB) {
-    if (lane == 0) launch_counters_zero(S.e);
-    __syncthreads();
-    sim_steps_call(K, args.n_substeps);
-  } else {
-    if (lane == 0) launch_counters_zero(S.e);
-    __syncthreads();
-    wait_until_stable(S, K, 0u, args.lin_thr, args.ang_thr, args.check_after, args.min_stable, args.max_steps);
-  }
-  __syncthreads();
-  {
-    uint32_t* dst = reinterpret_cast<uint32_t*>(g);
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.e);
-    for (int i = lane; i < W; i += 64) dst[i] = src[i];
-  }
-}
+#include "rv_env_kernel.h"
 
 #define ENV_THREAD() const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return; DevEnv& e = envs[i];
 
@@ -643,6 +509,7 @@ struct rv_world {
   hipEvent_t ev0, ev1;
   bool timed;
   int auto_reset;                         // rv_set_auto_reset
+  int occ2;                               // more envs than SIMDs: launch k_env_occ2 (rv_env_kernel.h)
 };
 
 static thread_local std::string g_err;
@@ -653,6 +520,11 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 static inline dim3 grid1(int n) { return dim3((unsigned)((n + 127) / 128)); }
 #define TPB 128
 
+// the register-rich kernel while every env has a SIMD of its own, the two-waves-per-SIMD build beyond that
+static void launch_k_env(rv_world* w, int mode, const EnvKernelArgs& a) {
+  if (w->occ2) rv_launch_k_env_occ2(mode, a, w->n, w->stream);
+  else rv_launch_k_env_here(mode, a, w->n, w->stream);
+}
 template <int MODE>
 static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, float ang, int ca, int ms, int mx,
                       int first_index = 0, int auto_reset = 0, const RolloutRec* rec = nullptr,
@@ -667,7 +539,7 @@ static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, fl
   a.n_substeps = n_sub; a.lin_thr = lin; a.ang_thr = ang; a.check_after = ca; a.min_stable = ms; a.max_steps = mx;
   HIPCHK(hipMemsetAsync(w->d_stats, 0, sizeof(rv_macro_stats), w->stream));
   HIPCHK(hipEventRecord(w->ev0, w->stream));
-  hipLaunchKernelGGL(k_env<MODE>, dim3((unsigned)w->n), dim3(64), 0, w->stream, a);
+  launch_k_env(w, MODE, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(w->ev1, w->stream));
   w->timed = true;
@@ -710,6 +582,15 @@ int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world*
   if (!w) return fail(RV_ERR_STATE, "rv_create: out of host memory");
   w->cfg = *cfg; w->device = device; w->n = cfg->n_envs; w->stream = nullptr; w->timed = false;
   w->d_snaps = nullptr; w->n_snaps_cap = 0;
+  {
+    // one wave per env: with more envs than SIMDs the two-waves-per-SIMD build of the env kernel pays
+    // (RV_ENV_OCC=1 / 2 in the environment forces a build: measurements)
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    w->occ2 = w->n > 4 * cus;
+    const char* f = getenv("RV_ENV_OCC");
+    if (f && (f[0] == '1' || f[0] == '2')) w->occ2 = f[0] == '2';
+  }
   HIPCHK(hipMalloc(&w->d_cfg, sizeof(rv_config)));
   HIPCHK(hipMalloc(&w->d_scene, sizeof(rv_scene)));
   HIPCHK(hipMalloc(&w->d_envs, sizeof(DevEnv) * (size_t)w->n));
@@ -853,7 +734,7 @@ int rv_step_poll(rv_world* w, int32_t max_substeps, int32_t max_usec, uint8_t* d
   }
   HIPCHK(hipMemsetAsync(w->d_stats, 0, sizeof(rv_macro_stats), w->stream));
   HIPCHK(hipEventRecord(w->ev0, w->stream));
-  hipLaunchKernelGGL(k_env<MODE_PARTIAL>, dim3((unsigned)w->n), dim3(64), 0, w->stream, a);
+  launch_k_env(w, MODE_PARTIAL, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(w->ev1, w->stream));
   w->timed = true;

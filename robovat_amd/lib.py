@@ -62,17 +62,37 @@ def built_source_hash():
 def build(force=False, verbose=False):
     """Compile csrc/rv_kernels.hip for gfx950 into librovat_hip.so (in-tree).
     The sha256 of the sources is baked into the binary (rv_source_hash)."""
-    src = os.path.join(CSRC, 'rv_kernels.hip')
+    srcs = [os.path.join(CSRC, 'rv_kernels.hip'), os.path.join(CSRC, 'rv_kernels_occ2.hip')]
     deps = SOURCES
     if (not force and os.path.exists(LIB_PATH) and
             all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps)):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + HIPCC_FLAGS + ['-DRV_SOURCE_HASH="%s"' % source_hash(), src, '-o', LIB_PATH]
+    compile_lib(LIB_PATH, hipcc=hipcc, verbose=verbose)
+    return LIB_PATH
+
+
+def compile_lib(out, extra=(), hipcc='/opt/rocm/bin/hipcc', verbose=False):
+    """The two translation units (rv_kernels.hip: C ABI + the register-rich env kernel; rv_kernels_occ2.hip: the
+    env kernel for two waves per SIMD) compiled side by side, then linked into one shared object."""
+    srcs = [os.path.join(CSRC, 'rv_kernels.hip'), os.path.join(CSRC, 'rv_kernels_occ2.hip')]
+    flags = [f for f in HIPCC_FLAGS if f != '-shared'] + ['-DRV_SOURCE_HASH="%s"' % source_hash()] + list(extra)
+    objs, procs = [], []
+    for src in srcs:
+        obj = os.path.join(os.path.dirname(out), '.' + os.path.basename(out) + '.' + os.path.basename(src) + '.o')
+        cmd = [hipcc] + flags + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append(subprocess.Popen(cmd)); objs.append(obj)
+    for p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, 'hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared'] + objs + ['-o', out]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    for o in objs:
+        os.remove(o)
 
 
 def load():

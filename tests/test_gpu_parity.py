@@ -274,3 +274,25 @@ def test_partial_batches_with_auto_reset():
             w2.step_begin(A[cnt.clamp(max=R - 1), ar], mask=go.to(torch.uint8))
     assert np.array_equal(w2.body_state().cpu().numpy(), final)
     world.close(); w2.close()
+
+
+def test_both_builds_of_the_env_kernel_match_the_oracle(monkeypatch):
+    """librovat_hip.so holds the env kernel twice (rv_env_kernel.h): the register-rich build for one env per SIMD and
+    the two-waves-per-SIMD build a world with more envs than SIMDs launches.  RV_ENV_OCC forces either on a small
+    world: both equal the float oracle bit for bit over resets and whole env.step() calls."""
+    from robovat_amd import lib
+    from oracle import orc
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(env_cfg=configs.push_env_config(MIN_MOVABLE_BODIES=2, MAX_MOVABLE_BODIES=4, MAX_STEPS=3),
+                                 n_envs=96, seed=41, shape_names=names)
+    ref = orc.OracleWorld(cfg, scene, double=False)
+    ref.reset(); ref.rollout(5, 0, True)
+    for occ in ('1', '2'):
+        monkeypatch.setenv('RV_ENV_OCC', occ)
+        w = lib.World(cfg, scene, device=0)
+        w.reset(); w.rollout(5, first_macro_index=0, auto_reset=True, record=False)
+        assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32)), occ
+        assert np.array_equal(w.joint_state().cpu().numpy(), ref.joint_state().astype(np.float32)), occ
+        assert np.array_equal(w.env_counters().cpu().numpy(), ref.env_counters()), occ
+        assert np.array_equal(w.manifold_counts().cpu().numpy(), ref.manifold_counts()), occ
+        w.close()

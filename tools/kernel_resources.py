@@ -3,26 +3,24 @@ clang offload bundle): python tools/kernel_resources.py [lib.so]"""
 import re, struct, subprocess, sys, tempfile, os
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), '..', 'robovat_amd', 'librovat_hip.so')
 d = open(path, 'rb').read()
-i = d.find(b'__CLANG_OFFLOAD_BUNDLE__')
-n = struct.unpack_from('<Q', d, i + 24)[0]
-off = i + 32
-for _ in range(n):
-    o, sz, ts = struct.unpack_from('<QQQ', d, off); off += 24
-    t = d[off:off + ts].decode(); off += ts
-    if 'gfx950' in t:
-        with tempfile.NamedTemporaryFile(suffix='.o', delete=False) as f:
-            f.write(d[i + o:i + o + sz]); co = f.name
-txt = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-readelf', '--notes', co], capture_output=True, text=True).stdout
-os.unlink(co)
-cur = {}
-for line in txt.splitlines():
-    m = re.match(r'\s*-?\s*\.(agpr_count|group_segment_fixed_size|name|private_segment_fixed_size|vgpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count):\s*(\S+)', line)
-    if m:
-        cur[m.group(1)] = m.group(2)
-        if m.group(1) == 'vgpr_spill_count' or (m.group(1) == 'vgpr_count' and 'name' in cur):
-            pass
-    if line.strip().startswith('- .agpr_count') and cur.get('name'):
-        cur = {'agpr_count': cur['agpr_count']}
+# one offload bundle per translation unit (rv_kernels.hip, rv_kernels_occ2.hip): read the gfx950 code object of each
+txt = ''
+start = 0
+while True:
+    i = d.find(b'__CLANG_OFFLOAD_BUNDLE__', start)
+    if i < 0:
+        break
+    start = i + 24
+    n = struct.unpack_from('<Q', d, i + 24)[0]
+    off = i + 32
+    for _ in range(n):
+        o, sz, ts = struct.unpack_from('<QQQ', d, off); off += 24
+        t = d[off:off + ts].decode(); off += ts
+        if 'gfx950' in t:
+            with tempfile.NamedTemporaryFile(suffix='.o', delete=False) as f:
+                f.write(d[i + o:i + o + sz]); co = f.name
+            txt += subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-readelf', '--notes', co], capture_output=True, text=True).stdout
+            os.unlink(co)
 rows = re.findall(r'\.agpr_count:\s*(\d+).*?\.group_segment_fixed_size:\s*(\d+).*?\.name:\s*(\S+).*?\.private_segment_fixed_size:\s*(\d+).*?\.sgpr_count:\s*(\d+).*?\.vgpr_count:\s*(\d+).*?\.vgpr_spill_count:\s*(\d+)', txt, re.S)
 print('%-44s %6s %6s %8s %9s %6s %6s' % ('kernel', 'vgpr', 'agpr', 'LDS B', 'scratch B', 'sgpr', 'spill'))
 for a, lds, name, scr, sg, vg, sp in rows:

@@ -22,9 +22,7 @@ PROF_LIB = os.path.join(ROOT, 'robovat_amd', 'librovat_hip_prof.so')
 
 if '--build' in sys.argv:
     from robovat_amd import lib
-    cmd = (['/opt/rocm/bin/hipcc'] + lib.HIPCC_FLAGS +
-           ['-DRV_PROFILE', '-DRV_SOURCE_HASH="%s"' % lib.source_hash(), os.path.join(lib.CSRC, 'rv_kernels.hip'), '-o', PROF_LIB])
-    subprocess.run(cmd, check=True)
+    lib.compile_lib(PROF_LIB, extra=['-DRV_PROFILE'])
     print('built', PROF_LIB)
     sys.exit(0)
 
