@@ -4145,7 +4145,7 @@ RV_DEV Consts lds_consts(const rv_scene* scene, int stop_after) {
 // The heavy part (contacts, solver) is a function of its own: it needs every
 // register and pays a large callee-saved spill in its prologue, so it is entered
 // only when the light part (arm, wake test, quiet check) says so.
-RV_DEV_NOINLINE void sim_substep_heavy_call(const rv_scene* scene, int stop_after) {
+RV_DEV void sim_substep_heavy_call(const rv_scene* scene, int stop_after) {
   Consts K = lds_consts(scene, stop_after);
   sim_substep_heavy(g_shared, K);
 }

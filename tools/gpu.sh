@@ -9,6 +9,7 @@
 #   headline       bench.py headline only (no CPU legs, no extra legs)
 #   k50            bench.py --steps 50 headline only
 #   profile        rocprofv3 kernel stats + PMC passes of the headline (tools/profile_bench.sh)
+#   profile_c5 / _c3 / _c4   the same for configs 5 / 3 / 4
 #   profile_nd     the same for the reference-semantics (no deactivation) launch
 #   parts          per-part shader-clock table of the bench launch (RV_PROFILE build)
 #   parts_nd       per-part table with PHYSICS.SLEEP_STEPS=0, 2 steps
@@ -39,6 +40,9 @@ for STAGE in "$@"; do
       cut -c1-300 $O/k50.json ;;
     profile)    bash tools/profile_bench.sh $TAG/profile > $O/profile.log 2>&1; tail -2 $O/profile.log ;;
     profile_nd) bash tools/profile_bench.sh $TAG/profile_nd --steps 2 --warmup 1 --over PHYSICS.SLEEP_STEPS=0 > $O/profile_nd.log 2>&1; tail -2 $O/profile_nd.log ;;
+    profile_c5) bash tools/profile_bench.sh $TAG/profile_c5 --workload config5 --steps 10 --warmup 2 > $O/profile_c5.log 2>&1; tail -2 $O/profile_c5.log ;;
+    profile_c3) bash tools/profile_bench.sh $TAG/profile_c3 --workload config3 --steps 10 --warmup 2 > $O/profile_c3.log 2>&1; tail -2 $O/profile_c3.log ;;
+    profile_c4) bash tools/profile_bench.sh $TAG/profile_c4 --workload config4 --steps 10 --warmup 2 > $O/profile_c4.log 2>&1; tail -2 $O/profile_c4.log ;;
     parts)      timeout 400 python tools/prof_rollout.py --warm 1 --warm-steps 5 --top 10 > $O/parts.txt 2>&1; head -40 $O/parts.txt ;;
     parts_nd)   timeout 600 python tools/prof_rollout.py --warm 0 --steps 2 --top 4 --over PHYSICS.SLEEP_STEPS=0 > $O/parts_nd.txt 2>&1; head -48 $O/parts_nd.txt ;;
     parts_c3)   timeout 600 python tools/prof_rollout.py --warm 0 --envs 4096 --steps 10 --top 6 --over TASK_NAME=crossing LAYOUT_ID=0 MOVABLE_NAME=CONCAVE MAX_STEPS=10 > $O/parts_c3.txt 2>&1; head -40 $O/parts_c3.txt ;;
