@@ -1264,7 +1264,7 @@ static real dotj(const orc_j6* j, const real* pl, const real* pa) { return v3dot
  * velocity, impulse within +-finger_max_force dt minus what the joint motors of the light part already
  * spent on the free motion.  The Delassus matrix gets the finger terms, nothing else changes; the fingers
  * then move with the solved velocity. */
-static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const orc_rowid* id, int n_rows, const int* use, const int* big, const int* label, const int fing, const orc_limb* L) {
+static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const orc_rowid* id, int n_rows, const int* use, const int* big, const int* label, const int fing, const orc_limb* L, const int motor_isl) {
   const rv_config* c = &w->cfg;
   const rv_arm* arm = &w->scene.arm;
   static __thread real A[SOLVE_ROWS + 9][SOLVE_ROWS + 9];
@@ -1280,7 +1280,7 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
   const int n_all = n_rows + nfm + nlm;
   int la[SOLVE_ROWS + 9]; real ja[SOLVE_ROWS + 9][RV_NLIMB], pj[SOLVE_ROWS + 9][RV_NLIMB], dq0[RV_NLIMB];
   for (int x = 0; x < RV_NLIMB; ++x) dq0[x] = L ? -e->limb_dv[x] : R(0.0);     /* the solve starts from the velocity before the motor step */
-  int fisl = 0;      /* the island the motor rows belong to: the awake body's (there is at most one) */
+  int fisl = 0;      /* the island the motor rows belong to: the awake body's when there is at most one, else motor_isl */
   orc_j6 jx[SOLVE_ROWS][RV_MAXB];
   for (int r = 0; r < n_rows; ++r) {
     const orc_row* rw = &rows[id[r].mi][id[r].i]; const orc_manifold* mm = &e->man[id[r].mi];
@@ -1312,6 +1312,7 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
     }
     g[r] = gg;
   }
+  if (motor_isl >= 0) fisl = motor_isl;
   for (int m = 0; fing && m < 2; ++m) {       /* motor rows */
     const int r = n_rows + m;
     const real i0 = mf * e->fing_dv[m];
@@ -1529,7 +1530,15 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
       orc_limb L; limb_prepare(w, e, rows, use, &L);
       int n_on = 0;
       for (int b = 0; b < RV_MAXB; ++b) n_on += use[TIDX(b)];
-      if (n_on <= 1 && !any_con && !getenv("ORC_LIMB_SYS")) solve_rows(w, e, rows, id, n_rows, use, big, label, c->finger_dynamics && e->arm_enabled, &L);
+      /* ... or several awake bodies of which ONE touches the arm and is an island by itself (the pushed body while
+       * another one is still sliding on): the limb rows live in that island, the other islands of one or two bodies
+       * are the usual independent problems of the same impulse-space solve */
+      int n_arm = 0, lb = -1, any_big = 0, lone = 0;
+      for (int b = 0; b < RV_MAXB; ++b) { if (use[AIDX(b)] && e->man[AIDX(b)].n > 0) { ++n_arm; lb = b; } any_big |= big[b]; }
+      if (n_arm == 1) { int members = 0; for (int x = 0; x < RV_MAXB; ++x) members += (use[TIDX(x)] && label[x] == label[lb]); lone = members == 1; }
+      const int fingers = c->finger_dynamics && e->arm_enabled;
+      if (!any_con && !getenv("ORC_LIMB_SYS") && (n_on <= 1 || (!fingers && lone && !any_big)))
+        solve_rows(w, e, rows, id, n_rows, use, big, label, fingers, &L, n_on <= 1 ? -1 : label[lb]);
       else solve_with_fingers(w, e, rows, use, &L);
       arm_update_kinematics(w, e);      /* the link frames follow the solved joint state */
       return;
@@ -1541,11 +1550,11 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
      * velocity-space system solver */
     int n_on = 0;
     for (int b = 0; b < RV_MAXB; ++b) n_on += use[TIDX(b)];
-    if (n_on <= 1) solve_rows(w, e, rows, id, n_rows, use, big, label, 1, NULL);
+    if (n_on <= 1) solve_rows(w, e, rows, id, n_rows, use, big, label, 1, NULL, -1);
     else solve_with_fingers(w, e, rows, use, NULL);
     return;
   }
-  if (n_rows > 0) solve_rows(w, e, rows, id, n_rows, use, big, label, 0, NULL);
+  if (n_rows > 0) solve_rows(w, e, rows, id, n_rows, use, big, label, 0, NULL, -1);
   /* big islands: warm start first */
   for (int b = 0; b < RV_MAXB; ++b)
     for (int kind = 0; kind <= 2; kind += 2) {

@@ -2064,7 +2064,7 @@ RV_DEV void solve_island_fingers(Shared& S, const Consts& K, const int X, const 
 // fing != 0 (rv_config.finger_dynamics, at most one awake body): the two finger joints are DOFs of
 // the system as well -- contact rows on a finger pad carry jf on their finger's velocity, each finger
 // has a motor row after the contact rows (see solve_island_fingers, the device version)
-RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int fing, const int limb) {
+RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int fing, const int limb, const int motor_isl) {
   DevEnv& e = S.e; const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
   static thread_local float A[RV_SOLVE_ROWS + 9][RV_SOLVE_ROWS + 9];
   float g[RV_SOLVE_ROWS + 9], lam[RV_SOLVE_ROWS + 9], invk[RV_SOLVE_ROWS + 9], bias[RV_SOLVE_ROWS + 9], mu[RV_SOLVE_ROWS + 9], cap[RV_SOLVE_ROWS + 9];
@@ -2117,6 +2117,7 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
     jx[r][ra].l = dir; jx[r][ra].a = rxa;
     if (rb >= 0) { jx[r][rb].l = nd; jx[r][rb].a = nrxb; }
   }
+  if (motor_isl >= 0) fisl = motor_isl;
   for (int m = 0; fing && m < 2; ++m) {       // motor rows
     const int r = n_rows + m;
     const float i0 = mf * S.s.fing_dv[m];
@@ -3681,14 +3682,30 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   }
   // one awake body at most and no user constraint: impulse space, one lane per row, with the finger / limb
   // DOFs and their motor rows; else the velocity-space system solver
-  const int fing_fast = (with_fingers || limb) && n_on <= 1 && !any_con;
+  // ... or several awake bodies of which ONE touches the arm and is an island by itself (the pushed body while
+  // another one is still sliding on): the limb rows live in that island, the other islands of one or two bodies
+  // are the usual independent problems
+  int lone = 0;
+  if (limb) {
+    int n_arm = 0, lb = -1, any_big = 0;
+#pragma unroll
+    for (int b = RV_MAXB - 1; b >= 0; --b) { if (on_[b] && S.e.man[RV_AIDX(b)].n > 0) { ++n_arm; lb = b; } any_big |= big_[b]; }
+    int alone = 0;
+#pragma unroll
+    for (int b = 0; b < RV_MAXB; ++b) if (b == lb) alone = mem_[b] == 1;
+    lone = n_arm == 1 && alone && !any_big && !with_fingers && n_on > 1;
+    if (lone) the_body = lb;
+  }
+  const int fing_fast = (with_fingers || limb) && !any_con && (n_on <= 1 || lone);
+  // the other islands keep their lane-per-row solvers unless the one-lane system solver takes everything
+  const int others_ok = !with_fingers && !any_con && (!limb || lone);
   // islands that are one body on the table and nothing else are set up and solved together by
   // solve_singles(): their rows never go through the Row records
   int smask = 0;
   const int rows_all = ((with_fingers || limb) && !fing_fast) || (any_con && !limb);
   (void)rows_all;
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
-  if (!with_fingers && !any_con && !limb) {
+  if (others_ok) {
 #pragma unroll
     for (int b = 0; b < RV_MAXB; ++b) if (on_[b] && mem_[b] == 1 && S.e.man[RV_AIDX(b)].n == 0) smask |= 1 << b;
     smask = __builtin_amdgcn_readfirstlane(smask);
@@ -3778,7 +3795,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       int m_ = 0, y_ = -1, kxy = 0;
 #pragma unroll
       for (int x = 0; x < RV_MAXB; ++x) if (x == b) { m_ = mem_[x]; y_ = isl_y[x]; kxy = isl_k[x]; }
-      m_ = (with_fingers || any_con) ? 0 : __builtin_amdgcn_readfirstlane(m_);
+      m_ = (!others_ok || (lone && b == the_body)) ? 0 : __builtin_amdgcn_readfirstlane(m_);
       if (m_ == 1 || m_ == 2)
         solve_island2(S, K, b, __builtin_amdgcn_readfirstlane(y_), __builtin_amdgcn_readfirstlane(kxy));
     }
@@ -3787,8 +3804,8 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   RV_LANES_BEGIN
     if (lane == 0) S.s.n_rows = (!fing_fast && (with_fingers || any_con)) ? 0 : solver_row_list(S, label, on_, act_, big_);
   RV_LANES_END
-  if (fing_fast) solve_rows(S, K, S.s.n_rows < 0 ? 0 : S.s.n_rows, with_fingers, limb);
-  else if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows, 0, 0);
+  if (fing_fast) solve_rows(S, K, S.s.n_rows < 0 ? 0 : S.s.n_rows, with_fingers, limb, lone ? label[the_body] : -1);
+  else if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows, 0, 0, -1);
 #endif
   if (limb) { arm_lq_phase(S, K); arm_fk_phases(S, K); }   // the link frames follow the solved joint state
   // an island of three or four bodies (there can be only one): velocity-space Gauss-Seidel in the
