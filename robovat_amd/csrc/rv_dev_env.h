@@ -1031,25 +1031,12 @@ RV_DEV void man_owner(int mi, int* kind, int* a, int* b) {
   else if (mi < RV_MAXB + RV_NBB) { *kind = 1; *a = bb_a(mi - RV_MAXB); *b = bb_b(mi - RV_MAXB); }
   else { *kind = 2; *a = mi - RV_MAXB - RV_NBB; *b = -1; }
 }
-// The Row of manifold point (mi, i) for the one-lane system solver.  Host emulation: the record the
-// row-setup phase left in LDS.  Device: no Row records exist (they were 13 KB of the env's LDS block, and
-// every lane-per-row solver sets its rows up in registers): the rare serial path recomputes the row --
-// row_setup() of the same inputs, so the same values -- each time it visits the point.
-RV_DEV Row fetch_row(const Shared& S, const Consts& K, int mi, int i) {
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
-  int kind, a, b;
-  man_owner(mi, &kind, &a, &b);
-  const DevMan& m = S.e.man[mi];
-  ManPoint pt;
-  pt.la = ld3(m.la[i]); pt.lb = ld3(m.lb[i]); pt.nrm = ld3(m.nrm[i]); pt.dist = m.dist[i]; pt.col = m.col[i];
-  Row r;
-  row_setup(S, K, kind, a, b, pt, r, m.n);
-  return r;
-#else
-  (void)K;
-  return S.s.u.r.rows[mi][i];
+// The Row of manifold point (mi, i) for the one-lane system solver of the host emulation: the record the
+// row-setup phase left in LDS.  (Device: no Row records exist -- they were 13 KB of the env's LDS block; see
+// SerialRows.)
+#if !defined(__HIPCC__) || defined(RV_EMULATE)
+RV_DEV Row fetch_row(const Shared& S, const Consts& K, int mi, int i) { (void)K; return S.s.u.r.rows[mi][i]; }
 #endif
-}
 
 // body velocity pair held in registers by the solving lane
 struct BV { v3 v, w; };
@@ -1310,7 +1297,67 @@ RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
   }
   return res;
 }
-RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb) {
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+// Device: the one-lane system solver is run by EVERY lane of the wave (the same scalar program on the same LDS
+// data: the lanes agree on every value they store), so that the row sets it visits can live in registers: lane
+// 4 mi + i holds the Row of point i of manifold mi -- and, in limb mode, the limb rows of an arm point -- set up
+// once per solve (serial_rows_setup), and a visit pulls them with v_readlane at a wave-uniform lane index.
+// (Recomputing the rows at every visit, as the first version without LDS Row records did, made the rare envs
+// that take this path the tail of the whole launch.)
+struct SerialRows { Row my; float lja[3][RV_NLIMB], lmi[3][RV_NLIMB], llk[3]; };
+RV_DEV float rdl_u(float x, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src)); }
+RV_DEV Row serial_pull_row(const SerialRows& R, const int src) {
+  Row r;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      r.dir[k][x] = rdl_u(R.my.dir[k][x], src); r.rxa[k][x] = rdl_u(R.my.rxa[k][x], src); r.rxb[k][x] = rdl_u(R.my.rxb[k][x], src);
+      r.aa[k][x] = rdl_u(R.my.aa[k][x], src); r.ab[k][x] = rdl_u(R.my.ab[k][x], src);
+    }
+    r.invk[k] = rdl_u(R.my.invk[k], src); r.vbc[k] = rdl_u(R.my.vbc[k], src); r.jf[k] = rdl_u(R.my.jf[k], src);
+  }
+  r.target = rdl_u(R.my.target, src); r.mu = rdl_u(R.my.mu, src); r.cap = rdl_u(R.my.cap, src);
+  r.fidx = __builtin_amdgcn_readlane(R.my.fidx, src);
+  return r;
+}
+RV_DEV void serial_pull_limb(const SerialRows& R, const int src, float (*pja)[RV_NLIMB], float (*pmi)[RV_NLIMB], float* plk) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int x = 0; x < RV_NLIMB; ++x) { pja[k][x] = rdl_u(R.lja[k][x], src); pmi[k][x] = rdl_u(R.lmi[k][x], src); }
+    plk[k] = rdl_u(R.llk[k], src);
+  }
+}
+RV_DEV void serial_rows_setup(const Shared& S, const Consts& K, const int limb, SerialRows& R) {
+  const DevEnv& e = S.e;
+  const int lane = (int)threadIdx.x;
+  const int L = lane < RV_NMAN * 4 ? lane : RV_NMAN * 4 - 1;
+  const int mi = L >> 2, i = L & 3;
+  int kind, a, b;
+  man_owner(mi, &kind, &a, &b);
+  const DevMan& m = e.man[mi];
+  const bool use = lane < RV_NMAN * 4 && body_on(e, a) && (kind != 1 || body_on(e, b)) && i < m.n;
+  ManPoint pt;
+  pt.la = ld3(m.la[i]); pt.lb = ld3(m.lb[i]); pt.nrm = ld3(m.nrm[i]); pt.dist = m.dist[i]; pt.col = m.col[i];
+  if (!use) pt.col = 0;                                  // (a stale collider index of an empty slot must not index anything)
+  row_setup(S, K, kind, a, b, pt, R.my, m.n);            // (lanes without a point compute a row nobody asks for)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int x = 0; x < RV_NLIMB; ++x) { R.lja[k][x] = 0.0f; R.lmi[k][x] = 0.0f; }
+    R.llk[k] = 0.0f;
+  }
+  if (limb && kind == 2 && use) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) limb_point_row(S, K, a, i, k, R.lja[k], R.lmi[k], &R.llk[k]);
+  }
+}
+#define RV_SERIAL_ROWS_ARG , const SerialRows& SR
+#else
+#define RV_SERIAL_ROWS_ARG
+#endif
+RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb RV_SERIAL_ROWS_ARG) {
   DevEnv& e = S.e; const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
   float dq[RV_NLIMB], lam_l[RV_NLIMB];
 #pragma unroll
@@ -1330,11 +1377,17 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb) {
         const int mi = kind == 0 ? RV_TIDX(b) : RV_AIDX(b);
         DevMan& m = e.man[mi];
         for (int i = 0; i < m.n; ++i) {
-          Row r = fetch_row(S, K, mi, i);
-          Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
           const int la = limb && kind == 1;
           float pja[3][RV_NLIMB], pmi[3][RV_NLIMB], plk[3];
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+          const int src = __builtin_amdgcn_readfirstlane(mi * 4 + i);
+          Row r = serial_pull_row(SR, src);
+          if (la) serial_pull_limb(SR, src, pja, pmi, plk);
+#else
+          Row r = fetch_row(S, K, mi, i);
           if (la) { for (int kk = 0; kk < 3; ++kk) limb_point_row(S, K, b, i, kk, pja[kk], pmi[kk], &plk[kk]); }
+#endif
+          Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
           if (it < 0) {
             warm_apply(A, nullptr, ima, 0.0f, l, r);
             if (r.fidx >= 0) { qf[r.fidx] += r.jf[0] * l.n * imf; qf[r.fidx] += r.jf[1] * l.t1 * imf; qf[r.fidx] += r.jf[2] * l.t2 * imf; }
@@ -1357,7 +1410,11 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb) {
         BV A = ld_bv(e, a_), B = ld_bv(e, b_);
         const float ima = e.inv_mass[a_], imb = e.inv_mass[b_];
         for (int i = 0; i < m.n; ++i) {
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+          Row r = serial_pull_row(SR, __builtin_amdgcn_readfirstlane(RV_BBIDX(k) * 4 + i));
+#else
           Row r = fetch_row(S, K, RV_BBIDX(k), i);
+#endif
           Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
           if (it < 0) warm_apply(A, &B, ima, imb, l, r);
           else { res = fmaxr(res, point_solve(A, &B, ima, imb, l, r)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
@@ -3766,9 +3823,19 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   any_con |= limb;
   if (limb) limb_prepare(S, K, fing_fast ? the_body : -1);
   if (((with_fingers || limb) && !fing_fast) || (any_con && !limb)) {
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+    {
+      SerialRows SR;
+      serial_rows_setup(S, K, limb, SR);
+      __syncthreads();
+      solve_with_fingers(S, K, limb, SR);      // (every lane: see SerialRows)
+      __syncthreads();
+    }
+#else
     RV_LANES_BEGIN
       if (lane == 0) solve_with_fingers(S, K, limb);
     RV_LANES_END
+#endif
   }
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
   if (fing_fast) solve_island_fingers(S, K, __builtin_amdgcn_readfirstlane(the_body), with_fingers, limb);
