@@ -214,6 +214,9 @@ struct Scratch {
   int jt_applied;                        // the motor targets hold the current joint target (per launch)
   int atflag[RV_NCOL];                   // collider box may be within the contact-query distance of the table
   int kin_fresh;                         // FK / collider scratch matches the joint state (per launch)
+  // "arm far" substeps (sim_substep_light): joint path lengths since the collider boxes were last computed, whether
+  // those boxes exist at all in this launch, substeps taken far since then, and this substep's verdict
+  float ftravel[RV_NJ]; int far_valid, far_n, far;
   int nearf[RV_MAXB][RV_NCOL], bnear[RV_MAXB], near_any;   // wake test stage 1 -> stage 2
   float sep[RV_MAXB][RV_NCOL], coltravel[RV_NCOL];          // distance-bound culling of the wake queries
   float cdelta[3][RV_NCOL];                                 // coasting: box travel bound per candidate length
@@ -2415,10 +2418,11 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
         S.s.jmoving[j] = fabsr(qd) > 1e-3f;
         if (j < RV_NLIMB) stq(S.s.lq[j], joint_local_quat(arm, j, qn));
       }
-      if (count_step) {
+      if (count_step == 1) {
         S.s.jtravel[j] += fabsr(qd) * dt;      // coasting: path length of the joint
         if (j == 0) { e.sim_steps++; e.substeps_last++; }
       }
+      if (count_step == 2) S.s.ftravel[j] += fabsr(qd) * dt;   // an "arm far" substep: the boxes are not recomputed
     }
   RV_LANES_END
 }
@@ -2531,7 +2535,8 @@ RV_DEV void arm_collider_phases(Shared& S, const Consts& K, const int arm_on) {
         S.s.coltravel[col] = tr * 1.02f + 1e-7f;
       }
     }
-    if (lane == 63) { S.s.kin_fresh = arm_on; S.s.clr_valid = 0; }   // left-over clearances are for coasting chains only
+    if (lane == 63) { S.s.kin_fresh = arm_on; S.s.clr_valid = 0; S.s.far_valid = arm_on; }   // left-over clearances are for coasting chains only
+    if (lane >= 32 && lane < 32 + RV_NJ) S.s.ftravel[lane - 32] = 0.0f;
   RV_LANES_END
 }
 // the eight world vertices of collider box col (lane k < 8 of the caller's choice)
@@ -3280,6 +3285,79 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   // bodies to come to rest) has the frames, collider boxes and table flags of the last substep:
   // only the per-substep flags are reset.  Exact: the skipped phases would recompute the same values.
   int arm_static = 0;
+  // "Arm far": while a body is awake but no collider box can be within contact / wake range of any body or of the
+  // table -- judged on the boxes as last computed, inflated by what the joints have travelled since plus what they
+  // can travel in this substep -- the arm's frames are not needed: no arm - body or arm - table query would run,
+  // no sleeper would be woken by it.  Such a substep moves the joints only (control update + motors); forward
+  // kinematics, collider boxes, arm wake tests and link twists wait until a box may be near something or somebody
+  // needs the frames (kin_fresh = 0).  Exact: every skipped test would have said "no".  (Without deactivation --
+  // the reference's most likely semantics -- the arm is far in ~80 % of the substeps.)
+  int far = 0;
+#if !defined(__HIPCC__) || defined(RV_EMULATE)
+  static const int rv_no_far = getenv("RV_NO_FAR") != nullptr;     // (host emulation: debugging aid)
+#else
+  const int rv_no_far = 0;
+#endif
+  if (arm_on && K.stop_after == 0 && S.s.far_valid && !rv_no_far && !c->finger_dynamics && !c->limb_dynamics) {
+    int ok = 0;
+#pragma unroll
+    for (int b = 0; b < RV_MAXB; ++b) ok |= body_on(S.e, b);
+#pragma unroll
+    for (int b = 0; b < RV_MAXB; ++b) if (S.e.man[RV_AIDX(b)].n != 0) ok = 0;
+    if (ok) {
+      int near_any = 0;
+      RV_LANES_BEGIN
+        const DevEnv& e = S.e; const rv_arm* arm = K.arm;
+        int near = 0;
+        if (lane < RV_MAXB * RV_NCOL + RV_NCOL) {
+          const int isb = lane < RV_MAXB * RV_NCOL;
+          const int b = isb ? lane / RV_NCOL : 0, col = isb ? lane - b * RV_NCOL : lane - RV_MAXB * RV_NCOL;
+          // travel bound of a vertex of the box: chain lever x joint path (so far, plus this substep's worst case)
+          float T = 0.0f;
+#pragma unroll
+          for (int j = 0; j < RV_NJ; ++j) T = T + S.s.ccoef[col][j] * (S.s.ftravel[j] + (fabsr(e.qd[j]) + arm->a_max[j] * c->dt) * c->dt);
+          T = T * 1.02f + 1e-4f;
+          float lo[3], hi[3];
+#pragma unroll
+          for (int x = 0; x < 3; ++x) { lo[x] = S.s.colmin[col][x] - T; hi[x] = S.s.colmax[col][x] + T; }
+          if (isb) {
+            if (body_present(e, b)) {
+              if (e.asleep[b]) {
+                const float r = wake_range(e, arm, c, b, col) + 2.0f * c->margin;
+                near = aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, lo, hi) < r * r;
+              } else {
+                // (the body itself moves before the heavy part looks: its travel of this substep is bounded by its speed
+                // after gravity; 2 x that and 1 mm for the velocity the solver may add)
+                const float vb = (len(ld3(e.body[b] + 7)) + len(ld3(e.body[b] + 10)) * e.radius[b] + fabsr(c->gravity_z) * c->dt) * c->dt;
+                const float r = e.radius[b] + brk_ab(e, arm, c, b, col) + 2.0f * vb + 1e-3f;
+                near = !(sphere_aabb_dist2(ld3(e.body[b]), lo, hi) >= r * r);
+              }
+            }
+          } else {
+            // the arm - table gate: the box stays above the contact-query distance of the table top
+            near = !(lo[2] - e.table_z - c->margin >= c->contact_query_dist);
+          }
+        }
+#if defined(__HIPCC__) && !defined(RV_EMULATE)
+        near_any = __builtin_amdgcn_ballot_w64(near != 0) != 0;
+#else
+        near_any |= near;
+#endif
+      RV_LANES_END
+      far = !near_any;
+    }
+  }
+  if (far) {
+    arm_motor_phases(S, K, 0, 2);
+    RV_PROF(40)
+    RV_LANES_BEGIN
+      if (lane < RV_MAXB) { S.s.wake[lane] = 0; S.s.bnear[lane] = 0; }
+      if (lane == 8) S.s.near_any = 0;
+      if (lane == 9) S.s.arm_moving = 0;
+      if (lane >= 16 && lane < 16 + RV_NCOL) { S.s.colflag[lane - 16] = 0; S.s.atflag[lane - 16] = 0; }
+      if (lane == 63) { S.s.kin_fresh = 0; S.s.clr_valid = 0; S.s.far = 1; S.s.far_n = S.s.far_n + 1; }
+    RV_LANES_END
+  } else
   if (arm_on) {
     arm_motor_phases(S, K, 1, 0);
     RV_PROF(40)
@@ -3301,7 +3379,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
       if (lane >= 16 && lane < 16 + RV_NCOL) { S.s.colflag[lane - 16] = 0; S.s.coltravel[lane - 16] = 0.0f * 1.02f + 1e-7f; }
       if (lane == 63) S.s.clr_valid = 0;
     RV_LANES_END
-  } else {
+  } else if (!far) {
     arm_collider_phases(S, K, arm_on);
   }
   RV_PROF(42)
@@ -3321,6 +3399,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
       // distance query, minus the box's travel since (a sleeper does not move); while it
       // is positive the query cannot hit and is skipped.  Exact: only the work changes.
       float sep = S.s.sep[b][col] - S.s.coltravel[col];
+      if (S.s.far_n != 0) sep = 0.0f;        // ("arm far" substeps did not keep the bound up to date: it starts again)
       if (arm_on && S.s.arm_moving && body_present(e, b) && e.asleep[b]) {
         float r = wake_range(e, K.arm, c, b, col) + 2.0f * c->margin;
         nr = aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col]) < r * r;
@@ -3435,7 +3514,8 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   RV_LANES_END
   RV_LANES_BEGIN
 #endif
-    if (arm_on && lane >= 16 && lane < 16 + RV_NFRAME) arm_twist_lane(S, K, lane - 16);
+    if (arm_on && !far && lane >= 16 && lane < 16 + RV_NFRAME) arm_twist_lane(S, K, lane - 16);
+    if (lane == 6) { S.s.far = far; if (!far) S.s.far_n = 0; }
     if (lane < RV_MAXB) {
       int b = lane; DevEnv& e = S.e;
 #if !defined(__HIPCC__) || defined(RV_EMULATE)
@@ -3495,7 +3575,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
 RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   const rv_config* c = K.cfg;
   const rv_arm* arm = K.arm;
-  const int arm_on = S.e.arm_enabled;
+  const int arm_on = S.e.arm_enabled && !S.s.far;     // ("arm far" substep: no box can be near anything, the frames are stale)
   // (the link twists are computed by idle lanes of the last light phase, arm_twist_lane)
   RV_STOP(2)
   RV_PROF(2)
@@ -4947,7 +5027,7 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
     DevEnv& e = S.e;
     if (lane == 0) {
       // per-launch scratch state that a reset kernel does not get from env_enter
-      S.s.jt_applied = 0; S.s.kin_fresh = 0; S.s.clr_valid = 0; S.s.bud_sub = 0; S.s.bud_clk = 0; S.s.suspended = 0; S.s.wus_resume = 0;
+      S.s.jt_applied = 0; S.s.kin_fresh = 0; S.s.clr_valid = 0; S.s.bud_sub = 0; S.s.bud_clk = 0; S.s.suspended = 0; S.s.wus_resume = 0; S.s.far_valid = 0; S.s.far_n = 0; S.s.far = 0;
       e.in_step = 0; e.step_stage = -1;
       S.s.rng = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RESET, (uint32_t)e.reset_count);
       e.reset_count++;
@@ -5161,7 +5241,7 @@ RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int fi
 // rebuild the per-launch caches that are not part of the persistent block
 RV_DEV void env_enter(Shared& S, const Consts& K) {
   RV_LANES_BEGIN
-    if (lane == 63) { S.s.jt_applied = 0; S.s.kin_fresh = 0; S.s.clr_valid = 0; S.s.bud_sub = 0; S.s.bud_clk = 0; S.s.suspended = 0; S.s.wus_resume = 0; }
+    if (lane == 63) { S.s.jt_applied = 0; S.s.kin_fresh = 0; S.s.clr_valid = 0; S.s.bud_sub = 0; S.s.bud_clk = 0; S.s.suspended = 0; S.s.wus_resume = 0; S.s.far_valid = 0; S.s.far_n = 0; S.s.far = 0; }
     if (lane < RV_MAXB * RV_NCOL) S.s.sep[lane / RV_NCOL][lane % RV_NCOL] = 0.0f;
     if (lane < 8) table_prepare(S, K, lane);
     if (lane >= 48 && lane < 48 + RV_NLIMB + 1) { int i = lane - 48; S.s.jlen[i] = len(ld3(K.arm->jpos[i])); }
