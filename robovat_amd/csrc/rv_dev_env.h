@@ -30,7 +30,11 @@ namespace rv {
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
 #define RV_LANES_BEGIN { const int lane = (int)threadIdx.x;
 #define RV_LANES_END } __syncthreads();
+// a value every lane holds alike (read from the env's LDS block), moved to the scalar unit so that the control flow
+// that hangs on it is compiled as uniform
+#define RV_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
 #else
+#define RV_UNI(x) ((int)(x))
 #define RV_LANES_BEGIN for (int lane = 0; lane < 64; ++lane) {
 #define RV_LANES_END }
 #endif
@@ -4306,14 +4310,6 @@ RV_DEV Consts lds_consts(const rv_scene* scene, int stop_after) {
   Consts K; K.cfg = &g_shared.cfg; K.arm = &g_shared.arm; K.scene = scene; K.stop_after = stop_after;
   return K;
 }
-// The heavy part (contacts, solver) is a function of its own: it needs every
-// register and pays a large callee-saved spill in its prologue, so it is entered
-// only when the light part (arm, wake test, quiet check) says so.
-RV_DEV void sim_substep_heavy_call(const rv_scene* scene, int stop_after) {
-  Consts K = lds_consts(scene, stop_after);
-  sim_substep_heavy(g_shared, K);
-}
-
 // Simulator.check_stable over a body mask (simulator.py:289-323)
 RV_DEV int bodies_stable(const DevEnv& e, unsigned mask, float lin_thr, float ang_thr) {
   for (int b = 0; b < RV_MAXB; ++b) {
@@ -4338,10 +4334,28 @@ RV_DEV void gphase_tick(Shared& S, const Consts& K);
 //   n_fixed < 0 : the phase loop of PushEnv._execute_action (push_env.py:648-719: step
 //                 until the next multiple of STEPS_CHECK, phase_tick, until 'done'),
 //                 followed by its closing wait_until_stable -- one call per env.step()
-RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_arg, unsigned mask,
-                                  float lin_thr, float ang_thr, int check_after, int min_stable, int max_steps) {
-  Consts K = lds_consts(scene, stop_after);
-  Shared& S = g_shared;
+#ifdef RV_HEAVY_NOINLINE      // (an option of the two-waves-per-SIMD build: the heavy part as a function of its own)
+RV_DEV_NOINLINE void sim_substep_heavy_call(Shared& S, const Consts& K) { sim_substep_heavy(S, K); }
+#endif
+// What one run of the substep loop is asked to do (the arguments of the former sim_run_call)
+struct RunReq { int n_arg; unsigned mask; float lin_thr, ang_thr; int check_after, min_stable, max_steps; };
+RV_DEV RunReq run_req(int n_arg, unsigned mask = 0u, float lin = 0.0f, float ang = 0.0f, int ca = 0, int ms = 0, int mx = 0) {
+  RunReq r; r.n_arg = n_arg; r.mask = mask; r.lin_thr = lin; r.ang_thr = ang; r.check_after = ca; r.min_stable = ms; r.max_steps = mx;
+  return r;
+}
+// The substep loop.  It exists ONCE in every env kernel: env_program() -- the reset / env.step() / rollout logic
+// written as a resumable program -- hands it one request after the other from a single call site, so nothing of it
+// is a function call (until round 4 it was an out-of-line function entered per env.step(), and its heavy part a
+// second one entered per awake substep: each call saved and restored ~200 registers through scratch memory).
+#ifdef RV_SIM_RUN_NOINLINE     // (the two-waves-per-SIMD build: a function boundary splits the register allocation under its 256-register cap)
+RV_DEV_NOINLINE
+#else
+RV_DEV
+#endif
+void sim_run(Shared& S, const Consts& K, const RunReq& rq) {
+  const rv_scene* scene = K.scene; const int stop_after = K.stop_after; (void)scene; (void)stop_after;
+  const int n_arg = rq.n_arg; const unsigned mask = rq.mask; const float lin_thr = rq.lin_thr, ang_thr = rq.ang_thr;
+  const int check_after = rq.check_after, min_stable = rq.min_stable, max_steps = rq.max_steps;
   int phase_mode = n_arg < 0;
   const int grasp_mode = n_arg == -2;     // Grasp4DofEnv: its phase machine looks at the world after EVERY substep
   // rv_step_poll: a budget of substeps and / or shader clocks for this launch; the call may return
@@ -4486,7 +4500,11 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
     if (sim_substep_light(S, K)) {
       RV_CNT(10, 1)
       RV_PROF(1)
-      sim_substep_heavy_call(scene, stop_after);
+#ifdef RV_HEAVY_NOINLINE
+      sim_substep_heavy_call(S, K);
+#else
+      sim_substep_heavy(S, K);
+#endif
       RV_PROF(6)
     } else {
       RV_PROF(0)
@@ -4526,15 +4544,6 @@ RV_DEV_NOINLINE void sim_run_call(const rv_scene* scene, int stop_after, int n_a
     RV_LANES_END
   }
 }
-RV_DEV void sim_steps_call(const Consts& K, int n) {
-  if (n > 0) sim_run_call(K.scene, K.stop_after, n, 0u, 0.0f, 0.0f, 0, 0, 0);
-}
-RV_DEV void wait_until_stable(Shared& S, const Consts& K, unsigned mask, float lin_thr, float ang_thr,
-                              int check_after, int min_stable, int max_steps) {
-  (void)S;
-  sim_run_call(K.scene, K.stop_after, 0, mask, lin_thr, ang_thr, check_after, min_stable, max_steps);
-}
-
 // ------------------------------------------------- observation / reward --
 RV_DEV void compute_obs(DevEnv& e) {
   for (int b = 0; b < RV_MAXB; ++b)
@@ -4824,16 +4833,10 @@ RV_DEV void env_step_epilogue(Shared& S, const Consts& K) {
   RV_LANES_END
   RV_PROF(31)
 }
-RV_DEV void env_step(Shared& S, const Consts& K, int zero_counters = 1) {
-  env_step_prologue(S, K, zero_counters, 1);
-  // phase loop + closing wait_until_stable, in one out-of-line call
-  sim_run_call(K.scene, K.stop_after, -1, 0u, 0.005f, 0.005f, 100, 100, 2000);
-  RV_PROF(30)
-  env_step_epilogue(S, K);
-}
-// rv_step_poll: the env.step() this env is in the middle of (S.e.in_step == 1), continued within
-// the budget set in S.s.bud_*; returns 1 when the step completed in this launch
-RV_DEV int env_step_partial(Shared& S, const Consts& K) {
+// (env.step() = env_step_prologue, one run of the substep loop with run_req(-1, ...), env_step_epilogue: env_program)
+// rv_step_poll: the env.step() this env is in the middle of (S.e.in_step == 1), continued within the budget set
+// in S.s.bud_*: what comes before the run of the substep loop ...
+RV_DEV void env_pstep_begin(Shared& S, const Consts& K) {
   if (S.e.step_stage < 0) env_step_prologue(S, K, 0, 0);
   else {
     RV_LANES_BEGIN
@@ -4846,7 +4849,9 @@ RV_DEV int env_step_partial(Shared& S, const Consts& K) {
       }
     RV_LANES_END
   }
-  sim_run_call(K.scene, K.stop_after, -1, 0u, 0.005f, 0.005f, 100, 100, 2000);
+}
+// ... and after it; returns 1 when the step completed in this launch
+RV_DEV int env_pstep_end(Shared& S, const Consts& K) {
   if (S.s.suspended) {
     RV_LANES_BEGIN
       if (lane == 0) {
@@ -4935,7 +4940,9 @@ RV_DEV void gphase_tick(Shared& S, const Consts& K) {
 // RobotEnv.step (robot_env.py:239-275) for Grasp4DofEnv: _execute_action (grasp_4dof_env.py:213-293),
 // observation, GraspReward.get_reward (grasp_reward.py:49-68: wait until the object is stable, success =
 // the arm still touches it; the episode ends after one grasp)
-RV_DEV void genv_step(Shared& S, const Consts& K, int zero_counters = 1) {
+// (three segments around two runs of the substep loop -- run_req(-2): the phase loop; then the reward's
+// wait_until_stable -- see env_program)
+RV_DEV void genv_step_begin(Shared& S, const Consts& K, int zero_counters) {
   const rv_config* c = K.cfg;
   RV_LANES_BEGIN
     if (lane == 0) {
@@ -4950,11 +4957,13 @@ RV_DEV void genv_step(Shared& S, const Consts& K, int zero_counters = 1) {
       e.phase = RV_GPHASE_INITIAL; e.num_action_steps = 0;
     }
   RV_LANES_END
-  sim_run_call(K.scene, K.stop_after, -2, 0u, 0.0f, 0.0f, 0, 0, 0);
+}
+RV_DEV void genv_step_observe(Shared& S) {
   RV_LANES_BEGIN
     if (lane == 0) { S.e.num_steps++; compute_obs(S.e); }
   RV_LANES_END
-  wait_until_stable(S, K, 0u, 0.005f, 0.005f, 100, 100, 2000);
+}
+RV_DEV void genv_step_end(Shared& S) {
   RV_LANES_BEGIN
     if (lane == 0) {
       DevEnv& e = S.e;
@@ -5020,8 +5029,9 @@ RV_DEV void sample_poses(Shared& S, const Consts& K, int nb) {
   }
 }
 
-// RobotEnv.reset for one env (robot_env.py:204-237)
-RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1) {
+// RobotEnv.reset for one env (robot_env.py:204-237), in the segments env_program runs between the settle waits
+// (each wait is one request to the substep loop).  (1) counters, table height, body count; Grasp4DofEnv: its object
+RV_DEV void env_reset_begin(Shared& S, const Consts& K, int gid, int zero_counters) {
   const rv_config* c = K.cfg;
   RV_LANES_BEGIN
     DevEnv& e = S.e;
@@ -5072,54 +5082,62 @@ RV_DEV void env_reset(Shared& S, const Consts& K, int gid, int zero_counters = 1
       }
     RV_LANES_END
   }
-  // PushEnv._load_movable_bodies (push_env.py:399-471)
-  while (!S.s.valid) {
-    RV_LANES_BEGIN
-      DevEnv& e = S.e;
-      if (lane == 0) {
-        for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; e.con_on[b] = 0; }
-        sample_poses(S, K, e.n_bodies);
-      }
-      if (lane >= 1 && lane <= RV_NMAN) e.man[lane - 1].n = 0;
-    RV_LANES_END
-    const int nb = S.e.n_bodies;
-    for (int i = 0; i < nb; ++i) {
-      RV_LANES_BEGIN
-        if (lane == 0) {
-          DevEnv& e = S.e; Rng& g = S.s.rng;
-          int use_target = (i == 0 && c->use_tiles && c->n_target > 0 && c->n_target_shapes > 0);
-          int shape = use_target ? c->target_shapes[rng_randint(g, c->n_target_shapes)]
-                                 : c->movable_shapes[rng_randint(g, c->n_movable_shapes)];
-          float sc = rng_uniform(g, c->scale_range[0], c->scale_range[1]);
-          e.active[i] = 1; e.frozen[i] = 0; e.asleep[i] = 0; e.sleep_count[i] = 0; e.deact_count[i] = 0; e.still_count[i] = 0; e.undisturbed[i] = 0; e.shape[i] = shape; e.scale[i] = sc; e.friction[i] = c->drop_friction;
-          body_set_mass(e, K, i, c->drop_mass);
-          cache_shape_meta(S, K, i);
-          for (int k = 0; k < 3; ++k) e.body[i][k] = S.s.poses[i][k];
-          for (int k = 0; k < 4; ++k) e.body[i][3 + k] = S.s.poses[i][3 + k];
-          for (int k = 7; k < 13; ++k) e.body[i][k] = 0.0f;
-        }
-      RV_LANES_END
-      RV_PROF(28)
-      wait_until_stable(S, K, 1u << i, 0.1f, 0.1f, 100, 100, 500);
-      RV_LANES_BEGIN
-        if (lane == 0) {
-          DevEnv& e = S.e; Rng& g = S.s.rng;
-          float mass = rng_uniform(g, c->mass_range[0], c->mass_range[1]);
-          float fr = rng_uniform(g, c->friction_range[0], c->friction_range[1]);
-          body_set_mass(e, K, i, mass); e.friction[i] = fr;
-        }
-      RV_LANES_END
+}
+// (2) PushEnv._load_movable_bodies (push_env.py:399-471): a new layout (while the last one was not valid)
+RV_DEV void env_reset_layout(Shared& S, const Consts& K) {
+  RV_LANES_BEGIN
+    DevEnv& e = S.e;
+    if (lane == 0) {
+      for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; e.con_on[b] = 0; }
+      sample_poses(S, K, e.n_bodies);
     }
-    RV_LANES_BEGIN
-      if (lane == 0) {
-        int valid = 1;
-        for (int i = 0; i < nb; ++i) if (S.e.body[i][2] < S.e.table_z) valid = 0;
-        S.s.valid = valid;
-      }
-    RV_LANES_END
-  }
-  RV_PROF(28)
-  wait_until_stable(S, K, 0u, 0.005f, 0.005f, 100, 100, 2000);
+    if (lane >= 1 && lane <= RV_NMAN) e.man[lane - 1].n = 0;
+  RV_LANES_END
+}
+// (3) body i is dropped; then wait_until_stable(body i, 0.1, 0.1, 100, 100, 500)
+RV_DEV void env_reset_place(Shared& S, const Consts& K, const int i) {
+  const rv_config* c = K.cfg;
+  RV_LANES_BEGIN
+    if (lane == 0) {
+      DevEnv& e = S.e; Rng& g = S.s.rng;
+      int use_target = (i == 0 && c->use_tiles && c->n_target > 0 && c->n_target_shapes > 0);
+      int shape = use_target ? c->target_shapes[rng_randint(g, c->n_target_shapes)]
+                             : c->movable_shapes[rng_randint(g, c->n_movable_shapes)];
+      float sc = rng_uniform(g, c->scale_range[0], c->scale_range[1]);
+      e.active[i] = 1; e.frozen[i] = 0; e.asleep[i] = 0; e.sleep_count[i] = 0; e.deact_count[i] = 0; e.still_count[i] = 0; e.undisturbed[i] = 0; e.shape[i] = shape; e.scale[i] = sc; e.friction[i] = c->drop_friction;
+      body_set_mass(e, K, i, c->drop_mass);
+      cache_shape_meta(S, K, i);
+      for (int k = 0; k < 3; ++k) e.body[i][k] = S.s.poses[i][k];
+      for (int k = 0; k < 4; ++k) e.body[i][3 + k] = S.s.poses[i][3 + k];
+      for (int k = 7; k < 13; ++k) e.body[i][k] = 0.0f;
+    }
+  RV_LANES_END
+}
+// (4) ... and gets its mass and friction
+RV_DEV void env_reset_after_body(Shared& S, const Consts& K, const int i) {
+  const rv_config* c = K.cfg;
+  RV_LANES_BEGIN
+    if (lane == 0) {
+      DevEnv& e = S.e; Rng& g = S.s.rng;
+      float mass = rng_uniform(g, c->mass_range[0], c->mass_range[1]);
+      float fr = rng_uniform(g, c->friction_range[0], c->friction_range[1]);
+      body_set_mass(e, K, i, mass); e.friction[i] = fr;
+    }
+  RV_LANES_END
+}
+// (5) a body that ended below the table top invalidates the layout
+RV_DEV void env_reset_validate(Shared& S, const int nb) {
+  RV_LANES_BEGIN
+    if (lane == 0) {
+      int valid = 1;
+      for (int i = 0; i < nb; ++i) if (S.e.body[i][2] < S.e.table_z) valid = 0;
+      S.s.valid = valid;
+    }
+  RV_LANES_END
+}
+// (6) after the closing wait_until_stable(all, 0.005, 0.005, 100, 100, 2000): the robot
+RV_DEV void env_reset_robot(Shared& S, const Consts& K) {
+  const rv_config* c = K.cfg;
   // ArmEnv._reset_robot (arm_env.py:101-107) -> SawyerSim.reboot (sawyer_sim.py:86-171)
   RV_LANES_BEGIN
     if (lane == 0) {
@@ -5169,73 +5187,194 @@ RV_DEV void random_action(const rv_config* c, int gid, int macro_index, float* a
     a[3] = RV_PI * (a[3] + 1.0f);
   }
 }
-// generate_episode's inner loop with the on-device RandomPolicy
-// (episode_generation.py:44-46, random_policy.py:14-23): n_steps env.step()
-// calls back to back for this env; see rv_rollout() in include/rovat.h.
-// budget != nullptr: asynchronous rollout.  The envs of the launch share a pool of
-// env.step() calls; each env takes its next step while the pool lasts, so fast
-// envs take more steps than slow ones and no SIMD idles (the reference's worker
-// processes are just as independent, tools/parallel_run.py:54-90).  The k-th step
-// an env takes in the launch uses macro index first_index + k as before.
-RV_DEV void env_rollout(Shared& S, const Consts& K, int gid, int n_steps, int first_index, int auto_reset,
-                        const RolloutRec& rec, int env, int n_envs, int* budget = nullptr) {
+// ---- the env program ------------------------------------------------------------------------------
+// Everything an env kernel does -- RobotEnv.reset, env.step() for PushEnv and Grasp4DofEnv, the rollout loop
+// of generate_episode with the on-device RandomPolicy (episode_generation.py:44-46, random_policy.py:14-23),
+// n plain substeps, wait_until_stable, the partial step of rv_step_poll -- written as ONE resumable program:
+// straight-line segments (the functions above) between REQUESTS to the substep loop.  The driver below runs a
+// segment, and when the segment ends on a request, the loop -- from a single call site, so sim_run() is inlined
+// once per kernel and no function call (with its register save / restore through scratch) is left on the path.
+// Rollout: n_steps x { action = policy(obs); env.step(action) } for this env; budget != nullptr: asynchronous
+// rollout -- the envs of the launch share a pool of env.step() calls; each env takes its next step while the pool
+// lasts, so fast envs take more steps than slow ones and no SIMD idles (the reference's worker processes are just
+// as independent, tools/parallel_run.py:54-90).  The k-th step an env takes uses macro index first_index + k.
+enum { RV_PROG_RESET = 0, RV_PROG_MACRO = 1, RV_PROG_SUB = 2, RV_PROG_WAIT = 3, RV_PROG_ROLLOUT = 4, RV_PROG_PARTIAL = 5 };
+struct ProgArgs {
+  int gid;                                   // global env id (reset, rollout)
+  int n_steps;                               // SUB: substeps; ROLLOUT: env.step() calls
+  float lin_thr, ang_thr; int check_after, min_stable, max_steps;   // WAIT
+  int first_index, auto_reset; RolloutRec rec; int env, n_envs; int* budget;   // ROLLOUT
+};
+// returns (RV_PROG_PARTIAL) 1 when the env.step() completed in this launch
+RV_DEV int env_program(Shared& S, const Consts& K, const int prog, const ProgArgs& A) {
   const rv_config* c = K.cfg;
-  RV_LANES_BEGIN
-    if (lane == 0) launch_counters_zero(S.e);
-  RV_LANES_END
-  int k_end = 0;
-  for (int k = 0; budget != nullptr || k < n_steps; ++k) {
-    if (budget != nullptr) {
-      RV_LANES_BEGIN
-        if (lane == 0) {
+  enum { PC_DONE = 0, PC_RESET_BEGIN, PC_RESET_LAYOUT, PC_RESET_BODY, PC_RESET_BODY_AFTER, PC_RESET_FINAL, PC_RESET_ROBOT,
+         PC_STEP_BEGIN, PC_STEP_END, PC_GSTEP_OBS, PC_GSTEP_END, PC_PSTEP_END,
+         PC_ROLL_TOP, PC_ROLL_ACTION, PC_ROLL_AFTER_STEP, PC_ROLL_TAIL };
+  int pc = PC_DONE, ret_reset = PC_DONE, ret_step = PC_DONE;
+  int reset_zero = 1, step_zero = 1;           // zero the per-launch counters (not inside a rollout)
+  int ri = 0, rnb = 0;                         // reset: body index, body count
+  int k = 0, k_end = 0, was_reset = 0;         // rollout
+  int fin = 0;
+  const int grasp = RV_UNI(c->env_type == RV_ENV_GRASP);
+  RunReq rq = run_req(0);
+  int run = 0;
+  if (prog == RV_PROG_RESET) pc = PC_RESET_BEGIN;
+  else if (prog == RV_PROG_MACRO) pc = PC_STEP_BEGIN;
+  else if (prog == RV_PROG_SUB) { if (A.n_steps > 0) { rq = run_req(A.n_steps); run = 1; } }
+  else if (prog == RV_PROG_WAIT) { rq = run_req(0, 0u, A.lin_thr, A.ang_thr, A.check_after, A.min_stable, A.max_steps); run = 1; }
+  else if (prog == RV_PROG_PARTIAL) { env_pstep_begin(S, K); rq = run_req(-1, 0u, 0.005f, 0.005f, 100, 100, 2000); run = 1; pc = PC_PSTEP_END; }
+  else {
+    RV_LANES_BEGIN
+      if (lane == 0) launch_counters_zero(S.e);
+    RV_LANES_END
+    reset_zero = 0; step_zero = 0;
+    pc = PC_ROLL_TOP;
+  }
+  for (;;) {
+    if (run) { sim_run(S, K, rq); run = 0; }        // THE call site of the substep loop
+    if (pc == PC_DONE) break;
+    switch (pc) {
+      // ---- RobotEnv.reset
+      case PC_RESET_BEGIN:
+        env_reset_begin(S, K, A.gid, reset_zero);
+        pc = PC_RESET_LAYOUT;
+        break;
+      case PC_RESET_LAYOUT:
+        if (RV_UNI(S.s.valid)) { pc = PC_RESET_FINAL; break; }
+        env_reset_layout(S, K);
+        rnb = RV_UNI(S.e.n_bodies); ri = 0;
+        pc = PC_RESET_BODY;
+        break;
+      case PC_RESET_BODY:
+        if (ri < rnb) {
+          env_reset_place(S, K, ri);
+          RV_PROF(28)
+          rq = run_req(0, 1u << ri, 0.1f, 0.1f, 100, 100, 500); run = 1;      // wait_until_stable(body)
+          pc = PC_RESET_BODY_AFTER;
+        } else {
+          env_reset_validate(S, rnb);
+          pc = PC_RESET_LAYOUT;
+        }
+        break;
+      case PC_RESET_BODY_AFTER:
+        env_reset_after_body(S, K, ri);
+        ++ri;
+        pc = PC_RESET_BODY;
+        break;
+      case PC_RESET_FINAL:
+        RV_PROF(28)
+        rq = run_req(0, 0u, 0.005f, 0.005f, 100, 100, 2000); run = 1;          // wait_until_stable(all)
+        pc = PC_RESET_ROBOT;
+        break;
+      case PC_RESET_ROBOT:
+        env_reset_robot(S, K);
+        pc = ret_reset;
+        break;
+      // ---- RobotEnv.step (robot_env.py:239-275)
+      case PC_STEP_BEGIN:
+        if (grasp) {
+          genv_step_begin(S, K, step_zero);
+          rq = run_req(-2); run = 1;                                           // the phase loop of Grasp4DofEnv
+          pc = PC_GSTEP_OBS;
+        } else {
+          env_step_prologue(S, K, step_zero, 1);
+          rq = run_req(-1, 0u, 0.005f, 0.005f, 100, 100, 2000); run = 1;       // phase loop + closing wait_until_stable
+          pc = PC_STEP_END;
+        }
+        break;
+      case PC_STEP_END:
+        RV_PROF(30)
+        env_step_epilogue(S, K);
+        pc = ret_step;
+        break;
+      case PC_GSTEP_OBS:
+        genv_step_observe(S);
+        rq = run_req(0, 0u, 0.005f, 0.005f, 100, 100, 2000); run = 1;          // GraspReward: wait until the object is stable
+        pc = PC_GSTEP_END;
+        break;
+      case PC_GSTEP_END:
+        genv_step_end(S);
+        pc = ret_step;
+        break;
+      case PC_PSTEP_END:
+        fin = RV_UNI(env_pstep_end(S, K));
+        pc = PC_DONE;
+        break;
+      // ---- the rollout loop
+      case PC_ROLL_TOP: {
+        if (!(A.budget != nullptr || k < A.n_steps)) { pc = PC_ROLL_TAIL; break; }
+        if (A.budget != nullptr) {
+          RV_LANES_BEGIN
+            if (lane == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
-          int left = atomicSub(budget, 1);
+              int left = atomicSub(A.budget, 1);
 #else
-          int left = (*budget)--;
+              int left = (*A.budget)--;
 #endif
-          S.s.loop_break = !(left > 0);
+              S.s.loop_break = !(left > 0);
+            }
+          RV_LANES_END
+          if (RV_UNI(S.s.loop_break)) { pc = PC_ROLL_TAIL; break; }
         }
-      RV_LANES_END
-      if (S.s.loop_break) break;
-    }
-    int was_reset = 0;
-    if (S.e.done) {
-      if (!auto_reset) break;
-      env_reset(S, K, gid, 0);
-      was_reset = 1;
-      RV_PROF(28)
-    }
-    RV_LANES_BEGIN
-      if (lane == 0) {
-        random_action(c, gid, first_index + k, &S.e.action[0][0]);
-        if (budget == nullptr) {
-          const size_t row = (size_t)k * n_envs + env;
-          if (rec.actions) {
-            const int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
-            for (int x = 0; x < G * 4; ++x) rec.actions[row * (size_t)(G * 4) + x] = (&S.e.action[0][0])[x];
-          }
-          if (rec.resets) rec.resets[row] = (uint8_t)was_reset;
-          if (was_reset) {      // what env.reset() returned (robot_env.py:204-237)
-            if (rec.has_robs) obs_write_row(&S.e, rec.robs, row, c);
-            if (rec.rsnaps) obs_snap_fill(S.e, K.arm, rec.rsnaps[row], 1);
-          }
+        was_reset = 0;
+        if (RV_UNI(S.e.done)) {
+          if (!A.auto_reset) { pc = PC_ROLL_TAIL; break; }
+          was_reset = 1;
+          ret_reset = PC_ROLL_ACTION;
+          pc = PC_RESET_BEGIN;
+          break;
         }
+        pc = PC_ROLL_ACTION;
+        break;
       }
-    RV_LANES_END
-    RV_PROF(20)
-    if (c->env_type == RV_ENV_GRASP) genv_step(S, K, 0); else env_step(S, K, 0);
-    RV_LANES_BEGIN
-      if (lane == 0 && budget == nullptr) rollout_record(rec, &S.e, (size_t)k * n_envs + env, c, K.arm);
-    RV_LANES_END
-    RV_PROF(23)
-    k_end = k + 1;
+      case PC_ROLL_ACTION:
+        if (was_reset) { RV_PROF(28) }
+        RV_LANES_BEGIN
+          if (lane == 0) {
+            random_action(c, A.gid, A.first_index + k, &S.e.action[0][0]);
+            if (A.budget == nullptr) {
+              const size_t row = (size_t)k * A.n_envs + A.env;
+              if (A.rec.actions) {
+                const int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
+                for (int x = 0; x < G * 4; ++x) A.rec.actions[row * (size_t)(G * 4) + x] = (&S.e.action[0][0])[x];
+              }
+              if (A.rec.resets) A.rec.resets[row] = (uint8_t)was_reset;
+              if (was_reset) {      // what env.reset() returned (robot_env.py:204-237)
+                if (A.rec.has_robs) obs_write_row(&S.e, A.rec.robs, row, c);
+                if (A.rec.rsnaps) obs_snap_fill(S.e, K.arm, A.rec.rsnaps[row], 1);
+              }
+            }
+          }
+        RV_LANES_END
+        RV_PROF(20)
+        ret_step = PC_ROLL_AFTER_STEP;
+        pc = PC_STEP_BEGIN;
+        break;
+      case PC_ROLL_AFTER_STEP:
+        RV_LANES_BEGIN
+          if (lane == 0 && A.budget == nullptr) rollout_record(A.rec, &S.e, (size_t)k * A.n_envs + A.env, c, K.arm);
+        RV_LANES_END
+        RV_PROF(23)
+        k_end = k + 1;
+        ++k;
+        pc = PC_ROLL_TOP;
+        break;
+      case PC_ROLL_TAIL:
+        // steps not taken (episode over, no auto-reset): reward 0, done
+        if (A.budget == nullptr) {
+          RV_LANES_BEGIN
+            for (int kk = k_end + lane; kk < A.n_steps; kk += 64) rollout_record(A.rec, nullptr, (size_t)kk * A.n_envs + A.env, c, K.arm);
+          RV_LANES_END
+        }
+        pc = PC_DONE;
+        break;
+      default:
+        pc = PC_DONE;
+        break;
+    }
   }
-  // steps not taken (episode over, no auto-reset): reward 0, done
-  if (budget == nullptr) {
-    RV_LANES_BEGIN
-      for (int k = k_end + lane; k < n_steps; k += 64) rollout_record(rec, nullptr, (size_t)k * n_envs + env, c, K.arm);
-    RV_LANES_END
-  }
+  return fin;
 }
 
 // rebuild the per-launch caches that are not part of the persistent block

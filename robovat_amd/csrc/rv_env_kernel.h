@@ -33,15 +33,20 @@ struct EnvKernelArgs {
   int32_t* steps_taken;          // optional [N]
   unsigned long long budget_clk; // MODE_PARTIAL: shader clocks this launch may spend per env (0: no limit)
   uint8_t* finished;             // MODE_PARTIAL: [N] 1 = the env.step() of this env completed in this launch
+  int mode;                      // k_env<-1>: which of the modes this launch is
 };
 
-template <int MODE>
+// TMODE = MODE_ROLLOUT: the single-launch rollout, a kernel of its own (it is the one bench.py times and the profiles
+// name); TMODE = -1: every other mode, picked at run time from args.mode -- the substep loop is inlined once per
+// kernel, so two instantiations instead of six keep the build at a minute
+template <int TMODE>
 #ifdef RV_WAVES_PER_EU      // experiment: cap the registers so that RV_WAVES_PER_EU waves fit a SIMD (tools/flag_variants.sh)
 #define RV_ENV_OCC __attribute__((amdgpu_waves_per_eu(RV_WAVES_PER_EU, RV_WAVES_PER_EU)))
 #else
 #define RV_ENV_OCC
 #endif
 __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
+  const int MODE = TMODE >= 0 ? TMODE : args.mode;
   Shared& S = g_shared;
   const int env = (int)blockIdx.x;
   if (env >= args.n_envs) return;
@@ -104,43 +109,37 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
     return;
   }
   if (MODE != MODE_RESET) env_enter(S, K);
-  if (MODE == MODE_RESET) {
-    env_reset(S, K, K.cfg->env_id_offset + env);
-  } else if (MODE == MODE_MACRO) {
-    if (lane == 0) launch_counters_zero(S.e);
-    __syncthreads();
-    if (K.cfg->env_type == RV_ENV_GRASP) genv_step(S, K); else env_step(S, K);
-  } else if (MODE == MODE_ROLLOUT) {
-    env_rollout(S, K, K.cfg->env_id_offset + env, args.n_substeps, args.first_index, args.auto_reset, args.rec, env, args.n_envs, args.budget);
-    if (lane == 0 && args.steps_taken) args.steps_taken[env] = S.e.stepped;
-  } else if (MODE == MODE_PARTIAL && S.e.in_step == 2) {
-    // rv_set_auto_reset: the step was begun on a finished episode -> env.reset(); the poll hands back what it returns
-    env_reset(S, K, K.cfg->env_id_offset + env);
-    __syncthreads();
-    if (lane == 0) {
-      S.e.in_step = 0; S.e.reward_valid = 0; S.e.last_reward = 0.0f;
-      if (args.finished) args.finished[env] = 1;
-      rollout_record(args.rec, &S.e, (size_t)env, &S.cfg, &S.arm);
-    }
-  } else if (MODE == MODE_PARTIAL) {
+  ProgArgs pa;
+  pa.gid = K.cfg->env_id_offset + env; pa.n_steps = args.n_substeps;
+  pa.lin_thr = args.lin_thr; pa.ang_thr = args.ang_thr; pa.check_after = args.check_after; pa.min_stable = args.min_stable; pa.max_steps = args.max_steps;
+  pa.first_index = args.first_index; pa.auto_reset = args.auto_reset; pa.rec = args.rec; pa.env = env; pa.n_envs = args.n_envs; pa.budget = args.budget;
+  // ONE call of the env program per kernel (it holds the only copy of the substep loop)
+  const int resetting = MODE == MODE_PARTIAL && RV_UNI(S.e.in_step == 2);   // rv_set_auto_reset: a step begun on a finished episode -> env.reset()
+  if (MODE == MODE_MACRO || MODE == MODE_SUB || MODE == MODE_WAIT || (MODE == MODE_PARTIAL && !resetting)) {
     if (lane == 0) {
       launch_counters_zero(S.e);
-      S.s.bud_sub = args.n_substeps; S.s.bud_sub0 = 0; S.s.bud_clk = args.budget_clk; S.s.bud_t0 = __builtin_amdgcn_s_memtime();
+      if (MODE == MODE_PARTIAL) { S.s.bud_sub = args.n_substeps; S.s.bud_sub0 = 0; S.s.bud_clk = args.budget_clk; S.s.bud_t0 = __builtin_amdgcn_s_memtime(); }
     }
     __syncthreads();
-    const int fin = env_step_partial(S, K);
-    if (lane == 0) {
+  }
+  const int prog = MODE == MODE_RESET || resetting ? RV_PROG_RESET : (MODE == MODE_MACRO ? RV_PROG_MACRO : (MODE == MODE_ROLLOUT ? RV_PROG_ROLLOUT :
+                   (MODE == MODE_PARTIAL ? RV_PROG_PARTIAL : (MODE == MODE_SUB ? RV_PROG_SUB : RV_PROG_WAIT))));
+  const int fin = env_program(S, K, prog, pa);
+  if (MODE == MODE_ROLLOUT) {
+    if (lane == 0 && args.steps_taken) args.steps_taken[env] = S.e.stepped;
+  } else if (MODE == MODE_PARTIAL) {
+    if (resetting) {
+      // the poll hands back what env.reset() returns
+      __syncthreads();
+      if (lane == 0) {
+        S.e.in_step = 0; S.e.reward_valid = 0; S.e.last_reward = 0.0f;
+        if (args.finished) args.finished[env] = 1;
+        rollout_record(args.rec, &S.e, (size_t)env, &S.cfg, &S.arm);
+      }
+    } else if (lane == 0) {
       if (args.finished) args.finished[env] = (uint8_t)fin;
       if (fin) rollout_record(args.rec, &S.e, (size_t)env, &S.cfg, &S.arm);     // what env.step() returns, for the envs that finished
     }
-  } else if (MODE == MODE_SUB) {
-    if (lane == 0) launch_counters_zero(S.e);
-    __syncthreads();
-    sim_steps_call(K, args.n_substeps);
-  } else {
-    if (lane == 0) launch_counters_zero(S.e);
-    __syncthreads();
-    wait_until_stable(S, K, 0u, args.lin_thr, args.ang_thr, args.check_after, args.min_stable, args.max_steps);
   }
   __syncthreads();
   {
@@ -152,16 +151,12 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
 
 
 // launch k_env<mode> of THIS translation unit
-static inline void rv_launch_k_env_here(int mode, const EnvKernelArgs& a, int n_envs, hipStream_t stream) {
+static inline void rv_launch_k_env_here(int mode, const EnvKernelArgs& a0, int n_envs, hipStream_t stream) {
   const dim3 g((unsigned)n_envs), b(64);
-  switch (mode) {
-    case MODE_RESET:   hipLaunchKernelGGL(k_env<MODE_RESET>, g, b, 0, stream, a); break;
-    case MODE_MACRO:   hipLaunchKernelGGL(k_env<MODE_MACRO>, g, b, 0, stream, a); break;
-    case MODE_SUB:     hipLaunchKernelGGL(k_env<MODE_SUB>, g, b, 0, stream, a); break;
-    case MODE_WAIT:    hipLaunchKernelGGL(k_env<MODE_WAIT>, g, b, 0, stream, a); break;
-    case MODE_ROLLOUT: hipLaunchKernelGGL(k_env<MODE_ROLLOUT>, g, b, 0, stream, a); break;
-    default:           hipLaunchKernelGGL(k_env<MODE_PARTIAL>, g, b, 0, stream, a); break;
-  }
+  EnvKernelArgs a = a0;
+  a.mode = mode;
+  if (mode == MODE_ROLLOUT) hipLaunchKernelGGL(k_env<MODE_ROLLOUT>, g, b, 0, stream, a);
+  else hipLaunchKernelGGL(k_env<-1>, g, b, 0, stream, a);
 }
 // ... and of the two-waves-per-SIMD build (rv_kernels_occ2.hip)
 void rv_launch_k_env_occ2(int mode, const EnvKernelArgs& a, int n_envs, hipStream_t stream);

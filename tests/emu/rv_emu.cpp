@@ -24,11 +24,14 @@ static void run_env(EmuWorld* w, int i, int mode, int n_sub, float lin, float an
   memcpy(&S.e, &w->envs[i], sizeof(DevEnv));
   if (mode == 1 && S.e.done) { w->envs[i].substeps_last = 0; w->envs[i].awake_last = 0; w->envs[i].pairs_last = 0; w->envs[i].stepped = 0; return; }
   if (mode != 0) env_enter(S, K);
-  if (mode == 0) env_reset(S, K, w->cfg.env_id_offset + i);
-  else if (mode == 1) { launch_counters_zero(S.e); if (K.cfg->env_type == RV_ENV_GRASP) genv_step(S, K); else env_step(S, K); }
-  else if (mode == 4) { RolloutRec rec; memset(&rec, 0, sizeof(rec)); env_rollout(S, K, w->cfg.env_id_offset + i, n_sub, ca, ms, rec, i, w->n); }
-  else if (mode == 2) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; sim_steps_call(K, n_sub); }
-  else { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; wait_until_stable(S, K, 0u, lin, ang, ca, ms, mx); }
+  ProgArgs pa; memset(&pa, 0, sizeof(pa));
+  pa.gid = w->cfg.env_id_offset + i; pa.n_steps = n_sub; pa.lin_thr = lin; pa.ang_thr = ang; pa.check_after = ca; pa.min_stable = ms; pa.max_steps = mx;
+  pa.env = i; pa.n_envs = w->n; pa.budget = nullptr;
+  if (mode == 0) env_program(S, K, RV_PROG_RESET, pa);
+  else if (mode == 1) { launch_counters_zero(S.e); env_program(S, K, RV_PROG_MACRO, pa); }
+  else if (mode == 4) { pa.first_index = ca; pa.auto_reset = ms; env_program(S, K, RV_PROG_ROLLOUT, pa); }
+  else if (mode == 2) { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; env_program(S, K, RV_PROG_SUB, pa); }
+  else { S.e.substeps_last = 0; S.e.awake_last = 0; S.e.pairs_last = 0; S.e.stepped = 0; env_program(S, K, RV_PROG_WAIT, pa); }
   memcpy(&w->envs[i], &S.e, sizeof(DevEnv));
 }
 
@@ -95,7 +98,7 @@ void emu_step_poll(EmuWorld* w, int max_substeps, uint8_t* finished) {
     memcpy(&S.e, &g, sizeof(DevEnv));
     env_enter(S, K);
     S.s.bud_sub = max_substeps; S.s.bud_sub0 = 0; S.s.bud_clk = 0; S.s.bud_t0 = 0;
-    finished[i] = (uint8_t)env_step_partial(S, K);
+    { ProgArgs pa; memset(&pa, 0, sizeof(pa)); finished[i] = (uint8_t)env_program(S, K, RV_PROG_PARTIAL, pa); }
     memcpy(&g, &S.e, sizeof(DevEnv));
   }
 }
