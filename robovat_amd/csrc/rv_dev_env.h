@@ -4335,7 +4335,8 @@ RV_DEV void gphase_tick(Shared& S, const Consts& K);
 //                 until the next multiple of STEPS_CHECK, phase_tick, until 'done'),
 //                 followed by its closing wait_until_stable -- one call per env.step()
 #ifdef RV_HEAVY_NOINLINE      // (an option of the two-waves-per-SIMD build: the heavy part as a function of its own)
-RV_DEV_NOINLINE void sim_substep_heavy_call(Shared& S, const Consts& K) { sim_substep_heavy(S, K); }
+RV_DEV_NOINLINE void sim_substep_heavy_fn(const rv_scene* scene, int stop_after) { const Consts K = lds_consts(scene, stop_after); sim_substep_heavy(g_shared, K); }
+RV_DEV void sim_substep_heavy_call(Shared& S, const Consts& K) { (void)S; sim_substep_heavy_fn(K.scene, K.stop_after); }
 #endif
 // What one run of the substep loop is asked to do (the arguments of the former sim_run_call)
 struct RunReq { int n_arg; unsigned mask; float lin_thr, ang_thr; int check_after, min_stable, max_steps; };
@@ -4347,12 +4348,7 @@ RV_DEV RunReq run_req(int n_arg, unsigned mask = 0u, float lin = 0.0f, float ang
 // written as a resumable program -- hands it one request after the other from a single call site, so nothing of it
 // is a function call (until round 4 it was an out-of-line function entered per env.step(), and its heavy part a
 // second one entered per awake substep: each call saved and restored ~200 registers through scratch memory).
-#ifdef RV_SIM_RUN_NOINLINE     // (the two-waves-per-SIMD build: a function boundary splits the register allocation under its 256-register cap)
-RV_DEV_NOINLINE
-#else
-RV_DEV
-#endif
-void sim_run(Shared& S, const Consts& K, const RunReq& rq) {
+RV_DEV void sim_run_body(Shared& S, const Consts& K, const RunReq& rq) {
   const rv_scene* scene = K.scene; const int stop_after = K.stop_after; (void)scene; (void)stop_after;
   const int n_arg = rq.n_arg; const unsigned mask = rq.mask; const float lin_thr = rq.lin_thr, ang_thr = rq.ang_thr;
   const int check_after = rq.check_after, min_stable = rq.min_stable, max_steps = rq.max_steps;
@@ -4544,6 +4540,23 @@ void sim_run(Shared& S, const Consts& K, const RunReq& rq) {
     RV_LANES_END
   }
 }
+#ifdef RV_SIM_RUN_NOINLINE
+// The two-waves-per-SIMD build keeps the loop as ONE function (a boundary for the register allocator under its
+// 256-register cap).  It addresses the env through the file-scope LDS object and rebuilds Consts from scalars: through
+// pointer arguments the LDS accesses would be compiled as flat loads.
+RV_DEV_NOINLINE void sim_run_fn(const rv_scene* scene, int stop_after, int n_arg, unsigned mask, float lin_thr, float ang_thr,
+                                int check_after, int min_stable, int max_steps) {
+  const Consts K = lds_consts(scene, stop_after);
+  sim_run_body(g_shared, K, run_req(n_arg, mask, lin_thr, ang_thr, check_after, min_stable, max_steps));
+}
+RV_DEV void sim_run(Shared& S, const Consts& K, const RunReq& rq) {
+  (void)S;
+  sim_run_fn(K.scene, K.stop_after, rq.n_arg, rq.mask, rq.lin_thr, rq.ang_thr, rq.check_after, rq.min_stable, rq.max_steps);
+}
+#else
+RV_DEV void sim_run(Shared& S, const Consts& K, const RunReq& rq) { sim_run_body(S, K, rq); }
+#endif
+
 // ------------------------------------------------- observation / reward --
 RV_DEV void compute_obs(DevEnv& e) {
   for (int b = 0; b < RV_MAXB; ++b)

@@ -58,7 +58,7 @@ for STAGE in "$@"; do
       cd $R; python tools/pmc_summary.py $O/lanes_head $O/lanes_nd > $O/lanes.txt 2>&1; cat $O/lanes.txt ;;
     variants)
       # every library variant under build/ (and the product library): headline, config 5 / 3 / 4 single-launch rollouts
-      for SO in robovat_amd/librovat_hip.so build/librovat_*.so; do
+      for SO in robovat_amd/librovat_hip.so $(ls build/librovat_*.so 2>/dev/null); do
         for W in "--steps 20 --warmup 5" "--workload config5 --steps 10 --warmup 2" "--workload config3 --steps 10 --warmup 2" "--workload config4 --steps 10 --warmup 2"; do
           V=$(RV_LIB=$R/$SO timeout 600 python bench.py $W --no-cpu-baseline --no-extra-legs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.0f env-steps/s  kernel %.1f ms' % (d['value'], d['roofline']['avg_kernel_ms']))")
           echo "$SO [$W]: $V" | tee -a $O/variants.txt
