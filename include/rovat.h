@@ -409,8 +409,18 @@ int  rv_grip(rv_world* w, float value);
  * position + xyzw quaternion in the body frame; NULL = the body frame itself) of movable body
  * `body` and the world frame target7, applying at most max_force newtons per row.  Every env of
  * the world gets it; calling again moves the world frame (the servo does that every substep);
- * max_force < 0 removes the constraint.  Other joint types / a movable child raise in the mirror. */
+ * max_force < 0 removes the constraint.  (A movable child / a point-to-point joint: rv_set_constraint_ex.) */
 int  rv_set_constraint(rv_world* w, int32_t body, const float* frame7, const float* target7, float max_force);
+/* The same with the other arguments of BulletPhysics.add_constraint (bullet_physics.py:748-806: createConstraint(parent,
+ * parentLink, child, childLink, jointType, jointAxis, parentFramePosition, childFramePosition, ...)): `child` = -1 (the
+ * world) or another movable body slot -- child_frame7 is then given in the CHILD's frame and every row acts on both
+ * bodies, which stay awake together; joint_type RV_JOINT_FIXED (six rows) or RV_JOINT_POINT2POINT (pybullet
+ * JOINT_POINT2POINT: the three linear rows, the bodies turn freely about the pivot).  Prismatic / gear joints:
+ * RV_ERR_NOTIMPL. */
+#define RV_JOINT_FIXED       4   /* pybullet.JOINT_FIXED */
+#define RV_JOINT_POINT2POINT 5   /* pybullet.JOINT_POINT2POINT */
+int  rv_set_constraint_ex(rv_world* w, int32_t body, int32_t child, int32_t joint_type, const float* frame7,
+                          const float* child_frame7, float max_force);
 /* BulletPhysics.set_gravity (bullet_physics.py:129-137): the gravity vector of every env of
  * the world from now on (host float[3]) */
 int  rv_set_gravity(rv_world* w, const float* gravity);

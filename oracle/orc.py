@@ -46,7 +46,7 @@ def _lib(double):
                      'orc_get_episode_returns', 'orc_get_stats', 'orc_eval_reward',
                      'orc_eval_waypoints', 'orc_set_external_control', 'orc_motor_targets',
                      'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout', 'orc_set_pose_f32',
-                     'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction', 'orc_set_constraint', 'orc_render_rgb'):
+                     'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction', 'orc_set_constraint', 'orc_render_rgb', 'orc_set_constraint_ex'):
             getattr(lib, name).restype = None
         lib.orc_is_limb_ready.restype = C.c_int
         lib.orc_is_gripper_ready.restype = C.c_int
@@ -192,10 +192,11 @@ class OracleWorld(object):
     def grip(self, value):
         self.lib.orc_grip(self.h, C.c_float(value))
 
-    def set_constraint(self, body, target7, frame7=None, max_force=500.0):
+    def set_constraint(self, body, target7, frame7=None, max_force=500.0, child=-1, joint_type='fixed'):
         t = np.ascontiguousarray(target7 if target7 is not None else [0, 0, 0, 0, 0, 0, 1], dtype=np.float64)
         f = None if frame7 is None else np.ascontiguousarray(frame7, dtype=np.float64)
-        self.lib.orc_set_constraint(self.h, C.c_int(int(body)), None if f is None else _p(f), _p(t), C.c_double(max_force))
+        self.lib.orc_set_constraint_ex(self.h, C.c_int(int(body)), C.c_int(int(child)), C.c_int({'fixed': 1, 'point2point': 2}[joint_type]),
+                                       None if f is None else _p(f), _p(t), C.c_double(max_force))
 
     def remove_constraint(self, body):
         self.lib.orc_set_constraint(self.h, C.c_int(int(body)), None, None, C.c_double(-1.0))

@@ -1133,39 +1133,71 @@ static real point_solve_g(orc_env* e, int a, orc_manifold* m, int i, const orc_r
  * constraint ControllableConstraint servoes, controllable_constraint.py:21-170): three linear rows at
  * the pivot, three angular rows, Baumgarte-stabilised with rv_config.erp, accumulated impulse within
  * +- con_fmax dt per row (pybullet changeConstraint maxForce).  lam[6]: accumulated impulses. */
+/* con_on encodes the joint: bits 0-3 the type (1 fixed: six rows, 2 point to point: the three linear rows), bits 4-7
+ * the child body + 1 (0: the world).  With a child body the frame (con_tpos, con_tquat) is given in the CHILD's frame
+ * and every row acts on both bodies; a child that is absent / frozen stands still like the world. */
+#define CON_TYPE(x) ((x) & 15)
+#define CON_CHILD(x) ((((x) >> 4) & 15) - 1)
 static real constraint_solve(const orc_world* w, orc_env* e, int b, real* lam) {
   const rv_config* c = &w->cfg; const orc_bparam* P = &e->bp[b]; orc_body* B = &e->body[b];
   const real dt = (real)c->dt, lim = P->con_fmax * dt;
+  const int ctype = CON_TYPE(P->con_on), cw = CON_CHILD(P->con_on);
+  int cb = cw;
+  if (cb >= 0 && !body_on(e, cb)) cb = -2;
   real rot[9], r[3], wp[3], res = R(0.0);
   qmat(rot, B->q); m3mulv(r, rot, P->con_lpos); v3add(wp, B->p, r);
   real qw[4], qc[4], qe[4];
   qmul(qw, B->q, P->con_lquat);                                  /* the joint frame of the body, in the world */
   qc[0] = -qw[0]; qc[1] = -qw[1]; qc[2] = -qw[2]; qc[3] = qw[3];
-  qmul(qe, P->con_tquat, qc);                                    /* rotation that takes it to the target frame */
+  real tp[3] = {P->con_tpos[0], P->con_tpos[1], P->con_tpos[2]}, rc[3] = {R(0.0), R(0.0), R(0.0)};
+  real tq[4] = {P->con_tquat[0], P->con_tquat[1], P->con_tquat[2], P->con_tquat[3]};
+  real imc = R(0.0);
+  if (cw >= 0) {
+    real rotc[9];
+    qmat(rotc, e->body[cw].q); m3mulv(rc, rotc, P->con_tpos); v3add(tp, e->body[cw].p, rc);
+    qmul(tq, e->body[cw].q, P->con_tquat);
+    if (cb >= 0) imc = e->bp[cb].inv_mass;
+  }
+  qmul(qe, tq, qc);                                              /* rotation that takes it to the target frame */
   const real sg = qe[3] < R(0.0) ? R(-2.0) : R(2.0);
   const real th[3] = {qe[0] * sg, qe[1] * sg, qe[2] * sg};
-  for (int k = 0; k < 6; ++k) {
-    real jl[3] = {R(0.0), R(0.0), R(0.0)}, ja[3] = {R(0.0), R(0.0), R(0.0)}, ia[3], bias;
+  const int n_rows = ctype == 2 ? 3 : 6;
+  for (int k = 0; k < n_rows; ++k) {
+    real jl[3] = {R(0.0), R(0.0), R(0.0)}, ja[3] = {R(0.0), R(0.0), R(0.0)}, jc[3] = {R(0.0), R(0.0), R(0.0)}, ia[3], ic[3] = {R(0.0), R(0.0), R(0.0)}, bias;
     if (k < 3) {
       jl[k] = R(1.0);
       real ek[3] = {R(0.0), R(0.0), R(0.0)}; ek[k] = R(1.0);
-      v3cross(ja, r, ek);
-      bias = (real)c->erp * (P->con_tpos[k] - wp[k]) / dt;
+      v3cross(ja, r, ek); v3cross(jc, rc, ek);
+      bias = (real)c->erp * (tp[k] - wp[k]) / dt;
     } else {
-      ja[k - 3] = R(1.0);
+      ja[k - 3] = R(1.0); jc[k - 3] = R(1.0);
       bias = (real)c->erp * th[k - 3] / dt;
     }
     m3mulv(ia, e->iinv[b], ja);
-    const real kk = (k < 3 ? P->inv_mass : R(0.0)) + v3dot(ja, ia);
-    const real jv = v3dot(jl, B->v) + v3dot(ja, B->w);
+    real kk = (k < 3 ? P->inv_mass : R(0.0)) + v3dot(ja, ia);
+    real jv = v3dot(jl, B->v) + v3dot(ja, B->w);
+    if (cb >= 0) {
+      m3mulv(ic, e->iinv[cb], jc);
+      kk = kk + ((k < 3 ? imc : R(0.0)) + v3dot(jc, ic));
+      jv = jv - (v3dot(jl, e->body[cb].v) + v3dot(jc, e->body[cb].w));
+    }
     real dl = (bias - jv) / kk;
     const real ln = rclamp(lam[k] + dl, -lim, lim);
     dl = ln - lam[k]; lam[k] = ln;
     res = rmax(res, rabs(dl));
     v3madd(B->v, B->v, jl, dl * P->inv_mass);
     v3madd(B->w, B->w, ia, dl);
+    if (cb >= 0) {
+      v3madd(e->body[cb].v, e->body[cb].v, jl, -(dl * imc));
+      v3madd(e->body[cb].w, e->body[cb].w, ic, -dl);
+    }
   }
   return res;
+}
+static int con_pair_member(const orc_env* e, int b) {
+  int m = CON_TYPE(e->bp[b].con_on) != 0 && CON_CHILD(e->bp[b].con_on) >= 0;
+  for (int x = 0; x < RV_MAXB; ++x) if (CON_TYPE(e->bp[x].con_on) != 0 && CON_CHILD(e->bp[x].con_on) == b) m = 1;
+  return m;
 }
 static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4], const int* use, const orc_limb* L) {
   const rv_config* c = &w->cfg; const rv_arm* arm = &w->scene.arm;
@@ -1784,7 +1816,7 @@ static void sim_substep(const orc_world* w, orc_env* e) {
        * sleep after a quarter of the usual wait */
       int quick = e->bp[b].undisturbed && 4 * e->bp[b].still_count >= c->sleep_steps && 4 * e->bp[b].sleep_count >= c->sleep_steps;
       /* a body the force-limited gripper holds stays active (its island contains the moving fingers) */
-      int held = c->finger_dynamics && e->man[AIDX(b)].n > 0;
+      int held = (c->finger_dynamics && e->man[AIDX(b)].n > 0) || con_pair_member(e, b);
       /* Bullet's own rule (0.8 m/s, 1 rad/s, 2 s) for a body whose island is the body alone */
       int deact = 0;
       if (c->deact_steps > 0) {
@@ -2639,17 +2671,21 @@ void orc_set_link_timeout(orc_world* w, double timeout) {
 /* Simulator.add_constraint / Constraint.pose setter (bullet_physics.py:748-957) for body `body` of every env:
  * frame7 = joint frame in the body frame (NULL: identity), target7 = the world frame it is tied to,
  * max_force < 0: the constraint is removed */
-void orc_set_constraint(orc_world* w, int body, const double* frame7, const double* target7, double max_force) {
+void orc_set_constraint_ex(orc_world* w, int body, int child, int joint_type, const double* frame7, const double* target7, double max_force) {
   for (int i = 0; i < w->n; ++i) {
     orc_bparam* P = &w->env[i].bp[body];
     if (max_force < 0.0) P->con_on = 0;
     else {
-      P->con_on = 1; P->con_fmax = (real)max_force;
+      P->con_on = (joint_type == 2 ? 2 : 1) | ((child + 1) << 4); P->con_fmax = (real)max_force;
       for (int k = 0; k < 3; ++k) { P->con_lpos[k] = frame7 ? (real)frame7[k] : R(0.0); P->con_tpos[k] = (real)target7[k]; }
       for (int k = 0; k < 4; ++k) { P->con_lquat[k] = frame7 ? (real)frame7[3 + k] : (k == 3 ? R(1.0) : R(0.0)); P->con_tquat[k] = (real)target7[3 + k]; }
     }
     P->asleep = 0; P->sleep_count = 0; P->deact_count = 0; P->still_count = 0; P->undisturbed = 0;
+    if (child >= 0) { orc_bparam* C = &w->env[i].bp[child]; C->asleep = 0; C->sleep_count = 0; C->deact_count = 0; C->still_count = 0; C->undisturbed = 0; }
   }
+}
+void orc_set_constraint(orc_world* w, int body, const double* frame7, const double* target7, double max_force) {
+  orc_set_constraint_ex(w, body, -1, 1, frame7, target7, max_force);
 }
 void orc_grip(orc_world* w, float value) { for (int i = 0; i < w->n; ++i) robot_grip(w, &w->env[i], (real)value); }
 int orc_is_limb_ready(orc_world* w, int env) { return arm_is_ready_limb(w, &w->env[env]); }

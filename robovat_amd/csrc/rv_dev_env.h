@@ -1270,39 +1270,79 @@ RV_DEV float point_solve_g(BV& A, float ima, Lam& l, const Row& r, float* qf, fl
 // constraint ControllableConstraint servoes, controllable_constraint.py:21-170): three linear rows at the
 // pivot, three angular rows, Baumgarte-stabilised with rv_config.erp, accumulated impulse within
 // +- con_fmax dt per row (pybullet changeConstraint maxForce).  lam[6]: accumulated impulses.
+// con_on[b] encodes the joint: bits 0-3 the type (RV_CON_FIXED: six rows, RV_CON_P2P: point to point, the three linear
+// rows only), bits 4-7 the child body + 1 (0: the world).  With a child body the frame (con_tpos, con_tquat) is given
+// in the CHILD's frame and every row acts on both bodies (opposite signs); a child that is absent or frozen stands
+// still like the world.
+#define RV_CON_FIXED 1
+#define RV_CON_P2P 2
+#define RV_CON_TYPE(x) ((x) & 15)
+#define RV_CON_CHILD(x) ((((x) >> 4) & 15) - 1)
 RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
   DevEnv& e = S.e; const rv_config* c = K.cfg;
   const float dt = c->dt, lim = e.con_fmax[b] * dt, ima = e.inv_mass[b];
+  const int ctype = RV_CON_TYPE(e.con_on[b]);
+  int cb = RV_CON_CHILD(e.con_on[b]);
+  if (cb >= 0 && !body_on(e, cb)) cb = -2;        // (an absent / frozen / sleeping child: a fixed frame where it is)
+  const int cw = RV_CON_CHILD(e.con_on[b]);       // (-1: the frame is a world frame)
   const m3 rot = qmat(ldq(e.body[b] + 3));
   const v3 r = mulv(rot, ld3(e.con_lpos[b])), wp = add(ld3(e.body[b]), r);
   const q4 qw = qmul(ldq(e.body[b] + 3), ldq(e.con_lquat[b]));
   q4 qc; qc.x = -qw.x; qc.y = -qw.y; qc.z = -qw.z; qc.w = qw.w;
-  const q4 qe = qmul(ldq(e.con_tquat[b]), qc);
+  // the frame the joint is tied to, in the world
+  v3 tpv = ld3(e.con_tpos[b]), rc = mk(0.0f, 0.0f, 0.0f);
+  q4 tq = ldq(e.con_tquat[b]);
+  float imc = 0.0f;
+  if (cw >= 0) {
+    const m3 rotc = qmat(ldq(e.body[cw] + 3));
+    rc = mulv(rotc, ld3(e.con_tpos[b]));
+    tpv = add(ld3(e.body[cw]), rc);
+    tq = qmul(ldq(e.body[cw] + 3), ldq(e.con_tquat[b]));
+    if (cb >= 0) imc = e.inv_mass[cb];
+  }
+  const q4 qe = qmul(tq, qc);
   const float sg = qe.w < 0.0f ? -2.0f : 2.0f;
   const float th[3] = {qe.x * sg, qe.y * sg, qe.z * sg};
-  const float tp[3] = {e.con_tpos[b][0], e.con_tpos[b][1], e.con_tpos[b][2]}, wpa[3] = {wp.x, wp.y, wp.z};
+  const float tp[3] = {tpv.x, tpv.y, tpv.z}, wpa[3] = {wp.x, wp.y, wp.z};
   float res = 0.0f;
-  for (int k = 0; k < 6; ++k) {
-    v3 jl = mk(0, 0, 0), ja = mk(0, 0, 0); float bias;
+  const int n_rows = ctype == RV_CON_P2P ? 3 : 6;
+  for (int k = 0; k < n_rows; ++k) {
+    v3 jl = mk(0, 0, 0), ja = mk(0, 0, 0), jc = mk(0, 0, 0); float bias;
     if (k < 3) {
       const v3 ek = mk(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f);
-      jl = ek; ja = cross(r, ek);
+      jl = ek; ja = cross(r, ek); jc = cross(rc, ek);
       bias = c->erp * (tp[k] - wpa[k]) / dt;
     } else {
-      ja = mk(k == 3 ? 1.0f : 0.0f, k == 4 ? 1.0f : 0.0f, k == 5 ? 1.0f : 0.0f);
+      ja = mk(k == 3 ? 1.0f : 0.0f, k == 4 ? 1.0f : 0.0f, k == 5 ? 1.0f : 0.0f); jc = ja;
       bias = c->erp * th[k - 3] / dt;
     }
     const v3 ia = mulv(ldm(S.s.iinv[b]), ja);
-    const float kk = (k < 3 ? ima : 0.0f) + dot(ja, ia);
-    const float jv = dot(jl, ld3(e.body[b] + 7)) + dot(ja, ld3(e.body[b] + 10));
+    float kk = (k < 3 ? ima : 0.0f) + dot(ja, ia);
+    float jv = dot(jl, ld3(e.body[b] + 7)) + dot(ja, ld3(e.body[b] + 10));
+    v3 ic = mk(0, 0, 0);
+    if (cb >= 0) {
+      ic = mulv(ldm(S.s.iinv[cb]), jc);
+      kk = kk + ((k < 3 ? imc : 0.0f) + dot(jc, ic));
+      jv = jv - (dot(jl, ld3(e.body[cb] + 7)) + dot(jc, ld3(e.body[cb] + 10)));
+    }
     float dl = (bias - jv) / kk;
     const float ln = fclampr(lam[k] + dl, -lim, lim);
     dl = ln - lam[k]; lam[k] = ln;
     res = fmaxr(res, fabsr(dl));
     st3(e.body[b] + 7, madd(ld3(e.body[b] + 7), jl, dl * ima));
     st3(e.body[b] + 10, madd(ld3(e.body[b] + 10), ia, dl));
+    if (cb >= 0) {
+      st3(e.body[cb] + 7, madd(ld3(e.body[cb] + 7), jl, -(dl * imc)));
+      st3(e.body[cb] + 10, madd(ld3(e.body[cb] + 10), ic, -dl));
+    }
   }
   return res;
+}
+// is body b a party to a body - body constraint?  (the two stay awake together: they never deactivate)
+RV_DEV int con_pair_member(const DevEnv& e, int b) {
+  int m = RV_CON_TYPE(e.con_on[b]) != 0 && RV_CON_CHILD(e.con_on[b]) >= 0;
+  for (int x = 0; x < RV_MAXB; ++x) if (RV_CON_TYPE(e.con_on[x]) != 0 && RV_CON_CHILD(e.con_on[x]) == b) m = 1;
+  return m;
 }
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
 // Device: the one-lane system solver is run by EVERY lane of the wave (the same scalar program on the same LDS
@@ -4195,7 +4235,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
           // to sleep after a quarter of the usual wait
           const int quick = e.undisturbed[b] && 4 * e.still_count[b] >= c->sleep_steps && 4 * e.sleep_count[b] >= c->sleep_steps;
           // a body the force-limited gripper holds stays active (its island contains the moving fingers)
-          const int held = c->finger_dynamics && e.man[RV_AIDX(b)].n > 0;
+          const int held = (c->finger_dynamics && e.man[RV_AIDX(b)].n > 0) || con_pair_member(e, b);
           // Bullet's own rule (0.8 m/s, 1 rad/s, 2 s) for a body whose island is the body alone:
           // no arm contact points, no contact points with another awake body
           int deact = 0;

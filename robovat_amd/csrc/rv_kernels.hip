@@ -136,18 +136,19 @@ __global__ void k_set_motor_targets(DevEnv* envs, int n, const float* q, const u
     e.motor_on[j] = 1; e.motor_q[j] = q[(size_t)i * RV_NJ + j]; e.motor_kp[j] = cfg->kp; e.motor_kd[j] = cfg->kd;
   }
 }
-struct ConArgs { int body; float lp[3], lq[4], tp[3], tq[4], fmax; };
+struct ConArgs { int body, child, type; float lp[3], lq[4], tp[3], tq[4], fmax; };
 __global__ void k_set_constraint(DevEnv* envs, int n, ConArgs a) {
   ENV_THREAD();
   const int b = a.body;
   // (a body that went to sleep hanging from its constraint must notice that it changed or is gone)
   if (a.fmax < 0.0f) e.con_on[b] = 0;
   else {
-    e.con_on[b] = 1; e.con_fmax[b] = a.fmax;
+    e.con_on[b] = a.type | ((a.child + 1) << 4); e.con_fmax[b] = a.fmax;      // (RV_CON_TYPE / RV_CON_CHILD, rv_dev_env.h)
     for (int k = 0; k < 3; ++k) { e.con_lpos[b][k] = a.lp[k]; e.con_tpos[b][k] = a.tp[k]; }
     for (int k = 0; k < 4; ++k) { e.con_lquat[b][k] = a.lq[k]; e.con_tquat[b][k] = a.tq[k]; }
   }
   e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0;
+  if (a.child >= 0) { const int cb = a.child; e.asleep[cb] = 0; e.sleep_count[cb] = 0; e.deact_count[cb] = 0; e.still_count[cb] = 0; e.undisturbed[cb] = 0; }
 }
 __global__ void k_set_friction(DevEnv* envs, int n, float mu_finger, float mu_table) {
   ENV_THREAD();
@@ -803,19 +804,24 @@ int rv_set_friction(rv_world* w, float mu_finger, float mu_table) {
   SIMPLE_LAUNCH(k_set_friction, w->d_envs, w->n, mu_finger, mu_table);
   return RV_OK;
 }
-int rv_set_constraint(rv_world* w, int32_t body, const float* frame7, const float* target7, float max_force) {
+int rv_set_constraint_ex(rv_world* w, int32_t body, int32_t child, int32_t joint_type, const float* frame7, const float* child_frame7, float max_force) {
   WCHK(w);
   if (body < 0 || body >= RV_MAXB) return fail(RV_ERR_VALUE, "rv_set_constraint: not a movable body slot");
-  if (max_force >= 0.0f && !target7) return fail(RV_ERR_VALUE, "rv_set_constraint: null target");
+  if (child < -1 || child >= RV_MAXB || child == body) return fail(RV_ERR_VALUE, "rv_set_constraint: the child is the world (-1) or another movable body slot");
+  if (joint_type != RV_JOINT_FIXED && joint_type != RV_JOINT_POINT2POINT) return fail(RV_ERR_NOTIMPL, "rv_set_constraint: joint types built: fixed, point2point");
+  if (max_force >= 0.0f && !child_frame7) return fail(RV_ERR_VALUE, "rv_set_constraint: null target");
   ConArgs a; memset(&a, 0, sizeof(a));
-  a.body = body; a.fmax = max_force; a.lq[3] = 1.0f; a.tq[3] = 1.0f;
+  a.body = body; a.child = child; a.type = joint_type == RV_JOINT_POINT2POINT ? 2 : 1; a.fmax = max_force; a.lq[3] = 1.0f; a.tq[3] = 1.0f;
   if (max_force >= 0.0f) {
     if (frame7) { for (int k = 0; k < 3; ++k) a.lp[k] = frame7[k]; for (int k = 0; k < 4; ++k) a.lq[k] = frame7[3 + k]; }
-    for (int k = 0; k < 3; ++k) a.tp[k] = target7[k];
-    for (int k = 0; k < 4; ++k) a.tq[k] = target7[3 + k];
+    for (int k = 0; k < 3; ++k) a.tp[k] = child_frame7[k];
+    for (int k = 0; k < 4; ++k) a.tq[k] = child_frame7[3 + k];
   }
   SIMPLE_LAUNCH(k_set_constraint, w->d_envs, w->n, a);
   return RV_OK;
+}
+int rv_set_constraint(rv_world* w, int32_t body, const float* frame7, const float* target7, float max_force) {
+  return rv_set_constraint_ex(w, body, -1, RV_JOINT_FIXED, frame7, target7, max_force);
 }
 int rv_grip(rv_world* w, float value) { WCHK(w); SIMPLE_LAUNCH(k_grip, w->d_envs, w->n, value, w->d_cfg, w->d_scene); return RV_OK; }
 int rv_reset_targets(rv_world* w) { WCHK(w); SIMPLE_LAUNCH(k_reset_targets, w->d_envs, w->n); return RV_OK; }

@@ -31,6 +31,7 @@ SYMBOLS = [
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
     'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll', 'rv_set_constraint', 'rv_render_rgb', 'rv_set_friction', 'rv_set_auto_reset',
+    'rv_set_constraint_ex',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -144,6 +145,7 @@ def load():
     lib.rv_set_friction.argtypes = [vp, f32, f32]
     lib.rv_set_auto_reset.argtypes = [vp, i32]
     lib.rv_set_constraint.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), f32]
+    lib.rv_set_constraint_ex.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), f32]
     lib.rv_get_state_ptrs.argtypes = [vp, C.POINTER(abi.rv_state_view)]
     lib.rv_set_joint_targets.argtypes = [vp, vp, f32, f32]
     lib.rv_set_link_target.argtypes = [vp, vp, f32, f32]
@@ -394,12 +396,17 @@ class World(object):
     def grip(self, value):
         check(self.lib.rv_grip(self.h, float(value)))
 
-    def set_constraint(self, body, target7, frame7=None, max_force=500.0):
-        """rv_set_constraint: tie frame7 (in the body frame; None = the body frame) of movable body
-        ``body`` to the world frame target7 with at most max_force N per row; max_force < 0 removes it."""
+    JOINT_TYPES = {'fixed': 4, 'point2point': 5}      # pybullet.JOINT_FIXED / JOINT_POINT2POINT
+
+    def set_constraint(self, body, target7, frame7=None, max_force=500.0, child=-1, joint_type='fixed'):
+        """rv_set_constraint_ex: tie frame7 (in the body frame; None = the body frame) of movable body ``body`` to
+        the frame target7 -- of the world (child = -1) or, given in its frame, of movable body ``child`` -- by a
+        'fixed' or a 'point2point' joint with at most max_force N per row; max_force < 0 removes it."""
+        if joint_type not in self.JOINT_TYPES:
+            raise NotImplementedError("joint types built: 'fixed', 'point2point' (not %r)" % (joint_type,))
         t = (C.c_float * 7)(*[float(x) for x in (target7 if target7 is not None else [0, 0, 0, 0, 0, 0, 1])])
         f = None if frame7 is None else (C.c_float * 7)(*[float(x) for x in frame7])
-        check(self.lib.rv_set_constraint(self.h, int(body), f, t, float(max_force)))
+        check(self.lib.rv_set_constraint_ex(self.h, int(body), int(child), self.JOINT_TYPES[joint_type], f, t, float(max_force)))
 
     def remove_constraint(self, body):
         check(self.lib.rv_set_constraint(self.h, int(body), None, None, -1.0))

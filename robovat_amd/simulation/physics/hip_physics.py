@@ -358,20 +358,24 @@ class HipPhysics(Physics):
     # ---- user constraints (bullet_physics.py:748-957: createConstraint / changeConstraint / removeConstraint)
     def add_constraint(self, parent_uid, child_uid, joint_type='fixed', joint_axis=[0, 0, 0],
                        parent_frame_pose=None, child_frame_pose=None):
-        """A FIXED joint between a frame of a movable body (the parent) and a frame of the world (child
-        None): the constraint ControllableConstraint servoes.  Returns the constraint uid."""
-        if joint_type != 'fixed':
-            raise NotImplementedError("only joint_type='fixed' is built (pose-servo constraints)")
-        if child_uid is not None:
-            raise NotImplementedError('the child of a constraint is the world (child=None)')
+        """A 'fixed' or 'point2point' joint between a frame of a movable body (the parent) and a frame of the world
+        (child None: the constraint ControllableConstraint servoes) or of another movable body (the child).
+        Prismatic / gear joints (and links of the arm as parties) are not built.  Returns the constraint uid."""
+        if joint_type not in ('fixed', 'point2point'):
+            raise NotImplementedError("joint types built: 'fixed', 'point2point' (not %r)" % (joint_type,))
         b = self._slot(parent_uid)
+        child = -1 if child_uid is None else self._slot(child_uid)
+        if child == b:
+            raise ValueError('a body cannot be constrained to itself')
         if b in self._constraints:
             raise ValueError('body %d already has a constraint' % b)
         frame = Pose(parent_frame_pose if parent_frame_pose is not None else [[0, 0, 0], [0, 0, 0]])
-        if child_frame_pose is None:        # where the joint frame of the body is now
+        if child_frame_pose is None:        # where the joint frame of the parent is now (seen from the child)
             child_frame_pose = self.get_body_pose(b).transform(frame)
-        child = Pose(child_frame_pose)
-        self._constraints[b] = {'frame': frame, 'pose': child, 'max_force': 500.0}     # pybullet's default maxForce
+            if child >= 0:
+                child_frame_pose = self.get_body_pose(child).inverse().transform(child_frame_pose)
+        pose = Pose(child_frame_pose)
+        self._constraints[b] = {'frame': frame, 'pose': pose, 'max_force': 500.0, 'child': child, 'joint_type': joint_type}     # pybullet's default maxForce
         self._push_constraint(b)
         return b
 
@@ -379,7 +383,7 @@ class HipPhysics(Physics):
         c = self._constraints[b]
         f = np.concatenate([np.asarray(c['frame'].position, np.float64), np.asarray(c['frame'].quaternion, np.float64)])
         t = np.concatenate([np.asarray(c['pose'].position, np.float64), np.asarray(c['pose'].quaternion, np.float64)])
-        self._world.set_constraint(b, t, frame7=f, max_force=c['max_force'])
+        self._world.set_constraint(b, t, frame7=f, max_force=c['max_force'], child=c.get('child', -1), joint_type=c.get('joint_type', 'fixed'))
 
     def _con(self, uid):
         if uid not in self._constraints:

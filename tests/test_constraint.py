@@ -55,6 +55,66 @@ def test_constraint_with_an_offset_frame_and_contacts(backend):
         w.close()
 
 
+def _rot(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_point2point_pivot_holds_and_the_body_swings(backend):
+    """pybullet JOINT_POINT2POINT to the world: the pivot (a corner-side point of the box) stays at its world
+    point while the box swings under it like a pendulum -- three rows, the rotation is free."""
+    w, cfg = T._world(backend)
+    T._bodies(w, [(0, 0.2, 0.5, (0.6, 0.0, 0.25), Q0, (0, 0, 0))])
+    piv_local = np.array([0.03, 0.0, 0.0])
+    piv_world = np.array([0.63, 0.0, 0.25])
+    w.set_constraint(0, list(piv_world) + [0, 0, 0, 1], frame7=list(piv_local) + [0, 0, 0, 1], max_force=50.0, joint_type='point2point')
+    zmin, tilt = 1.0, 0.0
+    for _ in range(40):
+        w.step_sub(25)
+        st = np.asarray(w.body_state())[0, 0]
+        piv = st[:3] + _rot(st[3:7]) @ piv_local
+        assert np.abs(piv - piv_world).max() < 1e-3, piv                      # the pivot holds
+        zmin = min(zmin, st[2]); tilt = max(tilt, abs(st[4]))
+    assert zmin < 0.25 - 0.02 and tilt > 0.3                                  # the centre swung down under the pivot: it turned about y
+    if hasattr(w, 'w'):
+        w.close()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_fixed_joint_between_two_bodies(backend):
+    """A fixed joint between two movable bodies: body 0 is carried by a world constraint and moved; body 1, fixed to
+    body 0 at an offset of 8 cm along y, follows it through the air keeping the relative pose; removing the
+    body--body joint drops body 1 only."""
+    w, cfg = T._world(backend)
+    T._bodies(w, [(0, 0.2, 0.5, (0.6, 0.0, 0.15), Q0, (0, 0, 0)), (0, 0.1, 0.5, (0.6, 0.08, 0.15), Q0, (0, 0, 0))])
+    w.set_constraint(0, [0.6, 0.0, 0.15, 0, 0, 0, 1], max_force=100.0)
+    # the joint frame = body 1's frame, seen from body 0 (the child here) at (0, 0.08, 0)
+    w.set_constraint(1, [0, 0.08, 0, 0, 0, 0, 1], max_force=100.0, child=0)
+    w.step_sub(400)
+    st = np.asarray(w.body_state())[0]
+    assert np.abs(st[1, :3] - st[0, :3] - [0, 0.08, 0]).max() < 1e-3 and abs(st[0, 2] - 0.15) < 1e-3 and abs(st[1, 2] - 0.15) < 2e-3
+    for i in range(60):        # carry body 0 along x and turn it about z: body 1 goes round with it
+        a = 0.3 * (i + 1) / 60
+        w.set_constraint(0, [0.6 + 0.001 * (i + 1), 0.0, 0.15, 0, 0, np.sin(a / 2), np.cos(a / 2)], max_force=100.0)
+        w.step_sub(10)
+    w.step_sub(300)
+    st = np.asarray(w.body_state())[0]
+    want = st[0, :3] + _rot(st[0, 3:7]) @ [0, 0.08, 0]
+    assert abs(st[0, 0] - 0.66) < 1e-3 and np.abs(st[1, :3] - want).max() < 1.5e-3, (st[0, :3], st[1, :3], want)
+    assert min(np.abs(st[1, 3:7] - st[0, 3:7]).max(), np.abs(st[1, 3:7] + st[0, 3:7]).max()) < 3e-3
+    assert abs(abs(st[0, 5]) - np.sin(0.15)) < 3e-3
+    w.remove_constraint(1)
+    w.step_sub(400)
+    st = np.asarray(w.body_state())[0]
+    assert st[1, 2] < 0.04 and abs(st[0, 2] - 0.15) < 1e-3
+    if hasattr(w, 'w'):
+        w.close()
+
+
+
 @pytest.mark.gpu
 def test_hip_equals_oracle_with_constraints():
     from robovat_amd import lib
@@ -75,6 +135,18 @@ def test_hip_equals_oracle_with_constraints():
     for x in (w, ref):
         x.remove_constraint(1)
     w.step_sub(300); ref.step_sub(300)
+    assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
+    # a point-to-point joint to the world on body 1 and a fixed joint body 2 -> body 0, then a push through them
+    st = ref.body_state()[0]
+    for x in (w, ref):
+        x.set_constraint(1, [float(st[1, 0]), float(st[1, 1]), float(st[1, 2]) + 0.04, 0, 0, 0, 1], frame7=[0.02, 0.01, 0.0, 0, 0, 0, 1],
+                         max_force=30.0, joint_type='point2point')
+        x.set_constraint(2, [0.0, 0.0, 0.07, 0, 0, 0, 1], max_force=40.0, child=0)
+    for k in range(3):
+        w.step_sub(150); ref.step_sub(150)
+        assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32)), k
+    a = ref.policy_random(1)
+    w.set_actions(a); ref.set_actions(a); w.step_macro(); ref.step_macro()
     assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
     w.close()
 
@@ -103,8 +175,10 @@ def test_simulator_add_constraint_and_pose_servo():
     # (the servo stops within POSITION_THRESHOLD = 1 cm of the target, controllable_constraint.py:16,135-156)
     assert np.abs(np.asarray(body.position) - [p0[0] + 0.03, p0[1], p0[2] + 0.02]).max() < 0.0105
     assert np.abs(np.asarray(body.position) - p0).max() > 0.015
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         sim.add_constraint(body, body, joint_type='fixed')
+    with pytest.raises(NotImplementedError):
+        sim.add_constraint(body, None, joint_type='prismatic')
     sim.remove_constraint('mocap')
     for _ in range(400):
         sim.step()
