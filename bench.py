@@ -334,7 +334,8 @@ def main():
         ('shipped', {}),
         ('bullet_rule_alone', {'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0, 'PHYSICS.SLEEP_STEPS': 2000,
                                'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.DEACTIVATION_STEPS': 0}),
-        ('no_deactivation', dict(NO_DEACT)),
+        ('no_deactivation', dict(NO_DEACT)),                # (without deactivation resting islands converge to SOLVER_TOL_REST = 1e-7: configs.py)
+        ('no_deactivation_one_tolerance', dict(NO_DEACT, **{'PHYSICS.SOLVER_TOL_REST': 0.0})),   # round 3's behaviour: resting bodies creep
         ('no_deactivation_50_sweeps', dict(NO_DEACT, **BULLET_SWEEPS)),
         ('no_deactivation_50_sweeps_unlimited_motor', dict(NO_DEACT, **BULLET_SWEEPS, **{'PHYSICS.ARM_ACCEL_SCALE': 1000.0})),
     ]
@@ -483,8 +484,10 @@ def main():
         legs = semantics_legs(n, min(args.steps, 20), quick=args.quick)
         deact = {'note': 'same workload / seed / actions, one rv_rollout_record launch without auto-reset; displacement = sum over the '
                          'bodies of an env of the xy distance moved by one env.step(), mm.  bullet_physics.py:173-181 passes no '
-                         'URDF_ENABLE_SLEEPING: the no_deactivation legs are the closest to the reference (see reference_semantics)'}
-        for k in ('shipped', 'bullet_rule_alone', 'no_deactivation', 'no_deactivation_50_sweeps'):
+                         'URDF_ENABLE_SLEEPING: the no_deactivation legs are the closest to the reference (see reference_semantics).  Without '
+                         'deactivation islands at rest converge to 1e-7 N s (SOLVER_TOL_REST); no_deactivation_one_tolerance = round 3 '
+                         '(1e-5 N s for every island: resting bodies creep, disp_p50_mm > 0)'}
+        for k in ('shipped', 'bullet_rule_alone', 'no_deactivation', 'no_deactivation_one_tolerance', 'no_deactivation_50_sweeps'):
             if k in legs:
                 deact[k] = legs[k]
         ref_name = 'no_deactivation_50_sweeps' if 'no_deactivation_50_sweeps' in legs else 'no_deactivation'

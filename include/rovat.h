@@ -276,6 +276,11 @@ typedef struct rv_config {
    * many sweeps in a row -- a Gauss-Seidel that cycles (friction rows dithering at the cone under a body the
    * arm pins to the table) instead of converging; 0: only solver_tol / solver_iters end a solve */
   int32_t  solver_stall;
+  /* > 0: an island all of whose bodies were below the sleep thresholds (sleep_lin / sleep_ang) after the last
+   * substep sweeps until its residual is below solver_tol_rest instead of solver_tol.  (With the plain 1e-5 N s
+   * exit resting bodies creep at ~4e-5 m/s -- visible only without deactivation; Bullet runs its 50 sweeps without
+   * an early exit.)  Islands that hold finger / limb motor rows keep solver_tol.  0 (or >= solver_tol): one tolerance */
+  float    solver_tol_rest;
 } rv_config;
 
 /* Per-launch statistics of rv_step_macro / rv_reset (device-side reductions of

@@ -1285,6 +1285,15 @@ static void solve_with_fingers(const orc_world* w, orc_env* e, orc_row rows[][4]
  * velocities g_r = J_r u - vbc_r evolve as g += A[:, s] dl, A_rs = J_r[a_s].P0_s + J_r[b_s].P1_s.
  * Same order, clamps and per-island residual test as the velocity-space solver below (which
  * remains the fallback for more than SOLVE_ROWS rows); velocities are rebuilt at the end. */
+/* The residual an island's sweeps stop on.  An island all of whose bodies were below the sleep thresholds after the
+ * last substep converges to rv_config.solver_tol_rest (< solver_tol): with the plain 1e-5 N s exit resting bodies
+ * creep at ~4e-5 m/s -- a solver artefact that only deactivation hides (Bullet runs its 50 sweeps without an early
+ * exit).  Islands that hold motor rows (fingers, limb) keep solver_tol. */
+static real island_tol(const rv_config* c, const orc_env* e, const int* use, const int* label, int root) {
+  if (!(c->solver_tol_rest > 0.0f && c->solver_tol_rest < c->solver_tol)) return (real)c->solver_tol;
+  for (int b = 0; b < RV_MAXB; ++b) if (use[TIDX(b)] && label[b] == root && !(e->bp[b].sleep_count > 0)) return (real)c->solver_tol;
+  return (real)c->solver_tol_rest;
+}
 #define SOLVE_ROWS 120
 typedef struct { int mi, i, k, a, b, isl; } orc_rowid;
 typedef struct { real l[3], a[3]; } orc_j6;
@@ -1394,6 +1403,8 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
   real best[RV_MAXB] = {R(1e30), R(1e30), R(1e30), R(1e30)}; int since[RV_MAXB] = {0, 0, 0, 0};
   for (int s2 = 0; s2 < n_rows; ++s2) isl_rows |= 1 << id[s2].isl;
   if (fing || L) isl_rows |= 1 << fisl;
+  real tolx[RV_MAXB];
+  for (int x = 0; x < RV_MAXB; ++x) tolx[x] = ((fing || L) && x == fisl) ? (real)c->solver_tol : island_tol(c, e, use, label, x);
   for (int it = 0; it < c->solver_iters; ++it) {
     real res[RV_MAXB] = {R(0.0), R(0.0), R(0.0), R(0.0)};
     real limtab[RV_NMAN][4];   /* friction bound of every point: mu x its normal impulse (the rows of a point need not be neighbours in the list) */
@@ -1426,7 +1437,7 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
       res[fisl] = rmax(res[fisl], rabs(d));
       for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][q] * d;
     }
-    for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < (real)c->solver_tol) done |= 1 << x;
+    for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < tolx[x]) done |= 1 << x;
     /* stalled islands (rv_config.solver_stall): no new smallest residual for that many sweeps */
     for (int x = 0; c->solver_stall > 0 && x < RV_MAXB; ++x) {
       if (!((isl_rows >> x) & 1) || ((done >> x) & 1)) continue;
@@ -1630,7 +1641,7 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
           orc_manifold* m = &e->man[BBIDX(k)];
           for (int i = 0; i < m->n; ++i) { res = rmax(res, point_solve(e, 1, BB_A[k], BB_B[k], m, i, &rows[BBIDX(k)][i])); rows_seen++; }
         }
-      if (rows_seen == 0 || res < (real)c->solver_tol) break;   /* residual-based early exit */
+      if (rows_seen == 0 || res < island_tol(c, e, use, label, root)) break;   /* residual-based early exit */
       if (c->solver_stall > 0) { if (res < big_best) { big_best = res; big_since = 0; } else if (++big_since >= c->solver_stall) break; }
     }
   }
@@ -1789,10 +1800,10 @@ static void sim_substep(const orc_world* w, orc_env* e) {
       e->bp[b].frozen = 1;
       v3set(B->v, R(0.0), R(0.0), R(0.0)); v3set(B->w, R(0.0), R(0.0), R(0.0));
     }
-    /* deactivation counter */
+    /* substeps in a row below the sleep thresholds (the deactivation counter; also what makes a row a 'rest' row of the solver) */
+    if (vv < (real)c->sleep_lin * (real)c->sleep_lin && ww < (real)c->sleep_ang * (real)c->sleep_ang) e->bp[b].sleep_count++;
+    else e->bp[b].sleep_count = 0;
     if (c->sleep_steps > 0) {
-      if (vv < (real)c->sleep_lin * (real)c->sleep_lin && ww < (real)c->sleep_ang * (real)c->sleep_ang) e->bp[b].sleep_count++;
-      else e->bp[b].sleep_count = 0;
       /* in-place oscillation: the pose has not left a small window around where it
        * was when the window opened */
       if ((real)c->sleep_pos_win > R(0.0)) {

@@ -1038,6 +1038,19 @@ RV_DEV void man_owner(int mi, int* kind, int* a, int* b) {
   else if (mi < RV_MAXB + RV_NBB) { *kind = 1; *a = bb_a(mi - RV_MAXB); *b = bb_b(mi - RV_MAXB); }
   else { *kind = 2; *a = mi - RV_MAXB - RV_NBB; *b = -1; }
 }
+// The residual an island's sweeps stop on: an island all of whose bodies were below the sleep thresholds after the last
+// substep converges to rv_config.solver_tol_rest (< solver_tol) -- with the plain early exit resting bodies creep at
+// ~4e-5 m/s, which only deactivation hides (Bullet: 50 sweeps, no exit).  Islands that hold finger / limb motor rows
+// keep solver_tol.  rest_mask: bit b = body b is awake and NOT at rest (sleep_count == 0).
+RV_DEV int unrest_mask(const DevEnv& e) {
+  int m = 0;
+#pragma unroll
+  for (int b = 0; b < RV_MAXB; ++b) if (body_on(e, b) && !(e.sleep_count[b] > 0)) m |= 1 << b;
+  return m;
+}
+RV_DEV float tol_of(const rv_config* c, const int unrest_members) {
+  return (c->solver_tol_rest > 0.0f && c->solver_tol_rest < c->solver_tol && unrest_members == 0) ? c->solver_tol_rest : c->solver_tol;
+}
 // The Row of manifold point (mi, i) for the one-lane system solver of the host emulation: the record the
 // row-setup phase left in LDS.  (Device: no Row records exist -- they were 13 KB of the env's LDS block; see
 // SerialRows.)
@@ -1582,7 +1595,7 @@ RV_DEV int isl_row_on(int s, int ntx, int nax, int nty, int nay, int nxy) {
   const int p = (s - 24 * blk) / 3;
   return blk == 0 ? (p < 4 ? p < ntx : p - 4 < nax) : (blk == 1 ? (p < 4 ? p < nty : p - 4 < nay) : p < nxy);
 }
-RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, const int kxy) {
+RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, const int kxy, const float tol) {
   DevEnv& e = S.e; const rv_config* c = K.cfg;
   const int lane = (int)threadIdx.x;
   const int ntx = __builtin_amdgcn_readfirstlane(e.man[RV_TIDX(X)].n), nax = __builtin_amdgcn_readfirstlane(e.man[RV_AIDX(X)].n);
@@ -1660,7 +1673,7 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
   }
 #pragma unroll
   for (int s = 48; s < 60; ++s) if (Y >= 0 && isl_row_on(s, ntx, nax, nty, nay, nxy)) g = g + A[s] * rdlane(lam, s);
-  const int iters = c->solver_iters; const float tol = c->solver_tol;
+  const int iters = c->solver_iters;
   RV_PROF(26)
   // (v_med3 gives what the ternaries of the host version give for every finite input; the
   // residual |d| is tracked on the scalar unit through its bit pattern, whose integer order is the
@@ -1788,7 +1801,7 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
 template <int S_> RV_DEV float grp_bcast(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x10 | (S_ << 5)));
 }
-RV_DEV void solve_singles(Shared& S, const Consts& K, const int smask) {
+RV_DEV void solve_singles(Shared& S, const Consts& K, const int smask, const int unrest) {
   DevEnv& e = S.e; const rv_config* c = K.cfg;
   const int lane = (int)threadIdx.x;
   const int b = lane >> 4, r = lane & 15;
@@ -1861,8 +1874,10 @@ RV_DEV void solve_singles(Shared& S, const Consts& K, const int smask) {
     for (int s = 0; s < 12; ++s) if (s / 3 < nt) g = g + A[s] * ls[s];
   }
   RV_PROF(26)
-  const int iters = c->solver_iters; const float tol = c->solver_tol;
-  const int toli = __builtin_bit_cast(int, tol);
+  const int iters = c->solver_iters;
+  // every island (= body) stops on its own tolerance: solver_tol_rest when the body is at rest (tol_of)
+  const int toli0 = __builtin_bit_cast(int, tol_of(c, unrest & 1)), toli1 = __builtin_bit_cast(int, tol_of(c, unrest & 2)),
+            toli2 = __builtin_bit_cast(int, tol_of(c, unrest & 4)), toli3 = __builtin_bit_cast(int, tol_of(c, unrest & 8));
   const int stall = c->solver_stall;
   int best0 = 0x7f800000, best1 = 0x7f800000, best2 = 0x7f800000, best3 = 0x7f800000;
   int since0 = 0, since1 = 0, since2 = 0, since3 = 0;
@@ -1904,7 +1919,7 @@ RV_DEV void solve_singles(Shared& S, const Consts& K, const int smask) {
     const int res0 = __builtin_amdgcn_readlane(resv, 0), res1 = __builtin_amdgcn_readlane(resv, 16),
               res2 = __builtin_amdgcn_readlane(resv, 32), res3 = __builtin_amdgcn_readlane(resv, 48);
     // every island stops on its own residual / stall count
-    if (tol > 0.0f) done |= (res0 < toli ? 1 : 0) | (res1 < toli ? 2 : 0) | (res2 < toli ? 4 : 0) | (res3 < toli ? 8 : 0);
+    done |= (res0 < toli0 ? 1 : 0) | (res1 < toli1 ? 2 : 0) | (res2 < toli2 ? 4 : 0) | (res3 < toli3 ? 8 : 0);     // (a tolerance of 0: never)
     if (stall > 0) {
       if (!(done & 1)) { if (res0 < best0) { best0 = res0; since0 = 0; } else if (++since0 >= stall) done |= 1; }
       if (!(done & 2)) { if (res1 < best1) { best1 = res1; since1 = 0; } else if (++since1 >= stall) done |= 2; }
@@ -2168,7 +2183,7 @@ RV_DEV void solve_island_fingers(Shared& S, const Consts& K, const int X, const 
 // fing != 0 (rv_config.finger_dynamics, at most one awake body): the two finger joints are DOFs of
 // the system as well -- contact rows on a finger pad carry jf on their finger's velocity, each finger
 // has a motor row after the contact rows (see solve_island_fingers, the device version)
-RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int fing, const int limb, const int motor_isl) {
+RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int fing, const int limb, const int motor_isl, const float* isl_tol) {
   DevEnv& e = S.e; const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
   static thread_local float A[RV_SOLVE_ROWS + 9][RV_SOLVE_ROWS + 9];
   float g[RV_SOLVE_ROWS + 9], lam[RV_SOLVE_ROWS + 9], invk[RV_SOLVE_ROWS + 9], bias[RV_SOLVE_ROWS + 9], mu[RV_SOLVE_ROWS + 9], cap[RV_SOLVE_ROWS + 9];
@@ -2325,7 +2340,7 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
       else rv_emu_cnt[36] += it + 1;
     }
 #endif
-    for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < c->solver_tol) done |= 1 << x;
+    for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < (((fing || limb) && x == fisl) ? c->solver_tol : isl_tol[x])) done |= 1 << x;
     // stalled islands (rv_config.solver_stall): no new smallest residual for that many sweeps
     for (int x = 0; c->solver_stall > 0 && x < RV_MAXB; ++x) {
       if (!((isl_rows >> x) & 1) || ((done >> x) & 1)) continue;
@@ -3979,7 +3994,8 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       for (int kk = 0; kk < RV_NBB; ++kk) if (bb_a(kk) == b && bb_b(kk) == y_) kxy = kk;
       isl_y[b] = mem_[b] == 2 ? y_ : -1; isl_k[b] = mem_[b] == 2 ? kxy : 0;
     }
-    if (smask) solve_singles(S, K, smask);
+    const int unrest = __builtin_amdgcn_readfirstlane(unrest_mask(S.e));
+    if (smask) solve_singles(S, K, smask, unrest);
 #pragma nounroll
     for (int b = 0; b < RV_MAXB; ++b) {
       if ((smask >> b) & 1) continue;
@@ -3987,16 +4003,27 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
 #pragma unroll
       for (int x = 0; x < RV_MAXB; ++x) if (x == b) { m_ = mem_[x]; y_ = isl_y[x]; kxy = isl_k[x]; }
       m_ = (!others_ok || (lone && b == the_body)) ? 0 : __builtin_amdgcn_readfirstlane(m_);
-      if (m_ == 1 || m_ == 2)
-        solve_island2(S, K, b, __builtin_amdgcn_readfirstlane(y_), __builtin_amdgcn_readfirstlane(kxy));
+      if (m_ == 1 || m_ == 2) {
+        const int y1 = __builtin_amdgcn_readfirstlane(y_);
+        solve_island2(S, K, b, y1, __builtin_amdgcn_readfirstlane(kxy), tol_of(c, unrest & ((1 << b) | (y1 >= 0 ? 1 << y1 : 0))));
+      }
     }
   }
 #else
   RV_LANES_BEGIN
     if (lane == 0) S.s.n_rows = (!fing_fast && (with_fingers || any_con)) ? 0 : solver_row_list(S, label, on_, act_, big_);
   RV_LANES_END
-  if (fing_fast) solve_rows(S, K, S.s.n_rows < 0 ? 0 : S.s.n_rows, with_fingers, limb, lone ? label[the_body] : -1);
-  else if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows, 0, 0, -1);
+  float isl_tol[RV_MAXB];
+  {
+    const int unrest = unrest_mask(S.e);
+    for (int x = 0; x < RV_MAXB; ++x) {
+      int u_ = 0;
+      for (int b = 0; b < RV_MAXB; ++b) if (on_[b] && label[b] == x) u_ |= (unrest >> b) & 1;
+      isl_tol[x] = tol_of(c, u_);
+    }
+  }
+  if (fing_fast) solve_rows(S, K, S.s.n_rows < 0 ? 0 : S.s.n_rows, with_fingers, limb, lone ? label[the_body] : -1, isl_tol);
+  else if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows, 0, 0, -1, isl_tol);
 #endif
   if (limb) { arm_lq_phase(S, K); arm_fk_phases(S, K); }   // the link frames follow the solved joint state
   // an island of three or four bodies (there can be only one): velocity-space Gauss-Seidel in the
@@ -4049,6 +4076,14 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       return r;
     };
     float big_best = 1e30f; int big_since = 0;        // rv_config.solver_stall
+    float big_tol;                                     // the island's own tolerance (tol_of)
+    {
+      const int unrest = __builtin_amdgcn_readfirstlane(unrest_mask(S.e));
+      int u_ = 0;
+#pragma unroll
+      for (int x = 0; x < RV_MAXB; ++x) if (on_[x] && label[x] == root) u_ |= (unrest >> x) & 1;
+      big_tol = tol_of(c, __builtin_amdgcn_readfirstlane(u_));
+    }
     const int iters = c->solver_iters;
     for (int it = -1; it < iters; ++it) {             // it == -1: warm start
       {
@@ -4112,7 +4147,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
 #pragma unroll
       for (int t = 0; t < 10; ++t) res = fmaxr(res, S.s.res[t]);
       res = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, res)));
-      if (it >= 0 && res < c->solver_tol) break;
+      if (it >= 0 && res < big_tol) break;
       if (it >= 0 && c->solver_stall > 0) { if (res < big_best) { big_best = res; big_since = 0; } else if (++big_since >= c->solver_stall) break; }
       __syncthreads();          // (S.s.res is written again by the next sweep)
     }
@@ -4171,7 +4206,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       float res = 0.0f;
 #pragma unroll
       for (int t = 0; t < 10; ++t) res = fmaxr(res, S.s.res[t]);
-      if (it >= 0 && res < c->solver_tol) break;
+      if (it >= 0 && res < isl_tol[root]) break;
       if (it >= 0 && c->solver_stall > 0) { if (res < big_best) { big_best = res; big_since = 0; } else if (++big_since >= c->solver_stall) break; }
     }
   }
@@ -4215,9 +4250,10 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
           e.frozen[b] = 1;
           st3(e.body[b] + 7, mk(0, 0, 0)); st3(e.body[b] + 10, mk(0, 0, 0));
         }
-        if (c->sleep_steps > 0) {   // deactivation counter
-          if (dot(v, v) < c->sleep_lin * c->sleep_lin && dot(w, w) < c->sleep_ang * c->sleep_ang) e.sleep_count[b]++;
-          else { e.sleep_count[b] = 0; }
+        // substeps in a row below the sleep thresholds (the deactivation counter; also what makes a row a 'rest' row of the solver)
+        if (dot(v, v) < c->sleep_lin * c->sleep_lin && dot(w, w) < c->sleep_ang * c->sleep_ang) e.sleep_count[b]++;
+        else { e.sleep_count[b] = 0; }
+        if (c->sleep_steps > 0) {
           // in-place oscillation: the pose has not left a small window around where
           // it was when the window opened
           if (c->sleep_pos_win > 0.0f) {

@@ -54,7 +54,8 @@ def _check(e, ref):
 @pytest.mark.parametrize('over', [{}, dict(TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=3),
                                   dict(MIN_MOVABLE_BODIES=1, MAX_MOVABLE_BODIES=4, NUM_GOAL_STEPS=2),
                                   {'PHYSICS.ARM_EFFORT_LIMIT': 1}, {'PHYSICS.GRAVITY_XY': (0.3, -0.2)},
-                                  {'PHYSICS.LIMB_DYNAMICS': 1}, {'PHYSICS.SOLVER_STALL': 0}, {'PHYSICS.SOLVER_STALL': 3}])
+                                  {'PHYSICS.LIMB_DYNAMICS': 1}, {'PHYSICS.SOLVER_STALL': 0}, {'PHYSICS.SOLVER_STALL': 3},
+                                  {'PHYSICS.SLEEP_STEPS': 0, 'MAX_STEPS': 2}, {'PHYSICS.SOLVER_TOL_REST': 1e-7}, {'PHYSICS.SLEEP_STEPS': 0, 'PHYSICS.SOLVER_TOL_REST': 0.0, 'MAX_STEPS': 2}])
 def test_emulated_kernel_is_bit_exact_vs_float_oracle(emu, over):
     from oracle import orc
     scene, names = scenes.make_scene()

@@ -157,7 +157,8 @@ def test_wide_rollout_matches_oracle_bit_for_bit():
 
 
 @pytest.mark.parametrize('over', [{'PHYSICS.ARM_EFFORT_LIMIT': 1}, {'PHYSICS.GRAVITY_XY': (0.3, -0.2)},
-                                  {'PHYSICS.SLEEP_STEPS': 0}])
+                                  {'PHYSICS.SLEEP_STEPS': 0}, {'PHYSICS.SOLVER_TOL_REST': 1e-7},
+                                  {'PHYSICS.SLEEP_STEPS': 0, 'PHYSICS.SOLVER_TOL_REST': 1e-6, 'MIN_MOVABLE_BODIES': 4, 'MAX_MOVABLE_BODIES': 4}])
 def test_optional_physics_match_oracle_bit_for_bit(over):
     """The optional pieces -- joint-effort limit on the arm's contact forces, a tilted gravity
     vector (set_gravity), no deactivation at all -- through a rollout with resets."""

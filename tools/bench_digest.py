@@ -24,7 +24,7 @@ for leg in ('config2_k50', 'lockstep_env_step', 'lockstep_partial', 'async_rollo
 print('limb', r(g('limb_dynamics', 'push_1024', 'value')), r(g('limb_dynamics', 'grasp_2048', 'value')))
 for k, v in (g('deactivation') or {}).items():
     if isinstance(v, dict) and 'value' in v:
-        print('deactivation.' + k, r(v['value']), 'disp', r(v.get('disp_mean_mm')), 'useful/unsafe/ineff',
+        print('deactivation.' + k, r(v['value']), 'disp', r(v.get('disp_mean_mm')), 'p50', v.get('disp_p50_mm'), 'useful/unsafe/ineff',
               round(v['useful'], 3), round(v['unsafe'], 3), round(v['ineffective'], 3))
 for k, v in (g('reference_semantics') or {}).items():
     if isinstance(v, dict):

@@ -37,7 +37,11 @@ VARIANTS = [
      {'PHYSICS.SLEEP_LINEAR': 0.8, 'PHYSICS.SLEEP_ANGULAR': 1.0, 'PHYSICS.SLEEP_STEPS': 2000, 'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.DEACTIVATION_STEPS': 0}),
     ('sleep: without Bullet\'s rule (the strict thresholds and the pose window only)', {'PHYSICS.DEACTIVATION_STEPS': 0}),
     ('sleep: strict velocity thresholds only (no pose window, no Bullet rule)', {'PHYSICS.SLEEP_POSITION_WINDOW': 0.0, 'PHYSICS.DEACTIVATION_STEPS': 0}),
-    ('no deactivation at all', {'PHYSICS.SLEEP_STEPS': 0}),
+    ('no deactivation at all (resting islands converge to 1e-7 N s: SOLVER_TOL_REST auto)', {'PHYSICS.SLEEP_STEPS': 0}),
+    ('no deactivation, one residual (1e-5 N s) for every island (round 3: resting bodies creep)', {'PHYSICS.SLEEP_STEPS': 0, 'PHYSICS.SOLVER_TOL_REST': 0.0}),
+    ('shipped + resting islands converge to 1e-7 N s', {'PHYSICS.SOLVER_TOL_REST': 1e-7}),
+    ('no deactivation, residual exit at 1e-7 N s for every island', {'PHYSICS.SLEEP_STEPS': 0, 'PHYSICS.SOLVER_TOL': 1e-7}),
+    ('no deactivation, 50 iterations, no early exit', {'PHYSICS.SLEEP_STEPS': 0, 'PHYSICS.SOLVER_TOL': 0.0, 'PHYSICS.SOLVER_STALL': 0}),
     ('contact breaking factor 0.04 (Bullet: 0.02 x the smaller shape\'s disc = shipped)', {'PHYSICS.BREAKING': 0.04}),
     ('narrow phase every substep (no gating)', {'PHYSICS.NARROWPHASE_MAX_AGE': 0}),
     ('all Bullet defaults (solver + sleep, no gating)',
@@ -83,9 +87,12 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--seed', type=int, default=1234)
     ap.add_argument('--json', default=None)
+    ap.add_argument('--only', default=None, help='run the variants whose name contains this text')
     args = ap.parse_args()
     rows = []
     for name, over in VARIANTS:
+        if args.only and args.only not in name:
+            continue
         res = run(over, args.envs, args.steps, args.seed)
         rows.append((name, over, res))
     print('# tools/sensitivity.py: BASELINE config 2, %d envs x %d env.step() (random policy, seed %d, one rv_rollout_record launch)'
