@@ -1796,10 +1796,12 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
 // deactivation (the reference's most likely semantics) all four bodies of the scene are such islands in
 // most substeps.  The rows are set up by the solver lanes themselves (row_setup()'s arithmetic for a
 // body - table point, one row per lane): no Row records go through LDS for them.
-// lane S of the caller's own 16-lane group, to every lane of the group: ds_swizzle in bit mode (source lane =
-// (lane & 0x10) | S within each half of the wave) -- the LDS crossbar, no LDS memory, no trip through SGPRs
+// lane S of the caller's own 16-lane group, to every lane of the group: the DPP control row_newbcast:S (gfx90a and
+// later: "broadcast lane S of each row of 16 to the whole row") -- ONE VALU instruction, which the compiler folds into
+// the consumer (v_fma / v_mul ..._dpp); no trip through SGPRs, and not the ~100 clocks of the LDS crossbar that the
+// ds_swizzle of the first version took on the critical path of every row step
 template <int S_> RV_DEV float grp_bcast(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x10 | (S_ << 5)));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + S_, 0xf, 0xf, false));
 }
 RV_DEV void solve_singles(Shared& S, const Consts& K, const int smask, const int unrest) {
   DevEnv& e = S.e; const rv_config* c = K.cfg;
@@ -1889,12 +1891,8 @@ RV_DEV void solve_singles(Shared& S, const Consts& K, const int smask, const int
     const bool alive = act && !((done >> b) & 1);
     const float invk_e = alive ? invk : 0.0f;
     int resv = 0;              // largest |d| of this lane's island in this sweep (bit pattern)
-    // One island left (a single body sliding on: the usual case with deactivation): its rows are broadcast
-    // with v_readlane at a wave-uniform lane index -- half the latency of the LDS crossbar.  (The lanes of the
-    // other groups see its values too; their rows are inert and their g is dead.)
-    const int alive_mask = (~done) & 15;
-    const bool one = (alive_mask & (alive_mask - 1)) == 0;
-    const int base = alive_mask == 1 ? 0 : (alive_mask == 2 ? 16 : (alive_mask == 4 ? 32 : 48));
+    // (the change of row s is broadcast inside each 16-lane group with the DPP control row_newbcast:s -- grp_bcast;
+    // a v_readlane variant for the case of one island left was 3 % slower than this and is gone)
 #define RV_ROW_STEP(pp_, kk_, BC_) { \
       constexpr int s_ = 3 * pp_ + kk_; \
       float nl; \
@@ -1907,14 +1905,11 @@ RV_DEV void solve_singles(Shared& S, const Consts& K, const int smask, const int
       const int mag = __builtin_bit_cast(int, sd) & 0x7fffffff; \
       resv = resv > mag ? resv : mag; \
       if (pp_ < nt && alive) g = g + A[s_] * sd; }
-#define RV_BC_SWZ(x_, s_) grp_bcast<s_>(x_)
-#define RV_BC_RDL(x_, s_) rdlane(x_, base + s_)
+#define RV_BC_DPP(x_, s_) grp_bcast<s_>(x_)
 #define RV_POINT(pp_, BC_) if (pp_ < nmax) { float lim = 0.0f; RV_ROW_STEP(pp_, 0, BC_) RV_ROW_STEP(pp_, 1, BC_) RV_ROW_STEP(pp_, 2, BC_) }
-    if (one) { RV_POINT(0, RV_BC_RDL) RV_POINT(1, RV_BC_RDL) RV_POINT(2, RV_BC_RDL) RV_POINT(3, RV_BC_RDL) }
-    else { RV_POINT(0, RV_BC_SWZ) RV_POINT(1, RV_BC_SWZ) RV_POINT(2, RV_BC_SWZ) RV_POINT(3, RV_BC_SWZ) }
+    RV_POINT(0, RV_BC_DPP) RV_POINT(1, RV_BC_DPP) RV_POINT(2, RV_BC_DPP) RV_POINT(3, RV_BC_DPP)
 #undef RV_POINT
-#undef RV_BC_SWZ
-#undef RV_BC_RDL
+#undef RV_BC_DPP
 #undef RV_ROW_STEP
     const int res0 = __builtin_amdgcn_readlane(resv, 0), res1 = __builtin_amdgcn_readlane(resv, 16),
               res2 = __builtin_amdgcn_readlane(resv, 32), res3 = __builtin_amdgcn_readlane(resv, 48);
