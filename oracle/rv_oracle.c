@@ -1421,7 +1421,9 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
       res[isl] = rmax(res[isl], rabs(d));
       for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s2] * d;
     }
-    for (int m = 0; fing && m < 2; ++m) {
+    /* (the motor rows belong to island fisl and stop with it -- other islands may still be sweeping) */
+    const int motors_on = !((done >> fisl) & 1);
+    for (int m = 0; fing && motors_on && m < 2; ++m) {
       const int q = n_rows + m;
       const real nl = rclamp(lam[q] + (-g[q] * invk[q]), mlo[m], mhi[m]);
       const real d = nl - lam[q];
@@ -1429,7 +1431,7 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
       res[fisl] = rmax(res[fisl], rabs(d));
       for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][q] * d;
     }
-    for (int j = 0; j < nlm; ++j) {
+    for (int j = 0; motors_on && j < nlm; ++j) {
       const int q = n_rows + nfm + j;
       const real nl = rclamp(lam[q] + (-g[q] * invk[q]), L->lo[j], L->hi[j]);
       const real d = nl - lam[q];

@@ -2306,7 +2306,9 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
 #endif
       for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s] * d;
     }
-    for (int m = 0; fing && m < 2; ++m) {
+    // (the motor rows belong to island fisl and stop with it -- other islands may still be sweeping)
+    const int motors_on = !((done >> fisl) & 1);
+    for (int m = 0; fing && motors_on && m < 2; ++m) {
       const int q = n_rows + m;
       const float nl = fclampr(lam[q] + (-g[q] * invk[q]), mlo[m], mhi[m]);
       const float d = nl - lam[q];
@@ -2314,7 +2316,7 @@ RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int f
       res[fisl] = fmaxr(res[fisl], fabsr(d));
       for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][q] * d;
     }
-    for (int j = 0; j < nlm; ++j) {
+    for (int j = 0; motors_on && j < nlm; ++j) {
       const int q = n_rows + nfm + j;
       const float nl = fclampr(lam[q] + (-g[q] * invk[q]), S.s.llo[j], S.s.lhi[j]);
       const float d = nl - lam[q];

@@ -196,3 +196,22 @@ def test_limb_dynamics_env_steps_match_the_oracle_bit_for_bit():
         for k in ('env_steps', 'substeps', 'awake_substeps', 'useful', 'successes'):
             assert ws[k] == rs[k], k
         w.close()
+
+
+@pytest.mark.gpu
+def test_lone_limb_island_stops_on_its_own_while_another_island_sweeps_on():
+    """Several awake bodies of which ONE touches the arm and is an island by itself: the limb motor rows belong to that
+    island and stop sweeping with it, while the island of another body may need more sweeps.  (Found by
+    tools/parity_sweep.py at 256 envs: the oracle kept iterating the motor rows for as long as ANY island iterated;
+    env 73 of seed 1001 is such a case in its third env.step().)"""
+    from robovat_amd import lib
+    from oracle import orc
+    scene, names = scenes.make_scene()
+    ecfg = configs.push_env_config(**{'PHYSICS.LIMB_DYNAMICS': 1, 'MIN_MOVABLE_BODIES': 1, 'MAX_MOVABLE_BODIES': 4})
+    cfg = configs.make_rv_config(env_cfg=ecfg, n_envs=96, seed=1001, shape_names=names)
+    w, ref = lib.World(cfg, scene, device=0), orc.OracleWorld(cfg, scene, double=False)
+    w.reset(); ref.reset()
+    w.rollout(4, first_macro_index=0, auto_reset=True, record=False); ref.rollout(4, 0, True)
+    assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
+    assert np.array_equal(w.joint_state().cpu().numpy(), ref.joint_state().astype(np.float32))
+    w.close()

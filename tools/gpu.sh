@@ -15,6 +15,7 @@
 #   parts_nd       per-part table with PHYSICS.SLEEP_STEPS=0, 2 steps
 #   parts_c3 / parts_c4 / parts_c5   per-part tables of configs 3 / 4 / 5
 #   variants       headline + configs 5 / 3 / 4 for the product library and every build/librovat_*.so
+#   sweep          tools/parity_sweep.py for both builds of the env kernel
 #   lanes          SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU lane-utilisation pass (headline and no-deactivation)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
@@ -56,6 +57,11 @@ for STAGE in "$@"; do
         rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/lanes_$V -o l --output-format csv -- $CMD > $O/lanes_$V.log 2>&1
       done
       cd $R; python tools/pmc_summary.py $O/lanes_head $O/lanes_nd > $O/lanes.txt 2>&1; cat $O/lanes.txt ;;
+    sweep)
+      # HIP == float oracle bit for bit over seeds / configs, for both builds of the env kernel
+      (echo "# tools/parity_sweep.py 8 256 6, register-rich build (RV_ENV_OCC=1)"; RV_ENV_OCC=1 timeout 1500 python tools/parity_sweep.py 8 256 6;
+       echo "# tools/parity_sweep.py 4 256 6, two-waves-per-SIMD build (RV_ENV_OCC=2)"; RV_ENV_OCC=2 timeout 1500 python tools/parity_sweep.py 4 256 6) > $O/parity_sweep.txt 2>&1
+      grep -c "True joints True" $O/parity_sweep.txt; grep MISMATCH $O/parity_sweep.txt ;;
     variants)
       # every library variant under build/ (and the product library): headline, config 5 / 3 / 4 single-launch rollouts
       for SO in robovat_amd/librovat_hip.so $(ls build/librovat_*.so 2>/dev/null); do
