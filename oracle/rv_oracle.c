@@ -18,7 +18,14 @@
  *     which is neither vendored under the reference tree nor installed here.
  *     The restated algorithm (GJK/EPA + persistent manifolds + PGS sequential
  *     impulses + kinematic articulated pusher + DLS IK) is specified in
- *     DESIGN.md §3 and anchored on the reference's call sites only.
+ *     DESIGN.md §3 and anchored on the reference's call sites only.  What
+ *     stands in for the missing reference run: analytic known answers
+ *     (tests/test_kat_contact.py, test_oracle_kat.py) and an INDEPENDENT numerical
+ *     pin that reads none of this file's solver or collision data
+ *     (tests/test_independent_pin.py: float64 complementarity certificate of the
+ *     contact solve, closed-form GJK / EPA cases, impulse-momentum bookkeeping of a
+ *     whole push, FP32-vs-FP64 tolerance at the end of an env.step()).
+ *     That pins the arithmetic to the published model, not to Bullet's binary.
  *
  * Build: see oracle/Makefile (float build = bit-for-bit target of the HIP
  * kernels; -DORC_DOUBLE build = pose-error oracle of record).

@@ -17,16 +17,26 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 CASES = [('config 2', {}), ('crossing / concave', dict(TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)),
          ('crowded: 4 bodies in a 20 cm square', {'MOVABLE.CONVEX.POSE.X': [0.5, 0.7], 'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07}),
          ('dynamic limb, 1-4 bodies', {'PHYSICS.LIMB_DYNAMICS': 1, 'MIN_MOVABLE_BODIES': 1, 'MAX_MOVABLE_BODIES': 4}),
-         ('no deactivation', {'PHYSICS.SLEEP_STEPS': 0, 'MAX_STEPS': 2})]
+         ('no deactivation', {'PHYSICS.SLEEP_STEPS': 0, 'MAX_STEPS': 2}),
+         ('no deactivation, crowded, rest tol 1e-6', {'PHYSICS.SLEEP_STEPS': 0, 'PHYSICS.SOLVER_TOL_REST': 1e-6, 'MAX_STEPS': 2, 'MOVABLE.CONVEX.POSE.X': [0.5, 0.7],
+                                                      'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07}),
+         ('arm effort limit + tilted gravity', {'PHYSICS.ARM_EFFORT_LIMIT': 1, 'PHYSICS.GRAVITY_XY': (0.3, -0.2)}),
+         ('dynamic limb, crowded', {'PHYSICS.LIMB_DYNAMICS': 1, 'MOVABLE.CONVEX.POSE.X': [0.5, 0.7], 'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07}),
+         ('user constraints (p2p to the world, body - body fixed)', {'CONSTRAINTS': 1})]
 bad = 0
 for name, over in CASES:
     scene, names = scenes.make_scene()
     for seed in range(n_seeds):
+        over = dict(over); cons = over.pop('CONSTRAINTS', 0)
         cfg = configs.make_rv_config(env_cfg=configs.push_env_config(**over), n_envs=n, seed=1000 + seed, shape_names=names)
         w = lib.World(cfg, scene, device=0); o = orc.OracleWorld(cfg, scene, double=False)
         w.reset(); o.reset()
-        w.rollout(steps, first_macro_index=0, auto_reset=True, record=False); w.synchronize()
-        o.rollout(steps, 0, True)
+        if cons:      # (the constraints are per world: every env gets them; a reset drops them, so no auto-reset below)
+            for x in (w, o):
+                x.set_constraint(1, [0.6, 0.05 * (seed % 3), 0.12, 0, 0, 0, 1], frame7=[0.02, 0.01, 0.0, 0, 0, 0, 1], max_force=30.0, joint_type='point2point')
+                x.set_constraint(2, [0.0, 0.0, 0.07, 0, 0, 0, 1], max_force=40.0, child=0)
+        w.rollout(steps if not cons else 2, first_macro_index=0, auto_reset=not cons, record=False); w.synchronize()
+        o.rollout(steps if not cons else 2, 0, not cons)
         eq_b = np.array_equal(w.body_state().cpu().numpy(), o.body_state().astype(np.float32))
         eq_j = np.array_equal(w.joint_state().cpu().numpy(), o.joint_state().astype(np.float32))
         eq_c = np.array_equal(w.env_counters().cpu().numpy()[:, :8], o.env_counters()[:, :8])
