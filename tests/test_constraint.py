@@ -183,3 +183,28 @@ def test_simulator_add_constraint_and_pose_servo():
     for _ in range(400):
         sim.step()
     assert body.position[2] < p0[2] - 0.03                                # free again: it falls
+
+
+@pytest.mark.gpu
+def test_constraint_entry_point_rejects_what_is_not_built():
+    """rv_set_constraint_ex: unknown joint types are RV_ERR_NOTIMPL, a bad body / child slot or a null target RV_ERR_VALUE
+    (bullet_physics.py:748-806 would hand pybullet a prismatic / gear joint; this build has none)."""
+    import ctypes as C
+    from robovat_amd import lib
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(n_envs=2, seed=3, shape_names=names)
+    w = lib.World(cfg, scene, device=0)
+    w.reset()
+    L = lib.load()
+    t7 = (C.c_float * 7)(0.6, 0.0, 0.1, 0, 0, 0, 1)
+    call = lambda body, child, jt, tgt, f: L.rv_set_constraint_ex(w.h, body, child, jt, None, tgt, f)
+    assert call(0, -1, 1, t7, 10.0) == abi.RV_ERR_NOTIMPL            # pybullet.JOINT_PRISMATIC
+    assert call(0, -1, 6, t7, 10.0) == abi.RV_ERR_NOTIMPL            # pybullet.JOINT_GEAR
+    assert call(abi.RV_MAXB, -1, 4, t7, 10.0) == abi.RV_ERR_VALUE     # not a movable body slot
+    assert call(0, 0, 4, t7, 10.0) == abi.RV_ERR_VALUE                # a body cannot be its own child
+    assert call(0, -1, 4, None, 10.0) == abi.RV_ERR_VALUE             # no target
+    assert call(0, 1, 5, t7, 10.0) == abi.RV_OK                       # point2point between two bodies
+    assert call(0, -1, 4, None, -1.0) == abi.RV_OK                    # removal needs no target
+    with pytest.raises(NotImplementedError):
+        w.set_constraint(0, [0.6, 0, 0.1, 0, 0, 0, 1], joint_type='prismatic')
+    w.close()
