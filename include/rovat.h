@@ -419,9 +419,12 @@ int  rv_set_constraint(rv_world* w, int32_t body, const float* frame7, const flo
 /* The same with the other arguments of BulletPhysics.add_constraint (bullet_physics.py:748-806: createConstraint(parent,
  * parentLink, child, childLink, jointType, jointAxis, parentFramePosition, childFramePosition, ...)): `child` = -1 (the
  * world) or another movable body slot -- child_frame7 is then given in the CHILD's frame and every row acts on both
- * bodies, which stay awake together; joint_type RV_JOINT_FIXED (six rows) or RV_JOINT_POINT2POINT (pybullet
- * JOINT_POINT2POINT: the three linear rows, the bodies turn freely about the pivot).  Prismatic / gear joints:
- * RV_ERR_NOTIMPL. */
+ * bodies, which stay awake together; joint_type RV_JOINT_FIXED (six rows), RV_JOINT_POINT2POINT (pybullet
+ * JOINT_POINT2POINT: the three linear rows, the bodies turn freely about the pivot) or RV_JOINT_PRISMATIC (the body
+ * slides along the X AXIS of the frame it is tied to -- child_frame7's orientation: two linear rows across that axis
+ * and the three angular rows; a jointAxis other than x is a rotation of both frames, which the HipPhysics mirror
+ * applies).  Gear joints (and revolute ones, which pybullet's createConstraint does not offer either): RV_ERR_NOTIMPL. */
+#define RV_JOINT_PRISMATIC   1   /* pybullet.JOINT_PRISMATIC */
 #define RV_JOINT_FIXED       4   /* pybullet.JOINT_FIXED */
 #define RV_JOINT_POINT2POINT 5   /* pybullet.JOINT_POINT2POINT */
 int  rv_set_constraint_ex(rv_world* w, int32_t body, int32_t child, int32_t joint_type, const float* frame7,

@@ -1168,24 +1168,33 @@ static real constraint_solve(const orc_world* w, orc_env* e, int b, real* lam) {
   qmul(qe, tq, qc);                                              /* rotation that takes it to the target frame */
   const real sg = qe[3] < R(0.0) ? R(-2.0) : R(2.0);
   const real th[3] = {qe[0] * sg, qe[1] * sg, qe[2] * sg};
-  const int n_rows = ctype == 2 ? 3 : 6;
+  /* prismatic (type 3; pybullet JOINT_PRISMATIC): the body slides along the x axis of the frame it is tied to -- two
+   * linear rows along that frame's y and z axes, then the three angular rows */
+  const int n_lin = ctype == 3 ? 2 : 3, n_rows = ctype == 2 ? 3 : n_lin + 3;
+  real rt[9], dtp[3];
+  qmat(rt, tq); v3sub(dtp, tp, wp);
   for (int k = 0; k < n_rows; ++k) {
     real jl[3] = {R(0.0), R(0.0), R(0.0)}, ja[3] = {R(0.0), R(0.0), R(0.0)}, jc[3] = {R(0.0), R(0.0), R(0.0)}, ia[3], ic[3] = {R(0.0), R(0.0), R(0.0)}, bias;
-    if (k < 3) {
+    if (k < n_lin && ctype == 3) {
+      real ek[3] = {R(0.0), R(0.0), R(0.0)}; ek[k + 1] = R(1.0);
+      m3mulv(jl, rt, ek);                                        /* column k + 1 of the frame's rotation */
+      v3cross(ja, r, jl); v3cross(jc, rc, jl);
+      bias = (real)c->erp * v3dot(jl, dtp) / dt;
+    } else if (k < n_lin) {
       jl[k] = R(1.0);
       real ek[3] = {R(0.0), R(0.0), R(0.0)}; ek[k] = R(1.0);
       v3cross(ja, r, ek); v3cross(jc, rc, ek);
       bias = (real)c->erp * (tp[k] - wp[k]) / dt;
     } else {
-      ja[k - 3] = R(1.0); jc[k - 3] = R(1.0);
-      bias = (real)c->erp * th[k - 3] / dt;
+      ja[k - n_lin] = R(1.0); jc[k - n_lin] = R(1.0);
+      bias = (real)c->erp * th[k - n_lin] / dt;
     }
     m3mulv(ia, e->iinv[b], ja);
-    real kk = (k < 3 ? P->inv_mass : R(0.0)) + v3dot(ja, ia);
+    real kk = (k < n_lin ? P->inv_mass : R(0.0)) + v3dot(ja, ia);
     real jv = v3dot(jl, B->v) + v3dot(ja, B->w);
     if (cb >= 0) {
       m3mulv(ic, e->iinv[cb], jc);
-      kk = kk + ((k < 3 ? imc : R(0.0)) + v3dot(jc, ic));
+      kk = kk + ((k < n_lin ? imc : R(0.0)) + v3dot(jc, ic));
       jv = jv - (v3dot(jl, e->body[cb].v) + v3dot(jc, e->body[cb].w));
     }
     real dl = (bias - jv) / kk;
@@ -2696,7 +2705,7 @@ void orc_set_constraint_ex(orc_world* w, int body, int child, int joint_type, co
     orc_bparam* P = &w->env[i].bp[body];
     if (max_force < 0.0) P->con_on = 0;
     else {
-      P->con_on = (joint_type == 2 ? 2 : 1) | ((child + 1) << 4); P->con_fmax = (real)max_force;
+      P->con_on = (joint_type == 2 || joint_type == 3 ? joint_type : 1) | ((child + 1) << 4); P->con_fmax = (real)max_force;
       for (int k = 0; k < 3; ++k) { P->con_lpos[k] = frame7 ? (real)frame7[k] : R(0.0); P->con_tpos[k] = (real)target7[k]; }
       for (int k = 0; k < 4; ++k) { P->con_lquat[k] = frame7 ? (real)frame7[3 + k] : (k == 3 ? R(1.0) : R(0.0)); P->con_tquat[k] = (real)target7[3 + k]; }
     }

@@ -1289,6 +1289,7 @@ RV_DEV float point_solve_g(BV& A, float ima, Lam& l, const Row& r, float* qf, fl
 // still like the world.
 #define RV_CON_FIXED 1
 #define RV_CON_P2P 2
+#define RV_CON_PRISMATIC 3
 #define RV_CON_TYPE(x) ((x) & 15)
 #define RV_CON_CHILD(x) ((((x) >> 4) & 15) - 1)
 RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
@@ -1318,24 +1319,33 @@ RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
   const float th[3] = {qe.x * sg, qe.y * sg, qe.z * sg};
   const float tp[3] = {tpv.x, tpv.y, tpv.z}, wpa[3] = {wp.x, wp.y, wp.z};
   float res = 0.0f;
-  const int n_rows = ctype == RV_CON_P2P ? 3 : 6;
+  // prismatic (RV_CON_PRISMATIC; pybullet JOINT_PRISMATIC): the body slides along the x axis of the frame it is tied
+  // to -- two linear rows along that frame's y and z axes, then the three angular rows
+  const int n_lin = ctype == RV_CON_PRISMATIC ? 2 : 3, n_rows = ctype == RV_CON_P2P ? 3 : n_lin + 3;
+  const m3 rt = qmat(tq);
+  const v3 dtp = sub(tpv, wp);
   for (int k = 0; k < n_rows; ++k) {
     v3 jl = mk(0, 0, 0), ja = mk(0, 0, 0), jc = mk(0, 0, 0); float bias;
-    if (k < 3) {
+    if (k < n_lin && ctype == RV_CON_PRISMATIC) {
+      jl = mulv(rt, mk(0.0f, k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f));      // column k + 1 of the frame's rotation
+      ja = cross(r, jl); jc = cross(rc, jl);
+      bias = c->erp * dot(jl, dtp) / dt;
+    } else if (k < n_lin) {
       const v3 ek = mk(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f);
       jl = ek; ja = cross(r, ek); jc = cross(rc, ek);
       bias = c->erp * (tp[k] - wpa[k]) / dt;
     } else {
-      ja = mk(k == 3 ? 1.0f : 0.0f, k == 4 ? 1.0f : 0.0f, k == 5 ? 1.0f : 0.0f); jc = ja;
-      bias = c->erp * th[k - 3] / dt;
+      const int a_ = k - n_lin;
+      ja = mk(a_ == 0 ? 1.0f : 0.0f, a_ == 1 ? 1.0f : 0.0f, a_ == 2 ? 1.0f : 0.0f); jc = ja;
+      bias = c->erp * th[a_] / dt;
     }
     const v3 ia = mulv(ldm(S.s.iinv[b]), ja);
-    float kk = (k < 3 ? ima : 0.0f) + dot(ja, ia);
+    float kk = (k < n_lin ? ima : 0.0f) + dot(ja, ia);
     float jv = dot(jl, ld3(e.body[b] + 7)) + dot(ja, ld3(e.body[b] + 10));
     v3 ic = mk(0, 0, 0);
     if (cb >= 0) {
       ic = mulv(ldm(S.s.iinv[cb]), jc);
-      kk = kk + ((k < 3 ? imc : 0.0f) + dot(jc, ic));
+      kk = kk + ((k < n_lin ? imc : 0.0f) + dot(jc, ic));
       jv = jv - (dot(jl, ld3(e.body[cb] + 7)) + dot(jc, ld3(e.body[cb] + 10)));
     }
     float dl = (bias - jv) / kk;

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 from robovat_amd import abi, configs, scenes
-from robovat_amd.math import Pose
+from robovat_amd.math import Pose, rotations
 from robovat_amd.simulation.physics.physics import Physics
 
 TABLE_UID = 100
@@ -358,11 +358,11 @@ class HipPhysics(Physics):
     # ---- user constraints (bullet_physics.py:748-957: createConstraint / changeConstraint / removeConstraint)
     def add_constraint(self, parent_uid, child_uid, joint_type='fixed', joint_axis=[0, 0, 0],
                        parent_frame_pose=None, child_frame_pose=None):
-        """A 'fixed' or 'point2point' joint between a frame of a movable body (the parent) and a frame of the world
+        """A 'fixed', 'point2point' or 'prismatic' (along joint_axis) joint between a frame of a movable body (the parent) and a frame of the world
         (child None: the constraint ControllableConstraint servoes) or of another movable body (the child).
-        Prismatic / gear joints (and links of the arm as parties) are not built.  Returns the constraint uid."""
-        if joint_type not in ('fixed', 'point2point'):
-            raise NotImplementedError("joint types built: 'fixed', 'point2point' (not %r)" % (joint_type,))
+        Gear joints (and links of the arm as parties) are not built.  Returns the constraint uid."""
+        if joint_type not in ('fixed', 'point2point', 'prismatic'):
+            raise NotImplementedError("joint types built: 'fixed', 'point2point', 'prismatic' (not %r)" % (joint_type,))
         b = self._slot(parent_uid)
         child = -1 if child_uid is None else self._slot(child_uid)
         if child == b:
@@ -376,6 +376,20 @@ class HipPhysics(Physics):
                 child_frame_pose = self.get_body_pose(child).inverse().transform(child_frame_pose)
         pose = Pose(child_frame_pose)
         self._constraints[b] = {'frame': frame, 'pose': pose, 'max_force': 500.0, 'child': child, 'joint_type': joint_type}     # pybullet's default maxForce
+        if joint_type == 'prismatic':
+            # the library slides along the x axis of the joint frame: a joint_axis (given in the child's joint frame,
+            # pybullet's jointAxis) other than x is the same rotation applied to both joint frames
+            a = np.asarray(joint_axis, np.float64)
+            if not np.linalg.norm(a) > 0.0:
+                raise ValueError('a prismatic joint needs a joint_axis')
+            a = a / np.linalg.norm(a)
+            n = np.cross([1.0, 0.0, 0.0], a)
+            if np.linalg.norm(n) < 1e-12:
+                qr = np.array([0.0, 0.0, 0.0, 1.0]) if a[0] > 0 else np.array([0.0, 0.0, 1.0, 0.0])
+            else:
+                th = np.arctan2(np.linalg.norm(n), a[0])
+                qr = np.concatenate([np.sin(0.5 * th) * n / np.linalg.norm(n), [np.cos(0.5 * th)]])
+            self._constraints[b]['axis_quat'] = qr
         self._push_constraint(b)
         return b
 
@@ -383,6 +397,8 @@ class HipPhysics(Physics):
         c = self._constraints[b]
         f = np.concatenate([np.asarray(c['frame'].position, np.float64), np.asarray(c['frame'].quaternion, np.float64)])
         t = np.concatenate([np.asarray(c['pose'].position, np.float64), np.asarray(c['pose'].quaternion, np.float64)])
+        if 'axis_quat' in c:
+            f[3:] = rotations.quaternion_multiply(f[3:], c['axis_quat']); t[3:] = rotations.quaternion_multiply(t[3:], c['axis_quat'])
         self._world.set_constraint(b, t, frame7=f, max_force=c['max_force'], child=c.get('child', -1), joint_type=c.get('joint_type', 'fixed'))
 
     def _con(self, uid):

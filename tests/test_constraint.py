@@ -148,6 +148,19 @@ def test_hip_equals_oracle_with_constraints():
     a = ref.policy_random(1)
     w.set_actions(a); ref.set_actions(a); w.step_macro(); ref.step_macro()
     assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
+    # prismatic joints: body 1 on a rail through the air (world), body 3 sliding on body 0
+    st = ref.body_state()[0]
+    qz = [0, 0, np.sin(0.4), np.cos(0.4)]
+    for x in (w, ref):
+        x.remove_constraint(1); x.remove_constraint(2)
+        x.set_constraint(1, [float(st[1, 0]), float(st[1, 1]), float(st[1, 2]) + 0.03] + qz, frame7=[0, 0, 0.01] + qz, max_force=60.0, joint_type='prismatic')
+        x.set_constraint(3, [0.0, 0.0, 0.08, 0, 0, 0, 1], max_force=40.0, child=0, joint_type='prismatic')
+    for k in range(3):
+        w.step_sub(150); ref.step_sub(150)
+        assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32)), k
+    a = ref.policy_random(2)
+    w.set_actions(a); ref.set_actions(a); w.step_macro(); ref.step_macro()
+    assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
     w.close()
 
 
@@ -178,11 +191,21 @@ def test_simulator_add_constraint_and_pose_servo():
     with pytest.raises(ValueError):
         sim.add_constraint(body, body, joint_type='fixed')
     with pytest.raises(NotImplementedError):
-        sim.add_constraint(body, None, joint_type='prismatic')
+        sim.add_constraint(body, None, joint_type='gear')
     sim.remove_constraint('mocap')
     for _ in range(400):
         sim.step()
     assert body.position[2] < p0[2] - 0.03                                # free again: it falls
+    # a prismatic joint along joint_axis = y (given in the joint frame): under gravity tilted towards +y the body
+    # rides the rail -- y grows, x and z stay
+    sim.physics.set_gravity([0.0, 1.5, -9.8])
+    rail = sim.add_body('box', pose=[[0.45, -0.2, 0.25], [0, 0, 0]], name='rail_rider')
+    sim.add_constraint(rail, None, joint_type='prismatic', joint_axis=[0, 1, 0], max_force=100.0, name='rail')
+    q0 = np.asarray(rail.position).copy()
+    for _ in range(300):
+        sim.step()
+    q1 = np.asarray(rail.position)
+    assert 0.05 < q1[1] - q0[1] < 0.075 and abs(q1[0] - q0[0]) < 1e-3 and abs(q1[2] - q0[2]) < 1e-3, (q0, q1)
 
 
 @pytest.mark.gpu
@@ -198,13 +221,44 @@ def test_constraint_entry_point_rejects_what_is_not_built():
     L = lib.load()
     t7 = (C.c_float * 7)(0.6, 0.0, 0.1, 0, 0, 0, 1)
     call = lambda body, child, jt, tgt, f: L.rv_set_constraint_ex(w.h, body, child, jt, None, tgt, f)
-    assert call(0, -1, 1, t7, 10.0) == abi.RV_ERR_NOTIMPL            # pybullet.JOINT_PRISMATIC
+    assert call(0, -1, 0, t7, 10.0) == abi.RV_ERR_NOTIMPL            # pybullet.JOINT_REVOLUTE (not a createConstraint type either)
     assert call(0, -1, 6, t7, 10.0) == abi.RV_ERR_NOTIMPL            # pybullet.JOINT_GEAR
     assert call(abi.RV_MAXB, -1, 4, t7, 10.0) == abi.RV_ERR_VALUE     # not a movable body slot
     assert call(0, 0, 4, t7, 10.0) == abi.RV_ERR_VALUE                # a body cannot be its own child
     assert call(0, -1, 4, None, 10.0) == abi.RV_ERR_VALUE             # no target
     assert call(0, 1, 5, t7, 10.0) == abi.RV_OK                       # point2point between two bodies
     assert call(0, -1, 4, None, -1.0) == abi.RV_OK                    # removal needs no target
+    assert call(0, -1, 1, t7, 10.0) == abi.RV_OK                      # pybullet.JOINT_PRISMATIC
     with pytest.raises(NotImplementedError):
-        w.set_constraint(0, [0.6, 0, 0.1, 0, 0, 0, 1], joint_type='prismatic')
+        w.set_constraint(0, [0.6, 0, 0.1, 0, 0, 0, 1], joint_type='gear')
     w.close()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_prismatic_joint_slides_along_its_axis_only(backend):
+    """pybullet JOINT_PRISMATIC to the world: the box can only slide along the x axis of the joint frame (here the
+    world's x turned by 30 degrees about z).  Under a gravity vector with a horizontal component it accelerates along
+    that axis with the component of gravity along it (semi-implicit Euler with Bullet's damping), stays on the line
+    and keeps its orientation."""
+    gx, gy = 2.0, 1.0
+    w, cfg = T._world(backend, **{'PHYSICS.GRAVITY_XY': (gx, gy)})
+    T._bodies(w, [(0, 0.2, 0.5, (0.5, -0.1, 0.2), Q0, (0, 0, 0))])
+    a = np.radians(30.0)
+    qz = [0, 0, np.sin(a / 2), np.cos(a / 2)]
+    ax = np.array([np.cos(a), np.sin(a), 0.0])
+    # the joint frame of the body is turned like the world frame's, so that the body keeps the identity orientation
+    w.set_constraint(0, [0.5, -0.1, 0.2] + qz, frame7=[0, 0, 0] + qz, max_force=100.0, joint_type='prismatic')
+    Tn = 300
+    w.step_sub(Tn)
+    st = np.asarray(w.body_state())[0, 0]
+    acc, v, x, damp = gx * ax[0] + gy * ax[1], 0.0, 0.0, float(cfg.lin_damp)
+    for _ in range(Tn):
+        v = (v + acc * float(cfg.dt)) * damp; x += v * float(cfg.dt)
+    d = st[:3] - [0.5, -0.1, 0.2]
+    along, off = float(d @ ax), d - (d @ ax) * ax
+    assert abs(along - x) < 0.02 * x + 1e-4, (along, x)
+    assert np.abs(off).max() < 1e-3, off                                           # neither across the axis nor down
+    assert np.abs(st[3:6]).max() < 2e-3 and np.abs(st[10:13]).max() < 2e-2          # no rotation
+    assert abs(float(st[7:10] @ ax) - v) < 0.02 * v + 1e-4
+    if hasattr(w, 'w'):
+        w.close()

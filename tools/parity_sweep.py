@@ -22,7 +22,7 @@ CASES = [('config 2', {}), ('crossing / concave', dict(TASK_NAME='crossing', LAY
                                                       'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07}),
          ('arm effort limit + tilted gravity', {'PHYSICS.ARM_EFFORT_LIMIT': 1, 'PHYSICS.GRAVITY_XY': (0.3, -0.2)}),
          ('dynamic limb, crowded', {'PHYSICS.LIMB_DYNAMICS': 1, 'MOVABLE.CONVEX.POSE.X': [0.5, 0.7], 'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07}),
-         ('user constraints (p2p to the world, body - body fixed)', {'CONSTRAINTS': 1})]
+         ('user constraints (p2p and prismatic to the world, body - body fixed)', {'CONSTRAINTS': 1})]
 bad = 0
 for name, over in CASES:
     scene, names = scenes.make_scene()
@@ -35,6 +35,7 @@ for name, over in CASES:
             for x in (w, o):
                 x.set_constraint(1, [0.6, 0.05 * (seed % 3), 0.12, 0, 0, 0, 1], frame7=[0.02, 0.01, 0.0, 0, 0, 0, 1], max_force=30.0, joint_type='point2point')
                 x.set_constraint(2, [0.0, 0.0, 0.07, 0, 0, 0, 1], max_force=40.0, child=0)
+                x.set_constraint(3, [0.55, -0.1, 0.1, 0, 0, np.sin(0.3), np.cos(0.3)], frame7=[0, 0, 0, 0, 0, np.sin(0.3), np.cos(0.3)], max_force=40.0, joint_type='prismatic')
         w.rollout(steps if not cons else 2, first_macro_index=0, auto_reset=not cons, record=False); w.synchronize()
         o.rollout(steps if not cons else 2, 0, not cons)
         eq_b = np.array_equal(w.body_state().cpu().numpy(), o.body_state().astype(np.float32))
