@@ -3104,6 +3104,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
         k10 += m; if (k10 >= RV_STEPS_TO_UPDATE_IK) k10 -= RV_STEPS_TO_UPDATE_IK * (k10 / RV_STEPS_TO_UPDATE_IK);
       }
     }
+    RV_PROF(44)
     if (any_tgt && (!quiet_ok || k100 == 0 || (C.lt_on && k10 == 0)) && st != skip) {
       int reached = 1;
       if (C.jt_on) {
@@ -3122,6 +3123,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
         break;
       }
     }
+    RV_PROF(45)
     float vd = 0.0f;
     if (on) vd = kp * (mq - q) * (1.0f / dt);
     const float raw = fabsr(vd);
@@ -3180,6 +3182,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
       const float nmin = rdlane(nf, 16);
       free_left = nmin >= 1.0f ? (int)nmin : 0;
     }
+    RV_PROF(46)
     q = qn; qd = qdn; trav = travn; ++st;
     if (++k10 == RV_STEPS_TO_UPDATE_IK) k10 = 0;
     if (++k100 == RV_STEPS_TO_CHECK_DONE) k100 = 0;
@@ -3194,6 +3197,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
       if (!(C.grasp ? ctl_gtick_noop(C, st, reached, st - uni(st0)) : ctl_tick_noop(C, st, reached))) { pending = 2; break; }
     }
     if (left == 0) { pending = 3; break; }      // (after the tick test: a tick that is due is never skipped)
+    RV_PROF(47)
   }
   const int n = st - uni(st0);
   if (n > 0) {

@@ -51,7 +51,7 @@ SLOTS = {
     4: 'heavy: solver row setup + flags', 25: 'solver: island entry + row loads', 26: 'solver: Delassus rows + warm start',
     27: 'solver: sweeps', 24: 'solver: island glue + epilogues', 5: 'solver: island of 3-4 bodies (velocity space)',
     6: 'heavy: integrate, sleep tests, return', 7: 'substep loop top', 21: 'coast: entry (clearances, loads)',
-    22: 'coast: fused substep loop', 19: 'coast: finish', 11: 'coast: after a fused run', 10: 'coast: kinematics re-measured',
+    22: 'coast: fused substep loop (entry / exit of the loop)', 44: 'coast loop: check-free substeps', 45: 'coast loop: is a controller update due / a no-op', 46: 'coast loop: motor step + out-of-reach test + look-ahead', 47: 'coast loop: counters + tick test', 19: 'coast: finish', 11: 'coast: after a fused run', 10: 'coast: kinematics re-measured',
     8: 'tick: kinematics refresh', 9: 'tick: phase machine', 29: 'env.step prologue', 30: 'env.step: after the run call',
     31: 'env.step epilogue (effectiveness, obs, reward)', 28: 'reset (drop and settle)', 20: 'random_action', 23: 'rollout_record',
 }
@@ -99,7 +99,7 @@ w.rollout(args.steps, first_macro_index=first, auto_reset=True, record=False); w
 ms = w.last_kernel_ms()
 p = prof() - p0
 st = w.stats()
-main = [k for k in range(32) if not (12 <= k < 18)] + [40, 41, 42, 43]
+main = [k for k in range(32) if not (12 <= k < 18)] + [40, 41, 42, 43, 44, 45, 46, 47]
 tot = p[:, main].sum(axis=1)
 slow = int(np.argmax(tot))
 clk = tot.max() / (ms * 1e-3)
