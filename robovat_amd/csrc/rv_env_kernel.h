@@ -61,6 +61,13 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
     dst = reinterpret_cast<uint32_t*>(&S.arm);
     for (int i = lane; i < (int)(sizeof(rv_arm) / 4); i += 64) dst[i] = src[i];
   }
+#ifdef RV_POISON_LDS      // debugging aid (tools/gpu.sh poison): the scratch part of the block starts as garbage that differs from launch
+  {                       // to launch, so that a read of a field no phase of THIS launch wrote shows up as a parity failure
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&S.s);
+    const uint32_t pat = (uint32_t)RV_POISON_LDS;
+    for (int i = lane; i < (int)(sizeof(Scratch) / 4); i += 64) dst[i] = pat + (uint32_t)i * 2654435761u * (pat & 1u);
+  }
+#endif
   Consts K = lds_consts(args.scene, (MODE == MODE_SUB) ? args.stop_after : 0);
   constexpr int W = (int)(sizeof(DevEnv) / 4);
   bool skip = false;

@@ -16,6 +16,7 @@
 #   parts_c3 / parts_c4 / parts_c5   per-part tables of configs 3 / 4 / 5
 #   variants       headline + configs 5 / 3 / 4 for the product library and every build/librovat_*.so
 #   sweep          tools/parity_sweep.py for both builds of the env kernel
+#   poison         pytest -m gpu with every build/librovat_poison_*.so (LDS scratch starts as garbage)
 #   lanes          SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU lane-utilisation pass (headline and no-deactivation)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
@@ -62,6 +63,12 @@ for STAGE in "$@"; do
       (echo "# tools/parity_sweep.py 8 256 6, register-rich build (RV_ENV_OCC=1)"; RV_ENV_OCC=1 timeout 1500 python tools/parity_sweep.py 8 256 6;
        echo "# tools/parity_sweep.py 4 256 6, two-waves-per-SIMD build (RV_ENV_OCC=2)"; RV_ENV_OCC=2 timeout 1500 python tools/parity_sweep.py 4 256 6) > $O/parity_sweep.txt 2>&1
       grep -c "True joints True" $O/parity_sweep.txt; grep MISMATCH $O/parity_sweep.txt ;;
+    poison)
+      # GPU parity tests with the LDS scratch poisoned at kernel start (tools/build_poison.py built the libraries)
+      for SO in $(ls build/librovat_poison_*.so 2>/dev/null); do
+        echo "== $SO" | tee -a $O/poison.txt
+        RV_LIB=$R/$SO timeout 900 python -m pytest tests -m gpu -q --deselect tests/test_gpu_api.py -k "not smoke" 2>&1 | grep "passed\|failed" | tail -3 | tee -a $O/poison.txt
+      done ;;
     variants)
       # every library variant under build/ (and the product library): headline, config 5 / 3 / 4 single-launch rollouts
       for SO in robovat_amd/librovat_hip.so $(ls build/librovat_*.so 2>/dev/null); do
