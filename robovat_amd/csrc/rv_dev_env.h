@@ -3152,6 +3152,9 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
     if (qn < lo) { qn = lo; qdn = 0.0f; }
     if (qn > hi) { qn = hi; qdn = 0.0f; }
     const float travn = trav + fabsr(qdn) * dt;
+    // (|speed| of the joint after this substep, for the look-ahead below: computed HERE, by every lane -- the box lanes
+    // read the joint lanes' values with v_readlane inside a branch only the box lanes take)
+    const float sp = fabsr(qdn);
     // the boxes after this substep: still out of reach of everything?
     RV_PCNT(33, 1)
     if (free_left > 0) --free_left;
@@ -3169,7 +3172,6 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
         nf = room / Bc - 1.0f;
         if (B2 > 0.0f && room > 0.0f) {
           float B1 = 0.0f;
-          const float sp = fabsr(qdn);
 #pragma unroll
           for (int k = 0; k < RV_NJ; ++k) B1 = __builtin_fmaf(cf[k], rdlane(sp, k), B1);
           const float hb = B1 * dt + 0.5f * B2;          // n hb + n^2 B2 / 2 <= room
