@@ -46,7 +46,7 @@ def _lib(double):
                      'orc_get_episode_returns', 'orc_get_stats', 'orc_eval_reward',
                      'orc_eval_waypoints', 'orc_set_external_control', 'orc_motor_targets',
                      'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout', 'orc_set_pose_f32',
-                     'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction', 'orc_set_constraint', 'orc_render_rgb', 'orc_set_constraint_ex'):
+                     'orc_debug_solver_counts', 'orc_set_num_threads', 'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction', 'orc_set_constraint', 'orc_render_rgb', 'orc_set_constraint_ex'):
             getattr(lib, name).restype = None
         lib.orc_is_limb_ready.restype = C.c_int
         lib.orc_is_gripper_ready.restype = C.c_int
@@ -272,6 +272,15 @@ class OracleWorld(object):
 
     def episode_returns(self):
         return self._get('orc_get_episode_returns', (self.n,))
+
+    def solver_counts(self):
+        """(island solves, sweeps, row steps) of the impulse-space / big-island solvers since the world was created."""
+        out = (C.c_long * 3)()
+        self.lib.orc_debug_solver_counts(self.h, out)
+        return {'island_solves': int(out[0]), 'sweeps': int(out[1]), 'row_steps': int(out[2])}
+
+    def set_num_threads(self, n):
+        self.lib.orc_set_num_threads(C.c_int(int(n)))
 
     def stats(self):
         s = abi.rv_macro_stats()

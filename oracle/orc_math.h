@@ -25,12 +25,14 @@ typedef double real;
 #define rsqrt_(x) sqrt(x)
 #define rabs(x) fabs(x)
 #define rrint(x) rint(x)
+#define rfma(a, b, c) __builtin_fma(a, b, c)     /* ONE rounding (the impulse-space solver's row update) */
 #else
 typedef float real;
 #define R(x) x##f
 #define rsqrt_(x) sqrtf(x)
 #define rabs(x) fabsf(x)
 #define rrint(x) rintf(x)
+#define rfma(a, b, c) __builtin_fmaf(a, b, c)    /* = v_fma_f32 on the device */
 #endif
 
 #define ORC_PI R(3.14159265358979323846)

@@ -32,6 +32,9 @@
  */
 #include <stdlib.h>
 #include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "../include/rovat.h"
 #include "orc_math.h"
 #include "orc_collide.h"
@@ -123,6 +126,7 @@ typedef struct {
   int has_prev;
   /* stats */
   long num_total_steps, num_unsafe, num_ineffective, num_useful, num_successes;
+  long cnt_islands, cnt_sweeps, cnt_rowsteps;   /* diagnostic (orc_debug_solver_counts): island solves, their sweeps, row steps */
 } orc_env;
 
 typedef struct orc_world {
@@ -637,6 +641,9 @@ static int collide_pair(const orc_world* w, orc_env* e, int kind, int a, int b, 
   real mg = (real)w->cfg.margin;
   real n[3], dist, pa[3], pb[3];
   e->pairs_last++;
+#ifdef ORC_DEBUG_PAIRS
+  fprintf(stderr, "P %d %d %d %d %d\n", e->sim_steps, kind, a, b, col);
+#endif
   if (!orc_gjk_epa_c(A, nA, B, nB, guess, brk + R(2.0) * mg, n, &dist, pa, pb,
                      m ? &m->gc : (orc_gjk_cache*)0, pair)) return 0;
   real d = dist - R(2.0) * mg;
@@ -830,6 +837,9 @@ static void collide_all(const orc_world* w, orc_env* e) {
         if (!body_on(e, b) || !run[AIDX(b)]) continue;
         real d[3]; v3sub(d, e->body[b].p, e->colc[col]);
         real r = e->bp[b].radius + brk_ab(w, e, b, col);
+#ifdef ORC_DEBUG_PAIRS
+        if (e->sim_steps >= 9640 && e->sim_steps <= 9654 && b == 2 && col == 8) fprintf(stderr, "ORC step %d colmin %.6f %.6f %.6f colmax %.6f %.6f %.6f body %.6f %.6f %.6f r %.6g d2 %.6g run %d\n", e->sim_steps, (double)e->colmin[col][0], (double)e->colmin[col][1], (double)e->colmin[col][2], (double)e->colmax[col][0], (double)e->colmax[col][1], (double)e->colmax[col][2], (double)e->body[b].p[0], (double)e->body[b].p[1], (double)e->body[b].p[2], (double)r, (double)sphere_aabb_dist2(e->body[b].p, e->colmin[col], e->colmax[col]), run[AIDX(b)]);
+#endif
         if (sphere_aabb_dist2(e->body[b].p, e->colmin[col], e->colmax[col]) >= r * r) continue;
         const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
         for (int h = 0; h < s->n_hulls; ++h) {
@@ -1415,6 +1425,19 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
       A[r][s2] = A[r][s2] + t;
     }
   for (int s2 = 0; s2 < n_rows; ++s2) for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s2] * lam[s2];
+  /* NORMALISED RESIDUAL FORM of the row step (round 5).  rr[r] = (bias[r] - g[r]) invk[r] is the change row r's impulse
+   * would take if it were unbounded; a row step is  nl = clamp(lam[s] + rr[s]); d = nl - lam[s]; rr[r] += C[r][s] d  with
+   * C[r][s] = -(A[r][s] invk[r]).  In exact arithmetic these are the iterates of  nl = clamp(lam + (bias - g) invk),
+   * g += A d;  on the device a row step is v_add, v_med3, v_sub, the broadcast and ONE v_fma instead of thirteen
+   * instructions with three selects (tools/ubench/sweep_step.hip: 92 -> 45 clocks per row step).  The update is a fused
+   * multiply-add (fmaf / v_fma_f32: a single rounding, the same on host and device).  (Tracking T = lam + rr instead
+   * would save the add, but T rounds at the scale of lam where rr rounds at the scale of the residual: run to
+   * convergence in FP32 it left 5e-6 m/s where this form leaves 3e-8 -- tests/test_independent_pin.py.) */
+  real rr[SOLVE_ROWS + 9];
+  for (int r = 0; r < n_all; ++r) {
+    rr[r] = (bias[r] - g[r]) * invk[r];
+    for (int s2 = 0; s2 < n_all; ++s2) A[r][s2] = -(A[r][s2] * invk[r]);
+  }
   int isl_rows = 0, done = 0;
   real best[RV_MAXB] = {R(1e30), R(1e30), R(1e30), R(1e30)}; int since[RV_MAXB] = {0, 0, 0, 0};
   for (int s2 = 0; s2 < n_rows; ++s2) isl_rows |= 1 << id[s2].isl;
@@ -1423,37 +1446,38 @@ static void solve_rows(const orc_world* w, orc_env* e, orc_row rows[][4], const 
   for (int x = 0; x < RV_MAXB; ++x) tolx[x] = ((fing || L) && x == fisl) ? (real)c->solver_tol : island_tol(c, e, use, label, x);
   for (int it = 0; it < c->solver_iters; ++it) {
     real res[RV_MAXB] = {R(0.0), R(0.0), R(0.0), R(0.0)};
+    for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && !((done >> x) & 1)) { e->cnt_sweeps++; if (it == 0) e->cnt_islands++; }
     real limtab[RV_NMAN][4];   /* friction bound of every point: mu x its normal impulse (the rows of a point need not be neighbours in the list) */
     for (int s2 = 0; s2 < n_rows; ++s2) {
       const int isl = id[s2].isl;
       if ((done >> isl) & 1) continue;
       real nl;
       const real lim = id[s2].k == 0 ? R(0.0) : limtab[id[s2].mi][id[s2].i];
-      if (id[s2].k == 0) nl = rclamp(lam[s2] + (bias[s2] - g[s2]) * invk[s2], R(0.0), cap[s2]);
-      else nl = rclamp(lam[s2] + (-g[s2] * invk[s2]), -lim, lim);
+      if (id[s2].k == 0) nl = rclamp(lam[s2] + rr[s2], R(0.0), cap[s2]);
+      else nl = rclamp(lam[s2] + rr[s2], -lim, lim);
       const real d = nl - lam[s2];
-      lam[s2] = nl;
+      lam[s2] = nl; e->cnt_rowsteps++;
       if (id[s2].k == 0) limtab[id[s2].mi][id[s2].i] = mu[s2] * nl;
       res[isl] = rmax(res[isl], rabs(d));
-      for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s2] * d;
+      for (int r = 0; r < n_all; ++r) rr[r] = rfma(A[r][s2], d, rr[r]);
     }
     /* (the motor rows belong to island fisl and stop with it -- other islands may still be sweeping) */
     const int motors_on = !((done >> fisl) & 1);
     for (int m = 0; fing && motors_on && m < 2; ++m) {
       const int q = n_rows + m;
-      const real nl = rclamp(lam[q] + (-g[q] * invk[q]), mlo[m], mhi[m]);
+      const real nl = rclamp(lam[q] + rr[q], mlo[m], mhi[m]);
       const real d = nl - lam[q];
       lam[q] = nl;
       res[fisl] = rmax(res[fisl], rabs(d));
-      for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][q] * d;
+      for (int r = 0; r < n_all; ++r) rr[r] = rfma(A[r][q], d, rr[r]);
     }
     for (int j = 0; motors_on && j < nlm; ++j) {
       const int q = n_rows + nfm + j;
-      const real nl = rclamp(lam[q] + (-g[q] * invk[q]), L->lo[j], L->hi[j]);
+      const real nl = rclamp(lam[q] + rr[q], L->lo[j], L->hi[j]);
       const real d = nl - lam[q];
       lam[q] = nl;
       res[fisl] = rmax(res[fisl], rabs(d));
-      for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][q] * d;
+      for (int r = 0; r < n_all; ++r) rr[r] = rfma(A[r][q], d, rr[r]);
     }
     for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < tolx[x]) done |= 1 << x;
     /* stalled islands (rv_config.solver_stall): no new smallest residual for that many sweeps */
@@ -1645,6 +1669,7 @@ static void solve_contacts(const orc_world* w, orc_env* e) {
     for (int it = 0; it < c->solver_iters; ++it) {
       real res = R(0.0);
       int rows_seen = 0;
+      e->cnt_sweeps++; if (it == 0) e->cnt_islands++;
       for (int b = root; b < RV_MAXB; ++b) {
         if (!use[TIDX(b)] || label[b] != root) continue;
         orc_manifold* m = &e->man[TIDX(b)];
@@ -3095,4 +3120,17 @@ int orc_eval_gjk(const double* A, int nA, const double* B, int nB, double max_di
 }
 
 /* debugging aid: GJK calls / iterations since the library was loaded (-DORC_COUNT_GJK builds) */
+/* diagnostics (bench.py, tools): island solves / sweeps / row steps of the impulse-space solver since the world was made;
+ * OpenMP threads of the stepping entry points */
+void orc_debug_solver_counts(orc_world* w, long* out) {
+  out[0] = out[1] = out[2] = 0;
+  for (int i = 0; i < w->n; ++i) { out[0] += w->env[i].cnt_islands; out[1] += w->env[i].cnt_sweeps; out[2] += w->env[i].cnt_rowsteps; }
+}
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 void orc_debug_gjk_counts(long* out) { out[0] = orc_gjk_calls; out[1] = orc_gjk_iters; }

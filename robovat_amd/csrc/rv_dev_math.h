@@ -34,6 +34,9 @@ RV_DEV float fminr(float a, float b) { return a < b ? a : b; }
 RV_DEV float fmaxr(float a, float b) { return a > b ? a : b; }
 RV_DEV float fclampr(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 RV_DEV float fabsr(float x) { return x < 0.0f ? -x : x; }
+// the ONE explicit fused multiply-add of the build (the row update of the impulse-space solvers): a single rounding,
+// v_fma_f32 on the device, fmaf on the host emulator and in the oracle (rfma); everything else is -ffp-contract=off
+RV_DEV float rv_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // sqrtf() lowers to the correctly rounded v_sqrt_f32 + fma fix-up sequence on
 // gfx950 (ROCm 7.2); __fsqrt_rn() lowers to the bare ~1 ulp v_sqrt_f32 and
 // breaks bit-parity with the CPU oracle.

@@ -375,10 +375,11 @@ class HipPhysics(Physics):
             if child >= 0:
                 child_frame_pose = self.get_body_pose(child).inverse().transform(child_frame_pose)
         pose = Pose(child_frame_pose)
-        self._constraints[b] = {'frame': frame, 'pose': pose, 'max_force': 500.0, 'child': child, 'joint_type': joint_type}     # pybullet's default maxForce
+        entry = {'frame': frame, 'pose': pose, 'max_force': 500.0, 'child': child, 'joint_type': joint_type}     # pybullet's default maxForce
         if joint_type == 'prismatic':
             # the library slides along the x axis of the joint frame: a joint_axis (given in the child's joint frame,
-            # pybullet's jointAxis) other than x is the same rotation applied to both joint frames
+            # pybullet's jointAxis) other than x is the same rotation applied to both joint frames.  Validated BEFORE the
+            # mirror entry exists: a rejected call must leave the body free to be constrained again
             a = np.asarray(joint_axis, np.float64)
             if not np.linalg.norm(a) > 0.0:
                 raise ValueError('a prismatic joint needs a joint_axis')
@@ -389,8 +390,13 @@ class HipPhysics(Physics):
             else:
                 th = np.arctan2(np.linalg.norm(n), a[0])
                 qr = np.concatenate([np.sin(0.5 * th) * n / np.linalg.norm(n), [np.cos(0.5 * th)]])
-            self._constraints[b]['axis_quat'] = qr
-        self._push_constraint(b)
+            entry['axis_quat'] = qr
+        self._constraints[b] = entry
+        try:
+            self._push_constraint(b)
+        except Exception:
+            del self._constraints[b]          # nothing reached the device: no mirror entry either
+            raise
         return b
 
     def _push_constraint(self, b):

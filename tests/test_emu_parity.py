@@ -21,7 +21,7 @@ def emu():
     csrc = os.path.join(EMU_DIR, '..', '..', 'robovat_amd', 'csrc')
     deps = [src] + [os.path.join(csrc, n) for n in ('rv_dev_env.h', 'rv_dev_collide.h', 'rv_dev_math.h')]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fopenmp', '-shared', src, '-o', so], check=True)
+        subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-ffp-contract=off', '-mfma', '-fopenmp', '-shared', src, '-o', so], check=True)
     lib = C.CDLL(so)
     lib.emu_create.restype = C.c_void_p
     lib.emu_create.argtypes = [C.POINTER(abi.rv_config), C.POINTER(abi.rv_scene)]

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 from robovat_amd import abi, configs, scenes  # noqa: E402
 
 so = '/tmp/librv_emu_cnt.so'
-subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-ffp-contract=off', '-shared', '-DRV_EMU_COUNT', '-I' + os.path.join(ROOT, 'include'),
+subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-ffp-contract=off', '-mfma', '-shared', '-DRV_EMU_COUNT', '-I' + os.path.join(ROOT, 'include'),
                 os.path.join(ROOT, 'tests', 'emu', 'rv_emu.cpp'), '-o', so], check=True)
 lib = C.CDLL(so)
 lib.emu_create.restype = C.c_void_p
