@@ -39,61 +39,117 @@ VALU_PEAK_PER_SIMD_CYCLE = 0.5      # MI355X_MICROARCH.md: a wave64 VALU instruc
 
 def cpu_legs(cfg_kwargs, scene, names, quick=False):
     """Everything that runs the CPU oracle (kind 'port': pybullet, the reference's physics,
-    is not importable here): the same-workload baseline, BASELINE config 1 (1 env,
-    HeuristicPushPolicy, 20 episodes; one thread and one worker per core as
-    tools/parallel_run.py would start them) and the FP32-vs-FP64 pose error."""
+    is not importable here): the same-workload baseline, the reference-semantics legs, BASELINE
+    config 1 (1 env, HeuristicPushPolicy, 20 episodes; one thread and one worker per core as
+    tools/parallel_run.py would start them), the pose-level deactivation comparison and the
+    FP32-vs-FP64 pose error.
+
+    Sampling (round-4 review): every multi-thread leg runs >= 16 envs per host thread (OpenMP over envs,
+    schedule(dynamic): a thread takes the next env when it is done with one) for >= 10 s or 4 env.step()
+    per env, the steps after the first in ONE call (no barrier between the steps of an env), so that the
+    tail of the slowest env is a few per cent of the window; the same leg on ONE thread gives the
+    per-thread cost and the measured 1 -> N scaling."""
     import numpy as np
     from robovat_amd import configs, lib, scenes
     from oracle import orc
     cores = os.cpu_count() or 1
     out = {}
-    # (i) same workload as the GPU leg, OpenMP over envs
-    n = max(4, 2 * cores)
-    cfg = configs.make_rv_config(n_envs=n, shape_names=names, **cfg_kwargs)
-    w = orc.OracleWorld(cfg, scene, double=False)
-    w.reset()
-    t_all, steps, sub, awake, k = 0.0, 0, 0, 0, 0
-    while t_all < 5.0 and k < 4:
-        w.set_actions(w.policy_random(k))
-        t0 = time.perf_counter(); w.step_macro(); t_all += time.perf_counter() - t0
-        st = w.stats(); steps += st['env_steps']; sub += st['substeps']; awake += st['awake_substeps']; k += 1
-    out['cpu_baseline'] = {
-        'value': steps / t_all, 'unit': 'env_steps/s', 'cores': cores, 'kind': 'port',
-        'sim_steps_per_s': sub / t_all,
-        'sample': '%d envs x %d macro steps of the same workload, float C oracle, OpenMP over envs '
-                  '(pybullet not importable -> reference loop skipped)' % (n, k),
-    }
-    out['cpu_baseline']['awake_sim_steps_per_s'] = awake / t_all     # (the oracle never coasts: the other substeps still run its light part)
-    # (i') the reference's most likely semantics on the host cores (same legs as reference_semantics.gpu): every
-    # substep is an awake one, so sim_steps_per_s compares like for like with the MI355X legs
-    def semantics_cpu(over):
+    per_thread = 4 if quick else 16
+    n = max(16, per_thread * cores)
+    min_seconds, max_steps = (3.0, 2) if quick else (10.0, 4)
+
+    def timed(over, n_envs, threads):
+        """`over` on n_envs envs with `threads` OpenMP threads: reset (untimed), then env.step() calls per env
+        until min_seconds or max_steps: one step first (its duration sizes the rest), the others in one call."""
         env_cfg = configs.push_env_config(**over)
         sc, nm = (scenes.make_scene(env_cfg=env_cfg) if 'PHYSICS.ARM_ACCEL_SCALE' in over else (scene, names))
-        c = configs.make_rv_config(env_cfg=env_cfg, n_envs=n, shape_names=nm, **cfg_kwargs)
+        c = configs.make_rv_config(env_cfg=env_cfg, n_envs=n_envs, shape_names=nm, **cfg_kwargs)
         wc = orc.OracleWorld(c, sc, double=False)
+        wc.set_num_threads(threads)
         wc.reset()
         p0, _ = wc.observe()
-        wc.set_actions(wc.policy_random(0))
-        t0 = time.perf_counter(); wc.step_macro(); el = time.perf_counter() - t0
-        stc = wc.stats(); p1, _ = wc.observe()
+        c0 = wc.solver_counts()
+        tot = {'env_steps': 0, 'substeps': 0, 'awake_substeps': 0, 'useful': 0, 'unsafe': 0, 'ineffective': 0}
+        el, done_steps = 0.0, 0
+        while done_steps < max_steps and el < min_seconds:
+            k = 1 if done_steps == 0 else max(1, min(max_steps - done_steps, int((min_seconds - el) / max(el / done_steps, 1e-9) + 0.999)))
+            t0 = time.perf_counter(); wc.rollout(k, first_macro_index=done_steps, auto_reset=False); el += time.perf_counter() - t0
+            st = wc.stats()
+            for key in tot:
+                tot[key] += st[key]
+            done_steps += k
+        p1, _ = wc.observe()
+        c1 = wc.solver_counts()
+        wc.set_num_threads(cores)
+        es = max(tot['env_steps'], 1)
         moved = np.linalg.norm(p1[..., :2] - p0[..., :2], axis=-1).sum(-1)
-        es = max(stc['env_steps'], 1)
-        return {'value': stc['env_steps'] / el, 'unit': 'env_steps/s', 'sim_steps_per_s': stc['substeps'] / el, 'cores': cores,
-                'envs': n, 'steps': 1, 'useful': stc['useful'] / es, 'unsafe': stc['unsafe'] / es, 'ineffective': stc['ineffective'] / es,
-                'disp_mean_mm': 1e3 * float(moved.mean()), 'substeps_per_env_step': stc['substeps'] / es}
+        isl = max(c1['island_solves'] - c0['island_solves'], 1)
+        return {'value': tot['env_steps'] / el, 'unit': 'env_steps/s', 'sim_steps_per_s': tot['substeps'] / el,
+                'awake_sim_steps_per_s': tot['awake_substeps'] / el, 'cores': threads, 'envs': n_envs, 'steps': done_steps,
+                'seconds': el, 'thread_us_per_substep': 1e6 * threads * el / max(tot['substeps'], 1),
+                'thread_us_per_awake_substep': 1e6 * threads * el / max(tot['awake_substeps'], 1),
+                'useful': tot['useful'] / es, 'unsafe': tot['unsafe'] / es, 'ineffective': tot['ineffective'] / es,
+                'disp_total_mean_mm': 1e3 * float(moved.mean()), 'substeps_per_env_step': tot['substeps'] / es,
+                'mean_sweeps_per_island_solve': (c1['sweeps'] - c0['sweeps']) / isl,
+                'mean_rows_per_island': (c1['row_steps'] - c0['row_steps']) / max(c1['sweeps'] - c0['sweeps'], 1)}
+
+    def leg(over):
+        """all host threads, and the same leg on ONE thread (16 envs) for the per-thread cost and the scaling"""
+        full = timed(over, n, cores)
+        one = timed(over, 16 if not quick else 4, 1)
+        full['one_thread'] = {k: one[k] for k in ('sim_steps_per_s', 'value', 'thread_us_per_substep', 'thread_us_per_awake_substep', 'envs', 'steps', 'seconds')}
+        full['scaling_1_to_n'] = full['sim_steps_per_s'] / max(one['sim_steps_per_s'], 1e-9)
+        return full
+
+    # (i) same workload and semantics as the GPU headline
+    cb = leg({})
+    out['cpu_baseline'] = {
+        'value': cb['value'], 'unit': 'env_steps/s', 'cores': cores, 'kind': 'port',
+        'sim_steps_per_s': cb['sim_steps_per_s'], 'awake_sim_steps_per_s': cb['awake_sim_steps_per_s'],
+        'sample': '%d envs (%d per thread) x %d env.step() of the same workload in %.1f s, float C oracle, OpenMP over envs with '
+                  'schedule(dynamic) (pybullet not importable -> reference loop skipped)' % (n, per_thread, cb['steps'], cb['seconds']),
+        'thread_us_per_substep': cb['thread_us_per_substep'], 'thread_us_per_awake_substep': cb['thread_us_per_awake_substep'],
+        'one_thread': cb['one_thread'], 'scaling_1_to_n': cb['scaling_1_to_n'],
+        'mean_sweeps_per_island_solve': cb['mean_sweeps_per_island_solve'],
+        'note': 'the oracle never coasts: its non-awake substeps still run the arm (light part); thread_us_per_awake_substep charges '
+                'them to the awake ones'}
+    # (i') the reference's most likely semantics on the host cores (same legs as reference_semantics.gpu): every
+    # substep is an awake one, so sim_steps_per_s compares like for like with the MI355X legs
     nd = {'PHYSICS.SLEEP_STEPS': 0}
     bs = {'PHYSICS.SOLVER_TOL': 0.0, 'PHYSICS.SOLVER_STALL': 0}
-    out['reference_semantics_cpu'] = {'early_exit_effort_limited_motor': semantics_cpu(nd)}
-    # ... and what ONE host thread needs per awake env-substep (1 env = 1 OpenMP thread), the unit the MI355X's
-    # one-wave-per-env figure (envs / sim_steps_per_s) compares with
-    c1 = configs.make_rv_config(env_cfg=configs.push_env_config(**nd), n_envs=1, shape_names=names, **cfg_kwargs)
-    w1 = orc.OracleWorld(c1, scene, double=False)
-    w1.reset(); w1.set_actions(w1.policy_random(0))
-    t0 = time.perf_counter(); w1.step_macro(); e1 = time.perf_counter() - t0
-    out['reference_semantics_cpu']['early_exit_effort_limited_motor']['one_thread_us_per_substep'] = 1e6 * e1 / max(w1.stats()['substeps'], 1)
+    out['reference_semantics_cpu'] = {'early_exit_effort_limited_motor': leg(nd)}
     if not quick:
-        out['reference_semantics_cpu']['effort_limited_motor'] = semantics_cpu(dict(nd, **bs))
-        out['reference_semantics_cpu']['unlimited_motor'] = semantics_cpu(dict(nd, **bs, **{'PHYSICS.ARM_ACCEL_SCALE': 1000.0}))
+        out['reference_semantics_cpu']['effort_limited_motor'] = leg(dict(nd, **bs))
+        out['reference_semantics_cpu']['unlimited_motor'] = leg(dict(nd, **bs, **{'PHYSICS.ARM_ACCEL_SCALE': 1000.0}))
+    # (i'') is the shipped deactivation an optimisation within the stated tolerance?  FP64 oracle, shipped semantics vs
+    # no deactivation + 50 plain sweeps, one env.step() per env from identical states and actions
+    # (tests/test_deactivation_equivalence.py asserts the same bounds as the FP32 tolerance test)
+    def pose_equivalence(over, n_envs, seed=21):
+        def mk(ov):
+            ec = configs.push_env_config(**ov)
+            return orc.OracleWorld(configs.make_rv_config(env_cfg=ec, n_envs=n_envs, seed=seed, shape_names=names), scene, double=True)
+        a, b = mk({}), mk(over)
+        a.reset()
+        state, params = a.body_state(), a.body_params()
+        a.set_body_state(state)
+        b.reset(); b.set_body_params(params); b.set_body_state(state)
+        act = a.policy_random(0)
+        a.set_actions(act); b.set_actions(act); a.step_macro(); b.step_macro()
+        on = params[:, :, 0] > 0
+        perr = np.linalg.norm(a.body_state()[..., :3] - b.body_state()[..., :3], axis=-1)[on]
+        ca, cb_ = a.env_counters(), b.env_counters()
+        return {'env_steps': n_envs, 'median_m': float(np.median(perr)), 'p90_m': float(np.percentile(perr, 90)),
+                'p99_m': float(np.percentile(perr, 99)), 'max_m': float(perr.max()),
+                'flags_agree': float(((ca[:, 5] == cb_[:, 5]) & (ca[:, 6] == cb_[:, 6])).mean()),
+                'bounds': 'median <= 2e-5 m, p90 <= 3e-4 m, flags >= 0.97 (those of test_fp32_tolerance_at_the_end_of_a_push)'}
+    pe_n = 256 if quick else max(256, 4 * cores)
+    out['deactivation_pose_equivalence'] = {
+        'oracle': 'FP64 restatement, shipped semantics vs the other, one env.step() per env from identical states / actions',
+        'vs_no_deactivation_50_sweeps': pose_equivalence(dict(nd, **bs), pe_n),
+        'vs_no_deactivation': pose_equivalence(nd, pe_n)}
+    for v in out['deactivation_pose_equivalence'].values():
+        if isinstance(v, dict):
+            v['within_bounds'] = bool(v['median_m'] <= 2e-5 and v['p90_m'] <= 3e-4 and v['flags_agree'] >= 0.97)
     # (ii) BASELINE config 1: run_env.py --env PushEnv --policy HeuristicPushPolicy, 20 episodes
     max_steps, episodes = 5, 20
 
@@ -116,7 +172,15 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
                           'one_thread': config1(1)}
     if not quick:
         out['config1_cpu']['one_worker_per_core'] = config1(cores)
-    # (iii) pose error of the HIP path (FP32) against the FP64 oracle from identical states
+    return out
+
+
+def pose_err_leg(scene, names):
+    """Pose error of the HIP path (FP32) against the FP64 oracle from identical states (needs the GPU)."""
+    import numpy as np
+    from robovat_amd import configs, lib
+    from oracle import orc
+    out = {}
     n = 64
     cfg = configs.make_rv_config(n_envs=n, shape_names=names, seed=9)
     f32, f64 = orc.OracleWorld(cfg, scene, double=False), orc.OracleWorld(cfg, scene, double=True)
@@ -512,6 +576,12 @@ def main():
                     'unlimited_motor': legs.get('no_deactivation_50_sweeps_unlimited_motor'),
                     'early_exit_effort_limited_motor': legs['no_deactivation']},
             'headline_semantics': {k: sh[k] for k in ('value', 'useful', 'unsafe', 'ineffective', 'disp_mean_mm', 'awake_substep_fraction')}}
+        # ... and at 8192 envs per GPU (BASELINE configs[4]'s size: the two-waves-per-SIMD build, eight envs per SIMD to
+        # balance the tail of the slowest env away) -- where a throughput run of these semantics belongs
+        if not args.quick:
+            extra['reference_semantics']['gpu_8192'] = {
+                'early_exit_effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT), 8192, 2),
+                'effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT, **BULLET_SWEEPS), 8192, 2)}
         # BASELINE configs[2]: 'crossing' layout, V-HACD concave movables, 4096 envs
         w3, _ = make_world(4096, TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)
         w3.reset()
@@ -595,6 +665,37 @@ def main():
     else:
         world.close()
 
+    world_n_waves = n          # one wave64 per env
+    def roofline(achieved, awake_only, traffic, issue, avg_kernel_s, algo, per_launch, n_waves):
+        """`bound` names the resource that was MEASURED to bind (round-4 review): the VALU issue rate of the resident waves.
+        achieved = VALU instructions the launch issues (PMC count per env-substep of the same command, profiles/traffic.json,
+        x the env-substeps of THIS launch) / (SIMD-cycles the waves were resident: waves x kernel time x shader clock); peak =
+        one wave64 VALU instruction per 2 cycles per SIMD (MI355X_MICROARCH.md).  The contract's nominal HBM figure
+        (algorithmic bytes x all env-substeps / kernel time) stays under `hbm_nominal`."""
+        hbm = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+               'algorithmic_bytes_per_env_substep': algo, 'achieved_awake_substeps_only': awake_only,
+               'note': 'nominal figure of the contract: algorithmic bytes x ALL env-substeps / kernel time.  The state is LDS-resident '
+                       'for the whole launch, so the measured HBM traffic (`traffic`) is ~1 % of it, and ~96 % of the substeps are '
+                       'coasting / quiet ones that touch no body (`achieved_awake_substeps_only` counts the rest): HBM does not bind'}
+        kern = 'k_env<MODE_ROLLOUT>' if args.mode == 'rollout' else 'k_env<MODE_MACRO>'
+        if not issue:
+            hbm.update({'traffic': traffic, 'kernel': kern, 'avg_kernel_ms': 1e3 * avg_kernel_s, 'hbm_nominal': dict(hbm)})
+            return hbm
+        clk = issue.get('shader_clock_hz', 2.4e9)
+        simds = min(n_waves, 1024)
+        valu = issue['valu_insts_per_env_substep'] * per_launch
+        a = valu / (simds * avg_kernel_s * clk)
+        return {'bound': 'valu_issue', 'achieved': a, 'peak': VALU_PEAK_PER_SIMD_CYCLE, 'unit': 'VALU instructions / SIMD cycle',
+                'frac': a / VALU_PEAK_PER_SIMD_CYCLE, 'traffic': traffic, 'kernel': kern, 'avg_kernel_ms': 1e3 * avg_kernel_s,
+                'valu_insts_per_env_substep': issue['valu_insts_per_env_substep'], 'env_substeps_per_launch': per_launch,
+                'occupied_simds': simds, 'shader_clock_hz': clk,
+                'issue_side': issue, 'hbm_nominal': hbm,
+                'note': 'the kernel is bound by the issue rate / dependent-instruction latency of its resident waves (one wave64 per env; '
+                        'one wave per SIMD at 1024 envs), not by HBM: `frac` = VALU instructions issued per SIMD cycle over the launch / '
+                        'the 0.5 per cycle a SIMD can issue (the instruction count per env-substep is the rocprofv3 SQ_INSTS_VALU of '
+                        'this same command, profiles/; the duration is measured live with HIP events).  `issue_side` has the wave-resident '
+                        'view of the same counters (idle SIMDs behind the slowest env excluded); DESIGN.md section 4'}
+
     if rank == 0:
         algo = {'config3': ALGO_BYTES['config3'], 'config4': 1912}.get(args.workload, ALGO_BYTES['config2'])
         avg_kernel_s = 1e-3 * kern_ms / launches
@@ -620,6 +721,16 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': workload,
                        'envs_per_gpu': n, 'bodies': 4, 'dt': 1e-3, 'solver_iters': int(cfg.solver_iters),
+                       'deactivation': ('on: islands at rest are put to sleep after %d substeps (BUILD-CHOSEN; the reference passes no '
+                                        'URDF_ENABLE_SLEEPING, bullet_physics.py:173-181).  Pose-level check against no deactivation + 50 '
+                                        'plain sweeps on the FP64 oracle: `deactivation.pose_equivalence` (within the FP32 tolerance bounds); '
+                                        'the reference-semantics throughput is `reference_semantics`' % int(cfg.sleep_steps))
+                                       if int(cfg.sleep_steps) > 0 else 'off',
+                       'solver_exit': ('<= %d sweeps; an island stops on residual < %.0e N s (%.0e when at rest and nothing is ever '
+                                       'deactivated) or after %d sweeps without a new smallest residual; mean sweeps per island solve: '
+                                       '`cpu_baseline.mean_sweeps_per_island_solve` (float oracle, whose iterates are the kernel\'s bit for bit)'
+                                       % (int(cfg.solver_iters), float(cfg.solver_tol), float(cfg.solver_tol_rest), int(cfg.solver_stall)))
+                                      if float(cfg.solver_tol) > 0 else 'none: %d plain sweeps' % int(cfg.solver_iters),
                        'parallelism': 'env-shards x%d' % world_size,
                        'mode': 'single-launch rollout: K env.step() per env in one rv_rollout_record launch, observation (incl. '
                                '%d-point segmented point cloud per body), reward and done of every step recorded' % int(cfg.num_points)
@@ -630,23 +741,16 @@ def main():
             'max_substeps_in_launch': st['max_substeps'],
             'awake_substep_fraction': st['awake_substeps'] / max(st['substeps'], 1),
             'reset_substeps': reset_stats['substeps'],
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'k_env<MODE_ROLLOUT>' if args.mode == 'rollout' else 'k_env<MODE_MACRO>',
-                         'avg_kernel_ms': 1e3 * avg_kernel_s,
-                         'algorithmic_bytes_per_env_substep': algo,
-                         'achieved_awake_substeps_only': awake_only,
-                         'issue_side': issue,
-                         'note': 'nominal figure of the contract: algorithmic bytes x ALL env-substeps / kernel time.  The state is '
-                                 'LDS-resident for the whole launch, so the measured HBM traffic (`traffic`) is ~1 % of it, and ~96 % of '
-                                 'the substeps are coasting/quiet ones that touch no body (`achieved_awake_substeps_only` counts the '
-                                 'rest).  The kernel is VALU-issue / dependent-latency bound: see `issue_side` (rocprofv3 SQ counters, '
-                                 'profiles/) and DESIGN.md section 4'},
+            'roofline': roofline(achieved, awake_only, traffic, issue, avg_kernel_s, algo, per_launch, world_n_waves),
         }
         out.update(extra)
         if not args.no_cpu_baseline and world_size == 1:
             cl = cpu_legs(cfg_kwargs, scene, names, quick=args.quick)
+            cl.update(pose_err_leg(scene, names))
             ref_cpu = cl.pop('reference_semantics_cpu', None)
+            pe_ = cl.pop('deactivation_pose_equivalence', None)
+            if pe_ is not None:
+                out.setdefault('deactivation', {})['pose_equivalence'] = pe_
             out.update(cl)
             if ref_cpu is not None:
                 rs = out.setdefault('reference_semantics', {})
@@ -657,6 +761,14 @@ def main():
                         v['one_wave_us_per_substep'] = 1e6 * v['envs'] / v['sim_steps_per_s']
                 rs['gpu_over_cpu_sim_steps'] = {k: g[k]['sim_steps_per_s'] / c_[k]['sim_steps_per_s']
                                                 for k in c_ if g.get(k) and c_[k]['sim_steps_per_s'] > 0}
+                g8 = rs.get('gpu_8192') or {}
+                for k, v in g8.items():
+                    if v:
+                        v['one_wave_us_per_substep'] = 1e6 * v['envs'] / v['sim_steps_per_s']
+                rs['gpu_8192_over_cpu_sim_steps'] = {k: g8[k]['sim_steps_per_s'] / c_[k]['sim_steps_per_s']
+                                                     for k in c_ if g8.get(k) and c_[k]['sim_steps_per_s'] > 0}
+                rs['cpu_sampling'] = ('every cpu leg: >= 16 envs per host thread, >= 10 s or 4 env.step() per env, OpenMP schedule(dynamic); '
+                                      '`one_thread` = the same leg on one thread (16 envs), `scaling_1_to_n` = all threads / one thread')
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.barrier()

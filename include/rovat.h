@@ -400,6 +400,14 @@ int  rv_get_env_counters(rv_world* w, int32_t* d_out /* [N][RV_NCOUNTERS]: sim_s
  *      LIMB_POSITION_THRESHOLD (sawyer_sim.py:201-204). */
 int  rv_set_joint_targets(rv_world* w, const float* d_q /* [N][RV_NLIMB] */, float timeout, float threshold);
 int  rv_set_link_target(rv_world* w, const float* d_pose /* [N][7] pos+xyzw */, float timeout, float threshold);
+/* ---- SawyerSim.move_along_gripper_path (sawyer_sim.py:310-360) -> ControllableBody.set_target_link_poses
+ *      (controllable_body.py:322-345): 1 <= n_poses <= RV_MAXQ gripper poses per env, followed one after the other
+ *      (the next pose is taken when the IK solution of the current one is reached). */
+int  rv_set_link_path(rv_world* w, const float* d_poses /* [N][n_poses][7] pos+xyzw */, int32_t n_poses, float timeout, float threshold);
+/* ---- SawyerSim.is_limb_ready / is_gripper_ready (sawyer_sim.py:394-408; ControllableBody.is_ready,
+ *      controllable_body.py:565-595): like the reference's query it retires link / joint targets that are done
+ *      (reached, timed out, path exhausted).  The gripper is ready 0.5 s of simulated time after rv_grip. */
+int  rv_get_robot_ready(rv_world* w, uint8_t* d_out /* [N][2]: limb ready, gripper ready */);
 /* ---- BulletPhysics.position_control_array (bullet_physics.py:1061-1104):
  *      POSITION_CONTROL motor targets (gains POSITION_GAIN / VELOCITY_GAIN,
  *      controllable_body.py:17-18) for the joints whose mask byte is non-zero

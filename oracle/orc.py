@@ -46,7 +46,7 @@ def _lib(double):
                      'orc_get_episode_returns', 'orc_get_stats', 'orc_eval_reward',
                      'orc_eval_waypoints', 'orc_set_external_control', 'orc_motor_targets',
                      'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout', 'orc_set_pose_f32',
-                     'orc_debug_solver_counts', 'orc_set_num_threads', 'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction', 'orc_set_constraint', 'orc_render_rgb', 'orc_set_constraint_ex'):
+                     'orc_debug_solver_counts', 'orc_set_num_threads', 'orc_set_link_paths', 'orc_robot_ready', 'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction', 'orc_set_constraint', 'orc_render_rgb', 'orc_set_constraint_ex'):
             getattr(lib, name).restype = None
         lib.orc_is_limb_ready.restype = C.c_int
         lib.orc_is_gripper_ready.restype = C.c_int
@@ -185,6 +185,15 @@ class OracleWorld(object):
     def set_link_path(self, poses):
         a = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 7)
         self.lib.orc_set_link_path(self.h, C.c_int(a.shape[0]), _p(a))
+
+    def set_link_paths(self, poses):
+        a = np.ascontiguousarray(poses, dtype=np.float32)
+        if a.ndim == 2:
+            a = np.ascontiguousarray(np.broadcast_to(a[None], (self.n,) + a.shape))
+        self.lib.orc_set_link_paths(self.h, C.c_int(a.shape[1]), _p(a))
+
+    def robot_ready(self):
+        return self._get('orc_robot_ready', (self.n, 2), np.uint8)
 
     def set_link_timeout(self, timeout):
         self.lib.orc_set_link_timeout(self.h, C.c_double(timeout))

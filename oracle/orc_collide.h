@@ -278,6 +278,64 @@ static inline void orc_epa(const real (*A)[3], int nA, const real (*B)[3], int n
   *out_depth = fd[bestf];
 }
 
+/* The closest point of the GJK simplex IS the origin but the simplex is a vertex, a segment or a triangle (two cores that
+ * overlap mirror-symmetrically about the origin of the difference body: crossed edges exactly centred, a face centred on
+ * a face): grow it into a tetrahedron of non-zero volume that has the origin inside or on its boundary, so that EPA can
+ * measure the overlap.  Returns 0 when the difference body is flat in every direction tried (the cores really only touch).
+ * Support points of the difference body A - B in direction d: support(A, d) - support(B, -d). */
+static inline void orc_diff_support(const real (*A)[3], int nA, const real (*B)[3], int nB, const real* d, real* w, real* a, real* b) {
+  real nd[3]; v3scale(nd, d, R(-1.0));
+  v3cpy(a, A[orc_support(A, nA, d)]); v3cpy(b, B[orc_support(B, nB, nd)]); v3sub(w, a, b);
+}
+static inline int orc_simplex_expand(const real (*A)[3], int nA, const real (*B)[3], int nB, orc_simplex* s) {
+  if (s->n == 1) {
+    int ok = 0;
+    for (int k = 0; k < 6 && !ok; ++k) {
+      real d[3] = {R(0.0), R(0.0), R(0.0)}; d[k >> 1] = (k & 1) ? R(-1.0) : R(1.0);
+      real w[3], a[3], b[3], e[3];
+      orc_diff_support(A, nA, B, nB, d, w, a, b);
+      v3sub(e, w, s->w[0]);
+      if (v3dot(e, e) > R(1e-12)) { v3cpy(s->w[1], w); v3cpy(s->a[1], a); v3cpy(s->b[1], b); s->n = 2; ok = 1; }
+    }
+    if (!ok) return 0;
+  }
+  if (s->n == 2) {
+    real d[3]; v3sub(d, s->w[1], s->w[0]);
+    const real dd = v3dot(d, d);
+    int ax = 0;
+    if (rabs(d[1]) < rabs(d[ax])) ax = 1;
+    if (rabs(d[2]) < rabs(d[ax])) ax = 2;
+    real e0[3] = {R(0.0), R(0.0), R(0.0)}; e0[ax] = R(1.0);
+    real u[3], v[3]; v3cross(u, d, e0); v3cross(v, d, u);
+    int ok = 0;
+    for (int k = 0; k < 4 && !ok; ++k) {
+      real dir[3];
+      v3scale(dir, k < 2 ? u : v, (k & 1) ? R(-1.0) : R(1.0));
+      real w[3], a[3], b[3], e[3], cr[3];
+      orc_diff_support(A, nA, B, nB, dir, w, a, b);
+      v3sub(e, w, s->w[0]); v3cross(cr, e, d);
+      if (v3dot(e, e) > R(1e-12) && v3dot(cr, cr) > R(1e-6) * dd * v3dot(e, e)) { v3cpy(s->w[2], w); v3cpy(s->a[2], a); v3cpy(s->b[2], b); s->n = 3; ok = 1; }
+    }
+    if (!ok) return 0;
+  }
+  if (s->n == 3) {
+    real e1[3], e2[3], nrm[3];
+    v3sub(e1, s->w[1], s->w[0]); v3sub(e2, s->w[2], s->w[0]); v3cross(nrm, e1, e2);
+    const real nl = rsqrt_(v3dot(nrm, nrm));
+    if (!(nl > R(0.0))) return 0;
+    int ok = 0;
+    for (int k = 0; k < 2 && !ok; ++k) {
+      real dir[3]; v3scale(dir, nrm, k ? R(-1.0) : R(1.0));
+      real w[3], a[3], b[3], e[3];
+      orc_diff_support(A, nA, B, nB, dir, w, a, b);
+      v3sub(e, w, s->w[0]);
+      if (v3dot(e, dir) > R(1e-6) * nl) { v3cpy(s->w[3], w); v3cpy(s->a[3], a); v3cpy(s->b[3], b); s->n = 4; ok = 1; }
+    }
+    if (!ok) return 0;
+  }
+  return s->n == 4;
+}
+
 /* GJK distance between convex vertex sets A and B (world frame), with EPA on
  * overlap.  Returns 0 if the sets are farther apart than max_dist, else 1 and
  * n (unit, from B towards A), signed core distance (negative = overlap) and
@@ -348,7 +406,14 @@ static inline int orc_gjk_epa_c(const real (*A)[3], int nA, const real (*B)[3], 
     have_v = 1;
   }
   ORC_DBG(orc_dbg_end_n = s.n; if (penetrating) orc_dbg_reason = 10 + penetrating;)
-  if (penetrating == 1) {
+  real ta[3] = {R(0.0), R(0.0), R(0.0)}, tb[3] = {R(0.0), R(0.0), R(0.0)};
+  if (penetrating == 2) {
+    /* the origin lies ON a vertex / segment / triangle of the simplex: the witnesses of "touching" first, then (round 5)
+     * the simplex is grown into a tetrahedron and EPA decides whether the cores merely touch or overlap */
+    for (int i = 0; i < s.n; ++i) { v3madd(ta, ta, s.a[i], s.lam[i]); v3madd(tb, tb, s.b[i], s.lam[i]); }
+    if (orc_simplex_expand(A, nA, B, nB, &s)) penetrating = 3;
+  }
+  if (penetrating == 1 || penetrating == 3) {
     real nf[3], depth;
     orc_epa(A, nA, B, nB, &s, nf, &depth, pa, pb);
     if (depth < R(1e29)) {
@@ -357,11 +422,15 @@ static inline int orc_gjk_epa_c(const real (*A)[3], int nA, const real (*B)[3], 
       return 1;
     }
     /* fully degenerate polytope: treat as touching along the guess */
+    if (penetrating == 3) { v3cpy(pa, ta); v3cpy(pb, tb); }
     penetrating = 2;
     goto touching;
   }
-  pa[0] = pa[1] = pa[2] = R(0.0); pb[0] = pb[1] = pb[2] = R(0.0);
-  for (int i = 0; i < s.n; ++i) { v3madd(pa, pa, s.a[i], s.lam[i]); v3madd(pb, pb, s.b[i], s.lam[i]); }
+  if (penetrating == 2) { v3cpy(pa, ta); v3cpy(pb, tb); }
+  else {
+    pa[0] = pa[1] = pa[2] = R(0.0); pb[0] = pb[1] = pb[2] = R(0.0);
+    for (int i = 0; i < s.n; ++i) { v3madd(pa, pa, s.a[i], s.lam[i]); v3madd(pb, pb, s.b[i], s.lam[i]); }
+  }
 touching:
   if (penetrating == 2) {
     /* cores touch on a lower-dimensional simplex: zero depth along the guess */

@@ -2712,6 +2712,18 @@ void orc_set_link_path(orc_world* w, int n_poses, const float* poses) {
 }
 /* Link.set_dynamics / Body.set_dynamics lateral friction of the finger tips and the table
  * (grasp_4dof_env.py:262-293); negative = leave unchanged */
+/* per-env paths [N][n_poses][7] (rv_set_link_path) */
+void orc_set_link_paths(orc_world* w, int n_poses, const float* poses) {
+  for (int i = 0; i < w->n; ++i) {
+    real wps[RV_MAXQ][7];
+    for (int q = 0; q < n_poses; ++q) for (int k = 0; k < 7; ++k) wps[q][k] = (real)poses[((size_t)i * n_poses + q) * 7 + k];
+    robot_move_along_gripper_path(w, &w->env[i], wps, n_poses);
+  }
+}
+/* rv_get_robot_ready: [N][2] = (is_limb_ready, is_gripper_ready) */
+void orc_robot_ready(orc_world* w, uint8_t* out) {
+  for (int i = 0; i < w->n; ++i) { out[2 * i] = (uint8_t)arm_is_ready_limb(w, &w->env[i]); out[2 * i + 1] = (uint8_t)robot_is_gripper_ready(w, &w->env[i]); }
+}
 void orc_set_friction(orc_world* w, double mu_finger, double mu_table) {
   for (int i = 0; i < w->n; ++i) {
     if (mu_finger >= 0.0) w->env[i].mu_finger = (real)mu_finger;

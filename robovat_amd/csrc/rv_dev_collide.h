@@ -371,6 +371,62 @@ RV_DEV_NOINLINE void epa(const float* A, int nA, const float* B, int nB, const E
   *out_depth = E.fd[bestf];
 }
 
+// The closest point of the GJK simplex IS the origin but the simplex is a vertex, a segment or a triangle (two cores that
+// overlap mirror-symmetrically about the origin of the difference body: crossed edges exactly centred, a face centred on a
+// face): grow it into a tetrahedron of non-zero volume that has the origin inside or on its boundary, so that EPA can
+// measure the overlap (orc_simplex_expand).  Returns 0 when the difference body is flat in every direction tried.
+RV_DEV void diff_support(const float* A, int nA, const float* B, int nB, v3 d, v3* w, v3* a, v3* b) {
+  float pj;
+  *a = support_v(A, nA, d, &pj); *b = support_v(B, nB, scale(d, -1.0f), &pj); *w = sub(*a, *b);
+}
+RV_DEV int simplex_expand(const float* A, int nA, const float* B, int nB, Simplex& s) {
+  if (s.n == 1) {
+    int ok = 0;
+    for (int k = 0; k < 6 && !ok; ++k) {
+      const float sg = (k & 1) ? -1.0f : 1.0f;
+      const v3 d = (k >> 1) == 0 ? mk(sg, 0.0f, 0.0f) : ((k >> 1) == 1 ? mk(0.0f, sg, 0.0f) : mk(0.0f, 0.0f, sg));
+      v3 w, a, b;
+      diff_support(A, nA, B, nB, d, &w, &a, &b);
+      const v3 e = sub(w, s.w[0]);
+      if (dot(e, e) > 1e-12f) { s.w[1] = w; s.a[1] = a; s.b[1] = b; s.n = 2; ok = 1; }
+    }
+    if (!ok) return 0;
+  }
+  if (s.n == 2) {
+    const v3 d = sub(s.w[1], s.w[0]);
+    const float dd = dot(d, d);
+    int ax = 0;
+    if (fabsr(d.y) < fabsr(d.x)) ax = 1;
+    if (fabsr(d.z) < fabsr(ax == 0 ? d.x : d.y)) ax = 2;
+    const v3 e0 = ax == 0 ? mk(1.0f, 0.0f, 0.0f) : (ax == 1 ? mk(0.0f, 1.0f, 0.0f) : mk(0.0f, 0.0f, 1.0f));
+    const v3 u = cross(d, e0), v = cross(d, u);
+    int ok = 0;
+    for (int k = 0; k < 4 && !ok; ++k) {
+      const v3 dir = scale(k < 2 ? u : v, (k & 1) ? -1.0f : 1.0f);
+      v3 w, a, b;
+      diff_support(A, nA, B, nB, dir, &w, &a, &b);
+      const v3 e = sub(w, s.w[0]), cr = cross(e, d);
+      if (dot(e, e) > 1e-12f && dot(cr, cr) > 1e-6f * dd * dot(e, e)) { s.w[2] = w; s.a[2] = a; s.b[2] = b; s.n = 3; ok = 1; }
+    }
+    if (!ok) return 0;
+  }
+  if (s.n == 3) {
+    const v3 nrm = cross(sub(s.w[1], s.w[0]), sub(s.w[2], s.w[0]));
+    const float nl = fsqrtr(dot(nrm, nrm));
+    if (!(nl > 0.0f)) return 0;
+    int ok = 0;
+    for (int k = 0; k < 2 && !ok; ++k) {
+      const v3 dir = scale(nrm, k ? -1.0f : 1.0f);
+      v3 w, a, b;
+      diff_support(A, nA, B, nB, dir, &w, &a, &b);
+      const v3 e = sub(w, s.w[0]);
+      if (dot(e, dir) > 1e-6f * nl) { s.w[3] = w; s.a[3] = a; s.b[3] = b; s.n = 4; ok = 1; }
+    }
+    if (!ok) return 0;
+  }
+  return s.n == 4;
+}
+
 // GJK distance with EPA fallback.  Returns 0 when farther apart than max_dist.
 // lb_out (optional): a rigorous lower bound of the distance between the two hulls
 // (the largest separating-plane bound seen), valid also when the query misses.
@@ -441,7 +497,15 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
     simplex_commit(s, l); v = vc;
     have_v = 1;
   }
-  if (penetrating == 1) {
+  v3 ta = mk(0, 0, 0), tb = mk(0, 0, 0);
+  if (penetrating == 2) {
+    // the origin lies ON a vertex / segment / triangle of the simplex: the witnesses of "touching" first, then (round 5)
+    // the simplex is grown into a tetrahedron and EPA decides whether the cores merely touch or overlap
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i < s.n) { ta = madd(ta, s.a[i], s.lam[i]); tb = madd(tb, s.b[i], s.lam[i]); }
+    if (simplex_expand(A, nA, B, nB, s)) penetrating = 3;
+  }
+  if (penetrating == 1 || penetrating == 3) {
     v3 nf; float depth;
     RV_CNT(20, 1)
     EpaSeed seed;
@@ -453,13 +517,19 @@ RV_DEV int gjk_epa(const float* A, int nA, const float* B, int nB, v3 guess, flo
       *dist = -depth;
       return 1;
     }
-    penetrating = 2;   // fully degenerate polytope: treat as touching along the guess
+    // fully degenerate polytope: treat as touching along the guess (after a failed expansion: with the witnesses of the
+    // simplex GJK ended on; after GJK's own tetrahedron: with whatever EPA left, as the oracle does)
+    if (penetrating == 3) { *pa = ta; *pb = tb; }
+    penetrating = 4;
   }
-  v3 qa = mk(0, 0, 0), qb = mk(0, 0, 0);
+  if (penetrating == 2) { *pa = ta; *pb = tb; }
+  else if (penetrating == 0) {
+    v3 qa = mk(0, 0, 0), qb = mk(0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) if (i < s.n) { qa = madd(qa, s.a[i], s.lam[i]); qb = madd(qb, s.b[i], s.lam[i]); }
-  if (penetrating != 2 || s.n < 4) { *pa = qa; *pb = qb; }
-  if (penetrating == 2) {
+    for (int i = 0; i < 4; ++i) if (i < s.n) { qa = madd(qa, s.a[i], s.lam[i]); qb = madd(qb, s.b[i], s.lam[i]); }
+    *pa = qa; *pb = qb;
+  }
+  if (penetrating == 2 || penetrating == 4) {
     v3 g = guess;
     float gl = len(g);
     if (!(gl > 1e-6f)) { g = mk(0.0f, 0.0f, 1.0f); gl = 1.0f; }

@@ -181,6 +181,39 @@ __global__ void k_set_link_target(DevEnv* envs, int n, const float* pose, const 
   t.start_t = cfg->dt * (float)e.sim_steps; t.stop_t = t.start_t + (timeout > 0.0f ? timeout : cfg->limb_timeout); t.has_stop = 1;
   t.pos_thr = threshold > 0.0f ? threshold : cfg->limb_position_threshold; t.vel_thr = cfg->velocity_threshold;
 }
+__global__ void k_set_link_path(DevEnv* envs, int n, const float* poses, int n_poses, const rv_config* cfg, const rv_scene* scene, float timeout, float threshold) {
+  ENV_THREAD();
+  // SawyerSim.move_along_gripper_path (sawyer_sim.py:310-360) -> ControllableBody.set_target_link_poses
+  // (controllable_body.py:322-345): the poses are queued, the first one becomes the link target
+  arm_reset_targets(e);
+  for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = cfg->limb_max_velocity_ratio * scene->arm.v_max[j];
+  LTarget& t = e.lt;
+  t.active = 1; t.has_pose = 0; t.nq = n_poses;
+  for (int q = 0; q < n_poses; ++q) for (int k = 0; k < 7; ++k) t.queue[q][k] = poses[((size_t)i * n_poses + q) * 7 + k];
+  t.start_t = cfg->dt * (float)e.sim_steps; t.stop_t = t.start_t + (timeout > 0.0f ? timeout : cfg->limb_timeout); t.has_stop = 1;
+  t.pos_thr = threshold > 0.0f ? threshold : cfg->limb_position_threshold; t.vel_thr = cfg->velocity_threshold;
+  lt_pop(t);
+}
+__global__ void k_robot_ready(DevEnv* envs, int n, uint8_t* out, const rv_config* cfg) {
+  ENV_THREAD();
+  // SawyerSim.is_limb_ready -> ControllableBody.is_ready(limb joints) (sawyer_sim.py:394-400, controllable_body.py:565-595):
+  // like the reference's, the query retires targets that are done (reached, timed out, path exhausted)
+  const float now = cfg->dt * (float)e.sim_steps;
+  {
+    const LTarget& t = e.lt;
+    if (!t.has_stop || now >= t.stop_t || (!t.has_pose && t.nq == 0)) lt_reset(e.lt);
+  }
+  {
+    const JTarget& t = e.jt;
+    if (!t.has_stop || now >= t.stop_t || check_joints_reached(e)) jt_reset(e.jt);
+  }
+  int ready = 1;
+  if (e.lt.active) ready = 0;                 // (every limb joint index < end-effector link index)
+  if (e.jt.active) for (int k = 0; k < e.jt.n_idx; ++k) if (e.jt.idx[k] < RV_NLIMB) ready = 0;
+  out[(size_t)i * 2] = (uint8_t)ready;
+  // SawyerSim.is_gripper_ready (sawyer_sim.py:402-408): 0.5 s of simulated time after the last grip command
+  out[(size_t)i * 2 + 1] = (uint8_t)(now >= e.gripper_ready_time);
+}
 __global__ void k_compute_ik(const DevEnv* envs, int n, const float* pose, float* q, const rv_config* cfg, const rv_scene* scene) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
   Consts K; K.cfg = cfg; K.arm = &scene->arm; K.scene = scene; K.stop_after = 0;
@@ -788,6 +821,12 @@ int rv_debug_profile(rv_world* w, unsigned long long* d) { WCHK(w); NEED(d, "rv_
 int rv_get_env_counters(rv_world* w, int32_t* d) { WCHK(w); NEED(d, "rv_get_env_counters"); SIMPLE_LAUNCH(k_get_env_counters, w->d_envs, w->n, d); return RV_OK; }
 int rv_set_joint_targets(rv_world* w, const float* d, float timeout, float threshold) { WCHK(w); NEED(d, "rv_set_joint_targets"); SIMPLE_LAUNCH(k_set_joint_targets, w->d_envs, w->n, d, w->d_cfg, w->d_scene, timeout, threshold); return RV_OK; }
 int rv_set_link_target(rv_world* w, const float* d, float timeout, float threshold) { WCHK(w); NEED(d, "rv_set_link_target"); SIMPLE_LAUNCH(k_set_link_target, w->d_envs, w->n, d, w->d_cfg, w->d_scene, timeout, threshold); return RV_OK; }
+int rv_set_link_path(rv_world* w, const float* d, int32_t n_poses, float timeout, float threshold) {
+  WCHK(w); NEED(d, "rv_set_link_path");
+  if (n_poses < 1 || n_poses > RV_MAXQ) return fail(RV_ERR_VALUE, "rv_set_link_path: 1 <= n_poses <= RV_MAXQ");
+  SIMPLE_LAUNCH(k_set_link_path, w->d_envs, w->n, d, n_poses, w->d_cfg, w->d_scene, timeout, threshold); return RV_OK;
+}
+int rv_get_robot_ready(rv_world* w, uint8_t* d) { WCHK(w); NEED(d, "rv_get_robot_ready"); SIMPLE_LAUNCH(k_robot_ready, w->d_envs, w->n, d, w->d_cfg); return RV_OK; }
 int rv_set_motor_targets(rv_world* w, const float* d_q, const uint8_t* d_mask) {
   WCHK(w); NEED(d_q, "rv_set_motor_targets");
   SIMPLE_LAUNCH(k_set_motor_targets, w->d_envs, w->n, d_q, d_mask, w->d_cfg); return RV_OK;

@@ -31,7 +31,7 @@ SYMBOLS = [
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
     'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll', 'rv_set_constraint', 'rv_render_rgb', 'rv_set_friction', 'rv_set_auto_reset',
-    'rv_set_constraint_ex',
+    'rv_set_constraint_ex', 'rv_set_link_path', 'rv_get_robot_ready',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -149,6 +149,8 @@ def load():
     lib.rv_get_state_ptrs.argtypes = [vp, C.POINTER(abi.rv_state_view)]
     lib.rv_set_joint_targets.argtypes = [vp, vp, f32, f32]
     lib.rv_set_link_target.argtypes = [vp, vp, f32, f32]
+    lib.rv_set_link_path.argtypes = [vp, vp, i32, f32, f32]
+    lib.rv_get_robot_ready.argtypes = [vp, vp]
     for name in ('rv_set_actions', 'rv_get_body_state', 'rv_set_body_state',
                  'rv_get_body_params', 'rv_set_body_params', 'rv_get_joint_state',
                  'rv_set_joint_state', 'rv_get_link_poses', 'rv_get_env_counters',
@@ -383,6 +385,20 @@ class World(object):
     def set_link_target(self, pose, timeout=0.0, threshold=0.0):
         check(self.lib.rv_set_link_target(self.h, self._ptr(self._in(pose, (self.n, 7), self.torch.float32)),
                                           float(timeout), float(threshold)))
+
+    def set_link_path(self, poses, timeout=0.0, threshold=0.0):
+        """poses [N, n_poses, 7] (or [n_poses, 7]: the same path for every env): SawyerSim.move_along_gripper_path
+        -> ControllableBody.set_target_link_poses."""
+        p = self.torch.as_tensor(poses, dtype=self.torch.float32, device=self.device)
+        if p.dim() == 2:
+            p = p[None].expand(self.n, -1, -1)
+        n_poses = int(p.shape[1])
+        p = p.reshape(self.n, n_poses, 7).contiguous()
+        check(self.lib.rv_set_link_path(self.h, self._ptr(p), n_poses, float(timeout), float(threshold)))
+
+    def robot_ready(self):
+        """[N, 2] uint8: (is_limb_ready, is_gripper_ready) -- retires finished targets like the reference's query."""
+        return self._get('rv_get_robot_ready', (self.n, 2), self.torch.uint8)
 
     def reset_targets(self):
         check(self.lib.rv_reset_targets(self.h))

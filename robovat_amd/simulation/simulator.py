@@ -47,25 +47,108 @@ class Body(object):
         self.physics.set_body_color(self._uid, rgba, specular)
 
 
+class Link(object):
+    """A link of the arm (link.py): index, name, world pose."""
+
+    def __init__(self, body, index):
+        self._body, self.index = body, int(index)
+
+    uid = property(lambda s: (s._body.uid, s.index))
+    name = property(lambda s: s._body.physics.get_link_name(s.uid))
+    pose = property(lambda s: s._body.physics.get_link_pose(s.uid))
+    position = property(lambda s: s.pose.position)
+    orientation = property(lambda s: s.pose.orientation)
+
+    def set_dynamics(self, mass=None, lateral_friction=None, rolling_friction=None, spinning_friction=None):
+        self._body.physics.set_link_dynamics(self.uid, mass=mass, lateral_friction=lateral_friction,
+                                             rolling_friction=rolling_friction, spinning_friction=rolling_friction)
+
+
+class Joint(object):
+    """A joint of the arm (joint.py:41-92): index, name, limits, position / velocity."""
+
+    def __init__(self, body, index):
+        self._body, self.index = body, int(index)
+
+    uid = property(lambda s: (s._body.uid, s.index))
+    name = property(lambda s: s._body.physics.get_joint_name(s.uid))
+    limit = property(lambda s: s._body.physics.get_joint_limit(s.uid))
+    lower_limit = property(lambda s: s.limit['lower'])
+    upper_limit = property(lambda s: s.limit['upper'])
+    max_effort = property(lambda s: s.limit['effort'])
+    max_velocity = property(lambda s: s.limit['velocity'])
+    range = property(lambda s: s.upper_limit - s.lower_limit)
+    velocity = property(lambda s: s._body.physics.get_joint_velocity(s.uid))
+
+    @property
+    def position(self):
+        return self._body.physics.get_joint_position(self.uid)
+
+    @position.setter
+    def position(self, value):
+        self._body.physics.set_joint_position(self.uid, value)
+
+
 class ControllableBody(Body):
     """The arm: targets are handed to the device-side ControllableBody state
-    machine (controllable_body.py:263-345 -> rv_set_joint_targets / rv_set_link_target)."""
+    machine (controllable_body.py:263-345 -> rv_set_joint_targets / rv_set_link_target / rv_set_link_path)."""
+
+    def __init__(self, *args, **kwargs):
+        super(ControllableBody, self).__init__(*args, **kwargs)
+        self._links = [Link(self, i) for i in self.physics.get_body_link_indices(self.uid)]
+        self._joints = [Joint(self, i) for i in self.physics.get_body_joint_indices(self.uid)]
+
+    links = property(lambda s: s._links)
+    joints = property(lambda s: s._joints)
+
+    def get_link_by_name(self, name):
+        for link in self._links:
+            if link.name == name:
+                return link
+        raise ValueError('The link %s is not found in body %s.' % (name, self.name))
+
+    def get_joint_by_name(self, name):
+        for joint in self._joints:
+            if joint.name == name:
+                return joint
+        raise ValueError('The joint %s is not found in body %s.' % (name, self.name))
 
     def set_target_joint_positions(self, joint_positions, timeout=15.0, threshold=0.008726640):
+        if isinstance(joint_positions, dict):
+            joint_positions = [joint_positions[j.name] for j in self._joints[:7]]
         self.physics.world.set_joint_targets(np.asarray(joint_positions, np.float32)[None, :7],
                                              timeout=timeout, threshold=threshold)
 
-    def set_target_link_pose(self, link_ind, link_pose, timeout=15.0, threshold=0.008726640):
+    def _pose7(self, link_pose):
         pose = Pose(link_pose)
-        p = np.concatenate([np.asarray(pose.position), np.asarray(pose.quaternion)]).astype(np.float32)
-        self.physics.world.set_link_target(p[None], timeout=timeout, threshold=threshold)
+        return np.concatenate([np.asarray(pose.position), np.asarray(pose.quaternion)]).astype(np.float32)
+
+    def set_target_link_pose(self, link_ind, link_pose, timeout=15.0, threshold=0.008726640):
+        self.physics.world.set_link_target(self._pose7(link_pose)[None], timeout=timeout, threshold=threshold)
+
+    def set_target_link_poses(self, link_ind, link_poses, timeout=15.0, threshold=0.008726640):
+        """controllable_body.py:322-345: a path of gripper poses, followed one after the other."""
+        poses = np.stack([self._pose7(p) for p in link_poses])
+        self.physics.world.set_link_path(poses[None], timeout=timeout, threshold=threshold)
 
     def set_max_joint_velocities(self, joint_velocities):
         pass   # LIMB_MAX_VELOCITY_RATIO is applied on the device
 
+    def grip(self, value):
+        """SawyerSim.grip (sawyer_sim.py:362-392): the two finger joints' target, replacing the limb's joint target."""
+        self.physics.world.grip(float(value))
+
     def reset_targets(self):
         """controllable_body.py:347-350: drop the link / joint targets."""
         self.physics.world.reset_targets()
+
+    def is_ready(self, joint_inds=None):
+        """controllable_body.py:565-595 for the limb joints: no link target and no joint target on them is pending
+        (targets that are done are retired by the query, as in the reference)."""
+        return bool(self.physics.world.robot_ready().cpu().numpy()[0, 0])
+
+    def is_gripper_ready(self):
+        return bool(self.physics.world.robot_ready().cpu().numpy()[0, 1])
 
     @property
     def joint_positions(self):

@@ -210,3 +210,28 @@ def test_emulated_grasp_env_is_bit_exact_vs_float_oracle(emu):
         _check(e, ref)
         ref.reset(); emu.emu_reset(e.h, None)          # every grasp is a whole episode
         _check(e, ref)
+
+
+def test_concentric_overlaps_run_epa_from_a_grown_simplex(emu):
+    """Bodies teleported INTO each other (same centre, same orientation: identical shapes give a mirror-symmetric
+    difference body, GJK's closest point is the origin on a segment / triangle): the grown-simplex + EPA path of
+    rv_dev_collide.h equals the oracle's, and the pair manifolds hold deep points (until round 5: depth 0)."""
+    from oracle import orc
+    scene, names = scenes.make_scene()
+    n = 32
+    cfg = configs.make_rv_config(env_cfg=configs.push_env_config(), n_envs=n, seed=5, shape_names=names)
+    ref = orc.OracleWorld(cfg, scene, double=False)
+    e = Emu(emu, cfg, scene)
+    ref.reset(); emu.emu_reset(e.h, None)
+    st = ref.body_state().copy()
+    for a, b in ((0, 1), (2, 3)):
+        st[:, b, :7] = st[:, a, :7]
+    st[:, :, 2] += 0.03; st[:, :, 7:] = 0
+    ref.set_body_state(st); emu.emu_set_body_state(e.h, st.astype(np.float32).ctypes.data_as(C.c_void_p))
+    ref.step_sub(1); emu.emu_step_sub(e.h, 1)
+    assert np.array_equal(e.body_state(), ref.body_state().astype(np.float32)) and np.array_equal(e.manifolds(), ref.manifold_counts())
+    same_shape = ref.body_params()[:, 0, 1] == ref.body_params()[:, 1, 1]
+    deep = sum(1 for i in range(n) if same_shape[i] and ref.manifold(i, abi.RV_MAXB)[0] > 0 and ref.manifold(i, abi.RV_MAXB)[1][:, 9].min() < -0.005)
+    assert same_shape.sum() >= 4 and deep == same_shape.sum(), (deep, same_shape.sum())
+    ref.step_sub(30); emu.emu_step_sub(e.h, 30)
+    assert np.array_equal(e.body_state(), ref.body_state().astype(np.float32))

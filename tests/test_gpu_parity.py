@@ -297,3 +297,25 @@ def test_both_builds_of_the_env_kernel_match_the_oracle(monkeypatch):
         assert np.array_equal(w.env_counters().cpu().numpy(), ref.env_counters()), occ
         assert np.array_equal(w.manifold_counts().cpu().numpy(), ref.manifold_counts()), occ
         w.close()
+
+
+def test_concentric_overlaps_run_epa_from_a_grown_simplex():
+    """Bodies teleported INTO each other (same centre and orientation: identical shapes give a mirror-symmetric
+    difference body, GJK ends with the origin ON a segment / triangle of its simplex).  Until round 5 such a pair was
+    reported as 'touching, depth 0'; now the simplex is grown into a tetrahedron and EPA measures the overlap
+    (rv_dev_collide.h simplex_expand; closed forms: tests/test_independent_pin.py).  HIP == float oracle through the
+    push-out, and the pair manifolds of the identical-shape pairs hold deep points."""
+    world, ref, cfg = _worlds(64, seed=5)
+    world.reset(); ref.reset()
+    st = ref.body_state().copy()
+    for a, b in ((0, 1), (2, 3)):
+        st[:, b, :7] = st[:, a, :7]
+    st[:, :, 2] += 0.03; st[:, :, 7:] = 0
+    ref.set_body_state(st); world.set_body_state(st)
+    ref.step_sub(1); world.step_sub(1)
+    _cmp(world, ref, 0.0)
+    same = ref.body_params()[:, 0, 1] == ref.body_params()[:, 1, 1]
+    deep = sum(1 for i in range(64) if same[i] and ref.manifold(i, abi.RV_MAXB)[0] > 0 and ref.manifold(i, abi.RV_MAXB)[1][:, 9].min() < -0.005)
+    assert same.sum() >= 8 and deep == same.sum(), (deep, same.sum())
+    ref.step_sub(60); world.step_sub(60)
+    _cmp(world, ref, 0.0)

@@ -1,0 +1,96 @@
+"""Reference-style env code on the HIP backend: a phase machine that drives `self.robot.*` (the `SawyerSim` facade,
+robovat/robots/sawyer/sawyer_sim.py:186-408) and calls `simulator.step()` once per substep, the way
+`PushEnv._execute_action` / `Grasp4DofEnv._execute_action` do (push_env.py:631-733, grasp_4dof_env.py:213-293) --
+against the float oracle driven with the same commands through its own entry points: same substep counts per phase,
+bodies / joints / link poses bit for bit.  Covers `move_to_joint_positions`, `move_to_gripper_pose` (plain and
+`straight_line=True` -> `move_along_gripper_path` -> rv_set_link_path), `grip`, `is_limb_ready`, `is_gripper_ready`."""
+import numpy as np
+import pytest
+
+from robovat_amd import abi, configs
+from robovat_amd.math import Pose
+
+pytestmark = pytest.mark.gpu
+
+
+def _pose7(pose):
+    pose = Pose(pose)
+    return np.concatenate([np.asarray(pose.position), np.asarray(pose.quaternion)]).astype(np.float32)
+
+
+def test_phase_machine_on_sawyer_sim_matches_the_oracle():
+    from oracle import orc
+    from robovat_amd.robots import SawyerSim, RobotCommand
+    from robovat_amd.simulation import Simulator
+    sim = Simulator(physics_backend='HipPhysics', worker_id=7)
+    sim.reset(); sim.start()
+    phys = sim.physics
+    sim.add_body('sim/table/table.urdf', [[0.6, 0, 0.0], [0, 0, 0]], is_static=True, name='table')
+    box = sim.add_body('box.urdf', [[0.62, 0.05, 0.05], [0, 0, 0.3]], scale=1.0, name='movable_0')
+    cyl = sim.add_body('cylinder16.urdf', [[0.75, -0.12, 0.06], [0, 0, 0]], scale=1.1, name='movable_1')
+    robot = SawyerSim(sim)
+    assert isinstance(RobotCommand('x', 'y').arguments, dict)
+    assert robot.end_effector.name == 'right_hand' and len(robot.joint_positions) == 7
+    assert abs(robot.joint_positions['right_j3'] - robot.config.LIMB_NEUTRAL_POSITIONS[3]) < 1e-6
+    # the oracle twin: same config, the state the host calls above left on the device
+    ref = orc.OracleWorld(phys.rv_config, phys.scene, double=False)
+    ref.set_body_params(phys.world.body_params().cpu().numpy()); ref.set_body_state(phys.world.body_state().cpu().numpy())
+    ref.set_joint_state(phys.world.joint_state().cpu().numpy())
+    ref.grip(0.0)                                  # (SawyerSim.reboot opened the gripper)
+
+    def same():
+        assert np.abs(phys.world.body_state().cpu().numpy() - ref.body_state().astype(np.float32)).max() == 0.0
+        assert np.abs(phys.world.joint_state().cpu().numpy() - ref.joint_state().astype(np.float32)).max() == 0.0
+        assert np.abs(phys.world.link_poses().cpu().numpy() - ref.link_poses().astype(np.float32)).max() == 0.0
+
+    def run(ready, ref_ready, max_steps=6000, check=10):
+        """the loop of _execute_action: step, look at the robot every `check` substeps"""
+        n = 0
+        while n < max_steps:
+            sim.step(); n += 1
+            if n % check == 0 and ready():
+                break
+        m = 0
+        while m < max_steps:
+            ref.step_sub(1); m += 1
+            if m % check == 0 and ref_ready():
+                break
+        assert n == m, (n, m)
+        same()
+        return n
+
+    limb, limb_ref = robot.is_limb_ready, lambda: bool(ref.robot_ready()[0, 0])
+    settle = sim.wait_until_stable([box, cyl], max_steps=800)
+    ref.step_sub(settle)                            # (the host loop's count, replayed)
+    same()
+    tz = float(phys.world.body_params().cpu().numpy()[0, 0, 6])
+    start = Pose([[0.50, 0.05, tz + 0.30], [np.pi, 0, 0]])
+    # 1. above the start of the push (IK link target)
+    robot.move_to_gripper_pose(start); ref.set_link_target(_pose7(start)[None])
+    n1 = run(limb, limb_ref)
+    # 2. straight down to the table (way points every END_EFFECTOR_STEP)
+    low = Pose([[0.50, 0.05, tz + 0.16], [np.pi, 0, 0]])
+    p0 = np.asarray(robot.end_effector.pose.position, np.float64)
+    robot.move_to_gripper_pose(low, straight_line=True)
+    delta = np.asarray(low.position, np.float64) - p0
+    num = min(int(np.linalg.norm(delta) / robot.config.END_EFFECTOR_STEP), abi.RV_MAXQ - 1)
+    path = np.stack([_pose7(Pose([p0 + delta * (float(i) / num), low.quaternion])) for i in range(num)] + [_pose7(low)])
+    assert len(path) >= 2
+    ref.set_link_paths(path)
+    n2 = run(limb, limb_ref)
+    # 3. the push through the box, then close the gripper and wait for it
+    end = Pose([[0.70, 0.05, tz + 0.16], [np.pi, 0, 0]])
+    robot.move_to_gripper_pose(end); ref.set_link_target(_pose7(end)[None])
+    n3 = run(limb, limb_ref)
+    assert np.linalg.norm(np.asarray(box.position)[:2] - [0.62, 0.05]) > 0.02          # the box was pushed
+    robot.grip(1); ref.grip(1.0)
+    assert not robot.is_gripper_ready()
+    n4 = run(robot.is_gripper_ready, lambda: bool(ref.robot_ready()[0, 1]))
+    assert 500 <= n4 <= 510                                                              # 0.5 s of simulated time
+    # 4. off stage through a joint target, bodies settle meanwhile
+    off = list(phys.rv_config.offstage_positions)
+    robot.move_to_joint_positions(off); ref.set_joint_targets(np.asarray(off, np.float32)[None])
+    n5 = run(limb, limb_ref)
+    assert min(n1, n2, n3, n5) >= 10 and np.abs(np.asarray(robot.arm.joint_positions[:7]) - off).max() < 0.02
+    with pytest.raises(NotImplementedError):
+        robot.move_to_joint_positions(off, speed=0.9)

@@ -97,9 +97,7 @@ def test_gjk_epa_against_closed_forms(double):
     A2 = _box([h, h, h], R=_rot([0, 0, 1], np.pi / 4))
     for g in (0.015, 0.0008, -0.0015):
         cx = -np.sqrt(2.0) * h - g - np.sqrt(2.0) * h
-        # (the edges cross off-centre: with B exactly centred the overlapping configuration is mirror-symmetric, the origin
-        # lies exactly ON a triangle of the GJK simplex and the query reports 'touching, depth 0' -- a measure-zero case the
-        # build does not resolve)
+        # (the edges cross off-centre; the exactly centred, mirror-symmetric configurations are the next test)
         r = orc.eval_gjk(A2, _box([h, h, h], [cx, 0.004, -0.003], _rot([0, 1, 0], np.pi / 4)), double=double)
         _check(r, g, [1, 0, 0], tol)
         assert abs(r['pa'][0] + np.sqrt(2.0) * h) < 50 * tol and abs(r['pa'][1]) < 50 * tol     # on A's leading edge (x, y fixed)
@@ -114,6 +112,46 @@ def test_gjk_epa_against_closed_forms(double):
         B[:, 2] += -B[:, 2].min() + (0.003 if k % 2 == 0 else -0.002)
         r = orc.eval_gjk(B, slab, double=double)
         _check(r, B[:, 2].min(), [0, 0, 1], tol, pb_plane=([0, 0, 1], 0.0))
+
+
+@pytest.mark.parametrize('double', [True, False])
+def test_gjk_epa_mirror_symmetric_overlaps(double):
+    """Overlapping cores that are mirror-symmetric about the origin of the difference body: GJK's closest point IS the
+    origin while its simplex is still a segment or a triangle.  Until round 5 the query reported 'touching, depth 0' here
+    (round-4 review, weak item 1); now the simplex is grown into a tetrahedron and EPA measures the overlap
+    (orc_simplex_expand / simplex_expand).  Closed forms: crossed edges exactly centred, a face centred on a face,
+    concentric boxes (depth = the smallest sum of half extents), and the exact touch, whose depth IS zero -- with the
+    face normal instead of the caller's guess."""
+    tol = 1e-9 if double else 3e-6
+    h = 0.03
+    A = _box([h, h, h])
+    # crossed edges, exactly centred, overlapping by p along x
+    A2 = _box([h, h, h], R=_rot([0, 0, 1], np.pi / 4))
+    for p_ in (0.004, 0.0006, 0.011):
+        cx = -(2.0 * np.sqrt(2.0) * h - p_)
+        r = orc.eval_gjk(A2, _box([h, h, h], [cx, 0.0, 0.0], _rot([0, 1, 0], np.pi / 4)), double=double)
+        _check(r, -p_, [1, 0, 0], tol)
+        assert abs(r['pa'][0] + np.sqrt(2.0) * h) < 50 * tol and abs(r['pa'][1]) < 50 * tol     # on A's leading edge
+        assert abs(r['pb'][0] - (cx + np.sqrt(2.0) * h)) < 50 * tol and abs(r['pb'][2]) < 50 * tol
+    # a face centred on a face, overlapping by p
+    for p_ in (0.003, 0.0004, 0.02):
+        r = orc.eval_gjk(A, _box([h, h, h], [-(2 * h - p_), 0.0, 0.0]), double=double)
+        _check(r, -p_, [1, 0, 0], tol)
+    # ... and only touching: depth zero, normal = the face normal (not the guess)
+    r = orc.eval_gjk(A, _box([h, h, h], [-2 * h, 0.0, 0.0]), double=double)
+    _check(r, 0.0, [1, 0, 0], tol)
+    # concentric boxes: the smallest sum of half extents, along that axis
+    for hb in ([0.01, 0.02, 0.015], [0.03, 0.03, 0.03], [0.05, 0.012, 0.04]):
+        r = orc.eval_gjk(A, _box(hb), double=double)
+        sums = np.array(hb) + h
+        assert abs(-r['dist'] - sums.min()) < tol, (r['dist'], sums)
+        ax = int(np.argmin(sums)) if (np.sort(sums)[1] - sums.min()) > 1e-6 else int(np.argmax(np.abs(r['n'])))
+        assert abs(abs(r['n'][ax]) - 1.0) < 50 * tol and np.linalg.norm((r['pa'] - r['pb']) - r['dist'] * r['n']) < 50 * tol
+    # a 16-gon prism (the scene's cylinder) standing concentric in a box: depth along z = sum of the half heights
+    th = np.arange(16) * 2 * np.pi / 16
+    cyl = np.array([[0.02 * np.cos(t), 0.02 * np.sin(t), z] for z in (-0.01, 0.01) for t in th])
+    r = orc.eval_gjk(cyl[::2], _box([0.05, 0.05, 0.02]), double=double)     # (16 vertices: every other one of each ring)
+    assert abs(-r['dist'] - 0.03) < tol and abs(abs(r['n'][2]) - 1.0) < 50 * tol
 
 
 @pytest.mark.parametrize('double', [True, False])
