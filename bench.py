@@ -37,6 +37,34 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_PER_SIMD_CYCLE = 0.5      # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
 
 
+def effective_cpus():
+    """Host threads this process may actually keep busy: the smallest of the CPU count, the affinity mask and the
+    cgroup CPU quota (a GPU box handed out as a slice of a node reports all 256 hardware threads in os.cpu_count() but
+    throttles the container to its quota -- 16 CPUs on this pool: 256 busy OpenMP threads then run 40 x slower per thread
+    than 16 do)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+                q = int(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_legs(cfg_kwargs, scene, names, quick=False):
     """Everything that runs the CPU oracle (kind 'port': pybullet, the reference's physics,
     is not importable here): the same-workload baseline, the reference-semantics legs, BASELINE
@@ -52,8 +80,10 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
     import numpy as np
     from robovat_amd import configs, lib, scenes
     from oracle import orc
-    cores = os.cpu_count() or 1
-    out = {}
+    cores = effective_cpus()
+    out = {'host': {'cpu_count': os.cpu_count(), 'threads_used': cores,
+                    'note': 'threads_used = min(CPU count, affinity mask, cgroup CPU quota): what the container may keep busy'}}
+    orc.set_num_threads(cores)
     per_thread = 4 if quick else 16
     n = max(16, per_thread * cores)
     min_seconds, max_steps = (3.0, 2) if quick else (10.0, 4)

@@ -281,6 +281,10 @@ typedef struct rv_config {
    * exit resting bodies creep at ~4e-5 m/s -- visible only without deactivation; Bullet runs its 50 sweeps without
    * an early exit.)  Islands that hold finger / limb motor rows keep solver_tol.  0 (or >= solver_tol): one tolerance */
   float    solver_tol_rest;
+  /* ArmEnv._reset_camera (arm_env.py:109-152; push_env.py:273-280): on every env.reset() the camera of that env gets the
+   * calibration above plus uniform noise in [-cam_noise, +cam_noise], element by element: [0..4] the five intrinsics
+   * (fx, fy, cx, cy, skew), [5..13] the rotation matrix, [14..16] the translation (KINECT2.DEPTH.*_NOISE; 0 = none) */
+  float    cam_noise[17];
 } rv_config;
 
 /* Per-launch statistics of rv_step_macro / rv_reset (device-side reductions of
@@ -455,6 +459,10 @@ int  rv_compute_ik(rv_world* w, const float* d_pose /* [N][7] */, float* d_q /* 
  *      (simulator.py:246-287, bullet_physics.py:1268-1304).
  *      d_out: uint8[N][2+RV_MAXB]: arm-table, arm-any-movable, arm-movable[b]. */
 int  rv_query_contacts(rv_world* w, uint8_t* d_out);
+/* ---- the camera calibration an env's observations are rendered with (Camera.intrinsics / translation / rotation,
+ *      camera.py:150-168; the camera-calibration observations of camera_obs.py:241-320): rv_config's values plus the
+ *      noise drawn at that env's last reset (cam_noise). */
+int  rv_get_camera(rv_world* w, float* d_out /* [N][17]: fx, fy, cx, cy, skew, rotation[9] row-major, translation[3] */);
 /* Number of manifold points per manifold slot, for parity tests. */
 int  rv_get_manifold_counts(rv_world* w, int32_t* d_out /* [N][RV_NMAN] */);
 

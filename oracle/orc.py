@@ -46,7 +46,7 @@ def _lib(double):
                      'orc_get_episode_returns', 'orc_get_stats', 'orc_eval_reward',
                      'orc_eval_waypoints', 'orc_set_external_control', 'orc_motor_targets',
                      'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout', 'orc_set_pose_f32',
-                     'orc_debug_solver_counts', 'orc_set_num_threads', 'orc_set_link_paths', 'orc_robot_ready', 'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction', 'orc_set_constraint', 'orc_render_rgb', 'orc_set_constraint_ex'):
+                     'orc_debug_solver_counts', 'orc_set_num_threads', 'orc_set_link_paths', 'orc_robot_ready', 'orc_get_camera', 'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction', 'orc_set_constraint', 'orc_render_rgb', 'orc_set_constraint_ex'):
             getattr(lib, name).restype = None
         lib.orc_is_limb_ready.restype = C.c_int
         lib.orc_is_gripper_ready.restype = C.c_int
@@ -195,6 +195,9 @@ class OracleWorld(object):
     def robot_ready(self):
         return self._get('orc_robot_ready', (self.n, 2), np.uint8)
 
+    def camera(self):
+        return self._get('orc_get_camera', (self.n, 17))
+
     def set_link_timeout(self, timeout):
         self.lib.orc_set_link_timeout(self.h, C.c_double(timeout))
 
@@ -295,6 +298,12 @@ class OracleWorld(object):
         s = abi.rv_macro_stats()
         self.lib.orc_get_stats(self.h, C.byref(s))
         return {k: getattr(s, k) for k, _ in s._fields_}
+
+
+def set_num_threads(n, double=False):
+    """OpenMP threads of the stepping entry points of both builds (process-wide)."""
+    for d in (False, True):
+        _lib(d).orc_set_num_threads(C.c_int(int(n)))
 
 
 def eval_reward(cfg, state, next_state, double=False):

@@ -112,6 +112,8 @@ typedef struct {
   int obs_num_steps, obs_num_episodes;   /* env.attributes snapshot (push_env.py:368-375, 637-644) */
   /* lateral friction of the finger tips / the table (Link.set_dynamics, grasp_4dof_env.py:262-293) */
   real mu_finger, mu_table;
+  /* the camera this env is observed with: rv_config's calibration + the noise of its last reset (arm_env.py:109-152) */
+  real cam_intrinsics[5], cam_rotation[9], cam_translation[3];
   int num_action_steps;                  /* Grasp4DofEnv: substeps spent in the 'start' phase */
   real fing_dv[2], fing_vt[2], fing_qd0[2];   /* finger motors this substep: velocity step, commanded velocity, velocity after it */
   real limb_lam[RV_NLIMB];   /* impulses of the limb motor rows of the last solve that had them (diagnostic) */
@@ -1188,7 +1190,12 @@ static real constraint_solve(const orc_world* w, orc_env* e, int b, real* lam) {
     if (k < n_lin && ctype == 3) {
       real ek[3] = {R(0.0), R(0.0), R(0.0)}; ek[k + 1] = R(1.0);
       m3mulv(jl, rt, ek);                                        /* column k + 1 of the frame's rotation */
-      v3cross(ja, r, jl); v3cross(jc, rc, jl);
+      /* ONE anchor for both parties: the parent's pivot wp (as Bullet's slider does).  Along the slide axis wp and the
+       * child's frame origin are far apart; equal and opposite impulses at two different points would be a spurious
+       * torque (round-4 advisor): the child's lever is wp - x_child, not its own frame origin */
+      real rcw[3] = {R(0.0), R(0.0), R(0.0)};
+      if (cw >= 0) v3sub(rcw, wp, e->body[cw].p);
+      v3cross(ja, r, jl); v3cross(jc, rcw, jl);
       bias = (real)c->erp * v3dot(jl, dtp) / dt;
     } else if (k < n_lin) {
       jl[k] = R(1.0);
@@ -2326,9 +2333,22 @@ static void sample_poses(const orc_world* w, orc_env* e, orc_rng* g, int nb, rea
 }
 
 /* RobotEnv.reset (robot_env.py:204-237) for one env */
+/* ArmEnv._reset_camera (arm_env.py:109-152; push_env.py:273-280): rv_config's calibration plus uniform noise, element by
+ * element, from a Philox stream of its own (the scene of an episode does not depend on the camera noise) */
+#define STREAM_CAMERA 4u
+static void camera_reset(const rv_config* c, orc_env* e, int gid, int use_noise) {
+  orc_rng g; rng_init(&g, c->seed_lo, c->seed_hi, (uint32_t)gid, STREAM_CAMERA, (uint32_t)e->reset_count);
+  for (int k = 0; k < 17; ++k) {
+    const real base = (real)(k < 5 ? c->cam_intrinsics[k] : (k < 14 ? c->cam_rotation[k - 5] : c->cam_translation[k - 14]));
+    const real nz = use_noise ? rng_uniform(&g, -(real)c->cam_noise[k], (real)c->cam_noise[k]) : R(0.0);
+    const real v = base + nz;
+    if (k < 5) e->cam_intrinsics[k] = v; else if (k < 14) e->cam_rotation[k - 5] = v; else e->cam_translation[k - 14] = v;
+  }
+}
 static void env_reset(const orc_world* w, orc_env* e, int gid) {
   const rv_config* c = &w->cfg;
   orc_rng g; rng_init(&g, c->seed_lo, c->seed_hi, (uint32_t)gid, STREAM_RESET, (uint32_t)e->reset_count);
+  camera_reset(c, e, gid, 1);
   e->reset_count++;
   e->substeps_last = 0; e->awake_last = 0; e->pairs_last = 0;
   e->sim_steps = 0; e->num_steps = 0; e->episode_reward = R(0.0); e->last_reward = R(0.0);
@@ -2423,6 +2443,7 @@ orc_world* orc_create(const rv_config* cfg, const rv_scene* scene) {
     for (int f = 0; f < RV_NFRAME; ++f) w->env[i].fquat[f][3] = R(1.0);
     w->env[i].done = 1; /* RobotEnv.__init__: self._done = True (robot_env.py:66) */
     w->env[i].mu_finger = (real)cfg->arm_friction; w->env[i].mu_table = (real)cfg->table_friction;
+    camera_reset(cfg, &w->env[i], 0, 0);
   }
   return w;
 }
@@ -2721,6 +2742,14 @@ void orc_set_link_paths(orc_world* w, int n_poses, const float* poses) {
   }
 }
 /* rv_get_robot_ready: [N][2] = (is_limb_ready, is_gripper_ready) */
+void orc_get_camera(orc_world* w, double* out) {
+  for (int i = 0; i < w->n; ++i) {
+    const orc_env* e = &w->env[i]; double* o = out + (size_t)i * 17;
+    for (int k = 0; k < 5; ++k) o[k] = (double)e->cam_intrinsics[k];
+    for (int k = 0; k < 9; ++k) o[5 + k] = (double)e->cam_rotation[k];
+    for (int k = 0; k < 3; ++k) o[14 + k] = (double)e->cam_translation[k];
+  }
+}
 void orc_robot_ready(orc_world* w, uint8_t* out) {
   for (int i = 0; i < w->n; ++i) { out[2 * i] = (uint8_t)arm_is_ready_limb(w, &w->env[i]); out[2 * i + 1] = (uint8_t)robot_is_gripper_ready(w, &w->env[i]); }
 }
@@ -2814,14 +2843,14 @@ void orc_observe(orc_world* w, double* position, double* body_mask, int64_t* att
  * reference takes the observation and is not rendered.  Sampling: the num_points smallest
  * per-pixel Philox keys (a uniformly random subset) or num_points draws with replacement. */
 #define STREAM_PC 7u
-static void pc_pixel_dir_cam(const rv_config* c, real u, real v, real* d) {
+static void pc_pixel_dir_cam(const orc_env* c, real u, real v, real* d) {
   const real fx = (real)c->cam_intrinsics[0], fy = (real)c->cam_intrinsics[1], cx = (real)c->cam_intrinsics[2], cy = (real)c->cam_intrinsics[3], sk = (real)c->cam_intrinsics[4];
   real y = (v - cy) / fy;
   real x = (u - cx - sk * y) / fx;
   d[0] = x; d[1] = y; d[2] = R(1.0);
 }
-static void pc_cam_rot(const rv_config* c, real* Rm) { for (int i = 0; i < 9; ++i) Rm[i] = (real)c->cam_rotation[i]; }
-static void pc_cam_position(const rv_config* c, real* o) {
+static void pc_cam_rot(const orc_env* c, real* Rm) { for (int i = 0; i < 9; ++i) Rm[i] = (real)c->cam_rotation[i]; }
+static void pc_cam_position(const orc_env* c, real* o) {
   real Rm[9], t[3] = {(real)c->cam_translation[0], (real)c->cam_translation[1], (real)c->cam_translation[2]}, p[3];
   pc_cam_rot(c, Rm); m3tmulv(p, Rm, t);
   o[0] = -p[0]; o[1] = -p[1]; o[2] = -p[2];
@@ -2932,7 +2961,7 @@ static int pc_render_pixel_n(const orc_world* w, const orc_env* e, real rot[][9]
 static int pc_render_pixel(const orc_world* w, const orc_env* e, real rot[][9], const real* cam_o, const real* dw, real* depth) {
   return pc_render_pixel_n(w, e, rot, cam_o, dw, depth, (real*)0);
 }
-static void pc_deproject(const rv_config* c, const real* cam_o, real u, real v, real z, real* out) {
+static void pc_deproject(const orc_env* c, const real* cam_o, real u, real v, real z, real* out) {
   real d[3], pc[3], Rm[9], pw[3];
   pc_pixel_dir_cam(c, u, v, d);
   pc[0] = d[0] * z; pc[1] = d[1] * z; pc[2] = d[2] * z;
@@ -2956,11 +2985,11 @@ static void pc_body_rots(const orc_env* e, real rot[][9]) { for (int b = 0; b < 
 void orc_render(orc_world* w, int env, float* depth, uint8_t* segmask) {
   const rv_config* c = &w->cfg; const orc_env* e = &w->env[env];
   real rot[RV_MAXB][9], cam_o[3], Rm[9];
-  pc_body_rots(e, rot); pc_cam_position(c, cam_o); pc_cam_rot(c, Rm);
+  pc_body_rots(e, rot); pc_cam_position(e, cam_o); pc_cam_rot(e, Rm);
   for (int v = 0; v < c->cam_height; ++v)
     for (int u = 0; u < c->cam_width; ++u) {
       real dc[3], dw[3], dep;
-      pc_pixel_dir_cam(c, (real)u, (real)v, dc); m3tmulv(dw, Rm, dc);
+      pc_pixel_dir_cam(e, (real)u, (real)v, dc); m3tmulv(dw, Rm, dc);
       int who = pc_render_pixel(w, e, rot, cam_o, dw, &dep);
       if (who >= 0 && !(dep > (real)c->cam_near)) who = -1;
       depth[(size_t)v * c->cam_width + u] = who >= 0 ? (float)dep : 0.0f;
@@ -2973,11 +3002,11 @@ void orc_render_rgb(orc_world* w, int env, uint8_t* rgb) {
   const rv_config* c = &w->cfg; const orc_env* e = &w->env[env];
   static const real base[RV_MAXB + 3][3] = {{230, 60, 60}, {60, 170, 230}, {250, 200, 40}, {90, 200, 110}, {150, 120, 90}, {185, 185, 195}, {30, 30, 30}};   /* bodies, table, arm, background */
   real rot[RV_MAXB][9], cam_o[3], Rm[9];
-  pc_body_rots(e, rot); pc_cam_position(c, cam_o); pc_cam_rot(c, Rm);
+  pc_body_rots(e, rot); pc_cam_position(e, cam_o); pc_cam_rot(e, Rm);
   for (int v = 0; v < c->cam_height; ++v)
     for (int u = 0; u < c->cam_width; ++u) {
       real dc[3], dw[3], dep, n[3];
-      pc_pixel_dir_cam(c, (real)u, (real)v, dc); m3tmulv(dw, Rm, dc);
+      pc_pixel_dir_cam(e, (real)u, (real)v, dc); m3tmulv(dw, Rm, dc);
       int who = pc_render_pixel_n(w, e, rot, cam_o, dw, &dep, n);
       if (who >= 0 && !(dep > (real)c->cam_near)) who = -1;
       const int idx = who < 0 ? RV_MAXB + 2 : who;
@@ -2999,7 +3028,7 @@ void orc_point_cloud(orc_world* w, float* out) {
     const uint32_t gid = (uint32_t)(c->env_id_offset + i);
     const uint32_t rng_arg = (uint32_t)e->reset_count * 4096u + (uint32_t)e->num_steps;
     real rot[RV_MAXB][9], cam_o[3], Rm[9];
-    pc_body_rots(e, rot); pc_cam_position(c, cam_o); pc_cam_rot(c, Rm);
+    pc_body_rots(e, rot); pc_cam_position(e, cam_o); pc_cam_rot(e, Rm);
     uint32_t* pix = (uint32_t*)malloc(sizeof(uint32_t) * RV_PC_MAXPIX * 3);
     uint32_t* key = pix + RV_PC_MAXPIX; uint32_t* sorted = key + RV_PC_MAXPIX;
     real* dep = (real*)malloc(sizeof(real) * RV_PC_MAXPIX);
@@ -3014,10 +3043,10 @@ void orc_point_cloud(orc_world* w, float* out) {
             const real sc = e->bp[b].scale;
             real l[3] = {(real)sh->verts[h][k][0] * sc, (real)sh->verts[h][k][1] * sc, (real)sh->verts[h][k][2] * sc}, rw[3], pw[3], pc[3];
             m3mulv(rw, rot[b], l); v3add(pw, e->body[b].p, rw);
-            m3mulv(pc, Rm, pw); pc[0] += (real)c->cam_translation[0]; pc[1] += (real)c->cam_translation[1]; pc[2] += (real)c->cam_translation[2];
+            m3mulv(pc, Rm, pw); pc[0] += e->cam_translation[0]; pc[1] += e->cam_translation[1]; pc[2] += e->cam_translation[2];
             real z = pc[2];
-            real u = ((real)c->cam_intrinsics[0] * pc[0] + (real)c->cam_intrinsics[4] * pc[1]) / pc[2] + (real)c->cam_intrinsics[2];
-            real v = (real)c->cam_intrinsics[1] * pc[1] / pc[2] + (real)c->cam_intrinsics[3];
+            real u = (e->cam_intrinsics[0] * pc[0] + e->cam_intrinsics[4] * pc[1]) / pc[2] + e->cam_intrinsics[2];
+            real v = e->cam_intrinsics[1] * pc[1] / pc[2] + e->cam_intrinsics[3];
             if (z < mz) mz = z;
             if (z > (real)c->cam_near) { if (u < mu) mu = u; if (u > xu) xu = u; if (v < mv) mv = v; if (v > xv) xv = v; }
           }
@@ -3034,10 +3063,10 @@ void orc_point_cloud(orc_world* w, float* out) {
             for (int idx = 0; idx < total; ++idx) {
               const int u = u0 + idx % ww, v = v0 + idx / ww;
               real dc[3], dw[3], d, pt[3];
-              pc_pixel_dir_cam(c, (real)u, (real)v, dc); m3tmulv(dw, Rm, dc);
+              pc_pixel_dir_cam(e, (real)u, (real)v, dc); m3tmulv(dw, Rm, dc);
               int who = pc_render_pixel(w, e, rot, cam_o, dw, &d);
               if (!(who == b && d > (real)c->cam_near)) continue;
-              pc_deproject(c, cam_o, (real)u, (real)v, d, pt);
+              pc_deproject(e, cam_o, (real)u, (real)v, d, pt);
               if (!pc_crop_ok(c, pt)) continue;
               if (n % stride == 0 && n / stride < RV_PC_MAXPIX) { pix[n / stride] = ((uint32_t)v << 16) | (uint32_t)u; dep[n / stride] = d; }
               n++;
@@ -3052,7 +3081,7 @@ void orc_point_cloud(orc_world* w, float* out) {
       if (n < P) {
         for (int j = 0; j < P; ++j) {
           uint32_t k = pc_hash(c, gid, rng_arg, ((uint32_t)b << 16) | (uint32_t)j) % (uint32_t)n;
-          real pt[3]; pc_deproject(c, cam_o, (real)(pix[k] & 0xffffu), (real)(pix[k] >> 16), dep[k], pt);
+          real pt[3]; pc_deproject(e, cam_o, (real)(pix[k] & 0xffffu), (real)(pix[k] >> 16), dep[k], pt);
           o[3 * j] = (float)pt[0]; o[3 * j + 1] = (float)pt[1]; o[3 * j + 2] = (float)pt[2];
         }
         continue;
@@ -3070,7 +3099,7 @@ void orc_point_cloud(orc_world* w, float* out) {
          * their keys (ties in scan order) */
         int rank = 0;
         for (int t = 0; t < n; ++t) rank += (key[t] < key[k] || (key[t] == key[k] && t < k)) ? 1 : 0;
-        real pt[3]; pc_deproject(c, cam_o, (real)(pix[k] & 0xffffu), (real)(pix[k] >> 16), dep[k], pt);
+        real pt[3]; pc_deproject(e, cam_o, (real)(pix[k] & 0xffffu), (real)(pix[k] >> 16), dep[k], pt);
         o[3 * rank] = (float)pt[0]; o[3 * rank + 1] = (float)pt[1]; o[3 * rank + 2] = (float)pt[2];
         outn++;
       }

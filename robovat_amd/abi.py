@@ -138,6 +138,7 @@ class rv_config(C.Structure):
         ('grasp_mu_descend', f32 * 2), ('grasp_mu_lift', f32 * 2),
         ('ground_z', f32), ('ground_friction', f32), ('rolling_friction', f32), ('wake_gap', f32), ('deact_lin', f32), ('deact_ang', f32), ('deact_steps', i32),
         ('gravity_xy', f32 * 2), ('arm_effort_limit', i32), ('limb_dynamics', i32), ('solver_stall', i32), ('solver_tol_rest', f32),
+        ('cam_noise', f32 * 17),
     ]
 
 

@@ -360,6 +360,20 @@ def make_rv_config(env_cfg=None, robot_cfg=None, shape_names=None, n_envs=1,
     abi.assign(c.cam_rotation, np.asarray(cam.ROTATION, dtype=np.float64).reshape(9).tolist())
     abi.assign(c.cam_translation, np.asarray(cam.TRANSLATION, dtype=np.float64).reshape(3).tolist())
     c.cam_near = 0.02                                    # bullet_camera.py:18
+    # ArmEnv._reset_camera (arm_env.py:109-152): uniform noise on the calibration at every env.reset(), element by element;
+    # each *_NOISE has the shape of what it perturbs (None = none)
+    noise = np.zeros(17)
+    if cam.get('INTRINSICS_NOISE') is not None:
+        kn = np.abs(np.asarray(cam.INTRINSICS_NOISE, dtype=np.float64)).reshape(3, 3)
+        noise[0:5] = [kn[0, 0], kn[1, 1], kn[0, 2], kn[1, 2], kn[0, 1]]
+    if cam.get('ROTATION_NOISE') is not None:
+        rn = np.abs(np.asarray(cam.ROTATION_NOISE, dtype=np.float64))
+        if rn.size != 9:
+            raise ValueError('KINECT2.DEPTH.ROTATION_NOISE must have the shape of ROTATION (3 x 3): arm_env.py:146-149 adds it element by element')
+        noise[5:14] = rn.reshape(9)
+    if cam.get('TRANSLATION_NOISE') is not None:
+        noise[14:17] = np.abs(np.asarray(cam.TRANSLATION_NOISE, dtype=np.float64)).reshape(3)
+    abi.assign(c.cam_noise, noise.tolist())
     if env_cfg.OBS.get('CROP_MIN') is not None and env_cfg.OBS.get('CROP_MAX') is not None:
         c.use_crop = 1
         abi.assign(c.crop_min, list(env_cfg.OBS.CROP_MIN))

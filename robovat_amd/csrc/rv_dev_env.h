@@ -72,6 +72,7 @@ __device__ __forceinline__ void g_shared_cnt(int i, int n);
 #define RV_STREAM_RESET  1u
 #define RV_STREAM_RANDOM 2u
 #define RV_STREAM_HEUR   3u
+#define RV_STREAM_CAMERA 4u
 #define RV_STEPS_TO_CHECK_DONE 100   // controllable_body.py:21
 #define RV_STEPS_TO_UPDATE_IK  10    // controllable_body.py:24
 
@@ -109,6 +110,9 @@ struct DevEnv {
   // con_tquat), which can apply at most con_fmax N per row
   int con_on[RV_MAXB]; float con_lpos[RV_MAXB][3], con_lquat[RV_MAXB][4], con_tpos[RV_MAXB][3], con_tquat[RV_MAXB][4], con_fmax[RV_MAXB];
   float table_z;
+  // the camera this env is observed with: rv_config's calibration + the noise drawn at its last reset (ArmEnv._reset_camera,
+  // arm_env.py:109-152): fx, fy, cx, cy, skew; rotation (row-major); translation
+  float cam_intrinsics[5], cam_rotation[9], cam_translation[3];
   int n_bodies;
   int arm_enabled;
   float q[RV_NJ], qd[RV_NJ];
@@ -1328,7 +1332,11 @@ RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
     v3 jl = mk(0, 0, 0), ja = mk(0, 0, 0), jc = mk(0, 0, 0); float bias;
     if (k < n_lin && ctype == RV_CON_PRISMATIC) {
       jl = mulv(rt, mk(0.0f, k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f));      // column k + 1 of the frame's rotation
-      ja = cross(r, jl); jc = cross(rc, jl);
+      // ONE anchor for both parties: the parent's pivot wp (as Bullet's slider does) -- along the slide axis wp and the
+      // child's frame origin are far apart, and equal and opposite impulses at two points would be a spurious torque
+      // (round-4 advisor): the child's lever is wp - x_child
+      const v3 rcw = cw >= 0 ? sub(wp, ld3(e.body[cw])) : mk(0.0f, 0.0f, 0.0f);
+      ja = cross(r, jl); jc = cross(rcw, jl);
       bias = c->erp * dot(jl, dtp) / dt;
     } else if (k < n_lin) {
       const v3 ek = mk(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f);
@@ -4729,6 +4737,9 @@ RV_DEV void obs_snap_fill(const DevEnv& e, const rv_arm* arm, ObsSnap& s, const 
     s.shape[b] = e.active[b] ? e.shape[b] : -1;
   }
   s.table_z = e.table_z;
+  for (int k = 0; k < 5; ++k) s.cam_intrinsics[k] = e.cam_intrinsics[k];
+  for (int k = 0; k < 9; ++k) s.cam_rotation[k] = e.cam_rotation[k];
+  for (int k = 0; k < 3; ++k) s.cam_translation[k] = e.cam_translation[k];
   s.rng_arg = (uint32_t)e.reset_count * 4096u + (uint32_t)e.num_steps;
   s.arm_on = e.arm_enabled;
   if (s.arm_on) obs_snap_arm(e, arm, s);
@@ -5195,6 +5206,17 @@ RV_DEV void sample_poses(Shared& S, const Consts& K, int nb) {
 
 // RobotEnv.reset for one env (robot_env.py:204-237), in the segments env_program runs between the settle waits
 // (each wait is one request to the substep loop).  (1) counters, table height, body count; Grasp4DofEnv: its object
+// ArmEnv._reset_camera (arm_env.py:109-152): the calibration of rv_config plus uniform noise, element by element.  A
+// stream of its own: the scene of an episode does not depend on whether the camera is perturbed (noise 0: x + 0 = x).
+RV_DEV void camera_reset(DevEnv& e, const rv_config* c, int gid, int use_noise) {
+  Rng g = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_CAMERA, (uint32_t)e.reset_count);
+  for (int k = 0; k < 17; ++k) {
+    const float base = k < 5 ? c->cam_intrinsics[k] : (k < 14 ? c->cam_rotation[k - 5] : c->cam_translation[k - 14]);
+    const float nz = use_noise ? rng_uniform(g, -c->cam_noise[k], c->cam_noise[k]) : 0.0f;
+    const float v = base + nz;
+    if (k < 5) e.cam_intrinsics[k] = v; else if (k < 14) e.cam_rotation[k - 5] = v; else e.cam_translation[k - 14] = v;
+  }
+}
 RV_DEV void env_reset_begin(Shared& S, const Consts& K, int gid, int zero_counters) {
   const rv_config* c = K.cfg;
   RV_LANES_BEGIN
@@ -5204,6 +5226,7 @@ RV_DEV void env_reset_begin(Shared& S, const Consts& K, int gid, int zero_counte
       S.s.jt_applied = 0; S.s.kin_fresh = 0; S.s.clr_valid = 0; S.s.bud_sub = 0; S.s.bud_clk = 0; S.s.suspended = 0; S.s.wus_resume = 0; S.s.far_valid = 0; S.s.far_n = 0; S.s.far = 0;
       e.in_step = 0; e.step_stage = -1;
       S.s.rng = rng_init(c->seed_lo, c->seed_hi, (uint32_t)gid, RV_STREAM_RESET, (uint32_t)e.reset_count);
+      camera_reset(e, c, gid, 1);
       e.reset_count++;
       if (zero_counters) launch_counters_zero(e);
       e.reward_valid = 0;

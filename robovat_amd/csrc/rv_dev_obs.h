@@ -32,6 +32,7 @@ struct ObsSnap {
   float scale[RV_MAXB];
   int shape[RV_MAXB];       // -1: body absent
   float table_z;
+  float cam_intrinsics[5], cam_rotation[9], cam_translation[3];   // the env's camera (DevEnv: rv_config's calibration + reset noise)
   uint32_t rng_arg;         // reset_count * 4096 + num_steps: one sampling stream per observation
   // the arm as the camera sees it: the collider boxes of the links (world centre, frame quaternion); arm_on = 0: no arm
   int arm_on;
@@ -41,14 +42,14 @@ struct ObsSnap {
 struct CamRay { v3 o, d; };   // world ray; the parameter along d is the eye-space depth
 
 // ray of pixel (u, v): K^-1 [u, v, 1] in the camera frame, rotated into the world
-RV_DEV v3 pixel_dir_cam(const rv_config* c, float u, float v) {
+RV_DEV v3 pixel_dir_cam(const ObsSnap* c, float u, float v) {
   const float fx = c->cam_intrinsics[0], fy = c->cam_intrinsics[1], cx = c->cam_intrinsics[2], cy = c->cam_intrinsics[3], sk = c->cam_intrinsics[4];
   float y = (v - cy) / fy;
   float x = (u - cx - sk * y) / fx;
   return mk(x, y, 1.0f);
 }
-RV_DEV v3 cam_to_world_dir(const rv_config* c, v3 d) { return tmulv(c->cam_rotation, d); }
-RV_DEV v3 cam_position(const rv_config* c) {
+RV_DEV v3 cam_to_world_dir(const ObsSnap* c, v3 d) { return tmulv(c->cam_rotation, d); }
+RV_DEV v3 cam_position(const ObsSnap* c) {
   v3 t = ld3(c->cam_translation);
   v3 p = tmulv(c->cam_rotation, t);
   return mk(-p.x, -p.y, -p.z);
@@ -178,7 +179,7 @@ RV_DEV void shade_rgb(int who, v3 n, uint8_t* out) {
   for (int k = 0; k < 3; ++k) out[k] = (uint8_t)(int)(base[idx][k] * sh + 0.5f);
 }
 // point of pixel (u, v) at eye depth z (Camera.deproject_pixel, camera.py:195-211)
-RV_DEV v3 deproject(const rv_config* c, v3 cam_o, float u, float v, float z) {
+RV_DEV v3 deproject(const ObsSnap* c, v3 cam_o, float u, float v, float z) {
   v3 pc = scale(pixel_dir_cam(c, u, v), z);
   return add(cam_o, tmulv(c->cam_rotation, pc));
 }
@@ -189,7 +190,7 @@ RV_DEV int crop_ok(const rv_config* c, v3 p) {
 }
 // screen rectangle (inclusive, clamped) of one body: its hull vertices projected, one pixel
 // of slack for the collision margin.  Returns 0 when the body is not in front of the camera.
-RV_DEV void project_vertex(const rv_config* c, v3 pw, float* u, float* v, float* z) {
+RV_DEV void project_vertex(const ObsSnap* c, v3 pw, float* u, float* v, float* z) {
   v3 pc = add(mulv(c->cam_rotation, pw), ld3(c->cam_translation));
   const float fx = c->cam_intrinsics[0], fy = c->cam_intrinsics[1], cx = c->cam_intrinsics[2], cy = c->cam_intrinsics[3], sk = c->cam_intrinsics[4];
   *z = pc.z;

@@ -24,7 +24,7 @@ using namespace rv;
 
 #define ENV_THREAD() const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return; DevEnv& e = envs[i];
 
-__global__ void k_init(DevEnv* envs, int n, float mu_finger, float mu_table) {
+__global__ void k_init(DevEnv* envs, int n, float mu_finger, float mu_table, const rv_config* cfg) {
   ENV_THREAD();
   uint32_t* p = reinterpret_cast<uint32_t*>(&e);
   for (int k = 0; k < (int)(sizeof(DevEnv) / 4); ++k) p[k] = 0u;
@@ -32,6 +32,7 @@ __global__ void k_init(DevEnv* envs, int n, float mu_finger, float mu_table) {
   for (int f = 0; f < RV_NFRAME; ++f) e.fquat[f][3] = 1.0f;
   e.done = 1;  // RobotEnv.__init__: self._done = True (robot_env.py:66)
   e.mu_finger = mu_finger; e.mu_table = mu_table;
+  camera_reset(e, cfg, 0, 0);      // (the unperturbed calibration until the first env.reset())
 }
 __global__ void k_get_body_state(const DevEnv* envs, int n, float* out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
@@ -229,6 +230,13 @@ __global__ void k_query_contacts(const DevEnv* envs, int n, uint8_t* out) {
   o[0] = (uint8_t)e.flag_arm_table; o[1] = (uint8_t)arm_touches_movables(e);
   for (int b = 0; b < RV_MAXB; ++b) o[2 + b] = (uint8_t)(e.active[b] && e.flag_arm_body[b]);
 }
+__global__ void k_get_camera(const DevEnv* envs, int n, float* out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
+  const DevEnv& e = envs[i]; float* o = out + (size_t)i * 17;
+  for (int k = 0; k < 5; ++k) o[k] = e.cam_intrinsics[k];
+  for (int k = 0; k < 9; ++k) o[5 + k] = e.cam_rotation[k];
+  for (int k = 0; k < 3; ++k) o[14 + k] = e.cam_translation[k];
+}
 __global__ void k_manifold_counts(const DevEnv* envs, int n, int32_t* out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
   for (int m = 0; m < RV_NMAN; ++m) out[(size_t)i * RV_NMAN + m] = envs[i].man[m].n;
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
   if (lane < RV_MAXB) { m3 m = qmat(ldq(s.pose[lane] + 3)); stm(s_rot[lane], m); }
   __syncthreads();
   int n = 0;
-  const v3 cam_o = cam_position(c);
+  const v3 cam_o = cam_position(&s);
   if (s.shape[b] >= 0) {
     // screen rectangle of the body
     const rv_shape* sh = &scene->shapes[s.shape[b]];
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
         const float sc = s.scale[b];
         v3 pw = add(ld3(s.pose[b]), mulv(s_rot[b], mk(sh->verts[h][i][0] * sc, sh->verts[h][i][1] * sc, sh->verts[h][i][2] * sc)));
         float u, v, z;
-        project_vertex(c, pw, &u, &v, &z);
+        project_vertex(&s, pw, &u, &v, &z);
         mz = z;
         if (z > c->cam_near) { mu = xu = u; mv = xv = v; }
       }
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
           const float hx = arm->col_half[lane][0] + c->margin, hy = arm->col_half[lane][1] + c->margin, hz = arm->col_half[lane][2] + c->margin;
           const float r = fsqrtr(hx * hx + hy * hy + hz * hz) * 1.01f + 1e-4f;
           float uc, vc, zc;
-          project_vertex(c, ld3(s.arm_c[lane]), &uc, &vc, &zc);
+          project_vertex(&s, ld3(s.arm_c[lane]), &uc, &vc, &zc);
           if (zc - r <= c->cam_near) may = zc + r > 0.0f;          // too close to bound its disc: keep it
           else {
             const float f = fmaxr(fabsr(c->cam_intrinsics[0]), fabsr(c->cam_intrinsics[1])) + fabsr(c->cam_intrinsics[4]);
@@ -314,9 +322,9 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
           bool vis = false; float dep = 0.0f; int u = 0, v = 0;
           if (idx < total) {
             u = u0 + idx % w; v = v0 + idx / w;
-            v3 dw = cam_to_world_dir(c, pixel_dir_cam(c, (float)u, (float)v));
+            v3 dw = cam_to_world_dir(&s, pixel_dir_cam(&s, (float)u, (float)v));
             int who = render_pixel(c, scene, s, s_rot, cam_o, dw, &dep, nullptr, arm_mask);
-            vis = (who == b) && dep > c->cam_near && crop_ok(c, deproject(c, cam_o, (float)u, (float)v, dep));
+            vis = (who == b) && dep > c->cam_near && crop_ok(c, deproject(&s, cam_o, (float)u, (float)v, dep));
           }
           const unsigned long long bal = __ballot(vis);
           const int rank = n + (int)__popcll(bal & ((1ull << lane) - 1ull));
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
     for (int j = lane; j < P; j += 64) {
       const uint32_t i = pc_hash(c, gid, s.rng_arg, RV_PC_DRAW_CTR(b, j)) % (uint32_t)n;
       const uint32_t px = s_pix[i];
-      st3(o + 3 * j, deproject(c, cam_o, (float)(px & 0xffffu), (float)(px >> 16), s_dep[i]));
+      st3(o + 3 * j, deproject(&s, cam_o, (float)(px & 0xffffu), (float)(px >> 16), s_dep[i]));
     }
     return;
   }
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
       const int jj = j0 + lane + 64 * q;
       if (jj < P) {
         const uint32_t px = s_pix[jj];
-        st3(o + 3 * rq[q], deproject(c, cam_o, (float)(px & 0xffffu), (float)(px >> 16), s_dep[jj]));
+        st3(o + 3 * rq[q], deproject(&s, cam_o, (float)(px & 0xffffu), (float)(px >> 16), s_dep[jj]));
       }
     }
   }
@@ -412,9 +420,9 @@ __global__ void k_render(const ObsSnap* snaps, int n, float* depth, uint8_t* seg
   const ObsSnap& s = snaps[i];
   float rot[RV_MAXB][9];
   for (int b = 0; b < RV_MAXB; ++b) { m3 m = qmat(ldq(s.pose[b] + 3)); stm(rot[b], m); }
-  const v3 cam_o = cam_position(c);
+  const v3 cam_o = cam_position(&s);
   float d;
-  int who = render_pixel(c, scene, s, rot, cam_o, cam_to_world_dir(c, pixel_dir_cam(c, (float)u, (float)v)), &d);
+  int who = render_pixel(c, scene, s, rot, cam_o, cam_to_world_dir(&s, pixel_dir_cam(&s, (float)u, (float)v)), &d);
   if (who >= 0 && !(d > c->cam_near)) who = -1;
   if (depth) depth[t] = who >= 0 ? d : 0.0f;
   if (seg) seg[t] = who >= 0 ? (uint8_t)who : (uint8_t)255;
@@ -521,9 +529,9 @@ __global__ void k_render_rgb(const ObsSnap* snaps, int n, uint8_t* rgb, const rv
   const ObsSnap& s = snaps[i];
   float rot[RV_MAXB][9];
   for (int b = 0; b < RV_MAXB; ++b) { m3 m = qmat(ldq(s.pose[b] + 3)); stm(rot[b], m); }
-  const v3 cam_o = cam_position(c);
+  const v3 cam_o = cam_position(&s);
   float d; v3 nrm;
-  int who = render_pixel(c, scene, s, rot, cam_o, cam_to_world_dir(c, pixel_dir_cam(c, (float)u, (float)v)), &d, &nrm);
+  int who = render_pixel(c, scene, s, rot, cam_o, cam_to_world_dir(&s, pixel_dir_cam(&s, (float)u, (float)v)), &d, &nrm);
   if (who >= 0 && !(d > c->cam_near)) who = -1;
   shade_rgb(who, nrm, rgb + t * 3);
 }
@@ -635,7 +643,7 @@ int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world*
   HIPCHK(hipMemset(w->d_stats, 0, sizeof(rv_macro_stats)));
   HIPCHK(hipEventCreate(&w->ev0));
   HIPCHK(hipEventCreate(&w->ev1));
-  hipLaunchKernelGGL(k_init, grid1(w->n), dim3(TPB), 0, w->stream, w->d_envs, w->n, cfg->arm_friction, cfg->table_friction);
+  hipLaunchKernelGGL(k_init, grid1(w->n), dim3(TPB), 0, w->stream, w->d_envs, w->n, cfg->arm_friction, cfg->table_friction, w->d_cfg);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(w->stream));
   *out = w;
@@ -826,6 +834,7 @@ int rv_set_link_path(rv_world* w, const float* d, int32_t n_poses, float timeout
   if (n_poses < 1 || n_poses > RV_MAXQ) return fail(RV_ERR_VALUE, "rv_set_link_path: 1 <= n_poses <= RV_MAXQ");
   SIMPLE_LAUNCH(k_set_link_path, w->d_envs, w->n, d, n_poses, w->d_cfg, w->d_scene, timeout, threshold); return RV_OK;
 }
+int rv_get_camera(rv_world* w, float* d) { WCHK(w); NEED(d, "rv_get_camera"); SIMPLE_LAUNCH(k_get_camera, w->d_envs, w->n, d); return RV_OK; }
 int rv_get_robot_ready(rv_world* w, uint8_t* d) { WCHK(w); NEED(d, "rv_get_robot_ready"); SIMPLE_LAUNCH(k_robot_ready, w->d_envs, w->n, d, w->d_cfg); return RV_OK; }
 int rv_set_motor_targets(rv_world* w, const float* d_q, const uint8_t* d_mask) {
   WCHK(w); NEED(d_q, "rv_set_motor_targets");

@@ -48,8 +48,16 @@ class VecGrasp4DofEnv(object):
     def get_observation(self):
         """CameraObs(OBSERVATION.TYPE = 'depth') + the camera calibration (grasp_4dof_env.py:97-115)."""
         depth, _ = self.world.render()
-        return {'depth': depth, 'intrinsics': self.camera.intrinsics.astype(np.float32),
-                'translation': self.camera.translation.astype(np.float32), 'rotation': self.camera.rotation.astype(np.float32)}
+        k, t, r = self.camera_calibration()
+        return {'depth': depth, 'intrinsics': k, 'translation': t, 'rotation': r}
+
+    def camera_calibration(self):
+        """(intrinsics [N, 3, 3], translation [N, 3], rotation [N, 3, 3]) each env is rendered with: the configured
+        calibration plus the noise of its last reset (ArmEnv._reset_camera, arm_env.py:109-152; rv_get_camera)."""
+        cam = self.world.camera().cpu().numpy()
+        k = np.zeros((self.num_envs, 3, 3), np.float32)
+        k[:, 0, 0], k[:, 1, 1], k[:, 0, 2], k[:, 1, 2], k[:, 0, 1], k[:, 2, 2] = cam[:, 0], cam[:, 1], cam[:, 2], cam[:, 3], cam[:, 4], 1.0
+        return k, cam[:, 14:17].copy(), cam[:, 5:14].reshape(-1, 3, 3).copy()
 
     def reset(self, mask=None):
         self.world.reset(mask)
@@ -113,7 +121,7 @@ class Grasp4DofEnv(object):
         out = collections.OrderedDict()
         out[self._config.OBSERVATION.TYPE] = obs['depth'][0].cpu().numpy()
         for key in ('intrinsics', 'translation', 'rotation'):
-            out[key] = obs[key]
+            out[key] = obs[key][0]
         return out
 
     def reset(self):

@@ -70,6 +70,15 @@ class VecPushEnv(object):
     def get_observation(self):
         return self.world.observe(point_cloud=self.use_point_cloud)
 
+    def camera_calibration(self):
+        """(intrinsics [N, 3, 3], translation [N, 3], rotation [N, 3, 3]) of the simulated Kinect2 of every env: the
+        configured calibration plus the uniform noise ArmEnv._reset_camera draws at each reset (arm_env.py:109-152;
+        KINECT2.DEPTH.INTRINSICS_NOISE / TRANSLATION_NOISE / ROTATION_NOISE, push_env.py:273-280)."""
+        cam = self.world.camera().cpu().numpy()
+        k = np.zeros((self.num_envs, 3, 3), np.float32)
+        k[:, 0, 0], k[:, 1, 1], k[:, 0, 2], k[:, 1, 2], k[:, 0, 1], k[:, 2, 2] = cam[:, 0], cam[:, 1], cam[:, 2], cam[:, 3], cam[:, 4], 1.0
+        return k, cam[:, 14:17].copy(), cam[:, 5:14].reshape(-1, 3, 3).copy()
+
     def reset(self, mask=None):
         """RobotEnv.reset for every env (or the masked ones)."""
         self.world.reset(mask)
@@ -96,9 +105,14 @@ class VecPushEnv(object):
         return a.reshape((self.num_envs,) + self.action_shape)
 
     def rollout(self, n_steps, auto_reset=True, record=True):
+        before = self.world.env_counters().cpu().numpy()[:, [2, 4]] if (auto_reset and self._physics is not None) else None
         out = self.world.rollout(n_steps, self._macro_index, auto_reset, record)
-        if auto_reset and self._physics is not None:
-            self._physics.on_env_reset()
+        if before is not None:
+            # the host mirror of the user constraints is dropped only when an env really was reset: its episode was over
+            # when the rollout began, or one ended inside it (num_episodes moved) and the next step reset the env
+            after = self.world.env_counters().cpu().numpy()[:, [2, 4]]
+            if (before[:, 1] != 0).any() or (after[:, 0] != before[:, 0]).any():
+                self._physics.on_env_reset()
         self._macro_index += int(n_steps)
         return out
 

@@ -31,7 +31,7 @@ SYMBOLS = [
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
     'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll', 'rv_set_constraint', 'rv_render_rgb', 'rv_set_friction', 'rv_set_auto_reset',
-    'rv_set_constraint_ex', 'rv_set_link_path', 'rv_get_robot_ready',
+    'rv_set_constraint_ex', 'rv_set_link_path', 'rv_get_robot_ready', 'rv_get_camera',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -63,10 +63,8 @@ def built_source_hash():
 def build(force=False, verbose=False):
     """Compile csrc/rv_kernels.hip for gfx950 into librovat_hip.so (in-tree).
     The sha256 of the sources is baked into the binary (rv_source_hash)."""
-    srcs = [os.path.join(CSRC, 'rv_kernels.hip'), os.path.join(CSRC, 'rv_kernels_occ2.hip')]
-    deps = SOURCES
     if (not force and os.path.exists(LIB_PATH) and
-            all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps)):
+            all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in SOURCES)):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     compile_lib(LIB_PATH, hipcc=hipcc, verbose=verbose)
@@ -75,25 +73,38 @@ def build(force=False, verbose=False):
 
 def compile_lib(out, extra=(), hipcc='/opt/rocm/bin/hipcc', verbose=False):
     """The two translation units (rv_kernels.hip: C ABI + the register-rich env kernel; rv_kernels_occ2.hip: the
-    env kernel for two waves per SIMD) compiled side by side, then linked into one shared object."""
+    env kernel for two waves per SIMD) compiled side by side, then linked into one shared object.  Objects and the
+    linked library are made in a private temporary directory next to `out` and the library is moved into place with
+    one rename: concurrent builds (the multi-rank tests) never see each other's half-written files, and a failed
+    translation unit leaves neither a running compiler nor objects behind."""
+    import shutil
+    import tempfile
     srcs = [os.path.join(CSRC, 'rv_kernels.hip'), os.path.join(CSRC, 'rv_kernels_occ2.hip')]
     flags = [f for f in HIPCC_FLAGS if f != '-shared'] + ['-DRV_SOURCE_HASH="%s"' % source_hash()] + list(extra)
-    objs, procs = [], []
-    for src in srcs:
-        obj = os.path.join(os.path.dirname(out), '.' + os.path.basename(out) + '.' + os.path.basename(src) + '.o')
-        cmd = [hipcc] + flags + ['-c', src, '-o', obj]
+    tmp = tempfile.mkdtemp(prefix='.build_', dir=os.path.dirname(os.path.abspath(out)))
+    procs = []
+    try:
+        objs = []
+        for src in srcs:
+            obj = os.path.join(tmp, os.path.basename(src) + '.o')
+            cmd = [hipcc] + flags + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            procs.append(subprocess.Popen(cmd)); objs.append(obj)
+        codes = [p.wait() for p in procs]          # (every compiler is waited for before an error is raised)
+        if any(codes):
+            raise subprocess.CalledProcessError(next(c for c in codes if c), 'hipcc')
+        linked = os.path.join(tmp, os.path.basename(out))
+        cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared'] + objs + ['-o', linked]
         if verbose:
             print(' '.join(cmd))
-        procs.append(subprocess.Popen(cmd)); objs.append(obj)
-    for p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, 'hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared'] + objs + ['-o', out]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.run(cmd, check=True)
-    for o in objs:
-        os.remove(o)
+        subprocess.run(cmd, check=True)
+        os.replace(linked, out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill(); p.wait()
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def load():
@@ -151,6 +162,7 @@ def load():
     lib.rv_set_link_target.argtypes = [vp, vp, f32, f32]
     lib.rv_set_link_path.argtypes = [vp, vp, i32, f32, f32]
     lib.rv_get_robot_ready.argtypes = [vp, vp]
+    lib.rv_get_camera.argtypes = [vp, vp]
     for name in ('rv_set_actions', 'rv_get_body_state', 'rv_set_body_state',
                  'rv_get_body_params', 'rv_set_body_params', 'rv_get_joint_state',
                  'rv_set_joint_state', 'rv_get_link_poses', 'rv_get_env_counters',
@@ -468,6 +480,11 @@ class World(object):
         q = self._new((self.n, abi.RV_NLIMB), self.torch.float32)
         check(self.lib.rv_compute_ik(self.h, self._ptr(p), self._ptr(q)))
         return q
+
+    def camera(self):
+        """[N, 17] float32: fx, fy, cx, cy, skew, rotation (row-major), translation -- the calibration each env is observed
+        with (rv_config's plus the noise of its last reset, KINECT2.DEPTH.*_NOISE)."""
+        return self._get('rv_get_camera', (self.n, 17), self.torch.float32)
 
     def query_contacts(self):
         return self._get('rv_query_contacts', (self.n, 2 + abi.RV_MAXB), self.torch.uint8)

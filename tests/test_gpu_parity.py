@@ -319,3 +319,27 @@ def test_concentric_overlaps_run_epa_from_a_grown_simplex():
     assert same.sum() >= 8 and deep == same.sum(), (deep, same.sum())
     ref.step_sub(60); world.step_sub(60)
     _cmp(world, ref, 0.0)
+
+
+def test_solver_exits_stay_close_to_plain_sweeps_at_1024_envs():
+    """The GPU leg of tests/test_solver_exits.py at BASELINE configs[1]'s size (round-4 review, weak item 9): the shipped
+    exits (residual 1e-5 N s, stall 12, <= 50 sweeps) against Bullet's 50 plain sweeps on the MI355X, one env.step() per
+    env from the same reset states and actions.  Contact-rich pushes diverge chaotically, so the statement is
+    distributional: median / 75th percentile over envs of the worst body, outcome counts within 1.5 % of the env steps."""
+    n = 1024
+    a, _, _ = _worlds(n, seed=7)
+    b, _, _ = _worlds(n, seed=7, **{'PHYSICS.SOLVER_STALL': 0, 'PHYSICS.SOLVER_TOL': 0.0})
+    a.reset(); b.reset()
+    p0 = a.body_state().cpu().numpy()
+    assert np.median(np.abs(p0[..., :3] - b.body_state().cpu().numpy()[..., :3]).max((-1, -2))) < 5e-5     # the same episodes
+    b.set_body_params(a.body_params()); b.set_body_state(a.body_state()); a.set_body_state(a.body_state())
+    act = a.policy_random(0)
+    a.set_actions(act); b.set_actions(act); a.step_macro(); b.step_macro()
+    sa, sb = a.body_state().cpu().numpy(), b.body_state().cpu().numpy()
+    dev = np.linalg.norm(sa[..., :3] - sb[..., :3], axis=-1).max(-1)
+    moved = np.linalg.norm(sa[..., :2] - p0[..., :2], axis=-1).max(-1)
+    assert (moved > 1e-3).mean() > 0.15
+    assert np.median(dev) < 1.5e-4 and np.percentile(dev, 75) < 1e-3, (np.median(dev), np.percentile(dev, 75))
+    ta, tb = a.stats(), b.stats()
+    for k in ('useful', 'unsafe', 'ineffective'):
+        assert abs(ta[k] - tb[k]) <= 16, (k, ta[k], tb[k])
