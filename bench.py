@@ -38,31 +38,8 @@ VALU_PEAK_PER_SIMD_CYCLE = 0.5      # MI355X_MICROARCH.md: a wave64 VALU instruc
 
 
 def effective_cpus():
-    """Host threads this process may actually keep busy: the smallest of the CPU count, the affinity mask and the
-    cgroup CPU quota (a GPU box handed out as a slice of a node reports all 256 hardware threads in os.cpu_count() but
-    throttles the container to its quota -- 16 CPUs on this pool: 256 busy OpenMP threads then run 40 x slower per thread
-    than 16 do)."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except (AttributeError, OSError):
-        pass
-    try:
-        with open('/sys/fs/cgroup/cpu.max') as f:
-            quota, period = f.read().split()[:2]
-        if quota != 'max':
-            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
-    except (OSError, ValueError):
-        try:
-            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
-                q = int(f.read())
-            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
-                per = int(f.read())
-            if q > 0:
-                n = min(n, max(1, int(q / per + 0.5)))
-        except (OSError, ValueError):
-            pass
-    return n
+    from oracle import orc
+    return orc.effective_cpus()
 
 
 def cpu_legs(cfg_kwargs, scene, names, quick=False):
@@ -88,7 +65,7 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
     n = max(16, per_thread * cores)
     min_seconds, max_steps = (3.0, 2) if quick else (10.0, 4)
 
-    def timed(over, n_envs, threads):
+    def timed(over, n_envs, threads, max_steps=max_steps):
         """`over` on n_envs envs with `threads` OpenMP threads: reset (untimed), then env.step() calls per env
         until min_seconds or max_steps: one step first (its duration sizes the rest), the others in one call."""
         env_cfg = configs.push_env_config(**over)
@@ -123,16 +100,16 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
                 'mean_sweeps_per_island_solve': (c1['sweeps'] - c0['sweeps']) / isl,
                 'mean_rows_per_island': (c1['row_steps'] - c0['row_steps']) / max(c1['sweeps'] - c0['sweeps'], 1)}
 
-    def leg(over):
+    def leg(over, max_steps=max_steps):
         """all host threads, and the same leg on ONE thread (16 envs) for the per-thread cost and the scaling"""
-        full = timed(over, n, cores)
-        one = timed(over, 16 if not quick else 4, 1)
+        full = timed(over, n, cores, max_steps)
+        one = timed(over, 16 if not quick else 4, 1, max_steps)
         full['one_thread'] = {k: one[k] for k in ('sim_steps_per_s', 'value', 'thread_us_per_substep', 'thread_us_per_awake_substep', 'envs', 'steps', 'seconds')}
         full['scaling_1_to_n'] = full['sim_steps_per_s'] / max(one['sim_steps_per_s'], 1e-9)
         return full
 
     # (i) same workload and semantics as the GPU headline
-    cb = leg({})
+    cb = leg({}, max_steps=4 if quick else 48)      # (with deactivation an env.step() costs the host ~3 ms: more steps fill the window)
     out['cpu_baseline'] = {
         'value': cb['value'], 'unit': 'env_steps/s', 'cores': cores, 'kind': 'port',
         'sim_steps_per_s': cb['sim_steps_per_s'], 'awake_sim_steps_per_s': cb['awake_sim_steps_per_s'],

@@ -16,6 +16,34 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
 
+def effective_cpus():
+    """Host threads this process may actually keep busy: the smallest of the CPU count, the affinity mask and the
+    cgroup CPU quota (a GPU box handed out as a slice of a node reports all 256 hardware threads in os.cpu_count() but
+    throttles the container to its quota -- 16 CPUs on this pool: 256 busy OpenMP threads then run 40 x slower per thread
+    than 16 do)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+                q = int(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def build(force=False):
     """Compile liborc_f32.so / liborc_f64.so with the Makefile next to this file."""
     targets = [os.path.join(_HERE, n) for n in ('liborc_f32.so', 'liborc_f64.so')]
@@ -54,6 +82,9 @@ def _lib(double):
         lib.orc_eval_gjk.restype = C.c_int
         lib.orc_get_manifold.restype = C.c_int
         lib.orc_eval_wait_until_stable.restype = C.c_int
+        # OpenMP would start one thread per hardware thread of the NODE; a container that is a slice of it (cgroup quota)
+        # is throttled into the ground by that: as many threads as the process may keep busy
+        lib.orc_set_num_threads(C.c_int(effective_cpus()))
         _LIBS[key] = lib
     return _LIBS[key]
 

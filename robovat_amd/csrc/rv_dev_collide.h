@@ -61,7 +61,7 @@ struct DevMan {
 // first-maximum loop returns (a clamped duplicate can never beat its original).
 // Every lane of the group ends up with the same result.
 // Host emulation: the serial loop.
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
 template <int N> RV_DEV float row_ror_f(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
 }

@@ -8,8 +8,9 @@
 // the 64 lanes works on its own item (a body, a manifold, a contact point, a
 // hull vertex ...) and only reads data produced by earlier phases; phases are
 // separated by a workgroup barrier (a workgroup is exactly one wave, so the
-// barrier is an LDS wait).  With -DRV_EMULATE the same source compiles as
-// host C++ where a phase is a loop over 64 lanes (tests/emu, debugging aid).
+// barrier is an LDS wait).  With RV_ON_DEVICE == 0 (rv_dev_math.h: -DRV_EMULATE or a plain C++ compiler) the same source
+// compiles as host C++ where a phase is a loop over 64 lanes (tests/emu, a debugging aid); the host bodies of the larger
+// hooks are in tests/emu/rv_emu_hooks.h, included at the `#define RV_EMU_SECTION n` points and never seen by hipcc.
 //
 // Reference behaviour restated here (file:line in StanfordVL/robovat):
 //   Simulator.step                      robovat/simulation/simulator.py:94-103
@@ -27,7 +28,7 @@
 
 namespace rv {
 
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
 #define RV_LANES_BEGIN { const int lane = (int)threadIdx.x;
 #define RV_LANES_END } __syncthreads();
 // a value every lane holds alike (read from the env's LDS block), moved to the scalar unit so that the control flow
@@ -179,7 +180,7 @@ struct Scratch {
   // scratch for the velocity update)
   struct {
     struct {
-#if !defined(__HIPCC__) || defined(RV_EMULATE)
+#if !RV_ON_DEVICE
       Row rows[RV_NMAN][4];      // host emulation only: on the device every solver sets its rows up in registers
 #endif
       float wv[RV_MAXB][RV_MAXH][RV_MAXV][3];
@@ -244,7 +245,7 @@ struct Scratch {
   int cn[RV_MAXB][RV_NCOL];
   int ow_run[RV_NMAN + RV_NCOL], olist[RV_NMAN + RV_NCOL], n_olist;
   int wvneed[RV_MAXB];                   // body has hulls in a convex query of this substep
-#if !defined(__HIPCC__) || defined(RV_EMULATE)
+#if !RV_ON_DEVICE
   int rowmap[120], n_rows;   // host emulation of the impulse-space solver: rows in visiting order
 #endif
   Rng rng;
@@ -535,7 +536,7 @@ RV_DEV void control_update_b(Shared& S, const Consts& K) {
   S.s.jt_applied = 0;
   control_update_tail(S, K, 1);
 }
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
 RV_DEV float ik_rdlane(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 // arm_ik() by the whole wave, same arithmetic in the same order (bit-identical result):
 // lane j < 7 owns joint j (its angle, its local quaternion, its Jacobian column); every lane runs
@@ -647,7 +648,7 @@ RV_DEV void control_update_phases(Shared& S, const Consts& K) {
     if (lane == 0) control_update_a(S, K);
   RV_LANES_END
   if (S.s.ik_need) {
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
     arm_ik_wave(S, K);
 #else
     {
@@ -1058,7 +1059,7 @@ RV_DEV float tol_of(const rv_config* c, const int unrest_members) {
 // The Row of manifold point (mi, i) for the one-lane system solver of the host emulation: the record the
 // row-setup phase left in LDS.  (Device: no Row records exist -- they were 13 KB of the env's LDS block; see
 // SerialRows.)
-#if !defined(__HIPCC__) || defined(RV_EMULATE)
+#if !RV_ON_DEVICE
 RV_DEV Row fetch_row(const Shared& S, const Consts& K, int mi, int i) { (void)K; return S.s.u.r.rows[mi][i]; }
 #endif
 
@@ -1375,7 +1376,7 @@ RV_DEV int con_pair_member(const DevEnv& e, int b) {
   for (int x = 0; x < RV_MAXB; ++x) if (RV_CON_TYPE(e.con_on[x]) != 0 && RV_CON_CHILD(e.con_on[x]) == b) m = 1;
   return m;
 }
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
 // Device: the one-lane system solver is run by EVERY lane of the wave (the same scalar program on the same LDS
 // data: the lanes agree on every value they store), so that the row sets it visits can live in registers: lane
 // 4 mi + i holds the Row of point i of manifold mi -- and, in limb mode, the limb rows of an arm point -- set up
@@ -1457,7 +1458,7 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb RV_SER
         for (int i = 0; i < m.n; ++i) {
           const int la = limb && kind == 1;
           float pja[3][RV_NLIMB], pmi[3][RV_NLIMB], plk[3];
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
           const int src = __builtin_amdgcn_readfirstlane(mi * 4 + i);
           Row r = serial_pull_row(SR, src);
           if (la) serial_pull_limb(SR, src, pja, pmi, plk);
@@ -1488,7 +1489,7 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb RV_SER
         BV A = ld_bv(e, a_), B = ld_bv(e, b_);
         const float ima = e.inv_mass[a_], imb = e.inv_mass[b_];
         for (int i = 0; i < m.n; ++i) {
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
           Row r = serial_pull_row(SR, __builtin_amdgcn_readfirstlane(RV_BBIDX(k) * 4 + i));
 #else
           Row r = fetch_row(S, K, RV_BBIDX(k), i);
@@ -1562,42 +1563,14 @@ RV_DEV void solve_with_fingers(Shared& S, const Consts& K, const int limb RV_SER
 #define RV_ROW_A(x)   (((x) >> 16) & 15)
 #define RV_ROW_B(x)   ((((x) >> 20) & 15) - 1)
 #define RV_ROW_ISL(x) (((x) >> 24) & 15)
-#if !defined(__HIPCC__) || defined(RV_EMULATE)
-// the row list of the islands of one or two bodies (host emulation)
-RV_DEV int solver_row_list(Shared& S, const int* label, const int* on_, const int* act_, const int* big_) {
-  DevEnv& e = S.e;
-  int n = 0;
-  // a body's own rows: bodies ascending; the two members X < Y of a two-body island are visited
-  // together, slot by slot (X's row of slot t, then Y's; slot = 3 * (4 * [arm] + point) + row)
-  for (int b = 0; b < RV_MAXB; ++b) {
-    if (!on_[b] || big_[label[b]]) continue;
-    int partner = -1;
-    for (int x = 0; x < RV_MAXB; ++x) if (x != b && on_[x] && label[x] == label[b]) partner = x;
-    if (partner >= 0 && partner < b) continue;
-    for (int t = 0; t < 24; ++t)
-      for (int side = 0; side < 2; ++side) {
-        const int body = side == 0 ? b : partner;
-        if (body < 0) continue;
-        const int p = t / 3, k = t % 3, mi = p < 4 ? RV_TIDX(body) : RV_AIDX(body), i = p & 3;
-        if (i >= e.man[mi].n) continue;
-        if (n + 1 > RV_SOLVE_ROWS) return -1;
-        S.s.rowmap[n++] = RV_ROW_PACK(mi, i, k, body, -1, label[body]);
-      }
-  }
-  for (int rd = 0; rd < 3; ++rd)
-    for (int x = 0; x < 2; ++x) {
-      const int kp = bb_round_pair(rd, x);
-      if (!act_[kp] || big_[label[bb_a(kp)]]) continue;
-      const int np_ = e.man[RV_BBIDX(kp)].n;
-      if (n + 3 * np_ > RV_SOLVE_ROWS) return -1;
-      for (int i = 0; i < np_; ++i) for (int k = 0; k < 3; ++k) S.s.rowmap[n++] = RV_ROW_PACK(RV_BBIDX(kp), i, k, bb_a(kp), bb_b(kp), label[bb_a(kp)]);
-    }
-  return n;
-}
+#if !RV_ON_DEVICE
+#define RV_EMU_SECTION 1
+#include "../../tests/emu/rv_emu_hooks.h"      // host lane emulation (test scaffolding; not compiled into the product)
+#undef RV_EMU_SECTION
 #endif
 struct J6 { v3 l, a; };
 RV_DEV float dotj(const J6& j, v3 pl, v3 pa) { return dot(j.l, pl) + dot(j.a, pa); }
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
 RV_DEV float rdlane(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 RV_DEV v3 rdlane3(v3 x, int l) { return mk(rdlane(x.x, l), rdlane(x.y, l), rdlane(x.z, l)); }
 // One island of TWO bodies X < Y, with a STATIC lane layout so that every index below is a compile-time
@@ -2244,228 +2217,9 @@ RV_DEV void solve_island_fingers(Shared& S, const Consts& K, const int X, const 
   else solve_island_fingers_t<false>(S, K, X, with_fingers);
 }
 #else
-// fing != 0 (rv_config.finger_dynamics, at most one awake body): the two finger joints are DOFs of
-// the system as well -- contact rows on a finger pad carry jf on their finger's velocity, each finger
-// has a motor row after the contact rows (see solve_island_fingers, the device version)
-RV_DEV void solve_rows(Shared& S, const Consts& K, const int n_rows, const int fing, const int limb, const int motor_isl, const float* isl_tol) {
-  DevEnv& e = S.e; const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
-  static thread_local float A[RV_SOLVE_ROWS + 9][RV_SOLVE_ROWS + 9];
-  float g[RV_SOLVE_ROWS + 9], lam[RV_SOLVE_ROWS + 9], invk[RV_SOLVE_ROWS + 9], bias[RV_SOLVE_ROWS + 9], mu[RV_SOLVE_ROWS + 9], cap[RV_SOLVE_ROWS + 9];
-  float jf[RV_SOLVE_ROWS + 9], pf[RV_SOLVE_ROWS + 9], mlo[2] = {0.0f, 0.0f}, mhi[2] = {0.0f, 0.0f}; int fi[RV_SOLVE_ROWS + 9];
-  const float mf = c->finger_mass, imf = fing ? 1.0f / c->finger_mass : 0.0f, fdt = c->finger_max_force * c->dt;
-  const float qf0[2] = {e.qd[RV_NLIMB], e.qd[RV_NLIMB + 1]};
-  // limb != 0 (rv_config.limb_dynamics, at most one awake body): the seven limb joints are DOFs as well.
-  // Rows of the arm manifold and the seven limb motor rows (after the finger motor rows) are 'limb rows':
-  // row r has the joint-space Jacobian ja[r] (a motor row: e_j) and the velocity change per unit impulse
-  // pj[r] = M^-1 ja^T (a motor row: column j of M^-1); A_rs gains ja[r] . pj[s]
-  const int nfm = fing ? 2 : 0, nlm = limb ? RV_NLIMB : 0;
-  const int n_all = n_rows + nfm + nlm;
-  int la[RV_SOLVE_ROWS + 9]; float ja[RV_SOLVE_ROWS + 9][RV_NLIMB], pj[RV_SOLVE_ROWS + 9][RV_NLIMB], dq0[RV_NLIMB];
-  for (int x = 0; x < RV_NLIMB; ++x) dq0[x] = limb ? -S.s.limb_dv[x] : 0.0f;     // the solve starts from the velocity before the motor step
-  int fisl = 0;
-  J6 jx[RV_SOLVE_ROWS][RV_MAXB];
-  for (int r = 0; r < n_rows; ++r) {
-    const int rm = S.s.rowmap[r];
-    const int mi = RV_ROW_MI(rm), pi = RV_ROW_I(rm), k = RV_ROW_K(rm), ra = RV_ROW_A(rm), rb = RV_ROW_B(rm);
-    const Row& R = S.s.u.r.rows[mi][pi];
-    const DevMan& mm = e.man[mi];
-    for (int x = 0; x < RV_MAXB; ++x) { jx[r][x].l = mk(0, 0, 0); jx[r][x].a = mk(0, 0, 0); }
-    const v3 dir = ld3(R.dir[k]), rxa = ld3(R.rxa[k]);
-    invk[r] = R.invk[k]; mu[r] = R.mu; bias[r] = k == 0 ? R.target : 0.0f; cap[r] = R.cap;
-    lam[r] = k == 0 ? mm.ln[pi] : (k == 1 ? mm.lt1[pi] : mm.lt2[pi]);
-    float gg = dot(dir, ld3(e.body[ra] + 7)) + dot(rxa, ld3(e.body[ra] + 10));
-    v3 nd = mk(0, 0, 0), nrxb = mk(0, 0, 0);
-    if (rb >= 0) {
-      const v3 rxb = ld3(R.rxb[k]);
-      gg -= dot(dir, ld3(e.body[rb] + 7)) + dot(rxb, ld3(e.body[rb] + 10));
-      nd = mk(-dir.x, -dir.y, -dir.z); nrxb = mk(-rxb.x, -rxb.y, -rxb.z);
-    } else gg -= R.vbc[k];
-    jf[r] = 0.0f; pf[r] = 0.0f; fi[r] = -1;
-    if (fing) {
-      fi[r] = R.fidx; fisl = RV_ROW_ISL(rm);
-      if (fi[r] >= 0) { jf[r] = R.jf[k]; pf[r] = jf[r] * imf; gg += jf[r] * qf0[fi[r]]; }
-    }
-    la[r] = 0;
-    if (limb) {
-      fisl = RV_ROW_ISL(rm);
-      if (mi >= RV_AIDX(0)) {
-        const int lrow = pi * 3 + k;
-        la[r] = 1; invk[r] = S.s.linvk[lrow];
-        float t = 0.0f;
-        for (int x = 0; x < RV_NLIMB; ++x) { ja[r][x] = S.s.lJa[lrow][x]; pj[r][x] = S.s.lMiJ[lrow][x]; t = t + ja[r][x] * dq0[x]; }
-        gg += t;
-      }
-    }
-    g[r] = gg;
-    jx[r][ra].l = dir; jx[r][ra].a = rxa;
-    if (rb >= 0) { jx[r][rb].l = nd; jx[r][rb].a = nrxb; }
-  }
-  if (motor_isl >= 0) fisl = motor_isl;
-  for (int m = 0; fing && m < 2; ++m) {       // motor rows
-    const int r = n_rows + m;
-    const float i0 = mf * S.s.fing_dv[m];
-    g[r] = qf0[m] - S.s.fing_vt[m]; lam[r] = 0.0f; invk[r] = mf; bias[r] = 0.0f; mu[r] = 0.0f; cap[r] = 0.0f;
-    jf[r] = 1.0f; pf[r] = imf; fi[r] = m;
-    mlo[m] = -fdt - i0; mhi[m] = fdt - i0;
-    la[r] = 0;
-  }
-  for (int j = 0; j < nlm; ++j) {             // limb motor rows
-    const int r = n_rows + nfm + j, lrow = 12 + j;
-    g[r] = dq0[j] - S.s.ltgt[j]; lam[r] = 0.0f; invk[r] = 1.0f / S.s.lA[j][RV_NLIMB + j]; bias[r] = 0.0f; mu[r] = 0.0f; cap[r] = 0.0f;
-    jf[r] = 0.0f; pf[r] = 0.0f; fi[r] = -1; la[r] = 1;
-    for (int x = 0; x < RV_NLIMB; ++x) { ja[r][x] = S.s.lJa[lrow][x]; pj[r][x] = S.s.lMiJ[lrow][x]; }
-  }
-  for (int r = 0; r < n_rows; ++r)
-    for (int s = 0; s < n_rows; ++s) {
-      const int q = S.s.rowmap[s];
-      const Row& Q = S.s.u.r.rows[RV_ROW_MI(q)][RV_ROW_I(q)];
-      const int ks = RV_ROW_K(q), as = RV_ROW_A(q), bs = RV_ROW_B(q);
-      const v3 ds = ld3(Q.dir[ks]);
-      float a_ = dotj(jx[r][as], scale(ds, e.inv_mass[as]), ld3(Q.aa[ks]));
-      if (bs >= 0) {
-        const v3 t = scale(ds, e.inv_mass[bs]), ab = ld3(Q.ab[ks]);
-        a_ = a_ + dotj(jx[r][bs], mk(-t.x, -t.y, -t.z), mk(-ab.x, -ab.y, -ab.z));
-      }
-      if (fing && fi[r] >= 0 && fi[r] == fi[s]) a_ = a_ + jf[r] * pf[s];
-      A[r][s] = a_;
-    }
-  for (int m = 0; fing && m < 2; ++m) {
-    const int q = n_rows + m;
-    for (int r = 0; r < n_rows; ++r) { A[r][q] = fi[r] == m ? jf[r] * pf[q] : 0.0f; A[q][r] = fi[r] == m ? pf[r] : 0.0f; }
-    for (int m2 = 0; m2 < 2; ++m2) A[q][n_rows + m2] = m == m2 ? pf[q] : 0.0f;
-  }
-  for (int j = 0; j < nlm; ++j) {
-    const int q = n_rows + nfm + j;
-    for (int r = 0; r < n_all; ++r) { A[r][q] = 0.0f; A[q][r] = 0.0f; }
-  }
-  for (int r = 0; limb && r < n_all; ++r)
-    for (int s = 0; s < n_all; ++s) {
-      if (!(la[r] && la[s])) continue;
-      float t = 0.0f;
-      for (int x = 0; x < RV_NLIMB; ++x) t = t + ja[r][x] * pj[s][x];
-      A[r][s] = A[r][s] + t;
-    }
-  for (int s = 0; s < n_rows; ++s) for (int r = 0; r < n_all; ++r) g[r] = g[r] + A[r][s] * lam[s];
-  // normalised residual form of the row step (see solve_singles / oracle solve_rows): rr = (bias - g) invk, C = -(A invk)
-  float rr[RV_SOLVE_ROWS + 9];
-  for (int r = 0; r < n_all; ++r) {
-    rr[r] = (bias[r] - g[r]) * invk[r];
-    for (int s = 0; s < n_all; ++s) A[r][s] = -(A[r][s] * invk[r]);
-  }
-  int isl_rows = 0, done = 0;
-  float best[RV_MAXB] = {1e30f, 1e30f, 1e30f, 1e30f}; int since[RV_MAXB] = {0, 0, 0, 0};
-  for (int s = 0; s < n_rows; ++s) isl_rows |= 1 << RV_ROW_ISL(S.s.rowmap[s]);
-  if (fing || limb) isl_rows |= 1 << fisl;
-  RV_CNT(21, 1) RV_CNT(23, n_rows)
-  for (int it = 0; it < c->solver_iters; ++it) {
-    RV_CNT(22, 1)
-    float res[RV_MAXB] = {0.0f, 0.0f, 0.0f, 0.0f};
-    float limtab[RV_NMAN][4];    // friction bound of every point: mu x its normal impulse (the rows of a point need not be neighbours in the list)
-    for (int s = 0; s < n_rows; ++s) {
-      const int q = S.s.rowmap[s];
-      const int isl = RV_ROW_ISL(q);
-      if ((done >> isl) & 1) continue;
-      float nl;
-      const float lim = RV_ROW_K(q) == 0 ? 0.0f : limtab[RV_ROW_MI(q)][RV_ROW_I(q)];
-      if (RV_ROW_K(q) == 0) nl = fclampr(lam[s] + rr[s], 0.0f, cap[s]);
-      else nl = fclampr(lam[s] + rr[s], -lim, lim);
-      const float d = nl - lam[s];
-      lam[s] = nl;
-      if (RV_ROW_K(q) == 0) limtab[RV_ROW_MI(q)][RV_ROW_I(q)] = mu[s] * nl;
-      res[isl] = fmaxr(res[isl], fabsr(d));
-#ifdef RV_EMU_COUNT
-      if (it == c->solver_iters - 1 && fabsr(d) >= c->solver_tol) {
-        const int mi_ = RV_ROW_MI(q), cls = (mi_ < RV_MAXB ? 0 : (mi_ < RV_MAXB + RV_NBB ? 1 : 2)) * 2 + (RV_ROW_K(q) != 0);
-        rv_emu_dbg[cls] += 1; if (RV_ROW_K(q) == 0 && nl >= cap[s]) rv_emu_dbg[6] += 1; if (RV_ROW_K(q) != 0 && (nl >= lim || nl <= -lim)) rv_emu_dbg[7] += 1;
-      }
-#endif
-      for (int r = 0; r < n_all; ++r) rr[r] = rv_fma(A[r][s], d, rr[r]);
-    }
-    // (the motor rows belong to island fisl and stop with it -- other islands may still be sweeping)
-    const int motors_on = !((done >> fisl) & 1);
-    for (int m = 0; fing && motors_on && m < 2; ++m) {
-      const int q = n_rows + m;
-      const float nl = fclampr(lam[q] + rr[q], mlo[m], mhi[m]);
-      const float d = nl - lam[q];
-      lam[q] = nl;
-      res[fisl] = fmaxr(res[fisl], fabsr(d));
-      for (int r = 0; r < n_all; ++r) rr[r] = rv_fma(A[r][q], d, rr[r]);
-    }
-    for (int j = 0; motors_on && j < nlm; ++j) {
-      const int q = n_rows + nfm + j;
-      const float nl = fclampr(lam[q] + rr[q], S.s.llo[j], S.s.lhi[j]);
-      const float d = nl - lam[q];
-      lam[q] = nl;
-      res[fisl] = fmaxr(res[fisl], fabsr(d));
-      for (int r = 0; r < n_all; ++r) rr[r] = rv_fma(A[r][q], d, rr[r]);
-    }
-#ifdef RV_EMU_COUNT
-    for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && !((done >> x) & 1) && (res[x] < c->solver_tol || it == c->solver_iters - 1)) {
-      int nr = 0, arm_rows = 0;
-      for (int s = 0; s < n_rows; ++s) if (RV_ROW_ISL(S.s.rowmap[s]) == x) { ++nr; arm_rows += RV_ROW_MI(S.s.rowmap[s]) >= RV_MAXB + RV_NBB; }
-      const int cap = !(res[x] < c->solver_tol);
-      rv_emu_cnt[35] += 1; rv_emu_cnt[33] += (long)nr * (it + 1);
-      if (cap && arm_rows && e.phase >= 0 && e.phase < 8) rv_emu_cnt[38 + e.phase] += 1;
-      if (cap && arm_rows) { float nn = 0.0f; for (int s = 0; s < n_rows; ++s) if (RV_ROW_ISL(S.s.rowmap[s]) == x && RV_ROW_K(S.s.rowmap[s]) == 0 && RV_ROW_MI(S.s.rowmap[s]) >= RV_MAXB + RV_NBB) nn += lam[s];
-        if (nn / c->dt > 100.0f) rv_emu_cnt[46] += 1; if (nn / c->dt > 1000.0f) rv_emu_cnt[47] += 1; }
-      if (cap) { rv_emu_cnt[arm_rows ? 31 : 32] += 1; rv_emu_cnt[34] += (long)nr * (it + 1); if (res[x] > 10.0f * c->solver_tol) rv_emu_cnt[37] += 1; }
-      else rv_emu_cnt[36] += it + 1;
-    }
-#endif
-    for (int x = 0; x < RV_MAXB; ++x) if (((isl_rows >> x) & 1) && res[x] < (((fing || limb) && x == fisl) ? c->solver_tol : isl_tol[x])) done |= 1 << x;
-    // stalled islands (rv_config.solver_stall): no new smallest residual for that many sweeps
-    for (int x = 0; c->solver_stall > 0 && x < RV_MAXB; ++x) {
-      if (!((isl_rows >> x) & 1) || ((done >> x) & 1)) continue;
-      if (res[x] < best[x]) { best[x] = res[x]; since[x] = 0; }
-      else if (++since[x] >= c->solver_stall) { done |= 1 << x; RV_CNT(7, 1) }
-    }
-    if ((done & isl_rows) == isl_rows) break;
-    if (it == c->solver_iters - 1) { RV_CNT(30, 1) }
-  }
-  for (int s = 0; s < n_rows; ++s) {
-    const int q = S.s.rowmap[s];
-    DevMan& mm = e.man[RV_ROW_MI(q)];
-    const int pi = RV_ROW_I(q), ks = RV_ROW_K(q);
-    if (ks == 0) mm.ln[pi] = lam[s]; else if (ks == 1) mm.lt1[pi] = lam[s]; else mm.lt2[pi] = lam[s];
-  }
-  for (int X = 0; X < RV_MAXB; ++X) {
-    if (!body_on(e, X)) continue;
-    for (int cc = 0; cc < 6; ++cc) {
-      float acc = e.body[X][7 + cc];
-      for (int s = 0; s < n_rows; ++s) {
-        const int q = S.s.rowmap[s];
-        const int as = RV_ROW_A(q), bs = RV_ROW_B(q), ks = RV_ROW_K(q);
-        if (as != X && bs != X) continue;
-        const Row& Q = S.s.u.r.rows[RV_ROW_MI(q)][RV_ROW_I(q)];
-        float coef;
-        if (as == X) coef = cc < 3 ? Q.dir[ks][cc] * e.inv_mass[X] : Q.aa[ks][cc - 3];
-        else coef = cc < 3 ? -(Q.dir[ks][cc] * e.inv_mass[X]) : -Q.ab[ks][cc - 3];
-        acc = acc + coef * lam[s];
-      }
-      e.body[X][7 + cc] = acc;
-    }
-  }
-  for (int m = 0; fing && m < 2; ++m) {        // the fingers move with the solved velocity
-    float qd = qf0[m];
-    for (int s = 0; s < n_rows; ++s) if (fi[s] == m) qd = qd + pf[s] * lam[s];
-    qd = qd + pf[n_rows + m] * lam[n_rows + m];
-    const int j = RV_NLIMB + m;
-    float qn = e.q[j] + (qd - S.s.fing_qd0[m]) * c->dt;
-    if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
-    if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
-    e.q[j] = qn; e.qd[j] = qd;
-  }
-  for (int x = 0; x < nlm; ++x) {              // the limb moves with the solved velocity
-    float dq = dq0[x];
-    for (int s = 0; s < n_all; ++s) if (la[s]) dq = dq + pj[s][x] * lam[s];
-    float qd = S.s.limb_qd0[x] + dq;
-    float qn = e.q[x] + dq * c->dt;
-    if (qn < arm->q_lo[x]) { qn = arm->q_lo[x]; qd = 0.0f; }
-    if (qn > arm->q_hi[x]) { qn = arm->q_hi[x]; qd = 0.0f; }
-    e.q[x] = qn; e.qd[x] = qd;
-  }
-  if (limb) S.s.kin_fresh = 0;
-}
+#define RV_EMU_SECTION 2
+#include "../../tests/emu/rv_emu_hooks.h"      // host lane emulation (test scaffolding; not compiled into the product)
+#undef RV_EMU_SECTION
 #endif
 
 // ---------------------------------------------------- Simulator.step -----
@@ -2483,7 +2237,7 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
   control_update_phases(S, K);
   // joint motors of the kinematic arm, (a) per joint: the raw
   // commanded velocity and the factor that would bring it within its limit
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
   {
     // (a) + (b) in one phase: the common scale is a 16-lane DPP min over the limb lanes (the
     // factors are positive floats, ordered like their bit patterns)
@@ -2504,18 +2258,9 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
     if (lane < RV_NJ) { S.s.vdraw[lane] = vd0; S.s.ratio[lane] = __builtin_bit_cast(float, r); }
   }
 #else
-  RV_LANES_BEGIN
-    if (lane < RV_NJ) {
-      const DevEnv& e = S.e; int j = lane;
-      float vd = 0.0f, ratio = 1.0f;
-      if (e.motor_on[j]) {
-        vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) * (1.0f / c->dt);
-        float raw = fabsr(vd);
-        if (j < RV_NLIMB && raw > e.vmax_cmd[j]) ratio = e.vmax_cmd[j] / raw;
-      }
-      S.s.vdraw[j] = vd; S.s.ratio[j] = ratio;
-    }
-  RV_LANES_END
+#define RV_EMU_SECTION 3
+#include "../../tests/emu/rv_emu_hooks.h"      // host lane emulation (test scaffolding; not compiled into the product)
+#undef RV_EMU_SECTION
 #endif
   // (b) limb joints move synchronised: one common scale (the smallest factor)
   // keeps every commanded velocity within its limit, so the path is a straight
@@ -2524,7 +2269,7 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
     if (lane < RV_NJ) {
       DevEnv& e = S.e; int j = lane; float dt = c->dt;
       float sync = 1.0f;
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
       sync = S.s.ratio[j];      // (its own store: the common scale)
 #else
 #pragma unroll
@@ -2784,7 +2529,7 @@ RV_DEV int coast_budget(Shared& S, const Consts& K, const int remaining, int* ki
 // Device: lane j < 9 keeps joint j in registers; the common scale of the limb joints
 // is a 16-lane DPP min all-reduce (min is exact, so the order does not matter).
 // Host emulation: the same arithmetic, joint by joint.
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
 template <int N> RV_DEV float row_ror_min(float x) {
   float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
   return o < x ? o : x;
@@ -2830,40 +2575,9 @@ RV_DEV void motors_only_substeps(Shared& S, const Consts& K, const int r) {
   __syncthreads();
 }
 #else
-RV_DEV void motors_only_substeps(Shared& S, const Consts& K, const int r) {
-  const rv_config* c = K.cfg; const rv_arm* arm = K.arm;
-  DevEnv& e = S.e;
-  const float dt = c->dt;
-  for (int i = 0; i < r; ++i) {
-    float vdr[RV_NJ], sync = 1.0f;
-    for (int j = 0; j < RV_NJ; ++j) {
-      float vd = 0.0f, ratio = 1.0f;
-      if (e.motor_on[j]) {
-        vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) * (1.0f / dt);
-        float raw = fabsr(vd);
-        if (j < RV_NLIMB && raw > e.vmax_cmd[j]) ratio = e.vmax_cmd[j] / raw;
-      }
-      vdr[j] = vd;
-      sync = fminr(sync, ratio);
-    }
-    for (int j = 0; j < RV_NJ; ++j) {
-      float vdd = 0.0f;
-      if (e.motor_on[j]) {
-        vdd = vdr[j];
-        if (j < RV_NLIMB) vdd = vdd * sync;
-        vdd = fclampr(vdd, -e.vmax_cmd[j], e.vmax_cmd[j]);
-      }
-      float dv = fclampr(vdd - e.qd[j], -arm->a_max[j] * dt, arm->a_max[j] * dt);
-      float qd = e.qd[j] + dv;
-      float qn = e.q[j] + qd * dt;
-      if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
-      if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
-      e.q[j] = qn; e.qd[j] = qd;
-      S.s.jtravel[j] += fabsr(qd) * dt;
-    }
-    e.sim_steps++; e.substeps_last++;
-  }
-}
+#define RV_EMU_SECTION 4
+#include "../../tests/emu/rv_emu_hooks.h"      // host lane emulation (test scaffolding; not compiled into the product)
+#undef RV_EMU_SECTION
 #endif
 
 // m coasting substeps, then the kinematics of the final joint state
@@ -3012,7 +2726,7 @@ RV_DEV int ctl_gtick_noop(const CoastCtl& C, int st, int reached, int start_tick
   if (C.lt_on || (C.jt_on && C.jt_limb)) return 1;                // limb not ready
   return C.dt * (float)st < C.g_ready_time;                       // limb ready: the gripper is not
 }
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
 template <int N> RV_DEV float row_ror_add(float x) {
   float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
   return o + x;
@@ -3053,7 +2767,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
   for (;;) {
   const int st0 = S.e.sim_steps;
   int pending = 0;             // 0 update due, 1 clearance used up, 2 tick
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
   CoastCtl C = coast_ctl_load(S, K);
   C.lt_on = uni(C.lt_on); C.jt_on = uni(C.jt_on); C.applied = uni(C.applied); C.from_ik = uni(C.from_ik);
   C.lt_has_stop = uni(C.lt_has_stop); C.lt_more = uni(C.lt_more); C.jt_has_stop = uni(C.jt_has_stop); C.jt_limb = uni(C.jt_limb);
@@ -3279,77 +2993,9 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
   if (lane == 0) S.s.fused_pending = pending;
   __syncthreads();
 #else
-  {
-    DevEnv& e = S.e;
-    CoastCtl C = coast_ctl_load(S, K);
-    const float dt = c->dt;
-    float trav[RV_NJ];
-    for (int j = 0; j < RV_NJ; ++j) trav[j] = S.s.jtravel[j];
-    int st = st0;
-    for (;;) {
-      if (st != skip_st && ctl_update_due(C, st) && !ctl_update_noop(C, st, check_joints_reached(e))) {
-        RV_CNT(4, 1)
-        for (int col = 0; col < RV_NCOL; ++col) {
-          float Tc = 0.0f;
-          for (int j = 0; j < RV_NJ; ++j) Tc = Tc + S.s.crun[col][j] * (trav[j] + (fabsr(e.qd[j]) + arm->a_max[j] * dt) * dt);
-          const float D = Tc * 1.02f + 1e-4f;
-          if (!(S.s.clr_t[col] > D && S.s.clr_b[col] > 2.0f * D)) pending = 1;
-        }
-        break;
-      }
-      float vdr[RV_NJ], sync = 1.0f, qn_[RV_NJ], qdn_[RV_NJ], tn_[RV_NJ];
-      for (int j = 0; j < RV_NJ; ++j) {
-        float vd = 0.0f, ratio = 1.0f;
-        if (e.motor_on[j]) {
-          vd = e.motor_kp[j] * (e.motor_q[j] - e.q[j]) * (1.0f / dt);
-          float raw = fabsr(vd);
-          if (j < RV_NLIMB && raw > e.vmax_cmd[j]) ratio = e.vmax_cmd[j] / raw;
-        }
-        vdr[j] = vd;
-        sync = fminr(sync, ratio);
-      }
-      for (int j = 0; j < RV_NJ; ++j) {
-        float vdd = 0.0f;
-        if (e.motor_on[j]) {
-          vdd = vdr[j];
-          if (j < RV_NLIMB) vdd = vdd * sync;
-          vdd = fclampr(vdd, -e.vmax_cmd[j], e.vmax_cmd[j]);
-        }
-        float dv = fclampr(vdd - e.qd[j], -arm->a_max[j] * dt, arm->a_max[j] * dt);
-        float qd = e.qd[j] + dv;
-        float qn = e.q[j] + qd * dt;
-        if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
-        if (qn > arm->q_hi[j]) { qn = arm->q_hi[j]; qd = 0.0f; }
-        qn_[j] = qn; qdn_[j] = qd; tn_[j] = trav[j] + fabsr(qd) * dt;
-      }
-      int out_of_reach = 1;
-      for (int col = 0; col < RV_NCOL; ++col) {
-        float Tc = 0.0f;
-        for (int j = 0; j < RV_NJ; ++j) Tc = Tc + S.s.crun[col][j] * tn_[j];
-        const float D = Tc * 1.02f + 1e-4f;
-        if (!(S.s.clr_t[col] > D && S.s.clr_b[col] > 2.0f * D)) {
-          out_of_reach = 0;
-#ifdef RV_EMU_COUNT
-          rv_emu_dbg2[col * 2 + !(S.s.clr_t[col] > D)] += 1;
-          rv_emu_dbg2[20 + col] += (long)(1e6f * (!(S.s.clr_t[col] > D) ? S.s.clr_t[col] : 0.5f * S.s.clr_b[col]));
-          rv_emu_dbg2[30 + col] += st - st0;
-#endif
-        }
-      }
-      if (!out_of_reach) { RV_CNT(5, 1) pending = 1; break; }
-      for (int j = 0; j < RV_NJ; ++j) { e.q[j] = qn_[j]; e.qd[j] = qdn_[j]; trav[j] = tn_[j]; }
-      ++st;
-      if (steps_check > 0 && st % steps_check == 0 &&
-          !(C.grasp ? ctl_gtick_noop(C, st, check_joints_reached(e), st - st0) : ctl_tick_noop(C, st, check_joints_reached(e)))) { pending = 2; break; }
-      if (S.s.fused_n + (st - st0) >= max_n) { pending = 3; break; }
-    }
-    const int n = st - st0;
-    for (int j = 0; j < RV_NJ; ++j) S.s.jtravel[j] = trav[j];
-    if (C.grasp && C.g_phase == RV_GPHASE_START) e.num_action_steps += n - (pending == 2 ? 1 : 0);
-    e.sim_steps += n; e.substeps_last += n;
-    S.s.fused_n += n; S.s.fused_pending = pending;
-    RV_CNT(2, 1) RV_CNT(3, n) RV_CNT(6, pending == 2)
-  }
+#define RV_EMU_SECTION 5
+#include "../../tests/emu/rv_emu_hooks.h"      // host lane emulation (test scaffolding; not compiled into the product)
+#undef RV_EMU_SECTION
 #endif
   if (S.s.fused_pending != 0) break;
   // ControllableBody.update of this step for real, then on with its motors
@@ -3381,7 +3027,7 @@ RV_DEV int coast_run(Shared& S, const Consts& K, const int steps_check, const in
     n += coast_fused(S, K, steps_check, want - n, &why);
     RV_PROF(11)
     if (why != 1 || S.s.kin_fresh) break;
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
     if (S.s.bud_clk != 0 && __builtin_amdgcn_s_memtime() - S.s.bud_t0 > S.s.bud_clk) break;   // rv_step_poll: out of time
 #endif
     arm_refresh_kinematics(S, K);
@@ -3430,7 +3076,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
   // needs the frames (kin_fresh = 0).  Exact: every skipped test would have said "no".  (Without deactivation --
   // the reference's most likely semantics -- the arm is far in ~80 % of the substeps.)
   int far = 0;
-#if !defined(__HIPCC__) || defined(RV_EMULATE)
+#if !RV_ON_DEVICE
   static const int rv_no_far = getenv("RV_NO_FAR") != nullptr;     // (host emulation: debugging aid)
 #else
   const int rv_no_far = 0;
@@ -3477,7 +3123,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
             near = !(lo[2] - e.table_z - c->margin >= c->contact_query_dist);
           }
         }
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
         near_any = __builtin_amdgcn_ballot_w64(near != 0) != 0;
 #else
         near_any |= near;
@@ -3585,7 +3231,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
     RV_LANES_BEGIN
       const DevEnv& e = S.e;
       const int b = lane >> 4;
-#if !defined(__HIPCC__) || defined(RV_EMULATE)
+#if !RV_ON_DEVICE
       if ((lane & 15) != 0) continue;   // host emulation: one lane per group does the work
 #endif
       if (S.s.bnear[b] && !S.s.wake[b]) {
@@ -3643,13 +3289,13 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
 #pragma unroll
         for (int x = 0; x < RV_MAXB; ++x) if (x == lane) me = aw[x] && pr[x] && e.asleep[x];
       }
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
       wake_me = me;
 #else
       S.s.ready[lane] = me;      // (host emulation: lane-local values do not survive the phase)
 #endif
     }
-#if !defined(__HIPCC__) || defined(RV_EMULATE)
+#if !RV_ON_DEVICE
   RV_LANES_END
   RV_LANES_BEGIN
 #endif
@@ -3657,7 +3303,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
     if (lane == 6) { S.s.far = far; if (!far) S.s.far_n = 0; }
     if (lane < RV_MAXB) {
       int b = lane; DevEnv& e = S.e;
-#if !defined(__HIPCC__) || defined(RV_EMULATE)
+#if !RV_ON_DEVICE
       wake_me = S.s.ready[lane];
 #endif
       if (S.s.wake[b] || wake_me) {
@@ -3794,7 +3440,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         S.s.cn[b][col] = near;
       }
     }
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
     {
       // the compact list of owners that run, in owner order
       const unsigned long long mk = __builtin_amdgcn_ballot_w64(runs != 0);
@@ -3805,7 +3451,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     (void)runs;
 #endif
   RV_LANES_END
-#if !defined(__HIPCC__) || defined(RV_EMULATE)
+#if !RV_ON_DEVICE
   RV_LANES_BEGIN
     if (lane == 0) {
       int n = 0;
@@ -3853,7 +3499,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   RV_LANES_BEGIN
     DevEnv& e = S.e;
     const int slot = lane >> 4;
-#if !defined(__HIPCC__) || defined(RV_EMULATE)
+#if !RV_ON_DEVICE
     if ((lane & 15) != 0) continue;   // host emulation: one lane per group does the work
 #endif
     RV_PROFG(5)   // (profiling build) time outside the narrow phase goes to a dump slot
@@ -3983,7 +3629,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   int smask = 0;
   const int rows_all = ((with_fingers || limb) && !fing_fast) || (any_con && !limb);
   (void)rows_all;
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
   if (others_ok) {
 #pragma unroll
     for (int b = 0; b < RV_MAXB; ++b) if (on_[b] && mem_[b] == 1 && !(lone && b == the_body)) smask |= 1 << b;     // (arm points or not)
@@ -4001,7 +3647,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       else if (mi < RV_MAXB + RV_NBB) { kind = 1; a = bb_a(mi - RV_MAXB); b = bb_b(mi - RV_MAXB); }
       else { kind = 2; a = mi - RV_MAXB - RV_NBB; }
       int use = body_on(e, a) && (kind != 1 || body_on(e, b));
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
       // the lane-per-row solvers (solve_singles, solve_island2) set their rows up themselves; Row records are
       // for the velocity-space paths only: an island of three or four bodies, the one-lane system solver
       // (and, for now, the finger / limb solver)
@@ -4017,7 +3663,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         ManPoint p;
         p.la = ld3(m.la[i]); p.lb = ld3(m.lb[i]); p.nrm = ld3(m.nrm[i]); p.dist = m.dist[i]; p.col = m.col[i];
         p.ln = m.ln[i]; p.lt1 = m.lt1[i]; p.lt2 = m.lt2[i];
-#if !defined(__HIPCC__) || defined(RV_EMULATE)
+#if !RV_ON_DEVICE
         Row r;
         row_setup(S, K, kind, a, b, p, r, m.n);
         S.s.u.r.rows[mi][i] = r;
@@ -4045,7 +3691,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
   any_con |= limb;
   if (limb) limb_prepare(S, K, fing_fast ? the_body : -1);
   if (((with_fingers || limb) && !fing_fast) || (any_con && !limb)) {
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
     {
       SerialRows SR;
       serial_rows_setup(S, K, limb, SR);
@@ -4059,10 +3705,10 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     RV_LANES_END
 #endif
   }
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
   if (fing_fast) solve_island_fingers(S, K, __builtin_amdgcn_readfirstlane(the_body), with_fingers, limb);
 #endif
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
   {
     // the partner / pair of every two-body island, then ONE instance of the island solver in
     // the instruction stream, entered once per island of one or two bodies
@@ -4093,20 +3739,9 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     }
   }
 #else
-  RV_LANES_BEGIN
-    if (lane == 0) S.s.n_rows = (!fing_fast && (with_fingers || any_con)) ? 0 : solver_row_list(S, label, on_, act_, big_);
-  RV_LANES_END
-  float isl_tol[RV_MAXB];
-  {
-    const int unrest = unrest_mask(S.e);
-    for (int x = 0; x < RV_MAXB; ++x) {
-      int u_ = 0;
-      for (int b = 0; b < RV_MAXB; ++b) if (on_[b] && label[b] == x) u_ |= (unrest >> b) & 1;
-      isl_tol[x] = tol_of(c, u_);
-    }
-  }
-  if (fing_fast) solve_rows(S, K, S.s.n_rows < 0 ? 0 : S.s.n_rows, with_fingers, limb, lone ? label[the_body] : -1, isl_tol);
-  else if (S.s.n_rows > 0) solve_rows(S, K, S.s.n_rows, 0, 0, -1, isl_tol);
+#define RV_EMU_SECTION 6
+#include "../../tests/emu/rv_emu_hooks.h"      // host lane emulation (test scaffolding; not compiled into the product)
+#undef RV_EMU_SECTION
 #endif
   if (limb) { arm_lq_phase(S, K); arm_fk_phases(S, K); }   // the link frames follow the solved joint state
   // an island of three or four bodies (there can be only one): velocity-space Gauss-Seidel in the
@@ -4117,7 +3752,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
 #pragma unroll
   for (int b = RV_MAXB - 1; b >= 0; --b) if (big_[b]) big_root = b;
   RV_PROF(24)
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
   if (!with_fingers && !any_con && __builtin_amdgcn_readfirstlane(big_root) >= 0) {
     // Device: no Row records in LDS.  Lane 4 mi + i sets up the row set of point i of manifold mi in its
     // REGISTERS (row_setup(): what the row-setup phase computes) and scales the impulses kept from the last
@@ -4236,64 +3871,9 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
     }
   }
 #else
-  if (!with_fingers && !any_con && big_root >= 0) {
-    const int root = big_root;
-    float big_best = 1e30f; int big_since = 0;        // rv_config.solver_stall
-    for (int it = -1; it < c->solver_iters; ++it) {   // it == -1: warm start
-      RV_LANES_BEGIN
-        DevEnv& e = S.e;
-        if (lane < RV_MAXB) {
-          const int b = lane;
-          float res = 0.0f;
-          if (body_on(e, b) && label[b] == root) {
-            BV A = ld_bv(e, b); const float ima = e.inv_mass[b];
-            for (int kind = 0; kind < 2; ++kind) {
-              DevMan& m = e.man[kind == 0 ? RV_TIDX(b) : RV_AIDX(b)];
-              const int mi = kind == 0 ? RV_TIDX(b) : RV_AIDX(b);
-              for (int i = 0; i < m.n; ++i) {
-                Row r = S.s.u.r.rows[mi][i];
-                Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
-                if (it < 0) warm_apply(A, nullptr, ima, 0.0f, l, r);
-                else { res = fmaxr(res, point_solve(A, nullptr, ima, 0.0f, l, r)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
-              }
-            }
-            st_bv(e, b, A);
-          }
-          S.s.res[b] = res;
-        }
-      RV_LANES_END
-      for (int rd = 0; rd < 3; ++rd) {
-        RV_LANES_BEGIN
-          DevEnv& e = S.e;
-          if (lane < 2) {
-            const int x = lane;
-            float res = 0.0f;
-            const int k = bb_round_pair(rd, x);
-            const int a_ = bb_a(k), b_ = bb_b(k);
-            if (body_on(e, a_) && body_on(e, b_) && label[a_] == root && e.man[RV_BBIDX(k)].n != 0) {
-              DevMan& m = e.man[RV_BBIDX(k)];
-              BV A = ld_bv(e, a_), B = ld_bv(e, b_);
-              const float ima = e.inv_mass[a_], imb = e.inv_mass[b_];
-              for (int i = 0; i < m.n; ++i) {
-                Row r = S.s.u.r.rows[RV_BBIDX(k)][i];
-                Lam l; l.n = m.ln[i]; l.t1 = m.lt1[i]; l.t2 = m.lt2[i];
-                if (it < 0) warm_apply(A, &B, ima, imb, l, r);
-                else { res = fmaxr(res, point_solve(A, &B, ima, imb, l, r)); m.ln[i] = l.n; m.lt1[i] = l.t1; m.lt2[i] = l.t2; }
-              }
-              st_bv(e, a_, A); st_bv(e, b_, B);
-            }
-            S.s.res[4 + 2 * rd + x] = res;
-          }
-        RV_LANES_END
-      }
-      float res = 0.0f;
-#pragma unroll
-      for (int t = 0; t < 10; ++t) res = fmaxr(res, S.s.res[t]);
-      if (it >= 0 && res < isl_tol[root]) break;
-      if (it >= 0 && c->solver_stall > 0) { if (res < big_best) { big_best = res; big_since = 0; } else if (++big_since >= c->solver_stall) break; }
-    }
-  }
-
+#define RV_EMU_SECTION 7
+#include "../../tests/emu/rv_emu_hooks.h"      // host lane emulation (test scaffolding; not compiled into the product)
+#undef RV_EMU_SECTION
 #endif
   RV_STOP(5)
   RV_PROF(5)
@@ -4374,7 +3954,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       }
     }
     if (lane == 32) { e.sim_steps++; e.substeps_last++; }
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
   }
   // islands go to sleep as a whole: a body sleeps when every awake body it is coupled to
   // (transitively) by manifolds that hold points is ready as well (the ready flags of the four
@@ -4397,23 +3977,9 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       for (int x = 0; x < RV_MAXB; ++x) if (on_[x] && label[x] == lb && !((rmask >> x) & 1u)) all = 0;
       if (mine && ((rmask >> b) & 1u) && !e.frozen[b] && all) {
 #else
-  RV_LANES_END
-  // islands go to sleep as a whole: a body sleeps when every awake body it is coupled to
-  // (transitively) by manifolds that hold points is ready as well
-  if (c->sleep_steps > 0) {
-  RV_LANES_BEGIN
-    DevEnv& e = S.e;
-    if (lane < RV_MAXB) {
-      int b = lane;
-      int mine = 0, all = 1;
-#pragma unroll
-      for (int x = 0; x < RV_MAXB; ++x) if (x == b) mine = on_[x] && label[x] >= 0;
-      int lb = 0;
-#pragma unroll
-      for (int x = 0; x < RV_MAXB; ++x) if (x == b) lb = label[x];
-#pragma unroll
-      for (int x = 0; x < RV_MAXB; ++x) if (on_[x] && label[x] == lb && !S.s.ready[x]) all = 0;
-      if (mine && S.s.ready[b] && !e.frozen[b] && all) {
+#define RV_EMU_SECTION 8
+#include "../../tests/emu/rv_emu_hooks.h"      // host lane emulation (test scaffolding; not compiled into the product)
+#undef RV_EMU_SECTION
 #endif
         {
           {
@@ -4438,7 +4004,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         }
       }
     }
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
   }
   __syncthreads();
 #else
@@ -4450,7 +4016,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
 // The env block lives in ONE statically addressed LDS object so that the
 // (large) substep body can be a real function with a single copy in the
 // instruction stream instead of being inlined at every call site.
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
 __shared__ Shared g_shared;
 #else
 static thread_local Shared g_shared;
@@ -4516,7 +4082,7 @@ RV_DEV void sim_run_body(Shared& S, const Consts& K, const RunReq& rq) {
   // rv_step_poll: a budget of substeps and / or shader clocks for this launch; the call may return
   // between any two substeps (S.s.suspended) and is entered again by the next launch -- the
   // substep sequence, and so every result, is the one of an uninterrupted call
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
   const int bud_sub = __builtin_amdgcn_readfirstlane(S.s.bud_sub);
   const unsigned long long bud_clk = S.s.bud_clk;
 #else
@@ -4551,7 +4117,7 @@ RV_DEV void sim_run_body(Shared& S, const Consts& K, const RunReq& rq) {
     if (bud_any) {
       int stop = 0;
       if (bud_sub > 0) { bud_left = bud_sub - (S.e.substeps_last - S.s.bud_sub0); if (bud_left <= 0) stop = 1; }
-#if defined(__HIPCC__) && !defined(RV_EMULATE)
+#if RV_ON_DEVICE
       if (bud_clk != 0) { if (__builtin_amdgcn_s_memtime() - S.s.bud_t0 > bud_clk) stop = 1; if (bud_left > 128) bud_left = 128; }
 #endif
       if (stop) { suspended = 1; break; }
@@ -5393,6 +4959,33 @@ struct ProgArgs {
   int first_index, auto_reset; RolloutRec rec; int env, n_envs; int* budget;   // ROLLOUT
 };
 // returns (RV_PROG_PARTIAL) 1 when the env.step() completed in this launch
+// The segments of the env program as functions of their own (RV_SEGMENTS_NOINLINE: the two-waves-per-SIMD build).  Round 4
+// kept the substep LOOP out of line in that build and paid for it with the callee-saved registers of that one big function
+// (~100 KB of scratch per call: 49 - 130 GB of L2 write-outs per launch, profiles/r04_final_c{3,4,5}_pmc.txt).  Inverted in
+// round 5: the loop is inlined into the kernel (a kernel saves nothing) and what is called are the short straight-line
+// segments between two runs of it -- a callee only saves the callee-saved registers it uses itself.  Like sim_run_fn did,
+// a segment addresses the env through the file-scope LDS object and rebuilds Consts from scalars (through pointer
+// arguments the LDS accesses would be compiled as flat loads).
+#ifdef RV_SEGMENTS_NOINLINE
+#define RV_SEG_K const Consts K = lds_consts(scene, 0); Shared& S = g_shared;
+RV_DEV_NOINLINE void seg_step_prologue(const rv_scene* scene, int zero_counters, int count_step) { RV_SEG_K env_step_prologue(S, K, zero_counters, count_step); }
+RV_DEV_NOINLINE void seg_step_epilogue(const rv_scene* scene) { RV_SEG_K env_step_epilogue(S, K); }
+RV_DEV_NOINLINE void seg_pstep_begin(const rv_scene* scene) { RV_SEG_K env_pstep_begin(S, K); }
+RV_DEV_NOINLINE int seg_pstep_end(const rv_scene* scene) { RV_SEG_K return env_pstep_end(S, K); }
+RV_DEV_NOINLINE void seg_gstep_begin(const rv_scene* scene, int zero_counters) { RV_SEG_K genv_step_begin(S, K, zero_counters); }
+RV_DEV_NOINLINE void seg_gstep_observe(const rv_scene* scene) { (void)scene; genv_step_observe(g_shared); }
+RV_DEV_NOINLINE void seg_gstep_end(const rv_scene* scene) { (void)scene; genv_step_end(g_shared); }
+RV_DEV_NOINLINE void seg_reset_begin(const rv_scene* scene, int gid, int zero_counters) { RV_SEG_K env_reset_begin(S, K, gid, zero_counters); }
+RV_DEV_NOINLINE void seg_reset_layout(const rv_scene* scene) { RV_SEG_K env_reset_layout(S, K); }
+RV_DEV_NOINLINE void seg_reset_place(const rv_scene* scene, int i) { RV_SEG_K env_reset_place(S, K, i); }
+RV_DEV_NOINLINE void seg_reset_after_body(const rv_scene* scene, int i) { RV_SEG_K env_reset_after_body(S, K, i); }
+RV_DEV_NOINLINE void seg_reset_validate(const rv_scene* scene, int nb) { (void)scene; env_reset_validate(g_shared, nb); }
+RV_DEV_NOINLINE void seg_reset_robot(const rv_scene* scene) { RV_SEG_K env_reset_robot(S, K); }
+#undef RV_SEG_K
+#define RV_SEG(inl_, out_) out_
+#else
+#define RV_SEG(inl_, out_) inl_
+#endif
 RV_DEV int env_program(Shared& S, const Consts& K, const int prog, const ProgArgs& A) {
   const rv_config* c = K.cfg;
   enum { PC_DONE = 0, PC_RESET_BEGIN, PC_RESET_LAYOUT, PC_RESET_BODY, PC_RESET_BODY_AFTER, PC_RESET_FINAL, PC_RESET_ROBOT,
@@ -5410,7 +5003,7 @@ RV_DEV int env_program(Shared& S, const Consts& K, const int prog, const ProgArg
   else if (prog == RV_PROG_MACRO) pc = PC_STEP_BEGIN;
   else if (prog == RV_PROG_SUB) { if (A.n_steps > 0) { rq = run_req(A.n_steps); run = 1; } }
   else if (prog == RV_PROG_WAIT) { rq = run_req(0, 0u, A.lin_thr, A.ang_thr, A.check_after, A.min_stable, A.max_steps); run = 1; }
-  else if (prog == RV_PROG_PARTIAL) { env_pstep_begin(S, K); rq = run_req(-1, 0u, 0.005f, 0.005f, 100, 100, 2000); run = 1; pc = PC_PSTEP_END; }
+  else if (prog == RV_PROG_PARTIAL) { RV_SEG(env_pstep_begin(S, K), seg_pstep_begin(K.scene)); rq = run_req(-1, 0u, 0.005f, 0.005f, 100, 100, 2000); run = 1; pc = PC_PSTEP_END; }
   else {
     RV_LANES_BEGIN
       if (lane == 0) launch_counters_zero(S.e);
@@ -5424,28 +5017,28 @@ RV_DEV int env_program(Shared& S, const Consts& K, const int prog, const ProgArg
     switch (pc) {
       // ---- RobotEnv.reset
       case PC_RESET_BEGIN:
-        env_reset_begin(S, K, A.gid, reset_zero);
+        RV_SEG(env_reset_begin(S, K, A.gid, reset_zero), seg_reset_begin(K.scene, A.gid, reset_zero));
         pc = PC_RESET_LAYOUT;
         break;
       case PC_RESET_LAYOUT:
         if (RV_UNI(S.s.valid)) { pc = PC_RESET_FINAL; break; }
-        env_reset_layout(S, K);
+        RV_SEG(env_reset_layout(S, K), seg_reset_layout(K.scene));
         rnb = RV_UNI(S.e.n_bodies); ri = 0;
         pc = PC_RESET_BODY;
         break;
       case PC_RESET_BODY:
         if (ri < rnb) {
-          env_reset_place(S, K, ri);
+          RV_SEG(env_reset_place(S, K, ri), seg_reset_place(K.scene, ri));
           RV_PROF(28)
           rq = run_req(0, 1u << ri, 0.1f, 0.1f, 100, 100, 500); run = 1;      // wait_until_stable(body)
           pc = PC_RESET_BODY_AFTER;
         } else {
-          env_reset_validate(S, rnb);
+          RV_SEG(env_reset_validate(S, rnb), seg_reset_validate(K.scene, rnb));
           pc = PC_RESET_LAYOUT;
         }
         break;
       case PC_RESET_BODY_AFTER:
-        env_reset_after_body(S, K, ri);
+        RV_SEG(env_reset_after_body(S, K, ri), seg_reset_after_body(K.scene, ri));
         ++ri;
         pc = PC_RESET_BODY;
         break;
@@ -5455,37 +5048,37 @@ RV_DEV int env_program(Shared& S, const Consts& K, const int prog, const ProgArg
         pc = PC_RESET_ROBOT;
         break;
       case PC_RESET_ROBOT:
-        env_reset_robot(S, K);
+        RV_SEG(env_reset_robot(S, K), seg_reset_robot(K.scene));
         pc = ret_reset;
         break;
       // ---- RobotEnv.step (robot_env.py:239-275)
       case PC_STEP_BEGIN:
         if (grasp) {
-          genv_step_begin(S, K, step_zero);
+          RV_SEG(genv_step_begin(S, K, step_zero), seg_gstep_begin(K.scene, step_zero));
           rq = run_req(-2); run = 1;                                           // the phase loop of Grasp4DofEnv
           pc = PC_GSTEP_OBS;
         } else {
-          env_step_prologue(S, K, step_zero, 1);
+          RV_SEG(env_step_prologue(S, K, step_zero, 1), seg_step_prologue(K.scene, step_zero, 1));
           rq = run_req(-1, 0u, 0.005f, 0.005f, 100, 100, 2000); run = 1;       // phase loop + closing wait_until_stable
           pc = PC_STEP_END;
         }
         break;
       case PC_STEP_END:
         RV_PROF(30)
-        env_step_epilogue(S, K);
+        RV_SEG(env_step_epilogue(S, K), seg_step_epilogue(K.scene));
         pc = ret_step;
         break;
       case PC_GSTEP_OBS:
-        genv_step_observe(S);
+        RV_SEG(genv_step_observe(S), seg_gstep_observe(K.scene));
         rq = run_req(0, 0u, 0.005f, 0.005f, 100, 100, 2000); run = 1;          // GraspReward: wait until the object is stable
         pc = PC_GSTEP_END;
         break;
       case PC_GSTEP_END:
-        genv_step_end(S);
+        RV_SEG(genv_step_end(S), seg_gstep_end(K.scene));
         pc = ret_step;
         break;
       case PC_PSTEP_END:
-        fin = RV_UNI(env_pstep_end(S, K));
+        fin = RV_UNI(RV_SEG(env_pstep_end(S, K), seg_pstep_end(K.scene)));
         pc = PC_DONE;
         break;
       // ---- the rollout loop

@@ -8,7 +8,15 @@
 #pragma once
 #include <stdint.h>
 
+// RV_ON_DEVICE -- defined HERE and nowhere else: 1 when the source is compiled by hipcc for the product, 0 when it is
+// compiled for the host by the lane emulator of tests/emu (-DRV_EMULATE, or any plain C++ compiler).  The kernel headers
+// test only this macro; the host bodies of the larger emulation hooks live in tests/emu/rv_emu_hooks.h.
 #if defined(__HIPCC__) && !defined(RV_EMULATE)
+#define RV_ON_DEVICE 1
+#else
+#define RV_ON_DEVICE 0
+#endif
+#if RV_ON_DEVICE
 #include <hip/hip_runtime.h>
 #define RV_DEV __device__ __forceinline__
 #define RV_DEV_NOINLINE __device__ __noinline__

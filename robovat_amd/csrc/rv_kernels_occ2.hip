@@ -1,7 +1,11 @@
 // rv_kernels_occ2.hip — the env kernel compiled for two waves per SIMD (see rv_env_kernel.h).
 // gfx950 only; built with hipcc --offload-arch=gfx950 into librovat_hip.so next to rv_kernels.hip.
 #define RV_WAVES_PER_EU 2
+#ifdef RV_OCC2_LOOP_OUT_OF_LINE     // (round 4's arrangement, kept as a build variant for measurements: tools/gpu.sh variants)
 #define RV_SIM_RUN_NOINLINE 1
+#else
+#define RV_SEGMENTS_NOINLINE 1      // the loop inlined into the kernel, the segments of the env program out of line: see env_program
+#endif
 #define k_env k_env_occ2
 #include "rv_env_kernel.h"
 

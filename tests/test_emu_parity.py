@@ -19,7 +19,7 @@ def emu():
     so = os.path.join(EMU_DIR, 'librv_emu.so')
     src = os.path.join(EMU_DIR, 'rv_emu.cpp')
     csrc = os.path.join(EMU_DIR, '..', '..', 'robovat_amd', 'csrc')
-    deps = [src] + [os.path.join(csrc, n) for n in ('rv_dev_env.h', 'rv_dev_collide.h', 'rv_dev_math.h')]
+    deps = [src, os.path.join(EMU_DIR, 'rv_emu_hooks.h')] + [os.path.join(csrc, n) for n in ('rv_dev_env.h', 'rv_dev_collide.h', 'rv_dev_math.h')]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-ffp-contract=off', '-mfma', '-fopenmp', '-shared', src, '-o', so], check=True)
     lib = C.CDLL(so)

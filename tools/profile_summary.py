@@ -45,7 +45,8 @@ cmdfile = os.path.join(src, 'command.txt')
 command = open(cmdfile).read().strip().replace(ROOT + '/', '') if os.path.exists(cmdfile) else 'python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs'
 command = command.split('/')[-1] if command.startswith('python /') else command
 headline = '--workload' not in command and '--over' not in command
-algo_bytes = bench['roofline']['algorithmic_bytes_per_env_substep']
+rl = bench['roofline']
+algo_bytes = rl.get('hbm_nominal', rl).get('algorithmic_bytes_per_env_substep', rl.get('algorithmic_bytes_per_env_substep'))
 lines = ['# rocprofv3 --kernel-trace --stats -- python ' + command.replace('python ', '', 1) + '      [' + bench['config']['workload'] + ']',
          '%-60s %8s %14s %14s %8s' % ('kernel', 'calls', 'total_us', 'avg_us', 'pct')]
 for r in ks[:12]:
