@@ -435,7 +435,10 @@ int  rv_set_constraint(rv_world* w, int32_t body, const float* frame7, const flo
  * JOINT_POINT2POINT: the three linear rows, the bodies turn freely about the pivot) or RV_JOINT_PRISMATIC (the body
  * slides along the X AXIS of the frame it is tied to -- child_frame7's orientation: two linear rows across that axis
  * and the three angular rows; a jointAxis other than x is a rotation of both frames, which the HipPhysics mirror
- * applies).  Gear joints (and revolute ones, which pybullet's createConstraint does not offer either): RV_ERR_NOTIMPL. */
+ * applies) or RV_JOINT_REVOLUTE (the fourth type of the reference's JOINT_TYPES_MAPPING, bullet_physics.py:20-25: a hinge about
+ * the X AXIS of the frame -- the three linear rows at the pivot and two angular rows across the axis).  Other pybullet joint
+ * types (gear ...) are not in the reference's mapping: RV_ERR_NOTIMPL. */
+#define RV_JOINT_REVOLUTE    0   /* pybullet.JOINT_REVOLUTE */
 #define RV_JOINT_PRISMATIC   1   /* pybullet.JOINT_PRISMATIC */
 #define RV_JOINT_FIXED       4   /* pybullet.JOINT_FIXED */
 #define RV_JOINT_POINT2POINT 5   /* pybullet.JOINT_POINT2POINT */

@@ -238,7 +238,7 @@ class OracleWorld(object):
     def set_constraint(self, body, target7, frame7=None, max_force=500.0, child=-1, joint_type='fixed'):
         t = np.ascontiguousarray(target7 if target7 is not None else [0, 0, 0, 0, 0, 0, 1], dtype=np.float64)
         f = None if frame7 is None else np.ascontiguousarray(frame7, dtype=np.float64)
-        self.lib.orc_set_constraint_ex(self.h, C.c_int(int(body)), C.c_int(int(child)), C.c_int({'fixed': 1, 'point2point': 2, 'prismatic': 3}[joint_type]),
+        self.lib.orc_set_constraint_ex(self.h, C.c_int(int(body)), C.c_int(int(child)), C.c_int({'fixed': 1, 'point2point': 2, 'prismatic': 3, 'revolute': 4}[joint_type]),
                                        None if f is None else _p(f), _p(t), C.c_double(max_force))
 
     def remove_constraint(self, body):

@@ -1182,7 +1182,9 @@ static real constraint_solve(const orc_world* w, orc_env* e, int b, real* lam) {
   const real th[3] = {qe[0] * sg, qe[1] * sg, qe[2] * sg};
   /* prismatic (type 3; pybullet JOINT_PRISMATIC): the body slides along the x axis of the frame it is tied to -- two
    * linear rows along that frame's y and z axes, then the three angular rows */
-  const int n_lin = ctype == 3 ? 2 : 3, n_rows = ctype == 2 ? 3 : n_lin + 3;
+  /* revolute (type 4; the reference's JOINT_TYPES_MAPPING 'revolute', bullet_physics.py:20-25): a hinge about the x axis of the
+   * frame -- the three linear rows at the pivot and two angular rows along that frame's y and z axes */
+  const int n_lin = ctype == 3 ? 2 : 3, n_ang = ctype == 4 ? 2 : 3, n_rows = ctype == 2 ? 3 : n_lin + n_ang;
   real rt[9], dtp[3];
   qmat(rt, tq); v3sub(dtp, tp, wp);
   for (int k = 0; k < n_rows; ++k) {
@@ -1202,6 +1204,11 @@ static real constraint_solve(const orc_world* w, orc_env* e, int b, real* lam) {
       real ek[3] = {R(0.0), R(0.0), R(0.0)}; ek[k] = R(1.0);
       v3cross(ja, r, ek); v3cross(jc, rc, ek);
       bias = (real)c->erp * (tp[k] - wp[k]) / dt;
+    } else if (ctype == 4) {
+      real ek[3] = {R(0.0), R(0.0), R(0.0)}; ek[k - n_lin + 1] = R(1.0);
+      m3mulv(ja, rt, ek);                                        /* column k - n_lin + 1 of the frame's rotation */
+      v3cpy(jc, ja);
+      bias = (real)c->erp * v3dot(ja, th) / dt;
     } else {
       ja[k - n_lin] = R(1.0); jc[k - n_lin] = R(1.0);
       bias = (real)c->erp * th[k - n_lin] / dt;
@@ -2771,7 +2778,7 @@ void orc_set_constraint_ex(orc_world* w, int body, int child, int joint_type, co
     orc_bparam* P = &w->env[i].bp[body];
     if (max_force < 0.0) P->con_on = 0;
     else {
-      P->con_on = (joint_type == 2 || joint_type == 3 ? joint_type : 1) | ((child + 1) << 4); P->con_fmax = (real)max_force;
+      P->con_on = (joint_type >= 2 && joint_type <= 4 ? joint_type : 1) | ((child + 1) << 4); P->con_fmax = (real)max_force;
       for (int k = 0; k < 3; ++k) { P->con_lpos[k] = frame7 ? (real)frame7[k] : R(0.0); P->con_tpos[k] = (real)target7[k]; }
       for (int k = 0; k < 4; ++k) { P->con_lquat[k] = frame7 ? (real)frame7[3 + k] : (k == 3 ? R(1.0) : R(0.0)); P->con_tquat[k] = (real)target7[3 + k]; }
     }

@@ -1295,6 +1295,7 @@ RV_DEV float point_solve_g(BV& A, float ima, Lam& l, const Row& r, float* qf, fl
 #define RV_CON_FIXED 1
 #define RV_CON_P2P 2
 #define RV_CON_PRISMATIC 3
+#define RV_CON_REVOLUTE 4
 #define RV_CON_TYPE(x) ((x) & 15)
 #define RV_CON_CHILD(x) ((((x) >> 4) & 15) - 1)
 RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
@@ -1326,7 +1327,9 @@ RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
   float res = 0.0f;
   // prismatic (RV_CON_PRISMATIC; pybullet JOINT_PRISMATIC): the body slides along the x axis of the frame it is tied
   // to -- two linear rows along that frame's y and z axes, then the three angular rows
-  const int n_lin = ctype == RV_CON_PRISMATIC ? 2 : 3, n_rows = ctype == RV_CON_P2P ? 3 : n_lin + 3;
+  // revolute (RV_CON_REVOLUTE; 'revolute' of the reference's JOINT_TYPES_MAPPING, bullet_physics.py:20-25): a hinge about the x
+  // axis of the frame -- the three linear rows at the pivot and two angular rows along that frame's y and z axes
+  const int n_lin = ctype == RV_CON_PRISMATIC ? 2 : 3, n_ang = ctype == RV_CON_REVOLUTE ? 2 : 3, n_rows = ctype == RV_CON_P2P ? 3 : n_lin + n_ang;
   const m3 rt = qmat(tq);
   const v3 dtp = sub(tpv, wp);
   for (int k = 0; k < n_rows; ++k) {
@@ -1343,6 +1346,10 @@ RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
       const v3 ek = mk(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f);
       jl = ek; ja = cross(r, ek); jc = cross(rc, ek);
       bias = c->erp * (tp[k] - wpa[k]) / dt;
+    } else if (ctype == RV_CON_REVOLUTE) {
+      const int a_ = k - n_lin;
+      ja = mulv(rt, mk(0.0f, a_ == 0 ? 1.0f : 0.0f, a_ == 1 ? 1.0f : 0.0f)); jc = ja;      // column a_ + 1 of the frame's rotation
+      bias = c->erp * dot(ja, mk(th[0], th[1], th[2])) / dt;
     } else {
       const int a_ = k - n_lin;
       ja = mk(a_ == 0 ? 1.0f : 0.0f, a_ == 1 ? 1.0f : 0.0f, a_ == 2 ? 1.0f : 0.0f); jc = ja;

@@ -856,10 +856,10 @@ int rv_set_constraint_ex(rv_world* w, int32_t body, int32_t child, int32_t joint
   WCHK(w);
   if (body < 0 || body >= RV_MAXB) return fail(RV_ERR_VALUE, "rv_set_constraint: not a movable body slot");
   if (child < -1 || child >= RV_MAXB || child == body) return fail(RV_ERR_VALUE, "rv_set_constraint: the child is the world (-1) or another movable body slot");
-  if (joint_type != RV_JOINT_FIXED && joint_type != RV_JOINT_POINT2POINT && joint_type != RV_JOINT_PRISMATIC) return fail(RV_ERR_NOTIMPL, "rv_set_constraint: joint types built: fixed, point2point, prismatic");
+  if (joint_type != RV_JOINT_FIXED && joint_type != RV_JOINT_POINT2POINT && joint_type != RV_JOINT_PRISMATIC && joint_type != RV_JOINT_REVOLUTE) return fail(RV_ERR_NOTIMPL, "rv_set_constraint: joint types built: fixed, point2point, prismatic, revolute");
   if (max_force >= 0.0f && !child_frame7) return fail(RV_ERR_VALUE, "rv_set_constraint: null target");
   ConArgs a; memset(&a, 0, sizeof(a));
-  a.body = body; a.child = child; a.type = joint_type == RV_JOINT_POINT2POINT ? 2 : (joint_type == RV_JOINT_PRISMATIC ? 3 : 1); a.fmax = max_force; a.lq[3] = 1.0f; a.tq[3] = 1.0f;
+  a.body = body; a.child = child; a.type = joint_type == RV_JOINT_POINT2POINT ? 2 : (joint_type == RV_JOINT_PRISMATIC ? 3 : (joint_type == RV_JOINT_REVOLUTE ? 4 : 1)); a.fmax = max_force; a.lq[3] = 1.0f; a.tq[3] = 1.0f;
   if (max_force >= 0.0f) {
     if (frame7) { for (int k = 0; k < 3; ++k) a.lp[k] = frame7[k]; for (int k = 0; k < 4; ++k) a.lq[k] = frame7[3 + k]; }
     for (int k = 0; k < 3; ++k) a.tp[k] = child_frame7[k];

@@ -424,7 +424,7 @@ class World(object):
     def grip(self, value):
         check(self.lib.rv_grip(self.h, float(value)))
 
-    JOINT_TYPES = {'prismatic': 1, 'fixed': 4, 'point2point': 5}      # pybullet.JOINT_PRISMATIC / JOINT_FIXED / JOINT_POINT2POINT
+    JOINT_TYPES = {'revolute': 0, 'prismatic': 1, 'fixed': 4, 'point2point': 5}      # pybullet.JOINT_REVOLUTE / _PRISMATIC / _FIXED / _POINT2POINT: the reference's JOINT_TYPES_MAPPING
 
     def set_constraint(self, body, target7, frame7=None, max_force=500.0, child=-1, joint_type='fixed'):
         """rv_set_constraint_ex: tie frame7 (in the body frame; None = the body frame) of movable body ``body`` to
@@ -432,7 +432,7 @@ class World(object):
         'fixed', a 'point2point' or a 'prismatic' joint (sliding along the x axis of the target frame) with at most
         max_force N per row; max_force < 0 removes it."""
         if joint_type not in self.JOINT_TYPES:
-            raise NotImplementedError("joint types built: 'fixed', 'point2point', 'prismatic' (not %r)" % (joint_type,))
+            raise NotImplementedError("joint types built: 'fixed', 'point2point', 'prismatic', 'revolute' (not %r)" % (joint_type,))
         t = (C.c_float * 7)(*[float(x) for x in (target7 if target7 is not None else [0, 0, 0, 0, 0, 0, 1])])
         f = None if frame7 is None else (C.c_float * 7)(*[float(x) for x in frame7])
         check(self.lib.rv_set_constraint_ex(self.h, int(body), int(child), self.JOINT_TYPES[joint_type], f, t, float(max_force)))

@@ -358,11 +358,12 @@ class HipPhysics(Physics):
     # ---- user constraints (bullet_physics.py:748-957: createConstraint / changeConstraint / removeConstraint)
     def add_constraint(self, parent_uid, child_uid, joint_type='fixed', joint_axis=[0, 0, 0],
                        parent_frame_pose=None, child_frame_pose=None):
-        """A 'fixed', 'point2point' or 'prismatic' (along joint_axis) joint between a frame of a movable body (the parent) and a frame of the world
+        """A 'fixed', 'point2point', 'prismatic' (along joint_axis) or 'revolute' (about joint_axis) joint -- the four types of the
+        reference's JOINT_TYPES_MAPPING (bullet_physics.py:20-25) -- between a frame of a movable body (the parent) and a frame of the world
         (child None: the constraint ControllableConstraint servoes) or of another movable body (the child).
         Gear joints (and links of the arm as parties) are not built.  Returns the constraint uid."""
-        if joint_type not in ('fixed', 'point2point', 'prismatic'):
-            raise NotImplementedError("joint types built: 'fixed', 'point2point', 'prismatic' (not %r)" % (joint_type,))
+        if joint_type not in ('fixed', 'point2point', 'prismatic', 'revolute'):
+            raise NotImplementedError("joint types built: 'fixed', 'point2point', 'prismatic', 'revolute' (not %r)" % (joint_type,))
         b = self._slot(parent_uid)
         child = -1 if child_uid is None else self._slot(child_uid)
         if child == b:
@@ -376,13 +377,13 @@ class HipPhysics(Physics):
                 child_frame_pose = self.get_body_pose(child).inverse().transform(child_frame_pose)
         pose = Pose(child_frame_pose)
         entry = {'frame': frame, 'pose': pose, 'max_force': 500.0, 'child': child, 'joint_type': joint_type}     # pybullet's default maxForce
-        if joint_type == 'prismatic':
-            # the library slides along the x axis of the joint frame: a joint_axis (given in the child's joint frame,
+        if joint_type in ('prismatic', 'revolute'):
+            # the library slides along (turns about) the x axis of the joint frame: a joint_axis (given in the child's joint frame,
             # pybullet's jointAxis) other than x is the same rotation applied to both joint frames.  Validated BEFORE the
             # mirror entry exists: a rejected call must leave the body free to be constrained again
             a = np.asarray(joint_axis, np.float64)
             if not np.linalg.norm(a) > 0.0:
-                raise ValueError('a prismatic joint needs a joint_axis')
+                raise ValueError('a %s joint needs a joint_axis' % joint_type)
             a = a / np.linalg.norm(a)
             n = np.cross([1.0, 0.0, 0.0], a)
             if np.linalg.norm(n) < 1e-12:

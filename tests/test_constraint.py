@@ -155,6 +155,7 @@ def test_hip_equals_oracle_with_constraints():
         x.remove_constraint(1); x.remove_constraint(2)
         x.set_constraint(1, [float(st[1, 0]), float(st[1, 1]), float(st[1, 2]) + 0.03] + qz, frame7=[0, 0, 0.01] + qz, max_force=60.0, joint_type='prismatic')
         x.set_constraint(3, [0.0, 0.0, 0.08, 0, 0, 0, 1], max_force=40.0, child=0, joint_type='prismatic')
+        x.set_constraint(2, [float(st[2, 0]), float(st[2, 1]), float(st[2, 2]) + 0.02] + qz, frame7=[0.015, 0, 0.0] + qz, max_force=50.0, joint_type='revolute')
     for k in range(3):
         w.step_sub(150); ref.step_sub(150)
         assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32)), k
@@ -211,7 +212,7 @@ def test_simulator_add_constraint_and_pose_servo():
 @pytest.mark.gpu
 def test_constraint_entry_point_rejects_what_is_not_built():
     """rv_set_constraint_ex: unknown joint types are RV_ERR_NOTIMPL, a bad body / child slot or a null target RV_ERR_VALUE
-    (bullet_physics.py:748-806 would hand pybullet a prismatic / gear joint; this build has none)."""
+    (the reference's JOINT_TYPES_MAPPING, bullet_physics.py:20-25, has revolute / prismatic / fixed / point2point: all four are built)."""
     import ctypes as C
     from robovat_amd import lib
     scene, names = scenes.make_scene()
@@ -221,7 +222,7 @@ def test_constraint_entry_point_rejects_what_is_not_built():
     L = lib.load()
     t7 = (C.c_float * 7)(0.6, 0.0, 0.1, 0, 0, 0, 1)
     call = lambda body, child, jt, tgt, f: L.rv_set_constraint_ex(w.h, body, child, jt, None, tgt, f)
-    assert call(0, -1, 0, t7, 10.0) == abi.RV_ERR_NOTIMPL            # pybullet.JOINT_REVOLUTE (not a createConstraint type either)
+    assert call(0, -1, 0, t7, 10.0) == abi.RV_OK                      # pybullet.JOINT_REVOLUTE ('revolute' of the reference's mapping)
     assert call(0, -1, 6, t7, 10.0) == abi.RV_ERR_NOTIMPL            # pybullet.JOINT_GEAR
     assert call(abi.RV_MAXB, -1, 4, t7, 10.0) == abi.RV_ERR_VALUE     # not a movable body slot
     assert call(0, 0, 4, t7, 10.0) == abi.RV_ERR_VALUE                # a body cannot be its own child
@@ -307,5 +308,45 @@ def test_prismatic_joint_between_two_free_bodies_conserves_momentum(backend):
     # ... and it is a joint: seen from the carrier (which the off-centre sideways push has turned) the slider is on the rail
     rel = _qmat(st[1, 3:7]).T @ (st[0, :3] - st[1, :3])
     assert abs(rel[1]) < 1.5e-3 and abs(rel[2] - 0.08) < 1.5e-3 and rel[0] > 0.05, rel
+    if hasattr(w, 'w'):
+        w.close()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_revolute_joint_is_a_hinge(backend):
+    """'revolute' (the reference's JOINT_TYPES_MAPPING, bullet_physics.py:20-25): the body turns freely about the x axis of
+    the joint frame and about nothing else, and its pivot stays put.  A box is hinged to the world about a horizontal axis
+    (the world's x turned 25 degrees about z) through a pivot 3 cm off its centre of mass: under gravity it swings like a
+    physical pendulum about that axis -- the angular velocity stays along the axis, the pivot within a millimetre of its
+    world point, and at the bottom of the first swing the kinetic energy equals the potential energy it gave up (minus
+    Bullet's damping: a few per cent)."""
+    w, cfg = T._world(backend, **{'PHYSICS.SLEEP_STEPS': 0})
+    m = 0.25
+    x0 = np.array([0.5, 0.0, 0.35])
+    T._bodies(w, [(0, m, 0.5, tuple(x0), Q0, (0, 0, 0))])
+    a = np.radians(25.0)
+    qz = [0, 0, np.sin(a / 2), np.cos(a / 2)]
+    ax = np.array([np.cos(a), np.sin(a), 0.0])
+    perp = np.array([-np.sin(a), np.cos(a), 0.0])
+    lp = 0.03 * perp                                  # pivot in the body frame (identity orientation at the start): 3 cm sideways
+    piv = x0 + lp
+    w.set_constraint(0, list(piv) + qz, frame7=list(lp) + qz, max_force=200.0, joint_type='revolute')
+    scene, _ = scenes.make_scene()
+    ik = np.array(list(scene.shapes[0].inertia_k))
+    z_min, ke_at_min = 1e9, 0.0
+    for k in range(16):
+        w.step_sub(25)
+        st = np.asarray(w.body_state())[0, 0]
+        R = _qmat(st[3:7])
+        assert np.linalg.norm(st[:3] + R @ lp - piv) < 1e-3                                   # the pivot stays where it is
+        om = st[10:13]
+        assert np.linalg.norm(om - (om @ ax) * ax) < 0.03 * max(1.0, abs(om @ ax)), (k, om)   # it turns about the hinge axis only
+        assert np.linalg.norm(R @ np.array([np.cos(a), np.sin(a), 0.0]) - ax) < 2e-3          # the axis itself does not tilt
+        if st[2] < z_min:
+            I = R @ np.diag(m * ik) @ R.T
+            z_min, ke_at_min = st[2], 0.5 * m * st[7:10] @ st[7:10] + 0.5 * om @ I @ om
+    drop = x0[2] - z_min
+    assert 0.02 < drop <= 0.03 + 1e-3, drop                                                     # it swung down (to at most the arm's length)
+    assert abs(ke_at_min - m * T.G * drop) < 0.12 * m * T.G * drop, (ke_at_min, m * T.G * drop)
     if hasattr(w, 'w'):
         w.close()
