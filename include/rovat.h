@@ -437,7 +437,11 @@ int  rv_set_constraint(rv_world* w, int32_t body, const float* frame7, const flo
  * and the three angular rows; a jointAxis other than x is a rotation of both frames, which the HipPhysics mirror
  * applies) or RV_JOINT_REVOLUTE (the fourth type of the reference's JOINT_TYPES_MAPPING, bullet_physics.py:20-25: a hinge about
  * the X AXIS of the frame -- the three linear rows at the pivot and two angular rows across the axis).  Other pybullet joint
- * types (gear ...) are not in the reference's mapping: RV_ERR_NOTIMPL. */
+ * types (gear ...) are not in the reference's mapping: RV_ERR_NOTIMPL.  `child` = RV_CHILD_LINK(f): frame f of the ARM is the
+ * other party (createConstraint with a (body, link) entity, bullet_physics.py:773-790: e.g. an object attached to the hand) --
+ * child_frame7 is given in that link frame, which moves kinematically (the rows see the link's twist, the link takes no
+ * impulse); fixed and point2point joints. */
+#define RV_CHILD_LINK(f)     (RV_MAXB + (f))
 #define RV_JOINT_REVOLUTE    0   /* pybullet.JOINT_REVOLUTE */
 #define RV_JOINT_PRISMATIC   1   /* pybullet.JOINT_PRISMATIC */
 #define RV_JOINT_FIXED       4   /* pybullet.JOINT_FIXED */

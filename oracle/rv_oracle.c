@@ -1162,6 +1162,10 @@ static real constraint_solve(const orc_world* w, orc_env* e, int b, real* lam) {
   const real dt = (real)c->dt, lim = P->con_fmax * dt;
   const int ctype = CON_TYPE(P->con_on), cw = CON_CHILD(P->con_on);
   int cb = cw;
+  /* child >= RV_MAXB: frame cw - RV_MAXB of the ARM (a link as the other party, bullet_physics.py:773-779): a kinematic frame
+   * that moves with the link's twist and takes no impulse */
+  const int lf = cw >= RV_MAXB ? cw - RV_MAXB : -1;
+  if (lf >= 0) cb = -2;
   if (cb >= 0 && !body_on(e, cb)) cb = -2;
   real rot[9], r[3], wp[3], res = R(0.0);
   qmat(rot, B->q); m3mulv(r, rot, P->con_lpos); v3add(wp, B->p, r);
@@ -1171,7 +1175,15 @@ static real constraint_solve(const orc_world* w, orc_env* e, int b, real* lam) {
   real tp[3] = {P->con_tpos[0], P->con_tpos[1], P->con_tpos[2]}, rc[3] = {R(0.0), R(0.0), R(0.0)};
   real tq[4] = {P->con_tquat[0], P->con_tquat[1], P->con_tquat[2], P->con_tquat[3]};
   real imc = R(0.0);
-  if (cw >= 0) {
+  real lv[3] = {R(0.0), R(0.0), R(0.0)}, lw[3] = {R(0.0), R(0.0), R(0.0)};      /* velocity of the link frame at the pivot, its spin */
+  if (lf >= 0) {
+    real rotc[9];
+    qmat(rotc, e->fquat[lf]); m3mulv(rc, rotc, P->con_tpos); v3add(tp, e->fpos[lf], rc);
+    qmul(tq, e->fquat[lf], P->con_tquat);
+    if (e->arm_enabled) {
+      real d[3], cr[3]; v3sub(d, wp, e->fpos[lf]); v3cross(cr, e->fw[lf], d); v3add(lv, e->fv[lf], cr); v3cpy(lw, e->fw[lf]);
+    }
+  } else if (cw >= 0) {
     real rotc[9];
     qmat(rotc, e->body[cw].q); m3mulv(rc, rotc, P->con_tpos); v3add(tp, e->body[cw].p, rc);
     qmul(tq, e->body[cw].q, P->con_tquat);
@@ -1196,7 +1208,7 @@ static real constraint_solve(const orc_world* w, orc_env* e, int b, real* lam) {
        * child's frame origin are far apart; equal and opposite impulses at two different points would be a spurious
        * torque (round-4 advisor): the child's lever is wp - x_child, not its own frame origin */
       real rcw[3] = {R(0.0), R(0.0), R(0.0)};
-      if (cw >= 0) v3sub(rcw, wp, e->body[cw].p);
+      if (cw >= 0 && lf < 0) v3sub(rcw, wp, e->body[cw].p);
       v3cross(ja, r, jl); v3cross(jc, rcw, jl);
       bias = (real)c->erp * v3dot(jl, dtp) / dt;
     } else if (k < n_lin) {
@@ -1216,6 +1228,7 @@ static real constraint_solve(const orc_world* w, orc_env* e, int b, real* lam) {
     m3mulv(ia, e->iinv[b], ja);
     real kk = (k < n_lin ? P->inv_mass : R(0.0)) + v3dot(ja, ia);
     real jv = v3dot(jl, B->v) + v3dot(ja, B->w);
+    if (lf >= 0) jv = jv - (k < n_lin ? v3dot(jl, lv) : v3dot(ja, lw));
     if (cb >= 0) {
       m3mulv(ic, e->iinv[cb], jc);
       kk = kk + ((k < n_lin ? imc : R(0.0)) + v3dot(jc, ic));
@@ -2783,7 +2796,7 @@ void orc_set_constraint_ex(orc_world* w, int body, int child, int joint_type, co
       for (int k = 0; k < 4; ++k) { P->con_lquat[k] = frame7 ? (real)frame7[3 + k] : (k == 3 ? R(1.0) : R(0.0)); P->con_tquat[k] = (real)target7[3 + k]; }
     }
     P->asleep = 0; P->sleep_count = 0; P->deact_count = 0; P->still_count = 0; P->undisturbed = 0;
-    if (child >= 0) { orc_bparam* C = &w->env[i].bp[child]; C->asleep = 0; C->sleep_count = 0; C->deact_count = 0; C->still_count = 0; C->undisturbed = 0; }
+    if (child >= 0 && child < RV_MAXB) { orc_bparam* C = &w->env[i].bp[child]; C->asleep = 0; C->sleep_count = 0; C->deact_count = 0; C->still_count = 0; C->undisturbed = 0; }
   }
 }
 void orc_set_constraint(orc_world* w, int body, const double* frame7, const double* target7, double max_force) {

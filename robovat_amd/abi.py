@@ -18,6 +18,12 @@ RV_NCOL = 10
 RV_MAXTILES = 24
 RV_MAXG = 4
 RV_MAXQ = 8
+
+
+def RV_CHILD_LINK(f):
+    """child argument of rv_set_constraint_ex for frame f of the arm (include/rovat.h)"""
+    return RV_MAXB + int(f)
+
 RV_NBB = RV_MAXB * (RV_MAXB - 1) // 2
 RV_NMAN = 2 * RV_MAXB + RV_NBB
 RV_BODY_STRIDE = 13

@@ -1303,8 +1303,12 @@ RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
   const float dt = c->dt, lim = e.con_fmax[b] * dt, ima = e.inv_mass[b];
   const int ctype = RV_CON_TYPE(e.con_on[b]);
   int cb = RV_CON_CHILD(e.con_on[b]);
-  if (cb >= 0 && !body_on(e, cb)) cb = -2;        // (an absent / frozen / sleeping child: a fixed frame where it is)
   const int cw = RV_CON_CHILD(e.con_on[b]);       // (-1: the frame is a world frame)
+  // child >= RV_MAXB: frame cw - RV_MAXB of the ARM (a link as the other party, bullet_physics.py:773-779): a kinematic frame
+  // that moves with the link's twist and takes no impulse
+  const int lf = cw >= RV_MAXB ? cw - RV_MAXB : -1;
+  if (lf >= 0) cb = -2;
+  if (cb >= 0 && !body_on(e, cb)) cb = -2;        // (an absent / frozen / sleeping child: a fixed frame where it is)
   const m3 rot = qmat(ldq(e.body[b] + 3));
   const v3 r = mulv(rot, ld3(e.con_lpos[b])), wp = add(ld3(e.body[b]), r);
   const q4 qw = qmul(ldq(e.body[b] + 3), ldq(e.con_lquat[b]));
@@ -1313,7 +1317,14 @@ RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
   v3 tpv = ld3(e.con_tpos[b]), rc = mk(0.0f, 0.0f, 0.0f);
   q4 tq = ldq(e.con_tquat[b]);
   float imc = 0.0f;
-  if (cw >= 0) {
+  v3 lv = mk(0.0f, 0.0f, 0.0f), lw = mk(0.0f, 0.0f, 0.0f);      // velocity of the link frame at the pivot, its spin
+  if (lf >= 0) {
+    const m3 rotc = qmat(ldq(e.fquat[lf]));
+    rc = mulv(rotc, ld3(e.con_tpos[b]));
+    tpv = add(ld3(e.fpos[lf]), rc);
+    tq = qmul(ldq(e.fquat[lf]), ldq(e.con_tquat[b]));
+    if (e.arm_enabled) { lv = add(ld3(S.s.fv[lf]), cross(ld3(S.s.fw[lf]), sub(wp, ld3(e.fpos[lf])))); lw = ld3(S.s.fw[lf]); }
+  } else if (cw >= 0) {
     const m3 rotc = qmat(ldq(e.body[cw] + 3));
     rc = mulv(rotc, ld3(e.con_tpos[b]));
     tpv = add(ld3(e.body[cw]), rc);
@@ -1339,7 +1350,7 @@ RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
       // ONE anchor for both parties: the parent's pivot wp (as Bullet's slider does) -- along the slide axis wp and the
       // child's frame origin are far apart, and equal and opposite impulses at two points would be a spurious torque
       // (round-4 advisor): the child's lever is wp - x_child
-      const v3 rcw = cw >= 0 ? sub(wp, ld3(e.body[cw])) : mk(0.0f, 0.0f, 0.0f);
+      const v3 rcw = (cw >= 0 && lf < 0) ? sub(wp, ld3(e.body[cw])) : mk(0.0f, 0.0f, 0.0f);
       ja = cross(r, jl); jc = cross(rcw, jl);
       bias = c->erp * dot(jl, dtp) / dt;
     } else if (k < n_lin) {
@@ -1358,6 +1369,7 @@ RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
     const v3 ia = mulv(ldm(S.s.iinv[b]), ja);
     float kk = (k < n_lin ? ima : 0.0f) + dot(ja, ia);
     float jv = dot(jl, ld3(e.body[b] + 7)) + dot(ja, ld3(e.body[b] + 10));
+    if (lf >= 0) jv = jv - (k < n_lin ? dot(jl, lv) : dot(ja, lw));
     v3 ic = mk(0, 0, 0);
     if (cb >= 0) {
       ic = mulv(ldm(S.s.iinv[cb]), jc);
@@ -3094,6 +3106,8 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
     for (int b = 0; b < RV_MAXB; ++b) ok |= body_on(S.e, b);
 #pragma unroll
     for (int b = 0; b < RV_MAXB; ++b) if (S.e.man[RV_AIDX(b)].n != 0) ok = 0;
+#pragma unroll
+    for (int b = 0; b < RV_MAXB; ++b) if (RV_CON_TYPE(S.e.con_on[b]) != 0 && RV_CON_CHILD(S.e.con_on[b]) >= RV_MAXB) ok = 0;   // (a body tied to a LINK: the frames are needed)
     if (ok) {
       int near_any = 0;
       RV_LANES_BEGIN

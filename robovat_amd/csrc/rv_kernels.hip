@@ -149,7 +149,7 @@ __global__ void k_set_constraint(DevEnv* envs, int n, ConArgs a) {
     for (int k = 0; k < 4; ++k) { e.con_lquat[b][k] = a.lq[k]; e.con_tquat[b][k] = a.tq[k]; }
   }
   e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0;
-  if (a.child >= 0) { const int cb = a.child; e.asleep[cb] = 0; e.sleep_count[cb] = 0; e.deact_count[cb] = 0; e.still_count[cb] = 0; e.undisturbed[cb] = 0; }
+  if (a.child >= 0 && a.child < RV_MAXB) { const int cb = a.child; e.asleep[cb] = 0; e.sleep_count[cb] = 0; e.deact_count[cb] = 0; e.still_count[cb] = 0; e.undisturbed[cb] = 0; }
 }
 __global__ void k_set_friction(DevEnv* envs, int n, float mu_finger, float mu_table) {
   ENV_THREAD();
@@ -855,7 +855,8 @@ int rv_set_friction(rv_world* w, float mu_finger, float mu_table) {
 int rv_set_constraint_ex(rv_world* w, int32_t body, int32_t child, int32_t joint_type, const float* frame7, const float* child_frame7, float max_force) {
   WCHK(w);
   if (body < 0 || body >= RV_MAXB) return fail(RV_ERR_VALUE, "rv_set_constraint: not a movable body slot");
-  if (child < -1 || child >= RV_MAXB || child == body) return fail(RV_ERR_VALUE, "rv_set_constraint: the child is the world (-1) or another movable body slot");
+  if (child < -1 || child >= RV_MAXB + RV_NFRAME || child == body) return fail(RV_ERR_VALUE, "rv_set_constraint: the child is the world (-1), another movable body slot or RV_CHILD_LINK(frame)");
+  if (child >= RV_MAXB && joint_type != RV_JOINT_FIXED && joint_type != RV_JOINT_POINT2POINT) return fail(RV_ERR_NOTIMPL, "rv_set_constraint: a link of the arm as the other party: fixed and point2point joints");
   if (joint_type != RV_JOINT_FIXED && joint_type != RV_JOINT_POINT2POINT && joint_type != RV_JOINT_PRISMATIC && joint_type != RV_JOINT_REVOLUTE) return fail(RV_ERR_NOTIMPL, "rv_set_constraint: joint types built: fixed, point2point, prismatic, revolute");
   if (max_force >= 0.0f && !child_frame7) return fail(RV_ERR_VALUE, "rv_set_constraint: null target");
   ConArgs a; memset(&a, 0, sizeof(a));

@@ -428,7 +428,8 @@ class World(object):
 
     def set_constraint(self, body, target7, frame7=None, max_force=500.0, child=-1, joint_type='fixed'):
         """rv_set_constraint_ex: tie frame7 (in the body frame; None = the body frame) of movable body ``body`` to
-        the frame target7 -- of the world (child = -1) or, given in its frame, of movable body ``child`` -- by a
+        the frame target7 -- of the world (child = -1) or, given in its frame, of movable body ``child`` or of frame f of the arm
+        (child = abi.RV_CHILD_LINK(f): fixed / point2point only) -- by a
         'fixed', a 'point2point' or a 'prismatic' joint (sliding along the x axis of the target frame) with at most
         max_force N per row; max_force < 0 removes it."""
         if joint_type not in self.JOINT_TYPES:

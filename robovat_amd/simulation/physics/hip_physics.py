@@ -361,11 +361,27 @@ class HipPhysics(Physics):
         """A 'fixed', 'point2point', 'prismatic' (along joint_axis) or 'revolute' (about joint_axis) joint -- the four types of the
         reference's JOINT_TYPES_MAPPING (bullet_physics.py:20-25) -- between a frame of a movable body (the parent) and a frame of the world
         (child None: the constraint ControllableConstraint servoes) or of another movable body (the child).
-        Gear joints (and links of the arm as parties) are not built.  Returns the constraint uid."""
+        One party may be a LINK of the arm -- an `(ARM_UID, link_index)` entity as in the reference (bullet_physics.py:773-790),
+        e.g. an object attached to the hand: 'fixed' and 'point2point' joints; the link moves kinematically and takes no
+        impulse.  (The library's parent is always the movable body: with the link given as the parent the two frames swap
+        roles, which a fixed / point-to-point joint does not notice.)  Returns the constraint uid."""
         if joint_type not in ('fixed', 'point2point', 'prismatic', 'revolute'):
             raise NotImplementedError("joint types built: 'fixed', 'point2point', 'prismatic', 'revolute' (not %r)" % (joint_type,))
+
+        def is_link(uid):
+            return isinstance(uid, (tuple, list)) and len(uid) == 2 and uid[0] == ARM_UID
+        if is_link(parent_uid) and not is_link(child_uid) and child_uid is not None:
+            parent_uid, child_uid = child_uid, parent_uid
+            parent_frame_pose, child_frame_pose = child_frame_pose, parent_frame_pose
+        link = None
+        if is_link(child_uid):
+            link = int(child_uid[1])
+            if not 0 <= link < abi.RV_NFRAME:
+                raise ValueError('no such link of the arm: %r' % (child_uid,))
+            if joint_type not in ('fixed', 'point2point'):
+                raise NotImplementedError('a link of the arm as a party: fixed and point2point joints (not %r)' % (joint_type,))
         b = self._slot(parent_uid)
-        child = -1 if child_uid is None else self._slot(child_uid)
+        child = -1 if child_uid is None else (abi.RV_CHILD_LINK(link) if link is not None else self._slot(child_uid))
         if child == b:
             raise ValueError('a body cannot be constrained to itself')
         if b in self._constraints:
@@ -373,7 +389,9 @@ class HipPhysics(Physics):
         frame = Pose(parent_frame_pose if parent_frame_pose is not None else [[0, 0, 0], [0, 0, 0]])
         if child_frame_pose is None:        # where the joint frame of the parent is now (seen from the child)
             child_frame_pose = self.get_body_pose(b).transform(frame)
-            if child >= 0:
+            if link is not None:
+                child_frame_pose = self.get_link_pose((ARM_UID, link)).inverse().transform(child_frame_pose)
+            elif child >= 0:
                 child_frame_pose = self.get_body_pose(child).inverse().transform(child_frame_pose)
         pose = Pose(child_frame_pose)
         entry = {'frame': frame, 'pose': pose, 'max_force': 500.0, 'child': child, 'joint_type': joint_type}     # pybullet's default maxForce

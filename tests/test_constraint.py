@@ -350,3 +350,97 @@ def test_revolute_joint_is_a_hinge(backend):
     assert abs(ke_at_min - m * T.G * drop) < 0.12 * m * T.G * drop, (ke_at_min, m * T.G * drop)
     if hasattr(w, 'w'):
         w.close()
+
+
+def _qmul(a, b):
+    ax, ay, az, aw = a; bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def _attach_to_hand(w, n, link=7, drop=0.20, max_force=300.0, joint_type='fixed'):
+    """Put body 0 of every env `drop` below frame `link` of the arm and tie it to that frame; returns the relative pose."""
+    lp = np.asarray(w.link_poses(), np.float64)[:, link]
+    st = np.asarray(w.body_state(), np.float64).copy()
+    st[:, 0, :3] = lp[:, :3] + [0.0, 0.0, -drop]
+    st[:, 0, 3:7] = [0, 0, 0, 1]; st[:, 0, 7:] = 0
+    w.set_body_state(st)
+    rel = []
+    for i in range(1):          # (one constraint for every env of the world: the hand poses agree after the same reset command)
+        Rh = _qmat(lp[i, 3:7])
+        tp = Rh.T @ (st[i, 0, :3] - lp[i, :3])
+        qh_inv = lp[i, 3:7] * [-1, -1, -1, 1]
+        tq = _qmul(qh_inv, st[i, 0, 3:7])
+        rel = list(tp) + list(tq)
+    w.set_constraint(0, rel, max_force=max_force, child=abi.RV_CHILD_LINK(link), joint_type=joint_type)
+    return np.array(rel)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_a_body_fixed_to_the_hand_link_follows_the_arm(backend):
+    """A link of the arm as the other party of a constraint (bullet_physics.py:773-790: createConstraint with a
+    (body, link) entity), e.g. an object attached to the hand: the box hangs 20 cm under `right_hand` (clear of the finger pads) by a fixed joint,
+    the arm carries it through a 15 cm move, and the box stays where the joint says it is IN THE HAND FRAME (2 mm /
+    5e-3 in the quaternion while moving: the link is kinematic, the rows see its twist); released, it falls."""
+    w, cfg = T._world(backend)
+    w.reset()
+    rel = _attach_to_hand(w, 1)
+    lp0 = np.asarray(w.link_poses(), np.float64)[0, 7]
+    target = lp0.copy(); target[0] += 0.10; target[1] -= 0.08; target[2] += 0.08
+    w.set_link_target(np.asarray(target, np.float32)[None])
+    worst_p = worst_q = 0.0
+    for k in range(12):
+        w.step_sub(150)
+        lp = np.asarray(w.link_poses(), np.float64)[0, 7]
+        st = np.asarray(w.body_state(), np.float64)[0, 0]
+        want_p = lp[:3] + _qmat(lp[3:7]) @ rel[:3]
+        want_q = _qmul(lp[3:7], rel[3:7])
+        worst_p = max(worst_p, float(np.linalg.norm(st[:3] - want_p)))
+        worst_q = max(worst_q, float(min(np.abs(st[3:7] - want_q).max(), np.abs(st[3:7] + want_q).max())))
+    moved = np.linalg.norm(np.asarray(w.link_poses(), np.float64)[0, 7, :3] - lp0[:3])
+    assert moved > 0.12, moved
+    assert worst_p < 2e-3 and worst_q < 5e-3, (worst_p, worst_q)
+    z_held = float(np.asarray(w.body_state())[0, 0, 2])
+    w.remove_constraint(0)
+    w.step_sub(250)
+    assert float(np.asarray(w.body_state())[0, 0, 2]) < z_held - 0.05          # released: it falls
+    if hasattr(w, 'w'):
+        w.close()
+
+
+@pytest.mark.gpu
+def test_hip_equals_oracle_with_a_body_tied_to_a_link():
+    """HIP == float oracle bit for bit while the arm carries a body by a fixed joint to the hand and another swings from
+    a point-to-point joint on a finger link -- through link targets, a push of the other bodies and a release."""
+    from robovat_amd import lib
+    from oracle import orc
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(n_envs=32, seed=17, shape_names=names)
+    w, ref = lib.World(cfg, scene, device=0), orc.OracleWorld(cfg, scene, double=False)
+    w.reset(); ref.reset()
+    rel = _attach_to_hand(T._Np(w), 32)
+    _attach_to_hand(ref, 32)
+    lp = ref.link_poses()[:, 7]
+    for x in (w, ref):
+        x.set_constraint(1, [0.0, 0.0, -0.06, 0, 0, 0, 1], frame7=[0.01, 0.0, 0.02, 0, 0, 0, 1], max_force=80.0, child=abi.RV_CHILD_LINK(8), joint_type='point2point')
+    tgt = lp.copy(); tgt[:, 0] += 0.08; tgt[:, 2] -= 0.05
+    for x in (w, ref):
+        x.set_link_target(tgt.astype(np.float32))
+    for k in range(4):
+        w.step_sub(300); ref.step_sub(300)
+        assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32)), k
+        assert np.array_equal(w.joint_state().cpu().numpy(), ref.joint_state().astype(np.float32)), k
+    a = ref.policy_random(3)
+    w.set_actions(a); ref.set_actions(a); w.step_macro(); ref.step_macro()
+    assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
+    assert np.array_equal(w.env_counters().cpu().numpy(), ref.env_counters())
+    for x in (w, ref):
+        x.remove_constraint(0)
+    w.step_sub(200); ref.step_sub(200)
+    assert np.array_equal(w.body_state().cpu().numpy(), ref.body_state().astype(np.float32))
+    L = lib.load()
+    import ctypes as C
+    t7 = (C.c_float * 7)(0, 0, 0, 0, 0, 0, 1)
+    assert L.rv_set_constraint_ex(w.h, 0, abi.RV_CHILD_LINK(7), 1, None, t7, 10.0) == abi.RV_ERR_NOTIMPL      # prismatic to a link
+    assert L.rv_set_constraint_ex(w.h, 0, abi.RV_CHILD_LINK(abi.RV_NFRAME), 4, None, t7, 10.0) == abi.RV_ERR_VALUE
+    w.close()
