@@ -22,7 +22,8 @@ CASES = [('config 2', {}), ('crossing / concave', dict(TASK_NAME='crossing', LAY
                                                       'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07}),
          ('arm effort limit + tilted gravity', {'PHYSICS.ARM_EFFORT_LIMIT': 1, 'PHYSICS.GRAVITY_XY': (0.3, -0.2)}),
          ('dynamic limb, crowded', {'PHYSICS.LIMB_DYNAMICS': 1, 'MOVABLE.CONVEX.POSE.X': [0.5, 0.7], 'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07}),
-         ('user constraints (p2p and prismatic to the world, body - body fixed)', {'CONSTRAINTS': 1})]
+         ('user constraints (p2p and prismatic to the world, body - body fixed)', {'CONSTRAINTS': 1}),
+         ('user constraints (revolute to the world, fixed to the hand link, body - body prismatic)', {'CONSTRAINTS': 2})]
 bad = 0
 for name, over in CASES:
     scene, names = scenes.make_scene()
@@ -31,7 +32,14 @@ for name, over in CASES:
         cfg = configs.make_rv_config(env_cfg=configs.push_env_config(**over), n_envs=n, seed=1000 + seed, shape_names=names)
         w = lib.World(cfg, scene, device=0); o = orc.OracleWorld(cfg, scene, double=False)
         w.reset(); o.reset()
-        if cons:      # (the constraints are per world: every env gets them; a reset drops them, so no auto-reset below)
+        if cons == 2:
+            from robovat_amd import abi
+            qz = [0, 0, float(np.sin(0.2)), float(np.cos(0.2))]
+            for x in (w, o):
+                x.set_constraint(1, [0.6, 0.05 * (seed % 3), 0.1] + qz, frame7=[0.02, 0.0, 0.0] + qz, max_force=40.0, joint_type='revolute')
+                x.set_constraint(2, [0.0, 0.0, -0.22, 0, 0, 0, 1], max_force=120.0, child=abi.RV_CHILD_LINK(7))
+                x.set_constraint(3, [0.0, 0.0, 0.08, 0, 0, 0, 1], max_force=40.0, child=0, joint_type='prismatic')
+        elif cons:      # (the constraints are per world: every env gets them; a reset drops them, so no auto-reset below)
             for x in (w, o):
                 x.set_constraint(1, [0.6, 0.05 * (seed % 3), 0.12, 0, 0, 0, 1], frame7=[0.02, 0.01, 0.0, 0, 0, 0, 1], max_force=30.0, joint_type='point2point')
                 x.set_constraint(2, [0.0, 0.0, 0.07, 0, 0, 0, 1], max_force=40.0, child=0)
