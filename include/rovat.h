@@ -285,6 +285,13 @@ typedef struct rv_config {
    * calibration above plus uniform noise in [-cam_noise, +cam_noise], element by element: [0..4] the five intrinsics
    * (fx, fy, cx, cy, skew), [5..13] the rotation matrix, [14..16] the translation (KINECT2.DEPTH.*_NOISE; 0 = none) */
   float    cam_noise[17];
+  /* ArmEnv._reset_scene (arm_env.py:94-99): `if SIM.WALL.USE: self.wall = simulator.add_body(SIM.WALL.PATH, SIM.WALL.POSE,
+   * is_static=True)`.  wall_use = 1: every env.reset() puts a STATIC body (mass 0: it collides with the movable bodies and
+   * is seen by the cameras, nothing moves it) of shape template wall_shape, scaled by wall_scale, at wall_pose (x, y, z,
+   * quaternion) into body slot RV_MAXB - 1; n_bodies_max must then leave that slot free.  0: no wall */
+  int32_t  wall_use, wall_shape;
+  float    wall_scale;
+  float    wall_pose[7];
 } rv_config;
 
 /* Per-launch statistics of rv_step_macro / rv_reset (device-side reductions of

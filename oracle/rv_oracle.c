@@ -151,6 +151,13 @@ static const int BB_B[RV_NBB] = {1, 2, 3, 2, 3, 3};
 static const int BB_ROUND[3][2] = {{0, 5}, {1, 4}, {2, 3}};
 
 static int body_on(const orc_env* e, int b) { return e->bp[b].active && !e->bp[b].frozen && !e->bp[b].asleep; }
+/* A STATIC body (Simulator.add_body(..., is_static=True), simulator.py:195-224 -> bullet_physics.py:143-181 useFixedBase;
+ * the wall of ArmEnv._reset_scene, arm_env.py:94-99): mass 0 as in Bullet -- inverse mass and inverse inertia 0.  It keeps
+ * its slot among the bodies and its pair manifolds with the other bodies (its rows see a party that no impulse moves); it has
+ * no manifold with the table or the arm, takes no gravity and is not integrated.  The env logic (observations, reward,
+ * safety, policies, stability waits) looks at MOVABLE bodies only. */
+static int body_static(const orc_env* e, int b) { return e->bp[b].inv_mass == R(0.0); }
+static int body_movable(const orc_env* e, int b) { return e->bp[b].active && !body_static(e, b); }
 /* Contact-breaking threshold of a manifold = rv_config.breaking x the smaller "angular motion disc" of the
  * two shapes (btCollisionShape::getContactBreakingThreshold, btPersistentManifold): a movable's disc is
  * its bounding radius about the body origin, a collider box's its half diagonal; the table's and the
@@ -519,9 +526,9 @@ static void arm_motor_step(const orc_world* w, orc_env* e) {
 static void body_set_mass(const orc_world* w, orc_env* e, int b, real mass) {
   const rv_shape* s = &w->scene.shapes[e->bp[b].shape];
   orc_bparam* p = &e->bp[b];
-  p->mass = mass; p->inv_mass = R(1.0) / mass;
+  p->mass = mass; p->inv_mass = mass > R(0.0) ? R(1.0) / mass : R(0.0);      /* (mass 0: a static body) */
   real s2 = p->scale * p->scale;
-  for (int k = 0; k < 3; ++k) p->inv_inertia[k] = R(1.0) / (mass * s2 * (real)s->inertia_k[k]);
+  for (int k = 0; k < 3; ++k) p->inv_inertia[k] = mass > R(0.0) ? R(1.0) / (mass * s2 * (real)s->inertia_k[k]) : R(0.0);
   p->radius = (real)s->radius * p->scale + (real)w->cfg.margin;
 }
 
@@ -766,6 +773,7 @@ static void collide_all(const orc_world* w, orc_env* e) {
   /* refresh */
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!(e->bp[b].active && !e->bp[b].frozen)) { e->man[TIDX(b)].n = 0; e->man[AIDX(b)].n = 0; continue; }
+    if (body_static(e, b)) { e->man[TIDX(b)].n = 0; e->man[AIDX(b)].n = 0; run[TIDX(b)] = 0; run[AIDX(b)] = 0; continue; }   /* a static body: pair manifolds only */
     if (e->bp[b].asleep) continue; /* manifolds of a sleeping body stay frozen */
     {
       orc_manifold* m = &e->man[TIDX(b)];
@@ -785,8 +793,8 @@ static void collide_all(const orc_world* w, orc_env* e) {
   }
   for (int k = 0; k < RV_NBB; ++k) {
     int a = BB_A[k], b = BB_B[k];
-    int on = e->bp[a].active && !e->bp[a].frozen && e->bp[b].active && !e->bp[b].frozen;
-    if (!on) { e->man[BBIDX(k)].n = 0; continue; }
+    int on = e->bp[a].active && !e->bp[a].frozen && e->bp[b].active && !e->bp[b].frozen && !(body_static(e, a) && body_static(e, b));
+    if (!on) { e->man[BBIDX(k)].n = 0; run[BBIDX(k)] = 0; continue; }
     if (e->bp[a].asleep || e->bp[b].asleep) continue;
     {
       orc_manifold* m = &e->man[BBIDX(k)];
@@ -1742,7 +1750,7 @@ static void sim_substep(const orc_world* w, orc_env* e) {
         real r = e->bp[a].radius + e->bp[b].radius + brk_bb(e, c, a, b);
         if (v3dot(d, d) < r * r) wake[b] = 1;
       }
-      if (e->arm_enabled && e->arm_moving) {
+      if (e->arm_enabled && e->arm_moving && !body_static(e, b)) {      /* (a static body has no manifold with the arm) */
         /* the arm wakes a sleeper when one of its boxes comes within the contact-
          * breaking distance of the body's hulls (= when a contact point would be
          * created); boxes whose AABB is farther than that from the body's are skipped */
@@ -1804,6 +1812,7 @@ static void sim_substep(const orc_world* w, orc_env* e) {
   }
   for (int b = 0; b < RV_MAXB; ++b) {
     if (!body_on(e, b)) continue;
+    if (body_static(e, b)) { e->mot[b] = R(0.0); continue; }
     orc_body* B = &e->body[b];
     B->v[0] += (real)c->gravity_xy[0] * dt; B->v[1] += (real)c->gravity_xy[1] * dt;
     B->v[2] += (real)c->gravity_z * dt;
@@ -1861,6 +1870,7 @@ static void sim_substep(const orc_world* w, orc_env* e) {
       }
     }
     real vv = v3dot(B->v, B->v), ww = v3dot(B->w, B->w);
+    if (!body_static(e, b)) {      /* (a static body stays where it is: its velocities are zero, no impulse changes them) */
     v3madd(B->p, B->p, B->v, dt);
     real wq[4] = {B->w[0], B->w[1], B->w[2], R(0.0)}, dq[4];
     qmul(dq, wq, B->q);
@@ -1869,6 +1879,7 @@ static void sim_substep(const orc_world* w, orc_env* e) {
     if (B->p[2] < (real)c->ground_z - (real)c->fall_depth) {
       e->bp[b].frozen = 1;
       v3set(B->v, R(0.0), R(0.0), R(0.0)); v3set(B->w, R(0.0), R(0.0), R(0.0));
+    }
     }
     /* substeps in a row below the sleep thresholds (the deactivation counter; also what makes a row a 'rest' row of the solver) */
     if (vv < (real)c->sleep_lin * (real)c->sleep_lin && ww < (real)c->sleep_ang * (real)c->sleep_ang) e->bp[b].sleep_count++;
@@ -1986,7 +1997,7 @@ static int wait_until_stable(const orc_world* w, orc_env* e, unsigned mask, real
 static void compute_obs(orc_env* e) {
   memcpy(e->prev_obs_pos, e->obs_pos, sizeof(e->obs_pos));
   for (int b = 0; b < RV_MAXB; ++b) {
-    if (e->bp[b].active) v3cpy(e->obs_pos[b], e->body[b].p);
+    if (body_movable(e, b)) v3cpy(e->obs_pos[b], e->body[b].p);      /* (self.movable_bodies: a static body is not one) */
     else v3set(e->obs_pos[b], R(0.0), R(0.0), R(0.0));
   }
 }
@@ -2067,7 +2078,7 @@ static void compute_waypoints(const rv_config* c, const real* action, real* star
   set_gripper_pose(end, ex, ey, z);
 }
 static int arm_touches_movables(const orc_env* e) {
-  for (int b = 0; b < RV_MAXB; ++b) if (e->bp[b].active && e->flag_arm_body[b]) return 1;
+  for (int b = 0; b < RV_MAXB; ++b) if (body_movable(e, b) && e->flag_arm_body[b]) return 1;
   return 0;
 }
 /* PushEnv._check_safety (push_env.py:857-898) */
@@ -2086,7 +2097,7 @@ static int check_safety(const orc_world* w, const orc_env* e, real start_z) {
     real lx = (real)c->table_center[0] - R(0.5) * (real)c->workspace_x_range, hx = (real)c->table_center[0] + R(0.5) * (real)c->workspace_x_range;
     real ly = (real)c->table_center[1] - R(0.5) * (real)c->workspace_y_range, hy = (real)c->table_center[1] + R(0.5) * (real)c->workspace_y_range;
     for (int b = 0; b < RV_MAXB; ++b) {
-      if (!e->bp[b].active) continue;
+      if (!body_movable(e, b)) continue;
       const real* p = e->body[b].p;
       if (p[0] < lx || p[0] > hx || p[1] < ly || p[1] > hy) return 0;
     }
@@ -2365,6 +2376,20 @@ static void camera_reset(const rv_config* c, orc_env* e, int gid, int use_noise)
     if (k < 5) e->cam_intrinsics[k] = v; else if (k < 14) e->cam_rotation[k - 5] = v; else e->cam_translation[k - 14] = v;
   }
 }
+/* ArmEnv._reset_scene's wall (arm_env.py:94-99): simulator.add_body(SIM.WALL.PATH, SIM.WALL.POSE, is_static=True) -- a
+ * static body (mass 0) in the last body slot */
+static void wall_place(const orc_world* w, orc_env* e) {
+  const rv_config* c = &w->cfg;
+  if (!c->wall_use) return;
+  const int b = RV_MAXB - 1;
+  orc_bparam* p = &e->bp[b];
+  p->active = 1; p->frozen = 0; p->asleep = 0; p->sleep_count = 0; p->deact_count = 0; p->still_count = 0; p->undisturbed = 0; p->con_on = 0;
+  p->shape = c->wall_shape; p->scale = (real)c->wall_scale; p->friction = R(1.0);     /* (URDF template default, tools/templates/urdf_template.xml:11-22) */
+  body_set_mass(w, e, b, R(0.0));
+  for (int k = 0; k < 3; ++k) e->body[b].p[k] = (real)c->wall_pose[k];
+  for (int k = 0; k < 4; ++k) e->body[b].q[k] = (real)c->wall_pose[3 + k];
+  v3set(e->body[b].v, R(0.0), R(0.0), R(0.0)); v3set(e->body[b].w, R(0.0), R(0.0), R(0.0));
+}
 static void env_reset(const orc_world* w, orc_env* e, int gid) {
   const rv_config* c = &w->cfg;
   orc_rng g; rng_init(&g, c->seed_lo, c->seed_hi, (uint32_t)gid, STREAM_RESET, (uint32_t)e->reset_count);
@@ -2391,6 +2416,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
     real poses[RV_MAXB][7];
     for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].deact_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; e->bp[b].con_on = 0; }
     e->n_bodies = 1;
+    wall_place(w, e);
     sample_poses(w, e, &g, 1, poses);
     int shape = c->movable_shapes[rng_randint(&g, c->n_movable_shapes)];
     real scale = rng_uniform(&g, (real)c->scale_range[0], (real)c->scale_range[1]);
@@ -2406,6 +2432,7 @@ static void env_reset(const orc_world* w, orc_env* e, int gid) {
     real poses[RV_MAXB][7];
     for (int b = 0; b < RV_MAXB; ++b) { e->bp[b].active = 0; e->bp[b].frozen = 0; e->bp[b].asleep = 0; e->bp[b].sleep_count = 0; e->bp[b].deact_count = 0; e->bp[b].still_count = 0; e->bp[b].undisturbed = 0; e->bp[b].con_on = 0; }
     for (int i = 0; i < RV_NMAN; ++i) e->man[i].n = 0;
+    wall_place(w, e);
     sample_poses(w, e, &g, nb, poses);
     for (int i = 0; i < nb; ++i) {
       int use_target = (i == 0 && c->use_tiles && c->n_target > 0 && c->n_target_shapes > 0);
@@ -2584,7 +2611,7 @@ void orc_policy_heuristic(orc_world* w, int max_attempts, float* actions) {
   for (int i = 0; i < w->n; ++i) {
     const orc_env* e = &w->env[i];
     int nb = 0;
-    for (int b = 0; b < RV_MAXB; ++b) nb += e->bp[b].active;
+    for (int b = 0; b < RV_MAXB; ++b) nb += body_movable(e, b);
     if (nb == 0) nb = 1;
     /* counters come from the observation = the env.attributes snapshot (push_policy.py:46-49) */
     const int n_ep = e->obs_num_episodes, n_st = e->obs_num_steps;
@@ -2836,14 +2863,14 @@ void orc_observe(orc_world* w, double* position, double* body_mask, int64_t* att
     for (int b = 0; b < RV_MAXB; ++b) {
       const size_t ib = (size_t)i * RV_MAXB + b;
       for (int k = 0; k < 3; ++k) position[ib * 3 + k] = e->obs_pos[b][k];
-      body_mask[ib] = e->bp[b].active;
+      body_mask[ib] = body_movable(e, b);
       real eu[3] = {R(0.0), R(0.0), R(0.0)};
-      if (e->bp[b].active) quat_to_euler(e->body[b].q, eu);
+      if (body_movable(e, b)) quat_to_euler(e->body[b].q, eu);
       if (pose) for (int k = 0; k < 3; ++k) { pose[ib * 6 + k] = e->obs_pos[b][k]; pose[ib * 6 + 3 + k] = eu[k]; }
       if (pose2d) { pose2d[ib * 3] = e->obs_pos[b][0]; pose2d[ib * 3 + 1] = e->obs_pos[b][1]; pose2d[ib * 3 + 2] = eu[2]; }
       if (yaw_cossin) {
         real sn = R(0.0), cs = R(0.0);
-        if (e->bp[b].active) rsincos(eu[2], &sn, &cs);
+        if (body_movable(e, b)) rsincos(eu[2], &sn, &cs);
         yaw_cossin[ib * 2] = cs; yaw_cossin[ib * 2 + 1] = sn;
       }
     }
@@ -3055,7 +3082,7 @@ void orc_point_cloud(orc_world* w, float* out) {
     for (int b = 0; b < RV_MAXB; ++b) {
       float* o = out + ((size_t)i * RV_MAXB + b) * (size_t)P * 3;
       int n = 0;
-      if (e->bp[b].active) {
+      if (body_movable(e, b)) {      /* (the segmented cloud has the movable bodies; a static body is rendered -- it occludes -- but not sampled) */
         const rv_shape* sh = &w->scene.shapes[e->bp[b].shape];
         real mu = R(1e30), xu = R(-1e30), mv = R(1e30), xv = R(-1e30), mz = R(1e30);
         for (int h = 0; h < sh->n_hulls; ++h)

@@ -145,6 +145,7 @@ class rv_config(C.Structure):
         ('ground_z', f32), ('ground_friction', f32), ('rolling_friction', f32), ('wake_gap', f32), ('deact_lin', f32), ('deact_ang', f32), ('deact_steps', i32),
         ('gravity_xy', f32 * 2), ('arm_effort_limit', i32), ('limb_dynamics', i32), ('solver_stall', i32), ('solver_tol_rest', f32),
         ('cam_noise', f32 * 17),
+        ('wall_use', i32), ('wall_shape', i32), ('wall_scale', f32), ('wall_pose', f32 * 7),
     ]
 
 

@@ -73,6 +73,10 @@ PUSH_ENV_CONFIG = {
                   'THICKNESS': 0.05, 'FRICTION': 1.0},
         # the ground the table stands on (arm_env.py:85-88); z relative to the nominal table top
         'GROUND': {'Z': -0.75, 'FRICTION': 1.0},
+        # arm_env.py:94-99: an optional static body behind the table (the reference's YAML with SIM.WALL.PATH / POSE is
+        # not distributed: BUILD-CHOSEN slab 'wall' of scenes.default_shape_hulls at the far edge of the table).  With
+        # USE set the wall takes body slot RV_MAXB - 1: MAX_MOVABLE_BODIES <= 3
+        'WALL': {'USE': False, 'SHAPE': 'wall', 'SCALE': 1.0, 'POSE': [[1.0, 0.0, 0.4], [0, 0, 0]]},
         'STEPS_CHECK': 10,
         'MAX_PHASE_STEPS': 2000,
         'MAX_MOTION_STEPS': 3000,
@@ -374,6 +378,19 @@ def make_rv_config(env_cfg=None, robot_cfg=None, shape_names=None, n_envs=1,
     if cam.get('TRANSLATION_NOISE') is not None:
         noise[14:17] = np.abs(np.asarray(cam.TRANSLATION_NOISE, dtype=np.float64)).reshape(3)
     abi.assign(c.cam_noise, noise.tolist())
+    # ArmEnv._reset_scene's wall (arm_env.py:94-99): a static body in the last body slot
+    wall = env_cfg.SIM.get('WALL')
+    if wall is not None and wall.get('USE'):
+        from robovat_amd.math import Pose
+        if c.n_bodies_max > abi.RV_MAXB - 1:
+            raise ValueError('SIM.WALL.USE: the wall takes body slot %d, MAX_MOVABLE_BODIES must be <= %d' % (abi.RV_MAXB - 1, abi.RV_MAXB - 1))
+        if wall.SHAPE not in shape_names:
+            raise ValueError('SIM.WALL.SHAPE %r is not a shape template of the scene' % (wall.SHAPE,))
+        wp = Pose(wall.POSE)
+        c.wall_use = 1
+        c.wall_shape = list(shape_names).index(wall.SHAPE)
+        c.wall_scale = float(wall.get('SCALE', 1.0))
+        abi.assign(c.wall_pose, [float(v) for v in list(wp.position) + list(wp.quaternion)])
     if env_cfg.OBS.get('CROP_MIN') is not None and env_cfg.OBS.get('CROP_MAX') is not None:
         c.use_crop = 1
         abi.assign(c.crop_min, list(env_cfg.OBS.CROP_MIN))

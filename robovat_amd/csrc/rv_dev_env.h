@@ -295,6 +295,13 @@ RV_DEV float wake_range(const DevEnv& e, const rv_arm* arm, const rv_config* c, 
 RV_DEV float sim_time(const Shared& S, const Consts& K) { return K.cfg->dt * (float)S.e.sim_steps; }
 RV_DEV int body_present(const DevEnv& e, int b) { return e.active[b] && !e.frozen[b]; }
 RV_DEV int body_on(const DevEnv& e, int b) { return e.active[b] && !e.frozen[b] && !e.asleep[b]; }
+// A STATIC body (Simulator.add_body(..., is_static=True), simulator.py:195-224; the wall of ArmEnv._reset_scene,
+// arm_env.py:94-99): mass 0 as in Bullet -- inverse mass and inverse inertia 0.  It keeps its slot and its pair manifolds
+// with the other bodies (their rows see a party that no impulse moves); it has no manifold with the table or the arm, takes
+// no gravity and is not integrated; the arm does not wake it.  The env logic (observations, reward, safety, policies) looks
+// at MOVABLE bodies only.
+RV_DEV int body_static(const DevEnv& e, int b) { return e.inv_mass[b] == 0.0f; }
+RV_DEV int body_movable(const DevEnv& e, int b) { return e.active[b] && !body_static(e, b); }
 // start of a launch: nothing stepped yet (one lane)
 RV_DEV void launch_counters_zero(DevEnv& e) {
   e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; e.stepped = 0;
@@ -717,9 +724,9 @@ RV_DEV void robot_grip(Shared& S, const Consts& K, float value) {
 // ---------------------------------------------------------- rigid bodies --
 RV_DEV void body_set_mass(DevEnv& e, const Consts& K, int b, float mass) {
   const rv_shape* s = &K.scene->shapes[e.shape[b]];
-  e.mass[b] = mass; e.inv_mass[b] = 1.0f / mass;
+  e.mass[b] = mass; e.inv_mass[b] = mass > 0.0f ? 1.0f / mass : 0.0f;      // (mass 0: a static body)
   float s2 = e.scale[b] * e.scale[b];
-  for (int k = 0; k < 3; ++k) e.inv_inertia[b][k] = 1.0f / (mass * s2 * s->inertia_k[k]);
+  for (int k = 0; k < 3; ++k) e.inv_inertia[b][k] = mass > 0.0f ? 1.0f / (mass * s2 * s->inertia_k[k]) : 0.0f;
   e.radius[b] = s->radius * e.scale[b] + K.cfg->margin;
 }
 RV_DEV void cache_shape_meta(Shared& S, const Consts& K, int b) {
@@ -915,7 +922,7 @@ RV_DEV void owner_decode(const Shared& S, const Consts& K, int owner, int arm_on
   o.guess0 = mk(0.0f, 0.0f, 1.0f);
   if (owner < RV_MAXB) {
     const int a = owner; o.a = a; o.mi = RV_TIDX(a); o.kind = 0;
-    if (!body_present(e, a)) o.clear = 1;
+    if (!body_present(e, a) || body_static(e, a)) o.clear = 1;      // (a static body: pair manifolds only)
     else if (!e.asleep[a]) {
       o.live = 1;
       float r = e.radius[a] + brk_body(e, c, a);
@@ -929,7 +936,7 @@ RV_DEV void owner_decode(const Shared& S, const Consts& K, int owner, int arm_on
   } else if (owner < RV_MAXB + RV_NBB) {
     const int k = owner - RV_MAXB, a = bb_a(k), b = bb_b(k);
     o.a = a; o.b = b; o.mi = RV_BBIDX(k); o.kind = 1;
-    if (!(body_present(e, a) && body_present(e, b))) o.clear = 1;
+    if (!(body_present(e, a) && body_present(e, b)) || (body_static(e, a) && body_static(e, b))) o.clear = 1;
     else if (!e.asleep[a] && !e.asleep[b]) {
       o.live = 1;
       v3 d = sub(ld3(e.body[a]), ld3(e.body[b]));
@@ -939,7 +946,7 @@ RV_DEV void owner_decode(const Shared& S, const Consts& K, int owner, int arm_on
   } else if (owner < RV_NMAN) {
     const int a = owner - RV_MAXB - RV_NBB;
     o.a = a; o.mi = RV_AIDX(a); o.kind = 2;
-    if (!body_present(e, a)) o.clear = 1;
+    if (!body_present(e, a) || body_static(e, a)) o.clear = 1;
     else if (!e.asleep[a]) {
       if (!arm_on) o.clear = 1;
       else { o.live = 1; o.role = 2; o.n_outer = RV_NCOL; o.n_inner = S.n_hulls[a]; }
@@ -2464,7 +2471,7 @@ RV_DEV void coast_measure_clearances(Shared& S, const Consts& K, const int col) 
   const float tclear = zc > sc ? zc : sc;                 // either test rejecting is enough
   float bclear = 1e30f;
   for (int b = 0; b < RV_MAXB; ++b) {
-    if (!body_present(e, b)) continue;
+    if (!body_present(e, b) || body_static(e, b)) continue;      // (the arm does not wake a static body)
     float d = fsqrtr(aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col])) - (wake_range(e, K.arm, c, b, col) + 2.0f * c->margin);
     d = fmaxr(d, S.s.sep[b][col]);   // the distance bound left by the last wake query, if better
     bclear = fminr(bclear, d);
@@ -3125,7 +3132,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
 #pragma unroll
           for (int x = 0; x < 3; ++x) { lo[x] = S.s.colmin[col][x] - T; hi[x] = S.s.colmax[col][x] + T; }
           if (isb) {
-            if (body_present(e, b)) {
+            if (body_present(e, b) && !body_static(e, b)) {      // (a static body has no business with the arm)
               if (e.asleep[b]) {
                 const float r = wake_range(e, arm, c, b, col) + 2.0f * c->margin;
                 near = aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, lo, hi) < r * r;
@@ -3206,7 +3213,7 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
       // is positive the query cannot hit and is skipped.  Exact: only the work changes.
       float sep = S.s.sep[b][col] - S.s.coltravel[col];
       if (S.s.far_n != 0) sep = 0.0f;        // ("arm far" substeps did not keep the bound up to date: it starts again)
-      if (arm_on && S.s.arm_moving && body_present(e, b) && e.asleep[b]) {
+      if (arm_on && S.s.arm_moving && body_present(e, b) && e.asleep[b] && !body_static(e, b)) {
         float r = wake_range(e, K.arm, c, b, col) + 2.0f * c->margin;
         nr = aabb_aabb_dist2(e.baabb[b], e.baabb[b] + 3, S.s.colmin[col], S.s.colmax[col]) < r * r;
         if (nr && sep > 0.0f) nr = 0;
@@ -3335,12 +3342,15 @@ RV_DEV int sim_substep_light(Shared& S, const Consts& K) {
       }
       if (body_on(e, b)) {
         float dt = c->dt;
+        if (body_static(e, b)) S.s.mot[b] = 0.0f;      // (no gravity on a static body; its velocities stay zero)
+        else {
         e.body[b][7] += c->gravity_xy[0] * dt; e.body[b][8] += c->gravity_xy[1] * dt;
         e.body[b][9] += c->gravity_z * dt;
         v3 v = scale(ld3(e.body[b] + 7), c->lin_damp);
         v3 w = scale(ld3(e.body[b] + 10), c->ang_damp);
         st3(e.body[b] + 7, v); st3(e.body[b] + 10, w);
         S.s.mot[b] = (len(v) + len(w) * e.radius[b]) * dt;
+        }
         m3 m = qmat(ldq(e.body[b] + 3));
         stm(S.s.rot[b], m);
         const float* ii = e.inv_inertia[b];
@@ -3402,11 +3412,11 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       const int mi = lane >> 2, i = lane & 3;
       // whose manifold, and is it refreshed?  (the same conditions as owner_decode's `live`)
       int kind, a, b = -1, live;
-      if (mi < RV_MAXB) { kind = 0; a = mi; live = body_present(e, a) && !e.asleep[a]; }
+      if (mi < RV_MAXB) { kind = 0; a = mi; live = body_present(e, a) && !e.asleep[a] && !body_static(e, a); }
       else if (mi < RV_MAXB + RV_NBB) {
         kind = 1; a = bb_a(mi - RV_MAXB); b = bb_b(mi - RV_MAXB);
-        live = body_present(e, a) && body_present(e, b) && !e.asleep[a] && !e.asleep[b];
-      } else { kind = 2; a = mi - RV_MAXB - RV_NBB; live = body_present(e, a) && !e.asleep[a] && arm_on; }
+        live = body_present(e, a) && body_present(e, b) && !e.asleep[a] && !e.asleep[b] && !(body_static(e, a) && body_static(e, b));
+      } else { kind = 2; a = mi - RV_MAXB - RV_NBB; live = body_present(e, a) && !e.asleep[a] && arm_on && !body_static(e, a); }
       float d = 0.0f; int rm = 0;
       if (live && i < e.man[mi].n) refresh_point(S, K, kind, a, b, e.man[mi], i, &d, &rm);
       S.s.rf_dist[lane] = d; S.s.rf_rm[lane] = rm;
@@ -3454,7 +3464,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
       for (int t = (lane - RV_NMAN - RV_NCOL) * 2; t < (lane - RV_NMAN - RV_NCOL) * 2 + 2; ++t) {
         const int b = t / RV_NCOL, col = t - b * RV_NCOL;
         int near = 0;
-        if (arm_on && body_on(e, b)) {
+        if (arm_on && body_on(e, b) && !body_static(e, b)) {
           const float r = e.radius[b] + brk_ab(e, arm, c, b, col);
           near = !(sphere_aabb_dist2(ld3(e.body[b]), S.s.colmin[col], S.s.colmax[col]) >= r * r);
         }
@@ -3922,9 +3932,11 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
           }
         }
         v3 v = ld3(e.body[b] + 7), w = ld3(e.body[b] + 10);
-        v3 p = madd(ld3(e.body[b]), v, dt);
-        st3(e.body[b], p);
+        v3 p = ld3(e.body[b]);
         q4 q = ldq(e.body[b] + 3);
+        if (!body_static(e, b)) {      // (a static body stays where it is: its velocities are zero, no impulse changes them)
+        p = madd(p, v, dt);
+        st3(e.body[b], p);
         q4 wq; wq.x = w.x; wq.y = w.y; wq.z = w.z; wq.w = 0.0f;
         q4 dq = qmul(wq, q);
         q.x += 0.5f * dt * dq.x; q.y += 0.5f * dt * dq.y; q.z += 0.5f * dt * dq.z; q.w += 0.5f * dt * dq.w;
@@ -3933,6 +3945,7 @@ RV_DEV void sim_substep_heavy(Shared& S, const Consts& K) {
         if (p.z < c->ground_z - c->fall_depth) {
           e.frozen[b] = 1;
           st3(e.body[b] + 7, mk(0, 0, 0)); st3(e.body[b] + 10, mk(0, 0, 0));
+        }
         }
         // substeps in a row below the sleep thresholds (the deactivation counter; also what makes a row a 'rest' row of the solver)
         if (dot(v, v) < c->sleep_lin * c->sleep_lin && dot(w, w) < c->sleep_ang * c->sleep_ang) e.sleep_count[b]++;
@@ -4308,7 +4321,7 @@ RV_DEV void compute_obs(DevEnv& e) {
   for (int b = 0; b < RV_MAXB; ++b)
     for (int k = 0; k < 3; ++k) {
       e.prev_obs_pos[b][k] = e.obs_pos[b][k];
-      e.obs_pos[b][k] = e.active[b] ? e.body[b][k] : 0.0f;
+      e.obs_pos[b][k] = body_movable(e, b) ? e.body[b][k] : 0.0f;      // (self.movable_bodies: a static body is not one)
     }
   for (int b = 0; b < RV_MAXB; ++b)
     for (int k = 0; k < 4; ++k) e.obs_quat[b][k] = e.body[b][3 + k];
@@ -4322,6 +4335,7 @@ RV_DEV void obs_snap_fill(const DevEnv& e, const rv_arm* arm, ObsSnap& s, const 
     for (int k = 0; k < 7; ++k) s.pose[b][k] = !at_obs ? e.body[b][k] : (k < 3 ? e.obs_pos[b][k] : e.obs_quat[b][k - 3]);
     s.scale[b] = e.scale[b];
     s.shape[b] = e.active[b] ? e.shape[b] : -1;
+    s.is_static[b] = body_static(e, b);
   }
   s.table_z = e.table_z;
   for (int k = 0; k < 5; ++k) s.cam_intrinsics[k] = e.cam_intrinsics[k];
@@ -4346,7 +4360,7 @@ RV_DEV void obs_snap_arm(const DevEnv& e, const rv_arm* arm, ObsSnap& s) {
 RV_DEV void obs_write_row(const DevEnv* e, const rv_obs_buffers& o, size_t row, const rv_config* cfg) {
   for (int b = 0; b < RV_MAXB; ++b) {
     const size_t ib = row * RV_MAXB + b;
-    const int on = e ? e->active[b] : 0;
+    const int on = e ? body_movable(*e, b) : 0;
     float pos[3] = {0.0f, 0.0f, 0.0f}, eu[3] = {0.0f, 0.0f, 0.0f};
     if (e) for (int k = 0; k < 3; ++k) pos[k] = e->obs_pos[b][k];
     if (o.d_position) for (int k = 0; k < 3; ++k) o.d_position[ib * 3 + k] = pos[k];
@@ -4459,7 +4473,7 @@ RV_DEV void compute_waypoints(const rv_config* c, const float* action, float* st
   set_gripper_pose(end, ex, ey, z);
 }
 RV_DEV int arm_touches_movables(const DevEnv& e) {
-  for (int b = 0; b < RV_MAXB; ++b) if (e.active[b] && e.flag_arm_body[b]) return 1;
+  for (int b = 0; b < RV_MAXB; ++b) if (body_movable(e, b) && e.flag_arm_body[b]) return 1;
   return 0;
 }
 // PushEnv._check_safety (push_env.py:857-898)
@@ -4477,7 +4491,7 @@ RV_DEV int check_safety(const DevEnv& e, const rv_config* c, float start_z) {
     float lx = c->table_center[0] - 0.5f * c->workspace_x_range, hx = c->table_center[0] + 0.5f * c->workspace_x_range;
     float ly = c->table_center[1] - 0.5f * c->workspace_y_range, hy = c->table_center[1] + 0.5f * c->workspace_y_range;
     for (int b = 0; b < RV_MAXB; ++b) {
-      if (!e.active[b]) continue;
+      if (!body_movable(e, b)) continue;
       const float* p = e.body[b];
       if (p[0] < lx || p[0] > hx || p[1] < ly || p[1] > hy) return 0;
     }
@@ -4804,6 +4818,19 @@ RV_DEV void camera_reset(DevEnv& e, const rv_config* c, int gid, int use_noise) 
     if (k < 5) e.cam_intrinsics[k] = v; else if (k < 14) e.cam_rotation[k - 5] = v; else e.cam_translation[k - 14] = v;
   }
 }
+// ArmEnv._reset_scene's wall (arm_env.py:94-99): simulator.add_body(SIM.WALL.PATH, SIM.WALL.POSE, is_static=True) -- a
+// static body (mass 0) in the last body slot (lane 0)
+RV_DEV void wall_place(Shared& S, const Consts& K) {
+  const rv_config* c = K.cfg; DevEnv& e = S.e;
+  if (!c->wall_use) return;
+  const int b = RV_MAXB - 1;
+  e.active[b] = 1; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; e.con_on[b] = 0;
+  e.shape[b] = c->wall_shape; e.scale[b] = c->wall_scale; e.friction[b] = 1.0f;     // (URDF template default, tools/templates/urdf_template.xml:11-22)
+  body_set_mass(e, K, b, 0.0f);
+  cache_shape_meta(S, K, b);
+  for (int k = 0; k < 7; ++k) e.body[b][k] = c->wall_pose[k];
+  for (int k = 7; k < 13; ++k) e.body[b][k] = 0.0f;
+}
 RV_DEV void env_reset_begin(Shared& S, const Consts& K, int gid, int zero_counters) {
   const rv_config* c = K.cfg;
   RV_LANES_BEGIN
@@ -4842,6 +4869,7 @@ RV_DEV void env_reset_begin(Shared& S, const Consts& K, int gid, int zero_counte
         Rng& g = S.s.rng;
         for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; e.con_on[b] = 0; }
         e.n_bodies = 1;
+        wall_place(S, K);
         sample_poses(S, K, 1);
         int shape = c->movable_shapes[rng_randint(g, c->n_movable_shapes)];
         float sc = rng_uniform(g, c->scale_range[0], c->scale_range[1]);
@@ -4863,6 +4891,7 @@ RV_DEV void env_reset_layout(Shared& S, const Consts& K) {
     DevEnv& e = S.e;
     if (lane == 0) {
       for (int b = 0; b < RV_MAXB; ++b) { e.active[b] = 0; e.frozen[b] = 0; e.asleep[b] = 0; e.sleep_count[b] = 0; e.deact_count[b] = 0; e.still_count[b] = 0; e.undisturbed[b] = 0; e.con_on[b] = 0; }
+      wall_place(S, K);
       sample_poses(S, K, e.n_bodies);
     }
     if (lane >= 1 && lane <= RV_NMAN) e.man[lane - 1].n = 0;

@@ -31,6 +31,7 @@ struct ObsSnap {
   float pose[RV_MAXB][7];   // pos3, quat4 (xyzw)
   float scale[RV_MAXB];
   int shape[RV_MAXB];       // -1: body absent
+  int is_static[RV_MAXB];   // a static body (the wall): rendered -- it occludes -- but not one of the segmented clouds
   float table_z;
   float cam_intrinsics[5], cam_rotation[9], cam_translation[3];   // the env's camera (DevEnv: rv_config's calibration + reset noise)
   uint32_t rng_arg;         // reset_count * 4096 + num_steps: one sampling stream per observation

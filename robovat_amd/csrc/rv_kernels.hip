@@ -228,7 +228,7 @@ __global__ void k_query_contacts(const DevEnv* envs, int n, uint8_t* out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
   const DevEnv& e = envs[i]; uint8_t* o = out + (size_t)i * (2 + RV_MAXB);
   o[0] = (uint8_t)e.flag_arm_table; o[1] = (uint8_t)arm_touches_movables(e);
-  for (int b = 0; b < RV_MAXB; ++b) o[2 + b] = (uint8_t)(e.active[b] && e.flag_arm_body[b]);
+  for (int b = 0; b < RV_MAXB; ++b) o[2 + b] = (uint8_t)(e.active[b] && e.flag_arm_body[b]);      // (a static body: never)
 }
 __global__ void k_get_camera(const DevEnv* envs, int n, float* out) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); if (i >= n) return;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
   __syncthreads();
   int n = 0;
   const v3 cam_o = cam_position(&s);
-  if (s.shape[b] >= 0) {
+  if (s.shape[b] >= 0 && !s.is_static[b]) {
     // screen rectangle of the body
     const rv_shape* sh = &scene->shapes[s.shape[b]];
     float mu = 1e30f, xu = -1e30f, mv = 1e30f, xv = -1e30f, mz = 1e30f;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(64) void k_policy_heuristic(const DevEnv* envs, int
   const DevEnv& e = envs[i];
   int G = c->num_goal_steps > 0 ? c->num_goal_steps : 1;
   int nb = 0;
-  for (int b = 0; b < RV_MAXB; ++b) nb += e.active[b];
+  for (int b = 0; b < RV_MAXB; ++b) nb += body_movable(e, b);
   if (nb == 0) nb = 1;
   // the policy reads the counters from the observation (push_policy.py:46-49), i.e. the
   // env.attributes snapshot; like the reference it assumes the first nb slots are the bodies
@@ -614,6 +614,8 @@ int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world*
   if (cfg->n_bodies_max > RV_MAXB || cfg->n_bodies_min < 1 || cfg->n_bodies_min > cfg->n_bodies_max)
     return fail(RV_ERR_VALUE, "rv_create: body count outside [1, RV_MAXB]");
   if (scene->n_shapes <= 0 || scene->n_shapes > RV_MAX_SHAPES) return fail(RV_ERR_VALUE, "rv_create: bad n_shapes");
+  if (cfg->wall_use && (cfg->n_bodies_max > RV_MAXB - 1 || cfg->wall_shape < 0 || cfg->wall_shape >= scene->n_shapes || !(cfg->wall_scale > 0.0f)))
+    return fail(RV_ERR_VALUE, "rv_create: wall_use needs n_bodies_max <= RV_MAXB - 1, a shape template of the scene and a positive scale");
   int ndev = 0;
   hipError_t e0 = hipGetDeviceCount(&ndev);
   if (e0 != hipSuccess || ndev == 0)

@@ -178,6 +178,9 @@ def default_shape_hulls():
         ('grasp_bar', [box_hull(0.012, 0.035, 0.015)]),
         ('grasp_cyl', [cylinder_hull(0.014, 0.02, 8)]),
     ]
+    # the wall of ArmEnv._reset_scene (arm_env.py:94-99; SIM.WALL.PATH is not part of the reference tree: BUILD-CHOSEN
+    # slab, 4 cm thick, 1.3 m wide, 0.8 m high) -- loaded as a static body when SIM.WALL.USE is set
+    shapes += [('wall', [box_hull(0.02, 0.65, 0.4)])]
     return shapes
 
 

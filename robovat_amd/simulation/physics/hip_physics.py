@@ -127,8 +127,10 @@ class HipPhysics(Physics):
                 raise ValueError('all %d movable body slots are in use' % abi.RV_MAXB)
             b = free[0]
             table_z = params[0, 0, 6]
-            # URDF template defaults: mass 0.1, lateral friction 1.0 (tools/templates/urdf_template.xml:11-22)
-            params[0, b] = [1, self.shape_names.index(name), scale, 0.1, 1.0, 0, table_z, 0]
+            # URDF template defaults: mass 0.1, lateral friction 1.0 (tools/templates/urdf_template.xml:11-22);
+            # is_static (bullet_physics.py:173-181 useFixedBase): mass 0 -- the body collides with the movable bodies,
+            # nothing moves it (rv_dev_env.h: body_static)
+            params[0, b] = [1, self.shape_names.index(name), scale, 0.0 if is_static else 0.1, 1.0, 0, table_z, 0]
             params[0, 0, 6] = table_z
             state = self._np(self._world.body_state())
             state[0, b, :3] = pose.position

@@ -58,6 +58,22 @@ for STAGE in "$@"; do
         rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/lanes_$V -o l --output-format csv -- $CMD > $O/lanes_$V.log 2>&1
       done
       cd $R; python tools/pmc_summary.py $O/lanes_head $O/lanes_nd > $O/lanes.txt 2>&1; cat $O/lanes.txt ;;
+    icache)
+      # instruction-cache passes (SQC_ICACHE_*, SQ_IFETCH, SQ_IFETCH_LEVEL): the env kernel is ~0.7 MB of code, the
+      # instruction cache 64 KB per two CUs -- headline, no-deactivation (1024 and 8192 envs) and config 5
+      cd /tmp
+      for V in head nd nd8k c5; do
+        case $V in
+          head) A="--steps 20 --warmup 5" ;;
+          nd)   A="--steps 2 --warmup 1 --over PHYSICS.SLEEP_STEPS=0" ;;
+          nd8k) A="--steps 1 --warmup 1 --envs-per-gpu 8192 --over PHYSICS.SLEEP_STEPS=0" ;;
+          c5)   A="--workload config5 --steps 10 --warmup 2" ;;
+        esac
+        CMD="python $R/bench.py $A --no-cpu-baseline --no-extra-legs"
+        rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES -d $O/ic_$V -o i --output-format csv -- $CMD > $O/ic_$V.log 2>&1
+        rocprofv3 --kernel-trace --pmc SQ_IFETCH_LEVEL SQ_IFETCH SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS -d $O/il_$V -o i --output-format csv -- $CMD > $O/il_$V.log 2>&1
+      done
+      cd $R; python tools/pmc_summary.py $O/ic_head $O/ic_nd $O/ic_nd8k $O/ic_c5 $O/il_head $O/il_nd $O/il_nd8k $O/il_c5 > $O/icache.txt 2>&1; cat $O/icache.txt ;;
     sweep)
       # HIP == float oracle bit for bit over seeds / configs, for both builds of the env kernel
       (echo "# tools/parity_sweep.py 8 256 6, register-rich build (RV_ENV_OCC=1)"; RV_ENV_OCC=1 timeout 1500 python tools/parity_sweep.py 8 256 6;
