@@ -2276,7 +2276,7 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
       if (j0 < RV_NLIMB && raw > e0.vmax_cmd[j0]) ratio0 = e0.vmax_cmd[j0] / raw;
     }
     if (lane >= RV_NLIMB) ratio0 = 1.0f;
-    int r = __builtin_bit_cast(int, fminr(1.0f, ratio0));
+    int r = __builtin_bit_cast(int, ratio0);      // (<= 1: vmax / raw only where raw > vmax)
     r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x128, 0xf, 0xf, false));
     r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x124, 0xf, 0xf, false));
     r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x122, 0xf, 0xf, false));
@@ -2305,9 +2305,9 @@ RV_DEV void arm_motor_phases(Shared& S, const Consts& K, const int with_lq, cons
       if (e.motor_on[j]) {
         vd = S.s.vdraw[j];
         if (j < RV_NLIMB) vd = vd * sync;
-        vd = fclampr(vd, -e.vmax_cmd[j], e.vmax_cmd[j]);
+        vd = fclamp_pm(vd, e.vmax_cmd[j]);
       }
-      float dv = fclampr(vd - e.qd[j], -arm->a_max[j] * dt, arm->a_max[j] * dt);
+      float dv = fclamp_pm(vd - e.qd[j], arm->a_max[j] * dt);
       float qd = e.qd[j] + dv;
       float qn = e.q[j] + qd * dt;
       if (qn < arm->q_lo[j]) { qn = arm->q_lo[j]; qd = 0.0f; }
@@ -2580,15 +2580,15 @@ RV_DEV void motors_only_substeps(Shared& S, const Consts& K, const int r) {
       if (j < RV_NLIMB && raw > vmax) ratio = vmax / raw;
     }
     if (!mine) ratio = 1.0f;
-    float sync = fminr(1.0f, ratio);
+    float sync = ratio;      // (<= 1: vmax / raw only where raw > vmax)
     sync = row_ror_min<8>(sync); sync = row_ror_min<4>(sync); sync = row_ror_min<2>(sync); sync = row_ror_min<1>(sync);
     float vdd = 0.0f;
     if (on) {
       vdd = vd;
       if (j < RV_NLIMB) vdd = vdd * sync;
-      vdd = fclampr(vdd, -vmax, vmax);
+      vdd = fclamp_pm(vdd, vmax);
     }
-    float dv = fclampr(vdd - qd, -amax_dt, amax_dt);
+    float dv = fclamp_pm(vdd - qd, amax_dt);
     float qdn = qd + dv;
     float qn = q + qdn * dt;
     if (qn < lo) { qn = lo; qdn = 0.0f; }
@@ -2883,7 +2883,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
           if (__builtin_amdgcn_ballot_w64(sat) != 0) {
             float ratio = 1.0f;
             if (sat) ratio = vmax / raw;
-            int r = __builtin_bit_cast(int, fminr(1.0f, ratio));
+            int r = __builtin_bit_cast(int, ratio);      // (<= 1: vmax / raw only where raw > vmax)
             r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x128, 0xf, 0xf, false));
             r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x124, 0xf, 0xf, false));
             r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x122, 0xf, 0xf, false));
@@ -2894,9 +2894,9 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
           if (on) {
             vdd = vd;
             if (limb) vdd = vdd * sync;
-            vdd = fclampr(vdd, -vmax, vmax);
+            vdd = fclamp_pm(vdd, vmax);
           }
-          const float dv = fclampr(vdd - qd, -amax_dt, amax_dt);
+          const float dv = fclamp_pm(vdd - qd, amax_dt);
           float qdn = qd + dv;
           float qn = q + qdn * dt;
           if (qn < lo) { qn = lo; qdn = 0.0f; }
@@ -2938,7 +2938,7 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
       float ratio = 1.0f;
       if (sat) ratio = vmax / raw;
       // ratios are positive floats: their order is the order of their bit patterns
-      int r = __builtin_bit_cast(int, fminr(1.0f, ratio));
+      int r = __builtin_bit_cast(int, ratio);      // (<= 1)
       r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x128, 0xf, 0xf, false));
       r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x124, 0xf, 0xf, false));
       r = min(r, __builtin_amdgcn_update_dpp(0, r, 0x122, 0xf, 0xf, false));
@@ -2949,9 +2949,9 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
     if (on) {
       vdd = vd;
       if (limb) vdd = vdd * sync;
-      vdd = fclampr(vdd, -vmax, vmax);
+      vdd = fclamp_pm(vdd, vmax);
     }
-    float dv = fclampr(vdd - qd, -amax_dt, amax_dt);
+    float dv = fclamp_pm(vdd - qd, amax_dt);
     float qdn = qd + dv;
     float qn = q + qdn * dt;
     if (qn < lo) { qn = lo; qdn = 0.0f; }
@@ -2972,13 +2972,17 @@ RV_DEV int coast_fused(Shared& S, const Consts& K, const int steps_check, const 
       if (__builtin_amdgcn_ballot_w64(iscol && !(clt > D && clb > 2.0f * D)) != 0) { pending = 1; break; }   // no: this substep is not taken
       // how many of the next substeps need no test (smallest count over the box lanes 16 .. 25)
       float nf = 1e6f;
+      // (the cross-lane reads of the joint lanes' speeds happen HERE, where every lane is active: inside the branch below only
+      // the box lanes are, and a v_readlane of a lane that is inactive where it is executed is undefined to the compiler --
+      // it may sink the producer of `sp` into the branch, where the joint lanes never execute it.  Round 4 found this as a
+      // parity break of an `exact on paper' rewrite; round 5 again, with |x| as a source modifier: now it is out of the branch)
+      float B1 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < RV_NJ; ++k) B1 = __builtin_fmaf(cf[k], rdlane(sp, k), B1);
       if (iscol && Bc > 0.0f) {
         const float room = (slack - 2e-4f) * (1.0f / 1.05f) - T;
         nf = room / Bc - 1.0f;
         if (B2 > 0.0f && room > 0.0f) {
-          float B1 = 0.0f;
-#pragma unroll
-          for (int k = 0; k < RV_NJ; ++k) B1 = __builtin_fmaf(cf[k], rdlane(sp, k), B1);
           const float hb = B1 * dt + 0.5f * B2;          // n hb + n^2 B2 / 2 <= room
           const float nq = 0.98f * (fsqrtr(hb * hb + 2.0f * B2 * room) - hb) / B2 - 1.0f;
           nf = fmaxr(nf, nq);

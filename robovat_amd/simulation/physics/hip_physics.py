@@ -38,6 +38,7 @@ class HipPhysics(Physics):
         self._gravity = None
         self._static = {}
         self._constraints = {}
+        self._wrenches = {}          # apply_force_to_body / apply_torque_to_body: what the next step() applies
         self.scene, self.shape_names = scenes.make_scene()
         self._num_steps = None
 
@@ -92,6 +93,8 @@ class HipPhysics(Physics):
         self._num_steps = 0
 
     def step(self):
+        if self._wrenches:
+            self._apply_wrenches()
         self._world.step_sub(1)
         self._num_steps += 1
 
@@ -247,6 +250,46 @@ class HipPhysics(Physics):
     def set_body_color(self, body_uid, rgba, specular):
         pass   # no renderer
 
+    def get_body_contacts(self, body_uid):
+        """Body.contacts (body.py:142-144, bullet_physics.py:1268-1286): the contact points the body takes part in."""
+        return self.get_contact_points(body_uid)
+
+    # ---- external forces (bullet_physics.py:1161-1197: applyExternalForce / applyExternalTorque with LINK_FRAME, which
+    # act during ONE stepSimulation).  Kept on the host until the next step(), then applied as the velocity change
+    # F dt / m, I^-1 (r x F + T) dt of that step (force, position and torque in the BODY frame, as LINK_FRAME says)
+    def apply_force_to_body(self, uid, force, position):
+        b = self._slot(uid)
+        w = self._wrenches.setdefault(b, [np.zeros(3), np.zeros(3)])
+        f = np.asarray(force, np.float64); r = np.asarray(position, np.float64)
+        w[0] += f; w[1] += np.cross(r, f)
+
+    def apply_torque_to_body(self, uid, force, position):
+        b = self._slot(uid)
+        w = self._wrenches.setdefault(b, [np.zeros(3), np.zeros(3)])
+        w[1] += np.asarray(force, np.float64)
+
+    def apply_force_to_link(self, uid, force, position):
+        raise NotImplementedError('the arm is a kinematic pusher (its joints follow the position controller): an external force on a link moves nothing')
+
+    def apply_torque_to_link(self, uid, force, position):
+        raise NotImplementedError('the arm is a kinematic pusher (its joints follow the position controller): an external torque on a link moves nothing')
+
+    def _apply_wrenches(self):
+        params = self._np(self._world.body_params())
+        state = self._np(self._world.body_state())
+        dt = self._time_step
+        for b, (f, t) in self._wrenches.items():
+            active, shape, scale, mass = params[0, b, 0], int(params[0, b, 1]), float(params[0, b, 2]), float(params[0, b, 3])
+            if not active or not mass > 0.0:
+                continue                         # (absent, or a static body)
+            R = np.asarray(rotations.matrix3_from_quaternion(np.asarray(state[0, b, 3:7], np.float64)), np.float64)
+            ik = np.asarray(self.scene.shapes[shape].inertia_k[:], np.float64)      # principal inertia per unit mass at unit scale
+            inv_i = 1.0 / (mass * scale * scale * ik)
+            state[0, b, 7:10] += (R @ f) * (dt / mass)
+            state[0, b, 10:13] += R @ (inv_i * t) * dt
+        self._wrenches = {}
+        self._world.set_body_state(state)
+
     # ---- links / joints (bullet_physics.py:444-729)
     def get_link_name(self, link_uid):
         return scenes.LINK_NAMES[link_uid[1]]
@@ -257,6 +300,15 @@ class HipPhysics(Physics):
 
     def get_link_center_of_mass(self, link_uid):
         return self.get_link_pose(link_uid)
+
+    def get_link_dynamics(self, link_uid):
+        """bullet_physics.py:506-525: mass and the friction coefficients of a link (the limb links: PHYSICS.ARM_FRICTION,
+        the finger tips: what Link.set_dynamics last gave them)."""
+        mu = float(self._cfg.arm_friction)
+        return {'mass': self.get_link_mass(link_uid), 'lateral_friction': mu, 'rolling_friction': 0.0, 'spinning_friction': 0.0}
+
+    def set_link_mass(self, link_uid, mass):
+        raise NotImplementedError('This is still buggy in PyBullet.')      # (bullet_physics.py:527-534 raises the same)
 
     def get_link_mass(self, link_uid):
         """<inertial> mass of a limb link / the hand (rv_arm.link_mass); the finger links are massless pads."""
@@ -300,8 +352,39 @@ class HipPhysics(Physics):
         js[0, joint_uid[1], 1] = 0.0
         self._world.set_joint_state(js)
 
+    def set_joint_velocity(self, joint_uid, velocity):
+        """bullet_physics.py:713-729: resetJointState at the current position with this velocity."""
+        js = self._np(self._world.joint_state())
+        js[0, joint_uid[1], 1] = velocity
+        self._world.set_joint_state(js)
+
+    def enable_joint_sensor(self, joint_uid):
+        pass      # (bullet_physics.py:731-742; nothing to switch on: see get_joint_reaction_force)
+
     def get_joint_reaction_force(self, joint_uid):
         raise NotImplementedError('the kinematic arm has no reaction forces')
+
+    def get_joint_torque(self, joint_uid):
+        raise NotImplementedError('the kinematic arm has no motor torques (PHYSICS.LIMB_DYNAMICS keeps its motor impulses on the device)')
+
+    def position_control(self, joint_uid, target_position, target_velocity=None, max_velocity=None, max_force=None,
+                         position_gain=None, velocity_gain=None):
+        """bullet_physics.py:959-1006: POSITION_CONTROL of ONE joint -- position_control_array with one entry."""
+        if max_velocity is not None:
+            raise NotImplementedError('This is not implemented in pybullet.')
+        self.position_control_array(joint_uid[0], [joint_uid[1]], [target_position])
+
+    def velocity_control(self, joint_uid, target_velocity, max_force=None, position_gain=None, velocity_gain=None):
+        raise NotImplementedError('the device-side motor law is POSITION_CONTROL (controllable_body.py:458-466 uses nothing else): no VELOCITY_CONTROL')
+
+    def velocity_control_array(self, body_uid, joint_inds, target_velocities, max_forces=None, position_gains=None, velocity_gains=None):
+        raise NotImplementedError('the device-side motor law is POSITION_CONTROL (controllable_body.py:458-466 uses nothing else): no VELOCITY_CONTROL')
+
+    def torque_control(self, joint_uid, target_torque):
+        raise NotImplementedError('the device-side motor law is POSITION_CONTROL (controllable_body.py:458-466 uses nothing else): no TORQUE_CONTROL')
+
+    def torque_control_array(self, body_uid, joint_inds, target_torques):
+        raise NotImplementedError('the device-side motor law is POSITION_CONTROL (controllable_body.py:458-466 uses nothing else): no TORQUE_CONTROL')
 
     # ---- control (bullet_physics.py:1061-1104) and IK (:1203-1262)
     def position_control_array(self, body_uid, joint_inds, target_positions, target_velocities=None,

@@ -32,9 +32,48 @@ class Body(object):
     linear_velocity = property(lambda s: s.physics.get_body_linear_velocity(s._uid))
     angular_velocity = property(lambda s: s.physics.get_body_angular_velocity(s._uid))
 
+    matrix3 = property(lambda s: s.pose.matrix3)
+    dynamics = property(lambda s: s.physics.get_body_dynamics(s._uid))
+    contacts = property(lambda s: s.physics.get_body_contacts(s._uid))
+    links = property(lambda s: [])
+    joints = property(lambda s: [])
+    # (body.py:84-116: one list per joint property)
+    joint_velocities = property(lambda s: [j.velocity for j in s.joints])
+    joint_lower_limits = property(lambda s: [j.lower_limit for j in s.joints])
+    joint_upper_limits = property(lambda s: [j.upper_limit for j in s.joints])
+    joint_max_efforts = property(lambda s: [j.max_effort for j in s.joints])
+    joint_max_velocities = property(lambda s: [j.max_velocity for j in s.joints])
+    joint_dampings = property(lambda s: [j.damping for j in s.joints])
+    joint_frictions = property(lambda s: [j.friction for j in s.joints])
+    joint_ranges = property(lambda s: [j.range for j in s.joints])
+
     @pose.setter
     def pose(self, value):
         self.physics.set_body_pose(self._uid, value)
+
+    @position.setter
+    def position(self, value):
+        self.physics.set_body_position(self._uid, value)
+
+    @orientation.setter
+    def orientation(self, value):
+        self.physics.set_body_orientation(self._uid, value)
+
+    @linear_velocity.setter
+    def linear_velocity(self, value):
+        self.physics.set_body_linear_velocity(self._uid, value)
+
+    @angular_velocity.setter
+    def angular_velocity(self, value):
+        self.physics.set_body_angular_velocity(self._uid, value)
+
+    @property
+    def mass(self):
+        return self.physics.get_body_mass(self._uid)
+
+    @mass.setter
+    def mass(self, value):
+        self.physics.set_body_mass(self._uid, value)
 
     def update(self):
         pass
@@ -58,6 +97,10 @@ class Link(object):
     pose = property(lambda s: s._body.physics.get_link_pose(s.uid))
     position = property(lambda s: s.pose.position)
     orientation = property(lambda s: s.pose.orientation)
+    parent = property(lambda s: s._body)
+    center_of_mass = property(lambda s: s._body.physics.get_link_center_of_mass(s.uid))
+    mass = property(lambda s: s._body.physics.get_link_mass(s.uid))
+    dynamics = property(lambda s: s._body.physics.get_link_dynamics(s.uid))
 
     def set_dynamics(self, mass=None, lateral_friction=None, rolling_friction=None, spinning_friction=None):
         self._body.physics.set_link_dynamics(self.uid, mass=mass, lateral_friction=lateral_friction,
@@ -79,6 +122,26 @@ class Joint(object):
     max_velocity = property(lambda s: s.limit['velocity'])
     range = property(lambda s: s.upper_limit - s.lower_limit)
     velocity = property(lambda s: s._body.physics.get_joint_velocity(s.uid))
+    parent = property(lambda s: s._body)
+    dynamics = property(lambda s: s._body.physics.get_joint_dynamics(s.uid))
+    damping = property(lambda s: s.dynamics['damping'])
+    friction = property(lambda s: s.dynamics['friction'])
+    reaction_force = property(lambda s: s._body.physics.get_joint_reaction_force(s.uid))
+
+    def enable_sensor(self):
+        self._body.physics.enable_joint_sensor(self.uid)
+
+    def position_control(self, target_position, target_velocity=None, max_velocity=None, max_force=None,
+                         position_gain=None, velocity_gain=None):
+        """joint.py:129-155."""
+        self._body.physics.position_control(self.uid, target_position, target_velocity=target_velocity, max_velocity=max_velocity,
+                                            max_force=max_force, position_gain=position_gain, velocity_gain=velocity_gain)
+
+    def velocity_control(self, target_velocity, max_force=None, position_gain=None, velocity_gain=None):
+        self._body.physics.velocity_control(self.uid, target_velocity, max_force=max_force, position_gain=position_gain, velocity_gain=velocity_gain)
+
+    def torque_control(self, target_torque):
+        self._body.physics.torque_control(self.uid, target_torque)
 
     @property
     def position(self):

@@ -221,3 +221,68 @@ def test_env_reset_invalidates_the_constraint_mirror_and_configure_refuses_a_pop
     with pytest.raises(ValueError):
         envs.PushEnv(simulator=sim2, seed=4)
     env.close()
+
+
+def test_body_link_joint_api_of_the_reference_and_static_bodies():
+    """The rest of the reference's Body / Link / Joint / BulletPhysics surface (body.py:60-185, link.py, joint.py,
+    bullet_physics.py:506-534, 684-742, 959-1006, 1161-1197): per-joint property lists, setters of position / velocity /
+    mass, external forces (they act during ONE step, in the body frame), one-joint position control; what a kinematic arm
+    cannot do raises NotImplementedError with the reason; add_body(is_static=True) makes a static body."""
+    from robovat_amd.simulation import Simulator
+    sim = Simulator(physics_backend='HipPhysics', worker_id=1)
+    sim.reset(); sim.start()
+    sim.add_body('sim/table/table.urdf', [[0.6, 0, 0.0], [0, 0, 0]], is_static=True, name='table')
+    box = sim.add_body('box.urdf', [[0.6, 0.1, 0.031], [0, 0, 0]], name='movable_0')
+    sim.wait_until_stable(box, max_steps=400)
+    assert box.mass == pytest.approx(0.1) and box.dynamics['lateral_friction'] == pytest.approx(1.0)
+    assert len(box.contacts) > 0 and box.links == [] and box.joint_velocities == []
+    assert np.allclose(box.matrix3, np.eye(3), atol=1e-3)
+    # an external force acts during one step: dv = F dt / m (in the body frame; the box is axis-aligned), the normal
+    # force of the table takes the downward part, friction (mu 1, m g = 0.98 N) cannot hold 5 N
+    v0 = np.asarray(box.linear_velocity, np.float64)
+    sim.physics.apply_force_to_body(box.uid, [5.0, 0.0, 0.0], [0.0, 0.0, 0.0])
+    sim.step()
+    dv = np.asarray(box.linear_velocity, np.float64) - v0
+    assert 0.03 < dv[0] <= 5.0 * 1e-3 / 0.1 + 1e-6, dv            # 0.05 m/s less what friction took in that step
+    sim.step()
+    assert np.asarray(box.linear_velocity)[0] < dv[0] + v0[0]       # not applied again: friction now slows the box
+    # a torque about z spins it: dw = T dt / I_zz
+    sim.wait_until_stable(box, max_steps=600)
+    sim.physics.apply_torque_to_body(box.uid, [0.0, 0.0, 0.2], [0.0, 0.0, 0.0])      # (0.03 N m of friction torque resists)
+    sim.step()
+    assert 1.0 < box.angular_velocity[2] < 0.2 * 1e-3 / 7.0e-5
+    # setters
+    box.linear_velocity = [0.0, 0.0, 0.0]; box.angular_velocity = [0.0, 0.0, 0.0]
+    box.position = [0.55, -0.1, 0.031]
+    assert np.allclose(np.asarray(box.position), [0.55, -0.1, 0.031], atol=1e-6)
+    box.mass = 0.25
+    assert box.mass == pytest.approx(0.25)
+    # a static body: nothing moves it, the box stops at it
+    wall = sim.add_body('wall.urdf', [[0.72, 0.0, 0.4], [0, 0, 0]], is_static=True, name='wall')
+    assert wall.is_static and wall.mass == 0.0
+    w0 = np.asarray(wall.position).copy()
+    box.position = [0.6, 0.0, 0.031]; box.linear_velocity = [2.0, 0.0, 0.0]      # (friction alone would stop it after 20 cm)
+    for _ in range(600):
+        sim.step()
+    assert np.array_equal(np.asarray(wall.position), w0)
+    assert 0.65 < box.position.x < 0.67 and sim.check_contact(box, wall)
+    # the arm
+    arm = sim.add_body('sawyer.urdf', is_static=True, is_controllable=True, name='sawyer_arm')
+    assert len(arm.joint_lower_limits) == 9 and len(arm.joint_ranges) == 9 and arm.joint_dampings == [0.0] * 9
+    assert all(r > 0 for r in arm.joint_ranges) and arm.joint_max_velocities[0] == pytest.approx(1.74)
+    j0 = arm.joints[0]; l7 = arm.links[7]
+    assert j0.parent is arm and l7.parent is arm and l7.mass > 0 and l7.dynamics['lateral_friction'] > 0
+    assert np.allclose(np.asarray(l7.center_of_mass.position), np.asarray(l7.position))
+    q0 = j0.position
+    j0.position_control(q0 + 0.2)
+    sim.physics.world.step_sub(1500)      # (an acceleration-limited position controller: it overshoots and settles)
+    assert abs(j0.position - (q0 + 0.2)) < 5e-3 and abs(arm.joint_velocities[0]) < 0.05
+    sim.physics.set_joint_velocity(j0.uid, 0.3)
+    assert j0.velocity == pytest.approx(0.3)
+    j0.enable_sensor()
+    for call in (lambda: j0.reaction_force, lambda: j0.velocity_control(0.1), lambda: j0.torque_control(1.0),
+                 lambda: sim.physics.get_joint_torque(j0.uid), lambda: sim.physics.apply_force_to_link(l7.uid, [1, 0, 0], [0, 0, 0]),
+                 lambda: sim.physics.set_link_mass(l7.uid, 1.0), lambda: sim.physics.velocity_control_array(arm.uid, [0], [0.1]),
+                 lambda: sim.physics.torque_control_array(arm.uid, [0], [0.1])):
+        with pytest.raises(NotImplementedError):
+            call()

@@ -23,7 +23,11 @@ CASES = [('config 2', {}), ('crossing / concave', dict(TASK_NAME='crossing', LAY
          ('arm effort limit + tilted gravity', {'PHYSICS.ARM_EFFORT_LIMIT': 1, 'PHYSICS.GRAVITY_XY': (0.3, -0.2)}),
          ('dynamic limb, crowded', {'PHYSICS.LIMB_DYNAMICS': 1, 'MOVABLE.CONVEX.POSE.X': [0.5, 0.7], 'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07}),
          ('user constraints (p2p and prismatic to the world, body - body fixed)', {'CONSTRAINTS': 1}),
-         ('user constraints (revolute to the world, fixed to the hand link, body - body prismatic)', {'CONSTRAINTS': 2})]
+         ('user constraints (revolute to the world, fixed to the hand link, body - body prismatic)', {'CONSTRAINTS': 2}),
+         ('static wall across the workspace, 3 bodies', {'SIM.WALL.USE': True, 'SIM.WALL.POSE': [[0.66, 0.0, 0.4], [0, 0, 0]], 'MAX_MOVABLE_BODIES': 3, 'MIN_MOVABLE_BODIES': 3}),
+         ('static wall, bodies dropped next to / into it, no deactivation', {'SIM.WALL.USE': True, 'SIM.WALL.POSE': [[0.72, 0.0, 0.4], [0, 0, 0.3]], 'MAX_MOVABLE_BODIES': 3, 'MIN_MOVABLE_BODIES': 2,
+                                                                'PHYSICS.SLEEP_STEPS': 0, 'MAX_STEPS': 2, 'MOVABLE.CONVEX.POSE.X': [0.5, 0.7], 'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07}),
+         ('static wall + dynamic limb', {'SIM.WALL.USE': True, 'SIM.WALL.POSE': [[0.6, 0.12, 0.4], [0, 0, 1.5708]], 'MAX_MOVABLE_BODIES': 3, 'MIN_MOVABLE_BODIES': 1, 'PHYSICS.LIMB_DYNAMICS': 1})]
 bad = 0
 for name, over in CASES:
     scene, names = scenes.make_scene()
