@@ -1616,6 +1616,16 @@ RV_DEV int isl_row_on(int s, int ntx, int nax, int nty, int nay, int nxy) {
 // lane S of the caller's own 16-lane group, to every lane of the group: the DPP control row_newbcast:S (gfx90a and
 // later: "broadcast lane S of each row of 16 to the whole row") -- ONE VALU instruction; no trip through SGPRs, and not
 // the ~100 clocks of the LDS crossbar that the ds_swizzle of the first version took on the critical path of every row step
+// "is it this lane's turn" of the lane-per-row sweeps: (lane's row) == s for a compile-time s.  The compare is loop
+// invariant, so the compiler computes the 12 (36) lane masks once, keeps them in SGPR pairs -- and, out of SGPRs, spills them
+// into a VGPR: every row step then paid two v_readlane + a wait state to get its mask back.  An opaque copy of the lane's
+// row index makes the compare part of the step: v_cmp_eq (inline constant) + v_cndmask through vcc, two instructions.
+RV_DEV int opaque_i(int x) {
+#if RV_ON_DEVICE
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
 template <int S_> RV_DEV float grp_bcast(float x) {
   const int xi = __builtin_bit_cast(int, x);
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x150 + S_, 0xf, 0xf, true));
@@ -1713,8 +1723,10 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
   const int toli = __builtin_bit_cast(int, tol);
   const int stall = c->solver_stall; int besti = 0x7f800000, since = 0;
   const bool in_y = lane >= 24 && lane < 48;
+  const int slot_xy = lane < 24 ? lane : (lane < 48 ? lane - 24 : -1);      // (slot t of X is lane t, of Y lane 24 + t)
   for (int it = 0; it < iters; ++it) {
     const float lam0 = lam;
+    const int sq = opaque_i(slot_xy), lq = opaque_i(lane);      // (opaque once per sweep: see opaque_i)
     // the own rows of X and of Y do not couple (A[x][y] = 0), so slot t of X (lane t) and slot t of Y (lane 24 + t) are
     // solved in the same step; every row adds X's change first, then Y's -- the visiting order of the row list
 #pragma unroll
@@ -1726,7 +1738,7 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
         const int s = 3 * pp + kk;
         const float nl = kk == 0 ? __builtin_amdgcn_fmed3f(lam + T, 0.0f, hi) : __builtin_amdgcn_fmed3f(lam + T, -lim, lim);
         const float d = nl - lam;
-        if (lane == s || lane == s + 24) lam = nl;
+        if (sq == s) lam = nl;
         const float sdx = rdlane(d, s), sdy = rdlane(d, s + 24);
         if (kk == 0) { const float ml = mu * nl; const float lx = rdlane(ml, s), ly = rdlane(ml, s + 24); lim = in_y ? ly : lx; }
         T = rv_fma(A[s], sdx, T);
@@ -1742,7 +1754,7 @@ RV_DEV void solve_island2(Shared& S, const Consts& K, const int X, const int Y, 
         const int s = 3 * pp + kk;
         const float nl = kk == 0 ? __builtin_amdgcn_fmed3f(lam + T, 0.0f, hi) : __builtin_amdgcn_fmed3f(lam + T, -lim, lim);
         const float d = nl - lam;
-        if (lane == s) lam = nl;
+        if (lq == s) lam = nl;
         const float sd = rdlane(d, s);
         if (kk == 0) lim = rdlane(mu * nl, s);   // friction bound of the point: mu x its normal impulse
         T = rv_fma(A[s], sd, T);
@@ -1813,11 +1825,12 @@ RV_DEV void singles_sweeps(const int r, const int ntmax, const int namax, const 
   for (int it = 0; it < iters; ++it) {
     if (alive) {
       const float lamT0 = lamT, lamA0 = lamA;
+      const int rq = opaque_i(r);      // (the row index, opaque once per sweep: see opaque_i)
 #define RV_SSTEP_T(pp_, kk_) { \
       constexpr int s_ = 3 * pp_ + kk_; \
       const float nl = kk_ == 0 ? __builtin_amdgcn_fmed3f(lamT + TT, 0.0f, hiT) : __builtin_amdgcn_fmed3f(lamT + TT, -lim, lim); \
       const float d = nl - lamT; \
-      if (r == s_) lamT = nl; \
+      if (rq == s_) lamT = nl; \
       if (kk_ == 0) lim = grp_bcast<s_>(muT * nl); \
       const float bd = grp_bcast<s_>(d); \
       TT = rv_fma(CTT[s_], bd, TT); \
@@ -1826,7 +1839,7 @@ RV_DEV void singles_sweeps(const int r, const int ntmax, const int namax, const 
       constexpr int s_ = 3 * pp_ + kk_; \
       const float nl = kk_ == 0 ? __builtin_amdgcn_fmed3f(lamA + TA, 0.0f, hiA) : __builtin_amdgcn_fmed3f(lamA + TA, -lim, lim); \
       const float d = nl - lamA; \
-      if (r == s_) lamA = nl; \
+      if (rq == s_) lamA = nl; \
       if (kk_ == 0) lim = grp_bcast<s_>(muA * nl); \
       const float bd = grp_bcast<s_>(d); \
       TT = rv_fma(CTA[s_], bd, TT); \
@@ -2152,7 +2165,7 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
         const int s = 3 * pp + kk;
         const float nl = kk == 0 ? __builtin_amdgcn_fmed3f(lam + T, 0.0f, capn) : __builtin_amdgcn_fmed3f(lam + T, -lim, lim);
         const float d = nl - lam;
-        if (lane == s) lam = nl;
+        if (opaque_i(lane) == s) lam = nl;
         const float sd = rdlane(d, s);
         if (kk == 0) lim = rdlane(mu * nl, s);
         T = rv_fma(A[s], sd, T);
@@ -2163,7 +2176,7 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
       const int s = 24 + m;
       const float nl = __builtin_amdgcn_fmed3f(lam + T, lo, hi);
       const float d = nl - lam;
-      if (lane == s) lam = nl;
+      if (opaque_i(lane) == s) lam = nl;
       T = rv_fma(A[s], rdlane(d, s), T);
     }
     if (LIMB) {
@@ -2172,7 +2185,7 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
         const int s = 26 + j;
         const float nl = __builtin_amdgcn_fmed3f(lam + T, lo, hi);
         const float d = nl - lam;
-        if (lane == s) lam = nl;
+        if (opaque_i(lane) == s) lam = nl;
         T = rv_fma(A[s], rdlane(d, s), T);
       }
     }

@@ -33,24 +33,26 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, int
   out[blockIdx.x * 64 + threadIdx.x] = a + d + e2 + f + idx;
 }
 int main() {
-  float* dout; unsigned long long* dc; const int nb = 1024, iters = 200;
+  float* dout; unsigned long long* dc; const int nb = 8192, iters = 200;
   hipMalloc(&dout, nb * 64 * 4); hipMalloc(&dc, nb * 8);
   unsigned long long* hc = (unsigned long long*)malloc(nb * 8);
   const char* nm[13] = {"dependent v_add_f32", "dependent v_fma_f32", "dependent v_med3_f32", "4 independent v_add chains", "v_add -> s_nop 1 -> v_mov_dpp row_newbcast (pair)",
                         "v_add -> v_readlane -> v_add with the SGPR (triple)", "dependent v_cndmask (vcc)", "dependent ds_read_b32 + waitcnt", "v_add -> s_nop 1 -> v_fmac_dpp (pair)",
                         "dependent v_add interleaved with s_add (pair)", "v_cmp -> v_cndmask (pair)", "v_cmp sgpr -> s_and -> branch -> v_add (group)", "dependent v_pk_add_f32"};
   const int per[13] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64};
-  for (int nbv = 0; nbv < 2; ++nbv) {
-    const int blocks = nbv == 0 ? 1024 : 2048;
+  for (int nbv = 0; nbv < 4; ++nbv) {
+    const int blocks = 1024 << nbv;      // 1, 2, 4, 8 waves per SIMD (256 CUs x 4 SIMDs)
     for (int v = 0; v < 13; ++v) {
+      if (v == 9 || v == 11) continue;      // (these two clobber an SGPR the loop counter lives in: not measurements)
       for (int rep = 0; rep < 2; ++rep) {
 #define L(n) case n: hipLaunchKernelGGL(k<n>, dim3(blocks), dim3(64), 0, 0, dout, dc, iters, 1.5f); break;
         switch (v) { L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) }
         hipDeviceSynchronize();
       }
-      hipMemcpy(hc, dc, 1024 * 8, hipMemcpyDeviceToHost);
-      double sum = 0; for (int i = 0; i < 1024; ++i) sum += (double)hc[i];
-      printf("blocks=%d V%-2d %6.2f clocks per unit  (%s)\n", blocks, v, sum / 1024 / iters / per[v], nm[v]);
+      hipMemcpy(hc, dc, blocks * 8, hipMemcpyDeviceToHost);
+      double sum = 0; for (int i = 0; i < blocks; ++i) sum += (double)hc[i];
+      sum = sum * 1024 / blocks;      // (mean over the blocks, in the units of the print below)
+      printf("blocks=%d V%-2d %6.2f clocks per unit per wave = %5.2f per SIMD  (%s)\n", blocks, v, sum / 1024 / iters / per[v], sum / 1024 / iters / per[v] / (blocks / 1024), nm[v]);
     }
   }
   return 0;
