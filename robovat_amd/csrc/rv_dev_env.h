@@ -5024,6 +5024,9 @@ struct ProgArgs {
   int n_steps;                               // SUB: substeps; ROLLOUT: env.step() calls
   float lin_thr, ang_thr; int check_after, min_stable, max_steps;   // WAIT
   int first_index, auto_reset; RolloutRec rec; int env, n_envs; int* budget;   // ROLLOUT
+  // ROLLOUT as one task of a queue (rv_env_kernel.h): this call takes the steps k0 .. k_stop - 1 of the env's n_steps
+  // (k_stop = 0: all of them, from k0 = 0 -- a plain launch); the per-launch counters are zeroed by the task that starts at 0
+  int k0, k_stop;
 };
 // returns (RV_PROG_PARTIAL) 1 when the env.step() completed in this launch
 // The segments of the env program as functions of their own (RV_SEGMENTS_NOINLINE: the two-waves-per-SIMD build).  Round 4
@@ -5061,7 +5064,8 @@ RV_DEV int env_program(Shared& S, const Consts& K, const int prog, const ProgArg
   int pc = PC_DONE, ret_reset = PC_DONE, ret_step = PC_DONE;
   int reset_zero = 1, step_zero = 1;           // zero the per-launch counters (not inside a rollout)
   int ri = 0, rnb = 0;                         // reset: body index, body count
-  int k = 0, k_end = 0, was_reset = 0;         // rollout
+  int k = A.k0, k_end = A.k0, was_reset = 0;   // rollout
+  const int k_hi = A.k_stop > 0 ? A.k_stop : A.n_steps;
   int fin = 0;
   const int grasp = RV_UNI(c->env_type == RV_ENV_GRASP);
   RunReq rq = run_req(0);
@@ -5072,9 +5076,11 @@ RV_DEV int env_program(Shared& S, const Consts& K, const int prog, const ProgArg
   else if (prog == RV_PROG_WAIT) { rq = run_req(0, 0u, A.lin_thr, A.ang_thr, A.check_after, A.min_stable, A.max_steps); run = 1; }
   else if (prog == RV_PROG_PARTIAL) { RV_SEG(env_pstep_begin(S, K), seg_pstep_begin(K.scene)); rq = run_req(-1, 0u, 0.005f, 0.005f, 100, 100, 2000); run = 1; pc = PC_PSTEP_END; }
   else {
-    RV_LANES_BEGIN
-      if (lane == 0) launch_counters_zero(S.e);
-    RV_LANES_END
+    if (A.k0 == 0) {
+      RV_LANES_BEGIN
+        if (lane == 0) launch_counters_zero(S.e);
+      RV_LANES_END
+    }
     reset_zero = 0; step_zero = 0;
     pc = PC_ROLL_TOP;
   }
@@ -5150,7 +5156,7 @@ RV_DEV int env_program(Shared& S, const Consts& K, const int prog, const ProgArg
         break;
       // ---- the rollout loop
       case PC_ROLL_TOP: {
-        if (!(A.budget != nullptr || k < A.n_steps)) { pc = PC_ROLL_TAIL; break; }
+        if (!(A.budget != nullptr || k < k_hi)) { pc = PC_ROLL_TAIL; break; }
         if (A.budget != nullptr) {
           RV_LANES_BEGIN
             if (lane == 0) {
@@ -5211,7 +5217,7 @@ RV_DEV int env_program(Shared& S, const Consts& K, const int prog, const ProgArg
         // steps not taken (episode over, no auto-reset): reward 0, done
         if (A.budget == nullptr) {
           RV_LANES_BEGIN
-            for (int kk = k_end + lane; kk < A.n_steps; kk += 64) rollout_record(A.rec, nullptr, (size_t)kk * A.n_envs + A.env, c, K.arm);
+            for (int kk = k_end + lane; kk < k_hi; kk += 64) rollout_record(A.rec, nullptr, (size_t)kk * A.n_envs + A.env, c, K.arm);
           RV_LANES_END
         }
         pc = PC_DONE;

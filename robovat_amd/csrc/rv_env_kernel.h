@@ -34,11 +34,18 @@ struct EnvKernelArgs {
   unsigned long long budget_clk; // MODE_PARTIAL: shader clocks this launch may spend per env (0: no limit)
   uint8_t* finished;             // MODE_PARTIAL: [N] 1 = the env.step() of this env completed in this launch
   int mode;                      // k_env<-1>: which of the modes this launch is
+  // MODE_ROLLOUT through a task queue (worlds with more envs than the GPU has wave slots): a task is ONE env.step() of one
+  // env; the launch has as many workgroups as fit the GPU, each takes the next task, runs it from and back to the env's block
+  // in HBM, and puts the env back at the tail while it has steps left.  q_slots[t] = env of task t (-1: not yet published),
+  // q_total = n_envs x n_steps tasks in all.  nullptr: one workgroup per env, all its steps (the plain launch)
+  int* q_slots; unsigned* q_head; unsigned* q_tail; int* q_done; int q_total;
 };
 
 // TMODE = MODE_ROLLOUT: the single-launch rollout, a kernel of its own (it is the one bench.py times and the profiles
 // name); TMODE = -1: every other mode, picked at run time from args.mode -- the substep loop is inlined once per
 // kernel, so two instantiations instead of six keep the build at a minute
+template <int TMODE>
+__device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int MODE, const int env, Shared& S, const Consts& K, const int k0, const int k_stop);
 template <int TMODE>
 #ifdef RV_WAVES_PER_EU      // experiment: cap the registers so that RV_WAVES_PER_EU waves fit a SIMD (tools/flag_variants.sh)
 #define RV_ENV_OCC __attribute__((amdgpu_waves_per_eu(RV_WAVES_PER_EU, RV_WAVES_PER_EU)))
@@ -48,9 +55,8 @@ template <int TMODE>
 __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
   const int MODE = TMODE >= 0 ? TMODE : args.mode;
   Shared& S = g_shared;
-  const int env = (int)blockIdx.x;
-  if (env >= args.n_envs) return;
-  DevEnv* g = args.envs + env;
+  const bool queued = TMODE < 0 && args.q_slots != nullptr;      // (the run-time-dispatched instantiation only)
+  if (!queued && (int)blockIdx.x >= args.n_envs) return;
   const int lane = (int)threadIdx.x;
   {
     // stage the launch constants in LDS
@@ -69,6 +75,53 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
   }
 #endif
   Consts K = lds_consts(args.scene, (MODE == MODE_SUB) ? args.stop_after : 0);
+  // ---- the task queue (MODE_ROLLOUT; a plain launch is ONE pass of this loop: its env is the workgroup's own, all steps).
+  // Memory: the env blocks and the queue live in UNCACHED device memory when the queue is in use (rv_create:
+  // hipDeviceMallocUncached), so what one workgroup stored is what another loads, whichever XCD they run on, once the
+  // stores have completed (s_waitcnt vmcnt(0) = the workgroup-scope release below) -- agent-scope release / acquire
+  // would write back and invalidate the whole L2 of the XCD on every task, with everybody's scratch lines in it
+  // (measured: 8192 envs 121 k -> 116 k env-steps/s instead of a gain).  Lane 0 takes a ticket; the task of ticket t is published by whoever finished the
+  // env's previous step (release), or by the host for the first n_envs.  Every env is either in the queue or held by a
+  // running workgroup, and a workgroup that waits holds no env: the wait ends.  Results do not depend on who runs what:
+  // the envs are independent and their random streams are keyed by (env, step).
+  for (;;) {
+    int env = (int)blockIdx.x, k0 = 0;
+    if (queued) {
+      __syncthreads();
+      if (lane == 0) {
+        int e = -1;
+        const unsigned t = atomicAdd(args.q_head, 1u);
+        if (t < (unsigned)args.q_total) {
+          while ((e = __hip_atomic_load(&args.q_slots[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(16);
+        }
+        S.s.loop_break = e;
+      }
+      __syncthreads();
+      env = __builtin_amdgcn_readfirstlane(S.s.loop_break);
+      if (env < 0) return;
+      k0 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&args.q_done[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    rv_env_task<TMODE>(args, MODE, env, S, K, k0, queued ? k0 + 1 : 0);      // (the ONE call site of the env program in this kernel)
+    if (!queued) return;
+    __syncthreads();                                   // (the env's block is written: every lane's stores are issued)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (s_waitcnt vmcnt(0): the block has reached memory)
+    if (lane == 0) {
+      __hip_atomic_store(&args.q_done[env], k0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // (... and the step count, before the slot that hands the env on)
+      if (k0 + 1 < args.n_substeps) {
+        const unsigned p = atomicAdd(args.q_tail, 1u);
+        __hip_atomic_store(&args.q_slots[p], env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// One env, one run of the env program: load its block into LDS, run, store it back.  k0 / k_stop: MODE_ROLLOUT as a task
+// of the queue (the steps k0 .. k_stop - 1; 0 / 0: all steps).  Inlined at its single call site per branch of the kernel.
+template <int TMODE>
+__device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int MODE, const int env, Shared& S, const Consts& K, const int k0, const int k_stop) {
+  DevEnv* g = args.envs + env;
+  const int lane = (int)threadIdx.x;
   constexpr int W = (int)(sizeof(DevEnv) / 4);
   bool skip = false;
   if (MODE == MODE_RESET) skip = (args.mask != nullptr) && (args.mask[env] == 0);
@@ -109,10 +162,10 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
     // (the counters are per launch: an env the launch skips contributes nothing to rv_get_stats; an
     // env that a macro launch does not step -- its episode is over -- has no step result any more,
     // while a reset that masks it out, rv_step_sub or rv_wait_until_stable leave its reward alone)
-    if (lane == 0) launch_counters_zero(*g);
+    if (lane == 0 && k0 == 0) launch_counters_zero(*g);
     if (lane == 0 && (MODE == MODE_MACRO || MODE == MODE_ROLLOUT)) g->reward_valid = 0;
     if (MODE == MODE_ROLLOUT && args.budget == nullptr)   // steps not taken: reward 0, done, zero rows
-      for (int k = lane; k < args.n_substeps; k += 64) rollout_record(args.rec, nullptr, (size_t)k * args.n_envs + env, &S.cfg, &S.arm);
+      for (int k = k0 + lane; k < (k_stop > 0 ? k_stop : args.n_substeps); k += 64) rollout_record(args.rec, nullptr, (size_t)k * args.n_envs + env, &S.cfg, &S.arm);
     return;
   }
   if (MODE != MODE_RESET) env_enter(S, K);
@@ -120,6 +173,7 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
   pa.gid = K.cfg->env_id_offset + env; pa.n_steps = args.n_substeps;
   pa.lin_thr = args.lin_thr; pa.ang_thr = args.ang_thr; pa.check_after = args.check_after; pa.min_stable = args.min_stable; pa.max_steps = args.max_steps;
   pa.first_index = args.first_index; pa.auto_reset = args.auto_reset; pa.rec = args.rec; pa.env = env; pa.n_envs = args.n_envs; pa.budget = args.budget;
+  pa.k0 = k0; pa.k_stop = k_stop;
   // ONE call of the env program per kernel (it holds the only copy of the substep loop)
   const int resetting = MODE == MODE_PARTIAL && RV_UNI(S.e.in_step == 2);   // rv_set_auto_reset: a step begun on a finished episode -> env.reset()
   if (MODE == MODE_MACRO || MODE == MODE_SUB || MODE == MODE_WAIT || (MODE == MODE_PARTIAL && !resetting)) {
@@ -158,12 +212,21 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
 
 
 // launch k_env<mode> of THIS translation unit
-static inline void rv_launch_k_env_here(int mode, const EnvKernelArgs& a0, int n_envs, hipStream_t stream) {
-  const dim3 g((unsigned)n_envs), b(64);
+// (n_grid: one workgroup per env -- or, for a rollout through the task queue, as many as fit the GPU)
+static inline void rv_launch_k_env_here(int mode, const EnvKernelArgs& a0, int n_grid, hipStream_t stream) {
+  const dim3 g((unsigned)n_grid), b(64);
   EnvKernelArgs a = a0;
   a.mode = mode;
-  if (mode == MODE_ROLLOUT) hipLaunchKernelGGL(k_env<MODE_ROLLOUT>, g, b, 0, stream, a);
+  static const bool force_dispatch = getenv("RV_FORCE_DISPATCH") != nullptr;      // (measurement aid)
+  if (mode == MODE_ROLLOUT && a.q_slots == nullptr && !force_dispatch) hipLaunchKernelGGL(k_env<MODE_ROLLOUT>, g, b, 0, stream, a);
   else hipLaunchKernelGGL(k_env<-1>, g, b, 0, stream, a);
 }
+// workgroups of the run-time-dispatched kernel that are resident on one CU at a time (the queue's grid is this x CUs)
+static inline int rv_k_env_blocks_per_cu_here() {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_env<-1>, 64, 0) != hipSuccess) nb = 0;
+  return nb;
+}
 // ... and of the two-waves-per-SIMD build (rv_kernels_occ2.hip)
-void rv_launch_k_env_occ2(int mode, const EnvKernelArgs& a, int n_envs, hipStream_t stream);
+void rv_launch_k_env_occ2(int mode, const EnvKernelArgs& a, int n_grid, hipStream_t stream);
+int rv_k_env_occ2_blocks_per_cu();

@@ -552,6 +552,9 @@ struct rv_world {
   bool timed;
   int auto_reset;                         // rv_set_auto_reset
   int occ2;                               // more envs than SIMDs: launch k_env_occ2 (rv_env_kernel.h)
+  // rollouts of a world with more envs than the GPU has wave slots go through a task queue (rv_env_kernel.h): q_grid
+  // workgroups (what is resident at a time), d_q = [q_cap task slots][head, tail][n done counters]
+  int q_grid; int* d_q; size_t q_cap;
 };
 
 static thread_local std::string g_err;
@@ -564,8 +567,35 @@ static inline dim3 grid1(int n) { return dim3((unsigned)((n + 127) / 128)); }
 
 // the register-rich kernel while every env has a SIMD of its own, the two-waves-per-SIMD build beyond that
 static void launch_k_env(rv_world* w, int mode, const EnvKernelArgs& a) {
-  if (w->occ2) rv_launch_k_env_occ2(mode, a, w->n, w->stream);
-  else rv_launch_k_env_here(mode, a, w->n, w->stream);
+  const int n_grid = a.q_slots ? w->q_grid : w->n;
+  if (w->occ2) rv_launch_k_env_occ2(mode, a, n_grid, w->stream);
+  else rv_launch_k_env_here(mode, a, n_grid, w->stream);
+}
+__global__ void k_queue_init(int* slots, int n_envs, int total, unsigned* head_tail, int* done) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < total) slots[i] = i < n_envs ? i : -1;      // the first task of every env is published; the others by who finishes the step before
+  if (i < n_envs) done[i] = 0;
+  if (i == 0) { head_tail[0] = 0u; head_tail[1] = (unsigned)n_envs; }
+}
+// MODE_ROLLOUT of n_steps through the task queue?  Worlds with more envs than resident workgroups (RV_QUEUE=0: never)
+static int queue_setup(rv_world* w, int n_steps, EnvKernelArgs& a) {
+  a.q_slots = nullptr; a.q_head = nullptr; a.q_tail = nullptr; a.q_done = nullptr; a.q_total = 0;
+  const char* q = getenv("RV_QUEUE");      // (read per launch: the tests compare the two schedules in one process)
+  // (short rollouts gain nothing -- a task is an env.step(), so with few steps per env the tail is the same --; measured on
+  // 8192 envs: 2 steps -8 %, 10 steps +1 %, 20 steps +23 %, 30 steps +18 %.  RV_QUEUE=1 forces the queue, 0 forbids it)
+  if ((q && atoi(q) == 0) || w->q_grid <= 0 || w->n <= w->q_grid || (n_steps < 8 && !(q && atoi(q) == 1))) return RV_OK;
+  const size_t total = (size_t)w->n * (size_t)n_steps;
+  if (total > (size_t)0x3fffffff) return RV_OK;
+  const size_t need = total + 2 + (size_t)w->n;
+  if (w->q_cap < need) {
+    if (w->d_q) { HIPCHK(hipStreamSynchronize(w->stream)); HIPCHK(hipFree(w->d_q)); w->d_q = nullptr; w->q_cap = 0; }
+    HIPCHK(hipExtMallocWithFlags(reinterpret_cast<void**>(&w->d_q), need * sizeof(int), hipDeviceMallocUncached));
+    w->q_cap = need;
+  }
+  a.q_slots = w->d_q; a.q_head = reinterpret_cast<unsigned*>(w->d_q + total); a.q_tail = a.q_head + 1; a.q_done = w->d_q + total + 2; a.q_total = (int)total;
+  hipLaunchKernelGGL(k_queue_init, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, w->stream, a.q_slots, w->n, (int)total, a.q_head, a.q_done);
+  HIPCHK(hipGetLastError());
+  return RV_OK;
 }
 template <int MODE>
 static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, float ang, int ca, int ms, int mx,
@@ -579,6 +609,8 @@ static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, fl
   a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.mask = mask; a.n_envs = w->n;
   { const char* ds = getenv("RV_DEBUG_STOP"); a.stop_after = ds ? atoi(ds) : 0; }
   a.n_substeps = n_sub; a.lin_thr = lin; a.ang_thr = ang; a.check_after = ca; a.min_stable = ms; a.max_steps = mx;
+  a.q_slots = nullptr; a.q_head = nullptr; a.q_tail = nullptr; a.q_done = nullptr; a.q_total = 0;
+  if (MODE == MODE_ROLLOUT && budget == nullptr) { int rc = queue_setup(w, n_sub, a); if (rc != RV_OK) return rc; }
   HIPCHK(hipMemsetAsync(w->d_stats, 0, sizeof(rv_macro_stats), w->stream));
   HIPCHK(hipEventRecord(w->ev0, w->stream));
   launch_k_env(w, MODE, a);
@@ -632,12 +664,23 @@ int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world*
     int cus = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     w->occ2 = w->n > 4 * cus;
+    w->q_grid = 0; w->d_q = nullptr; w->q_cap = 0;
     const char* f = getenv("RV_ENV_OCC");
     if (f && (f[0] == '1' || f[0] == '2')) w->occ2 = f[0] == '2';
+    // the task queue's grid: every workgroup the GPU keeps resident of the kernel this world launches
+    const int per_cu = w->occ2 ? rv_k_env_occ2_blocks_per_cu() : rv_k_env_blocks_per_cu_here();
+    w->q_grid = per_cu > 0 ? per_cu * cus : 0;
   }
   HIPCHK(hipMalloc(&w->d_cfg, sizeof(rv_config)));
   HIPCHK(hipMalloc(&w->d_scene, sizeof(rv_scene)));
-  HIPCHK(hipMalloc(&w->d_envs, sizeof(DevEnv) * (size_t)w->n));
+  // a world whose rollouts go through the task queue keeps its env blocks in uncached device memory (rv_env_kernel.h: a
+  // block is handed from workgroup to workgroup between two env.step()s; it is touched at the ends of a task only)
+  if (w->q_grid > 0 && w->n > w->q_grid) {
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&w->d_envs), sizeof(DevEnv) * (size_t)w->n, hipDeviceMallocUncached) != hipSuccess) {
+      (void)hipGetLastError(); w->d_envs = nullptr; w->q_grid = 0;
+    }
+  }
+  if (!w->d_envs) HIPCHK(hipMalloc(&w->d_envs, sizeof(DevEnv) * (size_t)w->n));
   HIPCHK(hipMalloc(&w->d_stats, sizeof(rv_macro_stats)));
   HIPCHK(hipMalloc(&w->d_budget, sizeof(int)));
   HIPCHK(hipMemcpy(w->d_cfg, cfg, sizeof(rv_config), hipMemcpyHostToDevice));
@@ -656,7 +699,7 @@ int rv_destroy(rv_world* w) {
   if (!w) return RV_OK;
   (void)hipSetDevice(w->device);
   (void)hipStreamSynchronize(w->stream);
-  (void)hipFree(w->d_cfg); (void)hipFree(w->d_scene); (void)hipFree(w->d_envs); (void)hipFree(w->d_stats); (void)hipFree(w->d_budget);
+  (void)hipFree(w->d_cfg); (void)hipFree(w->d_scene); (void)hipFree(w->d_envs); (void)hipFree(w->d_stats); (void)hipFree(w->d_budget); if (w->d_q) (void)hipFree(w->d_q);
   if (w->d_snaps) (void)hipFree(w->d_snaps);
   (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1);
   delete w;

@@ -9,6 +9,7 @@
 #define k_env k_env_occ2
 #include "rv_env_kernel.h"
 
-void rv_launch_k_env_occ2(int mode, const EnvKernelArgs& a, int n_envs, hipStream_t stream) {
-  rv_launch_k_env_here(mode, a, n_envs, stream);
+void rv_launch_k_env_occ2(int mode, const EnvKernelArgs& a, int n_grid, hipStream_t stream) {
+  rv_launch_k_env_here(mode, a, n_grid, stream);
 }
+int rv_k_env_occ2_blocks_per_cu() { return rv_k_env_blocks_per_cu_here(); }

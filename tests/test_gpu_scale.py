@@ -463,3 +463,37 @@ def test_the_arm_is_drawn_and_occludes():
     assert np.array_equal(got, ref.point_cloud())
     assert not np.array_equal(got[0, 0], before[0, 0])                               # the occluded pixels are gone
     world.close()
+
+
+def test_rollout_through_the_task_queue_equals_the_plain_launch(monkeypatch):
+    """A world with more envs than the GPU keeps resident (2 x SIMDs) runs its rollouts through a task queue: one
+    env.step() per task, any workgroup, the env's block through HBM between its steps (rv_env_kernel.h).  Same results as
+    one workgroup per env -- states, per-step records, per-launch statistics -- with and without auto-reset, and the
+    64-env slice equals the oracle."""
+    from robovat_amd import lib
+    n = 4096 + 512
+    outs = []
+    for q in ('0', '1'):
+        monkeypatch.setenv('RV_QUEUE', q)
+        world = _world(n, seed=77, MAX_STEPS=2)
+        world.reset()
+        obs, r, d = world.rollout_record(3, first_macro_index=0, auto_reset=True, point_cloud=False)
+        st1 = world.stats()
+        r2, d2 = world.rollout(2, first_macro_index=3, auto_reset=False, record=True)
+        st2 = world.stats()
+        outs.append((world.body_state().cpu().numpy(), world.joint_state().cpu().numpy(), world.env_counters().cpu().numpy(),
+                     {k: v.cpu().numpy() for k, v in obs.items()}, r.cpu().numpy(), d.cpu().numpy(), r2.cpu().numpy(), d2.cpu().numpy(), st1, st2))
+        world.close()
+    a, b = outs
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
+    for k in a[3]:
+        assert np.array_equal(a[3][k], b[3][k]), k
+    for i in (4, 5, 6, 7):
+        assert np.array_equal(a[i], b[i]), i
+    assert a[8] == b[8] and a[9] == b[9]
+    assert a[8]['env_steps'] == 3 * n
+    # ... and the first 64 envs are the oracle's
+    ref = _oracle(64, seed=77, MAX_STEPS=2)
+    ref.reset(); ref.rollout(3, 0, True); ref.rollout(2, 3, False)
+    assert np.array_equal(b[0][:64], ref.body_state().astype(np.float32))
