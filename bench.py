@@ -599,16 +599,19 @@ def main():
                                       'roofline_frac_nominal': ALGO_BYTES['config3'] * st3['substeps'] / (1e-3 * km3) / 1e9 / HBM_PEAK_GBS})
         w3.close()
         # BASELINE configs[4], per-GPU point: config-2 scene, 8192 envs per GPU
+        # (the driver's N > 1 command: --steps 20 --warmup 5 at 8192 envs per GPU; rollouts of that size go through the task
+        # queue of rv_env_kernel.h, which needs some steps per env to pay: this leg runs args.steps after args.warmup too)
         w5, _ = make_world(8192)
         w5.reset()
-        el5, st5, km5, _ = time_rollout(w5, k3, 0)
-        extra['config5_8192'] = leg_summary(el5, st5, k3, 8192)
-        extra['config5_8192'].update({'workload': 'config-2 scene, 8192 envs per GPU',
+        w5.rollout(args.warmup, first_macro_index=0, auto_reset=True, record=True)
+        el5, st5, km5, _ = time_rollout(w5, args.steps, args.warmup)
+        extra['config5_8192'] = leg_summary(el5, st5, args.steps, 8192)
+        extra['config5_8192'].update({'workload': 'config-2 scene, 8192 envs per GPU, %d steps after %d warm-up steps (task queue: one env.step() per task)' % (args.steps, args.warmup),
                                       'roofline_frac_nominal': ALGO_BYTES['config2'] * st5['substeps'] / (1e-3 * km5) / 1e9 / HBM_PEAK_GBS})
         ea5 = None
         if not args.no_async:
             barrier(); ta = time.perf_counter()
-            w5.rollout_async(k3 * 8192, first_macro_index=k3)
+            w5.rollout_async(k3 * 8192, first_macro_index=args.warmup + args.steps)
             barrier(); ea5 = all_max(time.perf_counter() - ta)
             extra['config5_8192']['async_value'] = all_sum(w5.stats()['env_steps'])[0] / ea5
         w5.close()

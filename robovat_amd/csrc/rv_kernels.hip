@@ -668,7 +668,11 @@ int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world*
     const char* f = getenv("RV_ENV_OCC");
     if (f && (f[0] == '1' || f[0] == '2')) w->occ2 = f[0] == '2';
     // the task queue's grid: every workgroup the GPU keeps resident of the kernel this world launches
-    const int per_cu = w->occ2 ? rv_k_env_occ2_blocks_per_cu() : rv_k_env_blocks_per_cu_here();
+    // (the occupancy query does not see the waves-per-SIMD cap of the build: one wave per SIMD at 512 registers, two at
+    // 256 -- and the 20 KB LDS block allows eight workgroups per CU at most)
+    int per_cu = w->occ2 ? rv_k_env_occ2_blocks_per_cu() : rv_k_env_blocks_per_cu_here();
+    const int cap = w->occ2 ? 8 : 4;
+    if (per_cu > cap) per_cu = cap;
     w->q_grid = per_cu > 0 ? per_cu * cus : 0;
   }
   HIPCHK(hipMalloc(&w->d_cfg, sizeof(rv_config)));

@@ -42,7 +42,7 @@ for STAGE in "$@"; do
       cut -c1-300 $O/k50.json ;;
     profile)    bash tools/profile_bench.sh $TAG/profile > $O/profile.log 2>&1; tail -2 $O/profile.log ;;
     profile_nd) bash tools/profile_bench.sh $TAG/profile_nd --steps 2 --warmup 1 --over PHYSICS.SLEEP_STEPS=0 > $O/profile_nd.log 2>&1; tail -2 $O/profile_nd.log ;;
-    profile_c5) bash tools/profile_bench.sh $TAG/profile_c5 --workload config5 --steps 10 --warmup 2 > $O/profile_c5.log 2>&1; tail -2 $O/profile_c5.log ;;
+    profile_c5) bash tools/profile_bench.sh $TAG/profile_c5 --workload config5 --steps 20 --warmup 5 > $O/profile_c5.log 2>&1; tail -2 $O/profile_c5.log ;;
     profile_c3) bash tools/profile_bench.sh $TAG/profile_c3 --workload config3 --steps 10 --warmup 2 > $O/profile_c3.log 2>&1; tail -2 $O/profile_c3.log ;;
     profile_c4) bash tools/profile_bench.sh $TAG/profile_c4 --workload config4 --steps 10 --warmup 2 > $O/profile_c4.log 2>&1; tail -2 $O/profile_c4.log ;;
     parts)      timeout 400 python tools/prof_rollout.py --warm 1 --warm-steps 5 --top 10 > $O/parts.txt 2>&1; head -40 $O/parts.txt ;;

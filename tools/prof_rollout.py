@@ -38,6 +38,7 @@ ap.add_argument('--grasp', action='store_true', help='BASELINE config 4: Grasp4D
 args = ap.parse_args()
 
 os.environ['RV_LIB'] = PROF_LIB
+os.environ['RV_QUEUE'] = '0'      # (the per-env clock marks need an env to stay with one workgroup: the plain launch)
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 from robovat_amd import configs, scenes, lib   # noqa: E402
