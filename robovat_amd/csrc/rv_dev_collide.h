@@ -71,8 +71,16 @@ template <int N> RV_DEV int row_ror_i(int x) { return __builtin_amdgcn_update_dp
 // broadcast LDS read of the winning vertex
 // (v_max_f32 on the rotated value: equal to the ternary for every finite input up to the sign of a zero,
 // which neither the index search `val == m` nor the uses of the projection can see)
+// (ONE instruction, v_max_f32_dpp, behind the two wait states a DPP read of a just-written VGPR needs.  Through
+// __builtin_fmaxf(update_dpp(0, x), x) a step was five issue slots: the move of the `old' operand, the wait state, the DPP
+// move, a v_max x, x that quiets a possible signalling NaN of the moved value, and the maximum itself)
 template <int N> RV_DEV float row_ror_fmax(float x) {
-  return __builtin_fmaxf(row_ror_f<N>(x), x);
+  float r;
+  if (N == 8) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+  else if (N == 4) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+  else if (N == 2) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+  else asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+  return r;
 }
 template <int N> RV_DEV int row_ror_imin(int x) {
   int o = row_ror_i<N>(x);
