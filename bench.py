@@ -587,8 +587,11 @@ def main():
         # balance the tail of the slowest env away) -- where a throughput run of these semantics belongs
         if not args.quick:
             extra['reference_semantics']['gpu_8192'] = {
-                'early_exit_effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT), 8192, 2),
-                'effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT, **BULLET_SWEEPS), 8192, 2)}
+                # (8 steps per env: a launch of 2 leaves 25 - 30 % of the wave slots idle behind the last env.step()s -- an
+                # env.step() of these semantics is 0.25 - 0.6 s of one wave --, which says nothing about a run that goes on;
+                # from 8 steps on the rollout is scheduled step by step through the task queue of rv_env_kernel.h)
+                'early_exit_effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT), 8192, 8),
+                'effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT, **BULLET_SWEEPS), 8192, 8)}
         # BASELINE configs[2]: 'crossing' layout, V-HACD concave movables, 4096 envs
         w3, _ = make_world(4096, TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)
         w3.reset()
