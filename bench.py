@@ -586,12 +586,18 @@ def main():
         # ... and at 8192 envs per GPU (BASELINE configs[4]'s size: the two-waves-per-SIMD build, eight envs per SIMD to
         # balance the tail of the slowest env away) -- where a throughput run of these semantics belongs
         if not args.quick:
+            # 8 steps per env from a reset, and the first 2 alone (what rounds 4 / 5 quoted).  They differ by a factor of
+            # two, and not because of the GPU: without deactivation an env that has pushed a body against / onto another one
+            # keeps an island that needs all its sweeps in EVERY substep for the rest of the episode (with deactivation it
+            # falls asleep); the mean env costs the same per substep at every step of an episode, the slowest ones get 3 - 4 x
+            # slower, and a launch in which every env takes the same number of steps lasts as long as its slowest env
+            # (tools/nd_throttle_check.py: 2-step launches in a row 1.98 -> 2.47 -> 3.19 -> 3.78 s, a fresh world 1.97 s again)
             extra['reference_semantics']['gpu_8192'] = {
-                # (8 steps per env: a launch of 2 leaves 25 - 30 % of the wave slots idle behind the last env.step()s -- an
-                # env.step() of these semantics is 0.25 - 0.6 s of one wave --, which says nothing about a run that goes on;
-                # from 8 steps on the rollout is scheduled step by step through the task queue of rv_env_kernel.h)
                 'early_exit_effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT), 8192, 8),
-                'effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT, **BULLET_SWEEPS), 8192, 8)}
+                'effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT, **BULLET_SWEEPS), 8192, 4)}      # (4 steps: 11 s of GPU time as it is)
+            extra['reference_semantics']['gpu_8192_first_2_steps'] = {
+                'early_exit_effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT), 8192, 2),
+                'effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT, **BULLET_SWEEPS), 8192, 2)}
         # BASELINE configs[2]: 'crossing' layout, V-HACD concave movables, 4096 envs
         w3, _ = make_world(4096, TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)
         w3.reset()
