@@ -2156,6 +2156,7 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
   const int stall = c->solver_stall; int besti = 0x7f800000, since = 0;
   for (int it = 0; it < iters; ++it) {
     const float lam0 = lam;
+    const int lq = opaque_i(lane);      // (opaque once per sweep: see opaque_i)
 #pragma unroll
     for (int pp = 0; pp < 8; ++pp) {
       if (!(pp < 4 ? pp < ntx : pp - 4 < nax)) continue;
@@ -2165,7 +2166,7 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
         const int s = 3 * pp + kk;
         const float nl = kk == 0 ? __builtin_amdgcn_fmed3f(lam + T, 0.0f, capn) : __builtin_amdgcn_fmed3f(lam + T, -lim, lim);
         const float d = nl - lam;
-        if (opaque_i(lane) == s) lam = nl;
+        if (lq == s) lam = nl;
         const float sd = rdlane(d, s);
         if (kk == 0) lim = rdlane(mu * nl, s);
         T = rv_fma(A[s], sd, T);
@@ -2176,7 +2177,7 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
       const int s = 24 + m;
       const float nl = __builtin_amdgcn_fmed3f(lam + T, lo, hi);
       const float d = nl - lam;
-      if (opaque_i(lane) == s) lam = nl;
+      if (lq == s) lam = nl;
       T = rv_fma(A[s], rdlane(d, s), T);
     }
     if (LIMB) {
@@ -2185,7 +2186,7 @@ RV_DEV void solve_island_fingers_t(Shared& S, const Consts& K, const int X, cons
         const int s = 26 + j;
         const float nl = __builtin_amdgcn_fmed3f(lam + T, lo, hi);
         const float d = nl - lam;
-        if (opaque_i(lane) == s) lam = nl;
+        if (lq == s) lam = nl;
         T = rv_fma(A[s], rdlane(d, s), T);
       }
     }
