@@ -595,6 +595,28 @@ def main():
             extra['reference_semantics']['gpu_8192'] = {
                 'early_exit_effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT), 8192, 8),
                 'effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT, **BULLET_SWEEPS), 8192, 4)}      # (4 steps: 11 s of GPU time as it is)
+            # ... and work-conserving (rv_rollout_async: the envs share a pool of env.step() calls, each takes its next one
+            # while the pool lasts, episodes reset as they end) -- how the reference runs many envs: independent worker
+            # processes, each at its own pace (tools/parallel_run.py:54-90).  Nobody waits for the slowest env; the price
+            # is the mix: an env in a slow state contributes fewer steps (steps_per_env says how uneven it was)
+            def async_leg(over, per_env):
+                c = configs.make_rv_config(env_cfg=configs.push_env_config(**over), n_envs=8192, env_id_offset=rank * 8192, shape_names=names, **cfg_kwargs)
+                w = lib.World(c, scene, device=local_rank)
+                w.reset()
+                barrier(); t0 = time.perf_counter()
+                taken = w.rollout_async(per_env * 8192, first_macro_index=0)
+                st = w.stats()
+                barrier(); el = all_max(time.perf_counter() - t0)
+                tk = taken.cpu().numpy()
+                out = {'value': all_sum(st['env_steps'])[0] / el, 'unit': 'env_steps/s', 'sim_steps_per_s': all_sum(st['substeps'])[0] / el,
+                       'envs': 8192, 'pool': per_env * 8192, 'kernel_ms': w.last_kernel_ms(), 'episodes_done': st['episodes_done'],
+                       'steps_per_env': {'min': int(tk.min()), 'p10': float(np.percentile(tk, 10)), 'median': float(np.median(tk)), 'max': int(tk.max())}}
+                w.close()
+                return out
+            import numpy as np
+            extra['reference_semantics']['gpu_8192_work_conserving'] = {
+                'early_exit_effort_limited_motor': async_leg(dict(NO_DEACT), 8),
+                'effort_limited_motor': async_leg(dict(NO_DEACT, **BULLET_SWEEPS), 4)}
             extra['reference_semantics']['gpu_8192_first_2_steps'] = {
                 'early_exit_effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT), 8192, 2),
                 'effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT, **BULLET_SWEEPS), 8192, 2)}

@@ -104,10 +104,12 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
     rv_env_task<TMODE>(args, MODE, env, S, K, k0, queued ? k0 + 1 : 0);      // (the ONE call site of the env program in this kernel)
     if (!queued) return;
     __syncthreads();                                   // (the env's block is written: every lane's stores are issued)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (s_waitcnt vmcnt(0): the block has reached memory)
+    // (the block has reached memory: every store of the wave acknowledged.  A workgroup-scope release fence is NOT that -- for
+    // a workgroup of one wave it compiles to nothing --, and the hand-over lost a step now and then: 13 823 of 13 824)
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
     if (lane == 0) {
       __hip_atomic_store(&args.q_done[env], k0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // (... and the step count, before the slot that hands the env on)
+      __builtin_amdgcn_s_waitcnt(0x0F70);    // (... and the step count, before the slot that hands the env on)
       if (k0 + 1 < args.n_substeps) {
         const unsigned p = atomicAdd(args.q_tail, 1u);
         __hip_atomic_store(&args.q_slots[p], env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

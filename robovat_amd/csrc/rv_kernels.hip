@@ -12,6 +12,8 @@
 #include <stdlib.h>
 #include <stddef.h>
 #include <string>
+#include <vector>
+#include <mutex>
 #include <new>
 
 #include "../../include/rovat.h"
@@ -554,7 +556,7 @@ struct rv_world {
   int occ2;                               // more envs than SIMDs: launch k_env_occ2 (rv_env_kernel.h)
   // rollouts of a world with more envs than the GPU has wave slots go through a task queue (rv_env_kernel.h): q_grid
   // workgroups (what is resident at a time), d_q = [q_cap task slots][head, tail][n done counters]
-  int q_grid; int* d_q; size_t q_cap;
+  int q_grid; int* d_q; size_t q_cap; int envs_uc;
 };
 
 static thread_local std::string g_err;
@@ -571,6 +573,28 @@ static void launch_k_env(rv_world* w, int mode, const EnvKernelArgs& a) {
   if (w->occ2) rv_launch_k_env_occ2(mode, a, n_grid, w->stream);
   else rv_launch_k_env_here(mode, a, n_grid, w->stream);
 }
+// Uncached device memory (the env blocks and the queue of a world whose rollouts go through the task queue) is never
+// handed back to the allocator: after a hipFree of such a block, later worlds of the process read wrong data from the
+// ordinary allocations that took its place (ROCm 7.0, MI355X; found by the parity tests that ran after the first queue
+// test -- with the blocks leaked they pass).  A released block waits here for the next world that needs that size.
+struct UcBlock { void* p; size_t bytes; };
+static std::vector<UcBlock> g_uc_free;
+static std::mutex g_uc_mutex;
+static hipError_t uc_alloc(void** out, size_t bytes) {
+  bytes = ((bytes + ((size_t)2 << 20) - 1) >> 21) << 21;      // whole 2 MB pages
+  {
+    std::lock_guard<std::mutex> lk(g_uc_mutex);
+    for (size_t i = 0; i < g_uc_free.size(); ++i)
+      if (g_uc_free[i].bytes >= bytes && g_uc_free[i].bytes <= 2 * bytes) { *out = g_uc_free[i].p; g_uc_free.erase(g_uc_free.begin() + (long)i); return hipSuccess; }
+  }
+  return hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached);
+}
+static void uc_release(void* p, size_t bytes) {
+  if (!p) return;
+  bytes = ((bytes + ((size_t)2 << 20) - 1) >> 21) << 21;
+  std::lock_guard<std::mutex> lk(g_uc_mutex);
+  g_uc_free.push_back({p, bytes});
+}
 __global__ void k_queue_init(int* slots, int n_envs, int total, unsigned* head_tail, int* done) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i < total) slots[i] = i < n_envs ? i : -1;      // the first task of every env is published; the others by who finishes the step before
@@ -578,29 +602,34 @@ __global__ void k_queue_init(int* slots, int n_envs, int total, unsigned* head_t
   if (i == 0) { head_tail[0] = 0u; head_tail[1] = (unsigned)n_envs; }
 }
 // MODE_ROLLOUT of n_steps through the task queue?  Worlds with more envs than resident workgroups (RV_QUEUE=0: never)
-static int queue_setup(rv_world* w, int n_steps, EnvKernelArgs& a) {
+// pool > 0: the work-conserving rollout (rv_rollout_async) -- `pool` tasks in all, an env goes back to the tail after every
+// step, so the envs take turns and one in a slow state simply gets fewer of them
+static int queue_setup(rv_world* w, int n_steps, EnvKernelArgs& a, long long pool = 0) {
   a.q_slots = nullptr; a.q_head = nullptr; a.q_tail = nullptr; a.q_done = nullptr; a.q_total = 0;
   const char* q = getenv("RV_QUEUE");      // (read per launch: the tests compare the two schedules in one process)
   // (short rollouts gain nothing -- a task is an env.step(), so with few steps per env the tail is the same --; measured on
   // 8192 envs: 2 steps -8 %, 10 steps +1 %, 20 steps +23 %, 30 steps +18 %.  RV_QUEUE=1 forces the queue, 0 forbids it)
-  if ((q && atoi(q) == 0) || w->q_grid <= 0 || w->n <= w->q_grid || (n_steps < 8 && !(q && atoi(q) == 1))) return RV_OK;
-  const size_t total = (size_t)w->n * (size_t)n_steps;
+  if ((q && atoi(q) == 0) || w->q_grid <= 0 || w->n <= w->q_grid || (pool == 0 && n_steps < 8 && !(q && atoi(q) == 1))) return RV_OK;
+  const size_t total = pool > 0 ? (size_t)pool : (size_t)w->n * (size_t)n_steps;      // tasks that are taken
   if (total > (size_t)0x3fffffff) return RV_OK;
-  const size_t need = total + 2 + (size_t)w->n;
+  const size_t slots = total + (pool > 0 ? (size_t)w->n : 0);                           // ... and published (a pool: every env is put back)
+  const size_t need = slots + 2 + (size_t)w->n;
   if (w->q_cap < need) {
-    if (w->d_q) { HIPCHK(hipStreamSynchronize(w->stream)); HIPCHK(hipFree(w->d_q)); w->d_q = nullptr; w->q_cap = 0; }
-    HIPCHK(hipExtMallocWithFlags(reinterpret_cast<void**>(&w->d_q), need * sizeof(int), hipDeviceMallocUncached));
-    w->q_cap = need;
+    if (w->d_q) { HIPCHK(hipStreamSynchronize(w->stream)); uc_release(w->d_q, w->q_cap * sizeof(int)); w->d_q = nullptr; w->q_cap = 0; }
+    const size_t bytes = ((need * sizeof(int) + ((size_t)2 << 20) - 1) >> 21) << 21;
+    HIPCHK(uc_alloc(reinterpret_cast<void**>(&w->d_q), bytes));
+    w->q_cap = bytes / sizeof(int);
   }
-  a.q_slots = w->d_q; a.q_head = reinterpret_cast<unsigned*>(w->d_q + total); a.q_tail = a.q_head + 1; a.q_done = w->d_q + total + 2; a.q_total = (int)total;
-  hipLaunchKernelGGL(k_queue_init, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, w->stream, a.q_slots, w->n, (int)total, a.q_head, a.q_done);
+  a.q_slots = w->d_q; a.q_head = reinterpret_cast<unsigned*>(w->d_q + slots); a.q_tail = a.q_head + 1; a.q_done = w->d_q + slots + 2; a.q_total = (int)total;
+  const size_t init_n = slots > (size_t)w->n ? slots : (size_t)w->n;
+  hipLaunchKernelGGL(k_queue_init, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, w->stream, a.q_slots, w->n, (int)slots, a.q_head, a.q_done);
   HIPCHK(hipGetLastError());
   return RV_OK;
 }
 template <int MODE>
 static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, float ang, int ca, int ms, int mx,
                       int first_index = 0, int auto_reset = 0, const RolloutRec* rec = nullptr,
-                      int* budget = nullptr, int32_t* steps_taken = nullptr) {
+                      int* budget = nullptr, int32_t* steps_taken = nullptr, long long pool_tasks = 0) {
   EnvKernelArgs a;
   a.budget = budget; a.steps_taken = steps_taken; a.budget_clk = 0; a.finished = nullptr;
   a.first_index = first_index; a.auto_reset = auto_reset;
@@ -611,6 +640,12 @@ static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, fl
   a.n_substeps = n_sub; a.lin_thr = lin; a.ang_thr = ang; a.check_after = ca; a.min_stable = ms; a.max_steps = mx;
   a.q_slots = nullptr; a.q_head = nullptr; a.q_tail = nullptr; a.q_done = nullptr; a.q_total = 0;
   if (MODE == MODE_ROLLOUT && budget == nullptr) { int rc = queue_setup(w, n_sub, a); if (rc != RV_OK) return rc; }
+  if (MODE == MODE_ROLLOUT && budget != nullptr && pool_tasks > 0) {
+    // the work-conserving rollout of a world with more envs than resident workgroups: through the queue, or the
+    // workgroups that are resident first would use the pool up before the others have started
+    int rc = queue_setup(w, 0, a, pool_tasks); if (rc != RV_OK) return rc;
+    if (a.q_slots) { a.budget = nullptr; a.n_substeps = 0x7fffffff; }      // (an env always has "steps left": the pool ends the launch)
+  }
   HIPCHK(hipMemsetAsync(w->d_stats, 0, sizeof(rv_macro_stats), w->stream));
   HIPCHK(hipEventRecord(w->ev0, w->stream));
   launch_k_env(w, MODE, a);
@@ -680,9 +715,9 @@ int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world*
   // a world whose rollouts go through the task queue keeps its env blocks in uncached device memory (rv_env_kernel.h: a
   // block is handed from workgroup to workgroup between two env.step()s; it is touched at the ends of a task only)
   if (w->q_grid > 0 && w->n > w->q_grid) {
-    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&w->d_envs), sizeof(DevEnv) * (size_t)w->n, hipDeviceMallocUncached) != hipSuccess) {
+    if (uc_alloc(reinterpret_cast<void**>(&w->d_envs), sizeof(DevEnv) * (size_t)w->n) != hipSuccess) {
       (void)hipGetLastError(); w->d_envs = nullptr; w->q_grid = 0;
-    }
+    } else w->envs_uc = 1;
   }
   if (!w->d_envs) HIPCHK(hipMalloc(&w->d_envs, sizeof(DevEnv) * (size_t)w->n));
   HIPCHK(hipMalloc(&w->d_stats, sizeof(rv_macro_stats)));
@@ -703,7 +738,8 @@ int rv_destroy(rv_world* w) {
   if (!w) return RV_OK;
   (void)hipSetDevice(w->device);
   (void)hipStreamSynchronize(w->stream);
-  (void)hipFree(w->d_cfg); (void)hipFree(w->d_scene); (void)hipFree(w->d_envs); (void)hipFree(w->d_stats); (void)hipFree(w->d_budget); if (w->d_q) (void)hipFree(w->d_q);
+  (void)hipFree(w->d_cfg); (void)hipFree(w->d_scene);
+  if (w->envs_uc) uc_release(w->d_envs, sizeof(DevEnv) * (size_t)w->n); else (void)hipFree(w->d_envs); (void)hipFree(w->d_stats); (void)hipFree(w->d_budget); uc_release(w->d_q, w->q_cap * sizeof(int));
   if (w->d_snaps) (void)hipFree(w->d_snaps);
   (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1);
   delete w;
@@ -785,7 +821,7 @@ int rv_rollout_async(rv_world* w, int32_t total_env_steps, int32_t first_macro_i
   if (total_env_steps <= 0) return fail(RV_ERR_VALUE, "rv_rollout_async: total_env_steps must be positive");
   hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, w->stream, w->d_budget, (int)total_env_steps);
   HIPCHK(hipGetLastError());
-  return launch_env<MODE_ROLLOUT>(w, nullptr, 0, 0, 0, 0, 0, 0, first_macro_index, 1, nullptr, w->d_budget, d_steps_taken);
+  return launch_env<MODE_ROLLOUT>(w, nullptr, 0, 0, 0, 0, 0, 0, first_macro_index, 1, nullptr, w->d_budget, d_steps_taken, (long long)total_env_steps);
 }
 int rv_step_begin(rv_world* w, const float* d_actions, const uint8_t* d_mask) {
   WCHK(w);

@@ -497,3 +497,30 @@ def test_rollout_through_the_task_queue_equals_the_plain_launch(monkeypatch):
     ref = _oracle(64, seed=77, MAX_STEPS=2)
     ref.reset(); ref.rollout(3, 0, True); ref.rollout(2, 3, False)
     assert np.array_equal(b[0][:64], ref.body_state().astype(np.float32))
+
+
+def test_work_conserving_rollout_of_a_big_world_goes_through_the_queue(monkeypatch):
+    """rv_rollout_async on a world with more envs than resident workgroups: the pool of env.step() calls is shared by ALL
+    envs (through the task queue they take turns; with one workgroup per env the first-resident ones would use it up), the
+    steps taken add up to the pool, and every env's trajectory is a prefix of the one the lock-step rollout gives it."""
+    n, per_env = 4096 + 512, 3
+    monkeypatch.setenv('RV_QUEUE', '1')
+    world = _world(n, seed=78, MAX_STEPS=2)
+    world.reset()
+    taken = world.rollout_async(per_env * n, first_macro_index=0).cpu().numpy()
+    st = world.stats()
+    assert int(taken.sum()) == per_env * n == st['env_steps']
+    assert taken.min() >= 1 and taken.max() <= 3 * per_env and np.median(taken) == per_env      # everybody had its turns
+    got = world.body_state().cpu().numpy()
+    world.close()
+    # the same envs stepped in lock step, one step at a time: env i after taken[i] steps
+    ref = _world(n, seed=78, MAX_STEPS=2)
+    ref.reset()
+    want = ref.body_state().cpu().numpy().copy()
+    for k in range(int(taken.max())):
+        ref.rollout(1, first_macro_index=k, auto_reset=True)
+        cur = ref.body_state().cpu().numpy()
+        sel = taken == k + 1
+        want[sel] = cur[sel]
+    ref.close()
+    assert np.array_equal(got, want)
