@@ -151,6 +151,9 @@ struct DevEnv {
   // PushEnv leaves them at PHYSICS.ARM_FRICTION / SIM.TABLE.FRICTION
   float mu_finger, mu_table;
   int num_action_steps;       // Grasp4DofEnv: substeps spent in the 'start' phase
+  // rollouts through the task queue (rv_env_kernel.h): how many tasks of the running launch this block has been through, and
+  // the sum of its other words when it was last handed on -- the next workgroup takes the block only when both are right
+  int q_seq; unsigned q_sum;
 #ifdef RV_PROFILE
   unsigned long long prof[48], prof_t, prof_t2[4];   // tools/prof_rollout.py: shader-clock time per substep part
 #endif

@@ -76,14 +76,13 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
 #endif
   Consts K = lds_consts(args.scene, (MODE == MODE_SUB) ? args.stop_after : 0);
   // ---- the task queue (MODE_ROLLOUT; a plain launch is ONE pass of this loop: its env is the workgroup's own, all steps).
-  // Memory: the env blocks and the queue live in UNCACHED device memory when the queue is in use (rv_create:
-  // hipDeviceMallocUncached), so what one workgroup stored is what another loads, whichever XCD they run on, once the
-  // stores have completed (s_waitcnt vmcnt(0) = the workgroup-scope release below) -- agent-scope release / acquire
-  // would write back and invalidate the whole L2 of the XCD on every task, with everybody's scratch lines in it
-  // (measured: 8192 envs 121 k -> 116 k env-steps/s instead of a gain).  Lane 0 takes a ticket; the task of ticket t is published by whoever finished the
-  // env's previous step (release), or by the host for the first n_envs.  Every env is either in the queue or held by a
-  // running workgroup, and a workgroup that waits holds no env: the wait ends.  Results do not depend on who runs what:
-  // the envs are independent and their random streams are keyed by (env, step).
+  // Memory: a block is handed on with agent-scope ATOMIC stores and loads of its words (written through to memory / read
+  // from memory, past the XCD's L2), the slot that names the next task is published after those stores have been
+  // acknowledged (s_waitcnt vmcnt(0)), and the taker checks the block's step number and the sum of its words before it
+  // believes it (rv_env_task).  What was tried before: agent-scope release / acquire fences -- correct, but they write back and
+  // invalidate the XCD's whole L2 per task, everybody's scratch lines included (8192 envs: 121 k -> 116 k env-steps/s); and
+  // uncached device memory for the blocks -- fast, but intermittently wrong or stalled for seconds, and a hipFree of such
+  // memory corrupted later allocations of the process (ROCm 7.0).
   for (;;) {
     int env = (int)blockIdx.x, k0 = 0;
     if (queued) {
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
       __syncthreads();
       env = __builtin_amdgcn_readfirstlane(S.s.loop_break);
       if (env < 0) return;
-      k0 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&args.q_done[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      k0 = env / args.n_envs; env = env - k0 * args.n_envs;      // (a slot says whose turn it is AND which of its steps)
     }
     rv_env_task<TMODE>(args, MODE, env, S, K, k0, queued ? k0 + 1 : 0);      // (the ONE call site of the env program in this kernel)
     if (!queued) return;
@@ -108,16 +107,23 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
     // a workgroup of one wave it compiles to nothing --, and the hand-over lost a step now and then: 13 823 of 13 824)
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
     if (lane == 0) {
-      __hip_atomic_store(&args.q_done[env], k0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_s_waitcnt(0x0F70);    // (... and the step count, before the slot that hands the env on)
       if (k0 + 1 < args.n_substeps) {
         const unsigned p = atomicAdd(args.q_tail, 1u);
-        __hip_atomic_store(&args.q_slots[p], env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&args.q_slots[p], env + args.n_envs * (k0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
 }
 
+// sum of the words of the env block in LDS, the checksum word itself left out (every lane gets the total)
+__device__ __forceinline__ unsigned rv_block_sum(const Shared& S) {
+  constexpr int W = (int)(sizeof(DevEnv) / 4), QS = (int)(offsetof(DevEnv, q_sum) / 4);
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(&S.e);
+  unsigned acc = 0u;
+  for (int i = (int)threadIdx.x; i < W; i += 64) acc += (i == QS) ? 0u : w[i];
+  for (int o = 32; o > 0; o >>= 1) acc += (unsigned)__shfl_xor((int)acc, o);
+  return acc;
+}
 // One env, one run of the env program: load its block into LDS, run, store it back.  k0 / k_stop: MODE_ROLLOUT as a task
 // of the queue (the steps k0 .. k_stop - 1; 0 / 0: all steps).  Inlined at its single call site per branch of the kernel.
 template <int TMODE>
@@ -127,12 +133,25 @@ __device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int
   constexpr int W = (int)(sizeof(DevEnv) / 4);
   bool skip = false;
   if (MODE == MODE_RESET) skip = (args.mask != nullptr) && (args.mask[env] == 0);
-  {
+  for (;;) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&S.e);
-    for (int i = lane; i < W; i += 64) dst[i] = src[i];
+    // (a task of the queue: word by word with agent-scope atomic loads -- they go to memory, past the L2 of this XCD, which
+    // may hold what this block was several steps ago)
+    if (k_stop > 0) { for (int i = lane; i < W; i += 64) dst[i] = __hip_atomic_load(const_cast<uint32_t*>(&src[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else { for (int i = lane; i < W; i += 64) dst[i] = src[i]; }
+    __syncthreads();
+    // a task of the queue after the env's first: the block was stored by another workgroup a moment ago.  It is taken only
+    // when it carries the number of this step and its words add up to the sum its last owner left -- a block that is still
+    // on its way (the old one, or a mix) is read again.  (s_waitcnt vmcnt(0) before the hand-over made a stale read rare,
+    // not impossible: one step in ~80 000 tasks was still lost in the stress run, tools/queue_stress.py)
+    if (k_stop == 0 || k0 == 0) break;
+    const unsigned sum = rv_block_sum(S);
+    const int ok = __builtin_amdgcn_readfirstlane((int)(S.e.q_seq == k0 && S.e.q_sum == sum));
+    if (ok) break;
+    __syncthreads();
+    __builtin_amdgcn_s_sleep(8);
   }
-  __syncthreads();
 #ifdef RV_PROFILE
   if (lane == 0) { S.e.prof_t = __builtin_amdgcn_s_memtime(); for (int g2 = 0; g2 < 4; ++g2) S.e.prof_t2[g2] = S.e.prof_t; }
   __syncthreads();
@@ -143,7 +162,7 @@ __device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int
     // step (include/rovat.h, rv_step_begin): its phase machine is not resumed by a later poll -- without
     // this the next poll would run a second env.step() with the stale action.
     if (S.e.in_step != 0) {
-      if (lane == 0) { g->in_step = 0; g->step_stage = -1; }
+      if (lane == 0 && k_stop == 0) { g->in_step = 0; g->step_stage = -1; }      // (a task of the queue touches the block in HBM at its two ends only)
       __syncthreads();
       if (lane == 0) { S.e.in_step = 0; S.e.step_stage = -1; }
       __syncthreads();
@@ -164,12 +183,15 @@ __device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int
     // (the counters are per launch: an env the launch skips contributes nothing to rv_get_stats; an
     // env that a macro launch does not step -- its episode is over -- has no step result any more,
     // while a reset that masks it out, rv_step_sub or rv_wait_until_stable leave its reward alone)
-    if (lane == 0 && k0 == 0) launch_counters_zero(*g);
-    if (lane == 0 && (MODE == MODE_MACRO || MODE == MODE_ROLLOUT)) g->reward_valid = 0;
+    // (a task of the queue hands the block on through LDS like any other task: the changes go there)
+    DevEnv* tgt = k_stop > 0 ? &S.e : g;
+    if (lane == 0 && k0 == 0) launch_counters_zero(*tgt);
+    if (lane == 0 && (MODE == MODE_MACRO || MODE == MODE_ROLLOUT)) tgt->reward_valid = 0;
     if (MODE == MODE_ROLLOUT && args.budget == nullptr)   // steps not taken: reward 0, done, zero rows
       for (int k = k0 + lane; k < (k_stop > 0 ? k_stop : args.n_substeps); k += 64) rollout_record(args.rec, nullptr, (size_t)k * args.n_envs + env, &S.cfg, &S.arm);
-    return;
+    if (k_stop == 0) return;
   }
+  if (!skip) {
   if (MODE != MODE_RESET) env_enter(S, K);
   ProgArgs pa;
   pa.gid = K.cfg->env_id_offset + env; pa.n_steps = args.n_substeps;
@@ -189,7 +211,12 @@ __device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int
                    (MODE == MODE_PARTIAL ? RV_PROG_PARTIAL : (MODE == MODE_SUB ? RV_PROG_SUB : RV_PROG_WAIT))));
   const int fin = env_program(S, K, prog, pa);
   if (MODE == MODE_ROLLOUT) {
-    if (lane == 0 && args.steps_taken) args.steps_taken[env] = S.e.stepped;
+    // (through the queue the env's tasks run on different XCDs, each with an L2 of its own: plain stores of the same word
+    // from two of them may reach memory in either order at the end of the kernel -- an atomic store goes there at once)
+    if (lane == 0 && args.steps_taken) {
+      if (k_stop > 0) __hip_atomic_store(&args.steps_taken[env], S.e.stepped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else args.steps_taken[env] = S.e.stepped;
+    }
   } else if (MODE == MODE_PARTIAL) {
     if (resetting) {
       // the poll hands back what env.reset() returns
@@ -204,11 +231,21 @@ __device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int
       if (fin) rollout_record(args.rec, &S.e, (size_t)env, &S.cfg, &S.arm);     // what env.step() returns, for the envs that finished
     }
   }
+  }      // (!skip)
   __syncthreads();
+  if (k_stop > 0) {      // a task of the queue: the block leaves with its step number and the sum of its words
+    if (lane == 0) S.e.q_seq = k0 + 1;
+    __syncthreads();
+    const unsigned sum = rv_block_sum(S);
+    if (lane == 0) S.e.q_sum = sum;
+    __syncthreads();
+  }
   {
     uint32_t* dst = reinterpret_cast<uint32_t*>(g);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.e);
-    for (int i = lane; i < W; i += 64) dst[i] = src[i];
+    // (a task of the queue: agent-scope atomic stores -- written through to memory, where the next owner's loads look)
+    if (k_stop > 0) { for (int i = lane; i < W; i += 64) __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else { for (int i = lane; i < W; i += 64) dst[i] = src[i]; }
   }
 }
 

@@ -556,7 +556,7 @@ struct rv_world {
   int occ2;                               // more envs than SIMDs: launch k_env_occ2 (rv_env_kernel.h)
   // rollouts of a world with more envs than the GPU has wave slots go through a task queue (rv_env_kernel.h): q_grid
   // workgroups (what is resident at a time), d_q = [q_cap task slots][head, tail][n done counters]
-  int q_grid; int* d_q; size_t q_cap; int envs_uc;
+  int q_grid; int* d_q; size_t q_cap;
 };
 
 static thread_local std::string g_err;
@@ -573,28 +573,6 @@ static void launch_k_env(rv_world* w, int mode, const EnvKernelArgs& a) {
   if (w->occ2) rv_launch_k_env_occ2(mode, a, n_grid, w->stream);
   else rv_launch_k_env_here(mode, a, n_grid, w->stream);
 }
-// Uncached device memory (the env blocks and the queue of a world whose rollouts go through the task queue) is never
-// handed back to the allocator: after a hipFree of such a block, later worlds of the process read wrong data from the
-// ordinary allocations that took its place (ROCm 7.0, MI355X; found by the parity tests that ran after the first queue
-// test -- with the blocks leaked they pass).  A released block waits here for the next world that needs that size.
-struct UcBlock { void* p; size_t bytes; };
-static std::vector<UcBlock> g_uc_free;
-static std::mutex g_uc_mutex;
-static hipError_t uc_alloc(void** out, size_t bytes) {
-  bytes = ((bytes + ((size_t)2 << 20) - 1) >> 21) << 21;      // whole 2 MB pages
-  {
-    std::lock_guard<std::mutex> lk(g_uc_mutex);
-    for (size_t i = 0; i < g_uc_free.size(); ++i)
-      if (g_uc_free[i].bytes >= bytes && g_uc_free[i].bytes <= 2 * bytes) { *out = g_uc_free[i].p; g_uc_free.erase(g_uc_free.begin() + (long)i); return hipSuccess; }
-  }
-  return hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached);
-}
-static void uc_release(void* p, size_t bytes) {
-  if (!p) return;
-  bytes = ((bytes + ((size_t)2 << 20) - 1) >> 21) << 21;
-  std::lock_guard<std::mutex> lk(g_uc_mutex);
-  g_uc_free.push_back({p, bytes});
-}
 __global__ void k_queue_init(int* slots, int n_envs, int total, unsigned* head_tail, int* done) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i < total) slots[i] = i < n_envs ? i : -1;      // the first task of every env is published; the others by who finishes the step before
@@ -608,17 +586,16 @@ static int queue_setup(rv_world* w, int n_steps, EnvKernelArgs& a, long long poo
   a.q_slots = nullptr; a.q_head = nullptr; a.q_tail = nullptr; a.q_done = nullptr; a.q_total = 0;
   const char* q = getenv("RV_QUEUE");      // (read per launch: the tests compare the two schedules in one process)
   // (short rollouts gain nothing -- a task is an env.step(), so with few steps per env the tail is the same --; measured on
-  // 8192 envs: 2 steps -8 %, 10 steps +1 %, 20 steps +23 %, 30 steps +18 %.  RV_QUEUE=1 forces the queue, 0 forbids it)
-  if ((q && atoi(q) == 0) || w->q_grid <= 0 || w->n <= w->q_grid || (pool == 0 && n_steps < 8 && !(q && atoi(q) == 1))) return RV_OK;
+  // 8192 envs: 2 steps -8 %, 10 steps -4 ... +1 %, 20 steps +14 ... +23 %, 30 steps +18 %.  RV_QUEUE=1 forces the queue, 0 forbids it)
+  if ((q && atoi(q) == 0) || w->q_grid <= 0 || w->n <= w->q_grid || (pool == 0 && n_steps < 12 && !(q && atoi(q) == 1))) return RV_OK;
   const size_t total = pool > 0 ? (size_t)pool : (size_t)w->n * (size_t)n_steps;      // tasks that are taken
   if (total > (size_t)0x3fffffff) return RV_OK;
   const size_t slots = total + (pool > 0 ? (size_t)w->n : 0);                           // ... and published (a pool: every env is put back)
   const size_t need = slots + 2 + (size_t)w->n;
   if (w->q_cap < need) {
-    if (w->d_q) { HIPCHK(hipStreamSynchronize(w->stream)); uc_release(w->d_q, w->q_cap * sizeof(int)); w->d_q = nullptr; w->q_cap = 0; }
-    const size_t bytes = ((need * sizeof(int) + ((size_t)2 << 20) - 1) >> 21) << 21;
-    HIPCHK(uc_alloc(reinterpret_cast<void**>(&w->d_q), bytes));
-    w->q_cap = bytes / sizeof(int);
+    if (w->d_q) { HIPCHK(hipStreamSynchronize(w->stream)); HIPCHK(hipFree(w->d_q)); w->d_q = nullptr; w->q_cap = 0; }
+    HIPCHK(hipMalloc(&w->d_q, need * sizeof(int)));
+    w->q_cap = need;
   }
   a.q_slots = w->d_q; a.q_head = reinterpret_cast<unsigned*>(w->d_q + slots); a.q_tail = a.q_head + 1; a.q_done = w->d_q + slots + 2; a.q_total = (int)total;
   const size_t init_n = slots > (size_t)w->n ? slots : (size_t)w->n;
@@ -712,14 +689,7 @@ int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world*
   }
   HIPCHK(hipMalloc(&w->d_cfg, sizeof(rv_config)));
   HIPCHK(hipMalloc(&w->d_scene, sizeof(rv_scene)));
-  // a world whose rollouts go through the task queue keeps its env blocks in uncached device memory (rv_env_kernel.h: a
-  // block is handed from workgroup to workgroup between two env.step()s; it is touched at the ends of a task only)
-  if (w->q_grid > 0 && w->n > w->q_grid) {
-    if (uc_alloc(reinterpret_cast<void**>(&w->d_envs), sizeof(DevEnv) * (size_t)w->n) != hipSuccess) {
-      (void)hipGetLastError(); w->d_envs = nullptr; w->q_grid = 0;
-    } else w->envs_uc = 1;
-  }
-  if (!w->d_envs) HIPCHK(hipMalloc(&w->d_envs, sizeof(DevEnv) * (size_t)w->n));
+  HIPCHK(hipMalloc(&w->d_envs, sizeof(DevEnv) * (size_t)w->n));
   HIPCHK(hipMalloc(&w->d_stats, sizeof(rv_macro_stats)));
   HIPCHK(hipMalloc(&w->d_budget, sizeof(int)));
   HIPCHK(hipMemcpy(w->d_cfg, cfg, sizeof(rv_config), hipMemcpyHostToDevice));
@@ -739,7 +709,7 @@ int rv_destroy(rv_world* w) {
   (void)hipSetDevice(w->device);
   (void)hipStreamSynchronize(w->stream);
   (void)hipFree(w->d_cfg); (void)hipFree(w->d_scene);
-  if (w->envs_uc) uc_release(w->d_envs, sizeof(DevEnv) * (size_t)w->n); else (void)hipFree(w->d_envs); (void)hipFree(w->d_stats); (void)hipFree(w->d_budget); uc_release(w->d_q, w->q_cap * sizeof(int));
+  (void)hipFree(w->d_envs); (void)hipFree(w->d_stats); (void)hipFree(w->d_budget); if (w->d_q) (void)hipFree(w->d_q);
   if (w->d_snaps) (void)hipFree(w->d_snaps);
   (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1);
   delete w;
