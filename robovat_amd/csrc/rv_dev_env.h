@@ -2417,6 +2417,10 @@ RV_DEV void arm_collider_phases(Shared& S, const Consts& K, const int arm_on) {
   RV_LANES_BEGIN
     if (lane >= 16 && lane < 16 + RV_MAXB) { S.s.wake[lane - 16] = 0; S.s.bnear[lane - 16] = 0; }
     if (lane == 24) S.s.near_any = 0;
+    // (no arm in this substep -- the bodies settling after a reset: the boxes do not travel.  The wake test reads the travel
+    // whatever arm_on is and keeps its distance bounds; in a launch that BEGINS with a reset nothing had written it yet, and a
+    // negative left-over in LDS turned the bounds into "far away for ever" -- found by the poisoned-LDS build, round 5)
+    if (!arm_on && lane < RV_NCOL) S.s.coltravel[lane] = 0.0f;
     if (arm_on && lane < RV_NCOL) {
       const int col = lane; const int f = arm->col_frame[col];
       const v3 cc = ld3(arm->col_center[col]), hh = ld3(arm->col_half[col]);

@@ -39,6 +39,7 @@ struct EnvKernelArgs {
   // in HBM, and puts the env back at the tail while it has steps left.  q_slots[t] = env of task t (-1: not yet published),
   // q_total = n_envs x n_steps tasks in all.  nullptr: one workgroup per env, all its steps (the plain launch)
   int* q_slots; unsigned* q_head; unsigned* q_tail; int* q_done; int q_total;
+  int poison_lo, poison_hi;      // RV_POISON_LDS builds: the words of the scratch block that start as garbage (RV_POISON_LO / _HI: bisecting)
 };
 
 // TMODE = MODE_ROLLOUT: the single-launch rollout, a kernel of its own (it is the one bench.py times and the profiles
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
   {                       // to launch, so that a read of a field no phase of THIS launch wrote shows up as a parity failure
     uint32_t* dst = reinterpret_cast<uint32_t*>(&S.s);
     const uint32_t pat = (uint32_t)RV_POISON_LDS;
-    for (int i = lane; i < (int)(sizeof(Scratch) / 4); i += 64) dst[i] = pat + (uint32_t)i * 2654435761u * (pat & 1u);
+    for (int i = lane; i < (int)(sizeof(Scratch) / 4); i += 64) if (i >= args.poison_lo && i < args.poison_hi) dst[i] = pat + (uint32_t)i * 2654435761u * (pat & 1u);
   }
 #endif
   Consts K = lds_consts(args.scene, (MODE == MODE_SUB) ? args.stop_after : 0);

@@ -603,6 +603,11 @@ static int queue_setup(rv_world* w, int n_steps, EnvKernelArgs& a, long long poo
   HIPCHK(hipGetLastError());
   return RV_OK;
 }
+// RV_POISON_LDS builds (tools/build_poison.py): which words of the scratch block start as garbage; everything by default
+static void poison_range(EnvKernelArgs& a) {
+  const char* lo = getenv("RV_POISON_LO"); const char* hi = getenv("RV_POISON_HI");
+  a.poison_lo = lo ? atoi(lo) : 0; a.poison_hi = hi ? atoi(hi) : 0x7fffffff;
+}
 template <int MODE>
 static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, float ang, int ca, int ms, int mx,
                       int first_index = 0, int auto_reset = 0, const RolloutRec* rec = nullptr,
@@ -616,6 +621,7 @@ static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, fl
   { const char* ds = getenv("RV_DEBUG_STOP"); a.stop_after = ds ? atoi(ds) : 0; }
   a.n_substeps = n_sub; a.lin_thr = lin; a.ang_thr = ang; a.check_after = ca; a.min_stable = ms; a.max_steps = mx;
   a.q_slots = nullptr; a.q_head = nullptr; a.q_tail = nullptr; a.q_done = nullptr; a.q_total = 0;
+  poison_range(a);
   if (MODE == MODE_ROLLOUT && budget == nullptr) { int rc = queue_setup(w, n_sub, a); if (rc != RV_OK) return rc; }
   if (MODE == MODE_ROLLOUT && budget != nullptr && pool_tasks > 0) {
     // the work-conserving rollout of a world with more envs than resident workgroups: through the queue, or the
@@ -813,6 +819,7 @@ int rv_step_poll(rv_world* w, int32_t max_substeps, int32_t max_usec, uint8_t* d
   memset(&a, 0, sizeof(a));
   a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.n_envs = w->n;
   a.n_substeps = max_substeps; a.finished = d_finished; a.auto_reset = w->auto_reset;
+  poison_range(a);
   a.rec.rewards = d_reward; a.rec.dones = d_done;
   float* d_pc = nullptr;
   if (obs) {

@@ -16,11 +16,24 @@ struct EmuWorld {
   rv_config cfg; rv_scene scene; int n; DevEnv* envs;
 };
 
+/* LDS is not zero-initialised on the GPU: the scratch block starts as garbage.  NaNs by default; RV_EMU_POISON = another word
+   (a finite huge float finds other reads than a NaN does), on words [RV_EMU_POISON_LO, RV_EMU_POISON_HI) */
+static void poison_scratch(Shared& S) {
+  memset(&S.s, 0xFF, sizeof(S.s));
+  if (const char* pat = getenv("RV_EMU_POISON")) {
+    const uint32_t v = (uint32_t)strtoul(pat, nullptr, 0);
+    const char* lo = getenv("RV_EMU_POISON_LO"); const char* hi = getenv("RV_EMU_POISON_HI");
+    const long a = lo ? atol(lo) : 0, b = hi ? atol(hi) : (long)(sizeof(S.s) / 4);
+    uint32_t* dst = (uint32_t*)&S.s;
+    for (long k = 0; k < (long)(sizeof(S.s) / 4); ++k) if (k >= a && k < b) dst[k] = v;
+  }
+}
+
 static void run_env(EmuWorld* w, int i, int mode, int n_sub, float lin, float ang, int ca, int ms, int mx) {
   Shared& S = g_shared;
-  memset(&S.s, 0xFF, sizeof(S.s));
+  poison_scratch(S);
   S.cfg = w->cfg; S.arm = w->scene.arm;
-  Consts K = lds_consts(&w->scene, 0);  /* LDS is not zero-initialised on the GPU: poison it */
+  Consts K = lds_consts(&w->scene, 0);
   memcpy(&S.e, &w->envs[i], sizeof(DevEnv));
   if (mode == 1 && S.e.done) { w->envs[i].substeps_last = 0; w->envs[i].awake_last = 0; w->envs[i].pairs_last = 0; w->envs[i].stepped = 0; return; }
   if (mode != 0) env_enter(S, K);
@@ -92,7 +105,7 @@ void emu_step_poll(EmuWorld* w, int max_substeps, uint8_t* finished) {
     g.l_unsafe = 0; g.l_ineffective = 0; g.l_useful = 0; g.l_episodes = 0; g.l_successes = 0;
     if (g.in_step != 1) { finished[i] = g.in_step == 2; if (g.in_step == 2) { g.in_step = 0; g.reward_valid = 0; } continue; }
     Shared& S = g_shared;
-    memset(&S.s, 0xFF, sizeof(S.s));
+    poison_scratch(S);
     S.cfg = w->cfg; S.arm = w->scene.arm;
     Consts K = lds_consts(&w->scene, 0);
     memcpy(&S.e, &g, sizeof(DevEnv));

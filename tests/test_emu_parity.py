@@ -235,3 +235,22 @@ def test_concentric_overlaps_run_epa_from_a_grown_simplex(emu):
     assert same_shape.sum() >= 4 and deep == same_shape.sum(), (deep, same_shape.sum())
     ref.step_sub(30); emu.emu_step_sub(e.h, 30)
     assert np.array_equal(e.body_state(), ref.body_state().astype(np.float32))
+
+
+@pytest.mark.parametrize('garbage', ['0xe846f641', '0x7f7fffff', '0x00000000', '0x3f800000'])
+def test_a_launch_that_begins_with_a_reset_reads_nothing_left_over_in_the_scratch_block(emu, garbage, monkeypatch):
+    """One-step rollouts with auto_reset over episodes of two steps: every other launch begins with reset + settle (no arm
+    in those substeps) and goes straight on to a step.  The scratch block starts as `garbage` (tests/emu: RV_EMU_POISON; NaNs
+    otherwise).  With a huge negative float the wake test's box-travel scratch, which only substeps WITH the arm used to
+    write, turned the distance bounds of the sleepers into "far for ever" (round 5: 11 of 64 envs differed on the GPU's
+    poisoned-LDS build, tools/diag_poison_bisect.py named the word)."""
+    from oracle import orc
+    monkeypatch.setenv('RV_EMU_POISON', garbage)
+    scene, names = scenes.make_scene()
+    cfg = configs.make_rv_config(env_cfg=configs.push_env_config(MAX_STEPS=2), n_envs=24, seed=78, shape_names=names)
+    ref = orc.OracleWorld(cfg, scene, double=False)
+    e = Emu(emu, cfg, scene)
+    ref.reset(); emu.emu_reset(e.h, None)
+    for k in range(4):
+        ref.rollout(1, k, True); emu.emu_rollout(e.h, 1, k, 1)
+        _check(e, ref)
