@@ -25,7 +25,7 @@ static void poison_scratch(Shared& S) {
     const char* lo = getenv("RV_EMU_POISON_LO"); const char* hi = getenv("RV_EMU_POISON_HI");
     const long a = lo ? atol(lo) : 0, b = hi ? atol(hi) : (long)(sizeof(S.s) / 4);
     uint32_t* dst = (uint32_t*)&S.s;
-    for (long k = 0; k < (long)(sizeof(S.s) / 4); ++k) if (k >= a && k < b) dst[k] = v;
+    for (long k = 0; k < (long)(sizeof(S.s) / 4); ++k) if (k >= a && k < b) dst[k] = v + (uint32_t)k * 2654435761u * (v & 1u);   /* (an odd word is hashed per position, as in the kernel's RV_POISON_LDS) */
   }
 }
 

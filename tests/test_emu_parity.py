@@ -237,11 +237,11 @@ def test_concentric_overlaps_run_epa_from_a_grown_simplex(emu):
     assert np.array_equal(e.body_state(), ref.body_state().astype(np.float32))
 
 
-@pytest.mark.parametrize('garbage', ['0xe846f641', '0x7f7fffff', '0x00000000', '0x3f800000'])
+@pytest.mark.parametrize('garbage', ['0xe846f640', '0x7f7ffffe', '0x00000000', '0x3f9d7a31'])
 def test_a_launch_that_begins_with_a_reset_reads_nothing_left_over_in_the_scratch_block(emu, garbage, monkeypatch):
     """One-step rollouts with auto_reset over episodes of two steps: every other launch begins with reset + settle (no arm
     in those substeps) and goes straight on to a step.  The scratch block starts as `garbage` (tests/emu: RV_EMU_POISON; NaNs
-    otherwise).  With a huge negative float the wake test's box-travel scratch, which only substeps WITH the arm used to
+    otherwise; an odd word is hashed per position).  With a huge negative float the wake test's box-travel scratch, which only substeps WITH the arm used to
     write, turned the distance bounds of the sleepers into "far for ever" (round 5: 11 of 64 envs differed on the GPU's
     poisoned-LDS build, tools/diag_poison_bisect.py named the word)."""
     from oracle import orc
