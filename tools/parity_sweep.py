@@ -1,6 +1,9 @@
 #!/usr/bin/env python
 """HIP kernel vs float oracle, bit for bit, over many seeds / configs (MI355X; a wider net than the test-suite):
-    python tools/parity_sweep.py [n_seeds=8] [n_envs=128] [steps=8]
+    python tools/parity_sweep.py [n_seeds=8] [n_envs=128] [steps=8] [split]
+split: the steps of a run as several launches of 1, 2, 1, 3, ... steps (launches that begin with envs whose episode has just
+ended, i.e. with a reset; the oracle's result does not depend on the split).  RV_LIB=build/librovat_poison_*.so: the same with
+the LDS scratch block starting as garbage in every launch.
 """
 import os
 import sys
@@ -14,6 +17,18 @@ from oracle import orc  # noqa: E402
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+split = len(sys.argv) > 4 and sys.argv[4] == 'split'
+
+
+def launches(total):
+    if not split:
+        return [(0, total)]
+    out, k, i = [], 0, 0
+    while k < total:
+        c = min((1, 2, 1, 3)[i % 4], total - k); out.append((k, c)); k += c; i += 1
+    return out
+
+
 CASES = [('config 2', {}), ('crossing / concave', dict(TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)),
          ('crowded: 4 bodies in a 20 cm square', {'MOVABLE.CONVEX.POSE.X': [0.5, 0.7], 'MOVABLE.CONVEX.POSE.Y': [-0.1, 0.1], 'MOVABLE.CONVEX.MARGIN': 0.07}),
          ('dynamic limb, 1-4 bodies', {'PHYSICS.LIMB_DYNAMICS': 1, 'MIN_MOVABLE_BODIES': 1, 'MAX_MOVABLE_BODIES': 4}),
@@ -48,13 +63,14 @@ for name, over in CASES:
                 x.set_constraint(1, [0.6, 0.05 * (seed % 3), 0.12, 0, 0, 0, 1], frame7=[0.02, 0.01, 0.0, 0, 0, 0, 1], max_force=30.0, joint_type='point2point')
                 x.set_constraint(2, [0.0, 0.0, 0.07, 0, 0, 0, 1], max_force=40.0, child=0)
                 x.set_constraint(3, [0.55, -0.1, 0.1, 0, 0, np.sin(0.3), np.cos(0.3)], frame7=[0, 0, 0, 0, 0, np.sin(0.3), np.cos(0.3)], max_force=40.0, joint_type='prismatic')
-        w.rollout(steps if not cons else 2, first_macro_index=0, auto_reset=not cons, record=False); w.synchronize()
-        o.rollout(steps if not cons else 2, 0, not cons)
+        for k0, c in launches(steps if not cons else 2):
+            w.rollout(c, first_macro_index=k0, auto_reset=not cons, record=False); w.synchronize()
+            o.rollout(c, k0, not cons)
         eq_b = np.array_equal(w.body_state().cpu().numpy(), o.body_state().astype(np.float32))
         eq_j = np.array_equal(w.joint_state().cpu().numpy(), o.joint_state().astype(np.float32))
         eq_c = np.array_equal(w.env_counters().cpu().numpy()[:, :8], o.env_counters()[:, :8])
         st = w.stats()
-        print('%-38s seed %d: bodies %s joints %s counters %s | awake %.3f' % (name, 1000 + seed, eq_b, eq_j, eq_c, st['awake_substeps'] / st['substeps']), flush=True)
+        print('%-38s seed %d: bodies %s joints %s counters %s | awake %.3f' % (name, 1000 + seed, eq_b, eq_j, eq_c, st['awake_substeps'] / max(st['substeps'], 1)), flush=True)
         bad += not (eq_b and eq_j)
         w.close()
 # Grasp4DofEnv (force-limited gripper in the solver, phase machine ticking every substep), kinematic and dynamic limb
@@ -64,8 +80,9 @@ for seed in range(max(n_seeds // 2, 1) * 2):
     cfg = configs.make_rv_config(env_cfg=genv, n_envs=n, seed=2000 + seed, shape_names=gnames)
     w = lib.World(cfg, gscene, device=0); o = orc.OracleWorld(cfg, gscene, double=False)
     w.reset(); o.reset()
-    w.rollout(min(steps, 4), first_macro_index=0, auto_reset=True, record=False); w.synchronize()
-    o.rollout(min(steps, 4), 0, True)
+    for k0, c in launches(min(steps, 4)):
+        w.rollout(c, first_macro_index=k0, auto_reset=True, record=False); w.synchronize()
+        o.rollout(c, k0, True)
     eq_b = np.array_equal(w.body_state().cpu().numpy(), o.body_state().astype(np.float32))
     eq_j = np.array_equal(w.joint_state().cpu().numpy(), o.joint_state().astype(np.float32))
     st = w.stats()
