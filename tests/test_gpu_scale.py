@@ -524,3 +524,21 @@ def test_work_conserving_rollout_of_a_big_world_goes_through_the_queue(monkeypat
         want[sel] = cur[sel]
     ref.close()
     assert np.array_equal(got, want)
+
+
+def test_rollouts_cut_into_launches_of_any_length_equal_the_oracle():
+    """The steps of a run as launches of 1, 2, 1, 3 ... steps with auto_reset over episodes of two steps: launches begin with
+    envs whose episode has just ended (reset + settle, no arm in those substeps, then straight on to a step).  What a launch
+    finds in its LDS scratch block must not matter (round 5: the wake test's box travel was read before a substep with the
+    arm had written it; the poisoned-LDS builds run this test as well, tools/gpu.sh ... poison)."""
+    n = 96
+    world = _world(n, seed=78, MAX_STEPS=2)
+    ref = _oracle(n, seed=78, MAX_STEPS=2)
+    world.reset(); ref.reset()
+    k = 0
+    for c in (1, 2, 1, 3, 1, 1):
+        world.rollout(c, first_macro_index=k, auto_reset=True); ref.rollout(c, k, True)
+        k += c
+        assert np.array_equal(world.body_state().cpu().numpy(), ref.body_state().astype(np.float32)), k
+        assert np.array_equal(world.joint_state().cpu().numpy(), ref.joint_state().astype(np.float32)), k
+    world.close()
