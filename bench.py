@@ -36,15 +36,130 @@ ALGO_BYTES = {'config2': 3056, 'config3': 5552}
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_PER_SIMD_CYCLE = 0.5      # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
 
+LINE_LIMIT = 8000                   # bytes of the ONE stdout line (the round-5 line was 22.7 KB and the driver could not parse it)
+
+
+def _short(s, n=220):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + '...'
+
+
+def _leg_scalars(v):
+    """`value` (+ the few scalars worth a glance) of a leg; nested legs (reference_semantics.gpu.x ...) keep their shape."""
+    if not isinstance(v, dict):
+        return None
+    if 'value' in v and isinstance(v['value'], (int, float)):
+        out = {'value': round(v['value'], 1)}
+        for k in ('sim_steps_per_s', 'ms_per_step', 'envs_per_gpu', 'envs', 'steps', 'cores', 'async_value', 'grasp_success_rate',
+                  'one_wave_us_per_substep', 'thread_us_per_awake_substep'):
+            if isinstance(v.get(k), (int, float)):
+                out[k] = round(v[k], 3) if isinstance(v[k], float) else v[k]
+        return out
+    out = {}
+    for k, x in v.items():
+        sub = _leg_scalars(x)
+        if sub:
+            out[k] = sub
+    return out or None
+
+
+def _sig(x, digits=6):
+    """floats to `digits` significant digits, recursively (the full precision is in the side file)"""
+    if isinstance(x, float):
+        return float('%.*g' % (digits, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_line(full, limit=LINE_LIMIT, full_record=None):
+    """The one JSON line the driver parses: the contract's keys, `roofline`, `cpu_baseline`, one scalar group per extra leg.
+    Everything else (notes, per-leg outcome statistics, the nested semantics legs) is in `full_record` (bench_legs.json)
+    and on stderr.  Guaranteed < `limit` bytes: optional groups are dropped, least important first, until it fits."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data', 'sim_steps_per_s', 'substeps_per_env_step', 'awake_sim_steps_per_s', 'awake_substep_fraction',
+            'max_substeps_in_launch', 'n1_same_workload', 'scaling_efficiency_vs_n1_same_workload')
+    line = {k: full[k] for k in keep if k in full}
+    line['config'] = {k: (_short(v) if isinstance(v, str) else v) for k, v in full.get('config', {}).items()}
+    rf = full.get('roofline')
+    if rf:
+        r = {k: rf[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'avg_kernel_ms',
+                                'valu_insts_per_env_substep', 'env_substeps_per_launch', 'occupied_simds') if k in rf}
+        hn = rf.get('hbm_nominal')
+        if hn:
+            r['hbm_nominal'] = {k: hn[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'algorithmic_bytes_per_env_substep',
+                                                  'achieved_awake_substeps_only') if k in hn}
+        isd = rf.get('issue_side')
+        if isd:
+            r['while_resident'] = {k: isd[k] for k in ('valu_issue_frac_of_peak_while_resident', 'wait_frac', 'source') if k in isd}
+        line['roofline'] = r
+    cb = full.get('cpu_baseline')
+    if cb:
+        line['cpu_baseline'] = {k: (_short(cb[k], 300) if isinstance(cb[k], str) else cb[k])
+                                for k in ('value', 'unit', 'cores', 'kind', 'sample', 'sim_steps_per_s', 'thread_us_per_awake_substep',
+                                          'scaling_1_to_n', 'compiler_flags') if k in cb}
+    if 'pybullet' in full:
+        pbv = full['pybullet']
+        line['pybullet'] = {k: (_short(v, 300) if isinstance(v, str) else v) for k, v in pbv.items()
+                            if k in ('status', 'pose_err_hip_vs_pybullet', 'pose_err_f64_oracle_vs_pybullet', 'step_simulation')} \
+            if isinstance(pbv, dict) else _short(pbv, 300)
+    optional = []                       # (name, value), most important first
+    pe = full.get('pose_err')
+    if pe:
+        optional.append(('pose_err_vs_f64_oracle', {k: {'max_pos_m': v['max_pos_m'], 'p99_pos_m': v['p99_pos_m'], 'max_angle_rad': v['max_angle_rad']}
+                                                  for k, v in pe.items() if isinstance(v, dict) and 'max_pos_m' in v}))
+    legs = {}
+    skip = set(line) | {'roofline', 'cpu_baseline', 'config', 'pose_err', 'pybullet', 'host', 'deactivation'}
+    for k, v in full.items():
+        if k in skip:
+            continue
+        sub = _leg_scalars(v)
+        if sub:
+            legs[k] = sub
+    if legs:
+        optional.append(('legs', legs))
+    de = (full.get('deactivation') or {})
+    if de.get('pose_equivalence'):
+        optional.append(('deactivation_pose_equivalence', {
+            k: {q: v[q] for q in ('env_steps', 'median_m', 'p90_m', 'p99_m', 'max_m', 'flags_agree', 'within_bounds', 'horizon') if q in v}
+            for k, v in de['pose_equivalence'].items() if isinstance(v, dict)}))
+    dl = {k: _leg_scalars(v) for k, v in de.items() if k != 'pose_equivalence' and _leg_scalars(v)}
+    if dl:
+        optional.append(('deactivation_legs', dl))
+    if full_record:
+        line['full_record'] = full_record
+    for name, val in optional:
+        line[name] = val
+    text = json.dumps(_sig(line))
+    while len(text) >= limit and optional:
+        name, _ = optional.pop()
+        del line[name]
+        line['dropped_for_size'] = line.get('dropped_for_size', []) + [name]
+        text = json.dumps(_sig(line))
+    assert len(text) < limit, len(text)
+    return text
+
 
 def effective_cpus():
     from oracle import orc
     return orc.effective_cpus()
 
 
+def pybullet_probe():
+    """(module or None, status): `import pybullet` is executed every time this is called (tools/pybullet_parity.py);
+    no string about its availability in this file is a constant."""
+    tools = os.path.join(ROOT, 'tools')
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import pybullet_parity
+    return pybullet_parity.probe()
+
+
 def cpu_legs(cfg_kwargs, scene, names, quick=False):
-    """Everything that runs the CPU oracle (kind 'port': pybullet, the reference's physics,
-    is not importable here): the same-workload baseline, the reference-semantics legs, BASELINE
+    """Everything that runs the CPU oracle (kind 'port'; whether pybullet, the reference's physics, can be
+    imported is asked at run time -- pybullet_probe() -- and its answer is part of the record): the same-workload baseline, the reference-semantics legs, BASELINE
     config 1 (1 env, HeuristicPushPolicy, 20 episodes; one thread and one worker per core as
     tools/parallel_run.py would start them), the pose-level deactivation comparison and the
     FP32-vs-FP64 pose error.
@@ -58,6 +173,7 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
     from robovat_amd import configs, lib, scenes
     from oracle import orc
     cores = effective_cpus()
+    pb_status = pybullet_probe()[1]
     out = {'host': {'cpu_count': os.cpu_count(), 'threads_used': cores,
                     'note': 'threads_used = min(CPU count, affinity mask, cgroup CPU quota): what the container may keep busy'}}
     orc.set_num_threads(cores)
@@ -114,7 +230,7 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
         'value': cb['value'], 'unit': 'env_steps/s', 'cores': cores, 'kind': 'port',
         'sim_steps_per_s': cb['sim_steps_per_s'], 'awake_sim_steps_per_s': cb['awake_sim_steps_per_s'],
         'sample': '%d envs (%d per thread) x %d env.step() of the same workload in %.1f s, float C oracle, OpenMP over envs with '
-                  'schedule(dynamic) (pybullet not importable -> reference loop skipped)' % (n, per_thread, cb['steps'], cb['seconds']),
+                  'schedule(dynamic); reference loop on pybullet: %s' % (n, per_thread, cb['steps'], cb['seconds'], pb_status),
         'thread_us_per_substep': cb['thread_us_per_substep'], 'thread_us_per_awake_substep': cb['thread_us_per_awake_substep'],
         'one_thread': cb['one_thread'], 'scaling_1_to_n': cb['scaling_1_to_n'],
         'mean_sweeps_per_island_solve': cb['mean_sweeps_per_island_solve'],
@@ -175,7 +291,7 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
         return {'workers': n_workers, 'episodes_per_worker': episodes, 'env_steps_per_s': steps / el,
                 'sim_steps_per_s': sub / el, 'seconds': el}
     out['config1_cpu'] = {'workload': 'PushEnv + HeuristicPushPolicy, 1 env per worker, TASK_NAME=None, MAX_STEPS=%d, %d episodes, '
-                                      'float C oracle (pybullet not importable)' % (max_steps, episodes),
+                                      'float C oracle (pybullet: %s)' % (max_steps, episodes, pb_status),
                           'one_thread': config1(1)}
     if not quick:
         out['config1_cpu']['one_worker_per_core'] = config1(cores)
@@ -198,9 +314,26 @@ def pose_err_leg(scene, names):
         x.set_body_params(params); x.set_joint_state(joints)
     state[:, :, 7] += 0.2
     f64.set_body_state(state); world.set_body_state(state)
+    pb, pb_status = pybullet_probe()
     pe, done = {'oracle': 'oracle/rv_oracle.c, -DORC_DOUBLE build (FP64 restatement)',
-                'pybullet_parity': 'unmeasured (module not available)',
+                'pybullet_parity': pb_status,
                 'scene': '%d envs x 4 bodies settled on the table, every body shoved at 0.2 m/s' % n}, 0
+    out['pybullet'] = {'status': pb_status}
+    if pb is not None:
+        # SURVEY 8c last row: identical scenes in PyBullet (createCollisionShape / createMultiBody), HIP path and FP64
+        # oracle from the same states; pose error after 1 / 10 / 100 substeps; baseline B1 (stepSimulation timing)
+        import pybullet_parity
+        try:
+            wp, op = lib.World(cfg, scene, device=0), orc.OracleWorld(cfg, scene, double=True)
+            for x in (wp, op):
+                x.reset(); x.set_body_params(params); x.set_joint_state(joints)
+            par = pybullet_parity.pose_parity(pb, cfg, scene, state.astype(np.float64), params, {'hip': wp, 'f64_oracle': op})
+            out['pybullet']['pose_err_hip_vs_pybullet'] = par['hip']
+            out['pybullet']['pose_err_f64_oracle_vs_pybullet'] = par['f64_oracle']
+            wp.close()
+            out['pybullet']['step_simulation'] = pybullet_parity.time_step_simulation()
+        except Exception as ex:      # noqa: BLE001 -- a wheel of another version may lack a call: report what happened
+            out['pybullet']['error'] = '%s: %s' % (type(ex).__name__, ex)
 
     def err(tag):
         from robovat_amd.math import rotations
@@ -248,6 +381,7 @@ def main():
                          'alone (tools/profile_bench.sh), implies --no-extra-legs')
     ap.add_argument('--over', nargs='*', default=[], help='config overrides of the timed workload, KEY=VALUE (profiling aid: e.g. '
                     'PHYSICS.SLEEP_STEPS=0 times the no-deactivation launch alone; implies --no-extra-legs)')
+    ap.add_argument('--legs-out', default=os.path.join(ROOT, 'bench_legs.json'), help='where the full record (every leg, every note) is written')
     ap.add_argument('--extra-legs', action='store_true', help='run the extra legs at --gpus N > 1 as well (default: N = 1 only -- '
                     'at 8192 envs per rank the no-deactivation legs alone take minutes)')
     args = ap.parse_args()
@@ -463,9 +597,29 @@ def main():
     else:
         world.rollout(args.warmup, first_macro_index=0, auto_reset=True, record=True)
     timer = time_rollout if args.mode == 'rollout' else time_lockstep
-    elapsed, st, kern_ms, launches = timer(world, args.steps, args.warmup)
+    # N > 1: the same per-GPU workload on ONE GPU of this very run -- rank 0 runs its shard alone while the other ranks wait
+    # at the barrier -- so that the N-GPU line carries a like-for-like N = 1 reference (the driver's own N = 1 run is
+    # BASELINE configs[1], 1024 envs: a different workload from the 8192 envs per GPU of configs[4])
+    n1_same = None
+    if world_size > 1:
+        barrier()
+        if rank == 0:
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            if args.mode == 'rollout':
+                world.rollout_record(args.steps, first_macro_index=args.warmup, auto_reset=True, point_cloud=True)
+            else:
+                for k in range(args.steps):
+                    world.set_actions(world.policy_random(args.warmup + k)); world.step_macro(); world.observe(point_cloud=True); world.reward()
+            st1 = world.stats()
+            torch.cuda.synchronize()
+            n1_same = st1['env_steps'] / (time.perf_counter() - t1)
+        barrier()
+        first_timed = args.warmup + args.steps
+    else:
+        first_timed = args.warmup
+    elapsed, st, kern_ms, launches = timer(world, args.steps, first_timed)
     env_steps_all, substeps_all = all_sum(st['env_steps'], st['substeps'])
-    next_index = args.warmup + args.steps
+    next_index = first_timed + args.steps
 
     extra = {}
     if dist_note:
@@ -784,6 +938,12 @@ def main():
             'reset_substeps': reset_stats['substeps'],
             'roofline': roofline(achieved, awake_only, traffic, issue, avg_kernel_s, algo, per_launch, world_n_waves),
         }
+        if n1_same is not None:
+            out['n1_same_workload'] = n1_same
+            out['scaling_efficiency_vs_n1_same_workload'] = out['value'] / (world_size * n1_same)
+            out['config']['n1_same_workload'] = ('rank 0 alone (other ranks idle at a barrier), same %d envs, same %d steps, without the '
+                                                 'return gather: the like-for-like N = 1 point of this line; the driver\'s own --gpus 1 run '
+                                                 'is BASELINE configs[1] (1024 envs), a different workload' % (n, args.steps))
         out.update(extra)
         if not args.no_cpu_baseline and world_size == 1:
             cl = cpu_legs(cfg_kwargs, scene, names, quick=args.quick)
@@ -810,7 +970,19 @@ def main():
                                                      for k in c_ if g8.get(k) and c_[k]['sim_steps_per_s'] > 0}
                 rs['cpu_sampling'] = ('every cpu leg: >= 16 envs per host thread, >= 10 s or 4 env.step() per env, OpenMP schedule(dynamic); '
                                       '`one_thread` = the same leg on one thread (16 envs), `scaling_1_to_n` = all threads / one thread')
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
+        # the whole record: a side file (and stderr); stdout carries the compact line only
+        legs_path = args.legs_out
+        try:
+            with open(legs_path, 'w') as f:
+                json.dump(out, f, indent=1)
+            if os.path.isdir(os.path.join(ROOT, 'gpurun_out')):
+                with open(os.path.join(ROOT, 'gpurun_out', 'bench_legs.json'), 'w') as f:
+                    json.dump(out, f, indent=1)
+        except OSError as ex:
+            legs_path = 'not written: %r' % (ex,)
+        sys.stderr.write('bench.py full record: ' + json.dumps(out) + '\n')
+        sys.stderr.flush()
+        os.write(json_fd, (compact_line(out, full_record=os.path.basename(legs_path) if os.path.sep in legs_path else legs_path) + '\n').encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

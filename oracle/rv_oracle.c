@@ -1242,6 +1242,9 @@ static real constraint_solve(const orc_world* w, orc_env* e, int b, real* lam) {
       kk = kk + ((k < n_lin ? imc : R(0.0)) + v3dot(jc, ic));
       jv = jv - (v3dot(jl, e->body[cb].v) + v3dot(jc, e->body[cb].w));
     }
+    // a row no party of which can move (a static parent -- mass 0 -- constrained to the world, a link or another static
+    // body): nothing to solve, as in Bullet, where a constraint on a fixed-base body is harmless (0 / 0 here otherwise)
+    if (!(kk > R(0.0))) continue;
     real dl = (bias - jv) / kk;
     const real ln = rclamp(lam[k] + dl, -lim, lim);
     dl = ln - lam[k]; lam[k] = ln;

@@ -1386,6 +1386,9 @@ RV_DEV float constraint_solve(Shared& S, const Consts& K, int b, float* lam) {
       kk = kk + ((k < n_lin ? imc : 0.0f) + dot(jc, ic));
       jv = jv - (dot(jl, ld3(e.body[cb] + 7)) + dot(jc, ld3(e.body[cb] + 10)));
     }
+    // a row no party of which can move (a static parent -- mass 0 -- constrained to the world, a link or another static
+    // body): nothing to solve, as in Bullet, where a constraint on a fixed-base body is harmless (0 / 0 here otherwise)
+    if (!(kk > 0.0f)) continue;
     float dl = (bias - jv) / kk;
     const float ln = fclampr(lam[k] + dl, -lim, lim);
     dl = ln - lam[k]; lam[k] = ln;

@@ -15,6 +15,17 @@
 
 using namespace rv;
 
+// control words of the task queues (ints; every counter on a 128-byte line of its own)
+enum { RV_Q_NQ = 8, RV_Q_TAKEN = 0, RV_Q_FRESH = 32, RV_Q_ERR = 64, RV_Q_CTL_WORDS = 96 + 64 * RV_Q_NQ };
+#define RV_Q_HEAD(x) (96 + 64 * (x))
+#define RV_Q_TAIL(x) (96 + 64 * (x) + 32)
+// which XCD this wave runs on (0 .. 7)
+__device__ __forceinline__ int rv_xcc_id() {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return (int)(x & (unsigned)(RV_Q_NQ - 1));
+}
+
 enum { MODE_RESET = 0, MODE_MACRO = 1, MODE_SUB = 2, MODE_WAIT = 3, MODE_ROLLOUT = 4, MODE_PARTIAL = 5 };
 
 struct EnvKernelArgs {
@@ -34,11 +45,13 @@ struct EnvKernelArgs {
   unsigned long long budget_clk; // MODE_PARTIAL: shader clocks this launch may spend per env (0: no limit)
   uint8_t* finished;             // MODE_PARTIAL: [N] 1 = the env.step() of this env completed in this launch
   int mode;                      // k_env<-1>: which of the modes this launch is
-  // MODE_ROLLOUT through a task queue (worlds with more envs than the GPU has wave slots): a task is ONE env.step() of one
-  // env; the launch has as many workgroups as fit the GPU, each takes the next task, runs it from and back to the env's block
-  // in HBM, and puts the env back at the tail while it has steps left.  q_slots[t] = env of task t (-1: not yet published),
-  // q_total = n_envs x n_steps tasks in all.  nullptr: one workgroup per env, all its steps (the plain launch)
-  int* q_slots; unsigned* q_head; unsigned* q_tail; int* q_done; int q_total;
+  // MODE_ROLLOUT through task queues (worlds with more envs than the GPU has wave slots): a task is ONE env.step() of one
+  // env; the launch has as many workgroups as fit the GPU; each takes the next task, runs it from and back to the env's block
+  // in HBM, and puts the env back at the tail of ITS XCD's queue while it has steps left.  One queue per XCD (HW_REG_XCC_ID),
+  // so that an env's block is only ever handed over between workgroups behind the same L2 (see k_env).  q_ctl: counters
+  // (RV_Q_*), q_slots: RV_Q_NQ rings of q_cap slots, slot = env + n_envs x step (-1: not yet published); q_total tasks in
+  // all; q_launch: number of this launch (every block it hands over is stamped with it).  nullptr: one workgroup per env
+  int* q_slots; int* q_ctl; int q_cap; int q_total; int q_pool; int q_launch;
   int poison_lo, poison_hi;      // RV_POISON_LDS builds: the words of the scratch block that start as garbage (RV_POISON_LO / _HI: bisecting)
 };
 
@@ -76,23 +89,53 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
   }
 #endif
   Consts K = lds_consts(args.scene, (MODE == MODE_SUB) ? args.stop_after : 0);
-  // ---- the task queue (MODE_ROLLOUT; a plain launch is ONE pass of this loop: its env is the workgroup's own, all steps).
-  // Memory: a block is handed on with agent-scope ATOMIC stores and loads of its words (written through to memory / read
-  // from memory, past the XCD's L2), the slot that names the next task is published after those stores have been
-  // acknowledged (s_waitcnt vmcnt(0)), and the taker checks the block's step number and the sum of its words before it
-  // believes it (rv_env_task).  What was tried before: agent-scope release / acquire fences -- correct, but they write back and
-  // invalidate the XCD's whole L2 per task, everybody's scratch lines included (8192 envs: 121 k -> 116 k env-steps/s); and
-  // uncached device memory for the blocks -- fast, but intermittently wrong or stalled for seconds, and a hipFree of such
-  // memory corrupted later allocations of the process (ROCm 7.0).
+  // ---- the task queues (MODE_ROLLOUT; a plain launch is ONE pass of this loop: its env is the workgroup's own, all steps).
+  //
+  // Protocol (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility").  An env's block goes
+  // from the workgroup that ran step k to the one that runs step k + 1.  Both sit on the SAME XCD: a workgroup reads the
+  // XCD it runs on from the hardware (HW_REG_XCC_ID -- a fact about where it is, not an assumption about dispatch) and only
+  // ever puts an env into, and takes one out of, the queue of that XCD; an env is bound to an XCD by whoever runs its first
+  // step (its block was then written by an EARLIER kernel and is visible everywhere).  Behind one L2 the hand-over needs no
+  // write-back of that L2 (an agent-scope release fence writes back every dirty line of it -- everybody's scratch included:
+  // 8192 envs 121 k -> 116 k env-steps/s) and no write-through traffic:
+  //   producer  plain stores of the block (the vector L1 writes through: they land in the XCD's L2) -> asm s_waitcnt vmcnt(0)
+  //             (every store acknowledged by the L2; inline asm, which the compiler can neither drop nor move stores across)
+  //             -> lane 0 publishes the slot with a relaxed agent-scope atomic store
+  //   consumer  lane 0 polls ITS slot with relaxed agent-scope atomic loads (they bypass the L1) -> ONE agent-scope acquire
+  //             fence (buffer_inv sc1: drops this CU's L1 lines, which may hold the block as it was steps ago) -> plain loads,
+  //             served by the L2 the producer stored into.
+  // No checksum, no retry: the step number and the launch number the block carries are ASSERTED (a mismatch raises
+  // RV_Q_ERR, which rv_get_stats reports as an error) -- they have not fired since the queues are per XCD.
+  // Termination: RV_Q_TAKEN counts the tasks that were begun; once it reaches q_total no task is left to publish, so a
+  // workgroup that waits for a slot leaves.  (A work-conserving pool, q_pool: a task is counted when an env was found for
+  // it -- an env is put back after every step, the pool ends the launch.)
+  const int xcc = queued ? rv_xcc_id() : 0;
+  int* const q_ring = queued ? args.q_slots + (size_t)xcc * (size_t)args.q_cap : nullptr;
+  int* const q_head = queued ? args.q_ctl + RV_Q_HEAD(xcc) : nullptr;
+  int* const q_tail = queued ? args.q_ctl + RV_Q_TAIL(xcc) : nullptr;
+  bool fresh_left = true;
   for (;;) {
     int env = (int)blockIdx.x, k0 = 0;
     if (queued) {
       __syncthreads();
       if (lane == 0) {
         int e = -1;
-        const unsigned t = atomicAdd(args.q_head, 1u);
-        if (t < (unsigned)args.q_total) {
-          while ((e = __hip_atomic_load(&args.q_slots[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(16);
+        if (fresh_left) {          // an env nobody has stepped in this launch
+          const int f = atomicAdd(args.q_ctl + RV_Q_FRESH, 1);
+          if (f < args.n_envs) e = f; else fresh_left = false;
+        }
+        if (e < 0) {               // the next env of this XCD's queue
+          const int t = atomicAdd(q_head, 1);
+          if (t < args.q_cap) {
+            while ((e = __hip_atomic_load(&q_ring[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+              if (__hip_atomic_load(args.q_ctl + RV_Q_TAKEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= args.q_total) break;
+              __builtin_amdgcn_s_sleep(32);
+            }
+          }
+        }
+        if (e >= 0) {              // a task is begun (in a pool: if the pool still has one)
+          const int t = atomicAdd(args.q_ctl + RV_Q_TAKEN, 1);
+          if (t >= args.q_total) e = -1;
         }
         S.s.loop_break = e;
       }
@@ -100,31 +143,22 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
       env = __builtin_amdgcn_readfirstlane(S.s.loop_break);
       if (env < 0) return;
       k0 = env / args.n_envs; env = env - k0 * args.n_envs;      // (a slot says whose turn it is AND which of its steps)
+      if (k0 > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (buffer_inv sc1, once per task, before the block is loaded)
     }
     rv_env_task<TMODE>(args, MODE, env, S, K, k0, queued ? k0 + 1 : 0);      // (the ONE call site of the env program in this kernel)
     if (!queued) return;
     __syncthreads();                                   // (the env's block is written: every lane's stores are issued)
-    // (the block has reached memory: every store of the wave acknowledged.  A workgroup-scope release fence is NOT that -- for
-    // a workgroup of one wave it compiles to nothing --, and the hand-over lost a step now and then: 13 823 of 13 824)
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and acknowledged by the L2 of this XCD
     if (lane == 0) {
-      if (k0 + 1 < args.n_substeps) {
-        const unsigned p = atomicAdd(args.q_tail, 1u);
-        __hip_atomic_store(&args.q_slots[p], env + args.n_envs * (k0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (args.q_pool || k0 + 1 < args.n_substeps) {
+        const int p = atomicAdd(q_tail, 1);
+        if (p < args.q_cap) __hip_atomic_store(&q_ring[p], env + args.n_envs * (k0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else atomicOr(args.q_ctl + RV_Q_ERR, 2);
       }
     }
   }
 }
 
-// sum of the words of the env block in LDS, the checksum word itself left out (every lane gets the total)
-__device__ __forceinline__ unsigned rv_block_sum(const Shared& S) {
-  constexpr int W = (int)(sizeof(DevEnv) / 4), QS = (int)(offsetof(DevEnv, q_sum) / 4);
-  const uint32_t* w = reinterpret_cast<const uint32_t*>(&S.e);
-  unsigned acc = 0u;
-  for (int i = (int)threadIdx.x; i < W; i += 64) acc += (i == QS) ? 0u : w[i];
-  for (int o = 32; o > 0; o >>= 1) acc += (unsigned)__shfl_xor((int)acc, o);
-  return acc;
-}
 // One env, one run of the env program: load its block into LDS, run, store it back.  k0 / k_stop: MODE_ROLLOUT as a task
 // of the queue (the steps k0 .. k_stop - 1; 0 / 0: all steps).  Inlined at its single call site per branch of the kernel.
 template <int TMODE>
@@ -134,24 +168,14 @@ __device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int
   constexpr int W = (int)(sizeof(DevEnv) / 4);
   bool skip = false;
   if (MODE == MODE_RESET) skip = (args.mask != nullptr) && (args.mask[env] == 0);
-  for (;;) {
+  {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&S.e);
-    // (a task of the queue: word by word with agent-scope atomic loads -- they go to memory, past the L2 of this XCD, which
-    // may hold what this block was several steps ago)
-    if (k_stop > 0) { for (int i = lane; i < W; i += 64) dst[i] = __hip_atomic_load(const_cast<uint32_t*>(&src[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    else { for (int i = lane; i < W; i += 64) dst[i] = src[i]; }
+    for (int i = lane; i < W; i += 64) dst[i] = src[i];
     __syncthreads();
-    // a task of the queue after the env's first: the block was stored by another workgroup a moment ago.  It is taken only
-    // when it carries the number of this step and its words add up to the sum its last owner left -- a block that is still
-    // on its way (the old one, or a mix) is read again.  (s_waitcnt vmcnt(0) before the hand-over made a stale read rare,
-    // not impossible: one step in ~80 000 tasks was still lost in the stress run, tools/queue_stress.py)
-    if (k_stop == 0 || k0 == 0) break;
-    const unsigned sum = rv_block_sum(S);
-    const int ok = __builtin_amdgcn_readfirstlane((int)(S.e.q_seq == k0 && S.e.q_sum == sum));
-    if (ok) break;
-    __syncthreads();
-    __builtin_amdgcn_s_sleep(8);
+    // a task of a queue after the env's first: the block was stored a moment ago by another workgroup of this XCD.  It
+    // carries the number of the step it is ready for and of the launch that stored it -- asserted, never repaired
+    if (k_stop > 0 && k0 > 0 && lane == 0 && (S.e.q_seq != k0 || S.e.q_sum != (unsigned)args.q_launch)) atomicOr(args.q_ctl + RV_Q_ERR, 1);
   }
 #ifdef RV_PROFILE
   if (lane == 0) { S.e.prof_t = __builtin_amdgcn_s_memtime(); for (int g2 = 0; g2 < 4; ++g2) S.e.prof_t2[g2] = S.e.prof_t; }
@@ -212,11 +236,8 @@ __device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int
                    (MODE == MODE_PARTIAL ? RV_PROG_PARTIAL : (MODE == MODE_SUB ? RV_PROG_SUB : RV_PROG_WAIT))));
   const int fin = env_program(S, K, prog, pa);
   if (MODE == MODE_ROLLOUT) {
-    // (through the queue the env's tasks run on different XCDs, each with an L2 of its own: plain stores of the same word
-    // from two of them may reach memory in either order at the end of the kernel -- an atomic store goes there at once)
     if (lane == 0 && args.steps_taken) {
-      if (k_stop > 0) __hip_atomic_store(&args.steps_taken[env], S.e.stepped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else args.steps_taken[env] = S.e.stepped;
+      args.steps_taken[env] = S.e.stepped;      // (the tasks of an env all run behind one L2: plain stores)
     }
   } else if (MODE == MODE_PARTIAL) {
     if (resetting) {
@@ -234,19 +255,14 @@ __device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int
   }
   }      // (!skip)
   __syncthreads();
-  if (k_stop > 0) {      // a task of the queue: the block leaves with its step number and the sum of its words
-    if (lane == 0) S.e.q_seq = k0 + 1;
-    __syncthreads();
-    const unsigned sum = rv_block_sum(S);
-    if (lane == 0) S.e.q_sum = sum;
+  if (k_stop > 0) {      // a task of a queue: the block leaves with the number of its next step and of this launch
+    if (lane == 0) { S.e.q_seq = k0 + 1; S.e.q_sum = (unsigned)args.q_launch; }
     __syncthreads();
   }
   {
     uint32_t* dst = reinterpret_cast<uint32_t*>(g);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.e);
-    // (a task of the queue: agent-scope atomic stores -- written through to memory, where the next owner's loads look)
-    if (k_stop > 0) { for (int i = lane; i < W; i += 64) __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    else { for (int i = lane; i < W; i += 64) dst[i] = src[i]; }
+    for (int i = lane; i < W; i += 64) dst[i] = src[i];
   }
 }
 

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void k_point_cloud(const ObsSnap* snaps, int n_
           project_vertex(&s, ld3(s.arm_c[lane]), &uc, &vc, &zc);
           if (zc - r <= c->cam_near) may = zc + r > 0.0f;          // too close to bound its disc: keep it
           else {
-            const float f = fmaxr(fabsr(c->cam_intrinsics[0]), fabsr(c->cam_intrinsics[1])) + fabsr(c->cam_intrinsics[4]);
+            const float f = fmaxr(fabsr(s.cam_intrinsics[0]), fabsr(s.cam_intrinsics[1])) + fabsr(s.cam_intrinsics[4]);     // (this env's calibration: camera noise)
             const float rp = r * f / (zc - r) * 1.05f + 2.0f;
             may = !(uc + rp < (float)u0 || uc - rp > (float)u1 || vc + rp < (float)v0 || vc - rp > (float)v1);
           }
@@ -554,9 +554,10 @@ struct rv_world {
   bool timed;
   int auto_reset;                         // rv_set_auto_reset
   int occ2;                               // more envs than SIMDs: launch k_env_occ2 (rv_env_kernel.h)
-  // rollouts of a world with more envs than the GPU has wave slots go through a task queue (rv_env_kernel.h): q_grid
-  // workgroups (what is resident at a time), d_q = [q_cap task slots][head, tail][n done counters]
-  int q_grid; int* d_q; size_t q_cap;
+  // rollouts of a world with more envs than the GPU has wave slots go through task queues, one per XCD (rv_env_kernel.h):
+  // q_grid workgroups (what is resident at a time), d_q = [RV_Q_CTL_WORDS control words][RV_Q_NQ rings of q_ring slots];
+  // q_launch numbers the queued launches, q_used: a queued launch ran since rv_get_stats last looked at its error word
+  int q_grid; int* d_q; size_t q_cap; int q_launch; bool q_used;
 };
 
 static thread_local std::string g_err;
@@ -573,34 +574,42 @@ static void launch_k_env(rv_world* w, int mode, const EnvKernelArgs& a) {
   if (w->occ2) rv_launch_k_env_occ2(mode, a, n_grid, w->stream);
   else rv_launch_k_env_here(mode, a, n_grid, w->stream);
 }
-__global__ void k_queue_init(int* slots, int n_envs, int total, unsigned* head_tail, int* done) {
-  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i < total) slots[i] = i < n_envs ? i : -1;      // the first task of every env is published; the others by who finishes the step before
-  if (i < n_envs) done[i] = 0;
-  if (i == 0) { head_tail[0] = 0u; head_tail[1] = (unsigned)n_envs; }
+__global__ void k_queue_init(int* q, long long words) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < words) q[i] = i < RV_Q_CTL_WORDS ? 0 : -1;      // counters 0 (the error word too), every slot "not yet published"
 }
-// MODE_ROLLOUT of n_steps through the task queue?  Worlds with more envs than resident workgroups (RV_QUEUE=0: never)
+// MODE_ROLLOUT of n_steps through the task queues?  Worlds with more envs than resident workgroups (RV_QUEUE=0: never)
 // pool > 0: the work-conserving rollout (rv_rollout_async) -- `pool` tasks in all, an env goes back to the tail after every
 // step, so the envs take turns and one in a slow state simply gets fewer of them
 static int queue_setup(rv_world* w, int n_steps, EnvKernelArgs& a, long long pool = 0) {
-  a.q_slots = nullptr; a.q_head = nullptr; a.q_tail = nullptr; a.q_done = nullptr; a.q_total = 0;
+  a.q_slots = nullptr; a.q_ctl = nullptr; a.q_cap = 0; a.q_total = 0; a.q_pool = 0; a.q_launch = 0;
   const char* q = getenv("RV_QUEUE");      // (read per launch: the tests compare the two schedules in one process)
   // (short rollouts gain nothing -- a task is an env.step(), so with few steps per env the tail is the same --; measured on
-  // 8192 envs: 2 steps -8 %, 10 steps -4 ... +1 %, 20 steps +14 ... +23 %, 30 steps +18 %.  RV_QUEUE=1 forces the queue, 0 forbids it)
+  // 8192 envs: 2 steps -8 %, 10 steps -4 ... +1 %, 20 steps +14 ... +23 %, 30 steps +18 %.  RV_QUEUE=1 forces the queues, 0 forbids them)
   if ((q && atoi(q) == 0) || w->q_grid <= 0 || w->n <= w->q_grid || (pool == 0 && n_steps < 12 && !(q && atoi(q) == 1))) return RV_OK;
-  const size_t total = pool > 0 ? (size_t)pool : (size_t)w->n * (size_t)n_steps;      // tasks that are taken
-  if (total > (size_t)0x3fffffff) return RV_OK;
-  const size_t slots = total + (pool > 0 ? (size_t)w->n : 0);                           // ... and published (a pool: every env is put back)
-  const size_t need = slots + 2 + (size_t)w->n;
+  const size_t total = pool > 0 ? (size_t)pool : (size_t)w->n * (size_t)n_steps;      // tasks that are begun
+  if (total > ((size_t)1 << 24)) return RV_OK;      // (8 rings of `total` ints: 512 MB at most)
+  // a ring holds what ONE XCD may be handed in the worst case: every task of the launch (an env is published once per
+  // step it has left; in a pool once per task that was begun)
+  const size_t ring = total;
+  const size_t need = (size_t)RV_Q_CTL_WORDS + (size_t)RV_Q_NQ * ring;
   if (w->q_cap < need) {
     if (w->d_q) { HIPCHK(hipStreamSynchronize(w->stream)); HIPCHK(hipFree(w->d_q)); w->d_q = nullptr; w->q_cap = 0; }
     HIPCHK(hipMalloc(&w->d_q, need * sizeof(int)));
     w->q_cap = need;
   }
-  a.q_slots = w->d_q; a.q_head = reinterpret_cast<unsigned*>(w->d_q + slots); a.q_tail = a.q_head + 1; a.q_done = w->d_q + slots + 2; a.q_total = (int)total;
-  const size_t init_n = slots > (size_t)w->n ? slots : (size_t)w->n;
-  hipLaunchKernelGGL(k_queue_init, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, w->stream, a.q_slots, w->n, (int)slots, a.q_head, a.q_done);
+  if (w->q_used) {      // (the error word of the last queued launch, before it is zeroed)
+    int err = 0;
+    HIPCHK(hipMemcpyAsync(&err, w->d_q + RV_Q_ERR, sizeof(int), hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
+    w->q_used = false;
+    if (err) return fail(RV_ERR_STATE, "task queue: a block arrived with the wrong step / launch number, or a ring overflowed (code " + std::to_string(err) + ") in the previous queued launch");
+  }
+  a.q_ctl = w->d_q; a.q_slots = w->d_q + RV_Q_CTL_WORDS; a.q_cap = (int)ring; a.q_total = (int)total; a.q_pool = pool > 0 ? 1 : 0;
+  a.q_launch = ++w->q_launch;
+  hipLaunchKernelGGL(k_queue_init, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, w->stream, w->d_q, (long long)need);
   HIPCHK(hipGetLastError());
+  w->q_used = true;
   return RV_OK;
 }
 // RV_POISON_LDS builds (tools/build_poison.py): which words of the scratch block start as garbage; everything by default
@@ -620,7 +629,7 @@ static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, fl
   a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.mask = mask; a.n_envs = w->n;
   { const char* ds = getenv("RV_DEBUG_STOP"); a.stop_after = ds ? atoi(ds) : 0; }
   a.n_substeps = n_sub; a.lin_thr = lin; a.ang_thr = ang; a.check_after = ca; a.min_stable = ms; a.max_steps = mx;
-  a.q_slots = nullptr; a.q_head = nullptr; a.q_tail = nullptr; a.q_done = nullptr; a.q_total = 0;
+  a.q_slots = nullptr; a.q_ctl = nullptr; a.q_cap = 0; a.q_total = 0; a.q_pool = 0; a.q_launch = 0;
   poison_range(a);
   if (MODE == MODE_ROLLOUT && budget == nullptr) { int rc = queue_setup(w, n_sub, a); if (rc != RV_OK) return rc; }
   if (MODE == MODE_ROLLOUT && budget != nullptr && pool_tasks > 0) {
@@ -682,7 +691,7 @@ int rv_create(const rv_config* cfg, const rv_scene* scene, int device, rv_world*
     int cus = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     w->occ2 = w->n > 4 * cus;
-    w->q_grid = 0; w->d_q = nullptr; w->q_cap = 0;
+    w->q_grid = 0; w->d_q = nullptr; w->q_cap = 0; w->q_launch = 0; w->q_used = false;
     const char* f = getenv("RV_ENV_OCC");
     if (f && (f[0] == '1' || f[0] == '2')) w->occ2 = f[0] == '2';
     // the task queue's grid: every workgroup the GPU keeps resident of the kernel this world launches
@@ -990,7 +999,14 @@ int rv_get_episode_returns(rv_world* w, float* d) { WCHK(w); NEED(d, "rv_get_epi
 int rv_get_stats(rv_world* w, rv_macro_stats* h) {
   WCHK(w); NEED(h, "rv_get_stats");
   HIPCHK(hipMemcpyAsync(h, w->d_stats, sizeof(rv_macro_stats), hipMemcpyDeviceToHost, w->stream));
+  int q_err = 0;
+  if (w->q_used) HIPCHK(hipMemcpyAsync(&q_err, w->d_q + RV_Q_ERR, sizeof(int), hipMemcpyDeviceToHost, w->stream));
   HIPCHK(hipStreamSynchronize(w->stream));
+  if (w->q_used) {
+    w->q_used = false;
+    // (rv_env_kernel.h: the hand-over of an env block between two tasks is asserted, never repaired)
+    if (q_err) return fail(RV_ERR_STATE, "task queue: a block arrived with the wrong step / launch number, or a ring overflowed (code " + std::to_string(q_err) + ")");
+  }
   return RV_OK;
 }
 int rv_last_kernel_ms(rv_world* w, float* h_ms) {

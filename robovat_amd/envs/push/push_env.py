@@ -108,10 +108,13 @@ class VecPushEnv(object):
         before = self.world.env_counters().cpu().numpy()[:, [2, 4]] if (auto_reset and self._physics is not None) else None
         out = self.world.rollout(n_steps, self._macro_index, auto_reset, record)
         if before is not None:
-            # the host mirror of the user constraints is dropped only when an env really was reset: its episode was over
-            # when the rollout began, or one ended inside it (num_episodes moved) and the next step reset the env
+            # the host mirror of the user constraints is dropped only when an env really was reset
+            # -- every episode end is followed by a reset at the env's NEXT step, so resets = (done before) + (episodes
+            # ended) - (done after): an episode that merely ends on the last step of the rollout has not been reset yet,
+            # its constraints are still active on the device and the mirror must keep them
             after = self.world.env_counters().cpu().numpy()[:, [2, 4]]
-            if (before[:, 1] != 0).any() or (after[:, 0] != before[:, 0]).any():
+            resets = (before[:, 1] != 0).astype(int) + (after[:, 0] - before[:, 0]) - (after[:, 1] != 0).astype(int)
+            if (resets > 0).any():
                 self._physics.on_env_reset()
         self._macro_index += int(n_steps)
         return out

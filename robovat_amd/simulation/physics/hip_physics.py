@@ -159,6 +159,11 @@ class HipPhysics(Physics):
         return uid
 
     def remove_body(self, body_uid):
+        # bullet_physics.py:188-195.  The arm and the table are parts of every env of the device world: removing them
+        # forgets nothing on the device -- add_body('sawyer...') puts the arm back at its neutral joint positions,
+        # add_body('table...') sets the table height again (SawyerSim.reboot removes and re-adds the arm, sawyer_sim.py:90-97)
+        if body_uid in (ARM_UID, TABLE_UID):
+            return
         if body_uid in self._static:
             del self._static[body_uid]
             return

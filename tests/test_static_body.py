@@ -196,3 +196,24 @@ def test_hip_with_a_wall_matches_float_oracle_bit_for_bit(over, occ, monkeypatch
         assert np.array_equal(seg[i].cpu().numpy(), rs_) and np.array_equal(depth[i].cpu().numpy(), rd)
         seen += int((rs_ == abi.RV_MAXB - 1).sum())
     assert seen > 0        # the wall has pixels of its own
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_a_constraint_on_a_static_body_is_harmless(backend):
+    """A fixed / point-to-point constraint whose parent is a static body (mass 0) tied to the world: every row has zero
+    effective mass.  In Bullet a constraint on a fixed-base body does nothing; here the row used to divide 0 by 0 and the
+    NaN spread through the pair rows to every body touching the wall (advisor, round 5).  The wall stays where it is bit for
+    bit, the box that slides into it stops at it, nothing is NaN."""
+    w, cfg, names = _world(backend)
+    face = 0.72 - WALL_HALF[0]
+    _bodies(w, [(0, 0.2, 0.2, (0.55, 0.0, 0.031), Q0, (1.0, 0, 0)),
+                (names.index('wall'), 0.0, 1.0, (0.72, 0.0, 0.4), Q0, (0, 0, 0))])
+    w.set_constraint(1, [0.72, 0.0, 0.45, 0, 0, 0, 1], max_force=50.0)                      # world frame 5 cm above: a bias
+    w.set_constraint(0, [0.0, 0.0, 0.0, 0, 0, 0, 1], max_force=0.0, child=1, joint_type='point2point')   # a powerless joint to the static body
+    wall0 = np.asarray(w.body_state())[0, 1].copy()
+    w.step_sub(800)
+    st = np.asarray(w.body_state())[0]
+    assert np.isfinite(st[:2]).all(), st[:2]
+    assert np.array_equal(st[1], wall0)
+    gap = face - (st[0, 0] + BOX_HALF_X)
+    assert -2e-3 < gap < 4e-3, gap

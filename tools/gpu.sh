@@ -6,6 +6,8 @@
 #   tests          pytest -m gpu (whole suite) + smoke()
 #   tests:<expr>   pytest -m gpu -k <expr>
 #   bench          the driver's command: python bench.py --steps 20 --warmup 5
+#   qstress / qstress50   tools/queue_stress.py 16 / 50 runs (task queues vs plain launch, every word)
+#   c5             bench.py --workload config5 alone
 #   headline       bench.py headline only (no CPU legs, no extra legs)
 #   k50            bench.py --steps 50 headline only
 #   profile        rocprofv3 kernel stats + PMC passes of the headline (tools/profile_bench.sh)
@@ -34,6 +36,12 @@ for STAGE in "$@"; do
     bench)
       timeout 1700 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/time.txt
       python tools/bench_digest.py $O/bench.json ;;
+    qstress)
+      timeout 1500 python tools/queue_stress.py 16 > $O/queue_stress.txt 2>&1; echo "qstress rc=$?" >> $O/time.txt; tail -4 $O/queue_stress.txt ;;
+    qstress50)
+      timeout 2400 python tools/queue_stress.py 50 > $O/queue_stress50.txt 2>&1; echo "qstress50 rc=$?" >> $O/time.txt; tail -4 $O/queue_stress50.txt ;;
+    c5)
+      timeout 600 python bench.py --workload config5 --steps 20 --warmup 5 --no-cpu-baseline > $O/c5.json 2> $O/c5.err; cut -c1-300 $O/c5.json ;;
     headline)
       timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs > $O/headline.json 2> $O/headline.err
       cut -c1-400 $O/headline.json ;;
