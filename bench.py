@@ -187,7 +187,7 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
         env_cfg = configs.push_env_config(**over)
         sc, nm = (scenes.make_scene(env_cfg=env_cfg) if 'PHYSICS.ARM_ACCEL_SCALE' in over else (scene, names))
         c = configs.make_rv_config(env_cfg=env_cfg, n_envs=n_envs, shape_names=nm, **cfg_kwargs)
-        wc = orc.OracleWorld(c, sc, double=False)
+        wc = orc.OracleWorld(c, sc, double=False, native=True)      # (-O3 -march=native, built on this host)
         wc.set_num_threads(threads)
         wc.reset()
         p0, _ = wc.observe()
@@ -234,6 +234,7 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
         'thread_us_per_substep': cb['thread_us_per_substep'], 'thread_us_per_awake_substep': cb['thread_us_per_awake_substep'],
         'one_thread': cb['one_thread'], 'scaling_1_to_n': cb['scaling_1_to_n'],
         'mean_sweeps_per_island_solve': cb['mean_sweeps_per_island_solve'],
+        'compiler_flags': 'gcc ' + ' '.join(orc.NATIVE_FLAGS) + ' (built on this host; the bit-exact parity target keeps -O2)',
         'note': 'the oracle never coasts: its non-awake substeps still run the arm (light part); thread_us_per_awake_substep charges '
                 'them to the awake ones'}
     # (i') the reference's most likely semantics on the host cores (same legs as reference_semantics.gpu): every
@@ -279,7 +280,7 @@ def cpu_legs(cfg_kwargs, scene, names, quick=False):
     def config1(n_workers):
         env_cfg = configs.push_env_config(MAX_STEPS=max_steps)
         c1 = configs.make_rv_config(env_cfg=env_cfg, n_envs=n_workers, shape_names=names, seed=0)
-        w1 = orc.OracleWorld(c1, scene, double=False)
+        w1 = orc.OracleWorld(c1, scene, double=False, native=True)
         t0 = time.perf_counter()
         steps = sub = 0
         for _ in range(episodes):

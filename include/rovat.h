@@ -350,7 +350,9 @@ int  rv_rollout(rv_world* w, int32_t n_steps, int32_t first_macro_index, int32_t
  * Mixing with the lock-step entry points: rv_step_macro, rv_rollout*, rv_step_sub and
  * rv_wait_until_stable CANCEL the pending partial step of every env they run on (the env is no
  * longer "stepping": a later poll does not resume or repeat it; the physics the cancelled step
- * already did stays done); rv_reset cancels it as well.  Begin a new step to continue. */
+ * already did stays done); rv_reset cancels it as well.  Begin a new step to continue.
+ * Both env types: PushEnv (push_env.py:631-733) and Grasp4DofEnv (grasp_4dof_env.py:213-293: its phase loop ticks after
+ * every substep; the reward's wait_until_stable is resumable like the closing wait of a push). */
 int  rv_step_begin(rv_world* w, const float* d_actions /* [N][G][4] */, const uint8_t* d_mask /* [N] or NULL */);
 /* on != 0: a step begun on an env whose episode is over RESETS it instead (RobotEnv.reset, robot_env.py:204-237,
  * as the loop of generate_episodes does between episodes, episode_generation.py:36-46): the next poll reports the
@@ -419,6 +421,12 @@ int  rv_set_link_path(rv_world* w, const float* d_poses /* [N][n_poses][7] pos+x
  *      controllable_body.py:565-595): like the reference's query it retires link / joint targets that are done
  *      (reached, timed out, path exhausted).  The gripper is ready 0.5 s of simulated time after rv_grip. */
 int  rv_get_robot_ready(rv_world* w, uint8_t* d_out /* [N][2]: limb ready, gripper ready */);
+/* ControllableBody.set_max_joint_velocities (controllable_body.py:357-372), the robot command SawyerSim.move_to_joint_positions /
+ * move_to_gripper_pose / move_along_gripper_path send with every motion (sawyer_sim.py:212-220, 285-293, 336-344: `speed` x
+ * joint.max_velocity, default speed = LIMB_MAX_VELOCITY_RATIO): the speed limit (rad/s, > 0) of each of the seven limb joints
+ * for the targets that are being followed.  rv_set_joint_targets / rv_set_link_target / rv_set_link_path put the configured
+ * ratio back, so a per-call speed is set AFTER the target it belongs to (both before the next Simulator.step). */
+int  rv_set_max_joint_velocities(rv_world* w, const float* d_vmax /* [N][RV_NLIMB] */);
 /* ---- BulletPhysics.position_control_array (bullet_physics.py:1061-1104):
  *      POSITION_CONTROL motor targets (gains POSITION_GAIN / VELOCITY_GAIN,
  *      controllable_body.py:17-18) for the joints whose mask byte is non-zero

@@ -57,11 +57,43 @@ def build(force=False):
     return targets
 
 
-def _lib(double):
-    key = bool(double)
+NATIVE_FLAGS = ['-O3', '-march=native', '-std=gnu11', '-fPIC', '-ffp-contract=off', '-fno-fast-math', '-fopenmp', '-Wno-unused-function']
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.startswith('model name'):
+                    return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def build_native():
+    """the float oracle compiled `-O3 -march=native` for the TIMED cpu legs of bench.py -- on the machine
+    that runs them (a -march=native binary built in the build container need not run on the GPU box's host CPU), so it is
+    compiled at first use and rebuilt when the CPU model or the sources changed.  Same sources, -ffp-contract=off and no
+    fast-math as the bit-exact target: the arithmetic is that of liborc_f32.so (tests/test_oracle_native.py)."""
+    out = os.path.join(_HERE, 'liborc_f32_native.so')
+    stamp = out + '.host'
+    srcs = [os.path.join(_HERE, n) for n in ('rv_oracle.c', 'orc_math.h', 'orc_collide.h')] + [os.path.join(_HERE, '..', 'include', 'rovat.h')]
+    model = _cpu_model()
+    fresh = os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == model and \
+        all(os.path.getmtime(s) <= os.path.getmtime(out) for s in srcs)
+    if not fresh:
+        subprocess.run(['gcc'] + NATIVE_FLAGS + [os.path.join(_HERE, 'rv_oracle.c'), '-o', out, '-shared', '-lm', '-fopenmp'], check=True)
+        with open(stamp, 'w') as f:
+            f.write(model)
+    return out
+
+
+def _lib(double, native=False):
+    key = 'native' if native else bool(double)
     if key not in _LIBS:
         build()
-        lib = C.CDLL(os.path.join(_HERE, 'liborc_f64.so' if double else 'liborc_f32.so'))
+        lib = C.CDLL(build_native() if native else os.path.join(_HERE, 'liborc_f64.so' if double else 'liborc_f32.so'))
         lib.orc_create.restype = C.c_void_p
         lib.orc_create.argtypes = [C.POINTER(abi.rv_config), C.POINTER(abi.rv_scene)]
         for name in ('orc_destroy', 'orc_reset', 'orc_set_actions', 'orc_step_macro', 'orc_step_sub',
@@ -74,7 +106,7 @@ def _lib(double):
                      'orc_get_episode_returns', 'orc_get_stats', 'orc_eval_reward',
                      'orc_eval_waypoints', 'orc_set_external_control', 'orc_motor_targets',
                      'orc_compute_ik_seeded', 'orc_set_link_path', 'orc_grip', 'orc_set_link_timeout', 'orc_set_pose_f32',
-                     'orc_debug_solver_counts', 'orc_set_num_threads', 'orc_set_link_paths', 'orc_robot_ready', 'orc_get_camera', 'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction', 'orc_set_constraint', 'orc_render_rgb', 'orc_set_constraint_ex'):
+                     'orc_debug_solver_counts', 'orc_set_num_threads', 'orc_set_link_paths', 'orc_robot_ready', 'orc_get_camera', 'orc_rollout_counts', 'orc_render', 'orc_point_cloud', 'orc_set_friction', 'orc_set_constraint', 'orc_render_rgb', 'orc_set_constraint_ex', 'orc_set_max_joint_velocities'):
             getattr(lib, name).restype = None
         lib.orc_is_limb_ready.restype = C.c_int
         lib.orc_is_gripper_ready.restype = C.c_int
@@ -96,8 +128,9 @@ def _p(a):
 class OracleWorld(object):
     """N independent envs stepped on the CPU (OpenMP over envs)."""
 
-    def __init__(self, cfg, scene, double=False):
-        self.lib = _lib(double)
+    def __init__(self, cfg, scene, double=False, native=False):
+        assert not (double and native)
+        self.lib = _lib(double, native)
         self.double = double
         self.cfg = cfg
         self.scene = scene
@@ -222,6 +255,10 @@ class OracleWorld(object):
         if a.ndim == 2:
             a = np.ascontiguousarray(np.broadcast_to(a[None], (self.n,) + a.shape))
         self.lib.orc_set_link_paths(self.h, C.c_int(a.shape[1]), _p(a))
+
+    def set_max_joint_velocities(self, v):
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float32), (self.n, abi.RV_NLIMB)))
+        self.lib.orc_set_max_joint_velocities(self.h, _p(v))
 
     def robot_ready(self):
         return self._get('orc_robot_ready', (self.n, 2), np.uint8)

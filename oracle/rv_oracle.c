@@ -2767,6 +2767,10 @@ void orc_motor_targets(orc_world* w, int n, const int32_t* idx, const double* po
     }
   }
 }
+/* rv_set_max_joint_velocities (controllable_body.py:357-372) */
+void orc_set_max_joint_velocities(orc_world* w, const float* v) {
+  for (int i = 0; i < w->n; ++i) for (int j = 0; j < RV_NLIMB; ++j) w->env[i].vmax_cmd[j] = (real)v[(size_t)i * RV_NLIMB + j];
+}
 void orc_compute_ik_seeded(orc_world* w, const double* seed, const double* pose, double* q) {
   real p[7], sd[RV_NLIMB], out[RV_NLIMB];
   for (int k = 0; k < 7; ++k) p[k] = (real)pose[k];

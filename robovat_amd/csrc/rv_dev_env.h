@@ -4746,13 +4746,14 @@ RV_DEV void gphase_tick(Shared& S, const Consts& K) {
 // the arm still touches it; the episode ends after one grasp)
 // (three segments around two runs of the substep loop -- run_req(-2): the phase loop; then the reward's
 // wait_until_stable -- see env_program)
-RV_DEV void genv_step_begin(Shared& S, const Consts& K, int zero_counters) {
+RV_DEV void genv_step_begin(Shared& S, const Consts& K, int zero_counters, int count_step = 1) {
   const rv_config* c = K.cfg;
   RV_LANES_BEGIN
     if (lane == 0) {
       DevEnv& e = S.e; Scratch& s = S.s;
       if (zero_counters) { e.substeps_last = 0; e.awake_last = 0; e.pairs_last = 0; }
-      e.stepped += 1; e.reward_valid = 1;
+      if (count_step) { e.stepped += 1; e.reward_valid = 1; }
+      e.step_stage = 0;
       e.obs_num_steps = e.num_steps; e.obs_num_episodes = e.num_episodes;
       // start = Pose([[x, y, z + FINGER_TIP_OFFSET], [0, pi, angle]])
       s.gstart[0] = e.action[0][0]; s.gstart[1] = e.action[0][1]; s.gstart[2] = e.action[0][2] + c->finger_tip_offset;
@@ -4771,6 +4772,7 @@ RV_DEV void genv_step_end(Shared& S) {
   RV_LANES_BEGIN
     if (lane == 0) {
       DevEnv& e = S.e;
+      e.step_stage = -1;
       const int success = arm_touches_movables(e);
       const float r = success ? 1.0f : 0.0f;
       e.is_effective = success;
@@ -4783,6 +4785,48 @@ RV_DEV void genv_step_end(Shared& S) {
       if (success) { e.num_successes++; e.l_successes++; }
     }
   RV_LANES_END
+}
+
+// rv_step_poll on a Grasp4DofEnv (grasp_4dof_env.py:213-293 driven in partial batches): the env.step() this env is in the
+// middle of, continued within the launch's budget.  step_stage: -1 not begun, 0 in the phase loop, 1 in the reward's
+// wait_until_stable.  What the phase machine keeps outside the env block is the start pose -- a function of the action --
+// and the two counters of wait_until_stable (ms_wus_*), so a suspended step resumes exactly where it stopped.
+// Returns which run of the substep loop comes next: 0 the phase loop, 1 the closing wait
+RV_DEV int genv_pstep_begin(Shared& S, const Consts& K) {
+  const int stage = RV_UNI(S.e.step_stage);
+  if (stage < 0) { genv_step_begin(S, K, 0, 0); return 0; }
+  RV_LANES_BEGIN
+    if (lane == 0) {
+      DevEnv& e = S.e; Scratch& s = S.s; const rv_config* c = K.cfg;
+      s.gstart[0] = e.action[0][0]; s.gstart[1] = e.action[0][1]; s.gstart[2] = e.action[0][2] + c->finger_tip_offset;
+      stq(s.gstart + 3, euler_to_quat(0.0f, RV_PI, e.action[0][3]));
+      s.wus_resume = stage == 1;
+    }
+  RV_LANES_END
+  return stage == 1;
+}
+// after the phase loop: 0 = suspended in it (the launch ends), 1 = it is over: observation taken, the closing wait comes next
+RV_DEV int genv_pstep_observe(Shared& S) {
+  if (S.s.suspended) return 0;
+  genv_step_observe(S);
+  RV_LANES_BEGIN
+    if (lane == 0) S.e.step_stage = 1;
+  RV_LANES_END
+  return 1;
+}
+// after the closing wait: 1 when the step completed in this launch
+RV_DEV int genv_pstep_end(Shared& S) {
+  if (S.s.suspended) {
+    RV_LANES_BEGIN
+      if (lane == 0) { S.e.ms_wus_steps = S.s.wus_steps; S.e.ms_wus_stable = S.s.wus_stable; }
+    RV_LANES_END
+    return 0;
+  }
+  genv_step_end(S);
+  RV_LANES_BEGIN
+    if (lane == 0) { S.e.in_step = 0; S.e.stepped += 1; S.e.reward_valid = 1; }
+  RV_LANES_END
+  return 1;
 }
 
 // --------------------------------------------------------------- reset ---
@@ -5056,6 +5100,9 @@ RV_DEV_NOINLINE int seg_pstep_end(const rv_scene* scene) { RV_SEG_K return env_p
 RV_DEV_NOINLINE void seg_gstep_begin(const rv_scene* scene, int zero_counters) { RV_SEG_K genv_step_begin(S, K, zero_counters); }
 RV_DEV_NOINLINE void seg_gstep_observe(const rv_scene* scene) { (void)scene; genv_step_observe(g_shared); }
 RV_DEV_NOINLINE void seg_gstep_end(const rv_scene* scene) { (void)scene; genv_step_end(g_shared); }
+RV_DEV_NOINLINE int seg_gpstep_begin(const rv_scene* scene) { RV_SEG_K return genv_pstep_begin(S, K); }
+RV_DEV_NOINLINE int seg_gpstep_observe(const rv_scene* scene) { (void)scene; return genv_pstep_observe(g_shared); }
+RV_DEV_NOINLINE int seg_gpstep_end(const rv_scene* scene) { (void)scene; return genv_pstep_end(g_shared); }
 RV_DEV_NOINLINE void seg_reset_begin(const rv_scene* scene, int gid, int zero_counters) { RV_SEG_K env_reset_begin(S, K, gid, zero_counters); }
 RV_DEV_NOINLINE void seg_reset_layout(const rv_scene* scene) { RV_SEG_K env_reset_layout(S, K); }
 RV_DEV_NOINLINE void seg_reset_place(const rv_scene* scene, int i) { RV_SEG_K env_reset_place(S, K, i); }
@@ -5070,7 +5117,7 @@ RV_DEV_NOINLINE void seg_reset_robot(const rv_scene* scene) { RV_SEG_K env_reset
 RV_DEV int env_program(Shared& S, const Consts& K, const int prog, const ProgArgs& A) {
   const rv_config* c = K.cfg;
   enum { PC_DONE = 0, PC_RESET_BEGIN, PC_RESET_LAYOUT, PC_RESET_BODY, PC_RESET_BODY_AFTER, PC_RESET_FINAL, PC_RESET_ROBOT,
-         PC_STEP_BEGIN, PC_STEP_END, PC_GSTEP_OBS, PC_GSTEP_END, PC_PSTEP_END,
+         PC_STEP_BEGIN, PC_STEP_END, PC_GSTEP_OBS, PC_GSTEP_END, PC_PSTEP_END, PC_GPSTEP_OBS, PC_GPSTEP_END,
          PC_ROLL_TOP, PC_ROLL_ACTION, PC_ROLL_AFTER_STEP, PC_ROLL_TAIL };
   int pc = PC_DONE, ret_reset = PC_DONE, ret_step = PC_DONE;
   int reset_zero = 1, step_zero = 1;           // zero the per-launch counters (not inside a rollout)
@@ -5085,6 +5132,11 @@ RV_DEV int env_program(Shared& S, const Consts& K, const int prog, const ProgArg
   else if (prog == RV_PROG_MACRO) pc = PC_STEP_BEGIN;
   else if (prog == RV_PROG_SUB) { if (A.n_steps > 0) { rq = run_req(A.n_steps); run = 1; } }
   else if (prog == RV_PROG_WAIT) { rq = run_req(0, 0u, A.lin_thr, A.ang_thr, A.check_after, A.min_stable, A.max_steps); run = 1; }
+  else if (prog == RV_PROG_PARTIAL && grasp) {
+    const int in_wait = RV_UNI(RV_SEG(genv_pstep_begin(S, K), seg_gpstep_begin(K.scene)));
+    if (in_wait) { rq = run_req(0, 0u, 0.005f, 0.005f, 100, 100, 2000); run = 1; pc = PC_GPSTEP_END; }
+    else { rq = run_req(-2); run = 1; pc = PC_GPSTEP_OBS; }
+  }
   else if (prog == RV_PROG_PARTIAL) { RV_SEG(env_pstep_begin(S, K), seg_pstep_begin(K.scene)); rq = run_req(-1, 0u, 0.005f, 0.005f, 100, 100, 2000); run = 1; pc = PC_PSTEP_END; }
   else {
     if (A.k0 == 0) {
@@ -5163,6 +5215,16 @@ RV_DEV int env_program(Shared& S, const Consts& K, const int prog, const ProgArg
         break;
       case PC_PSTEP_END:
         fin = RV_UNI(RV_SEG(env_pstep_end(S, K), seg_pstep_end(K.scene)));
+        pc = PC_DONE;
+        break;
+      case PC_GPSTEP_OBS:
+        if (RV_UNI(RV_SEG(genv_pstep_observe(S), seg_gpstep_observe(K.scene)))) {
+          rq = run_req(0, 0u, 0.005f, 0.005f, 100, 100, 2000); run = 1;        // GraspReward: wait until the object is stable
+          pc = PC_GPSTEP_END;
+        } else pc = PC_DONE;
+        break;
+      case PC_GPSTEP_END:
+        fin = RV_UNI(RV_SEG(genv_pstep_end(S), seg_gpstep_end(K.scene)));
         pc = PC_DONE;
         break;
       // ---- the rollout loop

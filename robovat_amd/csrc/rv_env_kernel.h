@@ -52,6 +52,8 @@ struct EnvKernelArgs {
   // (RV_Q_*), q_slots: RV_Q_NQ rings of q_cap slots, slot = env + n_envs x step (-1: not yet published); q_total tasks in
   // all; q_launch: number of this launch (every block it hands over is stamped with it).  nullptr: one workgroup per env
   int* q_slots; int* q_ctl; int q_cap; int q_total; int q_pool; int q_launch;
+  int q_sticky;                  // 1: a workgroup keeps an env whose step was a slow one (k_env)
+  int q_wt;                      // 1: the block goes out write-through and comes in past the L1 (16-byte sc1 stores / loads): it does not occupy the L2
   int poison_lo, poison_hi;      // RV_POISON_LDS builds: the words of the scratch block that start as garbage (RV_POISON_LO / _HI: bisecting)
 };
 
@@ -114,13 +116,24 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
   int* const q_head = queued ? args.q_ctl + RV_Q_HEAD(xcc) : nullptr;
   int* const q_tail = queued ? args.q_ctl + RV_Q_TAIL(xcc) : nullptr;
   bool fresh_left = true;
+  // Which env goes back to the queue and which one does the workgroup keep?  A launch cannot end before the longest chain of
+  // steps of ONE env has, so the envs on that chain must not wait in a queue between their steps, while all the others are
+  // there to be balanced (list scheduling by the longest remaining chain).  After a task the workgroup compares what is left
+  // of this env -- its remaining steps x the duration of the step it just took (a contact-rich state persists) -- with what is
+  // left of the launch -- the tasks not yet begun x this workgroup's mean task duration / the number of workgroups --, and
+  // keeps the env (runs its next step at once) when the env's rest is more than half of the launch's.  Measured (profiles/
+  // r06_*queue_variants*): 8192 envs x 20 steps, throughput-bound, nothing is kept and the queues give + 14 %; 4096 concave
+  // envs x 10 steps and 8192 envs without deactivation are bound by their slowest env, where plain FIFO lost 5 - 9 %.
+  // keep >= 0: the task to run next without asking the queue.  Not in a pool (there the envs take turns)
+  int keep = -1;
+  unsigned long long clk_sum = 0ull; int clk_n = 0;
   for (;;) {
     int env = (int)blockIdx.x, k0 = 0;
     if (queued) {
       __syncthreads();
       if (lane == 0) {
-        int e = -1;
-        if (fresh_left) {          // an env nobody has stepped in this launch
+        int e = keep;
+        if (e < 0 && fresh_left) {          // an env nobody has stepped in this launch
           const int f = atomicAdd(args.q_ctl + RV_Q_FRESH, 1);
           if (f < args.n_envs) e = f; else fresh_left = false;
         }
@@ -145,20 +158,40 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
       k0 = env / args.n_envs; env = env - k0 * args.n_envs;      // (a slot says whose turn it is AND which of its steps)
       if (k0 > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (buffer_inv sc1, once per task, before the block is loaded)
     }
+    const unsigned long long t_begin = queued ? __builtin_amdgcn_s_memtime() : 0ull;
     rv_env_task<TMODE>(args, MODE, env, S, K, k0, queued ? k0 + 1 : 0);      // (the ONE call site of the env program in this kernel)
     if (!queued) return;
     __syncthreads();                                   // (the env's block is written: every lane's stores are issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and acknowledged by the L2 of this XCD
-    if (lane == 0) {
-      if (args.q_pool || k0 + 1 < args.n_substeps) {
-        const int p = atomicAdd(q_tail, 1);
-        if (p < args.q_cap) __hip_atomic_store(&q_ring[p], env + args.n_envs * (k0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else atomicOr(args.q_ctl + RV_Q_ERR, 2);
-      }
+    const unsigned long long dur = __builtin_amdgcn_s_memtime() - t_begin;
+    clk_sum += dur; ++clk_n;
+    const bool more = args.q_pool || k0 + 1 < args.n_substeps;
+    bool slow = false;
+    if (more && !args.q_pool && args.q_sticky) {
+      const int begun = __builtin_amdgcn_readfirstlane(__hip_atomic_load(args.q_ctl + RV_Q_TAKEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const unsigned long long left = (unsigned long long)(begun < args.q_total ? args.q_total - begun : 0);
+      const unsigned long long env_rest = (unsigned long long)(args.n_substeps - k0 - 1) * dur * (unsigned long long)gridDim.x;
+      slow = 2ull * env_rest * (unsigned long long)clk_n > left * clk_sum;
+    }
+    keep = slow ? env + args.n_envs * (k0 + 1) : -1;
+    if (lane == 0 && more && keep < 0) {
+      const int p = atomicAdd(q_tail, 1);
+      if (p < args.q_cap) __hip_atomic_store(&q_ring[p], env + args.n_envs * (k0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else atomicOr(args.q_ctl + RV_Q_ERR, 2);
     }
   }
 }
 
+// The env block between HBM and LDS with `sc1` accesses (relaxed agent-scope atomics, one word per lane and access): the stores
+// are written through -- the line does not stay in the XCD's L2, which the scratch of the eight resident waves of a CU wants
+// for itself --, the loads bypass the vector L1 and are served by the L2 / memory.  (6.4 KB per block: the width of the access
+// does not matter.)  Still the same-XCD protocol of k_env: one L2 orders the write-through and the later read of a word.
+__device__ __forceinline__ void rv_block_load_sc1(uint32_t* lds, const uint32_t* glb, const int W, const int lane) {
+  for (int i = lane; i < W; i += 64) lds[i] = __hip_atomic_load(const_cast<uint32_t*>(&glb[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void rv_block_store_sc1(uint32_t* glb, const uint32_t* lds, const int W, const int lane) {
+  for (int i = lane; i < W; i += 64) __hip_atomic_store(&glb[i], lds[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // One env, one run of the env program: load its block into LDS, run, store it back.  k0 / k_stop: MODE_ROLLOUT as a task
 // of the queue (the steps k0 .. k_stop - 1; 0 / 0: all steps).  Inlined at its single call site per branch of the kernel.
 template <int TMODE>
@@ -171,7 +204,8 @@ __device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&S.e);
-    for (int i = lane; i < W; i += 64) dst[i] = src[i];
+    if (k_stop > 0 && args.q_wt) rv_block_load_sc1(dst, src, W, lane);
+    else for (int i = lane; i < W; i += 64) dst[i] = src[i];
     __syncthreads();
     // a task of a queue after the env's first: the block was stored a moment ago by another workgroup of this XCD.  It
     // carries the number of the step it is ready for and of the launch that stored it -- asserted, never repaired
@@ -262,7 +296,8 @@ __device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int
   {
     uint32_t* dst = reinterpret_cast<uint32_t*>(g);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.e);
-    for (int i = lane; i < W; i += 64) dst[i] = src[i];
+    if (k_stop > 0 && args.q_wt) rv_block_store_sc1(dst, src, W, lane);
+    else for (int i = lane; i < W; i += 64) dst[i] = src[i];
   }
 }
 

@@ -197,6 +197,13 @@ __global__ void k_set_link_path(DevEnv* envs, int n, const float* poses, int n_p
   t.pos_thr = threshold > 0.0f ? threshold : cfg->limb_position_threshold; t.vel_thr = cfg->velocity_threshold;
   lt_pop(t);
 }
+__global__ void k_set_max_joint_velocities(DevEnv* envs, int n, const float* v) {
+  ENV_THREAD();
+  // ControllableBody.set_max_joint_velocities (controllable_body.py:357-372): the speed limits of the limb joints that the
+  // running (and the next) targets are followed with -- SawyerSim.move_to_*(speed=...) sends them with every motion command
+  // (sawyer_sim.py:212-220, 285-293, 336-344); a target setter puts LIMB_MAX_VELOCITY_RATIO x the URDF limits back
+  for (int j = 0; j < RV_NLIMB; ++j) e.vmax_cmd[j] = v[(size_t)i * RV_NLIMB + j];
+}
 __global__ void k_robot_ready(DevEnv* envs, int n, uint8_t* out, const rv_config* cfg) {
   ENV_THREAD();
   // SawyerSim.is_limb_ready -> ControllableBody.is_ready(limb joints) (sawyer_sim.py:394-400, controllable_body.py:565-595):
@@ -574,6 +581,7 @@ static void launch_k_env(rv_world* w, int mode, const EnvKernelArgs& a) {
   if (w->occ2) rv_launch_k_env_occ2(mode, a, n_grid, w->stream);
   else rv_launch_k_env_here(mode, a, n_grid, w->stream);
 }
+#define RV_QUEUE_MIN_STEPS 4
 __global__ void k_queue_init(int* q, long long words) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < words) q[i] = i < RV_Q_CTL_WORDS ? 0 : -1;      // counters 0 (the error word too), every slot "not yet published"
@@ -582,11 +590,13 @@ __global__ void k_queue_init(int* q, long long words) {
 // pool > 0: the work-conserving rollout (rv_rollout_async) -- `pool` tasks in all, an env goes back to the tail after every
 // step, so the envs take turns and one in a slow state simply gets fewer of them
 static int queue_setup(rv_world* w, int n_steps, EnvKernelArgs& a, long long pool = 0) {
-  a.q_slots = nullptr; a.q_ctl = nullptr; a.q_cap = 0; a.q_total = 0; a.q_pool = 0; a.q_launch = 0;
+  a.q_slots = nullptr; a.q_ctl = nullptr; a.q_cap = 0; a.q_total = 0; a.q_pool = 0; a.q_launch = 0; a.q_wt = 0; a.q_sticky = 0;
   const char* q = getenv("RV_QUEUE");      // (read per launch: the tests compare the two schedules in one process)
   // (short rollouts gain nothing -- a task is an env.step(), so with few steps per env the tail is the same --; measured on
   // 8192 envs: 2 steps -8 %, 10 steps -4 ... +1 %, 20 steps +14 ... +23 %, 30 steps +18 %.  RV_QUEUE=1 forces the queues, 0 forbids them)
-  if ((q && atoi(q) == 0) || w->q_grid <= 0 || w->n <= w->q_grid || (pool == 0 && n_steps < 12 && !(q && atoi(q) == 1))) return RV_OK;
+  const char* qm = getenv("RV_QUEUE_MIN_STEPS");
+  const int min_steps = qm ? atoi(qm) : RV_QUEUE_MIN_STEPS;
+  if ((q && atoi(q) == 0) || w->q_grid <= 0 || w->n <= w->q_grid || (pool == 0 && n_steps < min_steps && !(q && atoi(q) == 1))) return RV_OK;
   const size_t total = pool > 0 ? (size_t)pool : (size_t)w->n * (size_t)n_steps;      // tasks that are begun
   if (total > ((size_t)1 << 24)) return RV_OK;      // (8 rings of `total` ints: 512 MB at most)
   // a ring holds what ONE XCD may be handed in the worst case: every task of the launch (an env is published once per
@@ -607,6 +617,8 @@ static int queue_setup(rv_world* w, int n_steps, EnvKernelArgs& a, long long poo
   }
   a.q_ctl = w->d_q; a.q_slots = w->d_q + RV_Q_CTL_WORDS; a.q_cap = (int)ring; a.q_total = (int)total; a.q_pool = pool > 0 ? 1 : 0;
   a.q_launch = ++w->q_launch;
+  { const char* st = getenv("RV_QUEUE_STICKY"); a.q_sticky = st ? atoi(st) : 1; }
+  { const char* wt = getenv("RV_QUEUE_WT"); a.q_wt = wt ? atoi(wt) : 1; }      // (measurement aid: 0 = plain stores / loads of the block)
   hipLaunchKernelGGL(k_queue_init, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, w->stream, w->d_q, (long long)need);
   HIPCHK(hipGetLastError());
   w->q_used = true;
@@ -629,7 +641,7 @@ static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, fl
   a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.mask = mask; a.n_envs = w->n;
   { const char* ds = getenv("RV_DEBUG_STOP"); a.stop_after = ds ? atoi(ds) : 0; }
   a.n_substeps = n_sub; a.lin_thr = lin; a.ang_thr = ang; a.check_after = ca; a.min_stable = ms; a.max_steps = mx;
-  a.q_slots = nullptr; a.q_ctl = nullptr; a.q_cap = 0; a.q_total = 0; a.q_pool = 0; a.q_launch = 0;
+  a.q_slots = nullptr; a.q_ctl = nullptr; a.q_cap = 0; a.q_total = 0; a.q_pool = 0; a.q_launch = 0; a.q_wt = 0; a.q_sticky = 0;
   poison_range(a);
   if (MODE == MODE_ROLLOUT && budget == nullptr) { int rc = queue_setup(w, n_sub, a); if (rc != RV_OK) return rc; }
   if (MODE == MODE_ROLLOUT && budget != nullptr && pool_tasks > 0) {
@@ -811,7 +823,6 @@ int rv_rollout_async(rv_world* w, int32_t total_env_steps, int32_t first_macro_i
 int rv_step_begin(rv_world* w, const float* d_actions, const uint8_t* d_mask) {
   WCHK(w);
   if (!d_actions) return fail(RV_ERR_VALUE, "rv_step_begin: null buffer");
-  if (w->cfg.env_type != RV_ENV_PUSH) return fail(RV_ERR_NOTIMPL, "rv_step_begin: PushEnv only");
   const int G = w->cfg.num_goal_steps > 0 ? w->cfg.num_goal_steps : 1;
   hipLaunchKernelGGL(k_step_begin, grid1(w->n), dim3(TPB), 0, w->stream, w->d_envs, w->n, d_actions, d_mask, G);
   HIPCHK(hipGetLastError());
@@ -823,7 +834,6 @@ int rv_step_poll(rv_world* w, int32_t max_substeps, int32_t max_usec, uint8_t* d
   WCHK(w);
   if (!d_finished) return fail(RV_ERR_VALUE, "rv_step_poll: null buffer");
   if (max_substeps < 0 || max_usec < 0) return fail(RV_ERR_VALUE, "rv_step_poll: negative budget");
-  if (w->cfg.env_type != RV_ENV_PUSH) return fail(RV_ERR_NOTIMPL, "rv_step_poll: PushEnv only");
   EnvKernelArgs a;
   memset(&a, 0, sizeof(a));
   a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.n_envs = w->n;
@@ -904,6 +914,10 @@ int rv_set_link_path(rv_world* w, const float* d, int32_t n_poses, float timeout
   WCHK(w); NEED(d, "rv_set_link_path");
   if (n_poses < 1 || n_poses > RV_MAXQ) return fail(RV_ERR_VALUE, "rv_set_link_path: 1 <= n_poses <= RV_MAXQ");
   SIMPLE_LAUNCH(k_set_link_path, w->d_envs, w->n, d, n_poses, w->d_cfg, w->d_scene, timeout, threshold); return RV_OK;
+}
+int rv_set_max_joint_velocities(rv_world* w, const float* d) {
+  WCHK(w); NEED(d, "rv_set_max_joint_velocities");
+  SIMPLE_LAUNCH(k_set_max_joint_velocities, w->d_envs, w->n, d); return RV_OK;
 }
 int rv_get_camera(rv_world* w, float* d) { WCHK(w); NEED(d, "rv_get_camera"); SIMPLE_LAUNCH(k_get_camera, w->d_envs, w->n, d); return RV_OK; }
 int rv_get_robot_ready(rv_world* w, uint8_t* d) { WCHK(w); NEED(d, "rv_get_robot_ready"); SIMPLE_LAUNCH(k_robot_ready, w->d_envs, w->n, d, w->d_cfg); return RV_OK; }

@@ -31,7 +31,7 @@ SYMBOLS = [
     'rv_reward', 'rv_get_episode_returns', 'rv_get_stats', 'rv_last_kernel_ms',
     'rv_reset_targets', 'rv_get_state_ptrs', 'rv_source_hash', 'rv_set_motor_targets', 'rv_grip',
     'rv_rollout_record', 'rv_render', 'rv_set_gravity', 'rv_rollout_record_full', 'rv_step_begin', 'rv_step_poll', 'rv_set_constraint', 'rv_render_rgb', 'rv_set_friction', 'rv_set_auto_reset',
-    'rv_set_constraint_ex', 'rv_set_link_path', 'rv_get_robot_ready', 'rv_get_camera',
+    'rv_set_constraint_ex', 'rv_set_link_path', 'rv_get_robot_ready', 'rv_get_camera', 'rv_set_max_joint_velocities',
 ]
 
 _EXC = {abi.RV_ERR_VALUE: ValueError, abi.RV_ERR_STATE: RuntimeError,
@@ -162,6 +162,7 @@ def load():
     lib.rv_set_link_target.argtypes = [vp, vp, f32, f32]
     lib.rv_set_link_path.argtypes = [vp, vp, i32, f32, f32]
     lib.rv_get_robot_ready.argtypes = [vp, vp]
+    lib.rv_set_max_joint_velocities.argtypes = [vp, vp]
     lib.rv_get_camera.argtypes = [vp, vp]
     for name in ('rv_set_actions', 'rv_get_body_state', 'rv_set_body_state',
                  'rv_get_body_params', 'rv_set_body_params', 'rv_get_joint_state',
@@ -407,6 +408,11 @@ class World(object):
         n_poses = int(p.shape[1])
         p = p.reshape(self.n, n_poses, 7).contiguous()
         check(self.lib.rv_set_link_path(self.h, self._ptr(p), n_poses, float(timeout), float(threshold)))
+
+    def set_max_joint_velocities(self, vmax):
+        """rv_set_max_joint_velocities: speed limits [N, 7] (or [7]) of the limb joints for the targets being followed."""
+        v = self._in(np.broadcast_to(np.asarray(vmax, np.float32), (self.n, abi.RV_NLIMB)).copy(), (self.n, abi.RV_NLIMB), self.torch.float32)
+        check(self.lib.rv_set_max_joint_velocities(self.h, self._ptr(v)))
 
     def robot_ready(self):
         """[N, 2] uint8: (is_limb_ready, is_gripper_ready) -- retires finished targets like the reference's query."""

@@ -78,10 +78,10 @@ class SawyerSim(object):
 
     # ---- commands
     def _limits(self, speed, timeout, threshold):
-        ratio = self.config.LIMB_MAX_VELOCITY_RATIO
-        if speed is not None and abs(float(speed) - ratio) > 1e-9:
-            raise NotImplementedError('the device applies LIMB_MAX_VELOCITY_RATIO = %g to the URDF velocity limits; a per-call '
-                                      'speed of %g needs a world created with that ratio' % (ratio, speed))
+        """sawyer_sim.py:196-206: the defaults of the three optional arguments of a motion command."""
+        self._speed = self.config.LIMB_MAX_VELOCITY_RATIO if speed is None else float(speed)
+        if not self._speed > 0:
+            raise ValueError('speed must be a positive ratio of the joint velocity limits: %r' % (speed,))
         return (self.config.LIMB_TIMEOUT if timeout is None else timeout,
                 self.config.LIMB_POSITION_THRESHOLD if threshold is None else threshold)
 
@@ -89,7 +89,8 @@ class SawyerSim(object):
         self._simulator.receive_robot_commands(RobotCommand(component=self._arm.name, command_type=command_type, arguments=arguments))
 
     def _max_velocity_command(self):
-        ratio = self.config.LIMB_MAX_VELOCITY_RATIO
+        # sawyer_sim.py:212-220: speed x the URDF velocity limit of every limb joint, with every motion command
+        ratio = self._speed
         self._command('set_max_joint_velocities', joint_velocities=dict((j.name, ratio * j.max_velocity) for j in self._limb_joints))
 
     def move_to_joint_positions(self, positions, speed=None, timeout=None, threshold=None):

@@ -181,6 +181,7 @@ class ControllableBody(Body):
             joint_positions = [joint_positions[j.name] for j in self._joints[:7]]
         self.physics.world.set_joint_targets(np.asarray(joint_positions, np.float32)[None, :7],
                                              timeout=timeout, threshold=threshold)
+        self._apply_vmax()
 
     def _pose7(self, link_pose):
         pose = Pose(link_pose)
@@ -188,14 +189,32 @@ class ControllableBody(Body):
 
     def set_target_link_pose(self, link_ind, link_pose, timeout=15.0, threshold=0.008726640):
         self.physics.world.set_link_target(self._pose7(link_pose)[None], timeout=timeout, threshold=threshold)
+        self._apply_vmax()
 
     def set_target_link_poses(self, link_ind, link_poses, timeout=15.0, threshold=0.008726640):
         """controllable_body.py:322-345: a path of gripper poses, followed one after the other."""
         poses = np.stack([self._pose7(p) for p in link_poses])
         self.physics.world.set_link_path(poses[None], timeout=timeout, threshold=threshold)
+        self._apply_vmax()
 
     def set_max_joint_velocities(self, joint_velocities):
-        pass   # LIMB_MAX_VELOCITY_RATIO is applied on the device
+        """controllable_body.py:357-372.  The device applies LIMB_MAX_VELOCITY_RATIO x the URDF limits with every target it is
+        given; limits that differ from those (SawyerSim.move_to_*(speed=...)) are sent after the target they belong to."""
+        limb = self._joints[:7]
+        if isinstance(joint_velocities, dict):
+            v = [joint_velocities.get(j.name, None) for j in limb]
+        else:
+            v = list(joint_velocities)[:7]
+        ratio = np.float32(self.physics.rv_config.limb_max_velocity_ratio)
+        default = [float(ratio * np.float32(j.max_velocity)) for j in limb]
+        v = [d if x is None else float(x) for x, d in zip(v, default)]
+        if any(x <= 0 for x in v):
+            raise ValueError('joint velocities must be positive: %r' % (v,))
+        self._vmax_pending = None if np.allclose(v, default, rtol=1e-6, atol=0) else np.asarray(v, np.float32)
+
+    def _apply_vmax(self):
+        if getattr(self, '_vmax_pending', None) is not None:
+            self.physics.world.set_max_joint_velocities(self._vmax_pending)
 
     def grip(self, value):
         """SawyerSim.grip (sawyer_sim.py:362-392): the two finger joints' target, replacing the limb's joint target."""

@@ -212,6 +212,41 @@ def test_emulated_grasp_env_is_bit_exact_vs_float_oracle(emu):
         _check(e, ref)
 
 
+@pytest.mark.parametrize('budget', [53, 700, 6000])
+def test_partial_grasp_steps_equal_whole_steps(emu, budget):
+    """rv_step_begin / rv_step_poll on a Grasp4DofEnv (lane emulator, substep budget): the step cut inside the phase loop
+    (which ticks after every substep), inside the reward's wait_until_stable, or not at all ends where rv_step_macro ends."""
+    from oracle import orc
+    genv = configs.grasp_env_config()
+    scene, names = scenes.make_scene(env_cfg=genv)
+    cfg = configs.make_rv_config(env_cfg=genv, n_envs=6, seed=5, shape_names=names)
+    ref = orc.OracleWorld(cfg, scene, double=False)
+    e = Emu(emu, cfg, scene)
+    ref.reset(); emu.emu_reset(e.h, None)
+    a = ref.policy_random(0)
+    st = ref.body_state()
+    for i in range(0, 6, 2):
+        a[i, 0, :2] = st[i, 0, :2]
+    ref.set_actions(a); ref.step_macro()
+    emu.emu_step_begin(e.h, a.ctypes.data_as(C.c_void_p), None)
+    done_mask = np.zeros(6, np.uint8); polls = 0
+    while not done_mask.all():
+        fin = np.zeros(6, np.uint8)
+        emu.emu_step_poll(e.h, budget, fin.ctypes.data_as(C.c_void_p))
+        assert not (fin & done_mask).any()
+        done_mask |= fin; polls += 1
+        assert polls < 4000
+    assert polls > 1 or budget > 5000
+    assert np.array_equal(e.body_state(), ref.body_state().astype(np.float32))
+    assert np.array_equal(e.joint_state(), ref.joint_state().astype(np.float32))
+    assert np.array_equal(e.counters()[:, :7], ref.env_counters()[:, :7])
+    assert np.array_equal(e.manifolds(), ref.manifold_counts())
+    r = np.zeros(6, np.float32); d = np.zeros(6, np.uint8)
+    emu.emu_reward(e.h, r.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p))
+    rr, rd = ref.reward()
+    assert np.array_equal(r, rr.astype(np.float32)) and d.all()
+
+
 def test_concentric_overlaps_run_epa_from_a_grown_simplex(emu):
     """Bodies teleported INTO each other (same centre, same orientation: identical shapes give a mirror-symmetric
     difference body, GJK's closest point is the origin on a segment / triangle): the grown-simplex + EPA path of

@@ -59,6 +59,57 @@ def test_grasp_env_matches_float_oracle_bit_for_bit():
     world.close()
 
 
+def test_grasp_env_in_partial_batches_equals_the_lock_step():
+    """rv_step_begin / rv_step_poll on a Grasp4DofEnv (grasp_4dof_env.py:213-293 driven EnvPool style): however the step is
+    cut into launches -- by substeps, by GPU time, mid-phase and mid-wait -- every env ends where rv_step_macro (== the float
+    oracle, above) puts it, bit for bit, and the poll hands back the reward / done the lock step returns; a step begun on
+    the finished episode resets the env when rv_set_auto_reset is on."""
+    import torch
+    from robovat_amd import lib
+    from oracle import orc
+    cfg, scene = _cfg(40, seed=7)
+    ref = orc.OracleWorld(cfg, scene, double=False)
+    ref.reset()
+    a = _aimed(ref.body_state(), ref.policy_random(0))
+    ref.set_actions(a); ref.step_macro()
+    rr, rd = ref.reward()
+    for budget in (dict(max_substeps=137), dict(max_usec=300), dict(max_substeps=4000)):
+        world = lib.World(cfg, scene, device=0)
+        world.reset()
+        out = world.poll_buffers(point_cloud=False)
+        world.step_begin(torch.as_tensor(a).cuda())
+        done_mask = np.zeros(40, bool); polls = 0
+        rew = np.zeros(40, np.float32)
+        while not done_mask.all():
+            fin = world.step_poll(out=out, **budget).cpu().numpy().astype(bool)
+            assert not (fin & done_mask).any()                       # a step is reported once
+            rew[fin] = out['reward'].cpu().numpy()[fin]
+            assert out['done'].cpu().numpy()[fin].all()
+            done_mask |= fin; polls += 1
+            assert polls < 4000
+        assert polls > (1 if 'max_usec' not in budget else 0)
+        assert np.array_equal(world.body_state().cpu().numpy(), ref.body_state().astype(np.float32)), budget
+        assert np.array_equal(world.joint_state().cpu().numpy(), ref.joint_state().astype(np.float32)), budget
+        wc, rc = world.env_counters().cpu().numpy(), ref.env_counters()
+        assert np.array_equal(wc[:, :7], rc[:, :7]), budget            # (the per-launch columns 7.. count the last poll only)
+        assert np.array_equal(rew, rr.astype(np.float32)), budget
+        # nothing is pending: another poll finishes nobody
+        assert not world.step_poll(max_substeps=50).cpu().numpy().any()
+        # the episode is over (terminate_after_grasp): with auto-reset the next begin resets, the poll returns the reset
+        world.set_auto_reset(True)
+        world.step_begin(torch.as_tensor(a).cuda())
+        fin = np.zeros(40, bool)
+        for _ in range(4000):
+            fin |= world.step_poll(max_substeps=500, out=out).cpu().numpy().astype(bool)
+            if fin.all():
+                break
+        assert fin.all()
+        ref2 = orc.OracleWorld(cfg, scene, double=False)
+        ref2.reset(); ref2.set_actions(a); ref2.step_macro(); ref2.reset()
+        assert np.array_equal(world.body_state().cpu().numpy(), ref2.body_state().astype(np.float32)), budget
+        world.close()
+
+
 def test_config4_grasp_at_2048_envs():
     """BASELINE configs[3] at its stated size: properties + a 64-env slice bit-exact vs the oracle."""
     from robovat_amd import lib

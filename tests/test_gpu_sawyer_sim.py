@@ -92,5 +92,19 @@ def test_phase_machine_on_sawyer_sim_matches_the_oracle():
     robot.move_to_joint_positions(off); ref.set_joint_targets(np.asarray(off, np.float32)[None])
     n5 = run(limb, limb_ref)
     assert min(n1, n2, n3, n5) >= 10 and np.abs(np.asarray(robot.arm.joint_positions[:7]) - off).max() < 0.02
-    with pytest.raises(NotImplementedError):
-        robot.move_to_joint_positions(off, speed=0.9)
+    # 5. a per-call speed (sawyer_sim.py:186-234 `speed=`): back to neutral at 35 % of the joint velocity limits -- slower than
+    #    the same move at the configured ratio, and the oracle given the same limits follows bit for bit
+    neutral = list(robot.config.LIMB_NEUTRAL_POSITIONS)
+    vmax = np.asarray([0.35 * j.max_velocity for j in robot._limb_joints], np.float32)
+    robot.move_to_joint_positions(neutral, speed=0.35)
+    ref.set_joint_targets(np.asarray(neutral, np.float32)[None]); ref.set_max_joint_velocities(vmax)
+    n6 = run(limb, limb_ref)
+    assert np.abs(np.asarray(robot.arm.joint_positions[:7]) - neutral).max() < 0.02
+    robot.move_to_joint_positions(off); ref.set_joint_targets(np.asarray(off, np.float32)[None])     # (default speed again)
+    n7 = run(limb, limb_ref)
+    assert n6 > 1.5 * n7, (n6, n7)
+    with pytest.raises(ValueError):
+        robot.move_to_joint_positions(off, speed=0.0)
+    # SawyerSim.reboot twice (advisor, round 5: the second call removed the arm body, which HipPhysics.remove_body refused)
+    robot.reboot(); robot.reboot()
+    assert abs(robot.joint_positions['right_j3'] - robot.config.LIMB_NEUTRAL_POSITIONS[3]) < 1e-6

@@ -542,3 +542,34 @@ def test_rollouts_cut_into_launches_of_any_length_equal_the_oracle():
         assert np.array_equal(world.body_state().cpu().numpy(), ref.body_state().astype(np.float32)), k
         assert np.array_equal(world.joint_state().cpu().numpy(), ref.joint_state().astype(np.float32)), k
     world.close()
+
+
+def test_the_benched_queue_path_equals_the_oracle_directly():
+    """The configuration bench.py times as BASELINE configs[4] -- 8192 envs, the two-waves-per-SIMD build, 20 env.step() per env
+    with auto-reset through the per-XCD task queues, after a 5-step warm-up launch -- compared with the float oracle DIRECTLY
+    (not through the plain launch): three 64-env slices (first / middle / last global ids) bit for bit -- body states, joint
+    states, env counters and every recorded reward / done of the 20 steps -- and the queue's own assertion word clean."""
+    n, seed, warm, k = 8192, 1234, 5, 20
+    world = _world(n, seed)
+    world.reset()
+    world.rollout(warm, first_macro_index=0, auto_reset=True, record=True)
+    r, d = world.rollout(k, first_macro_index=warm, auto_reset=True, record=True)
+    st = world.stats()                               # (raises if a block arrived with the wrong step / launch number)
+    assert st['env_steps'] == n * k
+    body, joints, cnt = world.body_state().cpu().numpy(), world.joint_state().cpu().numpy(), world.env_counters().cpu().numpy()
+    r, d = r.cpu().numpy(), d.cpu().numpy()
+    for lo in (0, 4064, n - 64):
+        ref = _oracle(64, seed, offset=lo)
+        ref.reset()
+        ref.rollout(warm, 0, True)
+        rr = np.zeros((k, 64), np.float32); rd = np.zeros((k, 64), np.uint8)
+        for j in range(k):                           # (step by step: the oracle's rollout records nothing)
+            ref.rollout(1, warm + j, True)
+            x, y = ref.reward()
+            rr[j], rd[j] = x, y
+        assert np.array_equal(body[lo:lo + 64], ref.body_state().astype(np.float32)), lo
+        assert np.array_equal(joints[lo:lo + 64], ref.joint_state().astype(np.float32)), lo
+        assert np.array_equal(cnt[lo:lo + 64, :7], ref.env_counters()[:, :7]), lo
+        assert np.array_equal(r[:, lo:lo + 64], rr), lo
+        assert np.array_equal(d[:, lo:lo + 64], rd), lo
+    world.close()
