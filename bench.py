@@ -382,6 +382,7 @@ def main():
                          'alone (tools/profile_bench.sh), implies --no-extra-legs')
     ap.add_argument('--over', nargs='*', default=[], help='config overrides of the timed workload, KEY=VALUE (profiling aid: e.g. '
                     'PHYSICS.SLEEP_STEPS=0 times the no-deactivation launch alone; implies --no-extra-legs)')
+    ap.add_argument('--limb-legs', action='store_true', help='also time PHYSICS.LIMB_DYNAMICS=1 (optional mode, SURVEY 8 f1) on the headline and the grasp workload')
     ap.add_argument('--legs-out', default=os.path.join(ROOT, 'bench_legs.json'), help='where the full record (every leg, every note) is written')
     ap.add_argument('--extra-legs', action='store_true', help='run the extra legs at --gpus N > 1 as well (default: N = 1 only -- '
                     'at 8192 envs per rank the no-deactivation legs alone take minutes)')
@@ -818,33 +819,36 @@ def main():
             'grasp_success_rate': st4['successes'] / max(st4['env_steps'], 1),
             'roofline_frac_nominal': 1912 * st4['substeps'] / (1e-3 * w4.last_kernel_ms()) / 1e9 / HBM_PEAK_GBS})
         w4.close()
-        # the same two workloads with the dynamic limb (PHYSICS.LIMB_DYNAMICS: joint-space inertia,
-        # contact Jacobians and effort-limited motor rows of the seven joints in the solve of every substep in
-        # which the arm touches an awake body) -- cost and outcome next to the kinematic limb
-        limb = {'note': 'LIMB_DYNAMICS=1 vs the shipped kinematic limb (the headline and config4_grasp_2048 above): same seeds and actions'}
-        wl, _ = make_world(n, **{'PHYSICS.LIMB_DYNAMICS': 1})
-        wl.reset()
-        barrier(); tl = time.perf_counter()
-        wl.rollout(args.steps, first_macro_index=args.warmup, auto_reset=True, record=True)
-        stl = wl.stats()
-        barrier(); ell = all_max(time.perf_counter() - tl)
-        limb['push_%d' % n] = leg_summary(ell, stl, args.steps, n)
-        limb['push_%d' % n].update({k: stl[k] / max(stl['env_steps'], 1) for k in ('useful', 'unsafe', 'ineffective')})
-        limb['push_%d' % n]['kinematic'] = {k: st[k] / max(st['env_steps'], 1) for k in ('useful', 'unsafe', 'ineffective')}
-        wl.close()
-        genv = configs.grasp_env_config(**{'PHYSICS.LIMB_DYNAMICS': 1})
-        gc = configs.make_rv_config(env_cfg=genv, n_envs=2048, env_id_offset=rank * 2048, shape_names=gnames, **cfg_kwargs)
-        wl = lib.World(gc, gscene, device=local_rank)
-        wl.reset()
-        barrier(); tl = time.perf_counter()
-        wl.rollout(k3, first_macro_index=0, auto_reset=True, record=True)
-        stl = wl.stats()
-        barrier(); ell = all_max(time.perf_counter() - tl)
-        limb['grasp_2048'] = leg_summary(ell, stl, k3, 2048)
-        limb['grasp_2048']['grasp_success_rate'] = stl['successes'] / max(stl['env_steps'], 1)
-        limb['grasp_2048']['kinematic_grasp_success_rate'] = extra['config4_grasp_2048']['grasp_success_rate']
-        wl.close()
-        extra['limb_dynamics'] = limb
+        # (the kinematic pusher is the model -- DESIGN.md section 3 item 12; the optional contact-time limb dynamics
+        # stays a tested mode of the library and is timed only on request)
+        if args.limb_legs:
+            # the same two workloads with the dynamic limb (PHYSICS.LIMB_DYNAMICS: joint-space inertia,
+            # contact Jacobians and effort-limited motor rows of the seven joints in the solve of every substep in
+            # which the arm touches an awake body) -- cost and outcome next to the kinematic limb
+            limb = {'note': 'LIMB_DYNAMICS=1 vs the shipped kinematic limb (the headline and config4_grasp_2048 above): same seeds and actions'}
+            wl, _ = make_world(n, **{'PHYSICS.LIMB_DYNAMICS': 1})
+            wl.reset()
+            barrier(); tl = time.perf_counter()
+            wl.rollout(args.steps, first_macro_index=args.warmup, auto_reset=True, record=True)
+            stl = wl.stats()
+            barrier(); ell = all_max(time.perf_counter() - tl)
+            limb['push_%d' % n] = leg_summary(ell, stl, args.steps, n)
+            limb['push_%d' % n].update({k: stl[k] / max(stl['env_steps'], 1) for k in ('useful', 'unsafe', 'ineffective')})
+            limb['push_%d' % n]['kinematic'] = {k: st[k] / max(st['env_steps'], 1) for k in ('useful', 'unsafe', 'ineffective')}
+            wl.close()
+            genv = configs.grasp_env_config(**{'PHYSICS.LIMB_DYNAMICS': 1})
+            gc = configs.make_rv_config(env_cfg=genv, n_envs=2048, env_id_offset=rank * 2048, shape_names=gnames, **cfg_kwargs)
+            wl = lib.World(gc, gscene, device=local_rank)
+            wl.reset()
+            barrier(); tl = time.perf_counter()
+            wl.rollout(k3, first_macro_index=0, auto_reset=True, record=True)
+            stl = wl.stats()
+            barrier(); ell = all_max(time.perf_counter() - tl)
+            limb['grasp_2048'] = leg_summary(ell, stl, k3, 2048)
+            limb['grasp_2048']['grasp_success_rate'] = stl['successes'] / max(stl['env_steps'], 1)
+            limb['grasp_2048']['kinematic_grasp_success_rate'] = extra['config4_grasp_2048']['grasp_success_rate']
+            wl.close()
+            extra['limb_dynamics'] = limb
         # the path's only collective, alone: one RCCL all-gather of returns f32[8192] + all-reduce of 4
         # int64 counters on this run's group (the 8-rank curve is the driver's to measure)
         if dist is not None:

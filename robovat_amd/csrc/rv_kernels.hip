@@ -581,7 +581,7 @@ static void launch_k_env(rv_world* w, int mode, const EnvKernelArgs& a) {
   if (w->occ2) rv_launch_k_env_occ2(mode, a, n_grid, w->stream);
   else rv_launch_k_env_here(mode, a, n_grid, w->stream);
 }
-#define RV_QUEUE_MIN_STEPS 4
+#define RV_QUEUE_MIN_STEPS 10
 __global__ void k_queue_init(int* q, long long words) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < words) q[i] = i < RV_Q_CTL_WORDS ? 0 : -1;      // counters 0 (the error word too), every slot "not yet published"
@@ -592,8 +592,10 @@ __global__ void k_queue_init(int* q, long long words) {
 static int queue_setup(rv_world* w, int n_steps, EnvKernelArgs& a, long long pool = 0) {
   a.q_slots = nullptr; a.q_ctl = nullptr; a.q_cap = 0; a.q_total = 0; a.q_pool = 0; a.q_launch = 0; a.q_wt = 0; a.q_sticky = 0;
   const char* q = getenv("RV_QUEUE");      // (read per launch: the tests compare the two schedules in one process)
-  // (short rollouts gain nothing -- a task is an env.step(), so with few steps per env the tail is the same --; measured on
-  // 8192 envs: 2 steps -8 %, 10 steps -4 ... +1 %, 20 steps +14 ... +23 %, 30 steps +18 %.  RV_QUEUE=1 forces the queues, 0 forbids them)
+  // (measured with the per-XCD queues and the keep rule of k_env, profiles/r06_queue_variants.txt -- 8192 envs: 20 steps + 14 %, 10 steps
+  // + 13 ... 16 %, 5 steps + 16 ... 19 %, 2 steps - 5 %; 4096 concave envs x 10 steps, bound by their slowest env: + - 0;
+  // 8192 envs without deactivation, 8 steps, bound by envs that get slower step after step: - 6 %.  Rollouts of 10 steps and
+  // more go through the queues.  RV_QUEUE=1 forces them, 0 forbids them, RV_QUEUE_MIN_STEPS moves the threshold)
   const char* qm = getenv("RV_QUEUE_MIN_STEPS");
   const int min_steps = qm ? atoi(qm) : RV_QUEUE_MIN_STEPS;
   if ((q && atoi(q) == 0) || w->q_grid <= 0 || w->n <= w->q_grid || (pool == 0 && n_steps < min_steps && !(q && atoi(q) == 1))) return RV_OK;

@@ -3,6 +3,9 @@ import json
 import sys
 
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+if 'legs' in d:       # the compact stdout line of round 6: the legs are scalar groups under `legs`; the full record is the side file
+    for k, v in d['legs'].items():
+        d.setdefault(k, v)
 
 
 def g(*path, default=None):
