@@ -382,6 +382,7 @@ def main():
                          'alone (tools/profile_bench.sh), implies --no-extra-legs')
     ap.add_argument('--over', nargs='*', default=[], help='config overrides of the timed workload, KEY=VALUE (profiling aid: e.g. '
                     'PHYSICS.SLEEP_STEPS=0 times the no-deactivation launch alone; implies --no-extra-legs)')
+    ap.add_argument('--n1-reference', action='store_true', help='take the same-workload one-GPU reference of the N > 1 line also at N = 1 (exercises that code path on a one-GPU box)')
     ap.add_argument('--limb-legs', action='store_true', help='also time PHYSICS.LIMB_DYNAMICS=1 (optional mode, SURVEY 8 f1) on the headline and the grasp workload')
     ap.add_argument('--legs-out', default=os.path.join(ROOT, 'bench_legs.json'), help='where the full record (every leg, every note) is written')
     ap.add_argument('--extra-legs', action='store_true', help='run the extra legs at --gpus N > 1 as well (default: N = 1 only -- '
@@ -603,7 +604,7 @@ def main():
     # at the barrier -- so that the N-GPU line carries a like-for-like N = 1 reference (the driver's own N = 1 run is
     # BASELINE configs[1], 1024 envs: a different workload from the 8192 envs per GPU of configs[4])
     n1_same = None
-    if world_size > 1:
+    if world_size > 1 or args.n1_reference:
         barrier()
         if rank == 0:
             torch.cuda.synchronize(); t1 = time.perf_counter()

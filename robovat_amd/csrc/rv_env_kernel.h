@@ -16,9 +16,12 @@
 using namespace rv;
 
 // control words of the task queues (ints; every counter on a 128-byte line of its own)
-enum { RV_Q_NQ = 8, RV_Q_TAKEN = 0, RV_Q_FRESH = 32, RV_Q_ERR = 64, RV_Q_CTL_WORDS = 96 + 64 * RV_Q_NQ };
-#define RV_Q_HEAD(x) (96 + 64 * (x))
-#define RV_Q_TAIL(x) (96 + 64 * (x) + 32)
+enum { RV_Q_NQ = 8, RV_Q_TAKEN = 0, RV_Q_ERR = 64, RV_Q_CTL_WORDS = 96 + 96 * RV_Q_NQ + 64 };
+// measurement words (RV_QUEUE_DEBUG): per XCD the tasks it ran, the envs it kept, when its last workgroup left (s_memtime >> 10)
+#define RV_Q_DBG(x) (96 + 96 * RV_Q_NQ + 8 * (x))
+#define RV_Q_HEAD(x) (96 + 96 * (x))
+#define RV_Q_TAIL(x) (96 + 96 * (x) + 32)
+#define RV_Q_FRESH(x) (96 + 96 * (x) + 64)      // first steps handed out of the envs x, x + RV_Q_NQ, x + 2 RV_Q_NQ, ...
 // which XCD this wave runs on (0 .. 7)
 __device__ __forceinline__ int rv_xcc_id() {
   unsigned x;
@@ -52,6 +55,7 @@ struct EnvKernelArgs {
   // (RV_Q_*), q_slots: RV_Q_NQ rings of q_cap slots, slot = env + n_envs x step (-1: not yet published); q_total tasks in
   // all; q_launch: number of this launch (every block it hands over is stamped with it).  nullptr: one workgroup per env
   int* q_slots; int* q_ctl; int q_cap; int q_total; int q_pool; int q_launch;
+  int q_debug;                   // RV_QUEUE_DEBUG: fill the measurement words
   int q_sticky;                  // 1: a workgroup keeps an env whose step was a slow one (k_env)
   int q_wt;                      // 1: the block goes out write-through and comes in past the L1 (16-byte sc1 stores / loads): it does not occupy the L2
   int poison_lo, poison_hi;      // RV_POISON_LDS builds: the words of the scratch block that start as garbage (RV_POISON_LO / _HI: bisecting)
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
   int* const q_ring = queued ? args.q_slots + (size_t)xcc * (size_t)args.q_cap : nullptr;
   int* const q_head = queued ? args.q_ctl + RV_Q_HEAD(xcc) : nullptr;
   int* const q_tail = queued ? args.q_ctl + RV_Q_TAIL(xcc) : nullptr;
-  bool fresh_left = true;
+  unsigned fresh_mask = (1u << RV_Q_NQ) - 1u;      // pools (own XCD first) that may still hold an env: lane 0's
   // Which env goes back to the queue and which one does the workgroup keep?  A launch cannot end before the longest chain of
   // steps of ONE env has, so the envs on that chain must not wait in a queue between their steps, while all the others are
   // there to be balanced (list scheduling by the longest remaining chain).  After a task the workgroup compares what is left
@@ -133,9 +137,17 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
       __syncthreads();
       if (lane == 0) {
         int e = keep;
-        if (e < 0 && fresh_left) {          // an env nobody has stepped in this launch
-          const int f = atomicAdd(args.q_ctl + RV_Q_FRESH, 1);
-          if (f < args.n_envs) e = f; else fresh_left = false;
+        // an env nobody has stepped in this launch (its block was written by an earlier kernel: visible everywhere).  The envs
+        // are dealt out evenly -- env i belongs to pool i mod 8, a workgroup serves the pool of its own XCD first -- because
+        // every env brings the same number of steps: with ONE pool the XCDs ended up with 966 ... 1082 envs each, and the
+        // launch with the busiest one.  The pools of the other XCDs are looked at only when the own one is empty (an XCD that
+        // is faster takes a few more; a GPU partition without some XCD still runs every env)
+        for (int tr = 0; e < 0 && tr < RV_Q_NQ; ++tr) {
+          if (!(fresh_mask & (1u << tr))) continue;
+          const int px = (xcc + tr) & (RV_Q_NQ - 1);
+          const int f = atomicAdd(args.q_ctl + RV_Q_FRESH(px), 1);
+          const int cand = px + RV_Q_NQ * f;
+          if (cand < args.n_envs) e = cand; else fresh_mask &= ~(1u << tr);
         }
         if (e < 0) {               // the next env of this XCD's queue
           const int t = atomicAdd(q_head, 1);
@@ -154,7 +166,10 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
       }
       __syncthreads();
       env = __builtin_amdgcn_readfirstlane(S.s.loop_break);
-      if (env < 0) return;
+      if (env < 0) {
+        if (lane == 0 && args.q_debug) { atomicMax(args.q_ctl + RV_Q_DBG(xcc) + 2, (int)((__builtin_amdgcn_s_memrealtime() >> 4) & 0x7fffffffull)); atomicAdd(args.q_ctl + RV_Q_DBG(xcc) + 4, 1); }
+        return;
+      }
       k0 = env / args.n_envs; env = env - k0 * args.n_envs;      // (a slot says whose turn it is AND which of its steps)
       if (k0 > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (buffer_inv sc1, once per task, before the block is loaded)
     }
@@ -174,6 +189,7 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
       slow = 2ull * env_rest * (unsigned long long)clk_n > left * clk_sum;
     }
     keep = slow ? env + args.n_envs * (k0 + 1) : -1;
+    if (lane == 0 && args.q_debug) { atomicAdd(args.q_ctl + RV_Q_DBG(xcc), 1); if (slow) atomicAdd(args.q_ctl + RV_Q_DBG(xcc) + 1, 1); if (k0 == 0) atomicAdd(args.q_ctl + RV_Q_DBG(xcc) + 3, 1); }
     if (lane == 0 && more && keep < 0) {
       const int p = atomicAdd(q_tail, 1);
       if (p < args.q_cap) __hip_atomic_store(&q_ring[p], env + args.n_envs * (k0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
