@@ -704,6 +704,50 @@ def main():
                 'note': 'rv_rollout_async: K*N env.step() calls shared by the N envs of each GPU (work-conserving, no '
                         'observations recorded); per-env step counts vary'})
         world.close()
+        # (the other BASELINE configurations first, the slow semantics legs after them)
+        # BASELINE configs[2]: 'crossing' layout, V-HACD concave movables, 4096 envs
+        w3, _ = make_world(4096, TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)
+        w3.reset()
+        k3 = min(args.steps, 10)
+        el3, st3, km3, _ = time_rollout(w3, k3, 0)
+        extra['config3_4096'] = leg_summary(el3, st3, k3, 4096)
+        extra['config3_4096'].update({'workload': "PushEnv 'crossing' layout 0, V-HACD concave movables, PushReward, MAX_STEPS=10",
+                                      'roofline_frac_nominal': ALGO_BYTES['config3'] * st3['substeps'] / (1e-3 * km3) / 1e9 / HBM_PEAK_GBS})
+        w3.close()
+        # BASELINE configs[4], per-GPU point: config-2 scene, 8192 envs per GPU
+        # (the driver's N > 1 command: --steps 20 --warmup 5 at 8192 envs per GPU; rollouts of that size go through the task
+        # queue of rv_env_kernel.h, which needs some steps per env to pay: this leg runs args.steps after args.warmup too)
+        w5, _ = make_world(8192)
+        w5.reset()
+        w5.rollout(args.warmup, first_macro_index=0, auto_reset=True, record=True)
+        el5, st5, km5, _ = time_rollout(w5, args.steps, args.warmup)
+        extra['config5_8192'] = leg_summary(el5, st5, args.steps, 8192)
+        extra['config5_8192'].update({'workload': 'config-2 scene, 8192 envs per GPU, %d steps after %d warm-up steps (task queue: one env.step() per task)' % (args.steps, args.warmup),
+                                      'roofline_frac_nominal': ALGO_BYTES['config2'] * st5['substeps'] / (1e-3 * km5) / 1e9 / HBM_PEAK_GBS})
+        ea5 = None
+        if not args.no_async:
+            barrier(); ta = time.perf_counter()
+            w5.rollout_async(k3 * 8192, first_macro_index=args.warmup + args.steps)
+            barrier(); ea5 = all_max(time.perf_counter() - ta)
+            extra['config5_8192']['async_value'] = all_sum(w5.stats()['env_steps'])[0] / ea5
+        w5.close()
+        # BASELINE configs[3]: Grasp4DofEnv, 2048 envs, one graspable, force-limited gripper, random CUBOID grasps
+        genv = configs.grasp_env_config()
+        gscene, gnames = scenes.make_scene(env_cfg=genv)
+        gc = configs.make_rv_config(env_cfg=genv, n_envs=2048, env_id_offset=rank * 2048, shape_names=gnames, **cfg_kwargs)
+        w4 = lib.World(gc, gscene, device=local_rank)
+        w4.reset()
+        barrier(); t4 = time.perf_counter()
+        w4.rollout(k3, first_macro_index=0, auto_reset=True, record=True)
+        st4 = w4.stats()
+        barrier(); el4 = all_max(time.perf_counter() - t4)
+        extra['config4_grasp_2048'] = leg_summary(el4, st4, k3, 2048)
+        extra['config4_grasp_2048'].update({
+            'workload': 'Grasp4DofEnv, ACTION.TYPE=CUBOID random grasps, one graspable hull, 7-DoF FK / DLS IK every 10 substeps, '
+                        'two force-limited prismatic fingers in the contact solver; every env.step() is a whole episode (reset included)',
+            'grasp_success_rate': st4['successes'] / max(st4['env_steps'], 1),
+            'roofline_frac_nominal': 1912 * st4['substeps'] / (1e-3 * w4.last_kernel_ms()) / 1e9 / HBM_PEAK_GBS})
+        w4.close()
         # Deactivation semantics.  The reference loads its movables with
         # flags=URDF_USE_SELF_COLLISION_EXCLUDE_PARENT only (bullet_physics.py:173-181): no
         # URDF_ENABLE_SLEEPING, so PyBullet most likely never deactivates them.  Same workload,
@@ -777,49 +821,6 @@ def main():
             extra['reference_semantics']['gpu_8192_first_2_steps'] = {
                 'early_exit_effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT), 8192, 2),
                 'effort_limited_motor': gpu_semantics_leg(dict(NO_DEACT, **BULLET_SWEEPS), 8192, 2)}
-        # BASELINE configs[2]: 'crossing' layout, V-HACD concave movables, 4096 envs
-        w3, _ = make_world(4096, TASK_NAME='crossing', LAYOUT_ID=0, MOVABLE_NAME='CONCAVE', MAX_STEPS=10)
-        w3.reset()
-        k3 = min(args.steps, 10)
-        el3, st3, km3, _ = time_rollout(w3, k3, 0)
-        extra['config3_4096'] = leg_summary(el3, st3, k3, 4096)
-        extra['config3_4096'].update({'workload': "PushEnv 'crossing' layout 0, V-HACD concave movables, PushReward, MAX_STEPS=10",
-                                      'roofline_frac_nominal': ALGO_BYTES['config3'] * st3['substeps'] / (1e-3 * km3) / 1e9 / HBM_PEAK_GBS})
-        w3.close()
-        # BASELINE configs[4], per-GPU point: config-2 scene, 8192 envs per GPU
-        # (the driver's N > 1 command: --steps 20 --warmup 5 at 8192 envs per GPU; rollouts of that size go through the task
-        # queue of rv_env_kernel.h, which needs some steps per env to pay: this leg runs args.steps after args.warmup too)
-        w5, _ = make_world(8192)
-        w5.reset()
-        w5.rollout(args.warmup, first_macro_index=0, auto_reset=True, record=True)
-        el5, st5, km5, _ = time_rollout(w5, args.steps, args.warmup)
-        extra['config5_8192'] = leg_summary(el5, st5, args.steps, 8192)
-        extra['config5_8192'].update({'workload': 'config-2 scene, 8192 envs per GPU, %d steps after %d warm-up steps (task queue: one env.step() per task)' % (args.steps, args.warmup),
-                                      'roofline_frac_nominal': ALGO_BYTES['config2'] * st5['substeps'] / (1e-3 * km5) / 1e9 / HBM_PEAK_GBS})
-        ea5 = None
-        if not args.no_async:
-            barrier(); ta = time.perf_counter()
-            w5.rollout_async(k3 * 8192, first_macro_index=args.warmup + args.steps)
-            barrier(); ea5 = all_max(time.perf_counter() - ta)
-            extra['config5_8192']['async_value'] = all_sum(w5.stats()['env_steps'])[0] / ea5
-        w5.close()
-        # BASELINE configs[3]: Grasp4DofEnv, 2048 envs, one graspable, force-limited gripper, random CUBOID grasps
-        genv = configs.grasp_env_config()
-        gscene, gnames = scenes.make_scene(env_cfg=genv)
-        gc = configs.make_rv_config(env_cfg=genv, n_envs=2048, env_id_offset=rank * 2048, shape_names=gnames, **cfg_kwargs)
-        w4 = lib.World(gc, gscene, device=local_rank)
-        w4.reset()
-        barrier(); t4 = time.perf_counter()
-        w4.rollout(k3, first_macro_index=0, auto_reset=True, record=True)
-        st4 = w4.stats()
-        barrier(); el4 = all_max(time.perf_counter() - t4)
-        extra['config4_grasp_2048'] = leg_summary(el4, st4, k3, 2048)
-        extra['config4_grasp_2048'].update({
-            'workload': 'Grasp4DofEnv, ACTION.TYPE=CUBOID random grasps, one graspable hull, 7-DoF FK / DLS IK every 10 substeps, '
-                        'two force-limited prismatic fingers in the contact solver; every env.step() is a whole episode (reset included)',
-            'grasp_success_rate': st4['successes'] / max(st4['env_steps'], 1),
-            'roofline_frac_nominal': 1912 * st4['substeps'] / (1e-3 * w4.last_kernel_ms()) / 1e9 / HBM_PEAK_GBS})
-        w4.close()
         # (the kinematic pusher is the model -- DESIGN.md section 3 item 12; the optional contact-time limb dynamics
         # stays a tested mode of the library and is timed only on request)
         if args.limb_legs:

@@ -3075,7 +3075,7 @@ RV_DEV void arm_refresh_kinematics(Shared& S, const Consts& K) {
 }
 // up to `want` coasted substeps with the fused loop; the kinematics are measured again whenever the
 // clearance is used up (fresh clearances that buy nothing: close to something -> the caller steps)
-RV_DEV int coast_run(Shared& S, const Consts& K, const int steps_check, const int want, int* why_out) {
+RV_DEV int coast_run_body(Shared& S, const Consts& K, const int steps_check, const int want, int* why_out) {
   int why = 0, n = 0;
   for (;;) {
     n += coast_fused(S, K, steps_check, want - n, &why);
@@ -3091,6 +3091,23 @@ RV_DEV int coast_run(Shared& S, const Consts& K, const int steps_check, const in
   *why_out = why;
   return n;
 }
+#if defined(RV_COAST_NOINLINE) && RV_ON_DEVICE
+// A build variant of the 256-register kernel (RV_OCC2_COAST_OUT_OF_LINE, off): the coasting run as a function of its own.
+// Inlined into the substep loop its hottest loops -- one iteration per coasted substep, 97 % of all substeps -- carry reloads of
+// values the surrounding code pushed out to scratch (-Rpass-missed=regalloc: 22 + 4 + 1 reloads in the three nested loops of
+// coast_fused, 49 in this one); as a callee it is allocated by itself and those loops are clean -- but a run of coasted
+// substeps is short (tens of substeps) and the save / restore of the caller's live registers per call costs more than the
+// reloads did: measured - 9 % on config 5, - 11 % on config 4 (profiles/r06_k_occ2_coast_out_of_line.txt).  (n < 2^28; why in the top bits)
+RV_DEV_NOINLINE int coast_run_fn(const rv_scene* scene, int stop_after, int steps_check, int want);      // (defined below g_shared)
+RV_DEV int coast_run(Shared& S, const Consts& K, const int steps_check, const int want, int* why_out) {
+  (void)S;
+  const int r = coast_run_fn(K.scene, K.stop_after, steps_check, want);
+  *why_out = (int)((unsigned)r >> 28);
+  return r & 0x0fffffff;
+}
+#else
+RV_DEV int coast_run(Shared& S, const Consts& K, const int steps_check, const int want, int* why_out) { return coast_run_body(S, K, steps_check, want, why_out); }
+#endif
 
 // link twist of frame f (used by the arm-body contact rows; base is static): w_f = sum_k axis_k qd_k,
 // v_f = sum_k (axis_k qd_k) x (p_f - p_k) over the joints upstream of f; the fingers add their slide along
@@ -4097,6 +4114,14 @@ RV_DEV Consts lds_consts(const rv_scene* scene, int stop_after) {
   Consts K; K.cfg = &g_shared.cfg; K.arm = &g_shared.arm; K.scene = scene; K.stop_after = stop_after;
   return K;
 }
+#if defined(RV_COAST_NOINLINE) && RV_ON_DEVICE
+RV_DEV_NOINLINE int coast_run_fn(const rv_scene* scene, int stop_after, int steps_check, int want) {
+  const Consts K = lds_consts(scene, stop_after);
+  int why = 0;
+  const int n = coast_run_body(g_shared, K, steps_check, want, &why);
+  return n | (why << 28);
+}
+#endif
 // Simulator.check_stable over a body mask (simulator.py:289-323)
 RV_DEV int bodies_stable(const DevEnv& e, unsigned mask, float lin_thr, float ang_thr) {
   for (int b = 0; b < RV_MAXB; ++b) {

@@ -6,6 +6,9 @@
 #else
 #define RV_SEGMENTS_NOINLINE 1      // the loop inlined into the kernel, the segments of the env program out of line: see env_program
 #endif
+#ifdef RV_OCC2_COAST_OUT_OF_LINE   // (round 6, measured and rejected: the coasting run as a function of its own -- coast_run_fn.  Its loops then carry
+#define RV_COAST_NOINLINE 1        // no reload, but the call costs more than they did: config 5 160 k -> 146 k, config 4 27.5 k -> 24.5 k; profiles/r06_k_*)
+#endif
 #define k_env k_env_occ2
 #include "rv_env_kernel.h"
 
