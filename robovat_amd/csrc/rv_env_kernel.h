@@ -55,6 +55,8 @@ struct EnvKernelArgs {
   // (RV_Q_*), q_slots: RV_Q_NQ rings of q_cap slots, slot = env + n_envs x step (-1: not yet published); q_total tasks in
   // all; q_launch: number of this launch (every block it hands over is stamped with it).  nullptr: one workgroup per env
   int* q_slots; int* q_ctl; int q_cap; int q_total; int q_pool; int q_launch;
+  int q_steal;                   // 1: a workgroup whose own queue is dry serves the longest other one (k_env); needs q_wt
+  int q_global;                  // RV_QUEUE_GLOBAL (measurement aid): every workgroup serves queue 0 -- blocks cross XCDs (needs q_wt)
   int q_debug;                   // RV_QUEUE_DEBUG: fill the measurement words
   int q_sticky;                  // 1: a workgroup keeps an env whose step was a slow one (k_env)
   int q_wt;                      // 1: the block goes out write-through and comes in past the L1 (16-byte sc1 stores / loads): it does not occupy the L2
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
   // Termination: RV_Q_TAKEN counts the tasks that were begun; once it reaches q_total no task is left to publish, so a
   // workgroup that waits for a slot leaves.  (A work-conserving pool, q_pool: a task is counted when an env was found for
   // it -- an env is put back after every step, the pool ends the launch.)
-  const int xcc = queued ? rv_xcc_id() : 0;
+  const int xcc = (queued && !args.q_global) ? rv_xcc_id() : 0;      // (q_global, a measurement aid: ONE queue for every XCD)
   int* const q_ring = queued ? args.q_slots + (size_t)xcc * (size_t)args.q_cap : nullptr;
   int* const q_head = queued ? args.q_ctl + RV_Q_HEAD(xcc) : nullptr;
   int* const q_tail = queued ? args.q_ctl + RV_Q_TAIL(xcc) : nullptr;
@@ -149,10 +151,31 @@ __global__ __launch_bounds__(64) RV_ENV_OCC void k_env(EnvKernelArgs args) {
           const int cand = px + RV_Q_NQ * f;
           if (cand < args.n_envs) e = cand; else fresh_mask &= ~(1u << tr);
         }
-        if (e < 0) {               // the next env of this XCD's queue
-          const int t = atomicAdd(q_head, 1);
+        if (e < 0) {               // the next env of this XCD's queue ...
+          int* ring = q_ring; int* head = q_head;
+          if (args.q_steal && !args.q_global) {
+            // (RV_QUEUE_STEAL=1, off by default) ... unless nothing waits there while another XCD's queue is long: then its head is
+            // served and the env moves to this XCD.  A block then crosses XCDs: stored write-through, loaded past the L1 (q_wt: the
+            // R1 form of the guide, sc1 payload -> drained -> flag / poll -> sc1 loads; 0 differences in 50 stress runs with ONE
+            // queue for all XCDs, where every hand-over crosses: profiles/r06_o_*).  Measured: it buys nothing -- an XCD runs dry
+            // only at the very end of a launch, when the other queues are empty too (what is left are kept envs finishing their
+            // chains): 100 - 700 steals per XCD, same 40 - 57 ms between the first and the last XCD, same rate (profiles/r06_p_*).
+            // So the shipped hand-over never leaves an XCD.
+            const int own = __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (own <= 0) {
+              int best = 4, bx = -1;      // (a queue shorter than this is left to its own workgroups)
+              for (int d = 1; d < RV_Q_NQ; ++d) {
+                const int vx = (xcc + d) & (RV_Q_NQ - 1);
+                const int len = __hip_atomic_load(args.q_ctl + RV_Q_TAIL(vx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                                __hip_atomic_load(args.q_ctl + RV_Q_HEAD(vx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (len > best) { best = len; bx = vx; }
+              }
+              if (bx >= 0) { ring = args.q_slots + (size_t)bx * (size_t)args.q_cap; head = args.q_ctl + RV_Q_HEAD(bx); if (args.q_debug) atomicAdd(args.q_ctl + RV_Q_DBG(xcc) + 5, 1); }
+            }
+          }
+          const int t = atomicAdd(head, 1);
           if (t < args.q_cap) {
-            while ((e = __hip_atomic_load(&q_ring[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+            while ((e = __hip_atomic_load(&ring[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
               if (__hip_atomic_load(args.q_ctl + RV_Q_TAKEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= args.q_total) break;
               __builtin_amdgcn_s_sleep(32);
             }
@@ -287,7 +310,10 @@ __device__ __forceinline__ void rv_env_task(const EnvKernelArgs& args, const int
   const int fin = env_program(S, K, prog, pa);
   if (MODE == MODE_ROLLOUT) {
     if (lane == 0 && args.steps_taken) {
-      args.steps_taken[env] = S.e.stepped;      // (the tasks of an env all run behind one L2: plain stores)
+      // (the tasks of an env all run behind one L2: a plain store.  RV_QUEUE_GLOBAL sends them to every XCD: two L2s that each
+      // hold a dirty copy of the word write back in either order at the end of the kernel -- an atomic store goes to memory at once)
+      if (k_stop > 0 && args.q_global) __hip_atomic_store(&args.steps_taken[env], S.e.stepped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else args.steps_taken[env] = S.e.stepped;
     }
   } else if (MODE == MODE_PARTIAL) {
     if (resetting) {

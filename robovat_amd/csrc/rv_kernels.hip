@@ -591,7 +591,7 @@ __global__ void k_queue_init(int* q, long long words) {
 // pool > 0: the work-conserving rollout (rv_rollout_async) -- `pool` tasks in all, an env goes back to the tail after every
 // step, so the envs take turns and one in a slow state simply gets fewer of them
 static int queue_setup(rv_world* w, int n_steps, EnvKernelArgs& a, long long pool = 0) {
-  a.q_slots = nullptr; a.q_ctl = nullptr; a.q_cap = 0; a.q_total = 0; a.q_pool = 0; a.q_launch = 0; a.q_wt = 0; a.q_sticky = 0; a.q_debug = 0;
+  a.q_slots = nullptr; a.q_ctl = nullptr; a.q_cap = 0; a.q_total = 0; a.q_pool = 0; a.q_launch = 0; a.q_wt = 0; a.q_sticky = 0; a.q_debug = 0; a.q_global = 0; a.q_steal = 0;
   const char* q = getenv("RV_QUEUE");      // (read per launch: the tests compare the two schedules in one process)
   // (measured with the per-XCD queues and the keep rule of k_env, profiles/r06_queue_variants.txt -- 8192 envs: 20 steps + 14 %, 10 steps
   // + 13 ... 16 %, 5 steps + 16 ... 19 %, 2 steps - 5 %; 4096 concave envs x 10 steps, bound by their slowest env: + - 0;
@@ -621,8 +621,10 @@ static int queue_setup(rv_world* w, int n_steps, EnvKernelArgs& a, long long poo
   a.q_ctl = w->d_q; a.q_slots = w->d_q + RV_Q_CTL_WORDS; a.q_cap = (int)ring; a.q_total = (int)total; a.q_pool = pool > 0 ? 1 : 0;
   a.q_launch = ++w->q_launch;
   a.q_debug = getenv("RV_QUEUE_DEBUG") != nullptr;
+  a.q_global = getenv("RV_QUEUE_GLOBAL") != nullptr;
   { const char* st = getenv("RV_QUEUE_STICKY"); a.q_sticky = st ? atoi(st) : 1; }
   { const char* wt = getenv("RV_QUEUE_WT"); a.q_wt = wt ? atoi(wt) : 1; }      // (measurement aid: 0 = plain stores / loads of the block)
+  { const char* sl = getenv("RV_QUEUE_STEAL"); a.q_steal = (sl ? atoi(sl) : 0) && a.q_wt; }      // (off: measured, no gain -- rv_env_kernel.h)
   hipLaunchKernelGGL(k_queue_init, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, w->stream, w->d_q, (long long)need);
   HIPCHK(hipGetLastError());
   w->q_used = true;
@@ -645,7 +647,7 @@ static int launch_env(rv_world* w, const uint8_t* mask, int n_sub, float lin, fl
   a.cfg = w->d_cfg; a.scene = w->d_scene; a.envs = w->d_envs; a.mask = mask; a.n_envs = w->n;
   { const char* ds = getenv("RV_DEBUG_STOP"); a.stop_after = ds ? atoi(ds) : 0; }
   a.n_substeps = n_sub; a.lin_thr = lin; a.ang_thr = ang; a.check_after = ca; a.min_stable = ms; a.max_steps = mx;
-  a.q_slots = nullptr; a.q_ctl = nullptr; a.q_cap = 0; a.q_total = 0; a.q_pool = 0; a.q_launch = 0; a.q_wt = 0; a.q_sticky = 0; a.q_debug = 0;
+  a.q_slots = nullptr; a.q_ctl = nullptr; a.q_cap = 0; a.q_total = 0; a.q_pool = 0; a.q_launch = 0; a.q_wt = 0; a.q_sticky = 0; a.q_debug = 0; a.q_global = 0; a.q_steal = 0;
   poison_range(a);
   if (MODE == MODE_ROLLOUT && budget == nullptr) { int rc = queue_setup(w, n_sub, a); if (rc != RV_OK) return rc; }
   if (MODE == MODE_ROLLOUT && budget != nullptr && pool_tasks > 0) {
@@ -1026,8 +1028,8 @@ int rv_get_stats(rv_world* w, rv_macro_stats* h) {
     int t_max = 0;
     for (int x = 0; x < RV_Q_NQ; ++x) if (dbg[8 * x] > 0 && dbg[8 * x + 2] > t_max) t_max = dbg[8 * x + 2];
     for (int x = 0; x < RV_Q_NQ; ++x)      // (s_memrealtime: 100 MHz, one counter for the device; >> 4: units of 0.16 us)
-      fprintf(stderr, "queue of XCD %d: %d workgroups, %d tasks, %d envs bound to it, %d times an env was kept, its last workgroup left %.2f ms before the last of all\n",
-              x, dbg[8 * x + 4], dbg[8 * x], dbg[8 * x + 3], dbg[8 * x + 1], dbg[8 * x] > 0 ? (t_max - dbg[8 * x + 2]) * 16.0 / 100e6 * 1e3 : 0.0);
+      fprintf(stderr, "queue of XCD %d: %d workgroups, %d tasks, %d envs bound to it, %d times an env was kept, %d tasks taken from another XCD's queue, its last workgroup left %.2f ms before the last of all\n",
+              x, dbg[8 * x + 4], dbg[8 * x], dbg[8 * x + 3], dbg[8 * x + 1], dbg[8 * x + 5], dbg[8 * x] > 0 ? (t_max - dbg[8 * x + 2]) * 16.0 / 100e6 * 1e3 : 0.0);
   }
   if (w->q_used) {
     w->q_used = false;
