@@ -388,6 +388,7 @@ def main():
     ap.add_argument('--extra-legs', action='store_true', help='run the extra legs at --gpus N > 1 as well (default: N = 1 only -- '
                     'at 8192 envs per rank the no-deactivation legs alone take minutes)')
     args = ap.parse_args()
+    headline_only_run = args.no_extra_legs or args.workload != 'config2' or bool(args.over)      # (asked for on the command line: a profiling run)
     if args.gpus > 1 and not args.extra_legs:
         args.no_extra_legs = True
 
@@ -979,7 +980,10 @@ def main():
                                       '`one_thread` = the same leg on one thread (16 envs), `scaling_1_to_n` = all threads / one thread')
         # the whole record: a side file (and stderr); stdout carries the compact line only
         legs_path = args.legs_out
+        default_legs = os.path.join(ROOT, 'bench_legs.json')
         try:
+            if headline_only_run and legs_path == default_legs:      # (a headline-only / profiling run does not overwrite the record of a full one)
+                raise OSError('headline-only run: the side file of a full run is left alone (stderr has this record)')
             with open(legs_path, 'w') as f:
                 json.dump(out, f, indent=1)
             if os.path.isdir(os.path.join(ROOT, 'gpurun_out')):

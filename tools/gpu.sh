@@ -34,7 +34,7 @@ for STAGE in "$@"; do
       timeout 1500 python -m pytest tests -m gpu -x -q -k "${STAGE#tests:}" > $O/tests_k.log 2>&1; echo "tests -k rc=$?" >> $O/time.txt
       tail -5 $O/tests_k.log ;;
     bench)
-      timeout 1700 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/time.txt
+      timeout 1700 python bench.py --steps 20 --warmup 5 --legs-out $O/bench_legs.json > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/time.txt
       python tools/bench_digest.py $O/bench.json ;;
     qstress)
       timeout 1500 python tools/queue_stress.py 16 > $O/queue_stress.txt 2>&1; echo "qstress rc=$?" >> $O/time.txt; tail -4 $O/queue_stress.txt ;;
