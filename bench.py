@@ -881,6 +881,8 @@ def main():
                        'for the whole launch, so the measured HBM traffic (`traffic`) is ~1 % of it, and ~96 % of the substeps are '
                        'coasting / quiet ones that touch no body (`achieved_awake_substeps_only` counts the rest): HBM does not bind'}
         kern = 'k_env<MODE_ROLLOUT>' if args.mode == 'rollout' else 'k_env<MODE_MACRO>'
+        if args.mode == 'rollout' and n_waves > 1024:      # more envs than SIMDs: the 256-register build; >= 10 steps and more envs than wave slots: through the task queues
+            kern = 'k_env_occ2<-1> (per-XCD task queues)' if (n_waves > 2048 and args.steps >= 10) else 'k_env_occ2<MODE_ROLLOUT>'
         if not issue:
             hbm.update({'traffic': traffic, 'kernel': kern, 'avg_kernel_ms': 1e3 * avg_kernel_s, 'hbm_nominal': dict(hbm)})
             return hbm

@@ -39,6 +39,7 @@ class HipPhysics(Physics):
         self._static = {}
         self._constraints = {}
         self._wrenches = {}          # apply_force_to_body / apply_torque_to_body: what the next step() applies
+        self._velocity_targets = {}  # velocity_control(_array): joint index -> commanded velocity, refreshed every step()
         self.scene, self.shape_names = scenes.make_scene()
         self._num_steps = None
 
@@ -81,6 +82,7 @@ class HipPhysics(Physics):
         self._num_steps = None
         self._static = {}
         self._constraints = {}
+        self._velocity_targets = {}
 
     def on_env_reset(self):
         """The env that runs on this world was reset (RobotEnv.reset -> simulator.reset() in the reference,
@@ -95,6 +97,8 @@ class HipPhysics(Physics):
     def step(self):
         if self._wrenches:
             self._apply_wrenches()
+        if self._velocity_targets:
+            self._apply_velocity_targets()
         self._world.step_sub(1)
         self._num_steps += 1
 
@@ -380,10 +384,30 @@ class HipPhysics(Physics):
         self.position_control_array(joint_uid[0], [joint_uid[1]], [target_position])
 
     def velocity_control(self, joint_uid, target_velocity, max_force=None, position_gain=None, velocity_gain=None):
-        raise NotImplementedError('the device-side motor law is POSITION_CONTROL (controllable_body.py:458-466 uses nothing else): no VELOCITY_CONTROL')
+        """bullet_physics.py:1008-1031: VELOCITY_CONTROL of ONE joint -- velocity_control_array with one entry."""
+        self.velocity_control_array(joint_uid[0], [joint_uid[1]], [target_velocity])
 
     def velocity_control_array(self, body_uid, joint_inds, target_velocities, max_forces=None, position_gains=None, velocity_gains=None):
-        raise NotImplementedError('the device-side motor law is POSITION_CONTROL (controllable_body.py:458-466 uses nothing else): no VELOCITY_CONTROL')
+        """bullet_physics.py:1106-1150: VELOCITY_CONTROL of joints of the arm.  The device's motor law is the POSITION_CONTROL
+        one -- commanded velocity kp (q* - q) / dt, limited to the joint's speed limit and, per substep, to its
+        effort-equivalent acceleration limit.  A velocity command v is that law with the target kept dt v / kp ahead of the
+        joint: the commanded velocity is v exactly, the acceleration limit plays the role of the motor's maximum force
+        (`max_forces` cannot change it: the kinematic arm has no force, only that limit).  The target is refreshed before every
+        step() until the joint gets a position command (as PyBullet keeps a motor command until it is replaced)."""
+        for j, v in zip(joint_inds, target_velocities):
+            if not 0 <= int(j) < abi.RV_NJ:
+                raise ValueError('joint index %r outside the arm (%d joints)' % (j, abi.RV_NJ))
+            self._velocity_targets[int(j)] = float(v)
+
+    def _apply_velocity_targets(self):
+        js = self._np(self._world.joint_state())[0, :, 0]
+        kp, dt = np.float32(self._cfg.kp), np.float32(self._cfg.dt)
+        q = np.zeros((1, abi.RV_NJ), np.float32)
+        mask = np.zeros((1, abi.RV_NJ), np.uint8)
+        for j, v in self._velocity_targets.items():
+            q[0, j] = np.float32(js[j]) + np.float32(v) * dt / kp
+            mask[0, j] = 1
+        self._world.set_motor_targets(q, mask)
 
     def torque_control(self, joint_uid, target_torque):
         raise NotImplementedError('the device-side motor law is POSITION_CONTROL (controllable_body.py:458-466 uses nothing else): no TORQUE_CONTROL')
@@ -403,6 +427,7 @@ class HipPhysics(Physics):
                 raise ValueError('joint index %r outside the arm (%d joints)' % (j, abi.RV_NJ))
             q[0, int(j)] = v
             mask[0, int(j)] = 1
+            self._velocity_targets.pop(int(j), None)          # (a position command replaces a velocity command)
         self._world.set_motor_targets(q, mask)
 
     def compute_inverse_kinematics(self, link_uid, link_pose, upper_limits=None, lower_limits=None, ranges=None,
