@@ -280,9 +280,10 @@ def test_body_link_joint_api_of_the_reference_and_static_bodies():
     sim.physics.set_joint_velocity(j0.uid, 0.3)
     assert j0.velocity == pytest.approx(0.3)
     j0.enable_sensor()
-    for call in (lambda: j0.reaction_force, lambda: j0.velocity_control(0.1), lambda: j0.torque_control(1.0),
+    j0.velocity_control(0.0)                      # (joint.py:157-180 -> HipPhysics.velocity_control; tests/test_gpu_velocity_control.py)
+    for call in (lambda: j0.reaction_force, lambda: j0.torque_control(1.0),
                  lambda: sim.physics.get_joint_torque(j0.uid), lambda: sim.physics.apply_force_to_link(l7.uid, [1, 0, 0], [0, 0, 0]),
-                 lambda: sim.physics.set_link_mass(l7.uid, 1.0), lambda: sim.physics.velocity_control_array(arm.uid, [0], [0.1]),
+                 lambda: sim.physics.set_link_mass(l7.uid, 1.0),      # (velocity control: tests/test_gpu_velocity_control.py)
                  lambda: sim.physics.torque_control_array(arm.uid, [0], [0.1])):
         with pytest.raises(NotImplementedError):
             call()
