@@ -413,19 +413,23 @@ def main():
     if world_size == 1:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    try:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if 'MASTER_PORT' not in os.environ:
-            import socket
-            with socket.socket() as sk:
-                sk.bind(('127.0.0.1', 0))
-                os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world_size, device_id=torch.device('cuda', local_rank))
-    except Exception as ex:  # noqa: BLE001 -- only a one-rank run may go on without its group
-        if world_size > 1:
-            raise
-        dist_note = 'RCCL group not created: %r' % (ex,)
-        dist = None
+    own_port = 'MASTER_PORT' not in os.environ
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    for attempt in range(4):
+        try:
+            if own_port:      # (found by binding to port 0 and closing: somebody may take it before the store does -> try another one)
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(('127.0.0.1', 0))
+                    os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world_size, device_id=torch.device('cuda', local_rank))
+            break
+        except Exception as ex:  # noqa: BLE001 -- only a one-rank run may go on without its group
+            if world_size > 1:
+                raise
+            if attempt == 3:
+                dist_note = 'RCCL group not created: %r' % (ex,)
+                dist = None
     assert world_size == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     scene, names = scenes.make_scene()

@@ -67,12 +67,26 @@ def test_two_gpu_shards_and_rccl_gather_match_single_process():
     single.close()
 
 
+def _one_rank_group():
+    """A one-rank RCCL group on a free local port.  The port is found by binding to 0 and closing: somebody else may take it
+    before the store binds it (seen once: EADDRINUSE), so the rendezvous is retried on a new port."""
+    import torch.distributed as dist
+    last = None
+    for _ in range(8):
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+        try:
+            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=torch.device('cuda', 0))
+            return
+        except Exception as ex:      # noqa: BLE001 -- DistNetworkError (address in use): try the next port
+            last = ex
+    raise last
+
+
 def test_one_rank_nccl_group_gathers():
     """RCCL on the one GPU that is here: a one-rank process group through the same call."""
     import torch.distributed as dist
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
-    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    _one_rank_group()
     try:
         r = torch.arange(8, dtype=torch.float32, device='cuda'); c = torch.tensor([1, 2, 3, 4], dtype=torch.int64, device='cuda')
         out, cc = parallel.gather_returns(r, c)
@@ -121,9 +135,7 @@ def test_two_worlds_on_two_streams_in_one_process_are_reentrant():
     # ... and the path's collective on this process's own one-rank RCCL group
     import torch.distributed as dist
     if not dist.is_initialized():
-        with socket.socket() as s:
-            s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
-        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        _one_rank_group()
         made = True
     else:
         made = False
